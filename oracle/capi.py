@@ -1,0 +1,165 @@
+"""ctypes bindings to liboracle.so (oracle.c).  TEST INFRASTRUCTURE ONLY - see oracle/__init__.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def shift_right(R, subpix):
+    """List of the subpix right images (img_tools.py:713-752); image k>0 is one column narrower."""
+    R = _f32(R)
+    H, W = R.shape
+    out = [R]
+    for k in range(1, subpix):
+        o = np.empty((H, W - 1), np.float32)
+        lib().orc_shift_right(_p(R), H, W, subpix, k, _p(o))
+        out.append(o)
+    return out
+
+
+def pack_shifted(imgs):
+    """Back-to-back buffer of the shifted right images, the layout orc_* functions expect."""
+    return np.concatenate([_f32(i).ravel() for i in imgs])
+
+
+def census_transform(img, win):
+    img = _f32(img)
+    H, W = img.shape
+    nb = lib().orc_census_nb_chars(win)
+    out = np.empty((H, W, nb), np.uint8)
+    lib().orc_census_transform(_p(img), H, W, win, _p(out, C.c_uint8))
+    return out
+
+
+def _cv_call(fn, L, R, D, d0, subpix, win, *extra, fill_nan=True):
+    L = _f32(L)
+    H, W = L.shape
+    Rs = pack_shifted(shift_right(R, subpix))
+    cv = np.full((H, W, D), np.nan, np.float32) if fill_nan else np.empty((H, W, D), np.float32)
+    fn(_p(L), _p(Rs), H, W, D, int(d0), subpix, win, *extra, _p(cv))
+    return cv
+
+
+def census_cost(L, R, D, d0, subpix, win):
+    return _cv_call(lib().orc_census_cost, L, R, D, d0, subpix, win)
+
+
+def sad_ssd(L, R, D, d0, subpix, win, squared):
+    return _cv_call(lib().orc_sad_ssd, L, R, D, d0, subpix, win, int(squared))
+
+
+def zncc(L, R, D, d0, subpix, win):
+    return _cv_call(lib().orc_zncc, L, R, D, d0, subpix, win)
+
+
+def mask_dilatation(msk, win, valid=0, nodata=1):
+    msk = np.ascontiguousarray(msk, np.int16)
+    H, W = msk.shape
+    bad = np.empty((H, W), np.uint8)
+    lib().orc_mask_dilatation(_p(msk, C.c_int16), H, W, win, valid, nodata, _p(bad, C.c_uint8))
+    return bad
+
+
+def cv_masked(cv, d0, subpix, win, mskL=None, mskR=None, valid=0, nodata=1, dmin=None, dmax=None):
+    """In place."""
+    assert cv.dtype == np.float32 and cv.flags.c_contiguous
+    H, W, D = cv.shape
+    mL = None if mskL is None else np.ascontiguousarray(mskL, np.int16)
+    mR = None if mskR is None else np.ascontiguousarray(mskR, np.int16)
+    gmin = None if dmin is None else np.ascontiguousarray(dmin, np.float64)
+    gmax = None if dmax is None else np.ascontiguousarray(dmax, np.float64)
+    lib().orc_cv_masked(_p(cv), H, W, D, int(d0), subpix, win, _p(mL, C.c_int16), _p(mR, C.c_int16),
+                        valid, nodata, _p(gmin, C.c_double), _p(gmax, C.c_double))
+    return cv
+
+
+def median3(img):
+    img = _f32(img)
+    H, W = img.shape
+    out = np.empty_like(img)
+    lib().orc_median3(_p(img), H, W, _p(out))
+    return out
+
+
+def cross_support(img, len_arms, intensity):
+    img = _f32(img)
+    H, W = img.shape
+    cross = np.empty((H, W, 4), np.int16)
+    lib().orc_cross_support(_p(img), H, W, int(len_arms), C.c_float(intensity), _p(cross, C.c_int16))
+    return cross
+
+
+def cbca(cv, d0, subpix, offset, crossL, crossRs):
+    """In place.  crossRs: list of int16 arrays (one per sub-pixel phase)."""
+    assert cv.dtype == np.float32 and cv.flags.c_contiguous
+    H, W, D = cv.shape
+    cl = np.ascontiguousarray(crossL, np.int16)
+    cr = np.concatenate([np.ascontiguousarray(c, np.int16).ravel() for c in crossRs])
+    lib().orc_cbca(_p(cv), H, W, D, int(d0), subpix, offset, _p(cl, C.c_int16), _p(cr, C.c_int16))
+    return cv
+
+
+def sgm(cv, P1, P2, is_max=False, invalid_cost=None, overcounting=False):
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    out = np.empty_like(cv)
+    lib().orc_sgm(_p(cv), H, W, D, C.c_float(P1), C.c_float(P2), int(is_max), C.c_float(invalid_cost),
+                  int(overcounting), _p(out))
+    return out
+
+
+def wta(cv, d0, subpix, is_max=False, invalid_disparity=-9999.0, validity=None):
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    disp = np.empty((H, W), np.float32)
+    val = np.zeros((H, W), np.int64) if validity is None else np.ascontiguousarray(validity, np.int64).copy()
+    lib().orc_wta(_p(cv), H, W, D, C.c_double(d0), subpix, int(is_max), C.c_float(invalid_disparity),
+                  _p(disp), _p(val, C.c_int64))
+    return disp, val
+
+
+def refine(cv, disp, validity, d_min, d_max, subpix, is_max, method):
+    """method: 'vfit' | 'quadratic'.  Returns (itp, disp, validity) - copies."""
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    disp = _f32(disp).copy()
+    val = np.ascontiguousarray(validity, np.int64).copy()
+    itp = np.empty((H, W), np.float32)
+    lib().orc_refine(_p(cv), H, W, D, C.c_double(d_min), C.c_double(d_max), subpix, int(is_max),
+                     {"vfit": 0, "quadratic": 1}[method], _p(disp), _p(val, C.c_int64), _p(itp))
+    return itp, disp, val
+
+
+def reverse_cost_volume(cv, min_disp):
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    out = np.empty_like(cv)
+    lib().orc_reverse_cost_volume(_p(cv), H, W, D, int(min_disp), _p(out))
+    return out

@@ -1,0 +1,617 @@
+/* oracle.c - CPU restatement of the Pandora hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Not product code: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load liboracle.so.  The HIP library (pandora_amd/csrc) never links against it.
+ *
+ * Citations are relative to /root/reference/src/pandora.  Pinning status:
+ *   census / cross_support / cbca core / vfit / quadratic / loop_refinement / reverse_cost_volume
+ *       : diffed against the reference's own compiled C++ (oracle/_ref, built by oracle/Makefile)
+ *         and against the reference tests' golden vectors (tests/golden/).
+ *   sad / ssd / zncc / cv_masked / median3 / wta / shift_right_img
+ *       : restated from the reference Python; pinned by golden vectors transcribed from the
+ *         reference tests (tests/golden/) - the Python itself cannot be imported here.
+ *   sgm : the arithmetic lives in pandora_plugin_libsgm==1.5.7 (pyproject.toml:59-61), which is
+ *         NOT in the reference tree and has no numeric test there.  PARITY UNPINNED.  The
+ *         conventions below are this build's own, documented in DESIGN.md.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IDX3(r, c, k, W, D) (((size_t)(r) * (size_t)(W) + (size_t)(c)) * (size_t)(D) + (size_t)(k))
+
+/* width of the k-th shifted right image (img_tools.py:742: shifted images lose one column) */
+static inline int shifted_width(int W, int k) { return k == 0 ? W : W - 1; }
+
+/* pointer to the k-th image inside the back-to-back buffer Rs */
+static inline const float* shifted_ptr(const float* Rs, int H, int W, int k) {
+    if (k == 0) return Rs;
+    return Rs + (size_t)H * W + (size_t)(k - 1) * H * (W - 1);
+}
+
+/* floor division of the disparity index: disparity of index k is d0 + k/subpix, its integer
+ * part (floor) is d0 + k/subpix (k >= 0) and its sub-pixel phase is k % subpix. */
+
+/* ---------------------------------------------------------------------------------------------
+ * img_tools.py:713-752  shift_right_img: scipy.ndimage.zoom(order=1) sampled at k/subpix.
+ * Linear interpolation evaluated in double and stored as float32 (zoom's output dtype follows
+ * the float32 input).
+ * ------------------------------------------------------------------------------------------- */
+void orc_shift_right(const float* R, int H, int W, int subpix, int k, float* out) {
+    double f = (double)k / (double)subpix;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W - 1; ++c) {
+            double a = R[(size_t)r * W + c], b = R[(size_t)r * W + c + 1];
+            out[(size_t)r * (W - 1) + c] = (float)((1.0 - f) * a + f * b);
+        }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * census.cpp:32-43 get_census_info: nb_chars = bits/8 + bits%8 (over-allocates, harmless)
+ * ------------------------------------------------------------------------------------------- */
+int orc_census_nb_chars(int win) {
+    int bits = win * win;
+    return bits / 8 + bits % 8;
+}
+
+/* census.cpp:45-95: strict '>' against the centre, row-major, MSB first inside each byte;
+ * borders (half window) stay 0. */
+void orc_census_transform(const float* img, int H, int W, int win, uint8_t* out) {
+    int h = win / 2;
+    int nb = orc_census_nb_chars(win);
+    memset(out, 0, (size_t)H * W * nb);
+    for (int x = h; x < H - h; ++x)
+        for (int y = h; y < W - h; ++y) {
+            float val = img[(size_t)x * W + y];
+            uint8_t* o = out + ((size_t)x * W + y) * nb;
+            int bit = 0, chr = 0;
+            for (int wx = x - h; wx <= x + h; ++wx)
+                for (int wy = y - h; wy <= y + h; ++wy) {
+                    if (img[(size_t)wx * W + wy] > val) o[chr] = (uint8_t)(o[chr] + (0x80u >> bit));
+                    if (++bit >= 8) { ++chr; bit = 0; }
+                }
+        }
+}
+
+static inline int popcount8(uint8_t v) { return __builtin_popcount((unsigned)v); }
+
+/* census.cpp:97-180 compute_matching_costs */
+void orc_census_cost(const float* L, const float* Rs, int H, int W, int D, int d0, int subpix,
+                     int win, float* cv) {
+    int h = win / 2;
+    int nb = orc_census_nb_chars(win);
+    uint8_t* cl = (uint8_t*)malloc((size_t)H * W * nb);
+    uint8_t** cr = (uint8_t**)malloc(sizeof(uint8_t*) * (size_t)subpix);
+    orc_census_transform(L, H, W, win, cl);
+    for (int k = 0; k < subpix; ++k) {
+        int Wk = shifted_width(W, k);
+        cr[k] = (uint8_t*)malloc((size_t)H * Wk * nb);
+        orc_census_transform(shifted_ptr(Rs, H, W, k), H, Wk, win, cr[k]);
+    }
+    for (int row = h; row < H - h; ++row)
+        for (int col = h; col < W - h; ++col) {
+            const uint8_t* lp = cl + ((size_t)row * W + col) * nb;
+            for (int disp = 0; disp < D; disp += subpix) {
+                int right_x = col + disp / subpix + d0; /* census.cpp:138 */
+                if (right_x < h || right_x >= W - h) continue;
+                for (int id = 0; id < subpix && disp + id < D; ++id) {
+                    const uint8_t* rp;
+                    if (id != 0) {
+                        if (right_x >= W - h - 1) break; /* census.cpp:149 */
+                        rp = cr[id] + ((size_t)row * (W - 1) + right_x) * nb;
+                    } else {
+                        rp = cr[0] + ((size_t)row * W + right_x) * nb;
+                    }
+                    int weight = 0;
+                    for (int c = 0; c < nb; ++c) weight += popcount8((uint8_t)(rp[c] ^ lp[c]));
+                    cv[IDX3(row, col, disp + id, W, D)] = (float)weight;
+                }
+            }
+        }
+    free(cl);
+    for (int k = 0; k < subpix; ++k) free(cr[k]);
+    free(cr);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * SAD / SSD.  sad_ssd.py:146-207 + 226-368 and matching_cost.py:429-482 (point_interval).
+ * Cell (r,c,k) is finite iff the w x w window around (r,c) lies inside the image rows and inside
+ * the column overlap of disparity k (NaN padding propagates through np.sum otherwise); the
+ * right sample of left column p is column p + floor(d) of shifted image (k % subpix).
+ * The window sum runs rows-then-columns in float32 (exact for integer-valued images, the only
+ * case the reference tests pin; <=1e-5 relative otherwise).
+ * ------------------------------------------------------------------------------------------- */
+void orc_sad_ssd(const float* L, const float* Rs, int H, int W, int D, int d0, int subpix, int win,
+                 int squared, float* cv) {
+    int o = win / 2;
+    for (int k = 0; k < D; ++k) {
+        int ph = k % subpix, fl = d0 + k / subpix;
+        int Wk = shifted_width(W, ph);
+        const float* R = shifted_ptr(Rs, H, W, ph);
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c) {
+                float v = NAN;
+                int ok = (r - o >= 0) && (r + o < H) && (c - o >= 0) && (c + o < W) &&
+                         (c - o + fl >= 0) && (c + o + fl < Wk);
+                if (ok) {
+                    float s = 0.f;
+                    for (int i = -o; i <= o; ++i)
+                        for (int j = -o; j <= o; ++j) {
+                            float d = L[(size_t)(r + i) * W + c + j] - R[(size_t)(r + i) * Wk + c + j + fl];
+                            s += squared ? d * d : fabsf(d);
+                        }
+                    v = s;
+                }
+                cv[IDX3(r, c, k, W, D)] = v;
+            }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ZNCC.  zncc.py:153-241, apply_divide_standard :244-277, img_tools.py:834-879 (mean raster,
+ * float64 integral images) and :915-952 (std raster: squares rounded to float32 first, variance
+ * clipped to 0 below 1e-15*|E[x^2]|).  The product L*R is a float32 product (zncc.py:209-212)
+ * averaged in float64.  Direct float64 window sums are used instead of integral images: equal on
+ * integer-valued images, <=1e-9 apart otherwise.
+ * ------------------------------------------------------------------------------------------- */
+static void window_stats(const float* img, int H, int Wd, int win, double* mean, double* std) {
+    /* mean/std [H-2o][Wd-2o] of every full window */
+    int o = win / 2, Ho = H - 2 * o, Wo = Wd - 2 * o;
+    double n = (double)win * win;
+    for (int r = 0; r < Ho; ++r)
+        for (int c = 0; c < Wo; ++c) {
+            double s = 0, s2 = 0;
+            for (int i = 0; i < win; ++i)
+                for (int j = 0; j < win; ++j) {
+                    float x = img[(size_t)(r + i) * Wd + c + j];
+                    float x2 = x * x; /* selected_band**2 stays float32 (img_tools.py:941) */
+                    s += x;
+                    s2 += x2;
+                }
+            double m = s / n, m2 = s2 / n;
+            double var = m2 - m * m;
+            if (var < 1e-15 * fabs(m2)) var = 0; /* img_tools.py:951 */
+            mean[(size_t)r * Wo + c] = m;
+            std[(size_t)r * Wo + c] = sqrt(var);
+        }
+}
+
+void orc_zncc(const float* L, const float* Rs, int H, int W, int D, int d0, int subpix, int win,
+              float* cv) {
+    int o = win / 2;
+    size_t ncell = (size_t)H * W * D;
+    for (size_t i = 0; i < ncell; ++i) cv[i] = NAN;
+    if (H - 2 * o <= 0 || W - 2 * o <= 0) return;
+    int Ho = H - 2 * o;
+    double* lm = (double*)malloc(sizeof(double) * (size_t)Ho * (W - 2 * o));
+    double* ls = (double*)malloc(sizeof(double) * (size_t)Ho * (W - 2 * o));
+    double** rm = (double**)calloc((size_t)subpix, sizeof(double*));
+    double** rs = (double**)calloc((size_t)subpix, sizeof(double*));
+    window_stats(L, H, W, win, lm, ls);
+    for (int k = 0; k < subpix; ++k) {
+        int Wk = shifted_width(W, k);
+        if (Wk - 2 * o <= 0) continue;
+        rm[k] = (double*)malloc(sizeof(double) * (size_t)Ho * (Wk - 2 * o));
+        rs[k] = (double*)malloc(sizeof(double) * (size_t)Ho * (Wk - 2 * o));
+        window_stats(shifted_ptr(Rs, H, W, k), H, Wk, win, rm[k], rs[k]);
+    }
+    double n = (double)win * win;
+    for (int k = 0; k < D; ++k) {
+        int ph = k % subpix, fl = d0 + k / subpix;
+        int Wk = shifted_width(W, ph);
+        if (!rm[ph]) continue;
+        const float* R = shifted_ptr(Rs, H, W, ph);
+        int WoL = W - 2 * o, WoR = Wk - 2 * o;
+        for (int r = o; r < H - o; ++r)
+            for (int c = o; c < W - o; ++c) {
+                if (c - o + fl < 0 || c + o + fl >= Wk) continue;
+                double s = 0;
+                for (int i = -o; i <= o; ++i)
+                    for (int j = -o; j <= o; ++j) {
+                        float p = L[(size_t)(r + i) * W + c + j] * R[(size_t)(r + i) * Wk + c + j + fl];
+                        s += p;
+                    }
+                double z = s / n;
+                size_t il = (size_t)(r - o) * WoL + (c - o);
+                size_t ir = (size_t)(r - o) * WoR + (c - o + fl);
+                z -= lm[il] * rm[ph][ir];
+                double dv = ls[il] * rs[ph][ir];
+                if (dv > 0) z /= dv; else z = 0; /* zncc.py:273-277 */
+                cv[IDX3(r, c, k, W, D)] = (float)z;
+            }
+    }
+    free(lm); free(ls);
+    for (int k = 0; k < subpix; ++k) { free(rm[k]); free(rs[k]); }
+    free(rm); free(rs);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * matching_cost.py:484-602 masks_dilatation: bad = (msk != valid && msk != nodata) ||
+ * binary_dilation(msk == nodata, ones(win,win)).
+ * ------------------------------------------------------------------------------------------- */
+void orc_mask_dilatation(const int16_t* msk, int H, int W, int win, int valid_value, int nodata_value,
+                         uint8_t* bad) {
+    int o = win / 2;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            int16_t m = msk[(size_t)r * W + c];
+            int b = (m != valid_value) && (m != nodata_value);
+            for (int i = -o; i <= o && !b; ++i)
+                for (int j = -o; j <= o && !b; ++j) {
+                    int rr = r + i, cc = c + j;
+                    if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                    if (msk[(size_t)rr * W + cc] == nodata_value) b = 1;
+                }
+            bad[(size_t)r * W + c] = (uint8_t)b;
+        }
+}
+
+/* matching_cost.py:770-872 cv_masked, NaN injection part.
+ *  (1) :815-839 per disparity: cost += mask_left[p] + mask_right[q]; for an integer disparity
+ *      q = p + d inside the right image; for a fractional one the right mask is the 2-column
+ *      aggregate (:575-593) at index p + floor(d) in [0, W-2] (mask_column_interval_without_step
+ *      :658-712 resolves to exactly these intervals).
+ *  (2) :845-860 NaN where disparity < dmin[r,c] or > dmax[r,c]. */
+void orc_cv_masked(float* cv, int H, int W, int D, int d0, int subpix, int win, const int16_t* mskL,
+                   const int16_t* mskR, int valid_value, int nodata_value, const double* dmin,
+                   const double* dmax) {
+    uint8_t* bl = NULL;
+    uint8_t* br = NULL;
+    if (mskL) { bl = (uint8_t*)malloc((size_t)H * W); orc_mask_dilatation(mskL, H, W, win, valid_value, nodata_value, bl); }
+    if (mskR) { br = (uint8_t*)malloc((size_t)H * W); orc_mask_dilatation(mskR, H, W, win, valid_value, nodata_value, br); }
+    if (bl || br) {
+        for (int k = 0; k < D; ++k) {
+            int ph = k % subpix, fl = d0 + k / subpix;
+            for (int r = 0; r < H; ++r)
+                for (int p = 0; p < W; ++p) {
+                    int q = p + fl, bad = 0;
+                    if (ph == 0) {
+                        if (q < 0 || q > W - 1) continue;
+                        bad = (bl && bl[(size_t)r * W + p]) || (br && br[(size_t)r * W + q]);
+                    } else {
+                        if (q < 0 || q > W - 2) continue;
+                        bad = (bl && bl[(size_t)r * W + p]) ||
+                              (br && (br[(size_t)r * W + q] || br[(size_t)r * W + q + 1]));
+                    }
+                    if (bad) cv[IDX3(r, p, k, W, D)] = NAN;
+                }
+        }
+    }
+    if (dmin && dmax) {
+        for (int k = 0; k < D; ++k) {
+            double d = (double)d0 + (double)k / (double)subpix;
+            for (int r = 0; r < H; ++r)
+                for (int c = 0; c < W; ++c)
+                    if (d < dmin[(size_t)r * W + c] || d > dmax[(size_t)r * W + c])
+                        cv[IDX3(r, c, k, W, D)] = NAN;
+        }
+    }
+    free(bl); free(br);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * filter/median.py:134-179: 3x3 np.nanmedian on interior pixels; 1-px border copied; NaN input
+ * pixels stay NaN; even counts average the two middle values.
+ * ------------------------------------------------------------------------------------------- */
+void orc_median3(const float* in, int H, int W, float* out) {
+    memcpy(out, in, sizeof(float) * (size_t)H * W);
+    for (int r = 1; r < H - 1; ++r)
+        for (int c = 1; c < W - 1; ++c) {
+            float ctr = in[(size_t)r * W + c];
+            if (isnan(ctr)) continue;
+            float v[9];
+            int n = 0;
+            for (int i = -1; i <= 1; ++i)
+                for (int j = -1; j <= 1; ++j) {
+                    float x = in[(size_t)(r + i) * W + c + j];
+                    if (!isnan(x)) v[n++] = x;
+                }
+            for (int a = 1; a < n; ++a) { /* insertion sort */
+                float x = v[a];
+                int b = a - 1;
+                while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
+                v[b + 1] = x;
+            }
+            float m;
+            if (n & 1) m = v[n / 2];
+            else m = (v[n / 2 - 1] + v[n / 2]) / 2.0f; /* np.mean of two float32 */
+            out[(size_t)r * W + c] = m;
+        }
+}
+
+/* aggregation.cpp:224-321 cross_support */
+void orc_cross_support(const float* img, int H, int W, int len_arms, float intensity, int16_t* cross) {
+    for (int row = 0; row < H; ++row)
+        for (int col = 0; col < W; ++col) {
+            float cur = img[(size_t)row * W + col];
+            int16_t* o = cross + ((size_t)row * W + col) * 4;
+            if (!isfinite(cur)) { o[0] = o[1] = o[2] = o[3] = 0; continue; }
+            int16_t l = 0, rt = 0, up = 0, dn = 0;
+            int lo = col - len_arms; if (lo < -1) lo = -1;
+            for (int x = col - 1; x > lo; --x) {
+                if (fabsf(cur - img[(size_t)row * W + x]) >= intensity) break;
+                l++;
+            }
+            { int16_t m = (int16_t)(col >= 1 && isfinite(img[(size_t)row * W + col - 1])); if (m > l) l = m; }
+            int hi = col + len_arms; if (hi > W) hi = W;
+            for (int x = col + 1; x < hi; ++x) {
+                if (fabsf(cur - img[(size_t)row * W + x]) >= intensity) break;
+                rt++;
+            }
+            { int16_t m = (int16_t)(col < W - 1 && isfinite(img[(size_t)row * W + col + 1])); if (m > rt) rt = m; }
+            lo = row - len_arms; if (lo < -1) lo = -1;
+            for (int y = row - 1; y > lo; --y) {
+                if (fabsf(cur - img[(size_t)y * W + col]) >= intensity) break;
+                up++;
+            }
+            { int16_t m = (int16_t)(row >= 1 && isfinite(img[(size_t)(row - 1) * W + col])); if (m > up) up = m; }
+            hi = row + len_arms; if (hi > H) hi = H;
+            for (int y = row + 1; y < hi; ++y) {
+                if (fabsf(cur - img[(size_t)y * W + col]) >= intensity) break;
+                dn++;
+            }
+            { int16_t m = (int16_t)(row < H - 1 && isfinite(img[(size_t)(row + 1) * W + col])); if (m > dn) dn = m; }
+            o[0] = l; o[1] = rt; o[2] = up; o[3] = dn;
+        }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * CBCA for the whole volume: cbca.py:127-177 driving aggregation.cpp:28-221 per disparity.
+ * step 1 row running sum (NaN skipped), step 2 horizontal segment sum with combined arms,
+ * step 3 column running sum, step 4 vertical segment sum + support count; then
+ * out = NaN where in is NaN else step4 / (sum4 + 1).  step1(row,-1) is DEFINED as 0 here
+ * (the reference reads the previous row's zero pad / out of bounds, aggregation.cpp:113-114).
+ * ------------------------------------------------------------------------------------------- */
+void orc_cbca(float* cv, int H, int W, int D, int d0, int subpix, int offset, const int16_t* crossL,
+              const int16_t* crossRs) {
+    int o = offset;
+    int Hc = H - 2 * o, Wc = W - 2 * o;
+    if (Hc <= 0 || Wc <= 0) return;
+    float* s1 = (float*)malloc(sizeof(float) * (size_t)Hc * (Wc + 1));
+    float* e2 = (float*)malloc(sizeof(float) * (size_t)Hc * Wc);
+    float* n2 = (float*)malloc(sizeof(float) * (size_t)Hc * Wc);
+    float* s3 = (float*)malloc(sizeof(float) * (size_t)(Hc + 1) * Wc);
+    for (int k = 0; k < D; ++k) {
+        int ph = k % subpix;
+        double dd = (double)d0 + (double)k / (double)subpix;
+        int Wr = shifted_width(Wc, ph);
+        const int16_t* cr = crossRs;
+        if (ph > 0) cr = crossRs + (size_t)Hc * Wc * 4 + (size_t)(ph - 1) * Hc * (Wc - 1) * 4;
+        /* step 1 */
+        for (int r = 0; r < Hc; ++r) {
+            float acc = 0.f;
+            for (int c = 0; c < Wc; ++c) {
+                float v = cv[IDX3(r + o, c + o, k, W, D)];
+                if (!isnan(v)) acc = acc + v;
+                s1[(size_t)r * (Wc + 1) + c] = acc;
+            }
+            s1[(size_t)r * (Wc + 1) + Wc] = 0.f;
+        }
+        /* step 2 */
+        for (size_t i = 0; i < (size_t)Hc * Wc; ++i) { e2[i] = 0.f; n2[i] = 0.f; }
+        for (int r = 0; r < Hc; ++r)
+            for (int c = 0; c < Wc; ++c) {
+                double cr_col = (double)c + dd; /* cbca.py:156-157 */
+                if (!(cr_col >= 0 && cr_col < (double)Wr)) continue;
+                int q = (int)cr_col; /* astype(int) */
+                const int16_t* al = crossL + ((size_t)r * Wc + c) * 4;
+                const int16_t* ar = cr + ((size_t)r * Wr + q) * 4;
+                int left = al[0] < ar[0] ? al[0] : ar[0];
+                int right = al[1] < ar[1] ? al[1] : ar[1];
+                int lo = c - left - 1;
+                float a = s1[(size_t)r * (Wc + 1) + c + right];
+                float b = lo < 0 ? 0.f : s1[(size_t)r * (Wc + 1) + lo];
+                e2[(size_t)r * Wc + c] = a - b;
+                n2[(size_t)r * Wc + c] += (float)(left + right);
+            }
+        /* step 3 */
+        for (int c = 0; c < Wc; ++c) { s3[c] = e2[c]; s3[(size_t)Hc * Wc + c] = 0.f; }
+        for (int r = 1; r < Hc; ++r)
+            for (int c = 0; c < Wc; ++c)
+                s3[(size_t)r * Wc + c] = s3[(size_t)(r - 1) * Wc + c] + e2[(size_t)r * Wc + c];
+        /* step 4 + normalisation */
+        for (int r = 0; r < Hc; ++r)
+            for (int c = 0; c < Wc; ++c) {
+                float step4 = 0.f, sum4 = n2[(size_t)r * Wc + c];
+                double cr_col = (double)c + dd;
+                if (cr_col >= 0 && cr_col < (double)Wr) {
+                    int q = (int)cr_col;
+                    const int16_t* al = crossL + ((size_t)r * Wc + c) * 4;
+                    const int16_t* ar = cr + ((size_t)r * Wr + q) * 4;
+                    int top = al[2] < ar[2] ? al[2] : ar[2];
+                    int bot = al[3] < ar[3] ? al[3] : ar[3];
+                    int sr = r - top - 1;
+                    if (sr < 0) sr += Hc + 1; /* wraps to the zero row */
+                    step4 = s3[(size_t)(r + bot) * Wc + c] - s3[(size_t)sr * Wc + c];
+                    sum4 += (float)(top + bot);
+                    if (top > 0) { float s = 0; for (int i = 1; i <= top; ++i) s += n2[(size_t)(r - i) * Wc + c]; sum4 += s; }
+                    if (bot > 0) { float s = 0; for (int i = 1; i <= bot; ++i) s += n2[(size_t)(r + i) * Wc + c]; sum4 += s; }
+                }
+                sum4 += 1.f; /* cbca.py:166 */
+                size_t id = IDX3(r + o, c + o, k, W, D);
+                float in = cv[id];
+                float base = in * 0.f; /* cbca.py:145-146: NaN stays NaN, finite -> 0 */
+                cv[id] = (base + step4) / sum4;
+            }
+    }
+    free(s1); free(e2); free(n2); free(s3);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * SGM - this build's definition (PARITY UNPINNED; see header).  Energy of
+ * docs/source/userguide/plugins/plugin_libsgm.rst:11 minimised along 8 paths (Hirschmuller 2008):
+ *   C'(p,d)   = C(p,d) (negated for a "max" measure); NaN -> invalid_cost
+ *   L_r(p,d)  = C'(p,d) + ( min( L_r(p-r,d), min(L_r(p-r,d-1), L_r(p-r,d+1)) + P1, M + P2 ) - M )
+ *               with M = min_k L_r(p-r,k); L_r(p,d) = C'(p,d) when p-r is outside the image;
+ *               d-1 / d+1 outside [0,D) count as +inf
+ *   S(p,d)    = sum over r in order (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)
+ *               [(drow,dcol) of the step from p-r to p], accumulated in float32 in that order
+ *   overcounting: S -= 7*C'
+ *   output    = S (negated back for "max"); NaN wherever the input was NaN.
+ * All arithmetic is float32, in exactly the operation order written above.
+ * ------------------------------------------------------------------------------------------- */
+static void sgm_path(const float* Cp, int H, int W, int D, int dr, int dc, float P1, float P2,
+                     float* S, float* prev, float* cur) {
+    /* iterate pixels so that p-r is always visited before p */
+    int r0 = dr >= 0 ? 0 : H - 1, r1 = dr >= 0 ? H : -1, rs = dr >= 0 ? 1 : -1;
+    int c0 = dc >= 0 ? 0 : W - 1, c1 = dc >= 0 ? W : -1, cs = dc >= 0 ? 1 : -1;
+    /* L of the previous row (or previous pixel for horizontal paths) is kept in a rolling buffer:
+     * Lbuf[2][W][D] */
+    float* Lrow[2] = {prev, cur};
+    int which = 0;
+    for (int r = r0; r != r1; r += rs) {
+        float* Lc = Lrow[which];
+        float* Lp = Lrow[which ^ 1];
+        for (int c = c0; c != c1; c += cs) {
+            int pr = r - dr, pc = c - dc;
+            const float* Cc = Cp + IDX3(r, c, 0, W, D);
+            float* Lo = Lc + (size_t)c * D;
+            float* So = S + IDX3(r, c, 0, W, D);
+            if (pr < 0 || pr >= H || pc < 0 || pc >= W) {
+                for (int d = 0; d < D; ++d) { Lo[d] = Cc[d]; So[d] = So[d] + Cc[d]; }
+                continue;
+            }
+            const float* Lq = (dr == 0 ? Lc : Lp) + (size_t)pc * D;
+            float M = Lq[0];
+            for (int d = 1; d < D; ++d) if (Lq[d] < M) M = Lq[d];
+            float mp2 = M + P2;
+            for (int d = 0; d < D; ++d) {
+                float a = d > 0 ? Lq[d - 1] : INFINITY;
+                float b = d < D - 1 ? Lq[d + 1] : INFINITY;
+                float nb = (a < b ? a : b) + P1;
+                float t = Lq[d] < nb ? Lq[d] : nb;
+                t = t < mp2 ? t : mp2;
+                float l = Cc[d] + (t - M);
+                Lo[d] = l;
+                So[d] = So[d] + l;
+            }
+        }
+        if (dr != 0) which ^= 1;
+    }
+}
+
+void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
+             int overcounting, float* out) {
+    size_t n = (size_t)H * W * D;
+    float* Cp = (float*)malloc(sizeof(float) * n);
+    float* S = (float*)calloc(n, sizeof(float));
+    float* b0 = (float*)malloc(sizeof(float) * (size_t)W * D);
+    float* b1 = (float*)malloc(sizeof(float) * (size_t)W * D);
+    for (size_t i = 0; i < n; ++i) {
+        float v = cv[i];
+        if (isnan(v)) v = invalid_cost; else if (is_max) v = -v;
+        Cp[i] = v;
+    }
+    static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}, {1, 1}, {-1, -1}, {1, -1}, {-1, 1}};
+    for (int k = 0; k < 8; ++k) sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, S, b0, b1);
+    for (size_t i = 0; i < n; ++i) {
+        float s = S[i];
+        if (overcounting) s = s - 7.0f * Cp[i];
+        if (is_max) s = -s;
+        out[i] = isnan(cv[i]) ? NAN : s;
+    }
+    free(Cp); free(S); free(b0); free(b1);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * disparity.py:399-480 WinnerTakesAll.to_disp + argmin_split :482-516 / argmax_split :518-553.
+ * NaN counts as +inf (min) / -inf (max); first extremum wins; all-NaN pixels get
+ * invalid_disparity and, if no INVALID bit is set yet, validity := PANDORA_MSK_PIXEL_INVALID.
+ * ------------------------------------------------------------------------------------------- */
+#define MSK_INVALID 0x3C3 /* constants.py:31  0b01111000011 */
+#define MSK_STOPPED 0x8   /* constants.py:40 */
+
+void orc_wta(const float* cv, int H, int W, int D, double d0, int subpix, int is_max,
+             float invalid_disparity, float* disp, int64_t* validity) {
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const float* p = cv + IDX3(r, c, 0, W, D);
+            int best = 0, allnan = 1;
+            float bv = isnan(p[0]) ? (is_max ? -INFINITY : INFINITY) : p[0];
+            if (!isnan(p[0])) allnan = 0;
+            for (int k = 1; k < D; ++k) {
+                float v = p[k];
+                if (isnan(v)) v = is_max ? -INFINITY : INFINITY; else allnan = 0;
+                if (is_max ? (v > bv) : (v < bv)) { bv = v; best = k; }
+            }
+            size_t i = (size_t)r * W + c;
+            if (allnan) {
+                disp[i] = invalid_disparity;
+                if (validity && (validity[i] & MSK_INVALID) == 0) validity[i] = MSK_INVALID;
+            } else {
+                /* coords["disp"]: arange(dmin, dmax, 1/subpix) + [dmax] (matching_cost.py:409-427) */
+                double d = d0 + (double)best / (double)subpix;
+                disp[i] = (float)d;
+            }
+        }
+}
+
+/* refinement_tools.cpp:25-56 */
+static int validate_costs(float c0, float c1, float c2, int is_max, float* ic0, float* ic1, float* ic2) {
+    if (isnan(c0) || isnan(c2)) return 0;
+    float inv = is_max ? -1.f : 1.f;
+    *ic0 = inv * c0; *ic1 = inv * c1; *ic2 = inv * c2;
+    if (*ic1 > *ic0 || *ic1 > *ic2) return 0;
+    return 1;
+}
+
+/* vfit.cpp:28-56 */
+static void vfit(float c0, float c1, float c2, int is_max, float* sd, float* sc, int* flag) {
+    float ic0 = 0, ic1 = 0, ic2 = 0;
+    if (!validate_costs(c0, c1, c2, is_max, &ic0, &ic1, &ic2)) { *sd = 0.f; *sc = c1; *flag = MSK_STOPPED; return; }
+    float a = ic0 > ic2 ? c0 - c1 : c2 - c1;
+    if (fabs((double)a) < 1.0e-15) { *sd = 0.f; *sc = c1; *flag = 0; return; }
+    float sub = (c0 - c2) / (2 * a);
+    *sd = sub;
+    *sc = a * (sub - 1) + c2;
+    *flag = 0;
+}
+
+/* quadratic.cpp:28-50 (std::min/std::max comparison semantics preserved for NaN/inf) */
+static void quadratic(float c0, float c1, float c2, int is_max, float* sd, float* sc, int* flag) {
+    float ic0 = 0, ic1 = 0, ic2 = 0;
+    if (!validate_costs(c0, c1, c2, is_max, &ic0, &ic1, &ic2)) { *sd = 0.f; *sc = c1; *flag = MSK_STOPPED; return; }
+    float alpha = (c0 - 2.f * c1 + c2) / 2.f;
+    float beta = (c2 - c0) / 2.f;
+    float x = -beta / (2.f * alpha);
+    float mx = (-1.f < x) ? x : -1.f; /* std::max(-1.f, x) */
+    float sub = (mx < 1.f) ? mx : 1.f; /* std::min(1.f, mx) */
+    *sd = sub;
+    *sc = (alpha * sub * sub) + (beta * sub) + c1;
+    *flag = 0;
+}
+
+/* refinement.cpp:28-99 loop_refinement */
+void orc_refine(const float* cv, int H, int W, int D, double d_min, double d_max, int subpix, int is_max,
+                int method, float* disp, int64_t* validity, float* itp) {
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            size_t i = (size_t)r * W + c;
+            if ((MSK_INVALID & validity[i]) != 0) { itp[i] = NAN; continue; }
+            float raw = disp[i];
+            int k = (int)(((double)raw - d_min) * subpix);
+            float cost = cv[IDX3(r, c, k, W, D)];
+            if (isnan(cost)) { itp[i] = cost; continue; }
+            if ((double)raw == d_min || (double)raw == d_max) { itp[i] = cost; validity[i] += MSK_STOPPED; continue; }
+            float sd, sc; int flag;
+            float c0 = cv[IDX3(r, c, k - 1, W, D)], c2 = cv[IDX3(r, c, k + 1, W, D)];
+            if (method == 0) vfit(c0, cost, c2, is_max, &sd, &sc, &flag);
+            else quadratic(c0, cost, c2, is_max, &sd, &sc, &flag);
+            disp[i] = raw + sd / (float)subpix;
+            itp[i] = sc;
+            validity[i] += flag;
+        }
+}
+
+/* matching_cost.cpp:26-56 */
+void orc_reverse_cost_volume(const float* left_cv, int H, int W, int D, int min_disp, float* right_cv) {
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j)
+            for (int d = 0; d < D; ++d) {
+                int col = j + d + min_disp;
+                right_cv[IDX3(i, j, d, W, D)] =
+                    (col < 0 || col >= W) ? NAN : left_cv[IDX3(i, col, D - 1 - d, W, D)];
+            }
+}

@@ -1,0 +1,125 @@
+"""Pins the CPU oracle (oracle/oracle.c) against known answers transcribed from the reference's
+own tests (tests/golden/known_answers.py).  CPU only."""
+import numpy as np
+import pytest
+
+from tests.golden import known_answers as ka
+
+
+def _cv(oracle, method, left, right, win, subpix, dmin, dmax, masked=True, **mask_kw):
+    L = np.asarray(left, np.float32)
+    R = np.asarray(right, np.float32)
+    D = (dmax - dmin) * subpix + 1
+    if method == "census":
+        cv = oracle.census_cost(L, R, D, dmin, subpix, win)
+    elif method in ("sad", "ssd"):
+        cv = oracle.sad_ssd(L, R, D, dmin, subpix, win, method == "ssd")
+    else:
+        cv = oracle.zncc(L, R, D, dmin, subpix, win)
+    if masked:
+        H, W = L.shape
+        oracle.cv_masked(cv, dmin, subpix, win, dmin=np.full((H, W), dmin), dmax=np.full((H, W), dmax), **mask_kw)
+    return cv
+
+
+@pytest.mark.parametrize("case", ka.CENSUS, ids=lambda c: c["cite"])
+def test_census_known_answers(oracle, case):
+    cv = _cv(oracle, "census", case["left"], case["right"], case["win"], case["subpix"], case["dmin"], case["dmax"])
+    exp = np.moveaxis(np.array(case["expected_dhw"], np.float32), 0, -1)
+    np.testing.assert_array_equal(cv, exp)
+
+
+def _bits(code_bytes, nbits):
+    v = 0
+    for b in code_bytes:
+        v = (v << 8) | int(b)
+    total = 8 * len(code_bytes)
+    return v >> (total - nbits)
+
+
+def test_census_bit_strings(oracle):
+    # the python census_transform of the reference returns the w*w-bit integer, MSB = first window pixel;
+    # the C++ one packs the same bit order into bytes MSB-first (census.cpp:27-28,77)
+    img = np.asarray(ka.CENSUS_BITS_W3["image"], np.float32)
+    codes = oracle.census_transform(img, 3)
+    got = [[_bits(codes[r, c], 9) for c in range(1, 5)] for r in range(1, 4)]
+    assert got == ka.CENSUS_BITS_W3["expected"]
+    codes = oracle.census_transform(img, 5)
+    got = [_bits(codes[2, c], 25) for c in (2, 3)]
+    assert got == ka.CENSUS_BITS_W5["expected"]
+
+
+@pytest.mark.parametrize("case", ka.SAD_SSD, ids=lambda c: c["cite"])
+def test_sad_ssd_slices(oracle, case):
+    cv = _cv(oracle, "ssd" if case["squared"] else "sad", case["left"], case["right"], case["win"], case["subpix"],
+             case["dmin"], case["dmax"], masked=case["masked"])
+    np.testing.assert_array_equal(cv[:, :, case["disp_index"]], np.array(case["expected"], np.float32))
+
+
+@pytest.mark.parametrize("case", [ka.SAD_FULL, ka.SAD_SUBPIX], ids=lambda c: c["cite"])
+def test_sad_full_volumes(oracle, case):
+    cv = _cv(oracle, "sad", case["left"], case["right"], case["win"], case["subpix"], case["dmin"], case["dmax"])
+    np.testing.assert_array_equal(cv, np.array(case["expected"], np.float32))
+
+
+def test_zncc_known_answer(oracle):
+    c = ka.ZNCC
+    L = np.asarray(c["left"], np.float64)
+    R = np.asarray(c["right"], np.float64)
+    cv = _cv(oracle, "zncc", L, R, c["win"], c["subpix"], c["dmin"], c["dmax"])
+    for k, (l0, l1), (r0, r1), col in c["checks"]:
+        row, colr = L[:, l0:l1], R[:, r0:r1]
+        gt = (np.mean(row * colr) - np.mean(row) * np.mean(colr)) / (np.std(row) * np.std(colr))
+        exp = np.full(6, np.nan)
+        exp[col] = gt
+        np.testing.assert_allclose(cv[2, :, k], exp, rtol=1e-5)
+    # everything outside row 2 is NaN with a 5x5 window on a 5-row image
+    assert np.isnan(cv[[0, 1, 3, 4]]).all()
+
+
+@pytest.mark.parametrize("method", ["census", "sad", "ssd", "zncc"])
+@pytest.mark.parametrize("case", ka.CV_MASKED, ids=lambda c: c["cite"])
+def test_cv_masked_nan_pattern(oracle, case, method):
+    cv = _cv(oracle, method, case["left"], case["right"], case["win"], case["subpix"], case["dmin"], case["dmax"],
+             mskL=np.array(case["left_mask"], np.int16), mskR=np.array(case["right_mask"], np.int16),
+             valid=case["valid"], nodata=case["nodata"])
+    np.testing.assert_array_equal(np.isnan(cv), ka.nanmask(case["nan"]))
+
+
+def test_wta_known_answers(oracle):
+    c = ka.WTA
+    for (dmin, dmax), gt in c["cases"]:
+        cv = _cv(oracle, "sad", c["left"], c["right"], 1, 1, dmin, dmax)
+        disp, _ = oracle.wta(cv, dmin, 1, False, 0.0)
+        np.testing.assert_array_equal(disp, np.array(gt, np.float32))
+
+
+def test_cbca_known_answers(oracle):
+    c = ka.CBCA
+    L = np.asarray(c["left"], np.float32)
+    R = np.asarray(c["right"], np.float32)
+    arms = oracle.cross_support(L, c["distance"], c["intensity"])
+    np.testing.assert_array_equal(arms[:, :, 0], c["arms_left"])
+    np.testing.assert_array_equal(arms[:, :, 1], c["arms_right"])
+    np.testing.assert_array_equal(arms[:, :, 2], c["arms_top"])
+    np.testing.assert_array_equal(arms[:, :, 3], c["arms_bottom"])
+    # cost volume of the test's setUp: |L - R_d|, NaN outside the overlap (window 1 SAD)
+    cv = oracle.sad_ssd(L, R, 3, -1, 1, 1, False)
+    # cbca.py:184-295: arms on the 3x3-median-filtered images
+    cl = oracle.cross_support(np.nan_to_num(oracle.median3(L), nan=np.inf), c["distance"], c["intensity"])
+    cr = oracle.cross_support(np.nan_to_num(oracle.median3(R), nan=np.inf), c["distance"], c["intensity"])
+    oracle.cbca(cv, -1, 1, 0, cl, [cr])
+    np.testing.assert_allclose(cv, np.array(c["aggregated"], np.float32), rtol=1e-7)
+
+
+@pytest.mark.parametrize("case", ka.MEDIAN, ids=lambda c: c["cite"])
+def test_median_known_answers(oracle, case):
+    disp = np.array(case["disp"], np.float32)
+    valid = np.array(case["valid"])
+    masked = disp.copy()
+    masked[(valid & 0b01111000011) != 0] = np.nan
+    med = oracle.median3(masked)
+    out = disp.copy()
+    ok = np.isfinite(masked)
+    out[ok] = med[ok]
+    np.testing.assert_array_equal(out, np.array(case["expected"], np.float32))

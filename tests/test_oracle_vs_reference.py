@@ -1,0 +1,125 @@
+"""Diffs the C restatement (oracle/oracle.c) against the reference's OWN compiled C++ (oracle/_ref,
+built from /root/reference by oracle/Makefile) on random inputs.  CPU only; skipped if _ref is absent."""
+import numpy as np
+import pytest
+
+from oracle import ref
+
+mc = ref.load("matching_cost_cpp")
+ag = ref.load("aggregation_cpp")
+rf = ref.load("refinement_cpp")
+needs_ref = pytest.mark.skipif(mc is None or ag is None or rf is None, reason="oracle/_ref not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [(20, 30, -5, 3, 1, 5), (15, 25, -3, 4, 2, 3), (17, 23, -2, 2, 4, 7),
+                                                  (30, 40, 0, 8, 1, 13), (12, 50, -20, -4, 1, 9), (16, 33, 2, 9, 2, 11)])
+def test_census_matches_reference(oracle, H, W, dmin, dmax, sp, win):
+    rng = np.random.default_rng(H * W + win)
+    L = rng.integers(0, 40, (H, W)).astype(np.float32)
+    R = rng.integers(0, 40, (H, W)).astype(np.float32)
+    D = (dmax - dmin) * sp + 1
+    cv = np.full((H, W, D), np.nan, np.float32)
+    out = mc.compute_matching_costs(L, oracle.shift_right(R, sp), cv, np.arange(D) / sp + dmin, win, win)
+    np.testing.assert_array_equal(out, oracle.census_cost(L, R, D, dmin, sp, win))
+
+
+@needs_ref
+def test_shift_right_matches_scipy_zoom(oracle):
+    from scipy.ndimage import zoom
+
+    rng = np.random.default_rng(3)
+    R = (rng.random((9, 14)) * 255).astype(np.float32)
+    nx = R.shape[1]
+    for sp in (2, 4):
+        for k in range(1, sp):
+            z = zoom(R, (1, (nx * sp - (sp - 1)) / float(nx)), order=1)[:, k::sp]  # img_tools.py:742
+            np.testing.assert_array_equal(z, oracle.shift_right(R, sp)[k])
+
+
+@needs_ref
+def test_cross_support_matches_reference(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(8):
+        H, W = rng.integers(5, 30, 2)
+        img = (rng.random((H, W)) * 60).astype(np.float32)
+        img[rng.random((H, W)) < 0.1] = np.inf
+        la, it = int(rng.integers(1, 8)), float(rng.random() * 30 + 1)
+        np.testing.assert_array_equal(ag.cross_support(img.copy(), la, it), oracle.cross_support(img, la, it))
+
+
+def _ref_cbca_volume(cv, d0, sp, off, cl, crs):
+    """numpy glue mirroring aggregation/cbca.py:127-177 around the reference's aggregation_cpp.cbca"""
+    H, W, D = cv.shape
+    cvd = cv[off:H - off, off:W - off] if off > 0 else cv
+    nrow, ncol, nd = cvd.shape
+    agg = np.zeros((nd, ncol, nrow), np.float32)
+    agg += np.swapaxes(cvd, 0, 2)
+    agg *= 0
+    disps = d0 + np.arange(D) / sp
+    rc = np.arange(0, ncol)
+    for k in range(nd):
+        ir = int((disps[k] % 1) * sp)
+        rcr = rc + disps[k]
+        vi = np.where((rcr >= 0) & (rcr < crs[ir].shape[1]))
+        s4, n4 = ag.cbca(cvd[:, :, k], cl, crs[ir], rc[vi], rcr[vi].astype(int))
+        n4 += 1
+        agg[k] += np.swapaxes(s4, 0, 1)
+        agg[k] /= np.swapaxes(n4, 0, 1)
+    out = cv.copy()
+    if off > 0:
+        out[off:H - off, off:W - off] = np.swapaxes(agg, 0, 2)
+    else:
+        out = np.swapaxes(agg, 0, 2).copy()
+    return out
+
+
+@needs_ref
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [(20, 30, -5, 3, 1, 5), (15, 25, -3, 4, 2, 3), (17, 23, -2, 2, 4, 1)])
+def test_cbca_matches_reference(oracle, H, W, dmin, dmax, sp, win):
+    rng = np.random.default_rng(7)
+    L = (rng.random((H, W)) * 100).astype(np.float32)
+    R = (rng.random((H, W)) * 100).astype(np.float32)
+    D = (dmax - dmin) * sp + 1
+    off = win // 2
+    cv = oracle.sad_ssd(L, R, D, dmin, sp, win, False)
+    cv[rng.random(cv.shape) < 0.05] = np.nan
+
+    def arms(im):
+        m = np.nan_to_num(oracle.median3(im), nan=np.inf)
+        if off:
+            m = m[off:-off, off:-off]
+        return oracle.cross_support(np.ascontiguousarray(m), 5, 30.0)
+
+    cl, crs = arms(L), [arms(i) for i in oracle.shift_right(R, sp)]
+    np.testing.assert_array_equal(_ref_cbca_volume(cv, dmin, sp, off, cl, crs), oracle.cbca(cv.copy(), dmin, sp, off, cl, crs))
+
+
+@needs_ref
+@pytest.mark.parametrize("measure", ["min", "max"])
+@pytest.mark.parametrize("method", ["vfit", "quadratic"])
+def test_refinement_matches_reference(oracle, measure, method):
+    rng = np.random.default_rng(11)
+    H, W, D = 12, 14, 9
+    cv = (rng.random((H, W, D)) * 10).astype(np.float32)
+    cv[rng.random(cv.shape) < 0.1] = np.nan
+    cv[0, 0, :] = np.nan
+    cv[1, 1, :] = 3.0  # all-equal costs: quadratic hits 0/0
+    disp, val = oracle.wta(cv, -4, 1, measure == "max", -9999.0)
+    if method == "vfit":
+        f = lambda c, d, m: rf.vfit_refinement_method(c, d, m, 8)  # noqa: E731
+    else:
+        f = lambda c, d, m: rf.quadratic_refinement_method(c, d, m, 8)  # noqa: E731
+    itp_r, d_r, v_r = rf.loop_refinement(cv, disp.copy(), val.copy(), -4.0, 4.0, 1, measure, f, 0x3C3, 8)
+    itp, d, v = oracle.refine(cv, disp, val, -4.0, 4.0, 1, measure == "max", method)
+    np.testing.assert_array_equal(itp, itp_r)
+    np.testing.assert_array_equal(d, d_r)
+    np.testing.assert_array_equal(v, v_r)
+
+
+@needs_ref
+def test_reverse_cost_volume_matches_reference(oracle):
+    rng = np.random.default_rng(5)
+    cv = rng.random((6, 9, 5)).astype(np.float32)
+    for md in (-2, 0, -4):
+        np.testing.assert_array_equal(mc.reverse_cost_volume(cv, md), oracle.reverse_cost_volume(cv, md))
