@@ -1,0 +1,133 @@
+/* pandora_amd.h - C ABI of the MI355X-native stereo cost-volume engine (libpandora_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of CNES/Pandora:
+ *     matching_cost -> aggregation -> optimization -> disparity -> refinement
+ * Every entry point names the reference interface it replaces (paths relative to
+ * /root/reference/src/pandora).  Plain pointers and sizes only; no exceptions cross the ABI:
+ * functions return 0 on success and a negative code on error (text via pmx_last_error()).
+ *
+ * Ownership: the caller owns every host buffer; the library owns all device memory behind the
+ * opaque handles.  Host buffers are C-contiguous.  Images are float32 [H][W]; a cost volume is
+ * float32 [H][W][D] (disparity index innermost, exactly the reference's xarray layout,
+ * matching_cost/matching_cost.py:394-397); disparity index k means disparity d0 + k/subpix.
+ * Threading: a context is single-threaded (one HIP stream); use one context per thread/GPU.
+ */
+#ifndef PANDORA_AMD_H
+#define PANDORA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pmx_ctx pmx_ctx; /* one GPU, one stream, the resident stereo pair + scratch */
+typedef struct pmx_cv pmx_cv;   /* a device-resident cost volume */
+
+enum { PMX_OK = 0, PMX_ERR_ARG = -1, PMX_ERR_HIP = -2, PMX_ERR_STATE = -3, PMX_ERR_UNSUPPORTED = -4 };
+enum { PMX_REFINE_VFIT = 0, PMX_REFINE_QUADRATIC = 1 };
+
+/* stage ids for pmx_stage_time() */
+enum {
+    PMX_STAGE_CENSUS_TRANSFORM = 0, PMX_STAGE_CENSUS_COST = 1, PMX_STAGE_SAD_SSD = 2, PMX_STAGE_ZNCC = 3,
+    PMX_STAGE_MASK = 4, PMX_STAGE_CBCA_ARMS = 5, PMX_STAGE_CBCA_H = 6, PMX_STAGE_CBCA_V = 7,
+    PMX_STAGE_SGM_PATH = 8, PMX_STAGE_SGM_FINAL = 9, PMX_STAGE_WTA = 10, PMX_STAGE_REFINE = 11,
+    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_COUNT = 16
+};
+
+const char* pmx_last_error(void);
+int pmx_device_count(void);
+
+/* ---- context / data residency --------------------------------------------------------------- */
+pmx_ctx* pmx_create(int device);
+void pmx_destroy(pmx_ctx* ctx);
+int pmx_sync(pmx_ctx* ctx);
+
+/* Upload the stereo pair.  Also builds the subpix-1 shifted right images on the device
+ * (img_tools.py:713-752 shift_right_img, linear interpolation in double).  Replaces the numpy
+ * image hand-off of every compute_cost_volume (e.g. matching_cost/census.py:113-133). */
+int pmx_set_images(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix);
+
+/* Optional int16 masks (NULL = all valid), convention of img attrs valid_pixels / no_data_mask.
+ * Feeds the masks_dilatation predicate of cv_masked (matching_cost/matching_cost.py:484-602) and
+ * the CBCA pre-masking (aggregation/cbca.py:217-262). */
+int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_t* msk_right, int valid_value, int nodata_value);
+
+/* Optional per-pixel disparity grids, double [H][W] (NULL,NULL = none):
+ * matching_cost/matching_cost.py:845-860. */
+int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, const double* disp_max);
+
+/* ---- cost volume handles -------------------------------------------------------------------- */
+/* allocate_cost_volume (matching_cost/matching_cost.py:377-407): NaN-filled [H][W][D] on device */
+pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0);
+void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv);
+int pmx_cv_fill_nan(pmx_ctx* ctx, pmx_cv* cv);
+int pmx_cv_upload(pmx_ctx* ctx, pmx_cv* cv, const float* host);   /* cv["cost_volume"].data = ... */
+int pmx_cv_download(pmx_ctx* ctx, pmx_cv* cv, float* host);       /* ... = cv["cost_volume"].data */
+int pmx_cv_dims(const pmx_cv* cv, int* H, int* W, int* D, int* d0, int* subpix);
+
+/* ---- matching cost -------------------------------------------------------------------------- */
+/* matching_cost_cpp.compute_matching_costs (matching_cost/cpp/src/census.cpp:97-180) driven by
+ * Census.compute_cost_volume (matching_cost/census.py:74-153).  win in {3,5,7,9,11,13}. */
+int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win);
+/* SadSsd.compute_cost_volume (matching_cost/sad_ssd.py:75-207); squared=1 -> ssd */
+int pmx_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared);
+/* Zncc.compute_cost_volume (matching_cost/zncc.py:114-277) */
+int pmx_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);
+/* AbstractMatchingCost.cv_masked NaN injection (matching_cost/matching_cost.py:770-872) using the
+ * masks / grids set on the context. */
+int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);
+/* matching_cost_cpp.reverse_cost_volume (matching_cost/cpp/src/matching_cost.cpp:26-56) */
+pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, int min_disp);
+
+/* ---- aggregation ---------------------------------------------------------------------------- */
+/* CrossBasedCostAggregation.cost_volume_aggregation (aggregation/cbca.py:90-182) =
+ * median 3x3 (filter/median.py:134-179) + aggregation_cpp.cross_support
+ * (aggregation/cpp/src/aggregation.cpp:224-321) + aggregation_cpp.cbca (:28-221,323-356) per d. */
+int pmx_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance);
+/* the arms alone (int16 [H-2o][W-2o][4]) for tests: side 0 = left, 1.. = right shifted image k-1 */
+int pmx_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* host_out);
+
+/* ---- optimization --------------------------------------------------------------------------- */
+/* AbstractOptimization.optimize_cv (optimization/optimization.py:104-123) for method "sgm"; the
+ * arithmetic is external to the reference (pandora_plugin_libsgm==1.5.7): see DESIGN.md. */
+int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
+
+/* ---- disparity / refinement ----------------------------------------------------------------- */
+/* Upload the int64 validity mask computed by criteria.validity_mask (criteria.py:66-158);
+ * NULL = zeros. */
+int pmx_set_validity(pmx_ctx* ctx, const int64_t* validity);
+/* WinnerTakesAll.to_disp (disparity/disparity.py:399-516). Results stay on the device. */
+int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
+/* refinement_cpp.loop_refinement + vfit/quadratic (refinement/cpp/src/refinement.cpp:28-99,
+ * vfit.cpp:28-56, quadratic.cpp:28-50) on the device-resident WTA result. */
+int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
+/* Download disparity float32[H][W], validity int64[H][W], interpolated coeff float32[H][W]
+ * (any pointer may be NULL). */
+int pmx_get_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp);
+/* Upload a disparity map / validity (to refine a map that was edited on the host). */
+int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t* validity);
+
+/* ---- D-sharded multi-GPU WTA ---------------------------------------------------- */
+/* Per-pixel packed key (orderable cost bits << 32 | global disparity index) of the local shard:
+ * min over ranks of the key == np.argmin over the full volume, ties to the lowest index.
+ * keys: uint64 [H][W] DEVICE pointer owned by the caller (e.g. a torch tensor fed to RCCL). */
+int pmx_wta_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int global_index_offset, uint64_t* dev_keys);
+/* Decode reduced keys into the context's disparity/validity (d0_global = first disparity of the
+ * full range). */
+int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double d0_global, int subpix, float invalid_disparity);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
+int pmx_set_profiling(pmx_ctx* ctx, int enabled);
+int pmx_reset_stage_times(pmx_ctx* ctx);
+/* total GPU milliseconds and launch count of one stage since the last reset (syncs the stream) */
+int pmx_stage_time(pmx_ctx* ctx, int stage, double* total_ms, int* launches);
+/* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
+void* pmx_stream(pmx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANDORA_AMD_H */

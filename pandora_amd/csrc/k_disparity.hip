@@ -1,0 +1,239 @@
+// k_disparity.hip - winner-takes-all over D, sub-pixel refinement, the packed-key variant used
+// for D-sharded multi-GPU WTA, and reverse_cost_volume.  gfx950.
+//
+// WTA reads the volume once (4 B/cell algorithmic) and writes O(H*W): HBM-bound streaming
+// reduction; one wavefront per pixel, 64 disparities per coalesced 256-B load, (value, index)
+// lexicographic reduction with wave shuffles so ties resolve to the lowest index like np.argmin /
+// np.argmax (disparity/disparity.py:511,548).
+#include "pmx_internal.h"
+
+static constexpr int kBlock = 256;
+#define MSK_INVALID 0x3C3LL /* constants.py:31 */
+#define MSK_STOPPED 0x8LL   /* constants.py:40 */
+
+__device__ __forceinline__ float d_inf() { return __int_as_float(0x7f800000); }
+__device__ __forceinline__ float d_nan() { return __int_as_float(0x7fc00000); }
+
+// (v, idx) <- better of (v, idx) and (ov, oidx); "better" = smaller v for min (larger for max), ties
+// to the smaller index
+template <bool IS_MAX>
+__device__ __forceinline__ void take_better(float& v, int& idx, float ov, int oidx) {
+    bool better = IS_MAX ? (ov > v) : (ov < v);
+    bool tie = (ov == v) && (oidx < idx);
+    if (better || tie) { v = ov; idx = oidx; }
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ void wave_argbest(const float* __restrict__ p, int D, int lane, float& v, int& idx, int& any) {
+    v = IS_MAX ? -d_inf() : d_inf();
+    idx = 0x7fffffff;
+    any = 0;
+    for (int k = lane; k < D; k += 64) {
+        float x = p[k];
+        if (x == x) {
+            any = 1;
+        } else {
+            x = IS_MAX ? -d_inf() : d_inf();  // disparity.py:434-446
+        }
+        bool better = IS_MAX ? (x > v) : (x < v);
+        if (better || idx == 0x7fffffff) { v = x; idx = k; }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        float ov = __shfl_xor(v, s);
+        int oi = __shfl_xor(idx, s);
+        int oa = __shfl_xor(any, s);
+        take_better<IS_MAX>(v, idx, ov, oi);
+        any |= oa;
+    }
+}
+
+template <bool IS_MAX>
+__global__ __launch_bounds__(kBlock) void wta_kernel(const float* __restrict__ cv, size_t npix, int D, double d0, int subpix,
+                                                     float invalid_disparity, float* __restrict__ disp,
+                                                     int64_t* __restrict__ validity) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    for (size_t pix = wave; pix < npix; pix += nwaves) {
+        float v;
+        int idx, any;
+        wave_argbest<IS_MAX>(cv + pix * (size_t)D, D, lane, v, idx, any);
+        if (lane == 0) {
+            if (!any) {
+                disp[pix] = invalid_disparity;  // disparity.py:452-455
+                int64_t m = validity[pix];
+                if ((m & MSK_INVALID) == 0) validity[pix] = MSK_INVALID;  // disparity.py:471-474
+            } else {
+                disp[pix] = (float)(d0 + (double)idx / (double)subpix);
+            }
+        }
+    }
+}
+
+int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity) {
+    size_t npix = (size_t)cv->H * cv->W;
+    size_t want = (npix + 3) / 4;
+    int grid = (int)(want < 16384 ? want : 16384);
+    pmx_stage_scope t(ctx, PMX_STAGE_WTA);
+    if (is_max)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wta_kernel<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix, cv->D,
+                           (double)cv->d0, cv->subpix, invalid_disparity, ctx->disp, ctx->validity);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wta_kernel<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix, cv->D,
+                           (double)cv->d0, cv->subpix, invalid_disparity, ctx->disp, ctx->validity);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- sub-pixel refinement (refinement.cpp:28-99, vfit.cpp:28-56, quadratic.cpp:28-50) ----------
+__device__ __forceinline__ bool validate_costs(float c0, float c1, float c2, bool is_max, float& ic0, float& ic2) {
+    if (c0 != c0 || c2 != c2) return false;
+    float inv = is_max ? -1.f : 1.f;
+    ic0 = inv * c0;
+    float ic1 = inv * c1;
+    ic2 = inv * c2;
+    return !(ic1 > ic0 || ic1 > ic2);
+}
+
+__global__ __launch_bounds__(kBlock) void refine_kernel(const float* __restrict__ cv, size_t npix, int D, double d_min,
+                                                        double d_max, int subpix, int is_max, int method,
+                                                        float* __restrict__ disp, int64_t* __restrict__ validity,
+                                                        float* __restrict__ itp) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    int64_t m = validity[i];
+    if ((m & MSK_INVALID) != 0) { itp[i] = d_nan(); return; }
+    float raw = disp[i];
+    int k = (int)(((double)raw - d_min) * (double)subpix);
+    const float* p = cv + i * (size_t)D;
+    float c1 = p[k];
+    if (c1 != c1) { itp[i] = c1; return; }
+    if ((double)raw == d_min || (double)raw == d_max) { itp[i] = c1; validity[i] = m + MSK_STOPPED; return; }
+    float c0 = p[k - 1], c2 = p[k + 1];
+    float ic0, ic2, sd, sc;
+    int64_t flag = 0;
+    if (!validate_costs(c0, c1, c2, is_max != 0, ic0, ic2)) {
+        sd = 0.f; sc = c1; flag = MSK_STOPPED;
+    } else if (method == PMX_REFINE_VFIT) {
+        float a = ic0 > ic2 ? c0 - c1 : c2 - c1;
+        if (fabs((double)a) < 1.0e-15) {
+            sd = 0.f; sc = c1;
+        } else {
+            sd = (c0 - c2) / (2 * a);
+            sc = a * (sd - 1) + c2;
+        }
+    } else {
+        float alpha = (c0 - 2.f * c1 + c2) / 2.f;
+        float beta = (c2 - c0) / 2.f;
+        float x = -beta / (2.f * alpha);
+        float mx = (-1.f < x) ? x : -1.f;  // std::max(-1.f, x)
+        sd = (mx < 1.f) ? mx : 1.f;        // std::min(1.f, mx)
+        sc = (alpha * sd * sd) + (beta * sd) + c1;
+    }
+    disp[i] = raw + sd / (float)subpix;
+    itp[i] = sc;
+    validity[i] = m + flag;
+}
+
+int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max) {
+    size_t npix = (size_t)cv->H * cv->W;
+    double d_min = (double)cv->d0;
+    double d_max = (double)cv->d0 + (double)(cv->D - 1) / (double)cv->subpix;
+    pmx_stage_scope t(ctx, PMX_STAGE_REFINE);
+    hipLaunchKernelGGL(refine_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, cv->data,
+                       npix, cv->D, d_min, d_max, cv->subpix, is_max, method, ctx->disp, ctx->validity, ctx->itp);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- packed (cost, index) keys for D-sharded WTA ------------------------------------
+// key = orderable(cost) << 32 | global index, so that min over ranks of the uint64 key is the
+// lexicographic (cost, index) minimum.  For "max" measures the cost is negated first.
+// All-NaN shard -> key = 0xFFFFFFFF_FFFFFFFF.
+__device__ __forceinline__ uint32_t orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <bool IS_MAX>
+__global__ __launch_bounds__(kBlock) void minkey_kernel(const float* __restrict__ cv, size_t npix, int D, int index_offset,
+                                                        uint64_t* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    for (size_t pix = wave; pix < npix; pix += nwaves) {
+        float v;
+        int idx, any;
+        wave_argbest<IS_MAX>(cv + pix * (size_t)D, D, lane, v, idx, any);
+        if (lane == 0) {
+            uint64_t key = ~0ull;
+            if (any) {
+                float f = IS_MAX ? -v : v;
+                if (f == 0.f) f = 0.f;  // -0 and +0 must order equal
+                key = ((uint64_t)orderable(f) << 32) | (uint32_t)(idx + index_offset);
+            }
+            keys[pix] = key;
+        }
+    }
+}
+
+int pmx_launch_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int index_offset, uint64_t* keys) {
+    size_t npix = (size_t)cv->H * cv->W;
+    size_t want = (npix + 3) / 4;
+    int grid = (int)(want < 16384 ? want : 16384);
+    pmx_stage_scope t(ctx, PMX_STAGE_MINKEY);
+    if (is_max)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(minkey_kernel<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix, cv->D,
+                           index_offset, keys);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(minkey_kernel<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix,
+                           cv->D, index_offset, keys);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void from_keys_kernel(const uint64_t* __restrict__ keys, size_t npix, double d0, int subpix,
+                                                           float invalid_disparity, float* __restrict__ disp,
+                                                           int64_t* __restrict__ validity) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    uint64_t key = keys[i];
+    if (key == ~0ull) {
+        disp[i] = invalid_disparity;
+        int64_t m = validity[i];
+        if ((m & MSK_INVALID) == 0) validity[i] = MSK_INVALID;
+    } else {
+        uint32_t idx = (uint32_t)(key & 0xffffffffull);
+        disp[i] = (float)(d0 + (double)idx / (double)subpix);
+    }
+}
+
+int pmx_launch_from_keys(pmx_ctx* ctx, const uint64_t* keys, double d0, int subpix, float invalid_disparity) {
+    size_t npix = (size_t)ctx->H * ctx->W;
+    pmx_stage_scope t(ctx, PMX_STAGE_MINKEY);
+    hipLaunchKernelGGL(from_keys_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, keys, npix,
+                       d0, subpix, invalid_disparity, ctx->disp, ctx->validity);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- reverse_cost_volume (matching_cost.cpp:26-56): (i,j,d) -> (i, j+d, -d) ---------------------
+__global__ __launch_bounds__(kBlock) void reverse_kernel(const float* __restrict__ in, int W, int D, int min_disp,
+                                                         float* __restrict__ out) {
+    const int r = blockIdx.y;
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= W * D) return;
+    int c = j / D, d = j - c * D;
+    int col = c + d + min_disp;
+    size_t base = (size_t)r * W * D;
+    out[base + j] = (col < 0 || col >= W) ? d_nan() : in[base + (size_t)col * D + (D - 1 - d)];
+}
+
+int pmx_launch_reverse(pmx_ctx* ctx, const pmx_cv* in, int min_disp, pmx_cv* out) {
+    pmx_stage_scope t(ctx, PMX_STAGE_REVERSE);
+    dim3 grid((in->W * in->D + kBlock - 1) / kBlock, in->H);
+    hipLaunchKernelGGL(reverse_kernel, grid, dim3(kBlock), 0, ctx->stream, in->data, in->W, in->D, min_disp, out->data);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

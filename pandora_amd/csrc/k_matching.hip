@@ -1,0 +1,420 @@
+// k_matching.hip - matching-cost kernels: census transform + Hamming cost, SAD/SSD, ZNCC,
+// the cv_masked NaN predicate, mask dilation, sub-pixel right-image shift.  gfx950.
+//
+// HBM roofline: every kernel here WRITES the float32 volume once (4 B/cell algorithmic); the two
+// images and their census codes are O(H*W) and live in L2 / Infinity Cache.
+#include "pmx_internal.h"
+
+static constexpr int kBlock = 256;
+
+__device__ __forceinline__ float qnan() { return __int_as_float(0x7fc00000); }
+
+// ---- sub-pixel shift (img_tools.py:713-752) ---------------------------------------------------
+__global__ void shift_right_kernel(const float* __restrict__ R, int H, int W, double f, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (c >= W - 1) return;
+    double a = R[(size_t)r * W + c], b = R[(size_t)r * W + c + 1];
+    out[(size_t)r * (W - 1) + c] = (float)((1.0 - f) * a + f * b);
+}
+
+int pmx_launch_shift_right(pmx_ctx* ctx, const float* R, int H, int W, int subpix, int k, float* out) {
+    dim3 grid((W - 1 + kBlock - 1) / kBlock, H);
+    hipLaunchKernelGGL(shift_right_kernel, grid, dim3(kBlock), 0, ctx->stream, R, H, W, (double)k / (double)subpix, out);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- NaN fill -----------------------------------------------------------------------------------
+__global__ void fill_nan_kernel(float* __restrict__ p, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    float4 v = make_float4(qnan(), qnan(), qnan(), qnan());
+    for (; i + 3 < n; i += stride) *reinterpret_cast<float4*>(p + i) = v;
+    if (i < n)
+        for (size_t j = i; j < n; ++j) p[j] = qnan();
+}
+
+int pmx_launch_fill_nan(pmx_ctx* ctx, float* p, size_t n) {
+    size_t want = (n / 4 + kBlock - 1) / kBlock + 1;
+    int grid = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(fill_nan_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, p, n);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- mask dilation (matching_cost.py:484-602) ---------------------------------------------------
+__global__ void mask_dilate_kernel(const int16_t* __restrict__ msk, int H, int W, int o, int valid, int nodata,
+                                   uint8_t* __restrict__ bad) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (c >= W) return;
+    int16_t m = msk[(size_t)r * W + c];
+    bool b = (m != valid) && (m != nodata);
+    for (int i = -o; i <= o && !b; ++i) {
+        int rr = r + i;
+        if (rr < 0 || rr >= H) continue;
+        for (int j = -o; j <= o; ++j) {
+            int cc = c + j;
+            if (cc < 0 || cc >= W) continue;
+            if (msk[(size_t)rr * W + cc] == nodata) { b = true; break; }
+        }
+    }
+    bad[(size_t)r * W + c] = b ? 1 : 0;
+}
+
+int pmx_launch_mask_dilate(pmx_ctx* ctx, const int16_t* msk, int H, int W, int win, int valid, int nodata, uint8_t* bad) {
+    dim3 grid((W + kBlock - 1) / kBlock, H);
+    hipLaunchKernelGGL(mask_dilate_kernel, grid, dim3(kBlock), 0, ctx->stream, msk, H, W, win / 2, valid, nodata, bad);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- shared cell geometry -----------------------------------------------------------------------
+// A cell (r,c,k) has a cost iff the w x w window around (r,c) is inside the left image and the
+// window around (r, c + floor(d)) is inside shifted right image (k % subpix), whose width is W
+// (phase 0) or W-1.  Same rule for census (census.cpp:132-152), sad/ssd (sad_ssd.py:180-204) and
+// zncc (zncc.py:183-230) - the reference tests run one NaN-pattern fixture over all four.
+struct cell_geom {
+    int ph;  // sub-pixel phase = index of the shifted right image
+    int q;   // right column of the window centre
+    bool ok;
+};
+
+__device__ __forceinline__ cell_geom cell_geometry(int H, int W, int d0, int subpix, int o, int r, int c, int k) {
+    cell_geom g;
+    int kk = k / subpix;
+    g.ph = k - kk * subpix;
+    g.q = c + d0 + kk;
+    int wk = g.ph == 0 ? W : W - 1;
+    g.ok = (r >= o) && (r < H - o) && (c >= o) && (c < W - o) && (g.q >= o) && (g.q < wk - o);
+    return g;
+}
+
+// cv_masked predicate (matching_cost.py:815-860): true = the cell must be NaN
+__device__ __forceinline__ bool cell_masked(const pmx_mc_params& p, int r, int c, int k, int ph, int q) {
+    bool bad = false;
+    if (p.bad_left || p.bad_right) {
+        int qmax = ph == 0 ? p.W - 1 : p.W - 2;
+        if (q >= 0 && q <= qmax) {
+            if (p.bad_left && p.bad_left[(size_t)r * p.W + c]) bad = true;
+            if (p.bad_right) {
+                if (p.bad_right[(size_t)r * p.W + q]) bad = true;
+                if (ph != 0 && p.bad_right[(size_t)r * p.W + q + 1]) bad = true;
+            }
+        }
+    }
+    if (p.grid_min) {
+        double d = (double)p.d0 + (double)k / (double)p.subpix;
+        if (d < p.grid_min[(size_t)r * p.W + c] || d > p.grid_max[(size_t)r * p.W + c]) bad = true;
+    }
+    return bad;
+}
+
+static pmx_mc_params make_params(pmx_ctx* ctx, const pmx_cv* cv, int win) {
+    pmx_mc_params p;
+    p.H = cv->H; p.W = cv->W; p.D = cv->D; p.d0 = cv->d0; p.subpix = cv->subpix; p.win = win;
+    p.left = ctx->left;
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) p.right[k] = ctx->right[k];
+    p.bad_left = ctx->bad_left;
+    p.bad_right = ctx->bad_right;
+    p.grid_min = ctx->grid_min;
+    p.grid_max = ctx->grid_max;
+    p.apply_mask = 0;
+    return p;
+}
+
+// ---- census transform ---------------------------------------------------------------------------
+// census.cpp:45-95: bit = (window pixel > centre), strict.  Only the Hamming distance of two codes
+// is ever used, so any fixed bit order is equivalent to the reference's MSB-first bytes; codes are
+// packed little-end first into NW = ceil(w*w/32) uint32 words.  Border pixels get code 0.
+template <int WIN>
+__global__ __launch_bounds__(kBlock) void census_transform_kernel(const float* __restrict__ img, int H, int Wd,
+                                                                  uint32_t* __restrict__ codes) {
+    constexpr int O = WIN / 2;
+    constexpr int NW = (WIN * WIN + 31) / 32;
+    constexpr int TX = 64, TY = kBlock / TX;  // 64 x 4 pixel tile per block
+    __shared__ float tile[TY + 2 * O][TX + 2 * O + 1];
+    int c0 = blockIdx.x * TX, r0 = blockIdx.y * TY;
+    for (int i = threadIdx.x; i < (TY + 2 * O) * (TX + 2 * O); i += kBlock) {
+        int ty = i / (TX + 2 * O), tx = i - ty * (TX + 2 * O);
+        int r = r0 + ty - O, c = c0 + tx - O;
+        tile[ty][tx] = (r >= 0 && r < H && c >= 0 && c < Wd) ? img[(size_t)r * Wd + c] : 0.f;
+    }
+    __syncthreads();
+    int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    int r = r0 + ty, c = c0 + tx;
+    if (r >= H || c >= Wd) return;
+    uint32_t w[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = 0u;
+    if (r >= O && r < H - O && c >= O && c < Wd - O) {
+        float ctr = tile[ty + O][tx + O];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i)
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) {
+                int b = i * WIN + j;
+                if (tile[ty + i][tx + j] > ctr) w[b >> 5] |= (1u << (b & 31));
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) codes[((size_t)r * Wd + c) * NW + i] = w[i];
+}
+
+// ---- census Hamming cost (census.cpp:97-180) ----------------------------------------------------
+// One thread per 4 consecutive cells of a row (coalesced 16-B stores, disparity innermost).
+// Reads: left code once per pixel (broadcast), right codes of consecutive columns (L1-resident).
+template <int NW>
+struct code_ptrs {
+    const uint32_t* left;
+    const uint32_t* right[PMX_MAX_SUBPIX];
+};
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void census_cost_kernel(pmx_mc_params p, code_ptrs<NW> cp, float* __restrict__ cv) {
+    const int r = blockIdx.y;
+    const int o = p.win / 2;
+    const size_t row_base = (size_t)r * p.W * p.D;
+    const int row_cells = p.W * p.D;
+    const int mis = (int)(row_base & 3);  // float4 alignment of this row inside the volume
+    int j0 = (blockIdx.x * kBlock + threadIdx.x) * 4 - mis;
+    if (j0 >= row_cells) return;
+    float v[4];
+    int c = 0, k = 0;
+    bool started = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float val = qnan();
+        int j = j0 + e;
+        if (j >= 0 && j < row_cells) {
+            if (!started) {
+                c = j / p.D;
+                k = j - c * p.D;
+                started = true;
+            }
+            cell_geom g = cell_geometry(p.H, p.W, p.d0, p.subpix, o, r, c, k);
+            if (g.ok) {
+                int wk = g.ph == 0 ? p.W : p.W - 1;
+                const uint32_t* lc = cp.left + ((size_t)r * p.W + c) * NW;
+                const uint32_t* rc = cp.right[g.ph] + ((size_t)r * wk + g.q) * NW;
+                int w = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) w += __popc(lc[i] ^ rc[i]);
+                val = (float)w;
+                if (p.apply_mask && cell_masked(p, r, c, k, g.ph, g.q)) val = qnan();
+            }
+            if (++k == p.D) { k = 0; ++c; }
+        }
+        v[e] = val;
+    }
+    float* out = cv + row_base;
+    if (j0 >= 0 && j0 + 3 < row_cells) {
+        *reinterpret_cast<float4*>(out + j0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j0 + e >= 0 && j0 + e < row_cells) out[j0 + e] = v[e];
+    }
+}
+
+template <int WIN>
+static int census_run(pmx_ctx* ctx, pmx_cv* cv) {
+    constexpr int NW = (WIN * WIN + 31) / 32;
+    const int H = cv->H, W = cv->W;
+    size_t per_img = (size_t)H * W * NW * sizeof(uint32_t);
+    int rc = pmx_need_small(ctx, per_img * (1 + cv->subpix));
+    if (rc) return rc;
+    uint32_t* base = (uint32_t*)ctx->small;
+    code_ptrs<NW> cp;
+    cp.left = base;
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) cp.right[k] = nullptr;
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_TRANSFORM);
+        dim3 grid((W + 63) / 64, (H + 3) / 4);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), grid, dim3(kBlock), 0, ctx->stream, ctx->left, H, W, base);
+        for (int k = 0; k < cv->subpix; ++k) {
+            uint32_t* dst = base + (size_t)(k + 1) * H * W * NW;
+            cp.right[k] = dst;
+            int wk = pmx_shifted_width(W, k);
+            dim3 g2((wk + 63) / 64, (H + 3) / 4);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), g2, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, dst);
+        }
+    }
+    PMX_HIP(hipGetLastError());
+    pmx_mc_params p = make_params(ctx, cv, WIN);
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
+        int threads_per_row = (W * cv->D + 3) / 4 + 1;
+        dim3 grid((threads_per_row + kBlock - 1) / kBlock, H);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_kernel<NW>), grid, dim3(kBlock), 0, ctx->stream, p, cp, cv->data);
+    }
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int pmx_launch_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
+    switch (win) {
+        case 3: return census_run<3>(ctx, cv);
+        case 5: return census_run<5>(ctx, cv);
+        case 7: return census_run<7>(ctx, cv);
+        case 9: return census_run<9>(ctx, cv);
+        case 11: return census_run<11>(ctx, cv);
+        case 13: return census_run<13>(ctx, cv);
+    }
+    pmx_set_error("pmx_census: unsupported window %d", win);
+    return PMX_ERR_ARG;
+}
+
+// ---- cv_masked as its own pass (only launched when masks or grids are resident) ----------------
+__global__ __launch_bounds__(kBlock) void cv_masked_kernel(pmx_mc_params p, float* __restrict__ cv) {
+    const int r = blockIdx.y;
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= p.W * p.D) return;
+    int c = j / p.D, k = j - c * p.D;
+    int kk = k / p.subpix;
+    int ph = k - kk * p.subpix;
+    int q = c + p.d0 + kk;
+    if (cell_masked(p, r, c, k, ph, q)) cv[(size_t)r * p.W * p.D + j] = qnan();
+}
+
+int pmx_launch_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win) {
+    if (!ctx->bad_left && !ctx->bad_right && !ctx->grid_min) return PMX_OK;  // NaN pattern already complete
+    pmx_mc_params p = make_params(ctx, cv, win);
+    pmx_stage_scope t(ctx, PMX_STAGE_MASK);
+    dim3 grid((cv->W * cv->D + kBlock - 1) / kBlock, cv->H);
+    hipLaunchKernelGGL(cv_masked_kernel, grid, dim3(kBlock), 0, ctx->stream, p, cv->data);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- SAD / SSD (sad_ssd.py:146-207, 226-368) ---------------------------------------------------
+// float32 window sum, rows outer / columns inner (bit-exact on integer-valued images).
+__global__ __launch_bounds__(kBlock) void sad_ssd_kernel(pmx_mc_params p, int squared, float* __restrict__ cv) {
+    const int r = blockIdx.y;
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= p.W * p.D) return;
+    const int o = p.win / 2;
+    int c = j / p.D, k = j - c * p.D;
+    cell_geom g = cell_geometry(p.H, p.W, p.d0, p.subpix, o, r, c, k);
+    float val = qnan();
+    if (g.ok) {
+        int wk = g.ph == 0 ? p.W : p.W - 1;
+        const float* R = p.right[g.ph];
+        float s = 0.f;
+        for (int i = -o; i <= o; ++i) {
+            const float* lrow = p.left + (size_t)(r + i) * p.W + c;
+            const float* rrow = R + (size_t)(r + i) * wk + g.q;
+            for (int jj = -o; jj <= o; ++jj) {
+                float d = lrow[jj] - rrow[jj];
+                s = s + (squared ? d * d : fabsf(d));
+            }
+        }
+        val = s;
+    }
+    cv[(size_t)r * p.W * p.D + j] = val;
+}
+
+int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared) {
+    pmx_mc_params p = make_params(ctx, cv, win);
+    pmx_stage_scope t(ctx, PMX_STAGE_SAD_SSD);
+    dim3 grid((cv->W * cv->D + kBlock - 1) / kBlock, cv->H);
+    hipLaunchKernelGGL(sad_ssd_kernel, grid, dim3(kBlock), 0, ctx->stream, p, squared, cv->data);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- ZNCC (zncc.py:153-277 + img_tools.py:834-952) ---------------------------------------------
+// Window statistics in float64 (the reference's integral images are float64): mean and std of
+// every full window, std with the float32 squares and the 1e-15 clip of img_tools.py:941-951.
+__global__ __launch_bounds__(kBlock) void window_stats_kernel(const float* __restrict__ img, int H, int Wd, int win,
+                                                              double* __restrict__ mean, double* __restrict__ sd) {
+    int o = win / 2, Wo = Wd - 2 * o;
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    int r = blockIdx.y;
+    if (c >= Wo) return;
+    double s = 0, s2 = 0;
+    for (int i = 0; i < win; ++i)
+        for (int j = 0; j < win; ++j) {
+            float x = img[(size_t)(r + i) * Wd + c + j];
+            float x2 = x * x;
+            s += (double)x;
+            s2 += (double)x2;
+        }
+    double n = (double)win * win;
+    double m = s / n, m2 = s2 / n;
+    double var = m2 - m * m;
+    if (var < 1e-15 * fabs(m2)) var = 0;
+    mean[(size_t)r * Wo + c] = m;
+    sd[(size_t)r * Wo + c] = sqrt(var);
+}
+
+struct zncc_stats {
+    const double* lmean;
+    const double* lsd;
+    const double* rmean[PMX_MAX_SUBPIX];
+    const double* rsd[PMX_MAX_SUBPIX];
+};
+
+__global__ __launch_bounds__(kBlock) void zncc_kernel(pmx_mc_params p, zncc_stats st, float* __restrict__ cv) {
+    const int r = blockIdx.y;
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= p.W * p.D) return;
+    const int o = p.win / 2;
+    int c = j / p.D, k = j - c * p.D;
+    cell_geom g = cell_geometry(p.H, p.W, p.d0, p.subpix, o, r, c, k);
+    float val = qnan();
+    if (g.ok) {
+        int wk = g.ph == 0 ? p.W : p.W - 1;
+        const float* R = p.right[g.ph];
+        double s = 0;
+        for (int i = -o; i <= o; ++i) {
+            const float* lrow = p.left + (size_t)(r + i) * p.W + c;
+            const float* rrow = R + (size_t)(r + i) * wk + g.q;
+            for (int jj = -o; jj <= o; ++jj) {
+                float prod = lrow[jj] * rrow[jj];  // float32 product (zncc.py:209-212)
+                s += (double)prod;
+            }
+        }
+        double z = s / ((double)p.win * p.win);
+        size_t il = (size_t)(r - o) * (p.W - 2 * o) + (c - o);
+        size_t ir = (size_t)(r - o) * (wk - 2 * o) + (g.q - o);
+        z -= st.lmean[il] * st.rmean[g.ph][ir];
+        double dv = st.lsd[il] * st.rsd[g.ph][ir];
+        z = dv > 0 ? z / dv : 0.0;
+        val = (float)z;
+    }
+    cv[(size_t)r * p.W * p.D + j] = val;
+}
+
+int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
+    const int H = cv->H, W = cv->W, o = win / 2;
+    if (H - 2 * o <= 0 || W - 1 - 2 * o <= 0) return pmx_launch_fill_nan(ctx, cv->data, cv->cells());
+    size_t per = (size_t)(H - 2 * o) * (W - 2 * o) * sizeof(double);
+    int rc = pmx_need_small(ctx, per * 2 * (1 + cv->subpix));
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    zncc_stats st;
+    st.lmean = (double*)base;
+    st.lsd = (double*)(base + per);
+    pmx_mc_params p = make_params(ctx, cv, win);
+    pmx_stage_scope t(ctx, PMX_STAGE_ZNCC);
+    {
+        dim3 grid((W - 2 * o + kBlock - 1) / kBlock, H - 2 * o);
+        hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kBlock), 0, ctx->stream, ctx->left, H, W, win,
+                           (double*)st.lmean, (double*)st.lsd);
+    }
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) { st.rmean[k] = nullptr; st.rsd[k] = nullptr; }
+    for (int k = 0; k < cv->subpix; ++k) {
+        int wk = pmx_shifted_width(W, k);
+        st.rmean[k] = (double*)(base + per * (2 + 2 * k));
+        st.rsd[k] = (double*)(base + per * (3 + 2 * k));
+        dim3 grid((wk - 2 * o + kBlock - 1) / kBlock, H - 2 * o);
+        hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, win,
+                           (double*)st.rmean[k], (double*)st.rsd[k]);
+    }
+    dim3 grid((W * cv->D + kBlock - 1) / kBlock, H);
+    hipLaunchKernelGGL(zncc_kernel, grid, dim3(kBlock), 0, ctx->stream, p, st, cv->data);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

@@ -1,0 +1,263 @@
+// k_sgm.hip - 8-path semi-global matching on the device-resident float32 cost volume.  gfx950.
+//
+// Definition (this build's own; the reference delegates to pandora_plugin_libsgm, see DESIGN.md
+// and oracle/oracle.c orc_sgm, which this file matches operation for operation):
+//   C'(p,d) = C(p,d) (negated for "max" measures), NaN -> invalid_cost
+//   L_r(p,d) = C' + ( min( L_r(p-r,d), min(L_r(p-r,d-1), L_r(p-r,d+1)) + P1, M + P2 ) - M ),
+//              M = min_k L_r(p-r,k);  L_r = C' on the first pixel of a path
+//   S = sum_r L_r in the order (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)
+//
+// Execution model: ONE WAVEFRONT PER SCANLINE.  The 64 lanes of a wave hold the D path costs of the
+// current pixel, KPL consecutive disparities per lane (blocked layout -> the d-1/d+1 neighbours are
+// in-register except at the lane edges, fetched with DPP wave shifts); min over D is a DPP
+// row_shr/row_bcast reduction, no LDS.  A wave walks its line pixel by pixel; the cost-volume
+// reads of the next PF pixels are already in flight (register ring), so the recurrence latency
+// and the HBM latency overlap.  Diagonal lines wrap around the image width (the path restarts at
+// the wrap), which gives exactly W equally long lines per diagonal direction.
+//
+// Per pass the kernel reads C (4 B/cell), reads S (4) and writes S (4); the first pass skips the
+// S read, the last pass also restores NaN / un-negates.  No MFMA: this is an HBM-bound scan.
+#include "pmx_internal.h"
+
+static constexpr int kWavesPerBlock = 4;
+static constexpr int kPF = 8;  // pixels of read-ahead per wave (register ring)
+
+__device__ __forceinline__ float f_inf() { return __int_as_float(0x7f800000); }
+__device__ __forceinline__ float f_nan() { return __int_as_float(0x7fc00000); }
+__device__ __forceinline__ float fmin2(float a, float b) { return a < b ? a : b; }
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float oldv, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oldv), __float_as_int(src), CTRL, ROW_MASK,
+                                                      BANK_MASK, false));
+}
+
+// lane l receives the value of lane l-1 (lane 0 keeps `fill`)
+__device__ __forceinline__ float from_lane_below(float v, float fill) { return dpp_mov<0x138>(fill, v); }  // wave_shr:1
+// lane l receives the value of lane l+1 (lane 63 keeps `fill`)
+__device__ __forceinline__ float from_lane_above(float v, float fill) { return dpp_mov<0x130>(fill, v); }  // wave_shl:1
+
+// minimum over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ float wave_min(float v) {
+    v = fmin2(v, dpp_mov<0x111>(v, v));             // row_shr:1
+    v = fmin2(v, dpp_mov<0x112>(v, v));             // row_shr:2
+    v = fmin2(v, dpp_mov<0x114>(v, v));             // row_shr:4
+    v = fmin2(v, dpp_mov<0x118>(v, v));             // row_shr:8  -> lane 15 of every row holds the row min
+    v = fmin2(v, dpp_mov<0x142, 0xa>(v, v));        // row_bcast:15 into rows 1,3
+    v = fmin2(v, dpp_mov<0x143, 0xc>(v, v));        // row_bcast:31 into rows 2,3 -> lane 63 holds the min
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+enum { SGM_FIRST = 0, SGM_MID = 1, SGM_LAST = 2 };
+
+struct sgm_args {
+    const float* C;  // raw cost volume (NaN = invalid)
+    float* S;        // accumulator / output
+    int H, W, D;
+    int dr, dc;      // step from p-r to p
+    float P1, P2, invalid_cost;
+    int is_max, overcounting;
+};
+
+template <int KPL>
+struct lane_vals {
+    float v[KPL];
+};
+
+// load KPL consecutive floats starting at p (4-byte aligned only)
+template <int KPL>
+__device__ __forceinline__ lane_vals<KPL> load_vals(const float* p) {
+    lane_vals<KPL> r;
+    __builtin_memcpy(&r, p, sizeof(float) * KPL);
+    return r;
+}
+
+// Walks one line.  TAIL = (D % KPL != 0): the last active lane owns fewer than KPL disparities
+// and must store element-wise; without a tail every active lane does one KPL-wide store.
+template <int KPL, int MODE, bool TAIL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args a) {
+    const int lane = threadIdx.x & 63;
+    const int line = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const bool horizontal = (a.dr == 0);
+    const int nlines = horizontal ? a.H : a.W;
+    if (line >= nlines) return;
+    const int nsteps = horizontal ? a.W : a.H;
+    const int D = a.D;
+    const int d_first = lane * KPL;
+    const bool lane_active = d_first < D;  // lane owns at least one disparity
+    const size_t pix_stride = (size_t)D;
+
+    // cursor of the pixel being computed and of the pixel being prefetched
+    int r = horizontal ? line : (a.dr > 0 ? 0 : a.H - 1);
+    int c = horizontal ? (a.dc > 0 ? 0 : a.W - 1) : line;
+    int pr = r, pc = c;
+
+    lane_vals<KPL> cbuf[kPF];
+    lane_vals<KPL> sbuf[kPF];
+    // Loads are UNCONDITIONAL straight-line code (a load under a branch makes the compiler wait for
+    // it at the join, which would serialise the ring): lanes that own no disparity read the pixel's
+    // d = 0 instead, and read-ahead past the end of the line re-reads its last pixel.
+    const int d_load = lane_active ? d_first : 0;
+    int pleft = nsteps - 1;  // steps the prefetch cursor may still advance
+
+    auto prefetch = [&](lane_vals<KPL>& cslot, lane_vals<KPL>& sslot) {
+        size_t poff = ((size_t)pr * a.W + pc) * pix_stride + d_load;
+        cslot = load_vals<KPL>(a.C + poff);
+        if (MODE != SGM_FIRST) sslot = load_vals<KPL>(a.S + poff);
+        if (pleft > 0) {
+            --pleft;
+            pr += a.dr;
+            pc += a.dc;
+            if (!horizontal) { if (pc >= a.W) pc = 0; else if (pc < 0) pc = a.W - 1; }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < kPF; ++i) prefetch(cbuf[i], sbuf[i]);
+
+    float Lp[KPL];  // path costs of the previous pixel (+inf on padded disparities)
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) Lp[k] = (!TAIL || d_first + k < D) && lane_active ? 0.f : f_inf();
+    float M = 0.f;  // min_k Lp; (Lp = 0, M = 0) reproduces L = C' on the first pixel of a path
+
+    auto step = [&](lane_vals<KPL>& cslot, lane_vals<KPL>& sslot) {
+        const size_t off = ((size_t)r * a.W + c) * pix_stride + d_first;
+        // neighbours across the lane boundary
+        const float below = from_lane_below(Lp[KPL - 1], f_inf());
+        const float above = from_lane_above(Lp[0], f_inf());
+        const float mp2 = M + a.P2;
+        float Ln[KPL];
+        lane_vals<KPL> out;
+        float lmin = f_inf();
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            float cr = cslot.v[k];
+            float cc = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
+            float lo = (k > 0) ? Lp[k - 1] : below;
+            float hi = (k < KPL - 1) ? Lp[k + 1] : above;
+            float nb = fmin2(lo, hi) + a.P1;
+            float t = fmin2(Lp[k], nb);
+            t = fmin2(t, mp2);
+            float l = cc + (t - M);
+            bool valid = lane_active && (!TAIL || d_first + k < D);
+            Ln[k] = valid ? l : f_inf();
+            lmin = fmin2(lmin, Ln[k]);
+            float s = (MODE == SGM_FIRST) ? l : (sslot.v[k] + l);
+            if (MODE == SGM_LAST) {
+                if (a.overcounting) s = s - 7.0f * cc;
+                if (a.is_max) s = -s;
+                if (cr != cr) s = f_nan();
+            }
+            out.v[k] = s;
+        }
+        if (!TAIL) {
+            if (lane_active) __builtin_memcpy(a.S + off, &out, sizeof(float) * KPL);
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k)
+                if (d_first + k < D) a.S[off + k] = out.v[k];
+        }
+        // refill this ring slot with pixel i + kPF.  Issued AFTER the slot's last use so the new data
+        // lands in the same registers (no copy, hence no wait, at the loop back-edge).
+        prefetch(cslot, sslot);
+        M = wave_min(lmin);
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) Lp[k] = Ln[k];
+        // advance; a diagonal line that leaves the image re-enters on the other side and the path
+        // restarts there (border initialisation)
+        r += a.dr;
+        c += a.dc;
+        if (!horizontal && (c >= a.W || c < 0)) {
+            c = (c >= a.W) ? 0 : a.W - 1;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) Lp[k] = (!TAIL || d_first + k < D) && lane_active ? 0.f : f_inf();
+            M = 0.f;
+        }
+    };
+
+    int i = 0;
+    for (; i + kPF <= nsteps; i += kPF) {
+#pragma unroll
+        for (int j = 0; j < kPF; ++j) step(cbuf[j], sbuf[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kPF - 1; ++j)
+        if (i + j < nsteps) step(cbuf[j], sbuf[j]);
+}
+
+template <int KPL>
+static int sgm_run(pmx_ctx* ctx, const sgm_args& base) {
+    static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}, {1, 1}, {-1, -1}, {1, -1}, {-1, 1}};
+    for (int k = 0; k < 8; ++k) {
+        sgm_args a = base;
+        a.dr = dirs[k][0];
+        a.dc = dirs[k][1];
+        int nlines = a.dr == 0 ? a.H : a.W;
+        dim3 grid((nlines + kWavesPerBlock - 1) / kWavesPerBlock);
+        dim3 block(kWavesPerBlock * 64);
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
+        const bool tail = (a.D % KPL) != 0;
+#define PMX_SGM_LAUNCH(MODE)                                                                                       \
+    do {                                                                                                           \
+        if (tail)                                                                                                  \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, MODE, true>), grid, block, 0, ctx->stream, a); \
+        else                                                                                                       \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, MODE, false>), grid, block, 0, ctx->stream, a); \
+    } while (0)
+        if (k == 0)
+            PMX_SGM_LAUNCH(SGM_FIRST);
+        else if (k == 7)
+            PMX_SGM_LAUNCH(SGM_LAST);
+        else
+            PMX_SGM_LAUNCH(SGM_MID);
+#undef PMX_SGM_LAUNCH
+    }
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting) {
+    // accumulator volume: the context's scratch; +64 B so the over-read of a lane's tail is in bounds
+    size_t bytes = cv->cells() * sizeof(float) + 64;
+    int rc = pmx_need_scratch(ctx, bytes);
+    if (rc) return rc;
+    if (cv->bytes < bytes) {
+        // the input volume needs the same tail padding for the KPL-wide loads of its last pixel
+        float* grown = nullptr;
+        PMX_HIP(hipMalloc((void**)&grown, bytes));
+        PMX_HIP(hipMemcpyAsync(grown, cv->data, cv->cells() * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(cv->data));
+        cv->data = grown;
+        cv->bytes = bytes;
+    }
+    sgm_args a;
+    a.C = cv->data;
+    a.S = ctx->scratch;
+    a.H = cv->H; a.W = cv->W; a.D = cv->D;
+    a.dr = 0; a.dc = 0;
+    a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
+    a.is_max = is_max; a.overcounting = overcounting;
+    int kpl = (cv->D + 63) / 64;
+    switch (kpl) {
+        case 1: rc = sgm_run<1>(ctx, a); break;
+        case 2: rc = sgm_run<2>(ctx, a); break;
+        case 3: rc = sgm_run<3>(ctx, a); break;
+        case 4: rc = sgm_run<4>(ctx, a); break;
+        case 5: rc = sgm_run<5>(ctx, a); break;
+        case 6: rc = sgm_run<6>(ctx, a); break;
+        case 7: rc = sgm_run<7>(ctx, a); break;
+        case 8: rc = sgm_run<8>(ctx, a); break;
+        default:
+            pmx_set_error("pmx_sgm: D = %d not supported (max 512)", cv->D);
+            return PMX_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    // the accumulator becomes the volume; the old volume becomes the scratch
+    float* old = cv->data;
+    size_t old_bytes = cv->bytes;
+    cv->data = ctx->scratch;
+    cv->bytes = ctx->scratch_bytes;
+    ctx->scratch = old;
+    ctx->scratch_bytes = old_bytes;
+    return PMX_OK;
+}

@@ -1,0 +1,456 @@
+// pmx_api.hip - context, residency and the extern "C" surface of libpandora_amd.so.
+// Every entry point is declared (with the reference interface it replaces) in include/pandora_amd.h.
+#include <cstdarg>
+#include <cstring>
+
+#include "pmx_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void pmx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* pmx_last_error(void) { return g_err; }
+
+extern "C" int pmx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" pmx_ctx* pmx_create(int device) {
+    int n = pmx_device_count();
+    if (device < 0 || device >= n) {
+        pmx_set_error("pmx_create: device %d not available (%d HIP devices visible)", device, n);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        pmx_set_error("pmx_create: hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    pmx_ctx* ctx = new pmx_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        pmx_set_error("pmx_create: hipStreamCreate failed");
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+static void free_images(pmx_ctx* ctx) {
+    hipFree(ctx->left);
+    ctx->left = nullptr;
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) {
+        hipFree(ctx->right[k]);
+        ctx->right[k] = nullptr;
+    }
+    hipFree(ctx->msk_left); ctx->msk_left = nullptr;
+    hipFree(ctx->msk_right); ctx->msk_right = nullptr;
+    hipFree(ctx->bad_left); ctx->bad_left = nullptr;
+    hipFree(ctx->bad_right); ctx->bad_right = nullptr;
+    hipFree(ctx->grid_min); ctx->grid_min = nullptr;
+    hipFree(ctx->grid_max); ctx->grid_max = nullptr;
+    hipFree(ctx->disp); ctx->disp = nullptr;
+    hipFree(ctx->itp); ctx->itp = nullptr;
+    hipFree(ctx->validity); ctx->validity = nullptr;
+    ctx->bad_win = 0;
+}
+
+extern "C" void pmx_destroy(pmx_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_images(ctx);
+    hipFree(ctx->scratch);
+    hipFree(ctx->small);
+    for (auto& s : ctx->stages)
+        for (auto e : s.ev) hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int pmx_sync(pmx_ctx* ctx) {
+    PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_sync: null context");
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" void* pmx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int pmx_need_scratch(pmx_ctx* ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return PMX_OK;
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) PMX_HIP(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    PMX_HIP(hipMalloc((void**)&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return PMX_OK;
+}
+
+int pmx_need_small(pmx_ctx* ctx, size_t bytes) {
+    if (ctx->small_bytes >= bytes) return PMX_OK;
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->small) PMX_HIP(hipFree(ctx->small));
+    ctx->small = nullptr;
+    ctx->small_bytes = 0;
+    PMX_HIP(hipMalloc(&ctx->small, bytes));
+    ctx->small_bytes = bytes;
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix) {
+    PMX_CHECK(ctx && left && right, PMX_ERR_ARG, "pmx_set_images: null argument");
+    PMX_CHECK(H > 0 && W > 1, PMX_ERR_ARG, "pmx_set_images: bad shape %dx%d", H, W);
+    PMX_CHECK(subpix == 1 || subpix == 2 || subpix == 4, PMX_ERR_ARG,
+              "pmx_set_images: subpix must be 1, 2 or 4 (matching_cost.py:70), got %d", subpix);
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    free_images(ctx);
+    ctx->H = H; ctx->W = W; ctx->subpix = subpix;
+    size_t n = (size_t)H * W;
+    PMX_HIP(hipMalloc((void**)&ctx->left, n * sizeof(float)));
+    PMX_HIP(hipMalloc((void**)&ctx->right[0], n * sizeof(float)));
+    PMX_HIP(hipMemcpyAsync(ctx->left, left, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(ctx->right[0], right, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 1; k < subpix; ++k) {
+        PMX_HIP(hipMalloc((void**)&ctx->right[k], (size_t)H * (W - 1) * sizeof(float)));
+        int rc = pmx_launch_shift_right(ctx, ctx->right[0], H, W, subpix, k, ctx->right[k]);
+        if (rc) return rc;
+    }
+    PMX_HIP(hipMalloc((void**)&ctx->disp, n * sizeof(float)));
+    PMX_HIP(hipMalloc((void**)&ctx->itp, n * sizeof(float)));
+    PMX_HIP(hipMalloc((void**)&ctx->validity, n * sizeof(int64_t)));
+    PMX_HIP(hipMemsetAsync(ctx->validity, 0, n * sizeof(int64_t), ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_t* msk_right, int valid_value,
+                             int nodata_value) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_masks: call pmx_set_images first");
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    size_t n = (size_t)ctx->H * ctx->W;
+    hipFree(ctx->msk_left); ctx->msk_left = nullptr;
+    hipFree(ctx->msk_right); ctx->msk_right = nullptr;
+    hipFree(ctx->bad_left); ctx->bad_left = nullptr;
+    hipFree(ctx->bad_right); ctx->bad_right = nullptr;
+    ctx->bad_win = 0;
+    ctx->valid_value = valid_value;
+    ctx->nodata_value = nodata_value;
+    if (msk_left) {
+        PMX_HIP(hipMalloc((void**)&ctx->msk_left, n * sizeof(int16_t)));
+        PMX_HIP(hipMalloc((void**)&ctx->bad_left, n));
+        PMX_HIP(hipMemcpy(ctx->msk_left, msk_left, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    }
+    if (msk_right) {
+        PMX_HIP(hipMalloc((void**)&ctx->msk_right, n * sizeof(int16_t)));
+        PMX_HIP(hipMalloc((void**)&ctx->bad_right, n));
+        PMX_HIP(hipMemcpy(ctx->msk_right, msk_right, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    }
+    return PMX_OK;
+}
+
+int pmx_update_bad_masks(pmx_ctx* ctx, int win) {
+    if (ctx->bad_win == win) return PMX_OK;
+    if (ctx->msk_left) {
+        int rc = pmx_launch_mask_dilate(ctx, ctx->msk_left, ctx->H, ctx->W, win, ctx->valid_value, ctx->nodata_value,
+                                        ctx->bad_left);
+        if (rc) return rc;
+    }
+    if (ctx->msk_right) {
+        int rc = pmx_launch_mask_dilate(ctx, ctx->msk_right, ctx->H, ctx->W, win, ctx->valid_value, ctx->nodata_value,
+                                        ctx->bad_right);
+        if (rc) return rc;
+    }
+    ctx->bad_win = win;
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, const double* disp_max) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_disparity_grids: call pmx_set_images first");
+    PMX_CHECK((disp_min == nullptr) == (disp_max == nullptr), PMX_ERR_ARG,
+              "pmx_set_disparity_grids: give both grids or neither");
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->grid_min); ctx->grid_min = nullptr;
+    hipFree(ctx->grid_max); ctx->grid_max = nullptr;
+    if (disp_min) {
+        size_t n = (size_t)ctx->H * ctx->W * sizeof(double);
+        PMX_HIP(hipMalloc((void**)&ctx->grid_min, n));
+        PMX_HIP(hipMalloc((void**)&ctx->grid_max, n));
+        PMX_HIP(hipMemcpy(ctx->grid_min, disp_min, n, hipMemcpyHostToDevice));
+        PMX_HIP(hipMemcpy(ctx->grid_max, disp_max, n, hipMemcpyHostToDevice));
+    }
+    return PMX_OK;
+}
+
+// ---- cost volumes ---------------------------------------------------------------------------
+extern "C" pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0) {
+    if (!ctx || !ctx->left) {
+        pmx_set_error("pmx_cv_alloc: call pmx_set_images first");
+        return nullptr;
+    }
+    if (D <= 0) {
+        pmx_set_error("pmx_cv_alloc: D must be positive, got %d", D);
+        return nullptr;
+    }
+    hipSetDevice(ctx->device);
+    pmx_cv* cv = new pmx_cv();
+    cv->ctx = ctx;
+    cv->H = ctx->H; cv->W = ctx->W; cv->D = D; cv->d0 = d0; cv->subpix = ctx->subpix;
+    cv->bytes = cv->cells() * sizeof(float) + 64;  // tail pad: wide per-lane loads of the last pixel stay in bounds
+    hipError_t e = hipMalloc((void**)&cv->data, cv->bytes);
+    if (e != hipSuccess) {
+        pmx_set_error("pmx_cv_alloc: hipMalloc(%zu bytes) failed: %s", cv->bytes, hipGetErrorString(e));
+        delete cv;
+        return nullptr;
+    }
+    if (pmx_launch_fill_nan(ctx, cv->data, cv->cells()) != PMX_OK) {
+        hipFree(cv->data);
+        delete cv;
+        return nullptr;
+    }
+    return cv;
+}
+
+extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
+    if (!cv) return;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(cv->data);
+    delete cv;
+}
+
+extern "C" int pmx_cv_fill_nan(pmx_ctx* ctx, pmx_cv* cv) {
+    PMX_CHECK(ctx && cv, PMX_ERR_ARG, "pmx_cv_fill_nan: null argument");
+    return pmx_launch_fill_nan(ctx, cv->data, cv->cells());
+}
+
+extern "C" int pmx_cv_upload(pmx_ctx* ctx, pmx_cv* cv, const float* host) {
+    PMX_CHECK(ctx && cv && host, PMX_ERR_ARG, "pmx_cv_upload: null argument");
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipMemcpyAsync(cv->data, host, cv->cells() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_cv_download(pmx_ctx* ctx, pmx_cv* cv, float* host) {
+    PMX_CHECK(ctx && cv && host, PMX_ERR_ARG, "pmx_cv_download: null argument");
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipMemcpyAsync(host, cv->data, cv->cells() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_cv_dims(const pmx_cv* cv, int* H, int* W, int* D, int* d0, int* subpix) {
+    PMX_CHECK(cv, PMX_ERR_ARG, "pmx_cv_dims: null cv");
+    if (H) *H = cv->H;
+    if (W) *W = cv->W;
+    if (D) *D = cv->D;
+    if (d0) *d0 = cv->d0;
+    if (subpix) *subpix = cv->subpix;
+    return PMX_OK;
+}
+
+static int check_cv(pmx_ctx* ctx, const pmx_cv* cv, const char* who) {
+    PMX_CHECK(ctx && cv, PMX_ERR_ARG, "%s: null argument", who);
+    PMX_CHECK(cv->ctx == ctx, PMX_ERR_ARG, "%s: cost volume belongs to another context", who);
+    PMX_CHECK(ctx->left && cv->H == ctx->H && cv->W == ctx->W && cv->subpix == ctx->subpix, PMX_ERR_STATE,
+              "%s: cost volume does not match the resident images", who);
+    PMX_HIP(hipSetDevice(ctx->device));
+    return PMX_OK;
+}
+
+static bool census_window_ok(int win) { return win == 3 || win == 5 || win == 7 || win == 9 || win == 11 || win == 13; }
+
+extern "C" int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
+    int rc = check_cv(ctx, cv, "pmx_census");
+    if (rc) return rc;
+    PMX_CHECK(census_window_ok(win), PMX_ERR_ARG, "pmx_census: window_size must be in (3,5,7,9,11,13) (census.py:68), got %d", win);
+    return pmx_launch_census(ctx, cv, win);
+}
+
+extern "C" int pmx_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared) {
+    int rc = check_cv(ctx, cv, "pmx_sad_ssd");
+    if (rc) return rc;
+    PMX_CHECK(win > 0 && (win & 1), PMX_ERR_ARG, "pmx_sad_ssd: window_size must be odd and > 0 (sad_ssd.py:69), got %d", win);
+    return pmx_launch_sad_ssd(ctx, cv, win, squared);
+}
+
+extern "C" int pmx_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
+    int rc = check_cv(ctx, cv, "pmx_zncc");
+    if (rc) return rc;
+    PMX_CHECK(win > 0 && (win & 1), PMX_ERR_ARG, "pmx_zncc: window_size must be odd and > 0, got %d", win);
+    return pmx_launch_zncc(ctx, cv, win);
+}
+
+extern "C" int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win) {
+    int rc = check_cv(ctx, cv, "pmx_cv_masked");
+    if (rc) return rc;
+    rc = pmx_update_bad_masks(ctx, win);
+    if (rc) return rc;
+    return pmx_launch_cv_masked(ctx, cv, win);
+}
+
+extern "C" pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, int min_disp) {
+    if (check_cv(ctx, left_cv, "pmx_reverse_cost_volume")) return nullptr;
+    pmx_cv* out = pmx_cv_alloc(ctx, left_cv->D, min_disp);
+    if (!out) return nullptr;
+    if (pmx_launch_reverse(ctx, left_cv, min_disp, out) != PMX_OK) {
+        pmx_cv_free(ctx, out);
+        return nullptr;
+    }
+    return out;
+}
+
+extern "C" int pmx_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance) {
+    int rc = check_cv(ctx, cv, "pmx_cbca");
+    if (rc) return rc;
+    PMX_CHECK(offset >= 0 && distance >= 1 && intensity > 0.f, PMX_ERR_ARG,
+              "pmx_cbca: need offset >= 0, cbca_distance >= 1, cbca_intensity > 0 (cbca.py:59-82)");
+    PMX_CHECK(distance <= 32, PMX_ERR_UNSUPPORTED, "pmx_cbca: cbca_distance > 32 not supported");
+    return pmx_launch_cbca(ctx, cv, offset, intensity, distance);
+}
+
+extern "C" int pmx_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* host_out) {
+    PMX_CHECK(ctx && ctx->left && host_out, PMX_ERR_ARG, "pmx_cross_support: bad argument");
+    PMX_CHECK(side >= 0 && side <= ctx->subpix, PMX_ERR_ARG, "pmx_cross_support: side out of range");
+    PMX_HIP(hipSetDevice(ctx->device));
+    int Wd = side <= 1 ? ctx->W : ctx->W - 1;
+    size_t n = (size_t)(ctx->H - 2 * offset) * (Wd - 2 * offset) * 4 * sizeof(int16_t);
+    int16_t* dev = nullptr;
+    PMX_HIP(hipMalloc((void**)&dev, n));
+    int rc = pmx_launch_cross_support(ctx, side, offset, intensity, distance, dev);
+    if (rc == PMX_OK) {
+        hipError_t e = hipMemcpyAsync(host_out, dev, n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            pmx_set_error("pmx_cross_support: copy failed: %s", hipGetErrorString(e));
+            rc = PMX_ERR_HIP;
+        }
+    }
+    hipFree(dev);
+    return rc;
+}
+
+extern "C" int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting) {
+    int rc = check_cv(ctx, cv, "pmx_sgm");
+    if (rc) return rc;
+    PMX_CHECK(P1 > 0.f && P2 > P1, PMX_ERR_ARG, "pmx_sgm: need 0 < P1 < P2 (plugin_libsgm.rst:170-185), got %g %g", P1, P2);
+    PMX_CHECK(cv->D <= 512, PMX_ERR_UNSUPPORTED, "pmx_sgm: D = %d > 512 disparities not supported", cv->D);
+    return pmx_launch_sgm(ctx, cv, P1, P2, is_max, invalid_cost, overcounting);
+}
+
+extern "C" int pmx_set_validity(pmx_ctx* ctx, const int64_t* validity) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_validity: call pmx_set_images first");
+    PMX_HIP(hipSetDevice(ctx->device));
+    size_t n = (size_t)ctx->H * ctx->W * sizeof(int64_t);
+    if (validity) {
+        PMX_HIP(hipMemcpyAsync(ctx->validity, validity, n, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        PMX_HIP(hipMemsetAsync(ctx->validity, 0, n, ctx->stream));
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity) {
+    int rc = check_cv(ctx, cv, "pmx_wta");
+    if (rc) return rc;
+    return pmx_launch_wta(ctx, cv, is_max, invalid_disparity);
+}
+
+extern "C" int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max) {
+    int rc = check_cv(ctx, cv, "pmx_refine");
+    if (rc) return rc;
+    PMX_CHECK(method == PMX_REFINE_VFIT || method == PMX_REFINE_QUADRATIC, PMX_ERR_ARG,
+              "pmx_refine: unknown refinement method %d", method);
+    return pmx_launch_refine(ctx, cv, method, is_max);
+}
+
+extern "C" int pmx_get_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_get_disparity: nothing resident");
+    PMX_HIP(hipSetDevice(ctx->device));
+    size_t n = (size_t)ctx->H * ctx->W;
+    if (disp) PMX_HIP(hipMemcpyAsync(disp, ctx->disp, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (validity) PMX_HIP(hipMemcpyAsync(validity, ctx->validity, n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (itp) PMX_HIP(hipMemcpyAsync(itp, ctx->itp, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t* validity) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_disparity: call pmx_set_images first");
+    PMX_HIP(hipSetDevice(ctx->device));
+    size_t n = (size_t)ctx->H * ctx->W;
+    if (disp) PMX_HIP(hipMemcpyAsync(ctx->disp, disp, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (validity) PMX_HIP(hipMemcpyAsync(ctx->validity, validity, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_wta_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int global_index_offset, uint64_t* dev_keys) {
+    int rc = check_cv(ctx, cv, "pmx_wta_minkey");
+    if (rc) return rc;
+    PMX_CHECK(dev_keys, PMX_ERR_ARG, "pmx_wta_minkey: null key buffer");
+    return pmx_launch_minkey(ctx, cv, is_max, global_index_offset, dev_keys);
+}
+
+extern "C" int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double d0_global, int subpix,
+                                 float invalid_disparity) {
+    PMX_CHECK(ctx && ctx->left && dev_keys, PMX_ERR_ARG, "pmx_wta_from_keys: bad argument");
+    PMX_HIP(hipSetDevice(ctx->device));
+    return pmx_launch_from_keys(ctx, dev_keys, d0_global, subpix, invalid_disparity);
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+extern "C" int pmx_set_profiling(pmx_ctx* ctx, int enabled) {
+    PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_set_profiling: null context");
+    ctx->profiling = enabled != 0;
+    return PMX_OK;
+}
+
+static int fold_stage(pmx_ctx* ctx, int stage) {
+    pmx_stage_rec& s = ctx->stages[stage];
+    for (size_t i = 0; i + 1 < s.ev.size(); i += 2) {
+        float ms = 0.f;
+        PMX_HIP(hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+        s.total_ms += ms;
+        s.launches += 1;
+        hipEventDestroy(s.ev[i]);
+        hipEventDestroy(s.ev[i + 1]);
+    }
+    s.ev.clear();
+    return PMX_OK;
+}
+
+extern "C" int pmx_reset_stage_times(pmx_ctx* ctx) {
+    PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_reset_stage_times: null context");
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < PMX_STAGE_COUNT; ++i) {
+        int rc = fold_stage(ctx, i);
+        if (rc) return rc;
+        ctx->stages[i].total_ms = 0.0;
+        ctx->stages[i].launches = 0;
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_stage_time(pmx_ctx* ctx, int stage, double* total_ms, int* launches) {
+    PMX_CHECK(ctx && stage >= 0 && stage < PMX_STAGE_COUNT, PMX_ERR_ARG, "pmx_stage_time: bad argument");
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = fold_stage(ctx, stage);
+    if (rc) return rc;
+    if (total_ms) *total_ms = ctx->stages[stage].total_ms;
+    if (launches) *launches = ctx->stages[stage].launches;
+    return PMX_OK;
+}

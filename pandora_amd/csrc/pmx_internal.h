@@ -1,0 +1,133 @@
+// pmx_internal.h - shared declarations of libpandora_amd.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/pandora_amd.h"
+
+#define PMX_MAX_SUBPIX 4
+
+void pmx_set_error(const char* fmt, ...);
+
+#define PMX_HIP(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            pmx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PMX_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+#define PMX_CHECK(cond, code, ...)      \
+    do {                                \
+        if (!(cond)) {                  \
+            pmx_set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+struct pmx_stage_rec {
+    std::vector<hipEvent_t> ev;  // pairs (start, stop) not yet folded into total_ms
+    double total_ms = 0.0;
+    int launches = 0;
+};
+
+struct pmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int H = 0, W = 0, subpix = 1;
+    // resident pair; right[k] is the k-th shifted right image, width W (k=0) or W-1
+    float* left = nullptr;
+    float* right[PMX_MAX_SUBPIX] = {nullptr, nullptr, nullptr, nullptr};
+    // masks: raw int16 + the cv_masked predicate (1 = invalid or dilated no-data); bad_win = window
+    // the dilation was computed for (0 = stale)
+    int16_t* msk_left = nullptr;
+    int16_t* msk_right = nullptr;
+    int valid_value = 0, nodata_value = 1;
+    uint8_t* bad_left = nullptr;
+    uint8_t* bad_right = nullptr;
+    int bad_win = 0;
+    double* grid_min = nullptr;
+    double* grid_max = nullptr;
+    // WTA / refinement results
+    float* disp = nullptr;
+    float* itp = nullptr;
+    int64_t* validity = nullptr;
+    // scratch volume reused across calls (SGM accumulator, CBCA intermediate)
+    float* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // generic small scratch (census codes, arms, medians)
+    void* small = nullptr;
+    size_t small_bytes = 0;
+    bool profiling = false;
+    pmx_stage_rec stages[PMX_STAGE_COUNT];
+};
+
+struct pmx_cv {
+    pmx_ctx* ctx = nullptr;
+    float* data = nullptr;
+    size_t bytes = 0;  // capacity of data
+    int H = 0, W = 0, D = 0, d0 = 0, subpix = 1;
+    size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
+};
+
+// RAII-less helper: brackets a launch with events when profiling is on
+struct pmx_stage_scope {
+    pmx_ctx* ctx;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    pmx_stage_scope(pmx_ctx* c, int s) : ctx(c), stage(s) {
+        if (ctx->profiling) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~pmx_stage_scope() {
+        if (ctx->profiling) {
+            hipEventRecord(b, ctx->stream);
+            ctx->stages[stage].ev.push_back(a);
+            ctx->stages[stage].ev.push_back(b);
+        }
+    }
+};
+
+int pmx_need_scratch(pmx_ctx* ctx, size_t bytes);
+int pmx_need_small(pmx_ctx* ctx, size_t bytes);
+int pmx_update_bad_masks(pmx_ctx* ctx, int win);
+
+static inline int pmx_shifted_width(int W, int k) { return k == 0 ? W : W - 1; }
+
+// parameters shared by every matching-cost kernel: geometry + the cv_masked predicate inputs
+struct pmx_mc_params {
+    int H, W, D, d0, subpix, win;
+    const float* left;
+    const float* right[PMX_MAX_SUBPIX];
+    const uint8_t* bad_left;   // may be null
+    const uint8_t* bad_right;  // may be null
+    const double* grid_min;    // may be null
+    const double* grid_max;
+    int apply_mask;
+};
+
+// kernels (one translation unit each)
+int pmx_launch_shift_right(pmx_ctx* ctx, const float* R, int H, int W, int subpix, int k, float* out);
+int pmx_launch_census(pmx_ctx* ctx, pmx_cv* cv, int win);
+int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared);
+int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);
+int pmx_launch_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);
+int pmx_launch_mask_dilate(pmx_ctx* ctx, const int16_t* msk, int H, int W, int win, int valid, int nodata, uint8_t* bad);
+int pmx_launch_fill_nan(pmx_ctx* ctx, float* p, size_t n);
+int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
+int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
+int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
+int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance);
+int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
+int pmx_launch_reverse(pmx_ctx* ctx, const pmx_cv* in, int min_disp, pmx_cv* out);
+int pmx_launch_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int index_offset, uint64_t* keys);
+int pmx_launch_from_keys(pmx_ctx* ctx, const uint64_t* keys, double d0, int subpix, float invalid_disparity);

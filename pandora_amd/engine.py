@@ -1,0 +1,188 @@
+"""Thin object layer over the C ABI (include/pandora_amd.h): one Engine = one GPU context holding
+the resident stereo pair; DeviceCostVolume = a device-resident [H][W][D] float32 volume."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PmxError, check
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class DeviceCostVolume:
+    """Handle on a cost volume living in HBM.  ``to_host()`` materialises it lazily."""
+
+    def __init__(self, engine, handle, D, d0):
+        self.engine = engine
+        self.handle = handle
+        self.D = int(D)
+        self.d0 = int(d0)
+
+    @property
+    def shape(self):
+        return (self.engine.H, self.engine.W, self.D)
+
+    def to_host(self):
+        out = np.empty(self.shape, np.float32)
+        check(_lib.lib().pmx_cv_download(self.engine.ctx, self.handle, _p(out, C.c_float)), "pmx_cv_download")
+        return out
+
+    def from_host(self, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        if arr.shape != self.shape:
+            raise ValueError(f"cost volume shape {arr.shape} != {self.shape}")
+        check(_lib.lib().pmx_cv_upload(self.engine.ctx, self.handle, _p(arr, C.c_float)), "pmx_cv_upload")
+
+    def free(self):
+        if self.handle is not None and self.engine.ctx is not None:
+            _lib.lib().pmx_cv_free(self.engine.ctx, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class Engine:
+    """One MI355X context.  Raises if the HIP library is not built or no GPU is visible."""
+
+    def __init__(self, device=0):
+        self.ctx = None
+        L = _lib.lib()
+        n = L.pmx_device_count()
+        if n <= 0:
+            raise PmxError("pandora_amd: no HIP device visible (there is no CPU fallback)")
+        self.ctx = L.pmx_create(int(device))
+        if not self.ctx:
+            raise PmxError("pmx_create failed: " + L.pmx_last_error().decode())
+        self.device = int(device)
+        self.H = self.W = 0
+        self.subpix = 1
+
+    def close(self):
+        if self.ctx:
+            _lib.lib().pmx_destroy(self.ctx)
+        self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- residency ---------------------------------------------------------------------------
+    def set_images(self, left, right, subpix=1):
+        left = np.ascontiguousarray(left, np.float32)
+        right = np.ascontiguousarray(right, np.float32)
+        if left.ndim != 2 or left.shape != right.shape:
+            raise ValueError("left/right must be 2-D arrays of the same shape")
+        self.H, self.W = left.shape
+        self.subpix = int(subpix)
+        check(_lib.lib().pmx_set_images(self.ctx, _p(left, C.c_float), _p(right, C.c_float), self.H, self.W, self.subpix),
+              "pmx_set_images")
+
+    def set_masks(self, msk_left=None, msk_right=None, valid=0, nodata=1):
+        ml = None if msk_left is None else np.ascontiguousarray(msk_left, np.int16)
+        mr = None if msk_right is None else np.ascontiguousarray(msk_right, np.int16)
+        check(_lib.lib().pmx_set_masks(self.ctx, _p(ml, C.c_int16), _p(mr, C.c_int16), int(valid), int(nodata)),
+              "pmx_set_masks")
+
+    def set_disparity_grids(self, dmin=None, dmax=None):
+        a = None if dmin is None else np.ascontiguousarray(dmin, np.float64)
+        b = None if dmax is None else np.ascontiguousarray(dmax, np.float64)
+        check(_lib.lib().pmx_set_disparity_grids(self.ctx, _p(a, C.c_double), _p(b, C.c_double)), "pmx_set_disparity_grids")
+
+    def alloc_cv(self, D, d0):
+        h = _lib.lib().pmx_cv_alloc(self.ctx, int(D), int(d0))
+        if not h:
+            raise PmxError("pmx_cv_alloc failed: " + _lib.lib().pmx_last_error().decode())
+        return DeviceCostVolume(self, h, D, d0)
+
+    # -- steps -------------------------------------------------------------------------------
+    def census(self, cv, win):
+        check(_lib.lib().pmx_census(self.ctx, cv.handle, int(win)), "pmx_census")
+
+    def sad_ssd(self, cv, win, squared):
+        check(_lib.lib().pmx_sad_ssd(self.ctx, cv.handle, int(win), int(bool(squared))), "pmx_sad_ssd")
+
+    def zncc(self, cv, win):
+        check(_lib.lib().pmx_zncc(self.ctx, cv.handle, int(win)), "pmx_zncc")
+
+    def cv_masked(self, cv, win):
+        check(_lib.lib().pmx_cv_masked(self.ctx, cv.handle, int(win)), "pmx_cv_masked")
+
+    def reverse_cost_volume(self, cv, min_disp):
+        h = _lib.lib().pmx_reverse_cost_volume(self.ctx, cv.handle, int(min_disp))
+        if not h:
+            raise PmxError("pmx_reverse_cost_volume failed: " + _lib.lib().pmx_last_error().decode())
+        return DeviceCostVolume(self, h, cv.D, min_disp)
+
+    def cbca(self, cv, offset, intensity, distance):
+        check(_lib.lib().pmx_cbca(self.ctx, cv.handle, int(offset), float(intensity), int(distance)), "pmx_cbca")
+
+    def cross_support(self, side, offset, intensity, distance):
+        wd = self.W if side <= 1 else self.W - 1
+        out = np.empty((self.H - 2 * offset, wd - 2 * offset, 4), np.int16)
+        check(_lib.lib().pmx_cross_support(self.ctx, int(side), int(offset), float(intensity), int(distance),
+                                           _p(out, C.c_int16)), "pmx_cross_support")
+        return out
+
+    def sgm(self, cv, P1, P2, is_max=False, invalid_cost=0.0, overcounting=False):
+        check(_lib.lib().pmx_sgm(self.ctx, cv.handle, float(P1), float(P2), int(bool(is_max)), float(invalid_cost),
+                                 int(bool(overcounting))), "pmx_sgm")
+
+    def set_validity(self, validity=None):
+        v = None if validity is None else np.ascontiguousarray(validity, np.int64)
+        check(_lib.lib().pmx_set_validity(self.ctx, _p(v, C.c_int64)), "pmx_set_validity")
+
+    def wta(self, cv, is_max=False, invalid_disparity=-9999.0):
+        check(_lib.lib().pmx_wta(self.ctx, cv.handle, int(bool(is_max)), float(invalid_disparity)), "pmx_wta")
+
+    def refine(self, cv, method, is_max=False):
+        m = {"vfit": 0, "quadratic": 1}[method]
+        check(_lib.lib().pmx_refine(self.ctx, cv.handle, m, int(bool(is_max))), "pmx_refine")
+
+    def get_disparity(self, want_itp=False):
+        disp = np.empty((self.H, self.W), np.float32)
+        val = np.empty((self.H, self.W), np.int64)
+        itp = np.empty((self.H, self.W), np.float32) if want_itp else None
+        check(_lib.lib().pmx_get_disparity(self.ctx, _p(disp, C.c_float), _p(val, C.c_int64), _p(itp, C.c_float)),
+              "pmx_get_disparity")
+        return (disp, val, itp) if want_itp else (disp, val)
+
+    def set_disparity(self, disp=None, validity=None):
+        d = None if disp is None else np.ascontiguousarray(disp, np.float32)
+        v = None if validity is None else np.ascontiguousarray(validity, np.int64)
+        check(_lib.lib().pmx_set_disparity(self.ctx, _p(d, C.c_float), _p(v, C.c_int64)), "pmx_set_disparity")
+
+    def wta_minkey(self, cv, is_max, index_offset, dev_keys_ptr):
+        check(_lib.lib().pmx_wta_minkey(self.ctx, cv.handle, int(bool(is_max)), int(index_offset), C.c_void_p(dev_keys_ptr)),
+              "pmx_wta_minkey")
+
+    def wta_from_keys(self, dev_keys_ptr, d0_global, subpix, invalid_disparity):
+        check(_lib.lib().pmx_wta_from_keys(self.ctx, C.c_void_p(dev_keys_ptr), float(d0_global), int(subpix),
+                                           float(invalid_disparity)), "pmx_wta_from_keys")
+
+    # -- measurement -------------------------------------------------------------------------
+    def sync(self):
+        check(_lib.lib().pmx_sync(self.ctx), "pmx_sync")
+
+    def set_profiling(self, on):
+        check(_lib.lib().pmx_set_profiling(self.ctx, int(bool(on))), "pmx_set_profiling")
+
+    def reset_stage_times(self):
+        check(_lib.lib().pmx_reset_stage_times(self.ctx), "pmx_reset_stage_times")
+
+    def stage_time(self, name):
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        check(_lib.lib().pmx_stage_time(self.ctx, _lib.STAGES[name], C.byref(ms), C.byref(n)), "pmx_stage_time")
+        return ms.value, n.value
+
+    def stream(self):
+        return _lib.lib().pmx_stream(self.ctx)

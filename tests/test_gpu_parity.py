@@ -1,0 +1,279 @@
+"""GPU parity: every HIP kernel, called through the C ABI (ctypes -> libpandora_amd.so), against the
+CPU oracle on the same seeded inputs.  Bit-exact for census / NaN patterns / WTA indices / integer
+costs; float costs within the tolerance written in each test."""
+import numpy as np
+import pytest
+
+from tests.golden import known_answers as ka
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pandora_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def pair(H, W, seed, integer=True, shift=3):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (H, W + 2 * abs(shift) + 4)).astype(np.float32)
+    # low-pass so that census has ties
+    base = np.floor((base + np.roll(base, 1, 1) + np.roll(base, 1, 0)) / 3.0)
+    L = base[:, abs(shift):abs(shift) + W].copy()
+    R = base[:, abs(shift) + shift:abs(shift) + shift + W].copy() + rng.integers(-2, 3, (H, W))
+    if not integer:
+        L += rng.random((H, W)).astype(np.float32)
+        R += rng.random((H, W)).astype(np.float32)
+    return L.astype(np.float32), R.astype(np.float32)
+
+
+def gpu_cv(eng, method, L, R, dmin, dmax, subpix, win, masks=None, grids=None, masked=True):
+    eng.set_images(L, R, subpix)
+    if masks:
+        eng.set_masks(masks[0], masks[1], masks[2], masks[3])
+    if grids:
+        eng.set_disparity_grids(grids[0], grids[1])
+    D = (dmax - dmin) * subpix + 1
+    cv = eng.alloc_cv(D, dmin)
+    if method == "census":
+        eng.census(cv, win)
+    elif method in ("sad", "ssd"):
+        eng.sad_ssd(cv, win, method == "ssd")
+    else:
+        eng.zncc(cv, win)
+    if masked:
+        eng.cv_masked(cv, win)
+    return cv
+
+
+def cpu_cv(oracle, method, L, R, dmin, dmax, subpix, win, masks=None, grids=None):
+    D = (dmax - dmin) * subpix + 1
+    if method == "census":
+        cv = oracle.census_cost(L, R, D, dmin, subpix, win)
+    elif method in ("sad", "ssd"):
+        cv = oracle.sad_ssd(L, R, D, dmin, subpix, win, method == "ssd")
+    else:
+        cv = oracle.zncc(L, R, D, dmin, subpix, win)
+    kw = {}
+    if masks:
+        kw.update(mskL=masks[0], mskR=masks[1], valid=masks[2], nodata=masks[3])
+    if grids:
+        kw.update(dmin=grids[0], dmax=grids[1])
+    if kw:
+        oracle.cv_masked(cv, dmin, subpix, win, **kw)
+    return cv
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [
+    (37, 53, -7, 4, 1, 5), (16, 40, -3, 3, 2, 3), (21, 35, -2, 2, 4, 7), (40, 64, 0, 16, 1, 13),
+    (33, 129, -60, 0, 1, 5), (24, 50, 3, 9, 1, 9), (20, 47, -4, 1, 2, 11), (8, 9, -1, 1, 1, 3)])
+def test_census_bit_exact(eng, oracle, H, W, dmin, dmax, sp, win):
+    L, R = pair(H, W, seed=H * W + win)
+    got = gpu_cv(eng, "census", L, R, dmin, dmax, sp, win).to_host()
+    np.testing.assert_array_equal(got, cpu_cv(oracle, "census", L, R, dmin, dmax, sp, win))
+
+
+@pytest.mark.parametrize("case", ka.CENSUS + [ka.SAD_FULL, ka.SAD_SUBPIX], ids=lambda c: c["cite"])
+def test_reference_known_answers_on_gpu(eng, case):
+    method = "census" if "expected_dhw" in case else "sad"
+    L, R = np.array(case["left"], np.float32), np.array(case["right"], np.float32)
+    got = gpu_cv(eng, method, L, R, case["dmin"], case["dmax"], case["subpix"], case["win"]).to_host()
+    exp = np.moveaxis(np.array(case["expected_dhw"], np.float32), 0, -1) if method == "census" else np.array(case["expected"], np.float32)
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("method", ["census", "sad", "ssd", "zncc"])
+@pytest.mark.parametrize("case", ka.CV_MASKED, ids=lambda c: c["cite"])
+def test_reference_nan_patterns_on_gpu(eng, case, method):
+    L, R = np.array(case["left"], np.float32), np.array(case["right"], np.float32)
+    masks = (np.array(case["left_mask"], np.int16), np.array(case["right_mask"], np.int16), case["valid"], case["nodata"])
+    got = gpu_cv(eng, method, L, R, case["dmin"], case["dmax"], case["subpix"], case["win"], masks=masks).to_host()
+    np.testing.assert_array_equal(np.isnan(got), ka.nanmask(case["nan"]))
+
+
+@pytest.mark.parametrize("method,integer", [("sad", True), ("ssd", True), ("sad", False), ("ssd", False)])
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [(30, 44, -6, 3, 1, 5), (18, 33, -2, 2, 2, 3), (19, 31, -1, 2, 4, 1), (26, 40, 0, 5, 1, 9)])
+def test_sad_ssd(eng, oracle, method, integer, H, W, dmin, dmax, sp, win):
+    L, R = pair(H, W, seed=3 * H + W, integer=integer)
+    got = gpu_cv(eng, method, L, R, dmin, dmax, sp, win).to_host()
+    exp = cpu_cv(oracle, method, L, R, dmin, dmax, sp, win)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    # same float32 summation order as the oracle: bit-exact (reference tolerance would be 1e-5)
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("integer", [True, False])
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [(30, 44, -6, 3, 1, 5), (18, 33, -2, 2, 2, 3), (26, 40, 0, 5, 1, 11), (14, 30, -3, 0, 4, 5)])
+def test_zncc(eng, oracle, integer, H, W, dmin, dmax, sp, win):
+    L, R = pair(H, W, seed=5 * H + W, integer=integer)
+    L[2:8, 3:12] = 7.0  # constant patch: std = 0 -> zncc must be exactly 0 (zncc.py:273-277)
+    got = gpu_cv(eng, "zncc", L, R, dmin, dmax, sp, win).to_host()
+    exp = cpu_cv(oracle, "zncc", L, R, dmin, dmax, sp, win)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5)  # north_star: float costs within 1e-5
+
+
+def test_masks_and_variable_disparity_grids(eng, oracle):
+    H, W, dmin, dmax, sp, win = 28, 41, -5, 4, 2, 5
+    L, R = pair(H, W, seed=99)
+    rng = np.random.default_rng(5)
+    mL = rng.choice([0, 0, 0, 0, 1, 2], (H, W)).astype(np.int16)
+    mR = rng.choice([0, 0, 0, 0, 0, 1, 3], (H, W)).astype(np.int16)
+    gmin = rng.integers(dmin, 0, (H, W)).astype(np.float64)
+    gmax = rng.integers(0, dmax + 1, (H, W)).astype(np.float64)
+    for method in ("census", "sad"):
+        got = gpu_cv(eng, method, L, R, dmin, dmax, sp, win, masks=(mL, mR, 0, 1), grids=(gmin, gmax)).to_host()
+        exp = cpu_cv(oracle, method, L, R, dmin, dmax, sp, win, masks=(mL, mR, 0, 1), grids=(gmin, gmax))
+        np.testing.assert_array_equal(got, exp)
+    eng.set_masks(None, None)
+    eng.set_disparity_grids(None, None)
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,win,P1,P2", [(24, 37, -6, 3, 5, 8, 32), (33, 70, -60, 0, 5, 8, 32), (17, 90, 0, 128, 3, 4, 20),
+                                                      (9, 11, -2, 2, 3, 8, 32), (40, 30, -70, 0, 5, 1, 2)])
+def test_sgm_census_bit_exact(eng, oracle, H, W, dmin, dmax, win, P1, P2):
+    """Integer costs and integer penalties: every L_r is an exact small integer in float32, so the
+    8-path sum is order independent and the comparison is bit-exact."""
+    L, R = pair(H, W, seed=H + W)
+    cv = gpu_cv(eng, "census", L, R, dmin, dmax, 1, win)
+    cpu = cpu_cv(oracle, "census", L, R, dmin, dmax, 1, win)
+    eng.sgm(cv, P1, P2, False, float(win * win + 1), False)
+    np.testing.assert_array_equal(cv.to_host(), oracle.sgm(cpu, P1, P2, False, float(win * win + 1), False))
+
+
+@pytest.mark.parametrize("is_max,overcounting", [(False, False), (True, False), (False, True)])
+def test_sgm_float_costs(eng, oracle, is_max, overcounting):
+    H, W, dmin, dmax, win = 26, 45, -9, 5, 5
+    L, R = pair(H, W, seed=8, integer=False)
+    method = "zncc" if is_max else "sad"
+    cv = gpu_cv(eng, method, L, R, dmin, dmax, 1, win)
+    cpu = cv.to_host()
+    inv = 2.0 if is_max else 1e4
+    eng.sgm(cv, 0.5 if is_max else 8.5, 1.25 if is_max else 32.25, is_max, inv, overcounting)
+    got = cv.to_host()
+    exp = oracle.sgm(cpu, 0.5 if is_max else 8.5, 1.25 if is_max else 32.25, is_max, inv, overcounting)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    # same operation order as the oracle -> bit-exact; north_star tolerance for float costs is 1e-5
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("is_max", [False, True])
+@pytest.mark.parametrize("H,W,D,sp", [(13, 17, 9, 1), (20, 33, 129, 1), (11, 19, 65, 2), (7, 50, 300, 1), (6, 9, 1, 1)])
+def test_wta_and_refinement(eng, oracle, is_max, H, W, D, sp):
+    rng = np.random.default_rng(D)
+    cvh = rng.integers(0, 6, (H, W, D)).astype(np.float32)  # many ties: first extremum must win
+    cvh[rng.random(cvh.shape) < 0.15] = np.nan
+    cvh[0, 0, :] = np.nan
+    if D > 2:
+        cvh[1, 1, :] = 3.0
+    L = np.zeros((H, W), np.float32)
+    eng.set_images(L, L, sp)
+    d0 = -4
+    cv = eng.alloc_cv(D, d0)
+    cv.from_host(cvh)
+    val0 = rng.choice([0, 0, 0, 4, 1, 64], (H, W)).astype(np.int64)
+    eng.set_validity(val0)
+    eng.wta(cv, is_max, -9999.0)
+    disp, val = eng.get_disparity()
+    edisp, eval_ = oracle.wta(cvh, d0, sp, is_max, -9999.0, val0)
+    np.testing.assert_array_equal(disp, edisp)
+    np.testing.assert_array_equal(val, eval_)
+    d_max = d0 + (D - 1) / sp
+    for method in ("vfit", "quadratic"):
+        eng.set_disparity(edisp, eval_)
+        eng.refine(cv, method, is_max)
+        d, v, itp = eng.get_disparity(want_itp=True)
+        eitp, ed, ev = oracle.refine(cvh, edisp, eval_, d0, d_max, sp, is_max, method)
+        np.testing.assert_array_equal(d, ed)
+        np.testing.assert_array_equal(v, ev)
+        np.testing.assert_array_equal(itp, eitp)
+
+
+def test_wta_reference_known_answers(eng):
+    c = ka.WTA
+    for (dmin, dmax), gt in c["cases"]:
+        cv = gpu_cv(eng, "sad", np.array(c["left"], np.float32), np.array(c["right"], np.float32), dmin, dmax, 1, 1)
+        eng.set_validity(None)
+        eng.wta(cv, False, 0.0)
+        np.testing.assert_array_equal(eng.get_disparity()[0], np.array(gt, np.float32))
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,win,method,integer", [
+    (24, 38, -5, 3, 1, 5, "census", True), (19, 31, -3, 2, 2, 3, "sad", False), (16, 30, -2, 2, 4, 1, "sad", False),
+    (30, 45, -8, 0, 1, 5, "zncc", False)])
+def test_cbca(eng, oracle, H, W, dmin, dmax, sp, win, method, integer):
+    L, R = pair(H, W, seed=H * 7 + W, integer=integer)
+    rng = np.random.default_rng(1)
+    mL = rng.choice([0, 0, 0, 0, 0, 0, 1, 2], (H, W)).astype(np.int16)
+    mR = rng.choice([0, 0, 0, 0, 0, 0, 1, 2], (H, W)).astype(np.int16)
+    cv = gpu_cv(eng, method, L, R, dmin, dmax, sp, win, masks=(mL, mR, 0, 1))
+    cpu = cv.to_host()
+    off = win // 2
+    eng.cbca(cv, off, 30.0, 5)
+
+    def arms(im, msk, shifted):
+        m = im.copy()
+        bad = msk != 0
+        if shifted:
+            bad = bad[:, :-1] | bad[:, 1:]
+        m[bad] = np.nan
+        m = np.nan_to_num(oracle.median3(m), nan=np.inf)
+        if off:
+            m = m[off:-off, off:-off]
+        return oracle.cross_support(np.ascontiguousarray(m), 5, 30.0)
+
+    cl = arms(L, mL, False)
+    crs = [arms(im, mR, k > 0) for k, im in enumerate(oracle.shift_right(R, sp))]
+    np.testing.assert_array_equal(eng.cross_support(0, off, 30.0, 5), cl)
+    for k in range(sp):
+        np.testing.assert_array_equal(eng.cross_support(k + 1, off, 30.0, 5), crs[k])
+    exp = oracle.cbca(cpu.copy(), dmin, sp, off, cl, crs)
+    got = cv.to_host()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    np.testing.assert_array_equal(got, exp)  # sequential float32 scans, same order as the reference
+    eng.set_masks(None, None)
+
+
+def test_cbca_reference_known_answer(eng):
+    c = ka.CBCA
+    cv = gpu_cv(eng, "sad", np.array(c["left"], np.float32), np.array(c["right"], np.float32), -1, 1, 1, 1)
+    eng.cbca(cv, 0, c["intensity"], c["distance"])
+    np.testing.assert_allclose(cv.to_host(), np.array(c["aggregated"], np.float32), rtol=1e-7)
+
+
+def test_reverse_cost_volume(eng, oracle):
+    rng = np.random.default_rng(2)
+    H, W, D = 9, 21, 7
+    cvh = rng.random((H, W, D)).astype(np.float32)
+    z = np.zeros((H, W), np.float32)
+    eng.set_images(z, z, 1)
+    cv = eng.alloc_cv(D, -4)
+    cv.from_host(cvh)
+    for md in (-2, 0, -6):
+        out = eng.reverse_cost_volume(cv, md)
+        np.testing.assert_array_equal(out.to_host(), oracle.reverse_cost_volume(cvh, md))
+
+
+def test_full_size_properties(eng, oracle):
+    """BASELINE config C3 shape class (large H*W*D): properties that need no CPU volume.
+    (1) census+SGM+WTA is row-translation equivariant for the horizontal-only content: identical
+        rows give identical disparities; (2) the first rows/cols of a crop equal the oracle on the
+        crop for the stages without long-range coupling (census, WTA)."""
+    H, W, dmin, dmax = 256, 512, 0, 128
+    L, R = pair(8, W, seed=4, shift=-5)
+    Lb, Rb = np.tile(L, (H // 8, 1)), np.tile(R, (H // 8, 1))
+    cv = gpu_cv(eng, "census", Lb, Rb, dmin, dmax, 1, 5)
+    host = cv.to_host()
+    exp_rows = oracle.census_cost(Lb[:24], Rb[:24], dmax - dmin + 1, dmin, 1, 5)
+    np.testing.assert_array_equal(host[2:22], exp_rows[2:22])
+    eng.sgm(cv, 8, 32, False, 26.0, False)
+    eng.set_validity(None)
+    eng.wta(cv, False, -9999.0)
+    disp, _ = eng.get_disparity()
+    # vertically periodic input (period 8): interior rows far from the top/bottom borders repeat
+    mid = disp[64:192]
+    np.testing.assert_array_equal(mid[:64], mid[64:])
