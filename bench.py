@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--dmin", type=int, default=0)
     ap.add_argument("--dmax", type=int, default=128)
-    ap.add_argument("--cpu-rows", type=int, default=160, help="rows of the CPU-baseline strip (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline strip (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
