@@ -78,6 +78,9 @@ int pmx_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);
 /* AbstractMatchingCost.cv_masked NaN injection (matching_cost/matching_cost.py:770-872) using the
  * masks / grids set on the context. */
 int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);
+/* Pixels whose cost is NaN for every disparity (np.min(np.isnan(cv), axis=2)), uint8 [H][W] on the
+ * host: input of criteria.mask_invalid_variable_disparity_range (criteria.py:291-322). */
+int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out);
 /* matching_cost_cpp.reverse_cost_volume (matching_cost/cpp/src/matching_cost.cpp:26-56) */
 pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, int min_disp);
 

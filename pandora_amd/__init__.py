@@ -8,3 +8,24 @@ Device side: hand-written HIP kernels for gfx950 in ``csrc/`` behind the C ABI o
 There is NO CPU fallback: every plugin raises if the HIP library or a GPU is missing.
 """
 __version__ = "0.1.0"
+
+
+def run(pandora_machine, img_left, img_right, cfg):
+    """The reference's pandora.run (__init__.py:50-124) for the hot-path steps: runs every key of
+    cfg["pipeline"] in order on the machine and returns (left disparity dataset, None)."""
+    pandora_machine.run_prepare(cfg, img_left, img_right)
+    for step in list(cfg["pipeline"]):
+        pandora_machine.run(step, cfg)
+    pandora_machine.run_exit()
+    return pandora_machine.left_disparity, pandora_machine.right_disparity
+
+
+def import_plugin():
+    """The reference's pandora.import_plugin (__init__.py:141-148): load every entry point of the
+    group "pandora.plugin" so that external plugins register themselves."""
+    from importlib.metadata import entry_points
+
+    eps = entry_points()
+    group = eps.select(group="pandora.plugin") if hasattr(eps, "select") else eps.get("pandora.plugin", [])
+    for ep in group:
+        ep.load()

@@ -38,6 +38,7 @@ SIGNATURES = {
     "pmx_sad_ssd": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "pmx_zncc": (C.c_int, [vp, vp, C.c_int]),
     "pmx_cv_masked": (C.c_int, [vp, vp, C.c_int]),
+    "pmx_nan_pixels": (C.c_int, [vp, vp, C.POINTER(C.c_uint8)]),
     "pmx_reverse_cost_volume": (vp, [vp, vp, C.c_int]),
     "pmx_cbca": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int]),
     "pmx_cross_support": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, c_i16_p]),

@@ -218,6 +218,33 @@ int pmx_launch_from_keys(pmx_ctx* ctx, const uint64_t* keys, double d0, int subp
     return PMX_OK;
 }
 
+// ---- all-NaN pixels (criteria.py:303-305) ---------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void nan_pixels_kernel(const float* __restrict__ cv, size_t npix, int D,
+                                                            uint8_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    for (size_t pix = wave; pix < npix; pix += nwaves) {
+        const float* p = cv + pix * (size_t)D;
+        int any = 0;
+        for (int k = lane; k < D; k += 64) {
+            float x = p[k];
+            any |= (x == x);
+        }
+        unsigned long long b = __ballot(any);
+        if (lane == 0) out[pix] = b ? 0 : 1;
+    }
+}
+
+int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out) {
+    size_t npix = (size_t)cv->H * cv->W;
+    size_t want = (npix + 3) / 4;
+    int grid = (int)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(nan_pixels_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix, cv->D, dev_out);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 // ---- reverse_cost_volume (matching_cost.cpp:26-56): (i,j,d) -> (i, j+d, -d) ---------------------
 __global__ __launch_bounds__(kBlock) void reverse_kernel(const float* __restrict__ in, int W, int D, int min_disp,
                                                          float* __restrict__ out) {

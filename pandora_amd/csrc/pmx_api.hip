@@ -301,6 +301,20 @@ extern "C" int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win) {
     return pmx_launch_cv_masked(ctx, cv, win);
 }
 
+extern "C" int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out) {
+    int rc = check_cv(ctx, cv, "pmx_nan_pixels");
+    if (rc) return rc;
+    PMX_CHECK(host_out, PMX_ERR_ARG, "pmx_nan_pixels: null output");
+    size_t n = (size_t)cv->H * cv->W;
+    rc = pmx_need_small(ctx, n);
+    if (rc) return rc;
+    rc = pmx_launch_nan_pixels(ctx, cv, (uint8_t*)ctx->small);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(host_out, ctx->small, n, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
 extern "C" pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, int min_disp) {
     if (check_cv(ctx, left_cv, "pmx_reverse_cost_volume")) return nullptr;
     pmx_cv* out = pmx_cv_alloc(ctx, left_cv->D, min_disp);

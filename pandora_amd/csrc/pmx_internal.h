@@ -128,6 +128,7 @@ int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_dis
 int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance);
 int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
+int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
 int pmx_launch_reverse(pmx_ctx* ctx, const pmx_cv* in, int min_disp, pmx_cv* out);
 int pmx_launch_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int index_offset, uint64_t* keys);
 int pmx_launch_from_keys(pmx_ctx* ctx, const uint64_t* keys, double d0, int subpix, float invalid_disparity);

@@ -1,0 +1,88 @@
+"""AbstractDisparity + WinnerTakesAll (reference: disparity/disparity.py:42-553)."""
+from abc import ABCMeta, abstractmethod
+
+import numpy as np
+
+from ..dataset import DataArray, Dataset
+from ..matching_cost.matching_cost import ConfigError
+
+
+class AbstractDisparity:
+    __metaclass__ = ABCMeta
+
+    disparity_methods_avail = {}
+    cfg = None
+
+    def __new__(cls, **cfg):
+        if cls is AbstractDisparity:
+            if isinstance(cfg.get("disparity_method"), str):
+                try:
+                    return super(AbstractDisparity, cls).__new__(cls.disparity_methods_avail[cfg["disparity_method"]])
+                except KeyError:
+                    raise KeyError("No disparity method named {} supported".format(cfg["disparity_method"]))
+            raise KeyError("No disparity method named {} supported".format(cfg.get("disparity_method")))
+        return super(AbstractDisparity, cls).__new__(cls)
+
+    @classmethod
+    def register_subclass(cls, short_name):
+        def decorator(subclass):
+            cls.disparity_methods_avail[short_name] = subclass
+            return subclass
+
+        return decorator
+
+    @abstractmethod
+    def desc(self):
+        """Describes the disparity method"""
+
+    @abstractmethod
+    def to_disp(self, cv, img_left=None, img_right=None):
+        """Disparity computation and validity mask; returns the disparity dataset."""
+
+
+@AbstractDisparity.register_subclass("wta")
+class WinnerTakesAll(AbstractDisparity):
+    _INVALID_DISPARITY = -9999
+
+    def __init__(self, **cfg):
+        self.cfg = self.check_conf(**cfg)
+        self._invalid_disparity = self.cfg["invalid_disparity"]
+
+    def check_conf(self, **cfg):
+        if "invalid_disparity" not in cfg:
+            cfg["invalid_disparity"] = self._INVALID_DISPARITY
+        elif cfg["invalid_disparity"] == "NaN":
+            cfg["invalid_disparity"] = np.nan
+        if cfg.get("disparity_method") != "wta":
+            raise ConfigError("disparity_method must be wta")
+        if not isinstance(cfg["invalid_disparity"], (int, float)):
+            raise ConfigError("invalid_disparity must be a number or 'NaN'")
+        return cfg
+
+    def desc(self):
+        print("Winner takes all method")
+
+    def to_disp(self, cv, img_left=None, img_right=None):
+        """disparity.py:399-480: first arg-extremum over D with NaN -> +/-inf; pixels NaN for every d
+        get invalid_disparity and PANDORA_MSK_PIXEL_INVALID."""
+        arr = cv["cost_volume"]
+        if not hasattr(arr, "device_cv"):
+            raise TypeError("to_disp needs a device-resident cost volume (pandora_amd has no CPU path)")
+        dcv = arr.device_cv
+        eng = dcv.engine
+        is_max = cv.attrs["type_measure"] == "max"
+        vm = cv["validity_mask"].data if "validity_mask" in cv.data_vars else None
+        eng.set_validity(vm)
+        eng.wta(dcv, is_max, float(self._invalid_disparity))
+        disp, validity = eng.get_disparity()
+        coords = {"row": cv.coords["row"], "col": cv.coords["col"]}
+        disp_map = Dataset({"disparity_map": (("row", "col"), disp)}, coords=coords)
+        d = np.asarray(cv.coords["disp"])
+        disp_map["disparity_interval"] = DataArray(np.array([d[0], d[-1]]), ("disparity",))  # disparity.py:301-315
+        cv["disp_indices"] = DataArray(disp.copy(), ("row", "col"))
+        disp_map.attrs = dict(cv.attrs)
+        if "confidence_measure" in cv.data_vars:
+            disp_map["confidence_measure"] = cv["confidence_measure"]
+        disp_map["validity_mask"] = DataArray(validity, ("row", "col"))
+        disp_map.attrs["_device_cv"] = dcv  # lets the refinement step stay on the device
+        return disp_map

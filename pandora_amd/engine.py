@@ -116,6 +116,11 @@ class Engine:
     def cv_masked(self, cv, win):
         check(_lib.lib().pmx_cv_masked(self.ctx, cv.handle, int(win)), "pmx_cv_masked")
 
+    def nan_pixels(self, cv):
+        out = np.empty((self.H, self.W), np.uint8)
+        check(_lib.lib().pmx_nan_pixels(self.ctx, cv.handle, _p(out, C.c_uint8)), "pmx_nan_pixels")
+        return out.astype(bool)
+
     def reverse_cost_volume(self, cv, min_disp):
         h = _lib.lib().pmx_reverse_cost_volume(self.ctx, cv.handle, int(min_disp))
         if not h:

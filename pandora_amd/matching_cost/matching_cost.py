@@ -1,0 +1,163 @@
+"""AbstractMatchingCost - the reference's matching-cost plugin base re-stated for the MI355X engine.
+
+Same registry mechanics, method names, argument meaning and error behaviour as
+/root/reference/src/pandora/matching_cost/matching_cost.py:45-950 (register_subclass :109-131,
+__new__ dispatch :80-107, check_conf :158-184, allocate_cost_volume :377-407, cv_masked :770-872),
+but the cost volume lives in HBM (dataset.DeviceVolumeArray) and every O(H*W*D) operation is a HIP
+kernel behind include/pandora_amd.h.  There is no CPU path.
+"""
+from abc import ABCMeta, abstractmethod
+
+import numpy as np
+
+from .. import criteria, runtime
+from ..dataset import DataArray, Dataset, DeviceVolumeArray
+
+
+class ConfigError(ValueError):
+    """Raised where the reference's json_checker schema would reject a configuration."""
+
+
+class AbstractMatchingCost:
+    __metaclass__ = ABCMeta
+
+    matching_cost_methods_avail = {}
+    cfg = None
+    _WINDOW_SIZE = 5
+    _SUBPIX = 1
+    _BAND = None
+    _STEP_COL = 1
+    _SPLINE_ORDER = 1
+
+    def __new__(cls, **cfg):
+        if cls is AbstractMatchingCost:
+            if isinstance(cfg.get("matching_cost_method"), str):
+                try:
+                    return super(AbstractMatchingCost, cls).__new__(cls.matching_cost_methods_avail[cfg["matching_cost_method"]])
+                except KeyError:
+                    raise KeyError("No matching cost method named {} supported".format(cfg["matching_cost_method"]))
+            raise KeyError("No matching cost method named {} supported".format(cfg.get("matching_cost_method")))
+        return super(AbstractMatchingCost, cls).__new__(cls)
+
+    @classmethod
+    def register_subclass(cls, short_name, *args):
+        def decorator(subclass):
+            cls.matching_cost_methods_avail[short_name] = subclass
+            for arg in args:
+                cls.matching_cost_methods_avail[arg] = subclass
+            return subclass
+
+        return decorator
+
+    def desc(self):
+        print(f"{self._method} similarity measure")
+
+    # -- configuration (matching_cost.py:140-184) ----------------------------------------------
+    def instantiate_class(self, **cfg):
+        self.cfg = self.check_conf(**cfg)
+        self._window_size = int(self.cfg["window_size"])
+        self._subpix = int(self.cfg["subpix"])
+        self._band = self.cfg["band"]
+        self._step_col = int(self.cfg["step"])
+        self._method = str(self.cfg["matching_cost_method"])
+        self._spline_order = int(self.cfg["spline_order"])
+        del self.cfg["spline_order"]
+
+    def check_conf(self, **cfg):
+        cfg.setdefault("window_size", self._WINDOW_SIZE)
+        cfg.setdefault("subpix", self._SUBPIX)
+        cfg.setdefault("band", self._BAND)
+        if "step" in cfg and cfg["step"] != 1:
+            raise ValueError("Step parameter cannot be different from 1")
+        cfg.setdefault("step", self._STEP_COL)
+        cfg.setdefault("spline_order", self._SPLINE_ORDER)
+        if not isinstance(cfg["subpix"], int) or cfg["subpix"] not in (1, 2, 4):
+            raise ConfigError("subpix must be 1, 2 or 4")
+        if not (cfg["band"] is None or isinstance(cfg["band"], str)):
+            raise ConfigError("band must be a string or None")
+        if not isinstance(cfg["spline_order"], int) or not 1 <= cfg["spline_order"] <= 5:
+            raise ConfigError("spline_order must be an int in [1, 5]")
+        if cfg["spline_order"] != 1 and cfg["subpix"] != 1:
+            raise ConfigError("pandora_amd resamples the right image with spline_order 1 only")
+        if cfg["band"] is not None:
+            raise ConfigError("pandora_amd handles mono-band images only (select the band before the engine)")
+        return cfg
+
+    @property
+    def margins_value(self):
+        """HalfWindowMargins (matching_cost.py:76): (left, up, right, down)"""
+        o = int((self._window_size - 1) / 2)
+        return (o, o, o, o)
+
+    # -- geometry (matching_cost.py:330-427, 604-616) ------------------------------------------
+    @staticmethod
+    def get_min_max_from_grid(disp_min, disp_max):
+        return int(np.nanmin(disp_min)), int(np.nanmax(disp_max))
+
+    @staticmethod
+    def get_disparity_range(disparity_min, disparity_max, subpix):
+        if subpix == 1:
+            return np.arange(disparity_min, disparity_max + 1)
+        rng = np.arange(disparity_min, disparity_max, 1 / float(subpix), dtype=np.float64)
+        return np.append(rng, [disparity_max])
+
+    def allocate_cost_volume(self, image, disparity_grids, cfg=None):
+        """matching_cost.py:377-407: dataset with a NaN-filled float32 (row, col, disp) volume -
+        allocated in HBM - plus the attrs later steps read."""
+        if cfg and "ROI" in cfg:
+            raise ConfigError("ROI tiling is out of scope of pandora_amd (SURVEY 8: margins/ROI are caller-side)")
+        dmin, dmax = self.get_min_max_from_grid(np.asarray(disparity_grids[0].data if hasattr(disparity_grids[0], "data") else disparity_grids[0]),
+                                                np.asarray(disparity_grids[1].data if hasattr(disparity_grids[1], "data") else disparity_grids[1]))
+        disparity_range = self.get_disparity_range(dmin, dmax, self._subpix)
+        c_col = np.asarray(image.coords["col"])
+        index_compute_col = np.arange(c_col[0], c_col[-1] + 1, self._step_col)
+        cv = Dataset(coords={"row": image.coords["row"], "col": index_compute_col, "disp": disparity_range}, attrs=dict(image.attrs))
+        cv.attrs["sampling_interval"] = self._step_col
+        cv.attrs["col_to_compute"] = index_compute_col
+        cv.attrs.update({"window_size": self._window_size, "subpixel": self._subpix, "band_correl": self._band,
+                         "offset_row_col": int((self._window_size - 1) / 2), "measure": self._method})
+        # the device volume is bound to the engine in compute_cost_volume (it needs the pair resident)
+        cv.attrs["_d0"] = dmin
+        cv.attrs["_D"] = len(disparity_range)
+        return cv
+
+    def _bind_device_volume(self, img_left, img_right, cost_volume):
+        eng = runtime.ensure_pair(img_left, img_right, self._subpix)
+        dcv = eng.alloc_cv(cost_volume.attrs["_D"], cost_volume.attrs["_d0"])
+        cost_volume.data_vars["cost_volume"] = DeviceVolumeArray(dcv, {k: cost_volume.coords[k] for k in ("row", "col", "disp")})
+        return eng, dcv
+
+    @abstractmethod
+    def compute_cost_volume(self, img_left, img_right, cost_volume):
+        """Fill cost_volume["cost_volume"] for the pair; returns the dataset."""
+
+    # -- masking (matching_cost.py:770-872) ----------------------------------------------------
+    def cv_masked(self, img_left, img_right, cost_volume, disp_min, disp_max):
+        """In place: NaN for invalid / (dilated) no-data pixels and for disparities outside the
+        per-pixel [disp_min, disp_max]; then the validity-mask updates of criteria.py:291-353."""
+        eng = runtime.ensure_pair(img_left, img_right, self._subpix)
+        dcv = cost_volume["cost_volume"].device_cv
+        for side in (img_left, img_right):
+            if "msk" in side.data_vars and (side.attrs.get("valid_pixels", 0) != img_left.attrs.get("valid_pixels", 0)
+                                            or side.attrs.get("no_data_mask", 1) != img_left.attrs.get("no_data_mask", 1)):
+                raise ConfigError("left and right images must share one mask convention (valid_pixels / no_data_mask)")
+        disp_min = np.asarray(disp_min.data if hasattr(disp_min, "data") and not isinstance(disp_min, np.ndarray) else disp_min)
+        disp_max = np.asarray(disp_max.data if hasattr(disp_max, "data") and not isinstance(disp_max, np.ndarray) else disp_max)
+        ny_, nx_, _ = dcv.shape
+        disp_min, disp_max = disp_min[:ny_, :nx_], disp_max[:ny_, :nx_]
+        coords = np.asarray(cost_volume.coords["disp"])
+        uniform = (np.nanmin(disp_min) == np.nanmax(disp_min) and np.nanmin(disp_max) == np.nanmax(disp_max)
+                   and disp_min.flat[0] <= coords[0] and disp_max.flat[0] >= coords[-1] and not np.isnan(disp_min).any())
+        eng.set_disparity_grids(None, None) if uniform else eng.set_disparity_grids(disp_min, disp_max)
+        eng.cv_masked(dcv, self._window_size)
+        if "validity_mask" in cost_volume.data_vars:
+            criteria.mask_invalid_variable_disparity_range(cost_volume)
+            if cost_volume.attrs["offset_row_col"] > 0:
+                criteria.mask_border(cost_volume)
+
+    @staticmethod
+    def reverse_cost_volume(left_cv, disp_min):
+        """matching_cost.py:920-934 -> matching_cost_cpp.reverse_cost_volume; left_cv is a
+        DeviceVolumeArray, the result too."""
+        dcv = left_cv.device_cv
+        return DeviceVolumeArray(dcv.engine.reverse_cost_volume(dcv, int(disp_min)), dict(left_cv.coords))

@@ -1,0 +1,82 @@
+"""AbstractRefinement + vfit / quadratic (reference: refinement/refinement.py:38-260, vfit.py,
+quadratic.py and refinement/cpp/src/*.cpp)."""
+from abc import ABCMeta
+
+import numpy as np
+
+from ..dataset import DataArray
+from ..matching_cost.matching_cost import ConfigError
+
+
+class AbstractRefinement:
+    __metaclass__ = ABCMeta
+
+    subpixel_methods_avail = {}
+    cfg = None
+    _refinement_method_name = None
+
+    def __new__(cls, **cfg):
+        if cls is AbstractRefinement:
+            if isinstance(cfg.get("refinement_method"), str):
+                try:
+                    return super(AbstractRefinement, cls).__new__(cls.subpixel_methods_avail[cfg["refinement_method"]])
+                except KeyError:
+                    raise KeyError("No refinement method named {} supported".format(cfg["refinement_method"]))
+            raise KeyError("No refinement method named {} supported".format(cfg.get("refinement_method")))
+        return super(AbstractRefinement, cls).__new__(cls)
+
+    @classmethod
+    def register_subclass(cls, short_name):
+        def decorator(subclass):
+            cls.subpixel_methods_avail[short_name] = subclass
+            return subclass
+
+        return decorator
+
+    def desc(self):
+        print(f"{self._refinement_method_name} refinement method")
+
+    def subpixel_refinement(self, cv, disp):
+        """refinement.py:77-122: in place on disp["disparity_map"], disp["validity_mask"]; adds
+        disp["interpolated_coeff"]."""
+        arr = cv["cost_volume"]
+        if not hasattr(arr, "device_cv"):
+            raise TypeError("subpixel_refinement needs a device-resident cost volume (pandora_amd has no CPU path)")
+        dcv = arr.device_cv
+        eng = dcv.engine
+        is_max = cv.attrs["type_measure"] == "max"
+        # the host copies may have been edited since WTA (filters): they are the source of truth
+        eng.set_disparity(np.asarray(disp["disparity_map"].data, np.float32), np.asarray(disp["validity_mask"].data, np.int64))
+        eng.refine(dcv, self._refinement_method_name, is_max)
+        d, v, itp = eng.get_disparity(want_itp=True)
+        disp["disparity_map"].data = d
+        disp["validity_mask"].data = v
+        disp.attrs["refinement"] = self._refinement_method_name
+        disp["interpolated_coeff"] = DataArray(itp, ("row", "col"))
+
+
+def _simple_conf(name):
+    def check_conf(**cfg):
+        if cfg.get("refinement_method") != name:
+            raise ConfigError(f"refinement_method must be {name}")
+        return cfg
+
+    return staticmethod(check_conf)
+
+
+@AbstractRefinement.register_subclass("vfit")
+class Vfit(AbstractRefinement):
+    check_conf = _simple_conf("vfit")
+
+    def __init__(self, **cfg):
+        self.cfg = self.check_conf(**cfg)
+        self._refinement_method_name = str(self.cfg["refinement_method"])
+
+
+@AbstractRefinement.register_subclass("quadratic")
+class Quadratic(AbstractRefinement):
+    check_conf = _simple_conf("quadratic")
+
+    def __init__(self, **cfg):
+        self.cfg = self.check_conf(**cfg)
+        self._refinement_method_name = str(self.cfg["refinement_method"])

@@ -1,0 +1,58 @@
+"""Process-wide engine cache: one pandora_amd.engine.Engine per GPU, plus the bookkeeping of which
+stereo pair is resident so that successive plugin calls (compute_cost_volume, cv_masked,
+cost_volume_aggregation, ...) do not re-upload the images."""
+import os
+
+import numpy as np
+
+from .engine import Engine
+
+_ENGINES = {}
+_RESIDENT = {}
+
+
+def default_device():
+    return int(os.environ.get("PANDORA_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def get_engine(device=None):
+    device = default_device() if device is None else int(device)
+    if device not in _ENGINES:
+        _ENGINES[device] = Engine(device)
+    return _ENGINES[device]
+
+
+def _key(img_left, img_right, subpix):
+    def ident(ds):
+        im = ds["im"].data
+        msk = ds["msk"].data if "msk" in ds.data_vars else None
+        return (id(im), im.shape, None if msk is None else id(msk))
+
+    return (ident(img_left), ident(img_right), int(subpix), img_left.attrs.get("valid_pixels", 0),
+            img_left.attrs.get("no_data_mask", 1))
+
+
+def ensure_pair(img_left, img_right, subpix, device=None):
+    """Make (img_left, img_right) the resident pair of the engine (uploads images and masks once)."""
+    eng = get_engine(device)
+    key = _key(img_left, img_right, subpix)
+    if _RESIDENT.get(eng.device) != key:
+        eng.set_images(np.asarray(img_left["im"].data, np.float32), np.asarray(img_right["im"].data, np.float32), subpix)
+        ml = img_left["msk"].data if "msk" in img_left.data_vars else None
+        mr = img_right["msk"].data if "msk" in img_right.data_vars else None
+        # the reference keeps one mask convention per image; they are the same in practice
+        eng.set_masks(ml, mr, img_left.attrs.get("valid_pixels", 0), img_left.attrs.get("no_data_mask", 1))
+        eng.set_disparity_grids(None, None)
+        _RESIDENT[eng.device] = key
+    return eng
+
+
+def invalidate(device=None):
+    _RESIDENT.pop(default_device() if device is None else int(device), None)
+
+
+def shutdown():
+    for e in _ENGINES.values():
+        e.close()
+    _ENGINES.clear()
+    _RESIDENT.clear()

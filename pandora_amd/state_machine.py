@@ -1,0 +1,181 @@
+"""PandoraMachine - the reference's step sequencer (state_machine.py:70-1072) for the hot path.
+
+A dependency-free finite state machine (the reference builds on the `transitions` package, absent
+here): three states ``begin -> cost_volume -> disp_map``; triggers are the pipeline keys' prefixes
+(``"filter.after"`` -> ``filter``, state_machine.py:706-717).  Hot-path triggers are implemented
+(matching_cost, aggregation, optimization, disparity, refinement); the others of the reference
+(filter, validation, multiscale, cost_volume_confidence, semantic_segmentation) are outside this
+build's scope and raise ``MachineError`` naming the missing step.
+"""
+import logging
+
+import numpy as np
+
+from . import aggregation, disparity, matching_cost, optimization, refinement
+from .criteria import validity_mask
+
+
+class MachineError(Exception):
+    """An illegal transition (same role as transitions.MachineError)."""
+
+
+class PandoraMachine:
+    _transitions_run = {
+        # trigger: (source, dest, prepare, before)
+        "matching_cost": ("begin", "cost_volume", "matching_cost_prepare", "matching_cost_run"),
+        "aggregation": ("cost_volume", "cost_volume", None, "aggregation_run"),
+        "optimization": ("cost_volume", "cost_volume", None, "optimization_run"),
+        "disparity": ("cost_volume", "disp_map", None, "disparity_run"),
+        "refinement": ("disp_map", "disp_map", None, "refinement_run"),
+    }
+    _transitions_check = {
+        "check_matching_cost": ("begin", "cost_volume", "matching_cost_check_conf"),
+        "check_aggregation": ("cost_volume", "cost_volume", "aggregation_check_conf"),
+        "check_optimization": ("cost_volume", "cost_volume", "optimization_check_conf"),
+        "check_disparity": ("cost_volume", "disp_map", "disparity_check_conf"),
+        "check_refinement": ("disp_map", "disp_map", "refinement_check_conf"),
+    }
+    _out_of_scope = ("filter", "validation", "multiscale", "cost_volume_confidence", "semantic_segmentation")
+
+    def __init__(self):
+        self.left_img = None
+        self.right_img = None
+        self.disp_min = None
+        self.disp_max = None
+        self.scale_factor = 1
+        self.num_scales = 1
+        self.current_scale = 0
+        self.left_cv = None
+        self.right_cv = None
+        self.left_disparity = None
+        self.right_disparity = None
+        self.step = 1
+        self.pipeline_cfg = {"pipeline": {}}
+        self.right_disp_map = None
+        self.matching_cost_ = None
+        self.state = "begin"
+        self._mode = None  # "run" | "check"
+
+    # -- FSM core ------------------------------------------------------------------------------
+    def trigger(self, name, cfg, input_step):
+        table = self._transitions_run if self._mode == "run" else self._transitions_check
+        if name not in table:
+            base = name[len("check_"):] if name.startswith("check_") else name
+            if base in self._out_of_scope:
+                raise MachineError(f"step '{base}' is outside the hot path implemented by pandora_amd (SURVEY 8)")
+            raise MachineError(f"Can't trigger event {name}: unknown step")
+        t = table[name]
+        if self.state != t[0]:
+            raise MachineError(f"Can't trigger event {name} from state {self.state}!")
+        if self._mode == "run":
+            if t[2]:
+                getattr(self, t[2])(cfg, input_step)
+            getattr(self, t[3])(cfg, input_step)
+        else:
+            getattr(self, t[2])(cfg, input_step)
+        self.state = t[1]
+
+    def run_prepare(self, cfg, left_img, right_img, scale_factor=None, num_scales=None):
+        """state_machine.py:589-692 (mono-scale branch)."""
+        if num_scales not in (None, 1):
+            raise MachineError("multiscale processing is outside the hot path implemented by pandora_amd (SURVEY 8, N3)")
+        self.num_scales, self.scale_factor, self.current_scale = 1, 1, 0
+        self.left_img, self.right_img = left_img, right_img
+        self.disp_min = np.asarray(left_img["disparity"].sel(band_disp="min").data)
+        self.disp_max = np.asarray(left_img["disparity"].sel(band_disp="max").data)
+        self.left_disparity = None
+        self.right_disparity = None
+        if "validation" in cfg["pipeline"]:
+            raise MachineError("step 'validation' is outside the hot path implemented by pandora_amd (SURVEY 8)")
+        self.state = "begin"
+        self._mode = "run"
+
+    def run(self, input_step, cfg):
+        """state_machine.py:694-720"""
+        try:
+            trig = input_step.split(".")[0] if len(input_step.split(".")) != 1 else input_step
+            self.trigger(trig, cfg, input_step)
+        except (MachineError, KeyError, AttributeError):
+            logging.error("A problem occurs during Pandora running %s. Be sure of your sequencing", input_step)
+            raise
+
+    def run_exit(self):
+        """state_machine.py:722-730"""
+        self.state = "begin"
+        self._mode = None
+
+    # -- run callbacks (state_machine.py:292-490) ----------------------------------------------
+    def matching_cost_prepare(self, cfg, input_step):
+        self.matching_cost_ = matching_cost.AbstractMatchingCost(**cfg["pipeline"][input_step])
+        self.disp_min = self.disp_min * self.scale_factor
+        self.disp_max = self.disp_max * self.scale_factor
+        self.left_cv = self.matching_cost_.allocate_cost_volume(self.left_img, (self.disp_min, self.disp_max), cfg)
+        self.left_cv = validity_mask(self.left_img, self.right_img, self.left_cv)
+
+    def matching_cost_run(self, _, __):
+        logging.info("Matching cost computation...")
+        self.left_cv = self.matching_cost_.compute_cost_volume(self.left_img, self.right_img, self.left_cv)
+        self.matching_cost_.cv_masked(self.left_img, self.right_img, self.left_cv, self.disp_min, self.disp_max)
+
+    def aggregation_run(self, cfg, input_step):
+        logging.info("Aggregation computation...")
+        aggregation_ = aggregation.AbstractAggregation(**cfg["pipeline"][input_step])
+        aggregation_.cost_volume_aggregation(self.left_img, self.right_img, self.left_cv)
+
+    def optimization_run(self, cfg, input_step):
+        logging.info("Cost optimization...")
+        optimization_ = optimization.AbstractOptimization(self.left_img, **cfg["pipeline"][input_step])
+        self.left_cv = optimization_.optimize_cv(self.left_cv, self.left_img, self.right_img)
+
+    def disparity_run(self, cfg, input_step):
+        logging.info("Disparity computation...")
+        disparity_ = disparity.AbstractDisparity(**cfg["pipeline"][input_step])
+        self.left_disparity = disparity_.to_disp(self.left_cv, self.left_img, self.right_img)
+
+    def refinement_run(self, cfg, input_step):
+        logging.info("Subpixel refinement...")
+        refinement_ = refinement.AbstractRefinement(**cfg["pipeline"][input_step])
+        refinement_.subpixel_refinement(self.left_cv, self.left_disparity)
+
+    # -- configuration pass (state_machine.py:732-1008) ----------------------------------------
+    def matching_cost_check_conf(self, cfg, input_step):
+        m = matching_cost.AbstractMatchingCost(**cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = m.cfg
+        self.step = m._step_col
+
+    def aggregation_check_conf(self, cfg, input_step):
+        a = aggregation.AbstractAggregation(**cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = a.cfg
+
+    def optimization_check_conf(self, cfg, input_step):
+        if self.step != 1:  # state_machine.py:868-870
+            raise AttributeError("For performing the SGM optimization step, step attribute must be equal to 1")
+        o = optimization.AbstractOptimization(self.left_img, **cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = o.cfg
+
+    def disparity_check_conf(self, cfg, input_step):
+        d = disparity.AbstractDisparity(**cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = d.cfg
+
+    def refinement_check_conf(self, cfg, input_step):
+        r = refinement.AbstractRefinement(**cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = r.cfg
+
+    def check_conf(self, cfg, img_left=None, img_right=None, right_left_img_check=False):
+        """state_machine.py:950-1008: dry-run the FSM with the check_* triggers; returns the checked
+        pipeline configuration (defaults filled in)."""
+        self.left_img, self.right_img = img_left, img_right
+        self.state = "begin"
+        self._mode = "check"
+        self.pipeline_cfg = {"pipeline": {}}
+        for input_step in list(cfg["pipeline"]):
+            trig = "check_" + input_step.split(".")[0]
+            try:
+                self.trigger(trig, cfg["pipeline"], input_step)
+            except (MachineError, KeyError, AttributeError):
+                logging.error("Problem during Pandora checking configuration steps sequencing. "
+                              "Check your configuration file.")
+                raise
+        self.state = "begin"
+        self._mode = None
+        return self.pipeline_cfg

@@ -1,0 +1,173 @@
+"""GPU: whole pipelines driven through the reference-shaped plugin API (PandoraMachine ->
+AbstractMatchingCost / Aggregation / Optimization / Disparity / Refinement -> C ABI -> HIP) against
+the same pipeline composed from the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pandora_amd
+from pandora_amd import criteria, matching_cost
+from pandora_amd.dataset import make_image
+from pandora_amd.state_machine import PandoraMachine
+from tests.test_gpu_parity import pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_pipeline(oracle, L, R, cfg, dmin, dmax, mskL=None, mskR=None, validity0=None):
+    p = cfg["pipeline"]
+    mc = p["matching_cost"]
+    win, sp = mc.get("window_size", 5), mc.get("subpix", 1)
+    D = (dmax - dmin) * sp + 1
+    method = mc["matching_cost_method"]
+    if method == "census":
+        cv, is_max, cmax = oracle.census_cost(L, R, D, dmin, sp, win), False, win * win
+    elif method in ("sad", "ssd"):
+        cv, is_max = oracle.sad_ssd(L, R, D, dmin, sp, win, method == "ssd"), False
+        a, b = abs(L.max() - R.min()), abs(R.max() - L.min())
+        cmax = int(max(a, b) * win * win) if method == "sad" else int(max(a ** 2, b ** 2) * win * win)
+    else:
+        cv, is_max, cmax = oracle.zncc(L, R, D, dmin, sp, win), True, 1
+    if mskL is not None or mskR is not None:
+        oracle.cv_masked(cv, dmin, sp, win, mskL=mskL, mskR=mskR)
+    off = win // 2
+    if "aggregation" in p:
+        dist, inten = p["aggregation"].get("cbca_distance", 5), p["aggregation"].get("cbca_intensity", 30.0)
+
+        def arms(im, msk, shifted):
+            m = im.copy()
+            if msk is not None:
+                bad = msk != 0
+                if shifted:
+                    bad = bad[:, :-1] | bad[:, 1:]
+                m[bad] = np.nan
+            m = np.nan_to_num(oracle.median3(m), nan=np.inf)
+            if off:
+                m = m[off:-off, off:-off]
+            return oracle.cross_support(np.ascontiguousarray(m), dist, inten)
+
+        cl = arms(L, mskL, False)
+        crs = [arms(im, mskR, k > 0) for k, im in enumerate(oracle.shift_right(R, sp))]
+        oracle.cbca(cv, dmin, sp, off, cl, crs)
+        cmax = cmax * (2 * dist - 1) ** 2
+    if "optimization" in p:
+        pen = p["optimization"].get("penalty", {})
+        cv = oracle.sgm(cv, pen.get("P1", 8), pen.get("P2", 32), is_max, float(cmax) + 1.0, p["optimization"].get("overcounting", False))
+    inv = p["disparity"].get("invalid_disparity", -9999)
+    inv = np.nan if inv == "NaN" else inv
+    disp, val = oracle.wta(cv, dmin, sp, is_max, inv, validity0)
+    itp = None
+    if "refinement" in p:
+        itp, disp, val = oracle.refine(cv, disp, val, dmin, dmax, sp, is_max, p["refinement"]["refinement_method"])
+    return cv, disp, val, itp
+
+
+def run_machine(L, R, cfg, dmin, dmax, mskL=None, mskR=None):
+    left = make_image(L, disparity=[dmin, dmax], msk=mskL)
+    right = make_image(R, msk=mskR)
+    machine = PandoraMachine()
+    cfg = json.loads(json.dumps(cfg))
+    cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+    left_disp, _ = pandora_amd.run(machine, left, right, cfg)
+    return machine, left_disp
+
+
+def expected_validity(L, R, cfg, dmin, dmax, mskL, mskR, nan_pixels):
+    left = make_image(L, disparity=[dmin, dmax], msk=mskL)
+    right = make_image(R, msk=mskR)
+    m = matching_cost.AbstractMatchingCost(**cfg["pipeline"]["matching_cost"])
+    cv = m.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max")))
+    cv = criteria.validity_mask(left, right, cv)
+    criteria.mask_invalid_variable_disparity_range(cv, nan_pixels)
+    if cv.attrs["offset_row_col"] > 0:
+        criteria.mask_border(cv)
+    return cv["validity_mask"].data
+
+
+CASES = [
+    ("census5+sgm+wta+vfit", {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                                          "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                                          "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                                          "refinement": {"refinement_method": "vfit"}}}, (48, 80, -12, 3), True, True),
+    ("zncc5+cbca+wta+quadratic", {"pipeline": {"matching_cost": {"matching_cost_method": "zncc", "window_size": 5},
+                                              "aggregation": {"aggregation_method": "cbca", "cbca_intensity": 30.0, "cbca_distance": 5},
+                                              "disparity": {"disparity_method": "wta", "invalid_disparity": -9999},
+                                              "refinement": {"refinement_method": "quadratic"}}}, (40, 70, -8, 2), False, False),
+    ("sad3/subpix2+wta+vfit", {"pipeline": {"matching_cost": {"matching_cost_method": "sad", "window_size": 3, "subpix": 2},
+                                           "disparity": {"disparity_method": "wta", "invalid_disparity": -9999},
+                                           "refinement": {"refinement_method": "vfit"}}}, (30, 55, -4, 4), True, True),
+    ("census5+cbca+sgm+wta+vfit (BASELINE configs[1])",
+     {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                   "aggregation": {"aggregation_method": "cbca"},
+                   "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                   "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                   "refinement": {"refinement_method": "vfit"}}}, (36, 64, -10, 0), True, False),
+]
+
+
+@pytest.mark.parametrize("name,cfg,shape,integer,with_masks", CASES, ids=[c[0] for c in CASES])
+def test_machine_matches_oracle_pipeline(oracle, name, cfg, shape, integer, with_masks):
+    H, W, dmin, dmax = shape
+    L, R = pair(H, W, seed=H + W, integer=integer)
+    mskL = mskR = None
+    if with_masks:
+        rng = np.random.default_rng(3)
+        mskL = rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 2], (H, W)).astype(np.int16)
+        mskR = rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 2], (H, W)).astype(np.int16)
+    machine, left_disp = run_machine(L, R, cfg, dmin, dmax, mskL, mskR)
+    got_cv = machine.left_cv["cost_volume"].data
+    # expected: oracle matching cost -> NaN pixels -> host validity -> oracle rest
+    mc_only = {"pipeline": {"matching_cost": cfg["pipeline"]["matching_cost"], "disparity": {"disparity_method": "wta"}}}
+    cv0, _, _, _ = oracle_pipeline(oracle, L, R, mc_only, dmin, dmax, mskL, mskR)
+    val0 = expected_validity(L, R, cfg, dmin, dmax, mskL, mskR, np.min(np.isnan(cv0), axis=2))
+    ecv, edisp, eval_, eitp = oracle_pipeline(oracle, L, R, cfg, dmin, dmax, mskL, mskR, val0)
+    np.testing.assert_array_equal(np.isnan(got_cv), np.isnan(ecv))
+    if cfg["pipeline"]["matching_cost"]["matching_cost_method"] == "zncc":
+        np.testing.assert_allclose(got_cv, ecv, rtol=0, atol=1e-5)  # float64 window sums: within 1e-5
+        # WTA / refinement re-checked on the GPU volume itself (ties can flip on 1e-7 differences)
+        edisp, eval_ = oracle.wta(got_cv, dmin, 1, True, -9999, val0)
+        eitp, edisp, eval_ = oracle.refine(got_cv, edisp, eval_, dmin, dmax, 1, True, "quadratic")
+    else:
+        np.testing.assert_array_equal(got_cv, ecv)
+    np.testing.assert_array_equal(left_disp["disparity_map"].data, edisp)
+    np.testing.assert_array_equal(left_disp["validity_mask"].data, eval_)
+    np.testing.assert_array_equal(left_disp["interpolated_coeff"].data, eitp)
+    assert left_disp.attrs["refinement"] == cfg["pipeline"]["refinement"]["refinement_method"]
+    assert machine.left_cv.attrs["type_measure"] in ("min", "max")
+
+
+with open(os.path.join(ROOT, "tests", "golden", "validity_mask_cases.json")) as f:
+    VM_CASES = json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", VM_CASES, ids=lambda c: c["id"])
+def test_validity_mask_goldens_through_the_gpu_path(case):
+    """tests/test_criteria.py::test_validity_mask of the reference, with the product's own
+    compute_cost_volume + cv_masked (HIP) instead of the oracle."""
+    L, R = np.array(case["left_data"], np.float32), np.array(case["right_data"], np.float32)
+    left = make_image(L, disparity=case["disparity"], msk=np.array(case["left_msk"]), valid_pixels=case["left_valid"],
+                      no_data_mask=case["left_nodata"])
+    right = make_image(R, msk=np.array(case["right_msk"]), valid_pixels=case["right_valid"], no_data_mask=case["right_nodata"])
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="sad", window_size=case["window_size"], subpix=1)
+    dmin, dmax = left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max")
+    cv = m.allocate_cost_volume(left, (dmin, dmax))
+    cv = criteria.validity_mask(left, right, cv)
+    cv = m.compute_cost_volume(left, right, cv)
+    m.cv_masked(left, right, cv, dmin, dmax)
+    np.testing.assert_array_equal(cv["validity_mask"].data, np.array(case["gt_mask"]))
+
+
+def test_cost_volume_is_lazy_and_writable():
+    L, R = pair(20, 30, seed=1)
+    left, right = make_image(L, disparity=[-3, 3]), make_image(R)
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="census", window_size=3)
+    cv = m.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max")))
+    cv = m.compute_cost_volume(left, right, cv)
+    host = cv["cost_volume"].data
+    assert host.shape == (20, 30, 7) and host.dtype == np.float32
+    host2 = np.where(np.isnan(host), np.nan, host + 1).astype(np.float32)
+    cv["cost_volume"].data = host2  # the reference mutates cv["cost_volume"].data between steps
+    np.testing.assert_array_equal(cv["cost_volume"].data, host2)

@@ -1,0 +1,202 @@
+"""CPU tests of the host layer: plugin registries / error behaviour (mirrors the reference's own
+API tests), the state machine's sequencing rules, the validity-mask criteria against the reference's
+golden masks, the C ABI's exported surface, and the 'no oracle / no CPU fallback in the product'
+rules.  No GPU needed."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pandora_amd
+from pandora_amd import _lib, aggregation, criteria, disparity, matching_cost, optimization, refinement
+from pandora_amd.dataset import DataArray, Dataset, make_image
+from pandora_amd.matching_cost import ConfigError
+from pandora_amd.state_machine import MachineError, PandoraMachine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- registries (reference: tests/test_plugins.py, test_matching_cost*.py window-size tests) --------------
+def test_registries_hold_the_reference_short_names():
+    assert set(matching_cost.AbstractMatchingCost.matching_cost_methods_avail) >= {"census", "sad", "ssd", "zncc"}
+    assert "cbca" in aggregation.AbstractAggregation.aggreg_methods_avail
+    assert "sgm" in optimization.AbstractOptimization.optimization_methods_avail
+    assert "wta" in disparity.AbstractDisparity.disparity_methods_avail
+    assert set(refinement.AbstractRefinement.subpixel_methods_avail) >= {"vfit", "quadratic"}
+
+
+@pytest.mark.parametrize("factory,key,msg", [
+    (lambda **c: matching_cost.AbstractMatchingCost(**c), "matching_cost_method", "No matching cost method named {} supported"),
+    (lambda **c: aggregation.AbstractAggregation(**c), "aggregation_method", "No aggregation method named {} supported"),
+    (lambda **c: optimization.AbstractOptimization(None, **c), "optimization_method", "No optimization method named {} supported"),
+    (lambda **c: disparity.AbstractDisparity(**c), "disparity_method", "No disparity method named {} supported"),
+    (lambda **c: refinement.AbstractRefinement(**c), "refinement_method", "No refinement method named {} supported"),
+])
+def test_unknown_method_raises_keyerror_like_the_reference(factory, key, msg):
+    with pytest.raises(KeyError) as err:
+        factory(**{key: "does_not_exist"})
+    assert msg.format("does_not_exist") in str(err.value)
+
+
+def test_register_subclass_adds_a_plugin():
+    @matching_cost.AbstractMatchingCost.register_subclass("my_cost", "my_alias")
+    class Mine(matching_cost.AbstractMatchingCost):
+        def __init__(self, **cfg):
+            self.cfg = cfg
+
+        def compute_cost_volume(self, img_left, img_right, cost_volume):
+            return cost_volume
+
+    assert isinstance(matching_cost.AbstractMatchingCost(matching_cost_method="my_alias"), Mine)
+    del matching_cost.AbstractMatchingCost.matching_cost_methods_avail["my_cost"]
+    del matching_cost.AbstractMatchingCost.matching_cost_methods_avail["my_alias"]
+
+
+@pytest.mark.parametrize("window_size", [3, 5, 7, 9, 11, 13])
+def test_census_nominal_window_size(window_size):  # test_matching_cost_census.py:41-45
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="census", window_size=window_size)
+    assert m.cfg["window_size"] == window_size
+
+
+@pytest.mark.parametrize("window_size", [-5, -1, 0, 1, 2, 4, 6, 8, 14, 15])
+def test_census_rejects_invalid_window_size(window_size):  # test_matching_cost_census.py:47-51
+    with pytest.raises(ConfigError) as err:
+        matching_cost.AbstractMatchingCost(matching_cost_method="census", window_size=window_size)
+    assert "window_size" in str(err.value)
+
+
+def test_defaults_and_checks():
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="zncc")
+    assert m.cfg == {"matching_cost_method": "zncc", "window_size": 5, "subpix": 1, "band": None, "step": 1}
+    with pytest.raises(ValueError):
+        matching_cost.AbstractMatchingCost(matching_cost_method="sad", step=2)  # matching_cost.py:176-178
+    with pytest.raises(ConfigError):
+        matching_cost.AbstractMatchingCost(matching_cost_method="sad", subpix=3)
+    a = aggregation.AbstractAggregation(aggregation_method="cbca")
+    assert a.cfg["cbca_intensity"] == 30.0 and a.cfg["cbca_distance"] == 5  # cbca.py:46-47
+    with pytest.raises(ConfigError):
+        aggregation.AbstractAggregation(aggregation_method="cbca", cbca_intensity=-1.0)
+    d = disparity.AbstractDisparity(disparity_method="wta")
+    assert d.cfg["invalid_disparity"] == -9999  # disparity.py:356
+    assert np.isnan(disparity.AbstractDisparity(disparity_method="wta", invalid_disparity="NaN").cfg["invalid_disparity"])
+    o = optimization.AbstractOptimization(None, optimization_method="sgm")
+    assert o.cfg["penalty"]["P1"] == 8 and o.cfg["penalty"]["P2"] == 32 and o.cfg["overcounting"] is False
+    assert optimization.AbstractOptimization.margins_value == (40, 40, 40, 40)  # optimization.py:43
+    with pytest.raises(ConfigError):
+        optimization.AbstractOptimization(None, optimization_method="sgm", penalty={"P1": 8, "P2": 4})
+
+
+def test_disparity_range_like_the_reference():  # matching_cost.py:409-427
+    f = matching_cost.AbstractMatchingCost.get_disparity_range
+    np.testing.assert_array_equal(f(-2, 2, 1), [-2, -1, 0, 1, 2])
+    np.testing.assert_array_equal(f(-2, 2, 2), [-2, -1.5, -1, -0.5, 0, 0.5, 1, 1.5, 2])
+    np.testing.assert_array_equal(f(0, 1, 4), [0, 0.25, 0.5, 0.75, 1])
+
+
+# ---- state machine -----------------------------------------------------------------------------------------
+PIPE = {"pipeline": {"matching_cost": {"matching_cost_method": "census"}, "optimization": {"optimization_method": "sgm"},
+                     "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                     "refinement": {"refinement_method": "vfit"}}}
+
+
+def test_check_conf_fills_defaults_in_pipeline_order():
+    cfg = PandoraMachine().check_conf(json.loads(json.dumps(PIPE)))
+    assert list(cfg["pipeline"]) == ["matching_cost", "optimization", "disparity", "refinement"]
+    assert cfg["pipeline"]["matching_cost"]["window_size"] == 5
+
+
+def test_bad_sequencing_is_rejected():
+    m = PandoraMachine()
+    with pytest.raises(MachineError):  # disparity before any cost volume
+        m.check_conf({"pipeline": {"disparity": {"disparity_method": "wta"}}})
+    with pytest.raises(MachineError):  # aggregation after the disparity map exists
+        m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
+                                   "aggregation": {"aggregation_method": "cbca"}}})
+    with pytest.raises(MachineError) as err:  # out-of-scope step is named
+        m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
+                                   "filter": {"filter_method": "median"}}})
+    assert "filter" in str(err.value)
+
+
+def test_repeated_steps_use_the_key_prefix():  # state_machine.py:706-717 ("refinement.again" -> refinement)
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
+                        "refinement": {"refinement_method": "vfit"}, "refinement.again": {"refinement_method": "quadratic"}}}
+    out = PandoraMachine().check_conf(cfg)
+    assert out["pipeline"]["refinement.again"]["refinement_method"] == "quadratic"
+
+
+# ---- criteria: validity mask golden masks of the reference --------------------------------------------------
+with open(os.path.join(ROOT, "tests", "golden", "validity_mask_cases.json")) as f:
+    VM_CASES = json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", VM_CASES, ids=lambda c: c["id"])
+def test_validity_mask_reference_goldens(oracle, case):
+    """tests/test_criteria.py::test_validity_mask: validity_mask + compute_cost_volume + cv_masked.
+    The all-NaN-pixel reduction (GPU in the product) is supplied by the oracle here."""
+    L = np.array(case["left_data"], np.float32)
+    R = np.array(case["right_data"], np.float32)
+    left = make_image(L, disparity=case["disparity"], msk=np.array(case["left_msk"]), valid_pixels=case["left_valid"],
+                      no_data_mask=case["left_nodata"])
+    right = make_image(R, msk=np.array(case["right_msk"]), valid_pixels=case["right_valid"], no_data_mask=case["right_nodata"])
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="sad", window_size=case["window_size"], subpix=1)
+    cv = m.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max")))
+    cv = criteria.validity_mask(left, right, cv)
+    dmin, dmax = case["disparity"]
+    vol = oracle.sad_ssd(L, R, dmax - dmin + 1, dmin, 1, case["window_size"], False)
+    assert case["left_valid"] == case["right_valid"] and case["left_nodata"] == case["right_nodata"]
+    oracle.cv_masked(vol, dmin, 1, case["window_size"], mskL=np.array(case["left_msk"]), mskR=np.array(case["right_msk"]),
+                     valid=case["left_valid"], nodata=case["left_nodata"])
+    criteria.mask_invalid_variable_disparity_range(cv, np.min(np.isnan(vol), axis=2))
+    if cv.attrs["offset_row_col"] > 0:
+        criteria.mask_border(cv)
+    np.testing.assert_array_equal(cv["validity_mask"].data, np.array(case["gt_mask"]))
+
+
+# ---- the C ABI surface ------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _lib.header_symbols()
+    assert len(declared) >= 30
+    for sym in declared:
+        assert hasattr(handle, sym), f"{sym} declared in include/pandora_amd.h but not exported"
+    assert set(declared) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+
+
+def test_header_cites_the_reference_interface():
+    text = open(_lib.HEADER_PATH).read()
+    for needle in ("census.cpp:97-180", "aggregation.cpp:224-321", "refinement.cpp:28-99", "disparity.py:399-516",
+                   "optimization.py:104-123", "matching_cost.py:770-872"):
+        assert needle in text
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if _lib.lib().pmx_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from pandora_amd.engine import Engine
+
+    with pytest.raises(RuntimeError) as err:
+        Engine(0)
+    assert "no CPU fallback" in str(err.value)
+    left = make_image(np.zeros((8, 8)), disparity=[-1, 1])
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="census", window_size=3)
+    cv = m.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max")))
+    with pytest.raises(RuntimeError):
+        m.compute_cost_volume(left, left, cv)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "pandora_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                if re.search(r'(import\s+oracle|from\s+oracle\b|liboracle|include\s*[<"][^\n]*oracle)', text):
+                    bad.append(os.path.join(dirpath, fn))
+    assert not bad, f"product files reference the oracle: {bad}"
+    assert "pandora_amd" in pandora_amd.__name__

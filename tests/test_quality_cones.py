@@ -1,0 +1,60 @@
+"""The reference's only SGM acceptance criterion: on the cones pair, Census 5x5 + SGM(P1=8,P2=32) must
+leave <= 20 % of pixels more than 1 px away from the ground truth
+(tests/functional_tests/test_basic.py:120-156, error() of tests/test_pandora.py:45-69).
+Images and ground truth are the reference's own test data (tests/golden/cones/)."""
+import os
+
+import numpy as np
+import pytest
+
+CONES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cones")
+
+
+def load_cones():
+    from PIL import Image
+
+    L = np.array(Image.open(os.path.join(CONES, "left.png"))).astype(np.float32)
+    R = np.array(Image.open(os.path.join(CONES, "right.png"))).astype(np.float32)
+    gt = np.array(Image.open(os.path.join(CONES, "disp_left.tif"))).astype(np.float32)
+    return L, R, gt
+
+
+def error(data, ground_truth, threshold, unknown_disparity=0):
+    """tests/test_pandora.py:45-69 (Pandora disparities are the negative of the Middlebury ones)."""
+    mask = ground_truth != unknown_disparity
+    return (abs(data[mask] + ground_truth[mask]) > threshold).sum() / data.size
+
+
+def test_oracle_sgm_meets_the_reference_quality_gate(oracle):
+    L, R, gt = load_cones()
+    dmin, dmax = -60, 0
+    cv = oracle.census_cost(L, R, dmax - dmin + 1, dmin, 1, 5)
+    raw_disp, _ = oracle.wta(cv, dmin, 1, False, np.nan)
+    s = oracle.sgm(cv, 8, 32, False, 26.0, False)
+    disp, val = oracle.wta(s, dmin, 1, False, np.nan)
+    e_raw, e_sgm = error(np.nan_to_num(raw_disp, nan=1e4), gt, 1), error(np.nan_to_num(disp, nan=1e4), gt, 1)
+    assert e_sgm <= 0.20, e_sgm
+    assert e_sgm < e_raw  # the optimisation must actually help
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_on_cones(oracle):
+    import pandora_amd
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, gt = load_cones()
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5, "subpix": 1},
+                        "optimization": {"optimization_method": "sgm", "overcounting": False,
+                                         "penalty": {"penalty_method": "sgm_penalty", "P1": 8, "P2": 32, "p2_method": "constant"}},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                        "refinement": {"refinement_method": "vfit"}}}  # data_samples/json_conf_files/a_semi_global_matching.json
+    left, right = make_image(L, disparity=[-60, 0]), make_image(R)
+    machine = PandoraMachine()
+    cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+    disp, _ = pandora_amd.run(machine, left, right, cfg)
+    d = disp["disparity_map"].data
+    assert error(np.nan_to_num(d, nan=1e4), gt, 1) <= 0.20
+    # and identical to the oracle on the full cones volume (10.3 M cells)
+    s = oracle.sgm(oracle.census_cost(L, R, 61, -60, 1, 5), 8, 32, False, 26.0, False)
+    np.testing.assert_array_equal(machine.left_cv["cost_volume"].data, s)
