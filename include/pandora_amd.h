@@ -113,7 +113,8 @@ int pmx_get_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp);
 int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t* validity);
 
 /* ---- D-sharded multi-GPU WTA ---------------------------------------------------- */
-/* Per-pixel packed key (orderable cost bits << 32 | global disparity index) of the local shard:
+/* Per-pixel packed key (orderable cost bits << 31 | global disparity index; < 2^63, INT64_MAX = no
+ * finite cost) of the local shard:
  * min over ranks of the key == np.argmin over the full volume, ties to the lowest index.
  * keys: uint64 [H][W] DEVICE pointer owned by the caller (e.g. a torch tensor fed to RCCL). */
 int pmx_wta_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int global_index_offset, uint64_t* dev_keys);

@@ -148,9 +148,10 @@ int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max) {
 }
 
 // ---- packed (cost, index) keys for D-sharded WTA ------------------------------------
-// key = orderable(cost) << 32 | global index, so that min over ranks of the uint64 key is the
+// key = orderable(cost) << 31 | global index, so that min over ranks of the uint64 key is the
 // lexicographic (cost, index) minimum.  For "max" measures the cost is negated first.
-// All-NaN shard -> key = 0xFFFFFFFF_FFFFFFFF.
+// The cost takes bits 62..31 and the index bits 30..0, so keys are < 2^63 and can travel as int64
+// (RCCL / gloo reduce int64 MIN).  All-NaN shard -> key = INT64_MAX.
 __device__ __forceinline__ uint32_t orderable(float f) {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -167,11 +168,11 @@ __global__ __launch_bounds__(kBlock) void minkey_kernel(const float* __restrict_
         int idx, any;
         wave_argbest<IS_MAX>(cv + pix * (size_t)D, D, lane, v, idx, any);
         if (lane == 0) {
-            uint64_t key = ~0ull;
+            uint64_t key = 0x7fffffffffffffffull;
             if (any) {
                 float f = IS_MAX ? -v : v;
                 if (f == 0.f) f = 0.f;  // -0 and +0 must order equal
-                key = ((uint64_t)orderable(f) << 32) | (uint32_t)(idx + index_offset);
+                key = ((uint64_t)orderable(f) << 31) | (uint64_t)((uint32_t)(idx + index_offset) & 0x7fffffffu);
             }
             keys[pix] = key;
         }
@@ -199,12 +200,12 @@ __global__ __launch_bounds__(kBlock) void from_keys_kernel(const uint64_t* __res
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= npix) return;
     uint64_t key = keys[i];
-    if (key == ~0ull) {
+    if (key == 0x7fffffffffffffffull) {
         disp[i] = invalid_disparity;
         int64_t m = validity[i];
         if ((m & MSK_INVALID) == 0) validity[i] = MSK_INVALID;
     } else {
-        uint32_t idx = (uint32_t)(key & 0xffffffffull);
+        uint32_t idx = (uint32_t)(key & 0x7fffffffull);
         disp[i] = (float)(d0 + (double)idx / (double)subpix);
     }
 }

@@ -1,0 +1,87 @@
+"""world_size-2 gloo test (CPU) of the D-sharded WTA merge: two processes each reduce their
+disparity slice to packed keys (numpy restatement of the kernel's packing, test-only), one
+all_reduce(MIN) merges them, and the decode equals np.argmin over the full volume (first minimum on
+ties, NaN = +inf, all-NaN -> invalid)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pack_keys_numpy(cv, is_max, index_offset):
+    """mirror of minkey_kernel (pandora_amd/csrc/k_disparity.hip)"""
+    v = np.where(np.isnan(cv), -np.inf if is_max else np.inf, cv).astype(np.float32)
+    idx = (np.argmax(v, axis=2) if is_max else np.argmin(v, axis=2))
+    best = np.take_along_axis(v, idx[..., None], axis=2)[..., 0]
+    f = (-best if is_max else best).astype(np.float32)
+    f = np.where(f == 0, np.float32(0), f)
+    u = f.view(np.uint32).astype(np.uint64)
+    order = np.where(u & 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000).astype(np.uint64)
+    keys = ((order << np.uint64(31)) | (idx + index_offset).astype(np.uint64)).astype(np.int64)
+    keys[np.all(np.isnan(cv), axis=2)] = np.int64(0x7FFFFFFFFFFFFFFF)
+    return keys
+
+
+def _worker(rank, world, port, is_max, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from pandora_amd import dist as pdist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)  # same volume on both ranks
+    H, W, dmin, dmax = 9, 13, -7, 5
+    D = dmax - dmin + 1
+    cv = rng.integers(0, 5, (H, W, D)).astype(np.float32)
+    cv[rng.random(cv.shape) < 0.2] = np.nan
+    cv[0, 0] = np.nan
+    (lo, hi), _ = pdist.disparity_shard(dmin, dmax, 1, world, rank)
+    shard = cv[:, :, lo - dmin:hi - dmin + 1]
+    keys = torch.from_numpy(pack_keys_numpy(shard, is_max, lo - dmin).ravel().copy())
+    pdist.allreduce_min_keys(keys)
+    disp, none = pdist.decode_keys_numpy(keys.numpy().reshape(H, W), dmin, 1, -9999.0)
+    if rank == 0:
+        q.put((disp, none, cv))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("is_max", [False, True])
+def test_d_sharded_wta_merge_world2(oracle, is_max):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, is_max, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    disp, none, cv = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    edisp, _ = oracle.wta(cv, -7, 1, is_max, -9999.0)
+    np.testing.assert_array_equal(disp, edisp)
+    assert none[0, 0] and none.sum() == np.all(np.isnan(cv), axis=2).sum()
+
+
+def test_shard_ranges_cover_everything():
+    from pandora_amd import dist as pdist
+
+    for n in (1, 7, 129, 257):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                s, e = pdist.shard_range(n, world, r)
+                cover += list(range(s, e))
+            assert cover == list(range(n))
+    own, halo = pdist.disparity_shard(-60, 0, 1, 8, 3, halo=1)
+    assert halo[0] == own[0] - 1 and halo[1] == own[1] + 1
