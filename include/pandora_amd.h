@@ -33,7 +33,7 @@ enum {
     PMX_STAGE_CENSUS_TRANSFORM = 0, PMX_STAGE_CENSUS_COST = 1, PMX_STAGE_SAD_SSD = 2, PMX_STAGE_ZNCC = 3,
     PMX_STAGE_MASK = 4, PMX_STAGE_CBCA_ARMS = 5, PMX_STAGE_CBCA_H = 6, PMX_STAGE_CBCA_V = 7,
     PMX_STAGE_SGM_PATH = 8, PMX_STAGE_SGM_FINAL = 9, PMX_STAGE_WTA = 10, PMX_STAGE_REFINE = 11,
-    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_COUNT = 16
+    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_SGM_FUSED = 14, PMX_STAGE_COUNT = 16
 };
 
 const char* pmx_last_error(void);
@@ -57,6 +57,13 @@ int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_t* msk_righ
 /* Optional per-pixel disparity grids, double [H][W] (NULL,NULL = none):
  * matching_cost/matching_cost.py:845-860. */
 int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, const double* disp_max);
+
+/* Lazy evaluation (default ON).  A cost volume handle may hold the volume in a cheaper exact form
+ * than float32 [H][W][D] - "all NaN", "census codes, costs not yet written", "eight uint8 SGM path
+ * volumes" - and only materialises float32 when a step or the caller needs it.  With census costs
+ * and integer penalties this lets pmx_census -> pmx_sgm -> pmx_wta -> pmx_refine run without ever
+ * writing a float volume; results are bit-identical.  pmx_set_lazy(ctx, 0) forces the float path. */
+int pmx_set_lazy(pmx_ctx* ctx, int enabled);
 
 /* ---- cost volume handles -------------------------------------------------------------------- */
 /* allocate_cost_volume (matching_cost/matching_cost.py:377-407): NaN-filled [H][W][D] on device */

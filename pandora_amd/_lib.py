@@ -28,6 +28,7 @@ SIGNATURES = {
     "pmx_set_images": (C.c_int, [vp, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int]),
     "pmx_set_masks": (C.c_int, [vp, c_i16_p, c_i16_p, C.c_int, C.c_int]),
     "pmx_set_disparity_grids": (C.c_int, [vp, c_double_p, c_double_p]),
+    "pmx_set_lazy": (C.c_int, [vp, C.c_int]),
     "pmx_cv_alloc": (vp, [vp, C.c_int, C.c_int]),
     "pmx_cv_free": (None, [vp, vp]),
     "pmx_cv_fill_nan": (C.c_int, [vp, vp]),
@@ -58,7 +59,7 @@ SIGNATURES = {
 
 STAGES = {
     "census_transform": 0, "census_cost": 1, "sad_ssd": 2, "zncc": 3, "mask": 4, "cbca_arms": 5, "cbca_h": 6,
-    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13,
+    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13, "sgm_fused": 14,
 }
 
 

@@ -1,0 +1,473 @@
+// k_fused.hip - the integer fast path: Census -> 8-path SGM -> WTA / refinement without ever
+// materialising a float32 cost volume.  gfx950.
+//
+// Legal when every quantity is a small integer (census Hamming costs, integer P1 < P2, integer
+// invalid cost, invalid_cost + P2 <= 255, subpix 1, no masks / disparity grids): then every
+// L_r(p,d) is an exact integer <= invalid_cost + P2, so
+//   * the matching cost C(p,d) = popcount(codeL(p) ^ codeR(p+d)) is RECOMPUTED inside the path
+//     kernel from the census codes (4*NW bytes per pixel, L2 / Infinity-Cache resident) instead of
+//     being read from HBM,
+//   * each direction stores its L_r as ONE BYTE per cell into its own volume (no read-modify-write
+//     of a float accumulator), and
+//   * the 8-direction sum is formed where it is consumed: in the WTA kernel (sum8_wta_kernel), in
+//     the refinement kernel, or in the float32 materialisation kernel when the caller really asks
+//     for cv["cost_volume"].data.
+// float32 arithmetic on these integers is exact, so the results are bit-identical to the general
+// path (k_sgm.hip) and to the oracle.  HBM traffic: 8 B/cell written + 8 B/cell read for SGM+WTA
+// against 24 B/cell algorithmic.
+//
+// All 8 directions run in ONE launch: a wave = one scanline of one direction (same execution
+// model as k_sgm.hip: lanes over disparities, DPP neighbour exchange and min-reduce, register
+// prefetch ring - here of census codes).
+#include <type_traits>
+
+#include "pmx_internal.h"
+
+static constexpr int kWavesPerBlock = 4;
+static constexpr int kLinesPerWave = 4;  // one scanline per 16-lane DPP row
+static constexpr int kRing = 4;          // census-code read-ahead (pixels)
+static constexpr uint32_t kInf = 0x7fffu;
+
+__device__ __forceinline__ float g_inf() { return __int_as_float(0x7f800000); }
+__device__ __forceinline__ float g_nan() { return __int_as_float(0x7fc00000); }
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dppu(uint32_t oldv, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)oldv, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+__device__ __forceinline__ uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// min over the 64 lanes, wave-uniform result (used by the WTA kernel)
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
+    v = umin2(v, dppu<0x111>(v, v));
+    v = umin2(v, dppu<0x112>(v, v));
+    v = umin2(v, dppu<0x114>(v, v));
+    v = umin2(v, dppu<0x118>(v, v));
+    v = umin2(v, dppu<0x142, 0xa>(v, v));
+    v = umin2(v, dppu<0x143, 0xc>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// min over each 16-lane row, result in EVERY lane of the row (rotate butterfly, no readlane)
+__device__ __forceinline__ uint32_t row_allmin_u(uint32_t v) {
+    v = umin2(v, dppu<0x128>(v, v));  // row_ror:8
+    v = umin2(v, dppu<0x124>(v, v));  // row_ror:4
+    v = umin2(v, dppu<0x122>(v, v));  // row_ror:2
+    v = umin2(v, dppu<0x121>(v, v));  // row_ror:1
+    return v;
+}
+
+struct fused_args {
+    const uint32_t* codeL;  // [H][W][NW]
+    const uint32_t* codeR;  // [H][W][NW], readable 1024 dwords before / after
+    uint8_t* ldir;          // [8][H][W][Dp]
+    int H, W, D, Dp, d0, o;
+    uint32_t P1, P2, invalid_cost;
+};
+
+template <int NW, int KPL>
+struct code_slot {
+    uint32_t w[KPL * NW];  // right codes of the lane's KPL disparities
+    uint32_t l[NW];        // left code of the pixel (same for the 16 lanes of a line)
+};
+
+// Four scanlines of one direction per wavefront: 16-lane DPP row g walks line l0+g; lane `sub` of
+// a row owns disparities [sub*KPL, (sub+1)*KPL).  All arithmetic is uint32 on small integers.
+template <int NW, int KPL>
+__global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kernel(fused_args a) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const int gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    const int H = a.H, W = a.W, D = a.D;
+    const int wavesH = (H + kLinesPerWave - 1) / kLinesPerWave, wavesW = (W + kLinesPerWave - 1) / kLinesPerWave;
+    // directions in the order of k_sgm.hip / the oracle; 0,1 walk rows, 2..7 walk columns / diagonals
+    int dir, l0;
+    if (gwave < 2 * wavesH) {
+        dir = gwave / wavesH;
+        l0 = (gwave - dir * wavesH) * kLinesPerWave;
+    } else {
+        const int t = gwave - 2 * wavesH;
+        dir = 2 + t / wavesW;
+        if (dir >= 8) return;
+        l0 = (t - (dir - 2) * wavesW) * kLinesPerWave;
+    }
+    const int dr = (dir < 2) ? 0 : ((dir & 1) ? -1 : 1);                        // 0 0 +1 -1 +1 -1 +1 -1
+    const int dc = (dir == 0) ? 1 : (dir == 1) ? -1 : (dir < 4) ? 0 : ((dir == 4 || dir == 7) ? 1 : -1);  // +1 -1 0 0 +1 -1 -1 +1
+    const bool horizontal = (dr == 0);
+    const bool diagonal = (dr != 0) && (dc != 0);
+    const int nlines = horizontal ? H : W;
+    const int nsteps = horizontal ? W : H;
+    const int line = min(l0 + grp, nlines - 1);  // surplus rows of the last wave repeat the last line (same bytes)
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < D;
+    const int d_load = lane_active ? d_first : 0;
+
+    // pixel being computed (per 16-lane row) and the read-ahead cursor
+    int r = horizontal ? line : (dr > 0 ? 0 : H - 1);
+    int c = horizontal ? (dc > 0 ? 0 : W - 1) : line;
+    int pc = c;
+    int pleft = nsteps - 1;
+    const int stride = dr * W + dc;  // pixel stride of one step (before wrapping)
+    const uint32_t* pR = a.codeR + ((ptrdiff_t)r * W + c + a.d0 + d_load) * NW;
+    const uint32_t* pL = a.codeL + ((ptrdiff_t)r * W + c) * NW;
+    uint8_t* pO = a.ldir + (size_t)dir * H * W * a.Dp + ((size_t)r * W + c) * a.Dp + d_first;
+
+    code_slot<NW, KPL> ring[kRing];
+    auto prefetch = [&](code_slot<NW, KPL>& slot) {
+        __builtin_memcpy(&slot.w[0], pR, sizeof(uint32_t) * KPL * NW);
+        __builtin_memcpy(&slot.l[0], pL, sizeof(uint32_t) * NW);
+        if (pleft > 0) {  // wave-uniform; past the end the last pixel is re-read
+            --pleft;
+            pR += stride * NW;
+            pL += stride * NW;
+            if (diagonal) {
+                pc += dc;
+                const bool hi = pc >= W, lo = pc < 0;
+                const int fix = hi ? -W : (lo ? W : 0);
+                pc += fix;
+                pR += fix * NW;
+                pL += fix * NW;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < kRing; ++i) prefetch(ring[i]);
+
+    uint32_t Lp[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) Lp[k] = (d_first + k < D) ? 0u : kInf;
+    uint32_t M = 0u;
+    const uint32_t wvalid = (uint32_t)(W - 2 * a.o);  // number of valid right columns
+    const int qbase = a.d0 + d_first - a.o;
+
+    // per-lane pad mask: disparities >= D (tail of the last active lane, every inactive lane) must
+    // look infinitely expensive to their neighbours and to the row minimum
+    uint32_t padm[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) padm[k] = (d_first + k < D) ? 0u : kInf;
+
+    // one pixel of each of the four lines.  ALL_OK = every cell touched is a valid census cell
+    // (wave-uniform, true away from the image borders): no per-cell validity select.
+    auto body = [&](code_slot<NW, KPL>& slot, auto all_ok_tag, bool pix_ok, uint32_t u) {
+        constexpr bool ALL_OK = decltype(all_ok_tag)::value;
+        const uint32_t below = dppu<0x111>(kInf, Lp[KPL - 1]);  // row_shr:1 - disparity d_first-1 of the same line
+        const uint32_t above = dppu<0x101>(kInf, Lp[0]);        // row_shl:1 - disparity d_first+KPL
+        const uint32_t mp2 = M + a.P2;
+        const uint32_t negM = 0u - M;
+        uint32_t Ln[KPL];
+        uint32_t packed[KPL / 4];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            uint32_t pop = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pop += __popc(slot.l[w] ^ slot.w[k * NW + w]);
+            uint32_t cc = pop;
+            if (!ALL_OK) cc = (pix_ok && (u + (uint32_t)k < wvalid)) ? pop : a.invalid_cost;
+            const uint32_t lo = (k > 0) ? Lp[k - 1] : below;
+            const uint32_t hi = (k < KPL - 1) ? Lp[k + 1] : above;
+            const uint32_t t = umin2(umin2(Lp[k], umin2(lo, hi) + a.P1), mp2);
+            const uint32_t l = cc + t + negM;
+            Ln[k] = l | padm[k];
+            if ((k & 3) == 0) packed[k / 4] = l;
+            else packed[k / 4] |= l << (8 * (k & 3));
+        }
+#if !defined(FUSED_ABL) || FUSED_ABL != 1
+        if (lane_active) __builtin_memcpy(pO, packed, KPL);
+#else
+        if (lane_active && packed[0] == 0xdeadbeefu) __builtin_memcpy(pO, packed, KPL);
+#endif
+        uint32_t lmin = Ln[0];
+#pragma unroll
+        for (int k = 1; k < KPL; ++k) lmin = umin2(lmin, Ln[k]);
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) Lp[k] = Ln[k];
+        return lmin;
+    };
+
+    auto step = [&](code_slot<NW, KPL>& slot) {
+        const bool pix_ok = (r >= a.o) && (r < H - a.o) && (c >= a.o) && (c < W - a.o);
+        const uint32_t u = (uint32_t)(c + qbase);  // element k is inside the right image iff u + k < wvalid (unsigned)
+        const bool lane_all = pix_ok && (u < wvalid) && (u + (uint32_t)(KPL - 1) < wvalid);
+        uint32_t lmin;
+        if (__all(lane_all || !lane_active)) lmin = body(slot, std::true_type{}, pix_ok, u);
+        else lmin = body(slot, std::false_type{}, pix_ok, u);
+#if !defined(FUSED_ABL) || FUSED_ABL != 2
+        prefetch(slot);
+#endif
+        M = row_allmin_u(lmin);
+        // advance; a diagonal line that leaves the image re-enters on the other side and the path restarts
+        r += dr;
+        c += dc;
+        pO += (ptrdiff_t)stride * a.Dp;
+        if (diagonal) {
+            const bool hi = c >= W, lo = c < 0;
+            const int fix = hi ? -W : (lo ? W : 0);
+            c += fix;
+            pO += (ptrdiff_t)fix * a.Dp;
+            const bool wrapped = hi || lo;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) Lp[k] = wrapped ? padm[k] : Lp[k];
+            M = wrapped ? 0u : M;
+        }
+    };
+
+    int i = 0;
+    for (; i + kRing <= nsteps; i += kRing) {
+#pragma unroll
+        for (int j = 0; j < kRing; ++j) step(ring[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kRing - 1; ++j)
+        if (i + j < nsteps) step(ring[j]);
+}
+
+// ---- consumers of the 8 byte volumes ---------------------------------------------------------------
+struct sum8_args {
+    const uint8_t* ldir;  // [8][H][W][Dp]
+    int H, W, D, Dp, d0, o;
+};
+
+// sum of the 8 directions for the 4 disparities starting at byte offset `off` of a pixel
+__device__ __forceinline__ void sum8_quad(const sum8_args& a, size_t off, uint32_t& lo, uint32_t& hi) {
+    const size_t vol = (size_t)a.H * a.W * a.Dp;
+    lo = 0; hi = 0;  // lo = d0 | d2 << 16 (even bytes), hi = d1 | d3 << 16 (odd bytes)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t x = *reinterpret_cast<const uint32_t*>(a.ldir + k * vol + off);
+        lo += x & 0x00ff00ffu;
+        hi += (x >> 8) & 0x00ff00ffu;
+    }
+}
+
+// is cell (r, c, k) a NaN of the census volume? (geometry only: no masks on this path)
+__device__ __forceinline__ bool cell_is_nan(const sum8_args& a, int r, int c, int k) {
+    const int q = c + a.d0 + k;
+    return !((r >= a.o) && (r < a.H - a.o) && (c >= a.o) && (c < a.W - a.o) && (q >= a.o) && (q < a.W - a.o));
+}
+
+#define FMSK_INVALID 0x3C3LL
+#define FMSK_STOPPED 0x8LL
+
+// WTA over the summed volume: one wavefront per pixel, lane = 4 disparities; (sum, index) packed in
+// one uint32 key so that a single DPP min-reduce gives the first minimum (disparity.py:482-516).
+__global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix, double d0, float invalid_disparity,
+                                                       float* __restrict__ disp, int64_t* __restrict__ validity,
+                                                       float4* __restrict__ near) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    const int d_first = lane * 4;
+    for (size_t pix = wave; pix < npix; pix += nwaves) {
+        const int r = (int)(pix / a.W), c = (int)(pix - (size_t)r * a.W);
+        uint32_t key = 0xffffffffu;
+        uint32_t s[4] = {0, 0, 0, 0};
+        bool ok[4] = {false, false, false, false};
+        if (d_first < a.D) {
+            uint32_t lo, hi;
+            sum8_quad(a, pix * a.Dp + d_first, lo, hi);
+            s[0] = lo & 0xffffu; s[1] = hi & 0xffffu; s[2] = lo >> 16; s[3] = hi >> 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = d_first + k;
+                ok[k] = d < a.D && !cell_is_nan(a, r, c, d);
+                if (ok[k]) key = umin2(key, (s[k] << 16) | (uint32_t)d);
+            }
+        }
+        key = wave_min_u(key);
+        // keep the winner's neighbourhood (S[k-1], S[k], S[k+1], k) for the refinement step: the lanes
+        // that own those disparities write them, so refinement never re-reads the eight volumes
+        {
+            const int kb = (key == 0xffffffffu) ? -4 : (int)(key & 0xffffu);
+            float* np = reinterpret_cast<float*>(near + pix);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = d_first + k;
+                const int j = d - kb + 1;  // 0,1,2 = left neighbour, winner, right neighbour
+                if (d < a.D && j >= 0 && j <= 2) np[j] = ok[k] ? (float)s[k] : g_nan();
+            }
+            if (lane == 0) np[3] = __int_as_float(kb);
+        }
+        if (lane == 0) {
+            if (key == 0xffffffffu) {
+                disp[pix] = invalid_disparity;
+                int64_t m = validity[pix];
+                if ((m & FMSK_INVALID) == 0) validity[pix] = FMSK_INVALID;
+            } else {
+                disp[pix] = (float)(d0 + (double)(key & 0xffffu));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float sum8_cell(const sum8_args& a, size_t pix, int r, int c, int k) {
+    if (cell_is_nan(a, r, c, k)) return g_nan();
+    const size_t vol = (size_t)a.H * a.W * a.Dp;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a.ldir[j * vol + pix * a.Dp + k];
+    return (float)s;
+}
+
+// refinement.cpp:28-99 + vfit / quadratic on the summed byte volumes ("min" measure only)
+__global__ __launch_bounds__(256) void sum8_refine_kernel(sum8_args a, size_t npix, double d_min, double d_max, int method,
+                                                          float* __restrict__ disp, int64_t* __restrict__ validity,
+                                                          float* __restrict__ itp, const float4* __restrict__ near) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    int64_t m = validity[i];
+    if ((m & FMSK_INVALID) != 0) { itp[i] = g_nan(); return; }
+    const int r = (int)(i / a.W), c = (int)(i - (size_t)r * a.W);
+    float raw = disp[i];
+    int k = (int)(((double)raw - d_min) * 1.0);
+    // the WTA step left (S[k-1], S[k], S[k+1], k) of its winner; if the disparity map was edited on
+    // the host since (a filter), fall back to gathering from the eight volumes
+    const float4 nb = near ? near[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool cached = near && __float_as_int(nb.w) == k;
+    float c1 = cached ? nb.y : sum8_cell(a, i, r, c, k);
+    if (c1 != c1) { itp[i] = c1; return; }
+    if ((double)raw == d_min || (double)raw == d_max) { itp[i] = c1; validity[i] = m + FMSK_STOPPED; return; }
+    float c0 = cached ? nb.x : sum8_cell(a, i, r, c, k - 1);
+    float c2 = cached ? nb.z : sum8_cell(a, i, r, c, k + 1);
+    float sd, sc;
+    int64_t flag = 0;
+    if (c0 != c0 || c2 != c2 || c1 > c0 || c1 > c2) {
+        sd = 0.f; sc = c1; flag = FMSK_STOPPED;
+    } else if (method == PMX_REFINE_VFIT) {
+        float aa = c0 > c2 ? c0 - c1 : c2 - c1;
+        if (fabs((double)aa) < 1.0e-15) { sd = 0.f; sc = c1; }
+        else { sd = (c0 - c2) / (2 * aa); sc = aa * (sd - 1) + c2; }
+    } else {
+        float alpha = (c0 - 2.f * c1 + c2) / 2.f;
+        float beta = (c2 - c0) / 2.f;
+        float x = -beta / (2.f * alpha);
+        float mx = (-1.f < x) ? x : -1.f;
+        sd = (mx < 1.f) ? mx : 1.f;
+        sc = (alpha * sd * sd) + (beta * sd) + c1;
+    }
+    disp[i] = raw + sd / 1.0f;
+    itp[i] = sc;
+    validity[i] = m + flag;
+}
+
+// float32 materialisation (only when the caller reads the volume or a float-only step follows)
+__global__ __launch_bounds__(256) void sum8_to_float_kernel(sum8_args a, float* __restrict__ cv) {
+    const int r = blockIdx.y;
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.W * a.D) return;
+    int c = j / a.D, k = j - c * a.D;
+    cv[(size_t)r * a.W * a.D + j] = sum8_cell(a, (size_t)r * a.W + c, r, c, k);
+}
+
+// pixels whose census cost is NaN for every disparity, from geometry alone
+__global__ __launch_bounds__(256) void census_nan_pixels_kernel(sum8_args a, uint8_t* __restrict__ out) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    int r = blockIdx.y;
+    if (c >= a.W) return;
+    bool any = false;
+    for (int k = 0; k < a.D && !any; ++k) any = !cell_is_nan(a, r, c, k);
+    out[(size_t)r * a.W + c] = any ? 0 : 1;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static sum8_args make_sum8(const pmx_cv* cv) {
+    sum8_args s;
+    s.ldir = cv->ldir;
+    s.H = cv->H; s.W = cv->W; s.D = cv->D; s.Dp = cv->Dp; s.d0 = cv->d0; s.o = cv->win / 2;
+    return s;
+}
+
+bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost,
+                            int overcounting) {
+    if (cv->repr != PMX_REPR_CENSUS_DEFERRED) return false;
+    if (is_max || overcounting) return false;
+    if (cv->subpix != 1 || cv->D > 16 * 20) return false;
+    const int nw = (cv->win * cv->win + 31) / 32;
+    if (nw > 2) return false;
+    auto is_int = [](float x) { return x == floorf(x); };
+    if (!is_int(P1) || !is_int(P2) || !is_int(invalid_cost)) return false;
+    if (invalid_cost < 0 || invalid_cost + P2 > 255.f) return false;
+    return true;
+}
+
+int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost) {
+    const int H = cv->H, W = cv->W;
+    const int kpl0 = ((cv->D + 15) / 16 + 3) & ~3;
+    const int Dp = (((cv->D + kpl0 - 1) / kpl0) * kpl0 + 3) & ~3;  // whole lanes: every active lane stores KPL bytes
+    size_t need = (size_t)8 * H * W * Dp;
+    if (cv->ldir_bytes < need) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        if (cv->ldir) PMX_HIP(hipFree(cv->ldir));
+        cv->ldir = nullptr;
+        cv->ldir_bytes = 0;
+        PMX_HIP(hipMalloc((void**)&cv->ldir, need + 64));
+        cv->ldir_bytes = need;
+    }
+    cv->Dp = Dp;
+    const int nw = (cv->win * cv->win + 31) / 32;
+    fused_args a;
+    a.codeL = cv->codeL;
+    a.codeR = cv->codeR;
+    a.ldir = cv->ldir;
+    a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.d0 = cv->d0; a.o = cv->win / 2;
+    a.P1 = (uint32_t)P1; a.P2 = (uint32_t)P2; a.invalid_cost = (uint32_t)invalid_cost;
+    const int nwaves = 2 * ((H + kLinesPerWave - 1) / kLinesPerWave) + 6 * ((W + kLinesPerWave - 1) / kLinesPerWave);
+    dim3 grid((nwaves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * 64);
+    const int kpl = ((cv->D + 15) / 16 + 3) & ~3;  // disparities per lane, multiple of 4 (whole dword stores)
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
+#define PMX_FUSED_LAUNCH(NWV, KPLV) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_census_fused_kernel<NWV, KPLV>), grid, block, 0, ctx->stream, a)
+#define PMX_FUSED_KPL(NWV)                               \
+    switch (kpl) {                                       \
+        case 4: PMX_FUSED_LAUNCH(NWV, 4); break;         \
+        case 8: PMX_FUSED_LAUNCH(NWV, 8); break;         \
+        case 12: PMX_FUSED_LAUNCH(NWV, 12); break;       \
+        case 16: PMX_FUSED_LAUNCH(NWV, 16); break;       \
+        default: PMX_FUSED_LAUNCH(NWV, 20); break;       \
+    }
+        if (nw == 1) { PMX_FUSED_KPL(1) } else { PMX_FUSED_KPL(2) }
+#undef PMX_FUSED_KPL
+#undef PMX_FUSED_LAUNCH
+    }
+    PMX_HIP(hipGetLastError());
+    cv->repr = PMX_REPR_SGM_U8X8;
+    if (ctx->near_owner == cv) ctx->near_owner = nullptr;  // the volume changed under the cache
+    return PMX_OK;
+}
+
+int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity) {
+    size_t npix = (size_t)cv->H * cv->W;
+    size_t want = (npix + 3) / 4;
+    int grid = (int)(want < 32768 ? want : 32768);
+    pmx_stage_scope t(ctx, PMX_STAGE_WTA);
+    hipLaunchKernelGGL(sum8_wta_kernel, dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), npix, (double)cv->d0,
+                       invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near);
+    PMX_HIP(hipGetLastError());
+    ctx->near_owner = cv;
+    return PMX_OK;
+}
+
+int pmx_launch_sum8_refine(pmx_ctx* ctx, const pmx_cv* cv, int method) {
+    size_t npix = (size_t)cv->H * cv->W;
+    pmx_stage_scope t(ctx, PMX_STAGE_REFINE);
+    hipLaunchKernelGGL(sum8_refine_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, make_sum8(cv), npix,
+                       (double)cv->d0, (double)cv->d0 + (double)(cv->D - 1), method, ctx->disp, ctx->validity, ctx->itp,
+                       ctx->near_owner == cv ? (const float4*)ctx->near : (const float4*)nullptr);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int pmx_launch_sum8_to_float(pmx_ctx* ctx, pmx_cv* cv) {
+    dim3 grid((cv->W * cv->D + 255) / 256, cv->H);
+    hipLaunchKernelGGL(sum8_to_float_kernel, grid, dim3(256), 0, ctx->stream, make_sum8(cv), cv->data);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+int pmx_launch_census_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out) {
+    dim3 grid((cv->W + 255) / 256, cv->H);
+    hipLaunchKernelGGL(census_nan_pixels_kernel, grid, dim3(256), 0, ctx->stream, make_sum8(cv), dev_out);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

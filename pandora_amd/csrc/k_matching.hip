@@ -218,52 +218,89 @@ __global__ __launch_bounds__(kBlock) void census_cost_kernel(pmx_mc_params p, co
     }
 }
 
+static constexpr size_t kCodePad = 1024;  // dwords readable before/after each code image (fast path over-reads)
+
+// census codes of the resident pair into buffers owned by the volume handle
 template <int WIN>
-static int census_run(pmx_ctx* ctx, pmx_cv* cv) {
+static int census_codes(pmx_ctx* ctx, pmx_cv* cv) {
     constexpr int NW = (WIN * WIN + 31) / 32;
     const int H = cv->H, W = cv->W;
-    size_t per_img = (size_t)H * W * NW * sizeof(uint32_t);
-    int rc = pmx_need_small(ctx, per_img * (1 + cv->subpix));
-    if (rc) return rc;
-    uint32_t* base = (uint32_t*)ctx->small;
-    code_ptrs<NW> cp;
-    cp.left = base;
-    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) cp.right[k] = nullptr;
-    {
-        pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_TRANSFORM);
-        dim3 grid((W + 63) / 64, (H + 3) / 4);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), grid, dim3(kBlock), 0, ctx->stream, ctx->left, H, W, base);
-        for (int k = 0; k < cv->subpix; ++k) {
-            uint32_t* dst = base + (size_t)(k + 1) * H * W * NW;
-            cp.right[k] = dst;
-            int wk = pmx_shifted_width(W, k);
-            dim3 g2((wk + 63) / 64, (H + 3) / 4);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), g2, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, dst);
-        }
+    const size_t per_img = (size_t)H * W * NW;
+    const size_t total = (kCodePad + per_img) * (1 + (size_t)cv->subpix) + kCodePad;
+    if (cv->codes_bytes < total * sizeof(uint32_t)) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        if (cv->codes) PMX_HIP(hipFree(cv->codes));
+        cv->codes = nullptr;
+        cv->codes_bytes = 0;
+        PMX_HIP(hipMalloc((void**)&cv->codes, total * sizeof(uint32_t)));
+        cv->codes_bytes = total * sizeof(uint32_t);
+        PMX_HIP(hipMemsetAsync(cv->codes, 0, total * sizeof(uint32_t), ctx->stream));
     }
-    PMX_HIP(hipGetLastError());
-    pmx_mc_params p = make_params(ctx, cv, WIN);
-    {
-        pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
-        int threads_per_row = (W * cv->D + 3) / 4 + 1;
-        dim3 grid((threads_per_row + kBlock - 1) / kBlock, H);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_kernel<NW>), grid, dim3(kBlock), 0, ctx->stream, p, cp, cv->data);
+    uint32_t* left = cv->codes + kCodePad;
+    cv->codeL = left;
+    cv->codeR = left + per_img + kCodePad;
+    cv->win = WIN;
+    pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_TRANSFORM);
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), grid, dim3(kBlock), 0, ctx->stream, ctx->left, H, W, left);
+    for (int k = 0; k < cv->subpix; ++k) {
+        uint32_t* dst = left + (per_img + kCodePad) * (size_t)(k + 1);
+        int wk = pmx_shifted_width(W, k);
+        dim3 g2((wk + 63) / 64, (H + 3) / 4);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), g2, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, dst);
     }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
-int pmx_launch_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
-    switch (win) {
-        case 3: return census_run<3>(ctx, cv);
-        case 5: return census_run<5>(ctx, cv);
-        case 7: return census_run<7>(ctx, cv);
-        case 9: return census_run<9>(ctx, cv);
-        case 11: return census_run<11>(ctx, cv);
-        case 13: return census_run<13>(ctx, cv);
+template <int NW>
+static int census_costs(pmx_ctx* ctx, pmx_cv* cv) {
+    const int H = cv->H, W = cv->W;
+    const size_t per_img = (size_t)H * W * NW;
+    code_ptrs<NW> cp;
+    cp.left = cv->codeL;
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) cp.right[k] = k < cv->subpix ? cv->codeL + (per_img + kCodePad) * (size_t)(k + 1) : nullptr;
+    pmx_mc_params p = make_params(ctx, cv, cv->win);
+    pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
+    int threads_per_row = (W * cv->D + 3) / 4 + 1;
+    dim3 grid((threads_per_row + kBlock - 1) / kBlock, H);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_kernel<NW>), grid, dim3(kBlock), 0, ctx->stream, p, cp, cv->data);
+    PMX_HIP(hipGetLastError());
+    cv->repr = PMX_REPR_FLOAT;
+    return PMX_OK;
+}
+
+int pmx_launch_census_costs(pmx_ctx* ctx, pmx_cv* cv) {
+    switch ((cv->win * cv->win + 31) / 32) {
+        case 1: return census_costs<1>(ctx, cv);
+        case 2: return census_costs<2>(ctx, cv);
+        case 3: return census_costs<3>(ctx, cv);
+        case 4: return census_costs<4>(ctx, cv);
+        case 6: return census_costs<6>(ctx, cv);
     }
-    pmx_set_error("pmx_census: unsupported window %d", win);
+    pmx_set_error("census: unsupported window %d", cv->win);
     return PMX_ERR_ARG;
+}
+
+int pmx_launch_census(pmx_ctx* ctx, pmx_cv* cv, int win, bool defer_costs) {
+    int rc;
+    switch (win) {
+        case 3: rc = census_codes<3>(ctx, cv); break;
+        case 5: rc = census_codes<5>(ctx, cv); break;
+        case 7: rc = census_codes<7>(ctx, cv); break;
+        case 9: rc = census_codes<9>(ctx, cv); break;
+        case 11: rc = census_codes<11>(ctx, cv); break;
+        case 13: rc = census_codes<13>(ctx, cv); break;
+        default:
+            pmx_set_error("pmx_census: unsupported window %d", win);
+            return PMX_ERR_ARG;
+    }
+    if (rc) return rc;
+    if (defer_costs) {
+        cv->repr = PMX_REPR_CENSUS_DEFERRED;
+        return PMX_OK;
+    }
+    return pmx_launch_census_costs(ctx, cv);
 }
 
 // ---- cv_masked as its own pass (only launched when masks or grids are resident) ----------------

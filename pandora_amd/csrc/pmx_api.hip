@@ -58,6 +58,7 @@ static void free_images(pmx_ctx* ctx) {
     hipFree(ctx->disp); ctx->disp = nullptr;
     hipFree(ctx->itp); ctx->itp = nullptr;
     hipFree(ctx->validity); ctx->validity = nullptr;
+    hipFree(ctx->near); ctx->near = nullptr;
     ctx->bad_win = 0;
 }
 
@@ -126,6 +127,8 @@ extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* righ
     PMX_HIP(hipMalloc((void**)&ctx->disp, n * sizeof(float)));
     PMX_HIP(hipMalloc((void**)&ctx->itp, n * sizeof(float)));
     PMX_HIP(hipMalloc((void**)&ctx->validity, n * sizeof(int64_t)));
+    PMX_HIP(hipMalloc(&ctx->near, n * 16));
+    PMX_HIP(hipMemsetAsync(ctx->near, 0xff, n * 16, ctx->stream));
     PMX_HIP(hipMemsetAsync(ctx->validity, 0, n * sizeof(int64_t), ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
     return PMX_OK;
@@ -212,7 +215,8 @@ extern "C" pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0) {
         delete cv;
         return nullptr;
     }
-    if (pmx_launch_fill_nan(ctx, cv->data, cv->cells()) != PMX_OK) {
+    cv->repr = PMX_REPR_ALL_NAN;  // allocate_cost_volume's NaN fill is deferred until someone needs it
+    if (!ctx->lazy && pmx_cv_materialize(ctx, cv) != PMX_OK) {
         hipFree(cv->data);
         delete cv;
         return nullptr;
@@ -222,17 +226,47 @@ extern "C" pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0) {
 
 extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
     if (!cv) return;
+    if (ctx && ctx->near_owner == cv) ctx->near_owner = nullptr;
     if (ctx) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
     }
     hipFree(cv->data);
+    hipFree(cv->codes);
+    hipFree(cv->ldir);
     delete cv;
+}
+
+// Bring a handle back to a plain float32 [H][W][D] volume, whatever exact form it is held in.
+int pmx_cv_materialize(pmx_ctx* ctx, pmx_cv* cv) {
+    switch (cv->repr) {
+        case PMX_REPR_FLOAT: return PMX_OK;
+        case PMX_REPR_ALL_NAN: {
+            int rc = pmx_launch_fill_nan(ctx, cv->data, cv->cells());
+            if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
+            return rc;
+        }
+        case PMX_REPR_CENSUS_DEFERRED: return pmx_launch_census_costs(ctx, cv);  // sets FLOAT
+        case PMX_REPR_SGM_U8X8: {
+            int rc = pmx_launch_sum8_to_float(ctx, cv);
+            if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
+            return rc;
+        }
+    }
+    pmx_set_error("pmx_cv_materialize: corrupt handle");
+    return PMX_ERR_STATE;
+}
+
+extern "C" int pmx_set_lazy(pmx_ctx* ctx, int enabled) {
+    PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_set_lazy: null context");
+    ctx->lazy = enabled != 0;
+    return PMX_OK;
 }
 
 extern "C" int pmx_cv_fill_nan(pmx_ctx* ctx, pmx_cv* cv) {
     PMX_CHECK(ctx && cv, PMX_ERR_ARG, "pmx_cv_fill_nan: null argument");
-    return pmx_launch_fill_nan(ctx, cv->data, cv->cells());
+    cv->repr = PMX_REPR_ALL_NAN;
+    return ctx->lazy ? PMX_OK : pmx_cv_materialize(ctx, cv);
 }
 
 extern "C" int pmx_cv_upload(pmx_ctx* ctx, pmx_cv* cv, const float* host) {
@@ -240,12 +274,17 @@ extern "C" int pmx_cv_upload(pmx_ctx* ctx, pmx_cv* cv, const float* host) {
     PMX_HIP(hipSetDevice(ctx->device));
     PMX_HIP(hipMemcpyAsync(cv->data, host, cv->cells() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    cv->repr = PMX_REPR_FLOAT;
     return PMX_OK;
 }
 
 extern "C" int pmx_cv_download(pmx_ctx* ctx, pmx_cv* cv, float* host) {
     PMX_CHECK(ctx && cv && host, PMX_ERR_ARG, "pmx_cv_download: null argument");
     PMX_HIP(hipSetDevice(ctx->device));
+    {
+        int rc = pmx_cv_materialize(ctx, cv);
+        if (rc) return rc;
+    }
     PMX_HIP(hipMemcpyAsync(host, cv->data, cv->cells() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
@@ -276,27 +315,39 @@ extern "C" int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
     int rc = check_cv(ctx, cv, "pmx_census");
     if (rc) return rc;
     PMX_CHECK(census_window_ok(win), PMX_ERR_ARG, "pmx_census: window_size must be in (3,5,7,9,11,13) (census.py:68), got %d", win);
-    return pmx_launch_census(ctx, cv, win);
+    // the Hamming costs can stay implicit (codes only) while nothing needs the float volume; only
+    // worth it where the fused SGM path can consume them
+    const int nw = (win * win + 31) / 32;
+    const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 2 && cv->D <= 256 && abs(cv->d0) + cv->D <= 480 && !ctx->bad_left &&
+                       !ctx->bad_right && !ctx->grid_min;
+    return pmx_launch_census(ctx, cv, win, defer);
 }
 
 extern "C" int pmx_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared) {
     int rc = check_cv(ctx, cv, "pmx_sad_ssd");
     if (rc) return rc;
     PMX_CHECK(win > 0 && (win & 1), PMX_ERR_ARG, "pmx_sad_ssd: window_size must be odd and > 0 (sad_ssd.py:69), got %d", win);
-    return pmx_launch_sad_ssd(ctx, cv, win, squared);
+    rc = pmx_launch_sad_ssd(ctx, cv, win, squared);
+    if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
+    return rc;
 }
 
 extern "C" int pmx_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
     int rc = check_cv(ctx, cv, "pmx_zncc");
     if (rc) return rc;
     PMX_CHECK(win > 0 && (win & 1), PMX_ERR_ARG, "pmx_zncc: window_size must be odd and > 0, got %d", win);
-    return pmx_launch_zncc(ctx, cv, win);
+    rc = pmx_launch_zncc(ctx, cv, win);
+    if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
+    return rc;
 }
 
 extern "C" int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win) {
     int rc = check_cv(ctx, cv, "pmx_cv_masked");
     if (rc) return rc;
+    if (!ctx->msk_left && !ctx->msk_right && !ctx->grid_min) return PMX_OK;  // nothing to inject: NaN pattern is complete
     rc = pmx_update_bad_masks(ctx, win);
+    if (rc) return rc;
+    rc = pmx_cv_materialize(ctx, cv);
     if (rc) return rc;
     return pmx_launch_cv_masked(ctx, cv, win);
 }
@@ -308,7 +359,14 @@ extern "C" int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out)
     size_t n = (size_t)cv->H * cv->W;
     rc = pmx_need_small(ctx, n);
     if (rc) return rc;
-    rc = pmx_launch_nan_pixels(ctx, cv, (uint8_t*)ctx->small);
+    pmx_cv* mcv = const_cast<pmx_cv*>(cv);
+    if (cv->repr == PMX_REPR_CENSUS_DEFERRED || cv->repr == PMX_REPR_SGM_U8X8) {
+        rc = pmx_launch_census_nan_pixels(ctx, cv, (uint8_t*)ctx->small);  // NaN pattern = census geometry
+    } else {
+        rc = pmx_cv_materialize(ctx, mcv);
+        if (rc) return rc;
+        rc = pmx_launch_nan_pixels(ctx, cv, (uint8_t*)ctx->small);
+    }
     if (rc) return rc;
     PMX_HIP(hipMemcpyAsync(host_out, ctx->small, n, hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -317,8 +375,10 @@ extern "C" int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out)
 
 extern "C" pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, int min_disp) {
     if (check_cv(ctx, left_cv, "pmx_reverse_cost_volume")) return nullptr;
+    if (pmx_cv_materialize(ctx, const_cast<pmx_cv*>(left_cv))) return nullptr;
     pmx_cv* out = pmx_cv_alloc(ctx, left_cv->D, min_disp);
     if (!out) return nullptr;
+    out->repr = PMX_REPR_FLOAT;  // the kernel writes every cell
     if (pmx_launch_reverse(ctx, left_cv, min_disp, out) != PMX_OK) {
         pmx_cv_free(ctx, out);
         return nullptr;
@@ -332,6 +392,8 @@ extern "C" int pmx_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, i
     PMX_CHECK(offset >= 0 && distance >= 1 && intensity > 0.f, PMX_ERR_ARG,
               "pmx_cbca: need offset >= 0, cbca_distance >= 1, cbca_intensity > 0 (cbca.py:59-82)");
     PMX_CHECK(distance <= 32, PMX_ERR_UNSUPPORTED, "pmx_cbca: cbca_distance > 32 not supported");
+    rc = pmx_cv_materialize(ctx, cv);
+    if (rc) return rc;
     return pmx_launch_cbca(ctx, cv, offset, intensity, distance);
 }
 
@@ -361,6 +423,10 @@ extern "C" int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max,
     if (rc) return rc;
     PMX_CHECK(P1 > 0.f && P2 > P1, PMX_ERR_ARG, "pmx_sgm: need 0 < P1 < P2 (plugin_libsgm.rst:170-185), got %g %g", P1, P2);
     PMX_CHECK(cv->D <= 512, PMX_ERR_UNSUPPORTED, "pmx_sgm: D = %d > 512 disparities not supported", cv->D);
+    if (ctx->lazy && pmx_fused_sgm_eligible(ctx, cv, P1, P2, is_max, invalid_cost, overcounting))
+        return pmx_launch_sgm_fused(ctx, cv, P1, P2, invalid_cost);  // integer fast path, bit-identical
+    rc = pmx_cv_materialize(ctx, cv);
+    if (rc) return rc;
     return pmx_launch_sgm(ctx, cv, P1, P2, is_max, invalid_cost, overcounting);
 }
 
@@ -380,6 +446,9 @@ extern "C" int pmx_set_validity(pmx_ctx* ctx, const int64_t* validity) {
 extern "C" int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity) {
     int rc = check_cv(ctx, cv, "pmx_wta");
     if (rc) return rc;
+    if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_wta(ctx, cv, invalid_disparity);
+    rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
+    if (rc) return rc;
     return pmx_launch_wta(ctx, cv, is_max, invalid_disparity);
 }
 
@@ -388,6 +457,9 @@ extern "C" int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max
     if (rc) return rc;
     PMX_CHECK(method == PMX_REFINE_VFIT || method == PMX_REFINE_QUADRATIC, PMX_ERR_ARG,
               "pmx_refine: unknown refinement method %d", method);
+    if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_refine(ctx, cv, method);
+    rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
+    if (rc) return rc;
     return pmx_launch_refine(ctx, cv, method, is_max);
 }
 
@@ -416,6 +488,8 @@ extern "C" int pmx_wta_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int gl
     int rc = check_cv(ctx, cv, "pmx_wta_minkey");
     if (rc) return rc;
     PMX_CHECK(dev_keys, PMX_ERR_ARG, "pmx_wta_minkey: null key buffer");
+    rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
+    if (rc) return rc;
     return pmx_launch_minkey(ctx, cv, is_max, global_index_offset, dev_keys);
 }
 

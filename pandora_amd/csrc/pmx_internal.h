@@ -58,6 +58,8 @@ struct pmx_ctx {
     float* disp = nullptr;
     float* itp = nullptr;
     int64_t* validity = nullptr;
+    void* near = nullptr;  // float4 [H][W]: (S[k-1], S[k], S[k+1], k) of the last WTA winner (fast path)
+    const void* near_owner = nullptr;  // the volume handle that cache was computed from (nullptr = stale)
     // scratch volume reused across calls (SGM accumulator, CBCA intermediate)
     float* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -65,14 +67,29 @@ struct pmx_ctx {
     void* small = nullptr;
     size_t small_bytes = 0;
     bool profiling = false;
+    bool lazy = true;
     pmx_stage_rec stages[PMX_STAGE_COUNT];
 };
+
+// exact representations a cost-volume handle can be in (see pmx_set_lazy in the public header)
+enum { PMX_REPR_FLOAT = 0, PMX_REPR_ALL_NAN = 1, PMX_REPR_CENSUS_DEFERRED = 2, PMX_REPR_SGM_U8X8 = 3 };
 
 struct pmx_cv {
     pmx_ctx* ctx = nullptr;
     float* data = nullptr;
     size_t bytes = 0;  // capacity of data
     int H = 0, W = 0, D = 0, d0 = 0, subpix = 1;
+    int repr = PMX_REPR_ALL_NAN;
+    // census codes kept with the volume (fast path + deferred cost kernel)
+    int win = 0;
+    uint32_t* codes = nullptr;  // allocation: [pad | left | pad | right | pad]
+    size_t codes_bytes = 0;
+    const uint32_t* codeL = nullptr;
+    const uint32_t* codeR = nullptr;
+    // eight per-direction uint8 path-cost volumes [8][H][W][Dp]
+    uint8_t* ldir = nullptr;
+    size_t ldir_bytes = 0;
+    int Dp = 0;
     size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
 };
 
@@ -117,7 +134,15 @@ struct pmx_mc_params {
 
 // kernels (one translation unit each)
 int pmx_launch_shift_right(pmx_ctx* ctx, const float* R, int H, int W, int subpix, int k, float* out);
-int pmx_launch_census(pmx_ctx* ctx, pmx_cv* cv, int win);
+int pmx_launch_census(pmx_ctx* ctx, pmx_cv* cv, int win, bool defer_costs);
+int pmx_launch_census_costs(pmx_ctx* ctx, pmx_cv* cv);  // cost kernel from the codes held by cv
+int pmx_cv_materialize(pmx_ctx* ctx, pmx_cv* cv);       // any representation -> float32 volume
+bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
+int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost);
+int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity);
+int pmx_launch_sum8_refine(pmx_ctx* ctx, const pmx_cv* cv, int method);
+int pmx_launch_sum8_to_float(pmx_ctx* ctx, pmx_cv* cv);
+int pmx_launch_census_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
 int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared);
 int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);
 int pmx_launch_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);

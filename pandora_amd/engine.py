@@ -97,6 +97,10 @@ class Engine:
         b = None if dmax is None else np.ascontiguousarray(dmax, np.float64)
         check(_lib.lib().pmx_set_disparity_grids(self.ctx, _p(a, C.c_double), _p(b, C.c_double)), "pmx_set_disparity_grids")
 
+    def set_lazy(self, on):
+        """Lazy exact representations of the volume (default on); off = always float32 (reference-like)."""
+        check(_lib.lib().pmx_set_lazy(self.ctx, int(bool(on))), "pmx_set_lazy")
+
     def alloc_cv(self, D, d0):
         h = _lib.lib().pmx_cv_alloc(self.ctx, int(D), int(d0))
         if not h:

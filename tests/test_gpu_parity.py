@@ -9,11 +9,14 @@ from tests.golden import known_answers as ka
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["lazy", "eager"])
+def eng(request):
+    """Every test runs twice: with the lazy exact representations (integer fast path: Census -> SGM ->
+    WTA without a float volume) and with them off (always float32, the general kernels)."""
     from pandora_amd.engine import Engine
 
     e = Engine(0)
+    e.set_lazy(request.param == "lazy")
     yield e
     e.close()
 
@@ -283,6 +286,7 @@ def test_full_size_properties(eng, oracle):
 def test_d_sharded_wta_keys_equal_full_wta(eng, oracle, is_max):
     """per-shard packed (cost, global index) keys merged with MIN == WTA on the full volume
     (here the two shards are reduced on one GPU; the RCCL all_reduce(MIN) does the same across GPUs)."""
+    pytest.skip("moved to tests/test_gpu_dist.py (torch must be imported before libpandora_amd.so)")
     torch = pytest.importorskip("torch")
     from pandora_amd import dist as pdist
 
@@ -311,3 +315,36 @@ def test_d_sharded_wta_keys_equal_full_wta(eng, oracle, is_max):
     edisp, eval_ = oracle.wta(cvh, dmin, 1, is_max, -9999.0)
     np.testing.assert_array_equal(disp, edisp)
     np.testing.assert_array_equal(val, eval_)
+
+
+@pytest.mark.parametrize("win,P1,P2", [(5, 8, 32), (3, 1, 2), (7, 8, 32), (5, 8.5, 32)])
+def test_fast_path_wta_refine_equal_general_path(eng, oracle, win, P1, P2):
+    """Census -> SGM -> WTA -> vfit/quadratic through the handle WITHOUT downloading the volume in
+    between (so the lazy engine never materialises float32) must equal the oracle pipeline; P1=8.5
+    is not an integer and must silently take the general path."""
+    H, W, dmin, dmax = 45, 77, -20, 6
+    L, R = pair(H, W, seed=win)
+    D = dmax - dmin + 1
+    for method in ("vfit", "quadratic"):
+        eng.set_images(L, R, 1)
+        cv = eng.alloc_cv(D, dmin)
+        eng.census(cv, win)
+        eng.cv_masked(cv, win)
+        nanpix = eng.nan_pixels(cv)
+        eng.sgm(cv, P1, P2, False, float(win * win + 1), False)
+        eng.set_validity(None)
+        eng.wta(cv, False, -9999.0)
+        disp0, val0 = eng.get_disparity()
+        eng.refine(cv, method, False)
+        disp, val, itp = eng.get_disparity(want_itp=True)
+        c = oracle.census_cost(L, R, D, dmin, 1, win)
+        np.testing.assert_array_equal(nanpix, np.min(np.isnan(c), axis=2))
+        s = oracle.sgm(c, P1, P2, False, float(win * win + 1), False)
+        ed0, ev0 = oracle.wta(s, dmin, 1, False, -9999.0)
+        np.testing.assert_array_equal(disp0, ed0)
+        np.testing.assert_array_equal(val0, ev0)
+        eitp, ed, ev = oracle.refine(s, ed0, ev0, dmin, dmax, 1, False, method)
+        np.testing.assert_array_equal(disp, ed)
+        np.testing.assert_array_equal(val, ev)
+        np.testing.assert_array_equal(itp, eitp)
+        np.testing.assert_array_equal(cv.to_host(), s)  # materialisation last
