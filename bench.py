@@ -156,6 +156,16 @@ def main():
             algo_bytes_per_launch = SGM_ALGO_BYTES_PER_CELL / 8.0 * cells
         avg_launch_ms = sgm_ms / max(sgm_n, 1)
         achieved = algo_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if sgm_n else 0.0
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            w = pmc["workload"]
+            if stage["sgm_fused"][1] > 0 and (w["H"], w["W"], w["D"]) == (H, W, D):
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "Mdisparities/s (HxWxD/s) Census5x5+SGM",
             "value": round(value, 1),
@@ -167,14 +177,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "u32" if stage["sgm_fused"][1] > 0 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{H}x{W} synthetic pair, d=[{dmin},{dmax}] (D={D}), Census5x5 + SGM 8-path "
                                    f"(P1=8,P2=32) + WTA + vfit; one independent pair per GPU",
                        "parallelism": f"pair-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_launch_ms, 4), "launches": sgm_n,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch},
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
