@@ -90,7 +90,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PANDORA_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist_mod
 
