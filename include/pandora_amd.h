@@ -135,6 +135,10 @@ int pmx_set_profiling(pmx_ctx* ctx, int enabled);
 int pmx_reset_stage_times(pmx_ctx* ctx);
 /* total GPU milliseconds and launch count of one stage since the last reset (syncs the stream) */
 int pmx_stage_time(pmx_ctx* ctx, int stage, double* total_ms, int* launches);
+/* Debug / test hook: copy the eight uint8 per-direction SGM path-cost volumes [8][H][W][Dp] of a handle
+ * that is in the fused integer representation to the host; *Dp receives the byte stride per pixel.
+ * Returns PMX_ERR_STATE when the handle is not in that representation. */
+int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

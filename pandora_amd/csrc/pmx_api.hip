@@ -500,6 +500,19 @@ extern "C" int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double 
     return pmx_launch_from_keys(ctx, dev_keys, d0_global, subpix, invalid_disparity);
 }
 
+extern "C" int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp) {
+    PMX_CHECK(ctx && cv, PMX_ERR_ARG, "pmx_debug_path_costs: null argument");
+    PMX_CHECK(cv->repr == PMX_REPR_SGM_U8X8 && cv->ldir, PMX_ERR_STATE, "pmx_debug_path_costs: volume is not in the fused SGM representation");
+    if (Dp) *Dp = cv->Dp;
+    size_t n = (size_t)8 * cv->H * cv->W * cv->Dp;
+    if (!host_out) return PMX_OK;
+    PMX_CHECK(host_bytes >= n, PMX_ERR_ARG, "pmx_debug_path_costs: host buffer too small (%zu < %zu)", host_bytes, n);
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipMemcpyAsync(host_out, cv->ldir, n, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------
 extern "C" int pmx_set_profiling(pmx_ctx* ctx, int enabled) {
     PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_set_profiling: null context");

@@ -177,6 +177,14 @@ class Engine:
         check(_lib.lib().pmx_wta_from_keys(self.ctx, C.c_void_p(dev_keys_ptr), float(d0_global), int(subpix),
                                            float(invalid_disparity)), "pmx_wta_from_keys")
 
+    def debug_path_costs(self, cv):
+        """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation."""
+        dp = C.c_int(0)
+        check(_lib.lib().pmx_debug_path_costs(self.ctx, cv.handle, None, 0, C.byref(dp)), "pmx_debug_path_costs")
+        out = np.empty((8, self.H, self.W, dp.value), np.uint8)
+        check(_lib.lib().pmx_debug_path_costs(self.ctx, cv.handle, _p(out, C.c_uint8), out.nbytes, C.byref(dp)), "pmx_debug_path_costs")
+        return out[:, :, :, :cv.D]
+
     # -- measurement -------------------------------------------------------------------------
     def sync(self):
         check(_lib.lib().pmx_sync(self.ctx), "pmx_sync")
