@@ -19,6 +19,12 @@
 // All 8 directions run in ONE launch: a wave = one scanline of one direction (same execution
 // model as k_sgm.hip: lanes over disparities, DPP neighbour exchange and min-reduce, register
 // prefetch ring - here of census codes).
+//
+// Measured limits on MI355X (tools/ubench, profiles/r01_c_*): a SIMD issues about one instruction per 4
+// cycles whatever the mix (VALU, SALU, 1/2/4 waves), and the texture addresser spends ~20 cycles per
+// vector-memory instruction whatever its width - so the step below is written for FEW instructions and
+// FEW, WIDE memory operations (3 x 16-byte code loads + 1 left-code load + one 12-byte store per 4 pixels
+// for D = 129); variants with fewer ALU slots but one more store per step were slower.
 #include <type_traits>
 
 #include "pmx_internal.h"
@@ -51,10 +57,10 @@ __device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
 
 // min over each 16-lane row, result in EVERY lane of the row (rotate butterfly, no readlane)
 __device__ __forceinline__ uint32_t row_allmin_u(uint32_t v) {
-    v = umin2(v, dppu<0x128>(v, v));  // row_ror:8
-    v = umin2(v, dppu<0x124>(v, v));  // row_ror:4
-    v = umin2(v, dppu<0x122>(v, v));  // row_ror:2
-    v = umin2(v, dppu<0x121>(v, v));  // row_ror:1
+    v = umin2(v, dppu<0x128>(0xffffffffu, v));  // row_ror:8  (old = identity of min: lets the DPP fold into v_min_u32)
+    v = umin2(v, dppu<0x124>(0xffffffffu, v));  // row_ror:4
+    v = umin2(v, dppu<0x122>(0xffffffffu, v));  // row_ror:2
+    v = umin2(v, dppu<0x121>(0xffffffffu, v));  // row_ror:1
     return v;
 }
 
@@ -154,7 +160,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
         const uint32_t below = dppu<0x111>(kInf, Lp[KPL - 1]);  // row_shr:1 - disparity d_first-1 of the same line
         const uint32_t above = dppu<0x101>(kInf, Lp[0]);        // row_shl:1 - disparity d_first+KPL
         const uint32_t mp2 = M + a.P2;
-        const uint32_t negM = 0u - M;
+        uint32_t negM = 0u - M;
+        asm volatile("" : "+v"(negM));  // keep cc + t + negM a single three-operand add
         uint32_t Ln[KPL];
         uint32_t packed[KPL / 4];
 #pragma unroll
@@ -172,11 +179,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
             if ((k & 3) == 0) packed[k / 4] = l;
             else packed[k / 4] |= l << (8 * (k & 3));
         }
-#if !defined(FUSED_ABL) || FUSED_ABL != 1
         if (lane_active) __builtin_memcpy(pO, packed, KPL);
-#else
-        if (lane_active && packed[0] == 0xdeadbeefu) __builtin_memcpy(pO, packed, KPL);
-#endif
         uint32_t lmin = Ln[0];
 #pragma unroll
         for (int k = 1; k < KPL; ++k) lmin = umin2(lmin, Ln[k]);
@@ -192,9 +195,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
         uint32_t lmin;
         if (__all(lane_all || !lane_active)) lmin = body(slot, std::true_type{}, pix_ok, u);
         else lmin = body(slot, std::false_type{}, pix_ok, u);
-#if !defined(FUSED_ABL) || FUSED_ABL != 2
         prefetch(slot);
-#endif
         M = row_allmin_u(lmin);
         // advance; a diagonal line that leaves the image re-enters on the other side and the path restarts
         r += dr;
