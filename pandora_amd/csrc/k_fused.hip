@@ -250,53 +250,85 @@ __device__ __forceinline__ bool cell_is_nan(const sum8_args& a, int r, int c, in
 #define FMSK_INVALID 0x3C3LL
 #define FMSK_STOPPED 0x8LL
 
-// WTA over the summed volume: one wavefront per pixel, lane = 4 disparities; (sum, index) packed in
-// one uint32 key so that a single DPP min-reduce gives the first minimum (disparity.py:482-516).
+// WTA over the summed volume (disparity.py:399-516 on S = sum of the eight byte volumes).
+// Four pixels per wavefront, one per 16-lane DPP row; lane `sub` owns NB dwords = 4*NB consecutive
+// disparities of its pixel, i.e. ONE NB-dword load per direction volume (the texture addresser charges
+// per instruction, so few wide loads).  The bytes are summed SWAR-style (even/odd bytes in 16-bit fields),
+// (sum, index) is packed into one uint32 key per disparity so a single row min-reduce gives the FIRST
+// minimum, and the winner's lane also writes (S[k-1], S[k], S[k+1], k) for the refinement step.
+template <int NB>
 __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix, double d0, float invalid_disparity,
                                                        float* __restrict__ disp, int64_t* __restrict__ validity,
                                                        float4* __restrict__ near) {
+    constexpr int NE = 4 * NB;  // disparities per lane
     const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t nwaves = (size_t)gridDim.x * 4;
-    const int d_first = lane * 4;
-    for (size_t pix = wave; pix < npix; pix += nwaves) {
+    const int d_first = sub * NE;
+    const bool lane_active = d_first < a.D;
+    const size_t vol = (size_t)a.H * a.W * a.Dp;
+    const uint32_t wvalid = (uint32_t)(a.W - 2 * a.o);
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);  // surplus rows repeat the last pixel (same values)
         const int r = (int)(pix / a.W), c = (int)(pix - (size_t)r * a.W);
-        uint32_t key = 0xffffffffu;
-        uint32_t s[4] = {0, 0, 0, 0};
-        bool ok[4] = {false, false, false, false};
-        if (d_first < a.D) {
-            uint32_t lo, hi;
-            sum8_quad(a, pix * a.Dp + d_first, lo, hi);
-            s[0] = lo & 0xffffu; s[1] = hi & 0xffffu; s[2] = lo >> 16; s[3] = hi >> 16;
+        // ---- sum of the 8 directions: s[e] for the lane's NE disparities (0 outside the volume)
+        uint32_t lo[NB], hi[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int d = d_first + k;
-                ok[k] = d < a.D && !cell_is_nan(a, r, c, d);
-                if (ok[k]) key = umin2(key, (s[k] << 16) | (uint32_t)d);
+        for (int q = 0; q < NB; ++q) { lo[q] = 0; hi[q] = 0; }
+        const uint8_t* base = a.ldir + pix * a.Dp + (lane_active ? d_first : 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x[NB];
+            __builtin_memcpy(x, base + k * vol, 4 * NB);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                lo[q] += x[q] & 0x00ff00ffu;         // bytes 0 and 2 of the dword
+                hi[q] += (x[q] >> 8) & 0x00ff00ffu;  // bytes 1 and 3
             }
         }
-        key = wave_min_u(key);
-        // keep the winner's neighbourhood (S[k-1], S[k], S[k+1], k) for the refinement step: the lanes
-        // that own those disparities write them, so refinement never re-reads the eight volumes
-        {
-            const int kb = (key == 0xffffffffu) ? -4 : (int)(key & 0xffffu);
-            float* np = reinterpret_cast<float*>(near + pix);
+        uint32_t s[NE];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int d = d_first + k;
-                const int j = d - kb + 1;  // 0,1,2 = left neighbour, winner, right neighbour
-                if (d < a.D && j >= 0 && j <= 2) np[j] = ok[k] ? (float)s[k] : g_nan();
-            }
-            if (lane == 0) np[3] = __int_as_float(kb);
+        for (int q = 0; q < NB; ++q) {
+            s[4 * q] = lo[q] & 0xffffu; s[4 * q + 1] = hi[q] & 0xffffu; s[4 * q + 2] = lo[q] >> 16; s[4 * q + 3] = hi[q] >> 16;
         }
-        if (lane == 0) {
-            if (key == 0xffffffffu) {
-                disp[pix] = invalid_disparity;
-                int64_t m = validity[pix];
-                if ((m & FMSK_INVALID) == 0) validity[pix] = FMSK_INVALID;
-            } else {
-                disp[pix] = (float)(d0 + (double)(key & 0xffffu));
+        // ---- which of the lane's cells are NaN in the census volume (geometry only on this path)
+        const bool pix_ok = (r >= a.o) && (r < a.H - a.o) && (c >= a.o) && (c < a.W - a.o);
+        const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
+        uint32_t okbits = 0, key = 0xffffffffu;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const bool ok = lane_active && pix_ok && (d_first + e < a.D) && (u + (uint32_t)e < wvalid);
+            okbits |= ok ? (1u << e) : 0u;
+            if (ok) key = umin2(key, (s[e] << 16) | (uint32_t)(d_first + e));
+        }
+        key = row_allmin_u(key);  // every lane of the row now holds the pixel's (min sum, first index)
+        const bool none = key == 0xffffffffu;
+        const int kb = none ? -8 : (int)(key & 0xffffu);
+        // ---- the winner's lane fetches its neighbours (possibly from the adjacent lane) and writes the result
+        const uint32_t s_below = dppu<0x111>(0u, s[NE - 1]), ok_below = dppu<0x111>(0u, okbits >> (NE - 1));  // row_shr:1
+        const uint32_t s_above = dppu<0x101>(0u, s[0]), ok_above = dppu<0x101>(0u, okbits & 1u);             // row_shl:1
+        const int eb = kb - d_first;  // winner's slot in this lane, if 0 <= eb < NE
+        if (eb >= 0 && eb < NE && lane_active) {
+            uint32_t c0 = 0, c2 = 0;
+            bool v0 = false, v2 = false;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                if (e == eb) {
+                    c0 = (e > 0) ? s[e > 0 ? e - 1 : 0] : s_below;
+                    v0 = (e > 0) ? ((okbits >> (e > 0 ? e - 1 : 0)) & 1u) : (ok_below & 1u);
+                    c2 = (e < NE - 1) ? s[e < NE - 1 ? e + 1 : 0] : s_above;
+                    v2 = (e < NE - 1) ? ((okbits >> (e < NE - 1 ? e + 1 : 0)) & 1u) : (ok_above & 1u);
+                }
             }
+            near[pix] = make_float4(v0 ? (float)c0 : g_nan(), (float)(key >> 16), v2 ? (float)c2 : g_nan(), __int_as_float(kb));
+            disp[pix] = (float)(d0 + (double)kb);
+        }
+        if (none && sub == 0) {
+            near[pix] = make_float4(g_nan(), g_nan(), g_nan(), __int_as_float(-8));
+            disp[pix] = invalid_disparity;  // disparity.py:452-455
+            int64_t m = validity[pix];
+            if ((m & FMSK_INVALID) == 0) validity[pix] = FMSK_INVALID;  // disparity.py:471-474
         }
     }
 }
@@ -439,11 +471,21 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
 
 int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity) {
     size_t npix = (size_t)cv->H * cv->W;
-    size_t want = (npix + 3) / 4;
-    int grid = (int)(want < 32768 ? want : 32768);
+    size_t want = (npix + 15) / 16;  // 4 pixels per wave, 4 waves per block
+    int grid = (int)(want < 65536 ? want : 65536);
+    const int nb = (cv->Dp + 63) / 64;  // dwords per lane so that 16 lanes cover the Dp bytes of a pixel
     pmx_stage_scope t(ctx, PMX_STAGE_WTA);
-    hipLaunchKernelGGL(sum8_wta_kernel, dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), npix, (double)cv->d0,
-                       invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near);
+#define PMX_WTA8(NBV)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sum8_wta_kernel<NBV>), dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), npix, \
+                       (double)cv->d0, invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near)
+    switch (nb) {
+        case 1: PMX_WTA8(1); break;
+        case 2: PMX_WTA8(2); break;
+        case 3: PMX_WTA8(3); break;
+        case 4: PMX_WTA8(4); break;
+        default: PMX_WTA8(5); break;
+    }
+#undef PMX_WTA8
     PMX_HIP(hipGetLastError());
     ctx->near_owner = cv;
     return PMX_OK;
