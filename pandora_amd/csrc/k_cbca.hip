@@ -131,95 +131,163 @@ struct cbca_args {
     int ring;    // power of two >= 2A+2
 };
 
-// combined arm lengths of the support cross at (r, c, k); false when the right position is outside
-__device__ __forceinline__ bool combined_arms(const cbca_args& a, int r, int c, int k, int& left, int& right, int& top, int& bot) {
-    int kk = k / a.subpix;
-    int ph = k - kk * a.subpix;
-    int q = c + a.d0 + kk;
-    int Wr = ph == 0 ? a.Wc : a.Wc - 1;
-    if (q < 0 || q > Wr - 1) return false;  // cbca.py:156-158
-    short4 al = *reinterpret_cast<const short4*>(a.armsL + ((size_t)r * a.Wc + c) * 4);
-    short4 ar = *reinterpret_cast<const short4*>(a.armsR[ph] + ((size_t)r * Wr + q) * 4);
-    left = min((int)al.x, (int)ar.x);
-    right = min((int)al.y, (int)ar.y);
-    top = min((int)al.z, (int)ar.z);
-    bot = min((int)al.w, (int)ar.w);
-    return true;
+// combined arm lengths of the support cross at (r, c, k) packed as left | right<<8 | top<<16 | bot<<24;
+// 0xffffffff when the right position is outside the image (cbca.py:156-158)
+struct arm_pair {
+    short4 l, r;
+    bool inside;
+};
+
+__device__ __forceinline__ arm_pair load_arms(const cbca_args& a, int r, int c, int ph, int q) {
+    arm_pair p;
+    const int Wr = ph == 0 ? a.Wc : a.Wc - 1;
+    p.inside = (q >= 0) && (q <= Wr - 1);
+    const int qq = p.inside ? q : 0;
+    p.l = *reinterpret_cast<const short4*>(a.armsL + ((size_t)r * a.Wc + c) * 4);
+    p.r = *reinterpret_cast<const short4*>(a.armsR[ph] + ((size_t)r * Wr + qq) * 4);
+    return p;
 }
 
-// pass H: steps 1-2 (aggregation.cpp:28-121).  thread = (row, k); E_h(c) is emitted A columns late.
+__device__ __forceinline__ uint32_t combine(const arm_pair& p) {
+    if (!p.inside) return 0xffffffffu;
+    const uint32_t left = min((int)p.l.x, (int)p.r.x), right = min((int)p.l.y, (int)p.r.y);
+    const uint32_t top = min((int)p.l.z, (int)p.r.z), bot = min((int)p.l.w, (int)p.r.w);
+    return left | (right << 8) | (top << 16) | (bot << 24);
+}
+
+static constexpr int kCbcaPF = 8;  // rows / columns of read-ahead (register ring)
+
+// pass H: steps 1-2 (aggregation.cpp:28-121).  thread = (row, k) marches along the columns; the
+// segment sum E_h(c) needs the running sums up to A columns ahead, so it is emitted A columns late
+// from an LDS ring.  The cost stream and the arms are read kCbcaPF columns ahead into registers:
+// the scan itself is a serial fp32 dependency (the reference's rounding), the loads are not.
 __global__ __launch_bounds__(kBlock) void cbca_h_kernel(cbca_args a) {
     extern __shared__ float ring[];  // [ring][kBlock]
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int total = a.Hc * a.D;
-    if (t >= total) return;
-    const int r = t / a.D, k = t - r * a.D;
+    const bool live = t < total;
+    const int tt = live ? t : total - 1;
+    const int r = tt / a.D, k = tt - r * a.D;
+    const int kk = k / a.subpix, ph = k - kk * a.subpix, dq = a.d0 + kk;
     const int mask = a.ring - 1;
     float* my = ring + threadIdx.x;
     const size_t row_off = ((size_t)(r + a.o) * a.W + a.o) * a.D + k;
+    const int last = a.Wc - 1;
+    float vbuf[kCbcaPF];
+    arm_pair abuf[kCbcaPF];
+#pragma unroll
+    for (int j = 0; j < kCbcaPF; ++j) {
+        vbuf[j] = a.cv[row_off + (size_t)min(j, last) * a.D];
+        const int ce = min(max(j - a.A, 0), last);
+        abuf[j] = load_arms(a, r, ce, ph, ce + dq);
+    }
     float acc = 0.f;
-    for (int c = 0; c < a.Wc + a.A; ++c) {
-        if (c < a.Wc) {
-            float v = a.cv[row_off + (size_t)c * a.D];
-            if (v == v) acc = acc + v;  // NaN is skipped, the running sum carries on
-            my[(c & mask) * kBlock] = acc;
-        }
-        int ce = c - a.A;  // column whose segment sum can now be emitted
-        if (ce >= 0) {
-            int left, right, top, bot;
-            float e = 0.f;
-            if (combined_arms(a, r, ce, k, left, right, top, bot)) {
-                int lo = ce - left - 1;
-                float hi_v = my[((ce + right) & mask) * kBlock];
-                float lo_v = lo < 0 ? 0.f : my[(lo & mask) * kBlock];
-                e = hi_v - lo_v;
+    const int nsteps = a.Wc + a.A;
+    for (int c0 = 0; c0 < nsteps; c0 += kCbcaPF) {
+#pragma unroll
+        for (int j = 0; j < kCbcaPF; ++j) {
+            const int c = c0 + j;
+            const float v = vbuf[j];
+            const uint32_t arms = combine(abuf[j]);
+            {   // refill the slot with column c + kCbcaPF (clamped: surplus loads re-read the last column)
+                const int cn = c + kCbcaPF;
+                vbuf[j] = a.cv[row_off + (size_t)min(cn, last) * a.D];
+                const int ce = min(max(cn - a.A, 0), last);
+                abuf[j] = load_arms(a, r, ce, ph, ce + dq);
             }
-            a.eh[row_off + (size_t)ce * a.D] = e;
+            if (c < a.Wc) {
+                if (v == v) acc = acc + v;  // NaN is skipped, the running sum carries on
+                my[(c & mask) * kBlock] = acc;
+            }
+            const int ce = c - a.A;  // column whose segment sum can now be emitted
+            if (ce >= 0 && ce < a.Wc && c < nsteps) {
+                float e = 0.f;
+                if (arms != 0xffffffffu) {
+                    const int left = arms & 0xff, right = (arms >> 8) & 0xff;
+                    const int lo = ce - left - 1;
+                    const float hi_v = my[((ce + right) & mask) * kBlock];
+                    const float lo_v = lo < 0 ? 0.f : my[(lo & mask) * kBlock];
+                    e = hi_v - lo_v;
+                }
+                if (live) a.eh[row_off + (size_t)ce * a.D] = e;
+            }
         }
     }
 }
 
-// pass V: steps 3-4 + normalisation (aggregation.cpp:123-221, cbca.py:166-171).  thread = (col, k).
+// pass V: steps 3-4 + normalisation (aggregation.cpp:123-221, cbca.py:166-171).  thread = (col, k) marches
+// down the rows; the LDS ring holds the column prefix sums S3 and, packed in one word, n_h | top | bot of
+// every row still needed (so the emit stage never re-reads the arms).
 __global__ __launch_bounds__(kBlock) void cbca_v_kernel(cbca_args a) {
-    extern __shared__ float ring[];  // [2][ring][kBlock]: column prefix sums, n_h
+    extern __shared__ float ring[];  // [2][ring][kBlock]: column prefix sums; packed (n_h, top, bot)
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int total = a.Wc * a.D;
-    if (t >= total) return;
-    const int c = t / a.D, k = t - c * a.D;
+    const bool live = t < total;
+    const int tt = live ? t : total - 1;
+    const int c = tt / a.D, k = tt - c * a.D;
+    const int kk = k / a.subpix, ph = k - kk * a.subpix, q = c + a.d0 + kk;
     const int mask = a.ring - 1;
     float* s3 = ring + threadIdx.x;
-    float* nh = ring + (size_t)a.ring * kBlock + threadIdx.x;
+    uint32_t* info = reinterpret_cast<uint32_t*>(ring) + (size_t)a.ring * kBlock + threadIdx.x;
     const size_t col_off = ((size_t)a.o * a.W + (c + a.o)) * a.D + k;
     const size_t row_stride = (size_t)a.W * a.D;
+    const int last = a.Hc - 1;
+    float ebuf[kCbcaPF], cbuf[kCbcaPF];
+    arm_pair abuf[kCbcaPF];
+#pragma unroll
+    for (int j = 0; j < kCbcaPF; ++j) {
+        const int rr = min(j, last);
+        ebuf[j] = a.eh[col_off + (size_t)rr * row_stride];
+        abuf[j] = load_arms(a, rr, c, ph, q);
+        cbuf[j] = a.cv[col_off + (size_t)min(max(j - a.A, 0), last) * row_stride];
+    }
     float acc = 0.f;
-    for (int r = 0; r < a.Hc + a.A; ++r) {
-        if (r < a.Hc) {
-            float e = a.eh[col_off + (size_t)r * row_stride];
-            acc = (r == 0) ? e : acc + e;
-            s3[(r & mask) * kBlock] = acc;
-            int left, right, top, bot;
-            float n = 0.f;
-            if (combined_arms(a, r, c, k, left, right, top, bot)) n = (float)(left + right);
-            nh[(r & mask) * kBlock] = n;
-        }
-        int re = r - a.A;
-        if (re >= 0) {
-            int left, right, top, bot;
-            float step4 = 0.f;
-            float sum4 = nh[(re & mask) * kBlock];
-            if (combined_arms(a, re, c, k, left, right, top, bot)) {
-                int lo = re - top - 1;
-                float hi_v = s3[((re + bot) & mask) * kBlock];
-                float lo_v = lo < 0 ? 0.f : s3[(lo & mask) * kBlock];
-                step4 = hi_v - lo_v;
-                sum4 += (float)(top + bot);
-                if (top > 0) { float s = 0.f; for (int i = 1; i <= top; ++i) s += nh[((re - i) & mask) * kBlock]; sum4 += s; }
-                if (bot > 0) { float s = 0.f; for (int i = 1; i <= bot; ++i) s += nh[((re + i) & mask) * kBlock]; sum4 += s; }
+    uint32_t nacc = 0;
+    const int nsteps = a.Hc + a.A;
+    for (int r0 = 0; r0 < nsteps; r0 += kCbcaPF) {
+#pragma unroll
+        for (int j = 0; j < kCbcaPF; ++j) {
+            const int r = r0 + j;
+            const float e = ebuf[j];
+            const float in = cbuf[j];
+            const uint32_t arms = combine(abuf[j]);
+            {   // refill with row r + kCbcaPF (clamped)
+                const int rn = min(r + kCbcaPF, last);
+                ebuf[j] = a.eh[col_off + (size_t)rn * row_stride];
+                abuf[j] = load_arms(a, rn, c, ph, q);
+                cbuf[j] = a.cv[col_off + (size_t)min(max(r + kCbcaPF - a.A, 0), last) * row_stride];
             }
-            sum4 += 1.f;
-            size_t id = col_off + (size_t)re * row_stride;
-            float in = a.cv[id];
-            a.cv[id] = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
+            if (r < a.Hc) {
+                acc = (r == 0) ? e : acc + e;
+                s3[(r & mask) * kBlock] = acc;
+                // ring word: running count N(r) = sum_{i<=r} n_h(i) in bits 0..19 (n_h = left+right, 0 outside the
+                // right image), top in bits 20..25, bot in bits 26..31 (63,63 = this cell is outside).
+                // The support size of step 4 (aggregation.cpp:199-215) then is two ring reads instead of loops:
+                //   n_h(r) + sum_{i=1..top} n_h(r-i) + sum_{i=1..bot} n_h(r+i) = N(r+bot) - N(r-top-1)
+                uint32_t tb = (63u << 20) | (63u << 26);
+                if (arms != 0xffffffffu) {
+                    nacc += (arms & 0xff) + ((arms >> 8) & 0xff);
+                    tb = (((arms >> 16) & 0xff) << 20) | ((arms >> 24) << 26);
+                }
+                info[(r & mask) * kBlock] = nacc | tb;
+            }
+            const int re = r - a.A;
+            if (re >= 0 && re < a.Hc && r < nsteps) {
+                const uint32_t w = info[(re & mask) * kBlock];
+                float step4 = 0.f, sum4 = 0.f;
+                const int top = (w >> 20) & 63, bot = w >> 26;
+                if (top != 63) {
+                    const int lo = re - top - 1;
+                    const float hi_v = s3[((re + bot) & mask) * kBlock];
+                    const float lo_v = lo < 0 ? 0.f : s3[(lo & mask) * kBlock];
+                    step4 = hi_v - lo_v;
+                    const uint32_t n_hi = info[((re + bot) & mask) * kBlock] & 0xfffffu;
+                    const uint32_t n_lo = lo < 0 ? 0u : (info[(lo & mask) * kBlock] & 0xfffffu);
+                    sum4 = (float)(n_hi - n_lo + (uint32_t)(top + bot));  // small exact integers: any order
+                }
+                sum4 += 1.f;
+                if (live) a.cv[col_off + (size_t)re * row_stride] = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
+            }
         }
     }
 }
