@@ -301,7 +301,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     size_t arm_bytes = (size_t)Hc * Wc * 4 * sizeof(int16_t);
     int rc = pmx_need_small(ctx, 2 * img_bytes + arm_bytes * (1 + cv->subpix));
     if (rc) return rc;
-    rc = pmx_need_scratch(ctx, cv->cells() * sizeof(float) + 64);
+    rc = pmx_need_scratch(ctx, cv->cells() * sizeof(float) + 256);
     if (rc) return rc;
     char* base = (char*)ctx->small;
     float* tmp = (float*)base;

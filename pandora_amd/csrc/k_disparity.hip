@@ -48,24 +48,73 @@ __device__ __forceinline__ void wave_argbest(const float* __restrict__ p, int D,
     }
 }
 
-template <bool IS_MAX>
+// orderable(f): unsigned key with the same order as the float (NaN never reaches here)
+__device__ __forceinline__ uint32_t orderable_f(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    hi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// min over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ uint64_t row_allmin_u64(uint64_t v) {
+    uint64_t o;
+    o = dpp64<0x128>(v); v = o < v ? o : v;  // row_ror:8
+    o = dpp64<0x124>(v); v = o < v ? o : v;  // row_ror:4
+    o = dpp64<0x122>(v); v = o < v ? o : v;  // row_ror:2
+    o = dpp64<0x121>(v); v = o < v ? o : v;  // row_ror:1
+    return v;
+}
+
+// WTA on a float32 volume: four pixels per wavefront (one per 16-lane DPP row), lane `sub` owns NE = 4*NB
+// consecutive disparities read with NB 16-byte loads (few wide loads: the texture addresser charges per
+// instruction).  (orderable cost, index) is one uint64 key per disparity, so a row min-reduce yields the
+// FIRST extremum exactly like np.argmin / np.argmax (disparity.py:511,548); NaN counts as +/-inf (:434-446).
+template <bool IS_MAX, int NB>
 __global__ __launch_bounds__(kBlock) void wta_kernel(const float* __restrict__ cv, size_t npix, int D, double d0, int subpix,
                                                      float invalid_disparity, float* __restrict__ disp,
                                                      int64_t* __restrict__ validity) {
+    constexpr int NE = 4 * NB;
     const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
     const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
-    for (size_t pix = wave; pix < npix; pix += nwaves) {
-        float v;
-        int idx, any;
-        wave_argbest<IS_MAX>(cv + pix * (size_t)D, D, lane, v, idx, any);
-        if (lane == 0) {
-            if (!any) {
+    const int d_first = sub * NE;
+    const bool lane_active = d_first < D;
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);  // surplus rows repeat the last pixel (same values)
+        float x[NE];
+        __builtin_memcpy(x, cv + pix * (size_t)D + (lane_active ? d_first : 0), sizeof(float) * NE);  // the volume has a tail pad
+        uint64_t key = ~0ull;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            float v = x[e];
+            const bool in = lane_active && (d_first + e < D);
+            const bool finite = in && (v == v);
+            any = any || finite;
+            if (!(v == v)) v = IS_MAX ? -d_inf() : d_inf();
+            if (IS_MAX) v = -v;
+            if (v == 0.f) v = 0.f;  // -0 and +0 must tie
+            const uint64_t kk = ((uint64_t)orderable_f(v) << 32) | (uint32_t)(d_first + e);
+            if (in) key = kk < key ? kk : key;
+        }
+        key = row_allmin_u64(key);
+        const unsigned long long bal = __ballot(any);
+        const bool row_any = ((bal >> (grp * 16)) & 0xffffull) != 0;
+        if (sub == 0) {
+            if (!row_any) {
                 disp[pix] = invalid_disparity;  // disparity.py:452-455
                 int64_t m = validity[pix];
                 if ((m & MSK_INVALID) == 0) validity[pix] = MSK_INVALID;  // disparity.py:471-474
             } else {
-                disp[pix] = (float)(d0 + (double)idx / (double)subpix);
+                disp[pix] = (float)(d0 + (double)(uint32_t)key / (double)subpix);
             }
         }
     }
@@ -73,15 +122,31 @@ __global__ __launch_bounds__(kBlock) void wta_kernel(const float* __restrict__ c
 
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity) {
     size_t npix = (size_t)cv->H * cv->W;
-    size_t want = (npix + 3) / 4;
-    int grid = (int)(want < 16384 ? want : 16384);
+    size_t want = (npix + 15) / 16;
+    int grid = (int)(want < 65536 ? want : 65536);
+    const int nb = (cv->D + 63) / 64;
     pmx_stage_scope t(ctx, PMX_STAGE_WTA);
-    if (is_max)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wta_kernel<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix, cv->D,
-                           (double)cv->d0, cv->subpix, invalid_disparity, ctx->disp, ctx->validity);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wta_kernel<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix, cv->D,
-                           (double)cv->d0, cv->subpix, invalid_disparity, ctx->disp, ctx->validity);
+#define PMX_WTA(MAXV, NBV)                                                                                             \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(wta_kernel<MAXV, NBV>), dim3(grid), dim3(kBlock), 0, ctx->stream, cv->data, npix, \
+                       cv->D, (double)cv->d0, cv->subpix, invalid_disparity, ctx->disp, ctx->validity)
+#define PMX_WTA_NB(MAXV)                 \
+    switch (nb) {                        \
+        case 1: PMX_WTA(MAXV, 1); break; \
+        case 2: PMX_WTA(MAXV, 2); break; \
+        case 3: PMX_WTA(MAXV, 3); break; \
+        case 4: PMX_WTA(MAXV, 4); break; \
+        case 5: PMX_WTA(MAXV, 5); break; \
+        case 6: PMX_WTA(MAXV, 6); break; \
+        case 7: PMX_WTA(MAXV, 7); break; \
+        default: PMX_WTA(MAXV, 8); break; \
+    }
+    if (cv->D > 512) {
+        pmx_set_error("pmx_wta: D = %d > 512 disparities not supported", cv->D);
+        return PMX_ERR_UNSUPPORTED;
+    }
+    if (is_max) { PMX_WTA_NB(true) } else { PMX_WTA_NB(false) }
+#undef PMX_WTA_NB
+#undef PMX_WTA
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -217,7 +217,7 @@ static int sgm_run(pmx_ctx* ctx, const sgm_args& base) {
 
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting) {
     // accumulator volume: the context's scratch; +64 B so the over-read of a lane's tail is in bounds
-    size_t bytes = cv->cells() * sizeof(float) + 64;
+    size_t bytes = cv->cells() * sizeof(float) + 256;
     int rc = pmx_need_scratch(ctx, bytes);
     if (rc) return rc;
     if (cv->bytes < bytes) {

@@ -208,7 +208,7 @@ extern "C" pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0) {
     pmx_cv* cv = new pmx_cv();
     cv->ctx = ctx;
     cv->H = ctx->H; cv->W = ctx->W; cv->D = D; cv->d0 = d0; cv->subpix = ctx->subpix;
-    cv->bytes = cv->cells() * sizeof(float) + 64;  // tail pad: wide per-lane loads of the last pixel stay in bounds
+    cv->bytes = cv->cells() * sizeof(float) + 256;  // tail pad: wide per-lane loads of the last pixel stay in bounds
     hipError_t e = hipMalloc((void**)&cv->data, cv->bytes);
     if (e != hipSuccess) {
         pmx_set_error("pmx_cv_alloc: hipMalloc(%zu bytes) failed: %s", cv->bytes, hipGetErrorString(e));
