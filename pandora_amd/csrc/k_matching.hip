@@ -218,6 +218,56 @@ __global__ __launch_bounds__(kBlock) void census_cost_kernel(pmx_mc_params p, co
     }
 }
 
+// subpix == 1 fast variant: four pixels per wavefront (one per 16-lane row).  Lane `sub` owns, for each
+// block q < NB, the four disparities 64q + 4*sub + {0..3}: every 16-byte load of right codes and every
+// 16-byte store of costs is lane-contiguous (256 B per row per instruction), and there are few of them -
+// the texture addresser charges per instruction.  Codes carry kCodePad guard dwords on both sides.
+template <int NW, int NB>
+__global__ __launch_bounds__(kBlock) void census_cost4_kernel(pmx_mc_params p, const uint32_t* __restrict__ codeL,
+                                                               const uint32_t* __restrict__ codeR, float* __restrict__ cv) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const size_t npix = (size_t)p.H * p.W;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    const int o = p.win / 2;
+    const uint32_t wvalid = (uint32_t)(p.W - 2 * o);
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);  // surplus rows repeat the last pixel (same values)
+        const int r = (int)(pix / p.W), c = (int)(pix - (size_t)r * p.W);
+        uint32_t lc[NW];
+        __builtin_memcpy(lc, codeL + pix * NW, sizeof(uint32_t) * NW);
+        const bool pix_ok = (r >= o) && (r < p.H - o) && (c >= o) && (c < p.W - o);
+        float* const dst = cv + pix * (size_t)p.D;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int d_first = 64 * q + 4 * sub;
+            if (d_first < p.D) {  // (wave-uniform for all blocks but the last)
+                uint32_t rc[4 * NW];
+                __builtin_memcpy(rc, codeR + ((ptrdiff_t)pix + p.d0 + d_first) * NW, sizeof(uint32_t) * 4 * NW);
+                const uint32_t u = (uint32_t)(c + p.d0 + d_first - o);  // cell e valid iff u + e < wvalid (unsigned)
+                float out[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int w = 0;
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) w += __popc(lc[i] ^ rc[e * NW + i]);
+                    float val = (pix_ok && (u + (uint32_t)e < wvalid)) ? (float)w : qnan();
+                    if (p.apply_mask && val == val && cell_masked(p, r, c, d_first + e, 0, c + p.d0 + d_first + e)) val = qnan();
+                    out[e] = val;
+                }
+                if (d_first + 4 <= p.D) {
+                    __builtin_memcpy(dst + d_first, out, sizeof(float) * 4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (d_first + e < p.D) dst[d_first + e] = out[e];
+                }
+            }
+        }
+    }
+}
+
 static constexpr size_t kCodePad = 1024;  // dwords readable before/after each code image (fast path over-reads)
 
 // census codes of the resident pair into buffers owned by the volume handle
@@ -262,6 +312,27 @@ static int census_costs(pmx_ctx* ctx, pmx_cv* cv) {
     for (int k = 0; k < PMX_MAX_SUBPIX; ++k) cp.right[k] = k < cv->subpix ? cv->codeL + (per_img + kCodePad) * (size_t)(k + 1) : nullptr;
     pmx_mc_params p = make_params(ctx, cv, cv->win);
     pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
+    if (cv->subpix == 1 && cv->D <= 512 && abs(cv->d0) + cv->D <= (int)kCodePad / NW - 64) {
+        size_t want = ((size_t)H * W + 15) / 16;
+        int grid = (int)(want < 65536 ? want : 65536);
+        const int nb = (cv->D + 63) / 64;
+#define PMX_CC4(NBV) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost4_kernel<NW, NBV>), dim3(grid), dim3(kBlock), 0, ctx->stream, p, cv->codeL, cv->codeR, cv->data)
+        switch (nb) {
+            case 1: PMX_CC4(1); break;
+            case 2: PMX_CC4(2); break;
+            case 3: PMX_CC4(3); break;
+            case 4: PMX_CC4(4); break;
+            case 5: PMX_CC4(5); break;
+            case 6: PMX_CC4(6); break;
+            case 7: PMX_CC4(7); break;
+            default: PMX_CC4(8); break;
+        }
+#undef PMX_CC4
+        PMX_HIP(hipGetLastError());
+        cv->repr = PMX_REPR_FLOAT;
+        return PMX_OK;
+    }
     int threads_per_row = (W * cv->D + 3) / 4 + 1;
     dim3 grid((threads_per_row + kBlock - 1) / kBlock, H);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_kernel<NW>), grid, dim3(kBlock), 0, ctx->stream, p, cp, cv->data);
