@@ -137,8 +137,11 @@ void orc_sad_ssd(const float* L, const float* Rs, int H, int W, int D, int d0, i
                          (c - o + fl >= 0) && (c + o + fl < Wk);
                 if (ok) {
                     float s = 0.f;
-                    for (int i = -o; i <= o; ++i)
-                        for (int j = -o; j <= o; ++j) {
+                    /* np.sum over the two leading (stride-sorted) window axes of the (disp,col,row) buffer
+                     * (sad_ssd.py:340-368) adds sequentially in memory order: window columns outer, window
+                     * rows inner - pinned by tests/golden/sad_float_order.npz. */
+                    for (int j = -o; j <= o; ++j)
+                        for (int i = -o; i <= o; ++i) {
                             float d = L[(size_t)(r + i) * W + c + j] - R[(size_t)(r + i) * Wk + c + j + fl];
                             s += squared ? d * d : fabsf(d);
                         }

@@ -397,7 +397,7 @@ int pmx_launch_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win) {
 }
 
 // ---- SAD / SSD (sad_ssd.py:146-207, 226-368) ---------------------------------------------------
-// float32 window sum, rows outer / columns inner (bit-exact on integer-valued images).
+// float32 window sum in the reference's order: window columns outer, rows inner, sequential.
 __global__ __launch_bounds__(kBlock) void sad_ssd_kernel(pmx_mc_params p, int squared, float* __restrict__ cv) {
     const int r = blockIdx.y;
     int j = blockIdx.x * kBlock + threadIdx.x;
@@ -410,14 +410,11 @@ __global__ __launch_bounds__(kBlock) void sad_ssd_kernel(pmx_mc_params p, int sq
         int wk = g.ph == 0 ? p.W : p.W - 1;
         const float* R = p.right[g.ph];
         float s = 0.f;
-        for (int i = -o; i <= o; ++i) {
-            const float* lrow = p.left + (size_t)(r + i) * p.W + c;
-            const float* rrow = R + (size_t)(r + i) * wk + g.q;
-            for (int jj = -o; jj <= o; ++jj) {
-                float d = lrow[jj] - rrow[jj];
+        for (int jj = -o; jj <= o; ++jj)  // window columns outer, rows inner: numpy's order (sad_ssd.py:367)
+            for (int i = -o; i <= o; ++i) {
+                float d = p.left[(size_t)(r + i) * p.W + c + jj] - R[(size_t)(r + i) * wk + g.q + jj];
                 s = s + (squared ? d * d : fabsf(d));
             }
-        }
         val = s;
     }
     cv[(size_t)r * p.W * p.D + j] = val;
@@ -436,7 +433,8 @@ int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared) {
 // Window statistics in float64 (the reference's integral images are float64): mean and std of
 // every full window, std with the float32 squares and the 1e-15 clip of img_tools.py:941-951.
 __global__ __launch_bounds__(kBlock) void window_stats_kernel(const float* __restrict__ img, int H, int Wd, int win,
-                                                              double* __restrict__ mean, double* __restrict__ sd) {
+                                                              double* __restrict__ mean, double* __restrict__ sd,
+                                                              double* __restrict__ isd) {
     int o = win / 2, Wo = Wd - 2 * o;
     int c = blockIdx.x * kBlock + threadIdx.x;
     int r = blockIdx.y;
@@ -453,8 +451,10 @@ __global__ __launch_bounds__(kBlock) void window_stats_kernel(const float* __res
     double m = s / n, m2 = s2 / n;
     double var = m2 - m * m;
     if (var < 1e-15 * fabs(m2)) var = 0;
+    const double s_ = sqrt(var);
     mean[(size_t)r * Wo + c] = m;
-    sd[(size_t)r * Wo + c] = sqrt(var);
+    sd[(size_t)r * Wo + c] = s_;
+    isd[(size_t)r * Wo + c] = s_ > 0 ? 1.0 / s_ : 0.0;  // marching kernel: z = cov * isd_L * isd_R (0 when a std is 0)
 }
 
 struct zncc_stats {
@@ -495,34 +495,269 @@ __global__ __launch_bounds__(kBlock) void zncc_kernel(pmx_mc_params p, zncc_stat
     cv[(size_t)r * p.W * p.D + j] = val;
 }
 
+// ---- ZNCC, subpix == 1: marching kernel ---------------------------------------------------------
+// The reference gets the window mean of L*R_d from float64 integral images (img_tools.py:834-879), so any
+// float64 summation order is inside its own rounding noise; the contract is 1e-5 on the float32 result.
+// That licenses a separable, sliding evaluation that costs O(win) per cell instead of O(win^2):
+//   * a wavefront owns 64 adjacent columns (lane = column, 2o of them halo), kZnccND adjacent disparities and a
+//     strip of rows; the four wavefronts of a workgroup take four adjacent disparity chunks of the same columns;
+//   * every lane keeps colsum[e] = sum over the 2o+1 window ROWS of (double)(L*R) for its column in registers
+//     and slides it down the strip: + the row entering the window, - the row leaving it (2 products per cell);
+//   * the 2o+1 window COLUMNS are summed from the neighbour lanes' colsums through a wave-private LDS tile
+//     (conflict-free b64 reads, no workgroup barrier);
+//   * z = (box/n - mean_L*mean_R) * isd_L * isd_R, right-image statistics staged through LDS once per row;
+//   * the four chunks' results meet in LDS and leave as 128-byte runs per pixel (lane = 16 bytes of a pixel's
+//     32 disparities).  Lane-per-column stores of 32 bytes at a 4*D-byte stride cost 2x the whole kernel.
+// Loads are raw buffer loads: an offset outside the image returns 0 (rows above/below the image contribute
+// nothing), and offsets that run over a row end only ever feed cells that are NaN anyway.
+constexpr int kZnccND = 8;                      // disparities per lane
+constexpr int kZnccWaves = 4;                   // wavefronts (= disparity chunks) per workgroup
+constexpr int kZnccDB = kZnccND * kZnccWaves;   // disparities per workgroup
+constexpr int kZnccOutStride = kZnccDB + 4;     // floats per staged pixel row (16-byte aligned, skewed banks)
+
+struct zncc_march_params {
+    const float* left;
+    const float* right;
+    const double *lmean, *lisd, *rmean, *risd;
+    float* cv;
+    int H, W, D, d0, win;
+    int ntile, ndblock, nstrip, strip_rows;
+    uint32_t img_bytes, stat_bytes;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t zu32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t zu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    zu32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
+template <int WIN_T>  // window known at compile time (0: any)
+__global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_params q) {
+    constexpr int ND = kZnccND;
+    __shared__ double colbuf[kZnccWaves][ND][64];
+    __shared__ double rstat[kZnccWaves][2][64 + ND];  // [wave][mean|isd][column]
+    __shared__ __attribute__((aligned(16))) float ostage[2][64][kZnccOutStride];
+
+    const uint32_t logical = blockIdx.x;
+    const int dblock = logical % q.ndblock;
+    const int tile = (logical / q.ndblock) % q.ntile;
+    const int strip = logical / (q.ndblock * q.ntile);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int win = WIN_T ? WIN_T : q.win;
+    const int o = win / 2, W = q.W, H = q.H;
+    const int wo = W - 2 * o;                      // width of the statistics rasters
+    const int tile_c0 = tile * (64 - 2 * o);       // first output column of the tile
+    const int c = tile_c0 - o + lane;              // image column of this lane (halo lanes included)
+    const int k0 = dblock * kZnccDB + wv * ND;     // first disparity index of this wavefront's chunk
+    const bool chunk_live = k0 < q.D;
+    const int x0 = c + q.d0 + k0;                  // right-image column matched at e = 0
+    const int r0 = strip * q.strip_rows;
+    const int r1 = min(r0 + q.strip_rows, H);
+
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)q.left, 0, q.img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)q.right - kImgGuardBytes), 0,
+                                                                          q.img_bytes + 2 * (uint32_t)kImgGuardBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsLM = __builtin_amdgcn_make_buffer_rsrc((void*)q.lmean, 0, q.stat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsLI = __builtin_amdgcn_make_buffer_rsrc((void*)q.lisd, 0, q.stat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsRM = __builtin_amdgcn_make_buffer_rsrc((void*)q.rmean, 0, q.stat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsRI = __builtin_amdgcn_make_buffer_rsrc((void*)q.risd, 0, q.stat_bytes, 0x00020000);
+    constexpr uint32_t kOob = 0xfffffff0u;
+
+    // raw loads of one image row for this lane's ND cells (zeros outside the image rows)
+    struct row_vals { float lv; float rv[ND]; };
+    auto load_row = [&](int row, row_vals& v) {
+        const bool in = chunk_live && (row >= 0) && (row < H);
+        const uint32_t offL = in ? (uint32_t)((row * W + c) * 4) : kOob;
+        const uint32_t offR = in ? (uint32_t)((row * W + x0) * 4 + (int)kImgGuardBytes) : kOob;  // (guarded: pmx_api img_alloc)
+        v.lv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsL, offL, 0, 0));
+#pragma unroll
+        for (int i = 0; i < ND / 4; ++i) {
+            // (__uint_as_float, not __builtin_bit_cast(float, t.y): this clang reads element 0 for every
+            //  bit_cast of a vector-element lvalue)
+            zu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsR, offR + 16 * i, 0, 0);
+            v.rv[4 * i + 0] = __uint_as_float(t.x);
+            v.rv[4 * i + 1] = __uint_as_float(t.y);
+            v.rv[4 * i + 2] = __uint_as_float(t.z);
+            v.rv[4 * i + 3] = __uint_as_float(t.w);
+        }
+    };
+    // statistics of output row r: left for the lane's own pixel, right for columns x0 (and x0+64 for lane < ND)
+    struct stat_vals { double mL, iL, rm0, ri0, rm1, ri1; };
+    const bool col_ok = (c >= o) && (c < W - o);
+    auto load_stats = [&](int r, stat_vals& s) {
+        const bool row_ok = chunk_live && (r >= o) && (r < H - o);
+        const uint32_t srow = row_ok ? (uint32_t)((r - o) * wo) : 0u;
+        const uint32_t offLs = (row_ok && col_ok) ? (srow + (uint32_t)(c - o)) * 8u : kOob;
+        s.mL = buf_load_f64(rsLM, offLs);
+        s.iL = buf_load_f64(rsLI, offLs);
+        const int xs = x0 - o;  // statistics column of right pixel x0
+        const bool ok0 = row_ok && (xs >= 0) && (xs < wo);
+        const uint32_t off0 = ok0 ? (srow + (uint32_t)xs) * 8u : kOob;
+        s.rm0 = buf_load_f64(rsRM, off0);
+        s.ri0 = buf_load_f64(rsRI, off0);
+        const int xe = xs + 64;  // the ND columns past the tile's last lane
+        const bool ok1 = (lane < ND) && row_ok && (xe >= 0) && (xe < wo);
+        const uint32_t off1 = ok1 ? (srow + (uint32_t)xe) * 8u : kOob;
+        s.rm1 = buf_load_f64(rsRM, off1);
+        s.ri1 = buf_load_f64(rsRI, off1);
+    };
+
+    double colsum[ND];
+#pragma unroll
+    for (int e = 0; e < ND; ++e) colsum[e] = 0.0;
+    for (int i = -o; i < o; ++i) {  // prime with the 2o rows above the first window's last row
+        row_vals v;
+        load_row(r0 + i, v);
+#pragma unroll
+        for (int e = 0; e < ND; ++e) colsum[e] += (double)(v.lv * v.rv[e]);  // float32 product (zncc.py:209-212)
+    }
+
+    const double inv_n = 1.0 / ((double)win * win);
+    const bool out_lane = (lane >= o) && (lane < 64 - o);
+    // cooperative store: thread -> (pixel of the tile, 16 bytes of its kZnccDB disparities), two passes
+    constexpr int kParts = kZnccDB / 4;                    // float4 pieces per pixel
+    constexpr int kPixPerPass = 64 * kZnccWaves / kParts;  // pixels stored per pass
+    const int st_part = tid % kParts, st_pix0 = tid / kParts;
+    const int st_k = dblock * kZnccDB + 4 * st_part;
+
+    int par = 0;
+    row_vals vin, vout;
+    stat_vals sv;
+    load_row(r0 + o, vin);
+    load_row(-1, vout);
+    load_stats(r0, sv);
+    for (int r = r0; r < r1; ++r, par ^= 1) {
+        // the next row's operands are requested before this row's arithmetic so their latency hides behind it
+        row_vals nin, nout;
+        stat_vals ns;
+        load_row(r + 1 + o, nin);
+        load_row(r - o, nout);
+        load_stats(r + 1, ns);
+        const bool row_ok = (r >= o) && (r < H - o);
+        const double mL = sv.mL, iL = sv.iL;
+        rstat[wv][0][lane] = sv.rm0;
+        rstat[wv][1][lane] = sv.ri0;
+        if (lane < ND) {
+            rstat[wv][0][64 + lane] = sv.rm1;
+            rstat[wv][1][64 + lane] = sv.ri1;
+        }
+#pragma unroll
+        for (int e = 0; e < ND; ++e) {
+            colsum[e] = (colsum[e] - (double)(vout.lv * vout.rv[e])) + (double)(vin.lv * vin.rv[e]);
+            colbuf[wv][e][lane] = colsum[e];
+        }
+        vin = nin; vout = nout; sv = ns;
+        // colbuf / rstat are private to the wavefront: LDS executes its instructions in order, a wave-level
+        // fence keeps the compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (out_lane) {
+            float out[ND];
+            double box[ND];
+#pragma unroll
+            for (int e = 0; e < ND; ++e) box[e] = colbuf[wv][e][lane - o];
+            if (WIN_T) {
+#pragma unroll
+                for (int j = 1; j < (WIN_T ? WIN_T : 1); ++j)
+#pragma unroll
+                    for (int e = 0; e < ND; ++e) box[e] += colbuf[wv][e][lane - o + j];
+            } else {
+                for (int j = 1; j < win; ++j)
+#pragma unroll
+                    for (int e = 0; e < ND; ++e) box[e] += colbuf[wv][e][lane - o + j];
+            }
+#pragma unroll
+            for (int e = 0; e < ND; ++e) {
+                double z = box[e] * inv_n - mL * rstat[wv][0][lane + e];
+                z = z * iL * rstat[wv][1][lane + e];
+                const int x = x0 + e;
+                const bool ok = row_ok && col_ok && (x - o >= 0) && (x + o < W);
+                out[e] = ok ? (float)z : qnan();
+            }
+            __builtin_memcpy(&ostage[par][lane][wv * ND], out, sizeof(float) * ND);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();  // the only workgroup barrier per row: ostage[par] is complete
+#pragma unroll
+        for (int pass = 0; pass < 64 / kPixPerPass; ++pass) {
+            const int pix = st_pix0 + pass * kPixPerPass;  // lane index inside the tile
+            const int pc = tile_c0 - o + pix;
+            if (pix >= o && pix < 64 - o && pc < W && st_k < q.D) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&ostage[par][pix][4 * st_part]);
+                float* dst = q.cv + ((size_t)r * W + pc) * q.D + st_k;
+                if (st_k + 4 <= q.D) {
+                    __builtin_memcpy(dst, &v, 16);
+                } else {
+                    dst[0] = v.x;
+                    if (st_k + 1 < q.D) dst[1] = v.y;
+                    if (st_k + 2 < q.D) dst[2] = v.z;
+                }
+            }
+        }
+    }
+}
+
 int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
     const int H = cv->H, W = cv->W, o = win / 2;
     if (H - 2 * o <= 0 || W - 1 - 2 * o <= 0) return pmx_launch_fill_nan(ctx, cv->data, cv->cells());
     size_t per = (size_t)(H - 2 * o) * (W - 2 * o) * sizeof(double);
-    int rc = pmx_need_small(ctx, per * 2 * (1 + cv->subpix));
+    int rc = pmx_need_small(ctx, per * 3 * (1 + cv->subpix));
     if (rc) return rc;
     char* base = (char*)ctx->small;
     zncc_stats st;
     st.lmean = (double*)base;
     st.lsd = (double*)(base + per);
+    double* lisd = (double*)(base + per * 2);
+    double* risd[PMX_MAX_SUBPIX];
     pmx_mc_params p = make_params(ctx, cv, win);
     pmx_stage_scope t(ctx, PMX_STAGE_ZNCC);
     {
         dim3 grid((W - 2 * o + kBlock - 1) / kBlock, H - 2 * o);
         hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kBlock), 0, ctx->stream, ctx->left, H, W, win,
-                           (double*)st.lmean, (double*)st.lsd);
+                           (double*)st.lmean, (double*)st.lsd, lisd);
     }
-    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) { st.rmean[k] = nullptr; st.rsd[k] = nullptr; }
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) { st.rmean[k] = nullptr; st.rsd[k] = nullptr; risd[k] = nullptr; }
     for (int k = 0; k < cv->subpix; ++k) {
         int wk = pmx_shifted_width(W, k);
-        st.rmean[k] = (double*)(base + per * (2 + 2 * k));
-        st.rsd[k] = (double*)(base + per * (3 + 2 * k));
+        st.rmean[k] = (double*)(base + per * (3 + 3 * k));
+        st.rsd[k] = (double*)(base + per * (4 + 3 * k));
+        risd[k] = (double*)(base + per * (5 + 3 * k));
         dim3 grid((wk - 2 * o + kBlock - 1) / kBlock, H - 2 * o);
         hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, win,
-                           (double*)st.rmean[k], (double*)st.rsd[k]);
+                           (double*)st.rmean[k], (double*)st.rsd[k], risd[k]);
     }
-    dim3 grid((W * cv->D + kBlock - 1) / kBlock, H);
-    hipLaunchKernelGGL(zncc_kernel, grid, dim3(kBlock), 0, ctx->stream, p, st, cv->data);
+    const bool march = cv->subpix == 1 && 2 * o < 32 && (size_t)H * W * 4 < (1ull << 31) &&
+                       (size_t)H * W * 8 < (1ull << 32);
+    if (march) {
+        zncc_march_params q;
+        q.left = ctx->left; q.right = ctx->right[0];
+        q.lmean = st.lmean; q.lisd = lisd; q.rmean = st.rmean[0]; q.risd = risd[0];
+        q.cv = cv->data;
+        q.H = H; q.W = W; q.D = cv->D; q.d0 = cv->d0; q.win = win;
+        q.strip_rows = 64;
+        q.ntile = (W + (64 - 2 * o) - 1) / (64 - 2 * o);
+        q.ndblock = (cv->D + kZnccDB - 1) / kZnccDB;
+        q.nstrip = (H + q.strip_rows - 1) / q.strip_rows;
+        q.img_bytes = (uint32_t)((size_t)H * W * 4);
+        q.stat_bytes = (uint32_t)per;
+        const uint32_t grid = (uint32_t)q.ntile * q.ndblock * q.nstrip;
+        const dim3 block(64 * kZnccWaves);
+        switch (win) {
+#define PMX_ZNCC_CASE(WN) case WN: hipLaunchKernelGGL(zncc_march_kernel<WN>, dim3(grid), block, 0, ctx->stream, q); break;
+            PMX_ZNCC_CASE(1) PMX_ZNCC_CASE(3) PMX_ZNCC_CASE(5) PMX_ZNCC_CASE(7) PMX_ZNCC_CASE(9) PMX_ZNCC_CASE(11) PMX_ZNCC_CASE(13)
+#undef PMX_ZNCC_CASE
+            default: hipLaunchKernelGGL(zncc_march_kernel<0>, dim3(grid), block, 0, ctx->stream, q); break;
+        }
+    } else {
+        dim3 grid((W * cv->D + kBlock - 1) / kBlock, H);
+        hipLaunchKernelGGL(zncc_kernel, grid, dim3(kBlock), 0, ctx->stream, p, st, cv->data);
+    }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

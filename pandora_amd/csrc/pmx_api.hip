@@ -42,13 +42,24 @@ extern "C" pmx_ctx* pmx_create(int device) {
     return ctx;
 }
 
+// Images sit between two zeroed guards of kImgGuardBytes so that wide loads which start a few elements before
+// the first row or run past the last one stay inside the allocation.
+static hipError_t img_alloc(pmx_ctx* ctx, float** p, size_t n) {
+    char* raw = nullptr;
+    hipError_t e = hipMalloc((void**)&raw, n * sizeof(float) + 2 * kImgGuardBytes);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(raw, 0, n * sizeof(float) + 2 * kImgGuardBytes, ctx->stream);
+    *p = (float*)(raw + kImgGuardBytes);
+    return e;
+}
+static void img_free(float*& p) {
+    if (p) hipFree((char*)p - kImgGuardBytes);
+    p = nullptr;
+}
+
 static void free_images(pmx_ctx* ctx) {
-    hipFree(ctx->left);
-    ctx->left = nullptr;
-    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) {
-        hipFree(ctx->right[k]);
-        ctx->right[k] = nullptr;
-    }
+    img_free(ctx->left);
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) img_free(ctx->right[k]);
     hipFree(ctx->msk_left); ctx->msk_left = nullptr;
     hipFree(ctx->msk_right); ctx->msk_right = nullptr;
     hipFree(ctx->bad_left); ctx->bad_left = nullptr;
@@ -115,12 +126,12 @@ extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* righ
     free_images(ctx);
     ctx->H = H; ctx->W = W; ctx->subpix = subpix;
     size_t n = (size_t)H * W;
-    PMX_HIP(hipMalloc((void**)&ctx->left, n * sizeof(float)));
-    PMX_HIP(hipMalloc((void**)&ctx->right[0], n * sizeof(float)));
+    PMX_HIP(img_alloc(ctx, &ctx->left, n));
+    PMX_HIP(img_alloc(ctx, &ctx->right[0], n));
     PMX_HIP(hipMemcpyAsync(ctx->left, left, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipMemcpyAsync(ctx->right[0], right, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     for (int k = 1; k < subpix; ++k) {
-        PMX_HIP(hipMalloc((void**)&ctx->right[k], (size_t)H * (W - 1) * sizeof(float)));
+        PMX_HIP(img_alloc(ctx, &ctx->right[k], (size_t)H * (W - 1)));
         int rc = pmx_launch_shift_right(ctx, ctx->right[0], H, W, subpix, k, ctx->right[k]);
         if (rc) return rc;
     }

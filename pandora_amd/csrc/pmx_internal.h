@@ -121,6 +121,8 @@ int pmx_update_bad_masks(pmx_ctx* ctx, int win);
 static inline int pmx_shifted_width(int W, int k) { return k == 0 ? W : W - 1; }
 
 // parameters shared by every matching-cost kernel: geometry + the cv_masked predicate inputs
+constexpr size_t kImgGuardBytes = 256;  // zeroed bytes before and after every device image
+
 struct pmx_mc_params {
     int H, W, D, d0, subpix, win;
     const float* left;

@@ -120,6 +120,18 @@ def test_zncc(eng, oracle, integer, H, W, dmin, dmax, sp, win):
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5)  # north_star: float costs within 1e-5
 
 
+@pytest.mark.parametrize("H,W,dmin,dmax,win", [(150, 530, -20, 37, 11), (70, 260, 3, 12, 3), (130, 300, -9, -1, 1),
+                                               (66, 249, -300, -240, 5), (65, 247, 240, 262, 7), (80, 300, -5, 6, 15)])
+def test_zncc_marching_kernel_strips_tiles_chunks(eng, oracle, H, W, dmin, dmax, win):
+    """subpix == 1 takes the sliding kernel: several row strips (64 rows), column tiles (256 - 2o outputs), disparity
+    chunks of 8 with a ragged last chunk, ranges that leave the image entirely; non-integer images."""
+    L, R = pair(H, W, seed=H + W, integer=False)
+    got = gpu_cv(eng, "zncc", L, R, dmin, dmax, 1, win).to_host()
+    exp = cpu_cv(oracle, "zncc", L, R, dmin, dmax, 1, win)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5)
+
+
 def test_masks_and_variable_disparity_grids(eng, oracle):
     H, W, dmin, dmax, sp, win = 28, 41, -5, 4, 2, 5
     L, R = pair(H, W, seed=99)

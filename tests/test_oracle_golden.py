@@ -62,6 +62,17 @@ def test_sad_full_volumes(oracle, case):
     np.testing.assert_array_equal(cv, np.array(case["expected"], np.float32))
 
 
+@pytest.mark.parametrize("win", [3, 5])
+@pytest.mark.parametrize("squared", [0, 1])
+def test_sad_ssd_float_summation_order(oracle, win, squared):
+    """Non-integer float32 images: the w*w terms must be added in numpy's order (window columns outer, rows inner,
+    sad_ssd.py:340-368).  Fixture produced by tests/golden/gen_sad_float_golden.py from the reference's expressions."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sad_float_order.npz"))
+    cv = oracle.sad_ssd(g["left"], g["right"], 7, -3, 1, win, bool(squared))
+    np.testing.assert_array_equal(cv, g[f"w{win}_sq{squared}_d-3_n7"])
+
+
 def test_zncc_known_answer(oracle):
     c = ka.ZNCC
     L = np.asarray(c["left"], np.float64)

@@ -36,6 +36,11 @@ def timed(name, stages, fn, reps=3):
 
 
 cv = eng.alloc_cv(D, dmin)
+if os.environ.get("PMX_BENCH_ONLY") == "zncc":
+    timed("zncc5", ["zncc"], lambda: eng.zncc(cv, 5), reps=2)
+    timed("zncc11", ["zncc"], lambda: eng.zncc(cv, 11), reps=1)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 timed("census5 (float volume)", ["census_transform", "census_cost"], lambda: eng.census(cv, 5))
 timed("wta (float)", ["wta"], lambda: eng.wta(cv, False, -9999.0))
 timed("refine vfit", ["refine"], lambda: eng.refine(cv, "vfit", False))
