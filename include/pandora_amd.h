@@ -136,9 +136,11 @@ int pmx_reset_stage_times(pmx_ctx* ctx);
 /* total GPU milliseconds and launch count of one stage since the last reset (syncs the stream) */
 int pmx_stage_time(pmx_ctx* ctx, int stage, double* total_ms, int* launches);
 /* Debug / test hook: copy the eight uint8 per-direction SGM path-cost volumes [8][H][W][Dp] of a handle
- * that is in the fused integer representation to the host; *Dp receives the byte stride per pixel.
+ * that is in the fused integer representation to the host.  *Dp receives the byte stride per pixel, *gl and
+ * *kpl the lane map the kernels wrote them with: disparity index d of a pixel is byte
+ * (k < (kpl & ~3)) ? s*(kpl & ~3) + k : nact*(kpl & ~3) + s   with s = d / kpl, k = d % kpl, nact = ceil(D / kpl).
  * Returns PMX_ERR_STATE when the handle is not in that representation. */
-int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp);
+int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp, int* gl, int* kpl);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

@@ -51,7 +51,7 @@ SIGNATURES = {
     "pmx_set_disparity": (C.c_int, [vp, c_float_p, c_i64_p]),
     "pmx_wta_minkey": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "pmx_wta_from_keys": (C.c_int, [vp, vp, C.c_double, C.c_int, C.c_float]),
-    "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p]),
+    "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmx_reset_stage_times": (C.c_int, [vp]),
     "pmx_stage_time": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),

@@ -16,23 +16,33 @@
 // path (k_sgm.hip) and to the oracle.  HBM traffic: 8 B/cell written + 8 B/cell read for SGM+WTA
 // against 24 B/cell algorithmic.
 //
-// All 8 directions run in ONE launch: a wave = one scanline of one direction (same execution
-// model as k_sgm.hip: lanes over disparities, DPP neighbour exchange and min-reduce, register
-// prefetch ring - here of census codes).
+// All 8 directions run in ONE launch: a group of GL lanes (GL = 4, 8 or 16) walks one scanline of one
+// direction, lanes over disparities (KPL per lane), DPP neighbour exchange and min-reduce inside the group, a
+// register prefetch ring of census codes.  A wavefront therefore carries 64/GL scanlines.
 //
-// Measured limits on MI355X (tools/ubench, profiles/r01_c_*): a SIMD issues about one instruction per 4
-// cycles whatever the mix (VALU, SALU, 1/2/4 waves), and the texture addresser spends ~20 cycles per
-// vector-memory instruction whatever its width - so the step below is written for FEW instructions and
-// FEW, WIDE memory operations (3 x 16-byte code loads + 1 left-code load + one 12-byte store per 4 pixels
-// for D = 129); variants with fewer ALU slots but one more store per step were slower.
+// Measured limits on MI355X (tools/ubench, profiles/r01_c_pmc_sq.csv): a SIMD issues about one instruction
+// per 4 cycles whatever the mix (VALU, SALU, 1/2/4 waves) and this kernel sits exactly on that bound (1.55e9
+// wave-instructions per launch at C3 = 2.6 ms), and the texture addresser spends ~20 cycles per vector-memory
+// instruction whatever its width.  So the step is written for FEW instructions and FEW, WIDE memory
+// operations, and the lane map is chosen per D so that almost every lane-slot is a real disparity:
+// D = 129 -> 8 lanes x 17 (136 slots, 8 scanlines per wave) instead of 16 x 12 (192 slots, 4 scanlines).
+//
+// Byte layout of a pixel in the per-direction volumes ([8][H][W][Dp], internal): lane s of the group owns
+// disparities [s*KPL, (s+1)*KPL); its first M4 = KPL & ~3 bytes sit at s*M4 (one aligned wide store), the
+// (KPL & 3 <= 1) remaining byte at nact*M4 + s (stored four lanes at a time as one dword), nact = ceil(D/KPL)
+// = lanes that own a disparity.  Dp = nact*KPL rounded up to 4: no holes between pixels (a 192-byte pixel
+// stride for 132 bytes of payload cost +35 %).  fused_pos() maps a disparity to its byte.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "pmx_internal.h"
 
 static constexpr int kWavesPerBlock = 4;
-static constexpr int kLinesPerWave = 4;  // one scanline per 16-lane DPP row
-static constexpr int kRing = 4;          // census-code read-ahead (pixels)
 static constexpr uint32_t kInf = 0x7fffu;
+
+// census-code read-ahead (pixels): as deep as the register budget of the lane map allows
+__host__ __device__ constexpr int fused_ring(int nw, int kpl) { return nw * kpl <= 17 ? 4 : (nw * kpl <= 26 ? 3 : 2); }
 
 __device__ __forceinline__ float g_inf() { return __int_as_float(0x7f800000); }
 __device__ __forceinline__ float g_nan() { return __int_as_float(0x7fc00000); }
@@ -55,13 +65,29 @@ __device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// min over each 16-lane row, result in EVERY lane of the row (rotate butterfly, no readlane)
-__device__ __forceinline__ uint32_t row_allmin_u(uint32_t v) {
-    v = umin2(v, dppu<0x128>(0xffffffffu, v));  // row_ror:8  (old = identity of min: lets the DPP fold into v_min_u32)
-    v = umin2(v, dppu<0x124>(0xffffffffu, v));  // row_ror:4
-    v = umin2(v, dppu<0x122>(0xffffffffu, v));  // row_ror:2
-    v = umin2(v, dppu<0x121>(0xffffffffu, v));  // row_ror:1
+// min over each group of GL lanes, result in EVERY lane of the group (rotate / permute butterfly, no readlane;
+// old = identity of min lets each DPP move fold into the v_min_u32)
+template <int GL>
+__device__ __forceinline__ uint32_t group_allmin_u(uint32_t v) {
+    static_assert(GL == 4 || GL == 8 || GL == 16, "group size");
+    if (GL == 16) {
+        v = umin2(v, dppu<0x128>(0xffffffffu, v));  // row_ror:8
+        v = umin2(v, dppu<0x124>(0xffffffffu, v));  // row_ror:4
+        v = umin2(v, dppu<0x122>(0xffffffffu, v));  // row_ror:2
+        v = umin2(v, dppu<0x121>(0xffffffffu, v));  // row_ror:1
+    } else {
+        if (GL == 8) v = umin2(v, dppu<0x141>(0xffffffffu, v));  // row_half_mirror: lane i <-> 7-i
+        v = umin2(v, dppu<0x4e>(0xffffffffu, v));                // quad_perm [2,3,0,1]
+        v = umin2(v, dppu<0xb1>(0xffffffffu, v));                // quad_perm [1,0,3,2]
+    }
     return v;
+}
+__device__ __forceinline__ uint32_t row_allmin_u(uint32_t v) { return group_allmin_u<16>(v); }
+
+// byte offset of disparity index d inside a pixel of the per-direction volumes
+__host__ __device__ __forceinline__ int fused_pos(int d, int nact, int kpl) {
+    const int s = d / kpl, k = d - s * kpl, m4 = kpl & ~3;
+    return k < m4 ? s * m4 + k : nact * m4 + s;
 }
 
 struct fused_args {
@@ -69,6 +95,7 @@ struct fused_args {
     const uint32_t* codeR;  // [H][W][NW], readable 1024 dwords before / after
     uint8_t* ldir;          // [8][H][W][Dp]
     int H, W, D, Dp, d0, o;
+    int nact;               // lanes of a group that own at least one disparity (ceil(D / KPL))
     uint32_t P1, P2, invalid_cost;
 };
 
@@ -78,25 +105,32 @@ struct code_slot {
     uint32_t l[NW];        // left code of the pixel (same for the 16 lanes of a line)
 };
 
-// Four scanlines of one direction per wavefront: 16-lane DPP row g walks line l0+g; lane `sub` of
-// a row owns disparities [sub*KPL, (sub+1)*KPL).  All arithmetic is uint32 on small integers.
-template <int NW, int KPL>
-__global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kernel(fused_args a) {
+// 64/GL scanlines of one direction per wavefront: lane group g walks line l0+g; lane `sub` of a group owns
+// disparities [sub*KPL, (sub+1)*KPL).  All arithmetic is uint32 on small integers.  For GL < 16 the DPP
+// row shifts cross group borders; that is harmless because GL*KPL > D is required, so the last slot of every
+// group is a pad that reads as +infinity from below and whose own value is never stored or used.
+template <int NW, int GL, int KPL>
+__global__ __launch_bounds__(kWavesPerBlock * 64, 2) void sgm_census_fused_kernel(fused_args a) {
+    constexpr int LPW = 64 / GL;        // scanlines per wavefront
+    constexpr int M4 = KPL & ~3;        // bytes of the lane's wide store
+    constexpr int T = KPL & 3;          // 0 or 1 trailing byte
+    constexpr int kRing = fused_ring(NW, KPL);
+    static_assert(T <= 1, "KPL must be 0 or 1 mod 4");
     const int lane = threadIdx.x & 63;
-    const int sub = lane & 15, grp = lane >> 4;
+    const int sub = lane & (GL - 1), grp = lane / GL;
     const int gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     const int H = a.H, W = a.W, D = a.D;
-    const int wavesH = (H + kLinesPerWave - 1) / kLinesPerWave, wavesW = (W + kLinesPerWave - 1) / kLinesPerWave;
+    const int wavesH = (H + LPW - 1) / LPW, wavesW = (W + LPW - 1) / LPW;
     // directions in the order of k_sgm.hip / the oracle; 0,1 walk rows, 2..7 walk columns / diagonals
     int dir, l0;
     if (gwave < 2 * wavesH) {
         dir = gwave / wavesH;
-        l0 = (gwave - dir * wavesH) * kLinesPerWave;
+        l0 = (gwave - dir * wavesH) * LPW;
     } else {
         const int t = gwave - 2 * wavesH;
         dir = 2 + t / wavesW;
         if (dir >= 8) return;
-        l0 = (t - (dir - 2) * wavesW) * kLinesPerWave;
+        l0 = (t - (dir - 2) * wavesW) * LPW;
     }
     const int dr = (dir < 2) ? 0 : ((dir & 1) ? -1 : 1);                        // 0 0 +1 -1 +1 -1 +1 -1
     const int dc = (dir == 0) ? 1 : (dir == 1) ? -1 : (dir < 4) ? 0 : ((dir == 4 || dir == 7) ? 1 : -1);  // +1 -1 0 0 +1 -1 -1 +1
@@ -104,12 +138,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
     const bool diagonal = (dr != 0) && (dc != 0);
     const int nlines = horizontal ? H : W;
     const int nsteps = horizontal ? W : H;
-    const int line = min(l0 + grp, nlines - 1);  // surplus rows of the last wave repeat the last line (same bytes)
+    const int line = min(l0 + grp, nlines - 1);  // surplus groups of the last wave repeat the last line (same bytes)
     const int d_first = sub * KPL;
     const bool lane_active = d_first < D;
     const int d_load = lane_active ? d_first : 0;
 
-    // pixel being computed (per 16-lane row) and the read-ahead cursor
+    // pixel being computed (per lane group) and the read-ahead cursor
     int r = horizontal ? line : (dr > 0 ? 0 : H - 1);
     int c = horizontal ? (dc > 0 ? 0 : W - 1) : line;
     int pc = c;
@@ -117,7 +151,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
     const int stride = dr * W + dc;  // pixel stride of one step (before wrapping)
     const uint32_t* pR = a.codeR + ((ptrdiff_t)r * W + c + a.d0 + d_load) * NW;
     const uint32_t* pL = a.codeL + ((ptrdiff_t)r * W + c) * NW;
-    uint8_t* pO = a.ldir + (size_t)dir * H * W * a.Dp + ((size_t)r * W + c) * a.Dp + d_first;
+    uint8_t* pO = a.ldir + (size_t)dir * H * W * a.Dp + ((size_t)r * W + c) * a.Dp + sub * M4;
+    const int tail_delta = a.nact * M4 + sub - sub * M4;  // from the lane's wide store to its trailing byte
 
     code_slot<NW, KPL> ring[kRing];
     auto prefetch = [&](code_slot<NW, KPL>& slot) {
@@ -148,12 +183,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
     const int qbase = a.d0 + d_first - a.o;
 
     // per-lane pad mask: disparities >= D (tail of the last active lane, every inactive lane) must
-    // look infinitely expensive to their neighbours and to the row minimum
+    // look infinitely expensive to their neighbours and to the group minimum
     uint32_t padm[KPL];
 #pragma unroll
     for (int k = 0; k < KPL; ++k) padm[k] = (d_first + k < D) ? 0u : kInf;
 
-    // one pixel of each of the four lines.  ALL_OK = every cell touched is a valid census cell
+    // one pixel of each of the LPW lines.  ALL_OK = every cell touched is a valid census cell
     // (wave-uniform, true away from the image borders): no per-cell validity select.
     auto body = [&](code_slot<NW, KPL>& slot, auto all_ok_tag, bool pix_ok, uint32_t u) {
         constexpr bool ALL_OK = decltype(all_ok_tag)::value;
@@ -163,7 +198,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
         uint32_t negM = 0u - M;
         asm volatile("" : "+v"(negM));  // keep cc + t + negM a single three-operand add
         uint32_t Ln[KPL];
-        uint32_t packed[KPL / 4];
+        uint32_t packed[M4 / 4];
+        uint32_t tailv = 0;
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
             uint32_t pop = 0;
@@ -176,10 +212,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
             const uint32_t t = umin2(umin2(Lp[k], umin2(lo, hi) + a.P1), mp2);
             const uint32_t l = cc + t + negM;
             Ln[k] = l | padm[k];
-            if ((k & 3) == 0) packed[k / 4] = l;
+            if (k >= M4) tailv = l;
+            else if ((k & 3) == 0) packed[k / 4] = l;
             else packed[k / 4] |= l << (8 * (k & 3));
         }
-        if (lane_active) __builtin_memcpy(pO, packed, KPL);
+        if (lane_active) __builtin_memcpy(pO, packed, M4);
+        if (T) {
+            // byte stores cost about as much as the rest of the step (measured: 16x9 with a byte store 3.0 ms
+            // against 16x8 2.1 ms at 2048^2 x 127), so four neighbouring lanes' trailing bytes are gathered with
+            // two DPP shifts and leave as one dword from every fourth lane (pad lanes contribute don't-cares)
+            uint32_t y = tailv | (dppu<0x101>(0u, tailv) << 8);  // row_shl:1 - lane i sees lane i+1
+            y = y | (dppu<0x102>(0u, y) << 16);                  // row_shl:2
+            if ((sub & 3) == 0 && lane_active) *reinterpret_cast<uint32_t*>(pO + tail_delta) = y;  // stays inside Dp
+        }
         uint32_t lmin = Ln[0];
 #pragma unroll
         for (int k = 1; k < KPL; ++k) lmin = umin2(lmin, Ln[k]);
@@ -196,7 +241,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
         if (__all(lane_all || !lane_active)) lmin = body(slot, std::true_type{}, pix_ok, u);
         else lmin = body(slot, std::false_type{}, pix_ok, u);
         prefetch(slot);
-        M = row_allmin_u(lmin);
+        M = group_allmin_u<GL>(lmin);
         // advance; a diagonal line that leaves the image re-enters on the other side and the path restarts
         r += dr;
         c += dc;
@@ -225,21 +270,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void sgm_census_fused_kerne
 
 // ---- consumers of the 8 byte volumes ---------------------------------------------------------------
 struct sum8_args {
-    const uint8_t* ldir;  // [8][H][W][Dp]
+    const uint8_t* ldir;  // [8][H][W][Dp], bytes of a pixel in fused_pos() order
     int H, W, D, Dp, d0, o;
+    int gl, kpl, nact;    // lane map the volumes were written with (nact = ceil(D / kpl) lanes own a disparity)
 };
-
-// sum of the 8 directions for the 4 disparities starting at byte offset `off` of a pixel
-__device__ __forceinline__ void sum8_quad(const sum8_args& a, size_t off, uint32_t& lo, uint32_t& hi) {
-    const size_t vol = (size_t)a.H * a.W * a.Dp;
-    lo = 0; hi = 0;  // lo = d0 | d2 << 16 (even bytes), hi = d1 | d3 << 16 (odd bytes)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        uint32_t x = *reinterpret_cast<const uint32_t*>(a.ldir + k * vol + off);
-        lo += x & 0x00ff00ffu;
-        hi += (x >> 8) & 0x00ff00ffu;
-    }
-}
 
 // is cell (r, c, k) a NaN of the census volume? (geometry only: no masks on this path)
 __device__ __forceinline__ bool cell_is_nan(const sum8_args& a, int r, int c, int k) {
@@ -251,74 +285,81 @@ __device__ __forceinline__ bool cell_is_nan(const sum8_args& a, int r, int c, in
 #define FMSK_STOPPED 0x8LL
 
 // WTA over the summed volume (disparity.py:399-516 on S = sum of the eight byte volumes).
-// Four pixels per wavefront, one per 16-lane DPP row; lane `sub` owns NB dwords = 4*NB consecutive
-// disparities of its pixel, i.e. ONE NB-dword load per direction volume (the texture addresser charges
-// per instruction, so few wide loads).  The bytes are summed SWAR-style (even/odd bytes in 16-bit fields),
-// (sum, index) is packed into one uint32 key per disparity so a single row min-reduce gives the FIRST
+// Same lane map as the path kernel: 64/GL pixels per wavefront, lane `sub` of a group owns KPL consecutive
+// disparities of its pixel = ONE wide load (+ one byte when KPL = 1 mod 4) per direction volume (the texture
+// addresser charges per instruction).  The bytes are summed SWAR-style (even/odd bytes in 16-bit fields),
+// (sum, index) is packed into one uint32 key per disparity so a single group min-reduce gives the FIRST
 // minimum, and the winner's lane also writes (S[k-1], S[k], S[k+1], k) for the refinement step.
-template <int NB>
+// As in the path kernel, GL*KPL > D makes the last slot of a group a pad, so the row shifts that fetch the
+// neighbour lane's edge value never leak a value of the next pixel into a valid result.
+template <int GL, int KPL>
 __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix, double d0, float invalid_disparity,
                                                        float* __restrict__ disp, int64_t* __restrict__ validity,
                                                        float4* __restrict__ near) {
-    constexpr int NE = 4 * NB;  // disparities per lane
+    constexpr int PPW = 64 / GL;   // pixels per wavefront
+    constexpr int M4 = KPL & ~3, NB = M4 / 4, T = KPL & 3;
+    static_assert(T <= 1, "KPL must be 0 or 1 mod 4");
     const int lane = threadIdx.x & 63;
-    const int sub = lane & 15, grp = lane >> 4;
+    const int sub = lane & (GL - 1), grp = lane / GL;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t nwaves = (size_t)gridDim.x * 4;
-    const int d_first = sub * NE;
+    const int d_first = sub * KPL;
     const bool lane_active = d_first < a.D;
     const size_t vol = (size_t)a.H * a.W * a.Dp;
     const uint32_t wvalid = (uint32_t)(a.W - 2 * a.o);
-    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
-        const size_t pix = min(quad * 4 + grp, npix - 1);  // surplus rows repeat the last pixel (same values)
+    for (size_t quad = wave; quad * PPW < npix; quad += nwaves) {
+        const size_t pix = min(quad * PPW + grp, npix - 1);  // surplus groups repeat the last pixel (same values)
         const int r = (int)(pix / a.W), c = (int)(pix - (size_t)r * a.W);
-        // ---- sum of the 8 directions: s[e] for the lane's NE disparities (0 outside the volume)
-        uint32_t lo[NB], hi[NB];
+        // ---- sum of the 8 directions: s[e] for the lane's KPL disparities
+        uint32_t lo[NB], hi[NB], tl = 0;
 #pragma unroll
         for (int q = 0; q < NB; ++q) { lo[q] = 0; hi[q] = 0; }
-        const uint8_t* base = a.ldir + pix * a.Dp + (lane_active ? d_first : 0);
+        const uint8_t* base = a.ldir + pix * a.Dp + (lane_active ? sub * M4 : 0);  // idle lanes re-read lane 0
+        const uint8_t* tbase = a.ldir + pix * a.Dp + a.nact * M4 + (lane_active ? sub : 0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             uint32_t x[NB];
             __builtin_memcpy(x, base + k * vol, 4 * NB);
+            if (T) tl += tbase[k * vol];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 lo[q] += x[q] & 0x00ff00ffu;         // bytes 0 and 2 of the dword
                 hi[q] += (x[q] >> 8) & 0x00ff00ffu;  // bytes 1 and 3
             }
         }
-        uint32_t s[NE];
+        uint32_t s[KPL];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             s[4 * q] = lo[q] & 0xffffu; s[4 * q + 1] = hi[q] & 0xffffu; s[4 * q + 2] = lo[q] >> 16; s[4 * q + 3] = hi[q] >> 16;
         }
+        if (T) s[KPL - 1] = tl;
         // ---- which of the lane's cells are NaN in the census volume (geometry only on this path)
         const bool pix_ok = (r >= a.o) && (r < a.H - a.o) && (c >= a.o) && (c < a.W - a.o);
         const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
         uint32_t okbits = 0, key = 0xffffffffu;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
+        for (int e = 0; e < KPL; ++e) {
             const bool ok = lane_active && pix_ok && (d_first + e < a.D) && (u + (uint32_t)e < wvalid);
             okbits |= ok ? (1u << e) : 0u;
             if (ok) key = umin2(key, (s[e] << 16) | (uint32_t)(d_first + e));
         }
-        key = row_allmin_u(key);  // every lane of the row now holds the pixel's (min sum, first index)
+        key = group_allmin_u<GL>(key);  // every lane of the group now holds the pixel's (min sum, first index)
         const bool none = key == 0xffffffffu;
         const int kb = none ? -8 : (int)(key & 0xffffu);
         // ---- the winner's lane fetches its neighbours (possibly from the adjacent lane) and writes the result
-        const uint32_t s_below = dppu<0x111>(0u, s[NE - 1]), ok_below = dppu<0x111>(0u, okbits >> (NE - 1));  // row_shr:1
-        const uint32_t s_above = dppu<0x101>(0u, s[0]), ok_above = dppu<0x101>(0u, okbits & 1u);             // row_shl:1
-        const int eb = kb - d_first;  // winner's slot in this lane, if 0 <= eb < NE
-        if (eb >= 0 && eb < NE && lane_active) {
+        const uint32_t s_below = dppu<0x111>(0u, s[KPL - 1]), ok_below = dppu<0x111>(0u, okbits >> (KPL - 1));  // row_shr:1
+        const uint32_t s_above = dppu<0x101>(0u, s[0]), ok_above = dppu<0x101>(0u, okbits & 1u);               // row_shl:1
+        const int eb = kb - d_first;  // winner's slot in this lane, if 0 <= eb < KPL
+        if (eb >= 0 && eb < KPL && lane_active) {
             uint32_t c0 = 0, c2 = 0;
             bool v0 = false, v2 = false;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
+            for (int e = 0; e < KPL; ++e) {
                 if (e == eb) {
                     c0 = (e > 0) ? s[e > 0 ? e - 1 : 0] : s_below;
                     v0 = (e > 0) ? ((okbits >> (e > 0 ? e - 1 : 0)) & 1u) : (ok_below & 1u);
-                    c2 = (e < NE - 1) ? s[e < NE - 1 ? e + 1 : 0] : s_above;
-                    v2 = (e < NE - 1) ? ((okbits >> (e < NE - 1 ? e + 1 : 0)) & 1u) : (ok_above & 1u);
+                    c2 = (e < KPL - 1) ? s[e < KPL - 1 ? e + 1 : 0] : s_above;
+                    v2 = (e < KPL - 1) ? ((okbits >> (e < KPL - 1 ? e + 1 : 0)) & 1u) : (ok_above & 1u);
                 }
             }
             near[pix] = make_float4(v0 ? (float)c0 : g_nan(), (float)(key >> 16), v2 ? (float)c2 : g_nan(), __int_as_float(kb));
@@ -337,8 +378,9 @@ __device__ __forceinline__ float sum8_cell(const sum8_args& a, size_t pix, int r
     if (cell_is_nan(a, r, c, k)) return g_nan();
     const size_t vol = (size_t)a.H * a.W * a.Dp;
     uint32_t s = 0;
+    const int pos = fused_pos(k, a.nact, a.kpl);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += a.ldir[j * vol + pix * a.Dp + k];
+    for (int j = 0; j < 8; ++j) s += a.ldir[j * vol + pix * a.Dp + pos];
     return (float)s;
 }
 
@@ -407,6 +449,7 @@ static sum8_args make_sum8(const pmx_cv* cv) {
     sum8_args s;
     s.ldir = cv->ldir;
     s.H = cv->H; s.W = cv->W; s.D = cv->D; s.Dp = cv->Dp; s.d0 = cv->d0; s.o = cv->win / 2;
+    s.gl = cv->gl; s.kpl = cv->kpl; s.nact = cv->kpl ? (cv->D + cv->kpl - 1) / cv->kpl : 0;  // (no map before the SGM step)
     return s;
 }
 
@@ -414,7 +457,7 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
                             int overcounting) {
     if (cv->repr != PMX_REPR_CENSUS_DEFERRED) return false;
     if (is_max || overcounting) return false;
-    if (cv->subpix != 1 || cv->D > 16 * 20) return false;
+    if (cv->subpix != 1 || cv->D >= 16 * 20) return false;
     const int nw = (cv->win * cv->win + 31) / 32;
     if (nw > 2) return false;
     auto is_int = [](float x) { return x == floorf(x); };
@@ -423,10 +466,60 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
     return true;
 }
 
+// Lane map for a volume: gl lanes per scanline, kpl disparities per lane with gl*kpl > D (the pad slot the
+// DPP shifts rely on) and kpl = 0 or 1 mod 4 (one wide store + at most one byte).  Among the maps the kernels
+// are instantiated for, take the cheapest by an issue model calibrated on MI355X at 2048^2 (tools/bench_fused.py:
+// 16x8 2.07 ms and 8x16 2.40 ms at D=127; 16x12 2.55, 8x17 2.78, 16x9 2.92 ms at D=129): ~70 instructions of
+// per-step overhead, ~9.5 per disparity slot, ~25 issue slots per vector-memory instruction, a surcharge for the
+// trailing-byte store, times the rounds the waves need on the chip's 1024 SIMDs; maps that leave fewer than
+// three waves per SIMD are latency-bound and pay 1.5x.
+static void fused_choose_map(int H, int W, int D, int nw, int* gl_out, int* kpl_out) {
+    // test hook: PMX_FUSED_MAP=<gl>x<kpl> forces a map (used by the parity tests to reach every instantiation
+    // on small volumes); ignored unless it is a legal map for this D
+    if (const char* e = getenv("PMX_FUSED_MAP")) {
+        int gl = 0, kpl = 0;
+        if (sscanf(e, "%dx%d", &gl, &kpl) == 2 && (gl == 4 || gl == 8 || gl == 16) && gl * kpl > D && (kpl & 3) <= 1 &&
+            kpl >= 4 && kpl <= 20) {
+            *gl_out = gl;
+            *kpl_out = kpl;
+            return;
+        }
+    }
+    double best = 1e30;
+    *gl_out = 16;
+    *kpl_out = 20;
+    for (int gl = 4; gl <= 16; gl *= 2) {
+        for (int t = 0; t < 2; ++t) {
+            int kpl = D / gl + 1;  // gl*kpl > D
+            if (t == 0) kpl = (kpl + 3) & ~3;                                   // whole dwords only
+            else if ((kpl & 3) != 1) continue;                                  // dwords + one trailing byte
+            if (kpl < 4) kpl = 4;
+            if (kpl > 20) continue;
+            if (gl == 4 && kpl < 16) continue;  // (maps not instantiated: small D is served by wider groups)
+            if (gl == 8 && kpl < 8) continue;
+            const int lpw = 64 / gl;
+            const double waves = 2.0 * ((H + lpw - 1) / lpw) + 6.0 * ((W + lpw - 1) / lpw);
+            const double rounds = waves / 1024.0 > 1.0 ? waves / 1024.0 : 1.0;
+            const int nvmem = (kpl * nw + 3) / 4 + 2 + (kpl & 1);               // code loads + left code + store(s)
+            double cost = (70.0 + 9.5 * kpl * (nw > 1 ? 1.25 : 1.0) + 25.0 * nvmem + 40.0 * (kpl & 1)) * rounds;
+            if (waves > 1024.0 && waves < 3.0 * 1024.0) cost *= 1.5;           // too few waves per SIMD to hide latency
+            if (cost < best) { best = cost; *gl_out = gl; *kpl_out = kpl; }
+        }
+    }
+}
+
+// one switch for every (gl, kpl) pair the kernels exist for
+#define PMX_FUSED_MAPS(X)                                                                          \
+    X(16, 4) X(16, 5) X(16, 8) X(16, 9) X(16, 12) X(16, 13) X(16, 16) X(16, 17) X(16, 20)          \
+    X(8, 8) X(8, 9) X(8, 12) X(8, 13) X(8, 16) X(8, 17) X(8, 20)                                   \
+    X(4, 16) X(4, 17) X(4, 20)
+
 int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost) {
     const int H = cv->H, W = cv->W;
-    const int kpl0 = ((cv->D + 15) / 16 + 3) & ~3;
-    const int Dp = (((cv->D + kpl0 - 1) / kpl0) * kpl0 + 3) & ~3;  // whole lanes: every active lane stores KPL bytes
+    int gl, kpl;
+    fused_choose_map(H, W, cv->D, (cv->win * cv->win + 31) / 32, &gl, &kpl);
+    const int nact = (cv->D + kpl - 1) / kpl;
+    const int Dp = (nact * kpl + 3) & ~3;
     size_t need = (size_t)8 * H * W * Dp;
     if (cv->ldir_bytes < need) {
         PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -436,7 +529,7 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
         PMX_HIP(hipMalloc((void**)&cv->ldir, need + 64));
         cv->ldir_bytes = need;
     }
-    cv->Dp = Dp;
+    cv->Dp = Dp; cv->gl = gl; cv->kpl = kpl;
     const int nw = (cv->win * cv->win + 31) / 32;
     fused_args a;
     a.codeL = cv->codeL;
@@ -444,25 +537,23 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
     a.ldir = cv->ldir;
     a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.d0 = cv->d0; a.o = cv->win / 2;
     a.P1 = (uint32_t)P1; a.P2 = (uint32_t)P2; a.invalid_cost = (uint32_t)invalid_cost;
-    const int nwaves = 2 * ((H + kLinesPerWave - 1) / kLinesPerWave) + 6 * ((W + kLinesPerWave - 1) / kLinesPerWave);
+    a.nact = nact;
+    const int lpw = 64 / gl;
+    const int nwaves = 2 * ((H + lpw - 1) / lpw) + 6 * ((W + lpw - 1) / lpw);
     dim3 grid((nwaves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * 64);
-    const int kpl = ((cv->D + 15) / 16 + 3) & ~3;  // disparities per lane, multiple of 4 (whole dword stores)
+    bool launched = false;
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
-#define PMX_FUSED_LAUNCH(NWV, KPLV) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_census_fused_kernel<NWV, KPLV>), grid, block, 0, ctx->stream, a)
-#define PMX_FUSED_KPL(NWV)                               \
-    switch (kpl) {                                       \
-        case 4: PMX_FUSED_LAUNCH(NWV, 4); break;         \
-        case 8: PMX_FUSED_LAUNCH(NWV, 8); break;         \
-        case 12: PMX_FUSED_LAUNCH(NWV, 12); break;       \
-        case 16: PMX_FUSED_LAUNCH(NWV, 16); break;       \
-        default: PMX_FUSED_LAUNCH(NWV, 20); break;       \
+#define PMX_FUSED_CASE(GLV, KPLV)                                                                                      \
+    if (!launched && gl == GLV && kpl == KPLV) {                                                                       \
+        if (nw == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_census_fused_kernel<1, GLV, KPLV>), grid, block, 0, ctx->stream, a); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_census_fused_kernel<2, GLV, KPLV>), grid, block, 0, ctx->stream, a);         \
+        launched = true;                                                                                               \
     }
-        if (nw == 1) { PMX_FUSED_KPL(1) } else { PMX_FUSED_KPL(2) }
-#undef PMX_FUSED_KPL
-#undef PMX_FUSED_LAUNCH
+        PMX_FUSED_MAPS(PMX_FUSED_CASE)
+#undef PMX_FUSED_CASE
     }
+    PMX_CHECK(launched, PMX_ERR_STATE, "pmx_sgm (fused): no kernel for lane map %dx%d", gl, kpl);
     PMX_HIP(hipGetLastError());
     cv->repr = PMX_REPR_SGM_U8X8;
     if (ctx->near_owner == cv) ctx->near_owner = nullptr;  // the volume changed under the cache
@@ -471,21 +562,22 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
 
 int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity) {
     size_t npix = (size_t)cv->H * cv->W;
-    size_t want = (npix + 15) / 16;  // 4 pixels per wave, 4 waves per block
+    const int ppw = 64 / cv->gl;
+    size_t want = (npix + 4 * ppw - 1) / (4 * ppw);  // ppw pixels per wave, 4 waves per block
     int grid = (int)(want < 65536 ? want : 65536);
-    const int nb = (cv->Dp + 63) / 64;  // dwords per lane so that 16 lanes cover the Dp bytes of a pixel
-    pmx_stage_scope t(ctx, PMX_STAGE_WTA);
-#define PMX_WTA8(NBV)                                                                                                   \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(sum8_wta_kernel<NBV>), dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), npix, \
-                       (double)cv->d0, invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near)
-    switch (nb) {
-        case 1: PMX_WTA8(1); break;
-        case 2: PMX_WTA8(2); break;
-        case 3: PMX_WTA8(3); break;
-        case 4: PMX_WTA8(4); break;
-        default: PMX_WTA8(5); break;
+    bool launched = false;
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_WTA);
+#define PMX_WTA_CASE(GLV, KPLV)                                                                                         \
+    if (!launched && cv->gl == GLV && cv->kpl == KPLV) {                                                                \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sum8_wta_kernel<GLV, KPLV>), dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), \
+                           npix, (double)cv->d0, invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near);     \
+        launched = true;                                                                                                \
     }
-#undef PMX_WTA8
+        PMX_FUSED_MAPS(PMX_WTA_CASE)
+#undef PMX_WTA_CASE
+    }
+    PMX_CHECK(launched, PMX_ERR_STATE, "pmx_wta (fused): no kernel for lane map %dx%d", cv->gl, cv->kpl);
     PMX_HIP(hipGetLastError());
     ctx->near_owner = cv;
     return PMX_OK;

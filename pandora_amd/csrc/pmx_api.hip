@@ -329,7 +329,7 @@ extern "C" int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
     // the Hamming costs can stay implicit (codes only) while nothing needs the float volume; only
     // worth it where the fused SGM path can consume them
     const int nw = (win * win + 31) / 32;
-    const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 2 && cv->D <= 256 && abs(cv->d0) + cv->D <= 480 && !ctx->bad_left &&
+    const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 2 && cv->D < 320 && abs(cv->d0) + cv->D <= 1024 / nw - 32 && !ctx->bad_left &&
                        !ctx->bad_right && !ctx->grid_min;
     return pmx_launch_census(ctx, cv, win, defer);
 }
@@ -511,10 +511,13 @@ extern "C" int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double 
     return pmx_launch_from_keys(ctx, dev_keys, d0_global, subpix, invalid_disparity);
 }
 
-extern "C" int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp) {
+extern "C" int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp, int* gl,
+                                    int* kpl) {
     PMX_CHECK(ctx && cv, PMX_ERR_ARG, "pmx_debug_path_costs: null argument");
     PMX_CHECK(cv->repr == PMX_REPR_SGM_U8X8 && cv->ldir, PMX_ERR_STATE, "pmx_debug_path_costs: volume is not in the fused SGM representation");
     if (Dp) *Dp = cv->Dp;
+    if (gl) *gl = cv->gl;
+    if (kpl) *kpl = cv->kpl;
     size_t n = (size_t)8 * cv->H * cv->W * cv->Dp;
     if (!host_out) return PMX_OK;
     PMX_CHECK(host_bytes >= n, PMX_ERR_ARG, "pmx_debug_path_costs: host buffer too small (%zu < %zu)", host_bytes, n);

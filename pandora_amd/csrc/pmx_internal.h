@@ -90,6 +90,7 @@ struct pmx_cv {
     uint8_t* ldir = nullptr;
     size_t ldir_bytes = 0;
     int Dp = 0;
+    int gl = 0, kpl = 0;  // lane map of the fused kernels: gl lanes per scanline/pixel, kpl disparities per lane
     size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
 };
 

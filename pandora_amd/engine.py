@@ -63,6 +63,7 @@ class Engine:
         self.device = int(device)
         self.H = self.W = 0
         self.subpix = 1
+        self.lazy = True  # library default (pmx_set_lazy)
 
     def close(self):
         if self.ctx:
@@ -100,6 +101,7 @@ class Engine:
     def set_lazy(self, on):
         """Lazy exact representations of the volume (default on); off = always float32 (reference-like)."""
         check(_lib.lib().pmx_set_lazy(self.ctx, int(bool(on))), "pmx_set_lazy")
+        self.lazy = bool(on)
 
     def alloc_cv(self, D, d0):
         h = _lib.lib().pmx_cv_alloc(self.ctx, int(D), int(d0))
@@ -177,13 +179,21 @@ class Engine:
         check(_lib.lib().pmx_wta_from_keys(self.ctx, C.c_void_p(dev_keys_ptr), float(d0_global), int(subpix),
                                            float(invalid_disparity)), "pmx_wta_from_keys")
 
-    def debug_path_costs(self, cv):
-        """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation."""
-        dp = C.c_int(0)
-        check(_lib.lib().pmx_debug_path_costs(self.ctx, cv.handle, None, 0, C.byref(dp)), "pmx_debug_path_costs")
+    def debug_path_costs(self, cv, raw=False):
+        """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation
+        (raw=True: the device byte order [8][H][W][Dp] and the (gl, kpl) lane map)."""
+        dp, gl, kpl = C.c_int(0), C.c_int(0), C.c_int(0)
+        fn = _lib.lib().pmx_debug_path_costs
+        check(fn(self.ctx, cv.handle, None, 0, C.byref(dp), C.byref(gl), C.byref(kpl)), "pmx_debug_path_costs")
         out = np.empty((8, self.H, self.W, dp.value), np.uint8)
-        check(_lib.lib().pmx_debug_path_costs(self.ctx, cv.handle, _p(out, C.c_uint8), out.nbytes, C.byref(dp)), "pmx_debug_path_costs")
-        return out[:, :, :, :cv.D]
+        check(fn(self.ctx, cv.handle, _p(out, C.c_uint8), out.nbytes, C.byref(dp), C.byref(gl), C.byref(kpl)), "pmx_debug_path_costs")
+        if raw:
+            return out, gl.value, kpl.value
+        d = np.arange(cv.D)
+        s, k, m4 = d // kpl.value, d % kpl.value, kpl.value & ~3
+        nact = -(-cv.D // kpl.value)
+        pos = np.where(k < m4, s * m4 + k, nact * m4 + s)
+        return out[:, :, :, pos]
 
     # -- measurement -------------------------------------------------------------------------
     def sync(self):

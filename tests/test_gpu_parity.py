@@ -329,6 +329,44 @@ def test_d_sharded_wta_keys_equal_full_wta(eng, oracle, is_max):
     np.testing.assert_array_equal(val, eval_)
 
 
+@pytest.mark.parametrize("gl,kpl,dmin,dmax", [
+    (16, 4, -20, 6), (16, 5, -40, 30), (16, 8, -3, 100), (16, 9, 0, 128), (16, 12, -100, 80), (16, 13, -97, 100),
+    (16, 16, -120, 120), (16, 17, 0, 256), (16, 20, -150, 150),
+    (8, 8, -30, 30), (8, 9, -40, 26), (8, 12, -60, 30), (8, 13, 0, 100), (8, 16, -63, 63), (8, 17, 0, 128), (8, 17, -64, 64),
+    (8, 20, -100, 50), (4, 16, -60, 0), (4, 17, 0, 64), (4, 20, -70, 5)])
+def test_fused_lane_maps(eng, oracle, monkeypatch, gl, kpl, dmin, dmax):
+    """Every (lanes per scanline) x (disparities per lane) instantiation of the fused census->SGM kernel and of
+    its WTA consumer, forced through PMX_FUSED_MAP on a small pair (the automatic choice would always take the
+    widest group here): path costs, WTA, refinement and materialisation must equal the oracle bit for bit."""
+    if not eng.lazy:
+        pytest.skip("fused kernels only exist on the lazy path")
+    monkeypatch.setenv("PMX_FUSED_MAP", f"{gl}x{kpl}")
+    H, W, win = 21, 83, 5
+    D = dmax - dmin + 1
+    assert gl * kpl > D
+    L, R = pair(H, W, seed=gl * 100 + kpl, shift=-3)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(D, dmin)
+    eng.census(cv, win)
+    eng.sgm(cv, 8, 32, False, float(win * win + 1), False)
+    assert eng.debug_path_costs(cv, raw=True)[1:] == (gl, kpl)  # the forced map was taken
+    eng.set_validity(None)
+    eng.wta(cv, False, -9999.0)
+    disp0, val0 = eng.get_disparity()
+    eng.refine(cv, "vfit", False)
+    disp, val, itp = eng.get_disparity(want_itp=True)
+    c = oracle.census_cost(L, R, D, dmin, 1, win)
+    s = oracle.sgm(c, 8, 32, False, float(win * win + 1), False)
+    ed0, ev0 = oracle.wta(s, dmin, 1, False, -9999.0)
+    np.testing.assert_array_equal(disp0, ed0)
+    np.testing.assert_array_equal(val0, ev0)
+    eitp, ed, ev = oracle.refine(s, ed0, ev0, dmin, dmax, 1, False, "vfit")
+    np.testing.assert_array_equal(disp, ed)
+    np.testing.assert_array_equal(val, ev)
+    np.testing.assert_array_equal(itp, eitp)
+    np.testing.assert_array_equal(cv.to_host(), s)
+
+
 @pytest.mark.parametrize("win,P1,P2", [(5, 8, 32), (3, 1, 2), (7, 8, 32), (5, 8.5, 32)])
 def test_fast_path_wta_refine_equal_general_path(eng, oracle, win, P1, P2):
     """Census -> SGM -> WTA -> vfit/quadratic through the handle WITHOUT downloading the volume in

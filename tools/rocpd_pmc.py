@@ -17,14 +17,16 @@ def main(path):
     name_col = "display_name" if "display_name" in scols else "kernel_name"
     dcols = [r[1] for r in cur.execute(f"pragma table_info({disp})")]
     ev_col = "event_id" if "event_id" in dcols else "id"
-    q = (f"select s.{name_col}, i.name, p.value from {pm} p join {info} i on p.pmc_id = i.id "
+    q = (f"select s.{name_col}, i.name, p.value, d.id from {pm} p join {info} i on p.pmc_id = i.id "
          f"join {disp} d on d.{ev_col} = p.event_id join {sym} s on d.kernel_id = s.id")
-    acc = defaultdict(list)
-    for kname, cname, val in cur.execute(q):
-        acc[(kname, cname)].append(val)
+    acc = defaultdict(lambda: defaultdict(float))  # (kernel, counter) -> dispatch id -> sum over XCD/SE instances
+    for kname, cname, val, did in cur.execute(q):
+        acc[(kname, cname)][did] += val
     print("kernel,counter,dispatches,avg_value,units_note")
-    for (kname, cname), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-        print(f"\"{kname}\",{cname},{len(v)},{sum(v) / len(v):.1f},KiB per dispatch (FETCH_SIZE/WRITE_SIZE)")
+    for (kname, cname), per in sorted(acc.items(), key=lambda kv: -sum(kv[1].values())):
+        v = list(per.values())
+        note = "KiB per dispatch" if cname in ("FETCH_SIZE", "WRITE_SIZE") else "per dispatch (summed over XCD/SE instances)"
+        print(f"\"{kname}\",{cname},{len(v)},{sum(v) / len(v):.1f},{note}")
 
 
 if __name__ == "__main__":
