@@ -190,6 +190,17 @@ def main():
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
             "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         }
+        # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
+        host_out = eng.get_disparity(want_itp=True)  # (also faults the host pages in once, as a streaming caller would)
+        eng.sync()
+        t1 = time.perf_counter()
+        eng.set_images(L, R, 1)
+        run_pipeline(eng, cv, win, P1, P2)
+        eng.get_disparity(want_itp=True, out=host_out)
+        pcie_s = time.perf_counter() - t1
+        out["pcie_inclusive"] = {"ms_per_step": round(pcie_s * 1e3, 3), "value": round(cells / pcie_s / 1e6, 1), "unit": "Mdisp/s",
+                                 "note": "pmx_set_images (2 float32 images up, pageable host memory) + pipeline + "
+                                         "pmx_get_disparity (disp, validity int64, itp down); informational only"}
         if args.cpu_rows > 0:
             rows = min(args.cpu_rows, H)
             base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)

@@ -468,11 +468,14 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
 
 // Lane map for a volume: gl lanes per scanline, kpl disparities per lane with gl*kpl > D (the pad slot the
 // DPP shifts rely on) and kpl = 0 or 1 mod 4 (one wide store + at most one byte).  Among the maps the kernels
-// are instantiated for, take the cheapest by an issue model calibrated on MI355X at 2048^2 (tools/bench_fused.py:
-// 16x8 2.07 ms and 8x16 2.40 ms at D=127; 16x12 2.55, 8x17 2.78, 16x9 2.92 ms at D=129): ~70 instructions of
-// per-step overhead, ~9.5 per disparity slot, ~25 issue slots per vector-memory instruction, a surcharge for the
-// trailing-byte store, times the rounds the waves need on the chip's 1024 SIMDs; maps that leave fewer than
-// three waves per SIMD are latency-bound and pay 1.5x.
+// are instantiated for, take the cheapest by a model of one wave-step fitted on MI355X (tools/bench_fused.py with
+// forced maps; ns per wave-step = kernel time / steps / waves per SIMD):
+//   16x12 311, 16x8 252, 16x9 324 (2048^2, 4 waves/SIMD); 8x17 624, 8x20 683 (4096^2, 4 waves/SIMD);
+//   lone or paired waves (latency-bound): 16x5 521, 16x8 661, 8x12 857, 8x16 1172, 8x17 1357.
+//   issue   = 1.75 ns x (70 + 9.5 kpl + #vmem)          one instruction per ~4.2 cycles per SIMD
+//   memory  = #vmem x tau(gl), tau = 55 / 85 / 120 ns   texture path; narrower groups touch more rows per instruction
+//   latency = 250 + 60 kpl (+100 with a trailing byte)  what a step costs a wave that has the SIMD to itself
+//   step    = max(latency, waves_per_SIMD x max(issue, memory));  +8 % for trailing-byte maps (measured, unexplained)
 static void fused_choose_map(int H, int W, int D, int nw, int* gl_out, int* kpl_out) {
     // test hook: PMX_FUSED_MAP=<gl>x<kpl> forces a map (used by the parity tests to reach every instantiation
     // on small volumes); ignored unless it is a legal map for this D
@@ -488,7 +491,7 @@ static void fused_choose_map(int H, int W, int D, int nw, int* gl_out, int* kpl_
     double best = 1e30;
     *gl_out = 16;
     *kpl_out = 20;
-    for (int gl = 4; gl <= 16; gl *= 2) {
+    for (int gl = 16; gl >= 4; gl /= 2) {  // widest group first: a narrower one must win by 5 % (model accuracy)
         for (int t = 0; t < 2; ++t) {
             int kpl = D / gl + 1;  // gl*kpl > D
             if (t == 0) kpl = (kpl + 3) & ~3;                                   // whole dwords only
@@ -497,13 +500,18 @@ static void fused_choose_map(int H, int W, int D, int nw, int* gl_out, int* kpl_
             if (kpl > 20) continue;
             if (gl == 4 && kpl < 16) continue;  // (maps not instantiated: small D is served by wider groups)
             if (gl == 8 && kpl < 8) continue;
-            const int lpw = 64 / gl;
+            const int lpw = 64 / gl, tb = kpl & 1, m4 = kpl & ~3;
             const double waves = 2.0 * ((H + lpw - 1) / lpw) + 6.0 * ((W + lpw - 1) / lpw);
-            const double rounds = waves / 1024.0 > 1.0 ? waves / 1024.0 : 1.0;
-            const int nvmem = (kpl * nw + 3) / 4 + 2 + (kpl & 1);               // code loads + left code + store(s)
-            double cost = (70.0 + 9.5 * kpl * (nw > 1 ? 1.25 : 1.0) + 25.0 * nvmem + 40.0 * (kpl & 1)) * rounds;
-            if (waves > 1024.0 && waves < 3.0 * 1024.0) cost *= 1.5;           // too few waves per SIMD to hide latency
-            if (cost < best) { best = cost; *gl_out = gl; *kpl_out = kpl; }
+            const double w = waves / 1024.0 > 1.0 ? waves / 1024.0 : 1.0;
+            const int nstore = (m4 == 20 ? 2 : 1) + tb;                         // 20 bytes leave as 16 + 4
+            const int nvmem = (kpl * nw + 3) / 4 + 1 + nstore;                  // code loads + left code + stores
+            const double issue = 1.75 * (70.0 + 9.5 * kpl * (nw > 1 ? 1.25 : 1.0) + nvmem + 10.0 * tb);
+            const double memory = nvmem * (gl == 16 ? 55.0 : gl == 8 ? 85.0 : 120.0);
+            const double latency = 250.0 + 60.0 * kpl + 100.0 * tb;
+            double step = w * (issue > memory ? issue : memory);
+            if (step < latency) step = latency;
+            if (tb) step *= 1.08;
+            if (step < best * (gl == 16 ? 1.0 : 0.95)) { best = step; *gl_out = gl; *kpl_out = kpl; }
         }
     }
 }

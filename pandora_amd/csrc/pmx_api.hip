@@ -57,6 +57,17 @@ static void img_free(float*& p) {
     p = nullptr;
 }
 
+// masks and disparity grids belong to one pair
+static void free_pair_extras(pmx_ctx* ctx) {
+    hipFree(ctx->msk_left); ctx->msk_left = nullptr;
+    hipFree(ctx->msk_right); ctx->msk_right = nullptr;
+    hipFree(ctx->bad_left); ctx->bad_left = nullptr;
+    hipFree(ctx->bad_right); ctx->bad_right = nullptr;
+    hipFree(ctx->grid_min); ctx->grid_min = nullptr;
+    hipFree(ctx->grid_max); ctx->grid_max = nullptr;
+    ctx->bad_win = 0;
+}
+
 static void free_images(pmx_ctx* ctx) {
     img_free(ctx->left);
     for (int k = 0; k < PMX_MAX_SUBPIX; ++k) img_free(ctx->right[k]);
@@ -123,22 +134,29 @@ extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* righ
               "pmx_set_images: subpix must be 1, 2 or 4 (matching_cost.py:70), got %d", subpix);
     PMX_HIP(hipSetDevice(ctx->device));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
-    free_images(ctx);
-    ctx->H = H; ctx->W = W; ctx->subpix = subpix;
     size_t n = (size_t)H * W;
-    PMX_HIP(img_alloc(ctx, &ctx->left, n));
-    PMX_HIP(img_alloc(ctx, &ctx->right[0], n));
+    // a stream of pairs of one shape (the production case) keeps its device buffers: no hipFree / hipMalloc per pair
+    const bool same_shape = ctx->left && ctx->H == H && ctx->W == W && ctx->subpix == subpix;
+    if (same_shape) {
+        free_pair_extras(ctx);
+    } else {
+        free_images(ctx);
+        ctx->H = H; ctx->W = W; ctx->subpix = subpix;
+        PMX_HIP(img_alloc(ctx, &ctx->left, n));
+        PMX_HIP(img_alloc(ctx, &ctx->right[0], n));
+        for (int k = 1; k < subpix; ++k) PMX_HIP(img_alloc(ctx, &ctx->right[k], (size_t)H * (W - 1)));
+        PMX_HIP(hipMalloc((void**)&ctx->disp, n * sizeof(float)));
+        PMX_HIP(hipMalloc((void**)&ctx->itp, n * sizeof(float)));
+        PMX_HIP(hipMalloc((void**)&ctx->validity, n * sizeof(int64_t)));
+        PMX_HIP(hipMalloc(&ctx->near, n * 16));
+    }
+    ctx->near_owner = nullptr;
     PMX_HIP(hipMemcpyAsync(ctx->left, left, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipMemcpyAsync(ctx->right[0], right, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     for (int k = 1; k < subpix; ++k) {
-        PMX_HIP(img_alloc(ctx, &ctx->right[k], (size_t)H * (W - 1)));
         int rc = pmx_launch_shift_right(ctx, ctx->right[0], H, W, subpix, k, ctx->right[k]);
         if (rc) return rc;
     }
-    PMX_HIP(hipMalloc((void**)&ctx->disp, n * sizeof(float)));
-    PMX_HIP(hipMalloc((void**)&ctx->itp, n * sizeof(float)));
-    PMX_HIP(hipMalloc((void**)&ctx->validity, n * sizeof(int64_t)));
-    PMX_HIP(hipMalloc(&ctx->near, n * 16));
     PMX_HIP(hipMemsetAsync(ctx->near, 0xff, n * 16, ctx->stream));
     PMX_HIP(hipMemsetAsync(ctx->validity, 0, n * sizeof(int64_t), ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller

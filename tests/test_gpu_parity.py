@@ -398,3 +398,32 @@ def test_fast_path_wta_refine_equal_general_path(eng, oracle, win, P1, P2):
         np.testing.assert_array_equal(val, ev)
         np.testing.assert_array_equal(itp, eitp)
         np.testing.assert_array_equal(cv.to_host(), s)  # materialisation last
+
+
+def test_streaming_pairs_reuse_device_buffers_and_host_outputs(eng, oracle):
+    """A second pair of the same shape reuses the device buffers (pmx_set_images) and the caller's output arrays
+    (get_disparity(out=...)); masks of the first pair must not leak into the second."""
+    H, W, dmin, dmax, win = 33, 61, -7, 5, 5
+    D = dmax - dmin + 1
+    outs = None
+    for seed, masked in ((1, True), (2, False)):
+        L, R = pair(H, W, seed=seed)
+        eng.set_images(L, R, 1)
+        if masked:
+            m = np.zeros((H, W), np.int16)
+            m[5:9, 10:30] = 1
+            eng.set_masks(m, None, 0, 1)
+        cv = eng.alloc_cv(D, dmin)
+        eng.census(cv, win)
+        eng.cv_masked(cv, win)
+        eng.sgm(cv, 8, 32, False, float(win * win + 1), False)
+        eng.set_validity(None)
+        eng.wta(cv, False, -9999.0)
+        outs = eng.get_disparity(want_itp=False, out=outs)
+    c = oracle.census_cost(L, R, D, dmin, 1, win)
+    s = oracle.sgm(c, 8, 32, False, float(win * win + 1), False)
+    ed, ev = oracle.wta(s, dmin, 1, False, -9999.0)
+    np.testing.assert_array_equal(outs[0], ed)
+    np.testing.assert_array_equal(outs[1], ev)
+    with pytest.raises(ValueError):
+        eng.get_disparity(out=(np.empty((H, W), np.float64), outs[1]))
