@@ -141,6 +141,19 @@ int pmx_stage_time(pmx_ctx* ctx, int stage, double* total_ms, int* launches);
  * (k < (kpl & ~3)) ? s*(kpl & ~3) + k : nact*(kpl & ~3) + s   with s = d / kpl, k = d % kpl, nact = ceil(D / kpl).
  * Returns PMX_ERR_STATE when the handle is not in that representation. */
 int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp, int* gl, int* kpl);
+/* ---- validation --------------------------------------------------------------------------
+ * Replaces validation.CrossCheckingAccurate.disparity_checking (src/pandora/validation/validation.py:226-371; the
+ * class is registered for both "cross_checking_accurate" and "cross_checking_fast").  Host maps in/out, computed
+ * on the device: validity_left int64 [H][W] is updated in place (PANDORA_MSK_PIXEL_OCCLUSION / _MISMATCH added
+ * to the pixels the check rejects), conf_out float32 [H][W] receives |disp_right(q) + disp_left| (NaN where the
+ * pixel is invalid or q = rint(col + disp_left) leaves the row).  [dmin, dmax] is the dataset's
+ * "disparity_interval" (disparity.py:334-347).  mask_border (:368-369) stays with the caller. */
+int pmx_cross_checking(pmx_ctx* ctx, const float* disp_left, int64_t* validity_left, const float* disp_right, int H, int W,
+                       int dmin, int dmax, double threshold, float* conf_out);
+/* Replaces matching_cost_cpp.reverse_disp_range (matching_cost/cpp/src/matching_cost.cpp:59-132): per-pixel right
+ * disparity ranges from the left ones; [global_min, global_max] must bracket every (int)left_min / (int)left_max. */
+int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const float* left_max, int H, int W, int global_min,
+                           int global_max, float* right_min, float* right_max);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

@@ -163,3 +163,21 @@ def reverse_cost_volume(cv, min_disp):
     out = np.empty_like(cv)
     lib().orc_reverse_cost_volume(_p(cv), H, W, D, int(min_disp), _p(out))
     return out
+
+
+def reverse_disp_range(left_min, left_max):
+    a, b = _f32(left_min), _f32(left_max)
+    H, W = a.shape
+    rmin, rmax = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+    lib().orc_reverse_disp_range(_p(a), _p(b), H, W, _p(rmin), _p(rmax))
+    return rmin, rmax
+
+
+def cross_checking(disp_left, validity_left, disp_right, dmin, dmax, threshold):
+    """validation.py:226-371 -> (validity_left updated copy, confidence float32 [H][W])."""
+    dl, dr = _f32(disp_left), _f32(disp_right)
+    H, W = dl.shape
+    val = np.ascontiguousarray(validity_left, np.int64).copy()
+    conf = np.empty((H, W), np.float32)
+    lib().orc_cross_checking(_p(dl), _p(val, C.c_int64), _p(dr), H, W, int(dmin), int(dmax), C.c_double(threshold), _p(conf))
+    return val, conf

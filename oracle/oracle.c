@@ -618,3 +618,79 @@ void orc_reverse_cost_volume(const float* left_cv, int H, int W, int D, int min_
                     (col < 0 || col >= W) ? NAN : left_cv[IDX3(i, col, D - 1 - d, W, D)];
             }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * matching_cost.cpp:59-132 reverse_disp_range: per-pixel right disparity ranges from the left ones.
+ * For every left pixel and every integer d in [(int)min, (int)max] the right pixel col+d (when inside the
+ * row) receives -d into its running min / max; untouched right pixels end NaN.  NaN ranges are skipped.
+ * ------------------------------------------------------------------------------------------- */
+void orc_reverse_disp_range(const float* left_min, const float* left_max, int H, int W, float* right_min,
+                            float* right_max) {
+    for (size_t i = 0; i < (size_t)H * W; ++i) {
+        right_min[i] = INFINITY;
+        right_max[i] = -INFINITY;
+    }
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            float a = left_min[(size_t)r * W + c], b = left_max[(size_t)r * W + c];
+            if (isnan(a) || isnan(b)) continue;
+            int dmin = (int)a, dmax = (int)b;
+            for (int d = dmin; d <= dmax; ++d) {
+                int rc = c + d;
+                if (rc < 0) continue;
+                if (rc >= W) break;
+                size_t k = (size_t)r * W + rc;
+                if ((float)(-d) < right_min[k]) right_min[k] = (float)(-d);
+                if ((float)(-d) > right_max[k]) right_max[k] = (float)(-d);
+            }
+        }
+    for (size_t i = 0; i < (size_t)H * W; ++i)
+        if (isinf(right_min[i])) {
+            right_min[i] = NAN;
+            right_max[i] = NAN;
+        }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * validation/validation.py:226-371 CrossCheckingAccurate.disparity_checking (also registered as
+ * cross_checking_fast), per left pixel that is not PANDORA_MSK_PIXEL_INVALID:
+ *   q = rint(col + disp_left) (numpy rint: half to even; float32 + int64 promotes to float64);
+ *   q outside the row: nothing happens (the reference's `outside_right` test `(q < 0) & (q >= W)` is never
+ *   true, validation.py:354-355 - reproduced);
+ *   dist = |disp_right[q] + disp_left| in float32 with NaN -> +inf on both sides; conf = dist;
+ *   dist > threshold: MISMATCH (bit 9) if some d of arange(dmin, dmax+1) has col+d inside the row and
+ *   rint(disp_right[col+d]) == -d, else OCCLUSION (bit 8)  (:321-351).
+ * conf starts NaN.  A valid pixel whose disparity is NaN makes the reference's index arrays lose alignment
+ * (:278-280); the pipeline never produces one (invalid_disparity only lands on INVALID pixels) and this
+ * restatement treats it as "q outside".  mask_border (:368-369) is applied by the caller.
+ * ------------------------------------------------------------------------------------------- */
+#define ORC_MSK_INVALID 0x3C3
+#define ORC_MSK_OCCLUSION (1 << 8)
+#define ORC_MSK_MISMATCH (1 << 9)
+void orc_cross_checking(const float* disp_left, int64_t* validity_left, const float* disp_right, int H, int W,
+                        int dmin, int dmax, double threshold, float* conf) {
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            size_t i = (size_t)r * W + c;
+            conf[i] = NAN;
+            if (validity_left[i] & ORC_MSK_INVALID) continue;
+            float dl = disp_left[i];
+            if (isnan(dl)) continue;
+            double qf = rint((double)c + (double)dl);
+            if (!(qf >= 0 && qf < W)) continue;
+            int q = (int)qf;
+            float dr = disp_right[(size_t)r * W + q];
+            if (isnan(dr)) dr = INFINITY;
+            float dist = fabsf(dr + dl);
+            conf[i] = dist;
+            if (!((double)dist > threshold)) continue;
+            int mismatch = 0;
+            for (int d = dmin; d <= dmax && !mismatch; ++d) {
+                int cc = c + d;
+                if (cc < 0 || cc >= W) continue;
+                float v = disp_right[(size_t)r * W + cc];
+                if (rintf(v) == (float)(-d)) mismatch = 1;
+            }
+            validity_left[i] += mismatch ? ORC_MSK_MISMATCH : ORC_MSK_OCCLUSION;
+        }
+}

@@ -80,6 +80,14 @@ void orc_refine(const float* cv, int H, int W, int D, double d_min, double d_max
 /* matching_cost.cpp:26-56 (reverse_cost_volume): (i,j,d) -> (i, j+d, -d) */
 void orc_reverse_cost_volume(const float* left_cv, int H, int W, int D, int min_disp, float* right_cv);
 
+
+/* matching_cost.cpp:59-132 (reverse_disp_range) */
+void orc_reverse_disp_range(const float* left_min, const float* left_max, int H, int W, float* right_min,
+                            float* right_max);
+/* validation/validation.py:226-371 (CrossCheckingAccurate.disparity_checking, both validation methods) */
+void orc_cross_checking(const float* disp_left, int64_t* validity_left, const float* disp_right, int H, int W,
+                        int dmin, int dmax, double threshold, float* conf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,10 @@ SIGNATURES = {
     "pmx_set_disparity": (C.c_int, [vp, c_float_p, c_i64_p]),
     "pmx_wta_minkey": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "pmx_wta_from_keys": (C.c_int, [vp, vp, C.c_double, C.c_int, C.c_float]),
+    "pmx_cross_checking": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_double, C.POINTER(C.c_float)]),
+    "pmx_reverse_disp_range": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmx_reset_stage_times": (C.c_int, [vp]),

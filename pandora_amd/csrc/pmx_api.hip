@@ -587,3 +587,48 @@ extern "C" int pmx_stage_time(pmx_ctx* ctx, int stage, double* total_ms, int* la
     if (launches) *launches = ctx->stages[stage].launches;
     return PMX_OK;
 }
+
+
+// ---- validation on the device ---------------------------------------------------------
+extern "C" int pmx_cross_checking(pmx_ctx* ctx, const float* disp_left, int64_t* validity_left, const float* disp_right, int H, int W,
+                                  int dmin, int dmax, double threshold, float* conf_out) {
+    PMX_CHECK(ctx && disp_left && validity_left && disp_right && conf_out, PMX_ERR_ARG, "pmx_cross_checking: null argument");
+    PMX_CHECK(H > 0 && W > 0 && dmin <= dmax, PMX_ERR_ARG, "pmx_cross_checking: bad shape %dx%d or interval [%d,%d]", H, W, dmin, dmax);
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W;
+    int rc = pmx_need_small(ctx, n * (4 + 4 + 4 + 8));
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_val = (int64_t*)base;
+    float* d_dl = (float*)(base + n * 8);
+    float* d_dr = d_dl + n;
+    float* d_conf = d_dr + n;
+    PMX_HIP(hipMemcpyAsync(d_val, validity_left, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_dl, disp_left, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_dr, disp_right, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_cross_checking(ctx, d_dl, d_val, d_dr, H, W, dmin, dmax, threshold, d_conf);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(validity_left, d_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(conf_out, d_conf, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const float* left_max, int H, int W, int global_min,
+                                      int global_max, float* right_min, float* right_max) {
+    PMX_CHECK(ctx && left_min && left_max && right_min && right_max, PMX_ERR_ARG, "pmx_reverse_disp_range: null argument");
+    PMX_CHECK(H > 0 && W > 0, PMX_ERR_ARG, "pmx_reverse_disp_range: bad shape %dx%d", H, W);
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W;
+    int rc = pmx_need_small(ctx, n * 16);
+    if (rc) return rc;
+    float* d = (float*)ctx->small;
+    PMX_HIP(hipMemcpyAsync(d, left_min, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d + n, left_max, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_reverse_disp_range(ctx, d, d + n, H, W, global_min, global_max, d + 2 * n, d + 3 * n);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(right_min, d + 2 * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(right_max, d + 3 * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}

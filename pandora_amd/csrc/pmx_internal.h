@@ -146,6 +146,10 @@ int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity)
 int pmx_launch_sum8_refine(pmx_ctx* ctx, const pmx_cv* cv, int method);
 int pmx_launch_sum8_to_float(pmx_ctx* ctx, pmx_cv* cv);
 int pmx_launch_census_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
+int pmx_launch_cross_checking(pmx_ctx* ctx, const float* dl, int64_t* validity, const float* dr, int H, int W, int dmin, int dmax,
+                              double threshold, float* conf);
+int pmx_launch_reverse_disp_range(pmx_ctx* ctx, const float* lmin, const float* lmax, int H, int W, int gmin, int gmax, float* rmin,
+                                  float* rmax);
 int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared);
 int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);
 int pmx_launch_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);

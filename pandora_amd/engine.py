@@ -189,6 +189,34 @@ class Engine:
         check(_lib.lib().pmx_wta_from_keys(self.ctx, C.c_void_p(dev_keys_ptr), float(d0_global), int(subpix),
                                            float(invalid_disparity)), "pmx_wta_from_keys")
 
+    # -- validation -------------------------------------------------------------
+    def cross_checking(self, disp_left, validity_left, disp_right, dmin, dmax, threshold):
+        """validation.py:226-371 on the device; returns (validity int64 updated copy, confidence float32)."""
+        dl = np.ascontiguousarray(disp_left, np.float32)
+        dr = np.ascontiguousarray(disp_right, np.float32)
+        if dl.ndim != 2 or dl.shape != dr.shape:
+            raise ValueError("cross_checking: left/right disparity maps must be 2-D and of the same shape")
+        val = np.array(validity_left, np.int64, order="C", copy=True)
+        conf = np.empty(dl.shape, np.float32)
+        check(_lib.lib().pmx_cross_checking(self.ctx, _p(dl, C.c_float), _p(val, C.c_int64), _p(dr, C.c_float), dl.shape[0],
+                                            dl.shape[1], int(dmin), int(dmax), float(threshold), _p(conf, C.c_float)),
+              "pmx_cross_checking")
+        return val, conf
+
+    def reverse_disp_range(self, left_min, left_max):
+        """matching_cost.cpp:59-132 on the device; returns (right_min, right_max) float32."""
+        a = np.ascontiguousarray(left_min, np.float32)
+        b = np.ascontiguousarray(left_max, np.float32)
+        if a.ndim != 2 or a.shape != b.shape:
+            raise ValueError("reverse_disp_range: min/max grids must be 2-D and of the same shape")
+        if np.all(np.isnan(a)) or np.all(np.isnan(b)):
+            return np.full(a.shape, np.nan, np.float32), np.full(a.shape, np.nan, np.float32)
+        gmin, gmax = int(np.nanmin(a)), int(np.nanmax(b))
+        rmin, rmax = np.empty(a.shape, np.float32), np.empty(a.shape, np.float32)
+        check(_lib.lib().pmx_reverse_disp_range(self.ctx, _p(a, C.c_float), _p(b, C.c_float), a.shape[0], a.shape[1], gmin, gmax,
+                                                _p(rmin, C.c_float), _p(rmax, C.c_float)), "pmx_reverse_disp_range")
+        return rmin, rmax
+
     def debug_path_costs(self, cv, raw=False):
         """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation
         (raw=True: the device byte order [8][H][W][Dp] and the (gl, kpl) lane map)."""

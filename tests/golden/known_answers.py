@@ -207,3 +207,25 @@ MEDIAN = [
          valid=[[4, 0, 4, 16 + 1, 0], [128, 1, 256, 0, 0], [64, 512, 2, 4 + 8, 0], [2, 256, 64, 0, 2]],
          expected=[[7, 8, 4, 5, 5], [5, 9, 4, 3.5, 8], [5, 2, 7, 2, 2], [6, 1, 9, 2, 4]]),
 ]
+
+
+# ---- validation / cross-checking (tests/test_validation.py) -------------------------------------
+_RND = 1 << 1   # PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING
+_LBORDER = 1 << 0  # PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
+_OCC, _MIS = 1 << 8, 1 << 9
+_nan = float("nan")
+CROSS_CHECKING = [
+    {"cite": "test_validation.py:104-140 test_cross_checking",
+     "left": [[0, -1, 1, -2], [2, 2, -1, 0]], "right": [[0, 2, -1, -1], [1, 1, -2, -1]],
+     "validity": [[0, 0, 0, _RND], [0, 0, 0, 0]], "interval": (-2, 2), "threshold": 0.0,
+     "conf": [[0.0, 1.0, 0.0, _nan], [0.0, 1.0, 0.0, 1.0]],
+     "mask": [[0, _MIS, 0, _RND], [0, _MIS, 0, _OCC]]},
+    {"cite": "test_validation.py:142-252 test_distance_lr_rl",
+     "left": [[_nan] * 4, [_nan, 1, -1, _nan], [_nan] * 4], "right": [[_nan] * 4, [_nan, 0, -1, _nan], [_nan] * 4],
+     "validity": [[_LBORDER] * 4, [_LBORDER, 0, 0, _LBORDER], [_LBORDER] * 4], "interval": (-1, 1), "threshold": 0.0,
+     "conf": [[_nan] * 4, [_nan, 0.0, 1.0, _nan], [_nan] * 4], "mask": None},
+    {"cite": "test_validation.py:255-308 test_cross_checking_float_disparity",
+     "left": [[0, -1.2, 1, -2], [2, 1.8, -1, 0]], "right": [[0, 2, -1.2, -1], [0.8, 1, -2, -1]],
+     "validity": [[0, 0, 0, _RND], [0, 0, 0, 0]], "interval": (-2, 2), "threshold": 0.0,
+     "conf": None, "mask": [[0, _MIS, 0, _RND], [0, _MIS, 0, _OCC]]},
+]

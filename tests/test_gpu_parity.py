@@ -427,3 +427,42 @@ def test_streaming_pairs_reuse_device_buffers_and_host_outputs(eng, oracle):
     np.testing.assert_array_equal(outs[1], ev)
     with pytest.raises(ValueError):
         eng.get_disparity(out=(np.empty((H, W), np.float64), outs[1]))
+
+
+@pytest.mark.parametrize("case", ka.CROSS_CHECKING, ids=lambda c: c["cite"])
+def test_cross_checking_reference_vectors(eng, case):
+    val, conf = eng.cross_checking(np.array(case["left"], np.float32), np.array(case["validity"], np.int64),
+                                   np.array(case["right"], np.float32), case["interval"][0], case["interval"][1], case["threshold"])
+    if case["conf"] is not None:
+        np.testing.assert_array_equal(conf, np.array(case["conf"], np.float32))
+    if case["mask"] is not None:
+        np.testing.assert_array_equal(val, np.array(case["mask"], np.int64))
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,thr", [(37, 300, -20, 9, 1.0), (5, 64, 0, 12, 0.0), (64, 515, -3, 3, 0.5)])
+def test_cross_checking_random_maps(eng, oracle, H, W, dmin, dmax, thr):
+    """Float (refined) disparities, invalid pixels, NaN in the right map, pixels whose match leaves the row."""
+    rng = np.random.default_rng(H * W)
+    left = (rng.integers(dmin, dmax + 1, (H, W)) + rng.choice([0.0, 0.25, -0.5, 0.5], (H, W))).astype(np.float32)
+    right = -np.roll(left, 2, axis=1) + rng.choice([0.0, 0.0, 1.0, -2.0, 0.5], (H, W)).astype(np.float32)
+    right[rng.random((H, W)) < 0.02] = np.nan
+    val = np.where(rng.random((H, W)) < 0.1, 1 << 1, 0).astype(np.int64) | np.where(rng.random((H, W)) < 0.05, 1 << 3, 0)
+    got_val, got_conf = eng.cross_checking(left, val, right, dmin, dmax, thr)
+    exp_val, exp_conf = oracle.cross_checking(left, val, right, dmin, dmax, thr)
+    np.testing.assert_array_equal(got_val, exp_val)
+    np.testing.assert_array_equal(got_conf, exp_conf)
+    assert (exp_val & ((1 << 8) | (1 << 9))).any()
+
+
+def test_reverse_disp_range(eng, oracle):
+    rng = np.random.default_rng(12)
+    for H, W in ((7, 33), (20, 300)):
+        lo = rng.integers(-9, 4, (H, W)).astype(np.float32)
+        hi = lo + rng.integers(0, 8, (H, W)).astype(np.float32)
+        lo[0, 3] = np.nan
+        hi[1, 5] = np.nan
+        lo[2, :] = np.nan  # a whole row without a range -> NaN on the right
+        got = eng.reverse_disp_range(lo, hi)
+        exp = oracle.reverse_disp_range(lo, hi)
+        np.testing.assert_array_equal(got[0], exp[0])
+        np.testing.assert_array_equal(got[1], exp[1])

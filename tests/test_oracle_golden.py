@@ -134,3 +134,14 @@ def test_median_known_answers(oracle, case):
     ok = np.isfinite(masked)
     out[ok] = med[ok]
     np.testing.assert_array_equal(out, np.array(case["expected"], np.float32))
+
+
+@pytest.mark.parametrize("case", ka.CROSS_CHECKING, ids=lambda c: c["cite"])
+def test_cross_checking_known_answers(oracle, case):
+    val, conf = oracle.cross_checking(np.array(case["left"], np.float32), np.array(case["validity"], np.int64),
+                                      np.array(case["right"], np.float32), case["interval"][0], case["interval"][1],
+                                      case["threshold"])
+    if case["conf"] is not None:
+        np.testing.assert_array_equal(conf, np.array(case["conf"], np.float32))
+    if case["mask"] is not None:
+        np.testing.assert_array_equal(val, np.array(case["mask"], np.int64))

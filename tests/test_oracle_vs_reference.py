@@ -123,3 +123,22 @@ def test_reverse_cost_volume_matches_reference(oracle):
     cv = rng.random((6, 9, 5)).astype(np.float32)
     for md in (-2, 0, -4):
         np.testing.assert_array_equal(mc.reverse_cost_volume(cv, md), oracle.reverse_cost_volume(cv, md))
+
+
+@needs_ref
+def test_reverse_disp_range_matches_reference(oracle):
+    rng = np.random.default_rng(6)
+    for H, W in ((5, 17), (3, 40)):
+        lo = rng.integers(-6, 3, (H, W)).astype(np.float32)
+        hi = lo + rng.integers(0, 7, (H, W)).astype(np.float32)
+        lo[0, 3] = np.nan
+        hi[1, 5] = np.nan
+        rmin_r, rmax_r = mc.reverse_disp_range(lo, hi)
+        rmin, rmax = oracle.reverse_disp_range(lo, hi)
+        np.testing.assert_array_equal(rmin, rmin_r)
+        np.testing.assert_array_equal(rmax, rmax_r)
+    # the reference's own vectors (tests/test_cpp/test_matching_cost.cpp:103-201) are covered by the compiled
+    # module itself; a constant range gives -max / -min clipped at the borders
+    rmin, rmax = oracle.reverse_disp_range(np.full((2, 6), -2, np.float32), np.full((2, 6), 1, np.float32))
+    np.testing.assert_array_equal(rmin[0], [0, -1, -1, -1, -1, -1])
+    np.testing.assert_array_equal(rmax[0], [2, 2, 2, 2, 1, 0])
