@@ -531,10 +531,10 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
     size_t need = (size_t)8 * H * W * Dp;
     if (cv->ldir_bytes < need) {
         PMX_HIP(hipStreamSynchronize(ctx->stream));
-        if (cv->ldir) PMX_HIP(hipFree(cv->ldir));
+        pmx_pool_free(ctx, cv->ldir);
         cv->ldir = nullptr;
         cv->ldir_bytes = 0;
-        PMX_HIP(hipMalloc((void**)&cv->ldir, need + 64));
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->ldir, need + 64));
         cv->ldir_bytes = need;
     }
     cv->Dp = Dp; cv->gl = gl; cv->kpl = kpl;

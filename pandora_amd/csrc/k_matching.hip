@@ -279,10 +279,10 @@ static int census_codes(pmx_ctx* ctx, pmx_cv* cv) {
     const size_t total = (kCodePad + per_img) * (1 + (size_t)cv->subpix) + kCodePad;
     if (cv->codes_bytes < total * sizeof(uint32_t)) {
         PMX_HIP(hipStreamSynchronize(ctx->stream));
-        if (cv->codes) PMX_HIP(hipFree(cv->codes));
+        pmx_pool_free(ctx, cv->codes);
         cv->codes = nullptr;
         cv->codes_bytes = 0;
-        PMX_HIP(hipMalloc((void**)&cv->codes, total * sizeof(uint32_t)));
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->codes, total * sizeof(uint32_t)));
         cv->codes_bytes = total * sizeof(uint32_t);
         PMX_HIP(hipMemsetAsync(cv->codes, 0, total * sizeof(uint32_t), ctx->stream));
     }

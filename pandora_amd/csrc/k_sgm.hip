@@ -223,10 +223,10 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     if (cv->bytes < bytes) {
         // the input volume needs the same tail padding for the KPL-wide loads of its last pixel
         float* grown = nullptr;
-        PMX_HIP(hipMalloc((void**)&grown, bytes));
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&grown, bytes));
         PMX_HIP(hipMemcpyAsync(grown, cv->data, cv->cells() * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         PMX_HIP(hipStreamSynchronize(ctx->stream));
-        PMX_HIP(hipFree(cv->data));
+        pmx_pool_free(ctx, cv->data);
         cv->data = grown;
         cv->bytes = bytes;
     }

@@ -89,8 +89,9 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     free_images(ctx);
-    hipFree(ctx->scratch);
+    pmx_pool_free(ctx, ctx->scratch);
     hipFree(ctx->small);
+    pmx_pool_release(ctx);
     for (auto& s : ctx->stages)
         for (auto e : s.ev) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -105,13 +106,67 @@ extern "C" int pmx_sync(pmx_ctx* ctx) {
 
 extern "C" void* pmx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+// ---- caching allocator (see pmx_ctx) -------------------------------------------------------------------------
+hipError_t pmx_pool_alloc(pmx_ctx* ctx, void** p, size_t bytes) {
+    *p = nullptr;
+    // smallest cached block that fits without wasting more than a quarter
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool_free.size(); ++i) {
+        const size_t sz = ctx->pool_free[i].first;
+        if (sz >= bytes && sz <= bytes + bytes / 4 && (best < 0 || sz < ctx->pool_free[best].first)) best = i;
+    }
+    if (best >= 0) {
+        *p = ctx->pool_free[best].second;
+        ctx->pool_live[*p] = ctx->pool_free[best].first;
+        ctx->pool_free_bytes -= ctx->pool_free[best].first;
+        ctx->pool_free.erase(ctx->pool_free.begin() + best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {  // give the cache back to the driver and retry once
+        (void)hipGetLastError();
+        hipStreamSynchronize(ctx->stream);
+        pmx_pool_release(ctx);
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) ctx->pool_live[*p] = bytes;
+    return e;
+}
+
+void pmx_pool_free(pmx_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) {  // not ours (allocated before the pool existed)
+        hipFree(p);
+        return;
+    }
+    const size_t sz = it->second;
+    ctx->pool_live.erase(it);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
+    // keep at most a third of the device in the cache
+    if (total_b && ctx->pool_free_bytes + sz > total_b / 3) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(p);
+        return;
+    }
+    ctx->pool_free.emplace_back(sz, p);
+    ctx->pool_free_bytes += sz;
+}
+
+void pmx_pool_release(pmx_ctx* ctx) {
+    for (auto& b : ctx->pool_free) hipFree(b.second);
+    ctx->pool_free.clear();
+    ctx->pool_free_bytes = 0;
+}
+
 int pmx_need_scratch(pmx_ctx* ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return PMX_OK;
     PMX_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->scratch) PMX_HIP(hipFree(ctx->scratch));
+    pmx_pool_free(ctx, ctx->scratch);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
-    PMX_HIP(hipMalloc((void**)&ctx->scratch, bytes));
+    PMX_HIP(pmx_pool_alloc(ctx, (void**)&ctx->scratch, bytes));
     ctx->scratch_bytes = bytes;
     return PMX_OK;
 }
@@ -238,7 +293,7 @@ extern "C" pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0) {
     cv->ctx = ctx;
     cv->H = ctx->H; cv->W = ctx->W; cv->D = D; cv->d0 = d0; cv->subpix = ctx->subpix;
     cv->bytes = cv->cells() * sizeof(float) + 256;  // tail pad: wide per-lane loads of the last pixel stay in bounds
-    hipError_t e = hipMalloc((void**)&cv->data, cv->bytes);
+    hipError_t e = pmx_pool_alloc(ctx, (void**)&cv->data, cv->bytes);
     if (e != hipSuccess) {
         pmx_set_error("pmx_cv_alloc: hipMalloc(%zu bytes) failed: %s", cv->bytes, hipGetErrorString(e));
         delete cv;
@@ -246,7 +301,7 @@ extern "C" pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0) {
     }
     cv->repr = PMX_REPR_ALL_NAN;  // allocate_cost_volume's NaN fill is deferred until someone needs it
     if (!ctx->lazy && pmx_cv_materialize(ctx, cv) != PMX_OK) {
-        hipFree(cv->data);
+        pmx_pool_free(ctx, cv->data);
         delete cv;
         return nullptr;
     }
@@ -258,11 +313,14 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
     if (ctx && ctx->near_owner == cv) ctx->near_owner = nullptr;
     if (ctx) {
         hipSetDevice(ctx->device);
-        hipStreamSynchronize(ctx->stream);
+        pmx_pool_free(ctx, cv->data);
+        pmx_pool_free(ctx, cv->codes);
+        pmx_pool_free(ctx, cv->ldir);
+    } else {
+        hipFree(cv->data);
+        hipFree(cv->codes);
+        hipFree(cv->ldir);
     }
-    hipFree(cv->data);
-    hipFree(cv->codes);
-    hipFree(cv->ldir);
     delete cv;
 }
 

@@ -3,6 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -69,7 +73,17 @@ struct pmx_ctx {
     bool profiling = false;
     bool lazy = true;
     pmx_stage_rec stages[PMX_STAGE_COUNT];
+    // caching allocator for the big per-volume buffers (a hipMalloc / hipFree of a few GB costs ~100 ms each on this
+    // stack; a stream of pairs allocates and frees the same sizes over and over).  Single stream per context, so a
+    // block handed out again is ordered after the kernels that used it before.
+    std::unordered_map<void*, size_t> pool_live;       // blocks handed out -> their true size
+    std::vector<std::pair<size_t, void*>> pool_free;   // cached blocks
+    size_t pool_free_bytes = 0;
 };
+
+hipError_t pmx_pool_alloc(pmx_ctx* ctx, void** p, size_t bytes);
+void pmx_pool_free(pmx_ctx* ctx, void* p);
+void pmx_pool_release(pmx_ctx* ctx);  // hipFree every cached block
 
 // exact representations a cost-volume handle can be in (see pmx_set_lazy in the public header)
 enum { PMX_REPR_FLOAT = 0, PMX_REPR_ALL_NAN = 1, PMX_REPR_CENSUS_DEFERRED = 2, PMX_REPR_SGM_U8X8 = 3 };

@@ -3,16 +3,19 @@
 A dependency-free finite state machine (the reference builds on the `transitions` package, absent
 here): three states ``begin -> cost_volume -> disp_map``; triggers are the pipeline keys' prefixes
 (``"filter.after"`` -> ``filter``, state_machine.py:706-717).  Hot-path triggers are implemented
-(matching_cost, aggregation, optimization, disparity, refinement); the others of the reference
-(filter, validation, multiscale, cost_volume_confidence, semantic_segmentation) are outside this
-build's scope and raise ``MachineError`` naming the missing step.
+(matching_cost, aggregation, optimization, disparity, refinement) plus the validation step (SURVEY 8f
+N1: cross_checking_accurate / cross_checking_fast, with the left/right duplication of every step the
+reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
+others of the reference (filter, multiscale, cost_volume_confidence, semantic_segmentation) are
+outside this build's scope and raise ``MachineError`` naming the missing step.
 """
 import logging
 
 import numpy as np
 
-from . import aggregation, disparity, matching_cost, optimization, refinement
+from . import aggregation, disparity, matching_cost, optimization, refinement, validation
 from .criteria import validity_mask
+from .dataset import DataArray, Dataset
 
 
 class MachineError(Exception):
@@ -27,6 +30,7 @@ class PandoraMachine:
         "optimization": ("cost_volume", "cost_volume", None, "optimization_run"),
         "disparity": ("cost_volume", "disp_map", None, "disparity_run"),
         "refinement": ("disp_map", "disp_map", None, "refinement_run"),
+        "validation": ("disp_map", "disp_map", None, "validation_run"),
     }
     _transitions_check = {
         "check_matching_cost": ("begin", "cost_volume", "matching_cost_check_conf"),
@@ -34,14 +38,17 @@ class PandoraMachine:
         "check_optimization": ("cost_volume", "cost_volume", "optimization_check_conf"),
         "check_disparity": ("cost_volume", "disp_map", "disparity_check_conf"),
         "check_refinement": ("disp_map", "disp_map", "refinement_check_conf"),
+        "check_validation": ("disp_map", "disp_map", "validation_check_conf"),
     }
-    _out_of_scope = ("filter", "validation", "multiscale", "cost_volume_confidence", "semantic_segmentation")
+    _out_of_scope = ("filter", "multiscale", "cost_volume_confidence", "semantic_segmentation")
 
     def __init__(self):
         self.left_img = None
         self.right_img = None
         self.disp_min = None
         self.disp_max = None
+        self.right_disp_min = None
+        self.right_disp_max = None
         self.scale_factor = 1
         self.num_scales = 1
         self.current_scale = 0
@@ -83,10 +90,24 @@ class PandoraMachine:
         self.left_img, self.right_img = left_img, right_img
         self.disp_min = np.asarray(left_img["disparity"].sel(band_disp="min").data)
         self.disp_max = np.asarray(left_img["disparity"].sel(band_disp="max").data)
-        self.left_disparity = None
-        self.right_disparity = None
+        # right-side ranges (state_machine.py:659-675): the right image's own grids, else reversed from the left
+        if "disparity" in right_img.data_vars:
+            self.right_disp_min = np.asarray(right_img["disparity"].sel(band_disp="min").data)
+            self.right_disp_max = np.asarray(right_img["disparity"].sel(band_disp="max").data)
+        elif "validation" in cfg["pipeline"]:
+            self.right_disp_min, self.right_disp_max = matching_cost.AbstractMatchingCost.reverse_disp_range(self.disp_min, self.disp_max)
+            right_img.coords["band_disp"] = np.array(["min", "max"])
+            right_img["disparity"] = DataArray(np.stack([self.right_disp_min, self.right_disp_max], axis=0),
+                                               ("band_disp", "row", "col"), {"band_disp": ["min", "max"]})
+        self.left_disparity = Dataset()
+        self.right_disparity = Dataset()
+        self.right_cv = None
+        self.right_disp_map = None
         if "validation" in cfg["pipeline"]:
-            raise MachineError("step 'validation' is outside the hot path implemented by pandora_amd (SURVEY 8)")
+            if "interpolated_disparity" in cfg["pipeline"]["validation"]:
+                raise MachineError("'interpolated_disparity' (validation.AbstractInterpolation) is outside the hot path "
+                                   "implemented by pandora_amd (SURVEY 8)")
+            self.right_disp_map = cfg["pipeline"]["validation"]["validation_method"]
         self.state = "begin"
         self._mode = "run"
 
@@ -111,31 +132,70 @@ class PandoraMachine:
         self.disp_max = self.disp_max * self.scale_factor
         self.left_cv = self.matching_cost_.allocate_cost_volume(self.left_img, (self.disp_min, self.disp_max), cfg)
         self.left_cv = validity_mask(self.left_img, self.right_img, self.left_cv)
+        if self.right_disp_map is not None:  # state_machine.py:311-331
+            self.right_disp_min = self.right_disp_min * self.scale_factor
+            self.right_disp_max = self.right_disp_max * self.scale_factor
+            if self.right_disp_map == "cross_checking_accurate":
+                grids = (self.right_disp_min, self.right_disp_max)
+            else:  # fast: sized from the left range so that it matches the reversed left volume
+                grids = (-self.disp_max, -self.disp_min)
+            self.right_cv = self.matching_cost_.allocate_cost_volume(self.right_img, grids, cfg)
+            self.right_cv = validity_mask(self.right_img, self.left_img, self.right_cv)
 
     def matching_cost_run(self, _, __):
         logging.info("Matching cost computation...")
         self.left_cv = self.matching_cost_.compute_cost_volume(self.left_img, self.right_img, self.left_cv)
         self.matching_cost_.cv_masked(self.left_img, self.right_img, self.left_cv, self.disp_min, self.disp_max)
+        if self.right_disp_map == "cross_checking_accurate":
+            self.right_cv = self.matching_cost_.compute_cost_volume(self.right_img, self.left_img, self.right_cv)
+            self.matching_cost_.cv_masked(self.right_img, self.left_img, self.right_cv, self.right_disp_min, self.right_disp_max)
 
     def aggregation_run(self, cfg, input_step):
         logging.info("Aggregation computation...")
         aggregation_ = aggregation.AbstractAggregation(**cfg["pipeline"][input_step])
         aggregation_.cost_volume_aggregation(self.left_img, self.right_img, self.left_cv)
+        if self.right_disp_map == "cross_checking_accurate":
+            aggregation_.cost_volume_aggregation(self.right_img, self.left_img, self.right_cv)
 
     def optimization_run(self, cfg, input_step):
         logging.info("Cost optimization...")
         optimization_ = optimization.AbstractOptimization(self.left_img, **cfg["pipeline"][input_step])
         self.left_cv = optimization_.optimize_cv(self.left_cv, self.left_img, self.right_img)
+        if self.right_disp_map == "cross_checking_accurate":
+            self.right_cv = optimization_.optimize_cv(self.right_cv, self.right_img, self.left_img)
 
     def disparity_run(self, cfg, input_step):
         logging.info("Disparity computation...")
         disparity_ = disparity.AbstractDisparity(**cfg["pipeline"][input_step])
         self.left_disparity = disparity_.to_disp(self.left_cv, self.left_img, self.right_img)
+        if self.right_disp_map == "cross_checking_accurate":
+            self.right_disparity = disparity_.to_disp(self.right_cv, self.right_img, self.left_img)
+        elif self.right_disp_map == "cross_checking_fast":
+            # state_machine.py:438-448: the right volume is the re-indexed left one, built on the device at WTA time
+            self.right_cv.data_vars["cost_volume"] = matching_cost.AbstractMatchingCost.reverse_cost_volume(
+                self.left_cv["cost_volume"], np.nanmin(-self.disp_max))
+            self.right_cv.attrs["type_measure"] = self.left_cv.attrs["type_measure"]
+            self.right_cv.attrs["cmax"] = self.left_cv.attrs["cmax"]
+            self.right_disparity = disparity_.to_disp(self.right_cv, self.right_img, self.left_img)
 
     def refinement_run(self, cfg, input_step):
         logging.info("Subpixel refinement...")
         refinement_ = refinement.AbstractRefinement(**cfg["pipeline"][input_step])
         refinement_.subpixel_refinement(self.left_cv, self.left_disparity)
+        if self.right_disp_map is not None:
+            refinement_.subpixel_refinement(self.right_cv, self.right_disparity)
+
+    def validation_run(self, cfg, input_step):
+        """state_machine.py:493-519"""
+        logging.info("Validation...")
+        validation_ = validation.AbstractValidation(**cfg["pipeline"][input_step])
+        self.left_disparity = validation_.disparity_checking(self.left_disparity, self.right_disparity)
+        if self.right_disp_map is not None:
+            self.right_disparity = validation_.disparity_checking(self.right_disparity, self.left_disparity)
+        if self.right_disp_map == "cross_checking_fast":
+            # do not hand incomplete right-side data to the user
+            self.right_disparity = Dataset()
+            self.right_cv = None
 
     # -- configuration pass (state_machine.py:732-1008) ----------------------------------------
     def matching_cost_check_conf(self, cfg, input_step):
@@ -160,6 +220,23 @@ class PandoraMachine:
     def refinement_check_conf(self, cfg, input_step):
         r = refinement.AbstractRefinement(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = r.cfg
+
+    def validation_check_conf(self, cfg, input_step):
+        """state_machine.py:894-922"""
+        v = validation.AbstractValidation(**cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = v.cfg
+        if "interpolated_disparity" in v.cfg:
+            raise MachineError("'interpolated_disparity' (validation.AbstractInterpolation) is outside the hot path "
+                               "implemented by pandora_amd (SURVEY 8)")
+        self.right_disp_map = v.cfg["validation_method"]
+        if self.left_img is not None and self.right_img is not None:
+            ds_left = self.left_img.attrs.get("disparity_source")
+            ds_right = self.right_img.attrs.get("disparity_source")
+            if isinstance(ds_left, list) and isinstance(ds_right, list):
+                if ds_left[0] != -ds_right[1] or ds_left[1] != -ds_right[0]:
+                    raise AttributeError("disp_min != -disp_right_max or disp_max != -disp_right_min")
+            elif isinstance(ds_left, str) and isinstance(ds_right, str):
+                logging.warning("The right disp will be ignored, and instead computed from the left disp.")
 
     def check_conf(self, cfg, img_left=None, img_right=None, right_left_img_check=False):
         """state_machine.py:950-1008: dry-run the FSM with the check_* triggers; returns the checked

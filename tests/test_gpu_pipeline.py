@@ -171,3 +171,66 @@ def test_cost_volume_is_lazy_and_writable():
     host2 = np.where(np.isnan(host), np.nan, host + 1).astype(np.float32)
     cv["cost_volume"].data = host2  # the reference mutates cv["cost_volume"].data between steps
     np.testing.assert_array_equal(cv["cost_volume"].data, host2)
+
+
+# ---- validation step (cross-checking) through the machine -----------------------------------
+VALIDATION_CFG = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                               "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                               "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                               "refinement": {"refinement_method": "vfit"},
+                               "validation": {"validation_method": "cross_checking_accurate", "cross_checking_threshold": 1.0}}}
+
+
+def _geometry_validity(left_arr, right_arr, cfg, dmin, dmax):
+    left = make_image(left_arr, disparity=[dmin, dmax])
+    right = make_image(right_arr)
+    m = matching_cost.AbstractMatchingCost(**cfg["pipeline"]["matching_cost"])
+    cv = m.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max")))
+    return criteria.validity_mask(left, right, cv)
+
+
+@pytest.mark.parametrize("method", ["cross_checking_accurate", "cross_checking_fast"])
+def test_machine_validation_matches_oracle(oracle, method):
+    """Left AND right pipelines on the device, then the two cross-checks (state_machine.py:493-519): validity masks,
+    the left-right distance layer and the final disparities must equal the oracle composition."""
+    H, W, dmin, dmax = 44, 90, -11, 2
+    L, R = pair(H, W, seed=77)
+    R[10:20, 30:40] = 255 - R[10:20, 30:40]  # provoke mismatches / occlusions
+    cfg = json.loads(json.dumps(VALIDATION_CFG))
+    cfg["pipeline"]["validation"]["validation_method"] = method
+    machine, left_disp = run_machine(L, R, cfg, dmin, dmax)
+    right_disp = machine.right_disparity
+    no_val = {"pipeline": {k: v for k, v in cfg["pipeline"].items() if k != "validation"}}
+    mc_only = {"pipeline": {"matching_cost": cfg["pipeline"]["matching_cost"], "disparity": {"disparity_method": "wta"}}}
+    # left side
+    cv0, _, _, _ = oracle_pipeline(oracle, L, R, mc_only, dmin, dmax)
+    val0 = expected_validity(L, R, cfg, dmin, dmax, None, None, np.min(np.isnan(cv0), axis=2))
+    lcv, ldisp, lval, _ = oracle_pipeline(oracle, L, R, no_val, dmin, dmax, validity0=val0)
+    # right side
+    if method == "cross_checking_accurate":
+        rcv0, _, _, _ = oracle_pipeline(oracle, R, L, mc_only, -dmax, -dmin)
+        rval0 = expected_validity(R, L, cfg, -dmax, -dmin, None, None, np.min(np.isnan(rcv0), axis=2))
+        rcv, rdisp, rval, _ = oracle_pipeline(oracle, R, L, no_val, -dmax, -dmin, validity0=rval0)
+    else:
+        rcv = oracle.reverse_cost_volume(lcv, -dmax)
+        rval0 = _geometry_validity(R, L, cfg, -dmax, -dmin)["validity_mask"].data  # no cv_masked on the fast right side
+        rdisp, rval = oracle.wta(rcv, -dmax, 1, False, np.nan, rval0)
+        _, rdisp, rval = oracle.refine(rcv, rdisp, rval, -dmax, -dmin, 1, False, "vfit")
+    thr = cfg["pipeline"]["validation"]["cross_checking_threshold"]
+    lval2, lconf = oracle.cross_checking(ldisp, lval, rdisp, dmin, dmax, thr)
+    rval2, rconf = oracle.cross_checking(rdisp, rval, ldisp, -dmax, -dmin, thr)
+    for ds_val in (lval2, rval2):  # mask_border (validation.py:368-369)
+        ds_val[:2, :] = ds_val[-2:, :] = 1
+        ds_val[2:-2, :2] = ds_val[2:-2, -2:] = 1
+    np.testing.assert_array_equal(left_disp["disparity_map"].data, ldisp)
+    np.testing.assert_array_equal(left_disp["validity_mask"].data, lval2)
+    assert list(left_disp.coords["indicator"])[-1] == "confidence_from_left_right_consistency"
+    np.testing.assert_array_equal(left_disp["confidence_measure"].data[:, :, -1], lconf)
+    assert left_disp.attrs["validation"] == method
+    assert (lval2 & (1 << 8)).any() or (lval2 & (1 << 9)).any()
+    if method == "cross_checking_accurate":
+        np.testing.assert_array_equal(right_disp["disparity_map"].data, rdisp)
+        np.testing.assert_array_equal(right_disp["validity_mask"].data, rval2)
+        np.testing.assert_array_equal(right_disp["confidence_measure"].data[:, :, -1], rconf)
+    else:
+        assert not right_disp.data_vars and machine.right_cv is None  # state_machine.py:514-519

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import pandora_amd
-from pandora_amd import _lib, aggregation, criteria, disparity, matching_cost, optimization, refinement
+from pandora_amd import _lib, aggregation, criteria, disparity, matching_cost, optimization, refinement, validation
 from pandora_amd.dataset import DataArray, Dataset, make_image
 from pandora_amd.matching_cost import ConfigError
 from pandora_amd.state_machine import MachineError, PandoraMachine
@@ -26,6 +26,7 @@ def test_registries_hold_the_reference_short_names():
     assert "sgm" in optimization.AbstractOptimization.optimization_methods_avail
     assert "wta" in disparity.AbstractDisparity.disparity_methods_avail
     assert set(refinement.AbstractRefinement.subpixel_methods_avail) >= {"vfit", "quadratic"}
+    assert set(validation.AbstractValidation.validation_methods_avail) >= {"cross_checking_accurate", "cross_checking_fast"}
 
 
 @pytest.mark.parametrize("factory,key,msg", [
@@ -34,6 +35,7 @@ def test_registries_hold_the_reference_short_names():
     (lambda **c: optimization.AbstractOptimization(None, **c), "optimization_method", "No optimization method named {} supported"),
     (lambda **c: disparity.AbstractDisparity(**c), "disparity_method", "No disparity method named {} supported"),
     (lambda **c: refinement.AbstractRefinement(**c), "refinement_method", "No refinement method named {} supported"),
+    (lambda **c: validation.AbstractValidation(**c), "validation_method", "No validation method named {} supported"),
 ])
 def test_unknown_method_raises_keyerror_like_the_reference(factory, key, msg):
     with pytest.raises(KeyError) as err:
@@ -119,6 +121,51 @@ def test_bad_sequencing_is_rejected():
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
                                    "filter": {"filter_method": "median"}}})
     assert "filter" in str(err.value)
+
+
+def test_validation_configuration_like_the_reference():  # test_validation.py:78-102, validation.py:196-217
+    v = validation.AbstractValidation(validation_method="cross_checking_fast")
+    assert isinstance(v, validation.CrossCheckingAccurate) and v.cfg["cross_checking_threshold"] == 1.0
+    assert validation.AbstractValidation(validation_method="cross_checking_accurate", cross_checking_threshold=0).cfg[
+        "cross_checking_threshold"] == 0
+    with pytest.raises(KeyError):
+        validation.AbstractValidation()  # the method is mandatory
+    with pytest.raises(ConfigError):
+        validation.AbstractValidation(validation_method="cross_checking_fast", cross_checking_threshold="1")
+    with pytest.raises(ConfigError):
+        validation.AbstractValidation(validation_method="cross_checking_fast", interpolated_disparity="linear")
+
+
+def test_validation_step_is_sequenced_after_the_disparity_map():
+    pipe = json.loads(json.dumps(PIPE))
+    pipe["pipeline"]["validation"] = {"validation_method": "cross_checking_fast"}
+    m = PandoraMachine()
+    out = m.check_conf(pipe)
+    assert out["pipeline"]["validation"]["cross_checking_threshold"] == 1.0 and m.right_disp_map == "cross_checking_fast"
+    with pytest.raises(MachineError):  # no disparity map yet
+        PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"},
+                                                  "validation": {"validation_method": "cross_checking_fast"}}})
+    pipe["pipeline"]["validation"]["interpolated_disparity"] = "sgm"  # interpolation is not part of the hot path
+    with pytest.raises(MachineError) as err:
+        PandoraMachine().check_conf(pipe)
+    assert "interpolated_disparity" in str(err.value)
+    # disparity_source consistency (state_machine.py:912-918)
+    left = make_image(np.zeros((4, 6)), disparity=[-2, 1])
+    right = make_image(np.zeros((4, 6)), disparity=[-1, 3])
+    left.attrs["disparity_source"], right.attrs["disparity_source"] = [-2, 1], [-1, 3]
+    del pipe["pipeline"]["validation"]["interpolated_disparity"]
+    with pytest.raises(AttributeError):
+        PandoraMachine().check_conf(pipe, left, right)
+
+
+def test_allocate_confidence_map_appends_an_indicator():  # cost_volume_confidence.py:141-246
+    ds = Dataset({"disparity_map": (("row", "col"), np.zeros((2, 3), np.float32))}, coords={"row": [0, 1], "col": [0, 1, 2]})
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    ds, _ = validation.allocate_confidence_map("left_right_consistency", a, ds, None)
+    ds, _ = validation.allocate_confidence_map("ambiguity.disp_min", a + 1, ds, None)
+    assert list(ds.coords["indicator"]) == ["confidence_from_left_right_consistency", "ambiguity.disp_min"]
+    np.testing.assert_array_equal(ds["confidence_measure"].data[:, :, 0], a)
+    np.testing.assert_array_equal(ds["confidence_measure"].data[:, :, 1], a + 1)
 
 
 def test_repeated_steps_use_the_key_prefix():  # state_machine.py:706-717 ("refinement.again" -> refinement)
