@@ -154,6 +154,12 @@ int pmx_cross_checking(pmx_ctx* ctx, const float* disp_left, int64_t* validity_l
  * disparity ranges from the left ones; [global_min, global_max] must bracket every (int)left_min / (int)left_max. */
 int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const float* left_max, int H, int W, int global_min,
                            int global_max, float* right_min, float* right_max);
+/* ---- disparity filters ---------------------------------------------------------------------
+ * Replaces filter.MedianFilter.filter_disparity (src/pandora/filter/median.py:94-179): disp float32 [H][W] is
+ * filtered in place on the pixels that are valid (validity & PANDORA_MSK_PIXEL_INVALID == 0) and finite, with
+ * np.nanmedian over filter_size x filter_size in which invalid pixels are ignored; the frame of filter_size/2
+ * pixels and the invalid pixels keep their values.  Host maps in/out, computed on the device. */
+int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, int filter_size);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

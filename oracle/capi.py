@@ -181,3 +181,19 @@ def cross_checking(disp_left, validity_left, disp_right, dmin, dmax, threshold):
     conf = np.empty((H, W), np.float32)
     lib().orc_cross_checking(_p(dl), _p(val, C.c_int64), _p(dr), H, W, int(dmin), int(dmax), C.c_double(threshold), _p(conf))
     return val, conf
+
+
+def median_filter(img, size):
+    img = _f32(img)
+    H, W = img.shape
+    out = np.empty_like(img)
+    lib().orc_median_filter(_p(img), H, W, int(size), _p(out))
+    return out
+
+
+def filter_median_disparity(disp, validity, size):
+    """median.py:94-131 -> filtered copy of the disparity map."""
+    d = _f32(disp).copy()
+    v = np.ascontiguousarray(validity, np.int64)
+    lib().orc_filter_median_disparity(_p(d), _p(v, C.c_int64), d.shape[0], d.shape[1], int(size))
+    return d

@@ -694,3 +694,46 @@ void orc_cross_checking(const float* disp_left, int64_t* validity_left, const fl
             validity_left[i] += mismatch ? ORC_MSK_MISMATCH : ORC_MSK_OCCLUSION;
         }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * filter/median.py:134-179 median_filter for any odd size: np.nanmedian over size x size on the pixels whose
+ * window fits (the frame of size/2 pixels keeps its values); NaN input pixels stay NaN; even counts average
+ * the two middle values in float32.  orc_median3 is the size-3 case kept for the CBCA path.
+ * ------------------------------------------------------------------------------------------- */
+void orc_median_filter(const float* in, int H, int W, int size, float* out) {
+    int rad = size / 2;
+    memcpy(out, in, sizeof(float) * (size_t)H * W);
+    float* v = (float*)malloc(sizeof(float) * (size_t)size * size);
+    for (int r = rad; r < H - rad; ++r)
+        for (int c = rad; c < W - rad; ++c) {
+            if (isnan(in[(size_t)r * W + c])) continue;
+            int n = 0;
+            for (int i = -rad; i <= rad; ++i)
+                for (int j = -rad; j <= rad; ++j) {
+                    float x = in[(size_t)(r + i) * W + c + j];
+                    if (!isnan(x)) v[n++] = x;
+                }
+            for (int a = 1; a < n; ++a) {
+                float x = v[a];
+                int b = a - 1;
+                while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
+                v[b + 1] = x;
+            }
+            out[(size_t)r * W + c] = (n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.0f;
+        }
+    free(v);
+}
+
+/* filter/median.py:94-131 MedianFilter.filter_disparity: invalid pixels (validity & INVALID) -> NaN, median filter,
+ * written back on the pixels that were finite; the disparity of invalid pixels is left as it was. */
+void orc_filter_median_disparity(float* disp, const int64_t* validity, int H, int W, int size) {
+    size_t n = (size_t)H * W;
+    float* masked = (float*)calloc(n, sizeof(float));
+    float* med = (float*)calloc(n, sizeof(float));
+    for (size_t i = 0; i < n; ++i) masked[i] = (validity[i] & ORC_MSK_INVALID) ? NAN : disp[i];
+    orc_median_filter(masked, H, W, size, med);
+    for (size_t i = 0; i < n; ++i)
+        if (isfinite(masked[i])) disp[i] = med[i];
+    free(masked);
+    free(med);
+}

@@ -88,6 +88,10 @@ void orc_reverse_disp_range(const float* left_min, const float* left_max, int H,
 void orc_cross_checking(const float* disp_left, int64_t* validity_left, const float* disp_right, int H, int W,
                         int dmin, int dmax, double threshold, float* conf);
 
+/* filter/median.py:134-179 (median_filter, any odd size) and :94-131 (MedianFilter.filter_disparity) */
+void orc_median_filter(const float* in, int H, int W, int size, float* out);
+void orc_filter_median_disparity(float* disp, const int64_t* validity, int H, int W, int size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,7 @@ SIGNATURES = {
                                      C.c_int, C.c_double, C.POINTER(C.c_float)]),
     "pmx_reverse_disp_range": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pmx_median_filter_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int]),
     "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmx_reset_stage_times": (C.c_int, [vp]),

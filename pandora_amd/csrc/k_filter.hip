@@ -1,0 +1,97 @@
+// k_filter.hip - SURVEY 8f N2: disparity-map filters on the device (2-D work; host maps in / out like the
+// validation step).  gfx950.
+#include "pmx_internal.h"
+
+static constexpr int kBlock = 256;
+#define FMSK_INVALID 0x3C3LL
+
+__device__ __forceinline__ float f_nan() { return __int_as_float(0x7fc00000); }
+
+// filter/median.py:94-179 MedianFilter.filter_disparity: invalid pixels count as NaN; np.nanmedian over SIZE x SIZE
+// for the finite pixels whose window fits in the image (the frame keeps its values); even counts average the two
+// middle values in float32.  Thread per pixel; the window is sorted in registers (SIZE known at compile time).
+template <int SIZE>
+__global__ __launch_bounds__(kBlock) void median_disparity_kernel(const float* __restrict__ in, const int64_t* __restrict__ validity,
+                                                                  int H, int W, float* __restrict__ out) {
+    constexpr int RAD = SIZE / 2, N = SIZE * SIZE;
+    const int c = blockIdx.x * kBlock + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const size_t i = (size_t)r * W + c;
+    const float centre = in[i];
+    const bool centre_ok = (validity[i] & FMSK_INVALID) == 0 && isfinite(centre);
+    float res = centre;
+    if (centre_ok && r >= RAD && r < H - RAD && c >= RAD && c < W - RAD) {
+        float v[N];
+        int n = 0;
+#pragma unroll
+        for (int a = -RAD; a <= RAD; ++a)
+#pragma unroll
+            for (int b = -RAD; b <= RAD; ++b) {
+                const size_t k = (size_t)(r + a) * W + c + b;
+                const float x = in[k];
+                const bool ok = (validity[k] & FMSK_INVALID) == 0 && x == x;
+                v[a * SIZE + b + RAD * SIZE + RAD] = ok ? x : __int_as_float(0x7f800000);  // missing -> +inf: sorts last
+                n += ok ? 1 : 0;
+            }
+        // full sorting pass (odd-even transposition: fixed indices, stays in registers)
+#pragma unroll
+        for (int pass = 0; pass < N; ++pass)
+#pragma unroll
+            for (int k = pass & 1; k + 1 < N; k += 2) {
+                const float lo = fminf(v[k], v[k + 1]), hi = fmaxf(v[k], v[k + 1]);
+                v[k] = lo;
+                v[k + 1] = hi;
+            }
+        // a genuine +inf disparity sorts among the padding; it only matters if it is one of the middle values, where the
+        // value is +inf either way
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (k == (n - 1) / 2) m0 = v[k];
+            if (k == n / 2) m1 = v[k];
+        }
+        res = (n & 1) ? m1 : (m0 + m1) / 2.0f;
+    }
+    out[i] = res;
+}
+
+// any odd size: window gathered into a per-thread array (scratch memory), insertion sort
+__global__ __launch_bounds__(kBlock) void median_disparity_generic_kernel(const float* __restrict__ in, const int64_t* __restrict__ validity,
+                                                                          int H, int W, int size, float* __restrict__ out) {
+    constexpr int kMax = 15 * 15;
+    const int rad = size / 2;
+    const int c = blockIdx.x * kBlock + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const size_t i = (size_t)r * W + c;
+    const float centre = in[i];
+    const bool centre_ok = (validity[i] & FMSK_INVALID) == 0 && isfinite(centre);
+    float res = centre;
+    if (centre_ok && r >= rad && r < H - rad && c >= rad && c < W - rad) {
+        float v[kMax];
+        int n = 0;
+        for (int a = -rad; a <= rad; ++a)
+            for (int b = -rad; b <= rad; ++b) {
+                const size_t k = (size_t)(r + a) * W + c + b;
+                const float x = in[k];
+                if ((validity[k] & FMSK_INVALID) == 0 && x == x) {
+                    int p = n++;
+                    while (p > 0 && v[p - 1] > x) { v[p] = v[p - 1]; --p; }
+                    v[p] = x;
+                }
+            }
+        res = (n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.0f;
+    }
+    out[i] = res;
+}
+
+int pmx_launch_median_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int size, float* out) {
+    dim3 grid((W + kBlock - 1) / kBlock, H);
+    switch (size) {
+        case 1: hipLaunchKernelGGL(median_disparity_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, in, validity, H, W, out); break;
+        case 3: hipLaunchKernelGGL(median_disparity_kernel<3>, grid, dim3(kBlock), 0, ctx->stream, in, validity, H, W, out); break;
+        case 5: hipLaunchKernelGGL(median_disparity_kernel<5>, grid, dim3(kBlock), 0, ctx->stream, in, validity, H, W, out); break;
+        default: hipLaunchKernelGGL(median_disparity_generic_kernel, grid, dim3(kBlock), 0, ctx->stream, in, validity, H, W, size, out); break;
+    }
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

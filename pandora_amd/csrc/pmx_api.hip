@@ -690,3 +690,29 @@ extern "C" int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }
+
+
+// ---- disparity filters on the device -------------------------------------------------------
+extern "C" int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, int filter_size) {
+    PMX_CHECK(ctx && disp && validity, PMX_ERR_ARG, "pmx_median_filter_disparity: null argument");
+    PMX_CHECK(H > 0 && W > 0, PMX_ERR_ARG, "pmx_median_filter_disparity: bad shape %dx%d", H, W);
+    PMX_CHECK(filter_size >= 1 && (filter_size & 1) && filter_size <= 15, PMX_ERR_ARG,
+              "pmx_median_filter_disparity: filter_size must be odd, >= 1 (median.py:86) and <= 15, got %d", filter_size);
+    PMX_CHECK(filter_size <= H && filter_size <= W, PMX_ERR_ARG, "pmx_median_filter_disparity: filter_size %d exceeds the %dx%d map",
+              filter_size, H, W);
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W;
+    int rc = pmx_need_small(ctx, n * (8 + 4 + 4));
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_val = (int64_t*)base;
+    float* d_in = (float*)(base + n * 8);
+    float* d_out = d_in + n;
+    PMX_HIP(hipMemcpyAsync(d_val, validity, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_in, disp, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_median_disparity(ctx, d_in, d_val, H, W, filter_size, d_out);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(disp, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}

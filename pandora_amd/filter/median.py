@@ -1,0 +1,40 @@
+"""MedianFilter (reference: filter/median.py:40-179), computed on the device (pmx_median_filter_disparity)."""
+import numpy as np
+
+from .. import runtime
+from ..matching_cost.matching_cost import ConfigError
+from . import filter as _filter
+
+
+@_filter.AbstractFilter.register_subclass("median")
+class MedianFilter(_filter.AbstractFilter):
+    _FILTER_SIZE = 3
+
+    def __init__(self, *args, cfg=None, step=1, **kwargs):
+        self.cfg = self.check_conf(dict(cfg or {}))
+        self._filter_size = int(self.cfg["filter_size"])
+        self._step = step
+
+    def check_conf(self, cfg):
+        """median.py:68-90"""
+        if "filter_size" not in cfg:
+            cfg["filter_size"] = self._FILTER_SIZE
+        if cfg.get("filter_method") != "median":
+            raise ConfigError("filter_method must be median")
+        fs = cfg["filter_size"]
+        if isinstance(fs, bool) or not isinstance(fs, int) or fs < 1 or fs % 2 == 0:
+            raise ConfigError("filter_size must be an odd integer >= 1")
+        for key in cfg:
+            if key not in ("filter_method", "filter_size"):
+                raise ConfigError(f"unknown filter key {key!r}")
+        return cfg
+
+    def desc(self):
+        print("Median filter description")
+
+    def filter_disparity(self, disp, img_left=None, img_right=None, cv=None):
+        """median.py:94-131: median over the valid pixels, invalid neighbours ignored, in place."""
+        eng = runtime.get_engine()
+        disp["disparity_map"].data = eng.median_filter_disparity(np.asarray(disp["disparity_map"].data),
+                                                                 np.asarray(disp["validity_mask"].data), self._filter_size)
+        disp.attrs["filter"] = "median"

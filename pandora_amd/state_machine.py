@@ -6,14 +6,15 @@ here): three states ``begin -> cost_volume -> disp_map``; triggers are the pipel
 (matching_cost, aggregation, optimization, disparity, refinement) plus the validation step (SURVEY 8f
 N1: cross_checking_accurate / cross_checking_fast, with the left/right duplication of every step the
 reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
-others of the reference (filter, multiscale, cost_volume_confidence, semantic_segmentation) are
-outside this build's scope and raise ``MachineError`` naming the missing step.
+median disparity filter (N2; state_machine.py:449-473); the others of the reference (bilateral /
+median_for_intervals filters, multiscale, cost_volume_confidence, semantic_segmentation) are outside this
+build's scope: an unknown filter raises the reference's KeyError, an unknown step ``MachineError``.
 """
 import logging
 
 import numpy as np
 
-from . import aggregation, disparity, matching_cost, optimization, refinement, validation
+from . import aggregation, disparity, filter, matching_cost, optimization, refinement, validation
 from .criteria import validity_mask
 from .dataset import DataArray, Dataset
 
@@ -31,6 +32,7 @@ class PandoraMachine:
         "disparity": ("cost_volume", "disp_map", None, "disparity_run"),
         "refinement": ("disp_map", "disp_map", None, "refinement_run"),
         "validation": ("disp_map", "disp_map", None, "validation_run"),
+        "filter": ("disp_map", "disp_map", None, "filter_run"),
     }
     _transitions_check = {
         "check_matching_cost": ("begin", "cost_volume", "matching_cost_check_conf"),
@@ -39,8 +41,9 @@ class PandoraMachine:
         "check_disparity": ("cost_volume", "disp_map", "disparity_check_conf"),
         "check_refinement": ("disp_map", "disp_map", "refinement_check_conf"),
         "check_validation": ("disp_map", "disp_map", "validation_check_conf"),
+        "check_filter": ("disp_map", "disp_map", "filter_check_conf"),
     }
-    _out_of_scope = ("filter", "multiscale", "cost_volume_confidence", "semantic_segmentation")
+    _out_of_scope = ("multiscale", "cost_volume_confidence", "semantic_segmentation")
 
     def __init__(self):
         self.left_img = None
@@ -178,6 +181,19 @@ class PandoraMachine:
             self.right_cv.attrs["cmax"] = self.left_cv.attrs["cmax"]
             self.right_disparity = disparity_.to_disp(self.right_cv, self.right_img, self.left_img)
 
+    def _image_shape(self):
+        return (self.left_img.sizes["row"], self.left_img.sizes["col"]) if self.left_img is not None else None
+
+    def filter_run(self, cfg, input_step):
+        """state_machine.py:449-473"""
+        logging.info("Disparity filtering...")
+        filter_ = filter.AbstractFilter(cfg=cfg["pipeline"][input_step], image_shape=self._image_shape(), step=self.step)
+        filter_.filter_disparity(self.left_disparity, self.left_img)
+        if self.right_disp_map == "cross_checking_accurate" or (
+                self.right_disp_map == "cross_checking_fast"
+                and cfg["pipeline"][input_step]["filter_method"] != "median_for_intervals"):
+            filter_.filter_disparity(self.right_disparity, self.right_img)
+
     def refinement_run(self, cfg, input_step):
         logging.info("Subpixel refinement...")
         refinement_ = refinement.AbstractRefinement(**cfg["pipeline"][input_step])
@@ -216,6 +232,11 @@ class PandoraMachine:
     def disparity_check_conf(self, cfg, input_step):
         d = disparity.AbstractDisparity(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = d.cfg
+
+    def filter_check_conf(self, cfg, input_step):
+        """state_machine.py:775-792"""
+        f = filter.AbstractFilter(cfg=dict(cfg[input_step]), image_shape=self._image_shape(), step=self.step)
+        self.pipeline_cfg["pipeline"][input_step] = f.cfg
 
     def refinement_check_conf(self, cfg, input_step):
         r = refinement.AbstractRefinement(**cfg[input_step])

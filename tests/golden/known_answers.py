@@ -206,6 +206,14 @@ MEDIAN = [
          disp=[[7, 8, 4, 5, 5], [5, 9, 4, 3, 8], [5, 2, 7, 2, 2], [6, 1, 9, 2, 4]],
          valid=[[4, 0, 4, 16 + 1, 0], [128, 1, 256, 0, 0], [64, 512, 2, 4 + 8, 0], [2, 256, 64, 0, 2]],
          expected=[[7, 8, 4, 5, 5], [5, 9, 4, 3.5, 8], [5, 2, 7, 2, 2], [6, 1, 9, 2, 4]]),
+    dict(cite="test_filter.py:120-148,216 (dataset3)",
+         disp=[[7, 8, 4, 5, 5], [5, 9, 4, 3, 8], [5, 2, 7, 2, 2], [6, 1, 9, 2, 4]],
+         valid=[[4, 0, 4, 16 + 1, 0], [0, 0, 8, 0, 0], [0, 0, 0, 4 + 8, 0], [128, 0, 0, 0, 0]],
+         expected=[[7, 8, 4, 5, 5], [5, 5, 4, 4, 8], [5, 5, 3, 4, 2], [6, 1, 9, 2, 4]]),
+    dict(cite="test_filter.py:150-190,219-226 (dataset4, filter_size 5)", size=5,
+         disp=[[7, 8, 4, 5, 5], [5, 9, 4, 3, 8], [5, 2, 7, 2, 2], [6, 1, 9, 2, 4], [1, 6, 2, 7, 8]],
+         valid=[[4, 0, 4, 16 + 1, 0], [0, 0, 8, 0, 0], [0, 0, 0, 4 + 8, 0], [128, 0, 0, 0, 0], [64, 0, 4, 2 + 8, 0]],
+         expected=[[7, 8, 4, 5, 5], [5, 9, 4, 3, 8], [5, 2, 5, 2, 2], [6, 1, 9, 2, 4], [1, 6, 2, 7, 8]]),
 ]
 
 

@@ -466,3 +466,26 @@ def test_reverse_disp_range(eng, oracle):
         exp = oracle.reverse_disp_range(lo, hi)
         np.testing.assert_array_equal(got[0], exp[0])
         np.testing.assert_array_equal(got[1], exp[1])
+
+
+@pytest.mark.parametrize("case", ka.MEDIAN, ids=lambda c: c["cite"])
+def test_median_filter_reference_vectors(eng, case):
+    got = eng.median_filter_disparity(np.array(case["disp"], np.float32), np.array(case["valid"], np.int64), case.get("size", 3))
+    np.testing.assert_array_equal(got, np.array(case["expected"], np.float32))
+
+
+@pytest.mark.parametrize("size", [1, 3, 5, 7, 9])
+def test_median_filter_random_maps(eng, oracle, size):
+    """Sub-pixel disparities, ~20 % invalid pixels (ignored inside windows, untouched themselves), NaN and inf values,
+    even counts (mean of the two middles in float32), frame of size/2 pixels untouched; register-sorted and generic kernels."""
+    H, W = 41, 300
+    rng = np.random.default_rng(size)
+    disp = (rng.integers(-40, 10, (H, W)) + rng.choice([0.0, 0.25, 0.5, -0.125], (H, W))).astype(np.float32)
+    val = np.where(rng.random((H, W)) < 0.2, rng.choice([1, 2, 64, 128, 256, 512], (H, W)), 0).astype(np.int64)
+    val |= np.where(rng.random((H, W)) < 0.1, 4 | 8, 0)  # information bits only: still valid
+    disp[3, 7] = np.nan
+    disp[9, 11] = np.inf
+    got = eng.median_filter_disparity(disp, val, size)
+    exp = oracle.filter_median_disparity(disp, val, size)
+    np.testing.assert_array_equal(got, exp)
+    assert not np.array_equal(exp, disp) or size == 1

@@ -234,3 +234,31 @@ def test_machine_validation_matches_oracle(oracle, method):
         np.testing.assert_array_equal(right_disp["confidence_measure"].data[:, :, -1], rconf)
     else:
         assert not right_disp.data_vars and machine.right_cv is None  # state_machine.py:514-519
+
+
+def test_machine_filter_then_validation(oracle):
+    """The sample pipeline order (a_semi_global_matching.json: ... disparity, refinement, filter, validation) with the
+    median filter applied to the left AND right maps before the cross-check (state_machine.py:449-473)."""
+    H, W, dmin, dmax = 40, 72, -9, 3
+    L, R = pair(H, W, seed=5)
+    cfg = json.loads(json.dumps(VALIDATION_CFG))
+    cfg["pipeline"] = {"matching_cost": cfg["pipeline"]["matching_cost"], "optimization": cfg["pipeline"]["optimization"],
+                       "disparity": cfg["pipeline"]["disparity"], "refinement": cfg["pipeline"]["refinement"],
+                       "filter": {"filter_method": "median", "filter_size": 3},
+                       "validation": {"validation_method": "cross_checking_accurate"}}
+    machine, left_disp = run_machine(L, R, cfg, dmin, dmax)
+    base = {"pipeline": {k: v for k, v in cfg["pipeline"].items() if k not in ("filter", "validation")}}
+    mc_only = {"pipeline": {"matching_cost": cfg["pipeline"]["matching_cost"], "disparity": {"disparity_method": "wta"}}}
+    sides = []
+    for a, b, lo, hi in ((L, R, dmin, dmax), (R, L, -dmax, -dmin)):
+        cv0, _, _, _ = oracle_pipeline(oracle, a, b, mc_only, lo, hi)
+        val0 = expected_validity(a, b, cfg, lo, hi, None, None, np.min(np.isnan(cv0), axis=2))
+        _, d, v, _ = oracle_pipeline(oracle, a, b, base, lo, hi, validity0=val0)
+        sides.append((oracle.filter_median_disparity(d, v, 3), v))
+    (ld, lv), (rd, rv) = sides
+    lv2, _ = oracle.cross_checking(ld, lv, rd, dmin, dmax, 1.0)
+    lv2[:2, :] = lv2[-2:, :] = 1
+    lv2[2:-2, :2] = lv2[2:-2, -2:] = 1
+    np.testing.assert_array_equal(left_disp["disparity_map"].data, ld)
+    np.testing.assert_array_equal(left_disp["validity_mask"].data, lv2)
+    assert left_disp.attrs["filter"] == "median" and left_disp.attrs["validation"] == "cross_checking_accurate"

@@ -119,8 +119,15 @@ def test_bad_sequencing_is_rejected():
                                    "aggregation": {"aggregation_method": "cbca"}}})
     with pytest.raises(MachineError) as err:  # out-of-scope step is named
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
-                                   "filter": {"filter_method": "median"}}})
-    assert "filter" in str(err.value)
+                                   "multiscale": {"multiscale_method": "fixed_zoom_pyramid"}}})
+    assert "multiscale" in str(err.value)
+    with pytest.raises(KeyError) as err:  # a filter this build does not have: the reference's own error
+        m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
+                                   "filter": {"filter_method": "bilateral"}}})
+    assert "No filter method named bilateral supported" in str(err.value)
+    out = PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"},
+                                                    "disparity": {"disparity_method": "wta"}, "filter": {"filter_method": "median"}}})
+    assert out["pipeline"]["filter"]["filter_size"] == 3  # median.py:50
 
 
 def test_validation_configuration_like_the_reference():  # test_validation.py:78-102, validation.py:196-217

@@ -127,13 +127,17 @@ def test_cbca_known_answers(oracle):
 def test_median_known_answers(oracle, case):
     disp = np.array(case["disp"], np.float32)
     valid = np.array(case["valid"])
+    size = case.get("size", 3)
     masked = disp.copy()
     masked[(valid & 0b01111000011) != 0] = np.nan
-    med = oracle.median3(masked)
+    med = oracle.median3(masked) if size == 3 else oracle.median_filter(masked, size)
+    np.testing.assert_array_equal(med, oracle.median_filter(masked, size))  # the CBCA helper is the size-3 case
     out = disp.copy()
     ok = np.isfinite(masked)
     out[ok] = med[ok]
     np.testing.assert_array_equal(out, np.array(case["expected"], np.float32))
+    # MedianFilter.filter_disparity (median.py:94-131) as one call
+    np.testing.assert_array_equal(oracle.filter_median_disparity(disp, valid, size), np.array(case["expected"], np.float32))
 
 
 @pytest.mark.parametrize("case", ka.CROSS_CHECKING, ids=lambda c: c["cite"])
