@@ -58,3 +58,59 @@ def test_gpu_pipeline_on_cones(oracle):
     # and identical to the oracle on the full cones volume (10.3 M cells)
     s = oracle.sgm(oracle.census_cost(L, R, 61, -60, 1, 5), 8, 32, False, 26.0, False)
     np.testing.assert_array_equal(machine.left_cv["cost_volume"].data, s)
+
+
+SAMPLE_SGM = {"pipeline": {  # data_samples/json_conf_files/a_semi_global_matching.json:11-47, as written
+    "matching_cost": {"matching_cost_method": "census", "window_size": 5, "subpix": 1},
+    "optimization": {"optimization_method": "sgm", "overcounting": False,
+                     "penalty": {"penalty_method": "sgm_penalty", "P1": 8, "P2": 32, "p2_method": "constant"}},
+    "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+    "refinement": {"refinement_method": "vfit"},
+    "filter": {"filter_method": "median", "filter_size": 3},
+    "validation": {"validation_method": "cross_checking_accurate", "cross_checking_threshold": 1},
+    "filter.this_time_after_validation": {"filter_method": "median", "filter_size": 3}}}
+
+SAMPLE_LOCAL = {"pipeline": {  # data_samples/json_conf_files/a_local_block_matching.json:11-27, as written (BASELINE configs[0])
+    "matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 4},
+    "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+    "refinement": {"refinement_method": "quadratic"},
+    "validation": {"validation_method": "cross_checking_accurate"}}}
+
+VALIDATION_REF = {"pipeline": {  # tests/common.py:168-175 minus cost_volume_confidence (outside the hot path)
+    "matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 2},
+    "disparity": {"disparity_method": "wta", "invalid_disparity": -9999},
+    "refinement": {"refinement_method": "vfit"},
+    "filter": {"filter_method": "median", "filter_size": 3},
+    "validation": {"validation_method": "cross_checking_accurate", "cross_checking_threshold": 1.0}}}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg", [("a_semi_global_matching.json", SAMPLE_SGM), ("a_local_block_matching.json", SAMPLE_LOCAL),
+                                      ("tests/common.py validation_pipeline_cfg", VALIDATION_REF)], ids=lambda x: x if isinstance(x, str) else "")
+def test_sample_configurations_run_as_written_and_meet_the_reference_gates(name, cfg):
+    """The reference's sample pipelines, every step on the device, with the acceptance thresholds of
+    tests/test_pandora.py:269-298 (test_run_with_validation): left and right disparity <= 20 % bad pixels at 1 px,
+    occlusion mask (validity >= 512 = occlusion / mismatch bits) within 16 % of occlusion.png."""
+    import json
+
+    from PIL import Image
+
+    import pandora_amd
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, gt_left = load_cones()
+    gt_right = np.array(Image.open(os.path.join(CONES, "disp_right.tif"))).astype(np.float32)
+    occl = np.array(Image.open(os.path.join(CONES, "occlusion.png")))
+    left, right = make_image(L, disparity=[-60, 0]), make_image(R, disparity=[0, 60])
+    machine = PandoraMachine()
+    cfg = json.loads(json.dumps(cfg))
+    cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+    dl, dr = pandora_amd.run(machine, left, right, cfg)
+    assert error(np.nan_to_num(dl["disparity_map"].data, nan=1e4), gt_left, 1) <= 0.20
+    assert error(-1 * np.nan_to_num(dr["disparity_map"].data, nan=1e4), gt_right, 1) <= 0.20
+    occlusion = np.ones(dl["validity_mask"].data.shape)
+    occlusion[dl["validity_mask"].data >= 512] = 0
+    assert np.mean(occlusion != occl) <= 0.16
+    assert dl.attrs["validation"] == "cross_checking_accurate"
+    assert list(dl.coords["indicator"])[-1] == "confidence_from_left_right_consistency"
