@@ -190,37 +190,47 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void sgm_census_fused_kerne
 
     // one pixel of each of the LPW lines.  ALL_OK = every cell touched is a valid census cell
     // (wave-uniform, true away from the image borders): no per-cell validity select.
-    auto body = [&](code_slot<NW, KPL>& slot, auto all_ok_tag, bool pix_ok, uint32_t u) {
+    auto body = [&](code_slot<NW, KPL>& slot, auto all_ok_tag) {
         constexpr bool ALL_OK = decltype(all_ok_tag)::value;
         const uint32_t below = dppu<0x111>(kInf, Lp[KPL - 1]);  // row_shr:1 - disparity d_first-1 of the same line
         const uint32_t above = dppu<0x101>(kInf, Lp[0]);        // row_shl:1 - disparity d_first+KPL
         const uint32_t mp2 = M + a.P2;
         uint32_t negM = 0u - M;
         asm volatile("" : "+v"(negM));  // keep cc + t + negM a single three-operand add
+        // per-lane validity, only on the slow path (image borders, disparities that leave the right image)
+        bool pix_ok = true;
+        uint32_t u = 0;
+        if (!ALL_OK) {
+            pix_ok = (r >= a.o) & (r < H - a.o) & (c >= a.o) & (c < W - a.o);
+            u = (uint32_t)(c + qbase);  // element k is inside the right image iff u + k < wvalid (unsigned)
+        }
         uint32_t Ln[KPL];
-        uint32_t packed[M4 / 4];
-        uint32_t tailv = 0;
+        uint32_t bytes[KPL];
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
-            uint32_t pop = 0;
+            // the pad mask rides on v_bcnt's add operand: a pad slot carries ~kInf in its cost, so it stays out of
+            // every minimum without a separate OR; its (garbage) byte sits above the real ones of the lane
+            uint32_t cc = padm[k];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) pop += __popc(slot.l[w] ^ slot.w[k * NW + w]);
-            uint32_t cc = pop;
-            if (!ALL_OK) cc = (pix_ok && (u + (uint32_t)k < wvalid)) ? pop : a.invalid_cost;
+            for (int w = 0; w < NW; ++w) cc += __popc(slot.l[w] ^ slot.w[k * NW + w]);
+            if (!ALL_OK) cc = (pix_ok && (u + (uint32_t)k < wvalid)) ? cc : a.invalid_cost + padm[k];
             const uint32_t lo = (k > 0) ? Lp[k - 1] : below;
             const uint32_t hi = (k < KPL - 1) ? Lp[k + 1] : above;
             const uint32_t t = umin2(umin2(Lp[k], umin2(lo, hi) + a.P1), mp2);
             const uint32_t l = cc + t + negM;
-            Ln[k] = l | padm[k];
-            if (k >= M4) tailv = l;
-            else if ((k & 3) == 0) packed[k / 4] = l;
-            else packed[k / 4] |= l << (8 * (k & 3));
+            Ln[k] = l;
+            bytes[k] = l;
         }
+        uint32_t packed[M4 / 4];
+#pragma unroll
+        for (int q = 0; q < M4 / 4; ++q)  // three shift-or per dword
+            packed[q] = (((bytes[4 * q + 3] << 8) | bytes[4 * q + 2]) << 16) | ((bytes[4 * q + 1] << 8) | bytes[4 * q]);
         if (lane_active) __builtin_memcpy(pO, packed, M4);
         if (T) {
             // byte stores cost about as much as the rest of the step (measured: 16x9 with a byte store 3.0 ms
             // against 16x8 2.1 ms at 2048^2 x 127), so four neighbouring lanes' trailing bytes are gathered with
             // two DPP shifts and leave as one dword from every fourth lane (pad lanes contribute don't-cares)
+            const uint32_t tailv = bytes[KPL - 1] & 0xffu;
             uint32_t y = tailv | (dppu<0x101>(0u, tailv) << 8);  // row_shl:1 - lane i sees lane i+1
             y = y | (dppu<0x102>(0u, y) << 16);                  // row_shl:2
             if ((sub & 3) == 0 && lane_active) *reinterpret_cast<uint32_t*>(pO + tail_delta) = y;  // stays inside Dp
@@ -233,18 +243,29 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void sgm_census_fused_kerne
         return lmin;
     };
 
+    // Wave-uniform test "every cell of this step is a valid census cell", on scalars only: s_r / s_c follow the pixel of
+    // lane group 0; the groups of a row walk share the column and span LPW rows, those of a column / diagonal walk share
+    // the row and span LPW columns (a group that wrapped away from the others fails the column test, which is all it
+    // needs: the slow path is always correct).
+    const int nact = a.nact;
+    const int col_lo = max(a.o, a.o - a.d0);                                    // first column whose whole window is valid
+    const int col_hi = min(W - a.o - 1, W - a.o - a.d0 - nact * KPL);           // last one
+    const int rspan = horizontal ? LPW - 1 : 0, cspan = horizontal ? 0 : LPW - 1;
+    int s_r = horizontal ? l0 : (dr > 0 ? 0 : H - 1);
+    int s_c = horizontal ? (dc > 0 ? 0 : W - 1) : l0;
+
     auto step = [&](code_slot<NW, KPL>& slot) {
-        const bool pix_ok = (r >= a.o) && (r < H - a.o) && (c >= a.o) && (c < W - a.o);
-        const uint32_t u = (uint32_t)(c + qbase);  // element k is inside the right image iff u + k < wvalid (unsigned)
-        const bool lane_all = pix_ok && (u < wvalid) && (u + (uint32_t)(KPL - 1) < wvalid);
+        const bool all_ok = (s_r >= a.o) & (s_r + rspan < H - a.o) & (s_c >= col_lo) & (s_c + cspan <= col_hi);
         uint32_t lmin;
-        if (__all(lane_all || !lane_active)) lmin = body(slot, std::true_type{}, pix_ok, u);
-        else lmin = body(slot, std::false_type{}, pix_ok, u);
+        if (all_ok) lmin = body(slot, std::true_type{});
+        else lmin = body(slot, std::false_type{});
         prefetch(slot);
         M = group_allmin_u<GL>(lmin);
         // advance; a diagonal line that leaves the image re-enters on the other side and the path restarts
         r += dr;
         c += dc;
+        s_r += dr;
+        s_c += dc;
         pO += (ptrdiff_t)stride * a.Dp;
         if (diagonal) {
             const bool hi = c >= W, lo = c < 0;
@@ -255,6 +276,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void sgm_census_fused_kerne
 #pragma unroll
             for (int k = 0; k < KPL; ++k) Lp[k] = wrapped ? padm[k] : Lp[k];
             M = wrapped ? 0u : M;
+            s_c += (s_c >= W) ? -W : ((s_c < 0) ? W : 0);
         }
     };
 
