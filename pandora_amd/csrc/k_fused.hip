@@ -548,6 +548,28 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
     const int H = cv->H, W = cv->W;
     int gl, kpl;
     fused_choose_map(H, W, cv->D, (cv->win * cv->win + 31) / 32, &gl, &kpl);
+    {
+        // the packed-arithmetic kernels (k_sgm8.hip) are ~25 % faster than any map of the kernel below and exist for
+        // 16 lanes x whole dwords: unless a map is forced, take that one
+        const char* e8 = getenv("PMX_SGM8");
+        if (!getenv("PMX_FUSED_MAP") && !(e8 && e8[0] == '0')) {
+            gl = 16;
+            kpl = ((cv->D / 16 + 1) + 3) & ~3;
+        }
+    }
+    // the packed-arithmetic path (k_sgm8.hip: byte costs + two disparities per register) whenever the map allows it;
+    // PMX_SGM8=0 keeps the popcount-fused kernel below (test hook: both stay covered by the parity suite)
+    {
+        const char* e8 = getenv("PMX_SGM8");
+        const int nw8 = (cv->win * cv->win + 31) / 32;
+        if (!(e8 && e8[0] == '0') && pmx_sgm8_supported(gl, kpl, nw8)) {
+            int rc8 = pmx_launch_sgm8(ctx, cv, kpl, (uint32_t)P1, (uint32_t)P2, (uint32_t)invalid_cost);
+            if (rc8) return rc8;
+            cv->repr = PMX_REPR_SGM_U8X8;
+            if (ctx->near_owner == cv) ctx->near_owner = nullptr;
+            return PMX_OK;
+        }
+    }
     const int nact = (cv->D + kpl - 1) / kpl;
     const int Dp = (nact * kpl + 3) & ~3;
     size_t need = (size_t)8 * H * W * Dp;

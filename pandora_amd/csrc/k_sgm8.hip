@@ -1,0 +1,301 @@
+// k_sgm8.hip - the integer fast path with PACKED 16-bit arithmetic: census Hamming costs are written once as
+// uint8 [H][W][Dp] (1 byte per cell), then all 8 SGM directions run in one launch on two disparities per 32-bit
+// register (v_pk_min_u16 / v_pk_add_u16).  gfx950.
+//
+// Why: the popcount-fused kernel of k_fused.hip sits on the instruction-issue bound (about 176 wave-instructions per
+// step for 12 disparities per lane, one instruction per ~4.2 cycles per SIMD, profiles/r01_c_pmc_sq.csv); two of its six
+// instructions per disparity recompute the matching cost in every one of the 8 directions.  Reading a precomputed
+// byte instead costs 8 B/cell of extra HBM reads - traffic this path has to spare (5.9 GB against 10.8 GB algorithmic)
+// - and lets the recurrence run two disparities per instruction:
+//     per 4 disparities: 3 unpack (v_and_or / shift), 2 v_alignbit (neighbours d-1 / d+1 across registers),
+//     2 x (pk_min, pk_add P1, pk_min, pk_min, pk_sub M, pk_add C) = 17 instructions instead of 24, no validity
+//     logic at all (invalid cells carry invalid_cost in the byte), one 4*Q-byte load and one store per step.
+// Same semantics as k_fused.hip / k_sgm.hip / the oracle: L = C + min(Lp[d], min(Lp[d-1], Lp[d+1]) + P1, M + P2) - M,
+// borders start from (Lp, M) = (0, 0), diagonals wrap, results are exact small integers.
+//
+// Register layout of a lane (16 lanes per scanline, KPL = 4*Q disparities per lane, d = sub*KPL + 4q + i):
+//     A[q] = (L[4q], L[4q+2]) as (lo16, hi16),  B[q] = (L[4q+1], L[4q+3]).
+// Disparities >= D ("pads") carry kInf16 in their cost, so they never win a minimum; their stored bytes are garbage
+// above the lane's real bytes and are never read.
+#include "pmx_internal.h"
+
+static constexpr int kWaves8 = 4;       // wavefronts per workgroup
+static constexpr int kLines8 = 4;       // scanlines per wavefront (16 lanes each)
+static constexpr int kRing8 = 4;        // read-ahead (pixels)
+static constexpr uint32_t kInf16 = 0x7f00u;
+static constexpr uint32_t kInfPk = 0x7f007f00u;
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp8(uint32_t oldv, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)oldv, (int)src, CTRL, 0xf, 0xf, false);
+}
+
+// ---- matching costs as bytes ---------------------------------------------------------------------------------
+struct cost8_args {
+    const uint32_t* codeL;  // [H][W][NW]
+    const uint32_t* codeR;  // [H][W][NW], guard dwords on both sides
+    uint8_t* cost;          // [H][W][Dp]
+    int H, W, D, Dp, d0, o;
+    uint32_t invalid_cost;
+};
+
+// Four pixels per wavefront (one per 16-lane row), lane `sub` owns the same KPL disparities it owns in the path kernel:
+// KPL right codes come in as 16-byte loads, KPL bytes leave as one store.  Invalid census cells (window outside the
+// image on either side; census.cpp:97-180 leaves them NaN) carry invalid_cost, bytes at d >= D are don't-cares.
+template <int NW, int KPL>
+__global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
+    constexpr int Q = KPL / 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const size_t npix = (size_t)a.H * a.W;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < a.D;
+    const uint32_t wvalid = (uint32_t)(a.W - 2 * a.o);
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);  // surplus rows repeat the last pixel (same bytes)
+        const int r = (int)(pix / a.W), c = (int)(pix - (size_t)r * a.W);
+        const bool pix_ok = (r >= a.o) & (r < a.H - a.o) & (c >= a.o) & (c < a.W - a.o);
+        uint32_t lc[NW], rc[KPL * NW];
+        __builtin_memcpy(lc, a.codeL + pix * NW, sizeof(uint32_t) * NW);
+        __builtin_memcpy(rc, a.codeR + ((ptrdiff_t)pix + a.d0 + (lane_active ? d_first : 0)) * NW, sizeof(uint32_t) * KPL * NW);
+        const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
+        uint32_t out[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            uint32_t v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t pop = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) pop += __popc(lc[w] ^ rc[(4 * q + e) * NW + w]);
+                v[e] = (pix_ok && (u + (uint32_t)(4 * q + e) < wvalid)) ? pop : a.invalid_cost;
+            }
+            out[q] = (((v[3] << 8) | v[2]) << 16) | ((v[1] << 8) | v[0]);
+        }
+        if (lane_active) __builtin_memcpy(a.cost + pix * a.Dp + d_first, out, 4 * Q);
+    }
+}
+
+// ---- the 8 paths ---------------------------------------------------------------------------------------------------
+struct sgm8_args {
+    const uint8_t* cost;  // [H][W][Dp]
+    uint8_t* ldir;        // [8][H][W][Dp]
+    int H, W, D, Dp;
+    uint32_t P1, P2;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_args a) {
+    constexpr int Q = KPL / 4;
+    static_assert(KPL % 4 == 0, "whole dwords per lane");
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const int gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves8 + (threadIdx.x >> 6));
+    const int H = a.H, W = a.W, D = a.D;
+    const int wavesH = (H + kLines8 - 1) / kLines8, wavesW = (W + kLines8 - 1) / kLines8;
+    int dir, l0;  // directions in the order of k_sgm.hip / the oracle; 0,1 walk rows, 2..7 walk columns / diagonals
+    if (gwave < 2 * wavesH) {
+        dir = gwave / wavesH;
+        l0 = (gwave - dir * wavesH) * kLines8;
+    } else {
+        const int t = gwave - 2 * wavesH;
+        dir = 2 + t / wavesW;
+        if (dir >= 8) return;
+        l0 = (t - (dir - 2) * wavesW) * kLines8;
+    }
+    const int dr = (dir < 2) ? 0 : ((dir & 1) ? -1 : 1);                                                   // 0 0 +1 -1 +1 -1 +1 -1
+    const int dc = (dir == 0) ? 1 : (dir == 1) ? -1 : (dir < 4) ? 0 : ((dir == 4 || dir == 7) ? 1 : -1);  // +1 -1 0 0 +1 -1 -1 +1
+    const bool horizontal = (dr == 0);
+    const bool diagonal = (dr != 0) && (dc != 0);
+    const int nlines = horizontal ? H : W;
+    const int nsteps = horizontal ? W : H;
+    const int line = min(l0 + grp, nlines - 1);  // surplus groups of the last wave repeat the last line (same bytes)
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < D;
+
+    int r = horizontal ? line : (dr > 0 ? 0 : H - 1);
+    int c = horizontal ? (dc > 0 ? 0 : W - 1) : line;
+    int pc = c;
+    int pleft = nsteps - 1;
+    const int stride = dr * W + dc;  // pixel stride of one step (before wrapping)
+    const uint8_t* pC = a.cost + ((size_t)r * W + c) * a.Dp + (lane_active ? d_first : 0);
+    uint8_t* pO = a.ldir + (size_t)dir * H * W * a.Dp + ((size_t)r * W + c) * a.Dp + d_first;
+
+    struct slot_t { uint32_t x[Q]; };
+    slot_t ring[kRing8];
+    auto prefetch = [&](slot_t& s) {
+        __builtin_memcpy(s.x, pC, 4 * Q);
+        if (pleft > 0) {  // wave-uniform; past the end the last pixel is re-read
+            --pleft;
+            pC += (ptrdiff_t)stride * a.Dp;
+            if (diagonal) {
+                pc += dc;
+                const bool hi = pc >= W, lo = pc < 0;
+                const int fix = hi ? -W : (lo ? W : 0);
+                pc += fix;
+                pC += (ptrdiff_t)fix * a.Dp;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < kRing8; ++i) prefetch(ring[i]);
+
+    // pad masks (also the restart state of a path): kInf16 in the halves that hold a disparity >= D
+    uint32_t padA[Q], padB[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int d = d_first + 4 * q;
+        padA[q] = ((d < D) ? 0u : kInf16) | (((d + 2 < D) ? 0u : kInf16) << 16);
+        padB[q] = ((d + 1 < D) ? 0u : kInf16) | (((d + 3 < D) ? 0u : kInf16) << 16);
+    }
+    uint32_t A[Q], B[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
+    uint32_t M = 0u;  // group minimum of the previous pixel, in both halves
+    const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
+
+    auto step = [&](slot_t& s) {
+        const uint32_t belowB = dpp8<0x111>(kInfPk, B[Q - 1]);  // row_shr:1 - previous lane's (.., L[d_first-1])
+        const uint32_t aboveA = dpp8<0x101>(kInfPk, A[0]);      // row_shl:1 - next lane's (L[d_first+KPL], ..)
+        const uint32_t mp2 = pk_add(M, P2pk);
+        uint32_t nA[Q], nB[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t ccA = (s.x[q] & 0x00ff00ffu) | padA[q];          // costs of d, d+2
+            const uint32_t ccB = ((s.x[q] >> 8) & 0x00ff00ffu) | padB[q];   // costs of d+1, d+3
+            // neighbours: A = (d, d+2) has lo = (d-1, d+1), hi = (d+1, d+3) = B;  B has lo = A, hi = (d+2, d+4)
+            const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
+            const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
+            const uint32_t tA = pk_min(pk_min(A[q], pk_add(pk_min(loA, B[q]), P1pk)), mp2);
+            const uint32_t tB = pk_min(pk_min(B[q], pk_add(pk_min(A[q], hiB), P1pk)), mp2);
+            nA[q] = pk_add(ccA, pk_sub(tA, M));
+            nB[q] = pk_add(ccB, pk_sub(tB, M));
+        }
+        if (lane_active) {
+            uint32_t packed[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) packed[q] = nA[q] | (nB[q] << 8);  // bytes d, d+1, d+2, d+3 (pads spill upwards only)
+            __builtin_memcpy(pO, packed, 4 * Q);
+        }
+        uint32_t m = pk_min(nA[0], nB[0]);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) m = pk_min(m, pk_min(nA[q], nB[q]));
+        uint32_t m1 = m & 0xffffu, m2 = m >> 16;
+        uint32_t lmin = m1 < m2 ? m1 : m2;
+        prefetch(s);
+        // min over the 16 lanes of the line, in every lane (rotate butterfly; old = identity lets the DPP fold into v_min)
+        {
+            uint32_t t;
+            t = dpp8<0x128>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            t = dpp8<0x124>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            t = dpp8<0x122>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            t = dpp8<0x121>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+        }
+        M = lmin | (lmin << 16);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] = nA[q]; B[q] = nB[q]; }
+        // advance; a diagonal line that leaves the image re-enters on the other side and the path restarts
+        c += dc;
+        pO += (ptrdiff_t)stride * a.Dp;
+        if (diagonal) {
+            const bool hi = c >= W, lo = c < 0;
+            const int fix = hi ? -W : (lo ? W : 0);
+            c += fix;
+            pO += (ptrdiff_t)fix * a.Dp;
+            const bool wrapped = hi || lo;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                A[q] = wrapped ? padA[q] : A[q];
+                B[q] = wrapped ? padB[q] : B[q];
+            }
+            M = wrapped ? 0u : M;
+        }
+    };
+
+    int i = 0;
+    for (; i + kRing8 <= nsteps; i += kRing8) {
+#pragma unroll
+        for (int j = 0; j < kRing8; ++j) step(ring[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kRing8 - 1; ++j)
+        if (i + j < nsteps) step(ring[j]);
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+bool pmx_sgm8_supported(int gl, int kpl, int nw) { return gl == 16 && (kpl % 4) == 0 && kpl >= 4 && kpl <= 20 && nw <= 2; }
+
+int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2, uint32_t invalid_cost) {
+    const int H = cv->H, W = cv->W;
+    const int nact = (cv->D + kpl - 1) / kpl;
+    const int Dp = nact * kpl;  // multiple of 4
+    const size_t vol = (size_t)H * W * Dp;
+    if (cv->cost8_bytes < vol) {
+        pmx_pool_free(ctx, cv->cost8);
+        cv->cost8 = nullptr;
+        cv->cost8_bytes = 0;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->cost8, vol + 64));
+        cv->cost8_bytes = vol;
+    }
+    if (cv->ldir_bytes < 8 * vol) {
+        pmx_pool_free(ctx, cv->ldir);
+        cv->ldir = nullptr;
+        cv->ldir_bytes = 0;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->ldir, 8 * vol + 64));
+        cv->ldir_bytes = 8 * vol;
+    }
+    cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl;
+    const int nw = (cv->win * cv->win + 31) / 32;
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
+        cost8_args c;
+        c.codeL = cv->codeL; c.codeR = cv->codeR; c.cost = cv->cost8;
+        c.H = H; c.W = W; c.D = cv->D; c.Dp = Dp; c.d0 = cv->d0; c.o = cv->win / 2;
+        c.invalid_cost = invalid_cost;
+        const size_t want = ((size_t)H * W + 15) / 16;  // 4 pixels per wave, 4 waves per block
+        const dim3 grid((unsigned)(want < 65536 ? want : 65536));
+#define PMX_COST8(NWV, KPLV) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV>), grid, dim3(256), 0, ctx->stream, c)
+#define PMX_COST8_KPL(NWV)                 \
+    switch (kpl) {                         \
+        case 4: PMX_COST8(NWV, 4); break;  \
+        case 8: PMX_COST8(NWV, 8); break;  \
+        case 12: PMX_COST8(NWV, 12); break;\
+        case 16: PMX_COST8(NWV, 16); break;\
+        default: PMX_COST8(NWV, 20); break;\
+    }
+        if (nw == 1) { PMX_COST8_KPL(1) } else { PMX_COST8_KPL(2) }
+#undef PMX_COST8_KPL
+#undef PMX_COST8
+    }
+    PMX_HIP(hipGetLastError());
+    sgm8_args a;
+    a.cost = cv->cost8; a.ldir = cv->ldir;
+    a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.P1 = P1; a.P2 = P2;
+    const int nwaves = 2 * ((H + kLines8 - 1) / kLines8) + 6 * ((W + kLines8 - 1) / kLines8);
+    const dim3 grid((nwaves + kWaves8 - 1) / kWaves8), block(kWaves8 * 64);
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
+        switch (kpl) {
+            case 4: hipLaunchKernelGGL(sgm_u8_packed_kernel<4>, grid, block, 0, ctx->stream, a); break;
+            case 8: hipLaunchKernelGGL(sgm_u8_packed_kernel<8>, grid, block, 0, ctx->stream, a); break;
+            case 12: hipLaunchKernelGGL(sgm_u8_packed_kernel<12>, grid, block, 0, ctx->stream, a); break;
+            case 16: hipLaunchKernelGGL(sgm_u8_packed_kernel<16>, grid, block, 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL(sgm_u8_packed_kernel<20>, grid, block, 0, ctx->stream, a); break;
+        }
+    }
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

@@ -316,6 +316,7 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
         pmx_pool_free(ctx, cv->data);
         pmx_pool_free(ctx, cv->codes);
         pmx_pool_free(ctx, cv->ldir);
+        pmx_pool_free(ctx, cv->cost8);
     } else {
         hipFree(cv->data);
         hipFree(cv->codes);

@@ -105,6 +105,9 @@ struct pmx_cv {
     size_t ldir_bytes = 0;
     int Dp = 0;
     int gl = 0, kpl = 0;  // lane map of the fused kernels: gl lanes per scanline/pixel, kpl disparities per lane
+    // uint8 matching costs [H][W][Dp] in the same lane-map order (packed-arithmetic SGM path, k_sgm8.hip)
+    uint8_t* cost8 = nullptr;
+    size_t cost8_bytes = 0;
     size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
 };
 
@@ -157,6 +160,8 @@ int pmx_cv_materialize(pmx_ctx* ctx, pmx_cv* cv);       // any representation ->
 bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
 int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost);
 int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity);
+bool pmx_sgm8_supported(int gl, int kpl, int nw);
+int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2, uint32_t invalid_cost);  // cost8 + 8 path volumes
 int pmx_launch_sum8_refine(pmx_ctx* ctx, const pmx_cv* cv, int method);
 int pmx_launch_sum8_to_float(pmx_ctx* ctx, pmx_cv* cv);
 int pmx_launch_census_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);

@@ -367,6 +367,45 @@ def test_fused_lane_maps(eng, oracle, monkeypatch, gl, kpl, dmin, dmax):
     np.testing.assert_array_equal(cv.to_host(), s)
 
 
+@pytest.mark.parametrize("sgm8", ["1", "0"])
+@pytest.mark.parametrize("win,dmin,dmax", [(5, -20, 6), (7, -70, 30), (5, 0, 128), (3, -200, 50), (5, -150, 150)])
+def test_packed_and_popcount_fused_kernels_agree_with_the_oracle(eng, oracle, monkeypatch, sgm8, win, dmin, dmax):
+    """The default integer path (k_sgm8.hip: byte costs + packed 16-bit recurrence, KPL 4..20, one- and two-word census
+    codes) and the popcount-fused kernel behind PMX_SGM8=0 (k_fused.hip), both against the oracle pipeline."""
+    if not eng.lazy:
+        pytest.skip("fused kernels only exist on the lazy path")
+    monkeypatch.setenv("PMX_SGM8", sgm8)
+    H, W = 19, 70
+    D = dmax - dmin + 1
+    L, R = pair(H, W, seed=win + D, shift=-2)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(D, dmin)
+    eng.census(cv, win)
+    eng.sgm(cv, 8, 32, False, float(win * win + 1), False)
+    raw, gl, kpl = eng.debug_path_costs(cv, raw=True)
+    if sgm8 == "1":
+        assert gl == 16 and kpl == ((D // 16 + 1) + 3) // 4 * 4  # the packed kernels' map
+    eng.set_validity(None)
+    eng.wta(cv, False, -9999.0)
+    disp0, val0 = eng.get_disparity()
+    eng.refine(cv, "quadratic", False)
+    disp, val, itp = eng.get_disparity(want_itp=True)
+    c = oracle.census_cost(L, R, D, dmin, 1, win)
+    s = oracle.sgm(c, 8, 32, False, float(win * win + 1), False)
+    ed0, ev0 = oracle.wta(s, dmin, 1, False, -9999.0)
+    np.testing.assert_array_equal(disp0, ed0)
+    np.testing.assert_array_equal(val0, ev0)
+    eitp, ed, ev = oracle.refine(s, ed0, ev0, dmin, dmax, 1, False, "quadratic")
+    np.testing.assert_array_equal(disp, ed)
+    np.testing.assert_array_equal(val, ev)
+    np.testing.assert_array_equal(itp, eitp)
+    # the eight byte volumes sum to the oracle's aggregated cost wherever it is a number
+    paths = eng.debug_path_costs(cv)
+    assert paths.shape == (8, H, W, D)
+    np.testing.assert_array_equal(paths.astype(np.float32).sum(axis=0)[~np.isnan(s)], s[~np.isnan(s)])
+    np.testing.assert_array_equal(cv.to_host(), s)  # materialisation last (the handle becomes float32)
+
+
 @pytest.mark.parametrize("win,P1,P2", [(5, 8, 32), (3, 1, 2), (7, 8, 32), (5, 8.5, 32)])
 def test_fast_path_wta_refine_equal_general_path(eng, oracle, win, P1, P2):
     """Census -> SGM -> WTA -> vfit/quadratic through the handle WITHOUT downloading the volume in
