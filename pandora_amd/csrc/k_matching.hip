@@ -420,11 +420,106 @@ __global__ __launch_bounds__(kBlock) void sad_ssd_kernel(pmx_mc_params p, int sq
     cv[(size_t)r * p.W * p.D + j] = val;
 }
 
+// subpix == 1, window <= 7: four pixels per wavefront (one per 16-lane row), lane `sub` owns the four disparities
+// 64q + 4*sub + {0..3} of block q.  The WIN x WIN left window and the WIN x (WIN+3) right window of a block live in
+// registers (raw buffer loads: an offset before the first / past the last row returns 0, and such cells are NaN
+// anyway), so a term costs two instructions; the float32 sum runs in the reference's order (window columns outer,
+// rows inner, sad_ssd.py:367) and stays bit-exact.  Costs leave as lane-contiguous 16-byte stores.
+typedef uint32_t su32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t su32x2 __attribute__((ext_vector_type(2)));
+// N consecutive floats at byte offset `off` of a raw buffer, as few loads as possible (16 / 8 / 4 bytes)
+template <int N>
+__device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t rs, uint32_t off, float (&dst)[N]) {
+    int k = 0;
+#pragma unroll
+    for (; k + 4 <= N; k += 4) {
+        su32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 4 * k, 0, 0);
+        dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y); dst[k + 2] = __uint_as_float(t.z); dst[k + 3] = __uint_as_float(t.w);
+    }
+    if (k + 2 <= N) {
+        su32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 4 * k, 0, 0);
+        dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y);
+        k += 2;
+    }
+    if (k < N) dst[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * k, 0, 0));
+}
+
+template <int WIN, bool SQUARED>
+__global__ __launch_bounds__(kBlock) void sad_ssd_window_kernel(pmx_mc_params p, uint32_t img_bytes, float* __restrict__ cv) {
+    constexpr int O = WIN / 2, RW = WIN + 3;  // right columns a lane touches per row
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const size_t npix = (size_t)p.H * p.W;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    const uint32_t wvalid = (uint32_t)(p.W - 2 * O);
+    const int nblk = (p.D + 63) / 64;
+    // the resources start at the images' zeroed guards (pmx_api img_alloc): a wide load that runs a few elements past
+    // the last row must not be range-checked away as a whole
+    constexpr uint32_t G = (uint32_t)kImgGuardBytes;
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.left - G), 0, img_bytes + 2 * G, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.right[0] - G), 0, img_bytes + 2 * G, 0x00020000);
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);  // surplus rows repeat the last pixel (same values)
+        const int r = (int)(pix / p.W), c = (int)(pix - (size_t)r * p.W);
+        const bool pix_ok = (r >= O) & (r < p.H - O) & (c >= O) & (c < p.W - O);
+        float lw[WIN][WIN];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) buf_load_row<WIN>(rsL, (uint32_t)(((r + i - O) * p.W + c - O) * 4) + G, lw[i]);
+        float* const dst = cv + pix * (size_t)p.D;
+        for (int q = 0; q < nblk; ++q) {
+            const int d_first = 64 * q + 4 * sub;
+            if (d_first >= p.D) continue;  // (whole groups of lanes in the last block)
+            float rw[WIN][RW];
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) buf_load_row<RW>(rsR, (uint32_t)(((r + i - O) * p.W + c + p.d0 + d_first - O) * 4) + G, rw[i]);
+            const uint32_t u = (uint32_t)(c + p.d0 + d_first - O);  // cell e valid iff u + e < wvalid (unsigned)
+            float out[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < WIN; ++j)
+#pragma unroll
+                    for (int i = 0; i < WIN; ++i) {
+                        const float d = lw[i][j] - rw[i][j + e];
+                        s = s + (SQUARED ? d * d : fabsf(d));
+                    }
+                out[e] = (pix_ok && (u + (uint32_t)e < wvalid)) ? s : qnan();
+            }
+            if (d_first + 4 <= p.D) {
+                __builtin_memcpy(dst + d_first, out, sizeof(float) * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (d_first + e < p.D) dst[d_first + e] = out[e];
+            }
+        }
+    }
+}
+
 int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared) {
     pmx_mc_params p = make_params(ctx, cv, win);
     pmx_stage_scope t(ctx, PMX_STAGE_SAD_SSD);
-    dim3 grid((cv->W * cv->D + kBlock - 1) / kBlock, cv->H);
-    hipLaunchKernelGGL(sad_ssd_kernel, grid, dim3(kBlock), 0, ctx->stream, p, squared, cv->data);
+    const size_t img_bytes = (size_t)cv->H * cv->W * 4;
+    if (cv->subpix == 1 && win <= 7 && img_bytes < (1ull << 31)) {
+        size_t want = ((size_t)cv->H * cv->W + 15) / 16;  // 4 pixels per wave, 4 waves per block
+        dim3 grid((unsigned)(want < 65536 ? want : 65536));
+#define PMX_SAD_CASE(WN)                                                                                                        \
+    case WN:                                                                                                                    \
+        if (squared) hipLaunchKernelGGL(HIP_KERNEL_NAME(sad_ssd_window_kernel<WN, true>), grid, dim3(kBlock), 0, ctx->stream, p, \
+                                        (uint32_t)img_bytes, cv->data);                                                        \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(sad_ssd_window_kernel<WN, false>), grid, dim3(kBlock), 0, ctx->stream, p,       \
+                                (uint32_t)img_bytes, cv->data);                                                                \
+        break;
+        switch (win) {
+            PMX_SAD_CASE(1) PMX_SAD_CASE(3) PMX_SAD_CASE(5) PMX_SAD_CASE(7)
+        }
+#undef PMX_SAD_CASE
+    } else {
+        dim3 grid((cv->W * cv->D + kBlock - 1) / kBlock, cv->H);
+        hipLaunchKernelGGL(sad_ssd_kernel, grid, dim3(kBlock), 0, ctx->stream, p, squared, cv->data);
+    }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -109,6 +109,18 @@ def test_sad_ssd(eng, oracle, method, integer, H, W, dmin, dmax, sp, win):
     np.testing.assert_array_equal(got, exp)
 
 
+@pytest.mark.parametrize("method", ["sad", "ssd"])
+@pytest.mark.parametrize("H,W,dmin,dmax,win", [(23, 210, -70, 75, 5), (17, 140, 3, 70, 7), (20, 90, -129, -1, 3), (9, 75, -2, 66, 1)])
+def test_sad_ssd_register_window_kernel_blocks(eng, oracle, method, H, W, dmin, dmax, win):
+    """subpix 1, window <= 7 takes the register-window kernel: several 64-disparity blocks with a ragged last one,
+    ranges that leave the image, non-integer images (float32 summation order must be the reference's), first/last rows
+    where the wide loads run into the image guards."""
+    L, R = pair(H, W, seed=H * W, integer=False)
+    got = gpu_cv(eng, method, L, R, dmin, dmax, 1, win).to_host()
+    exp = cpu_cv(oracle, method, L, R, dmin, dmax, 1, win)
+    np.testing.assert_array_equal(got, exp)
+
+
 @pytest.mark.parametrize("integer", [True, False])
 @pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [(30, 44, -6, 3, 1, 5), (18, 33, -2, 2, 2, 3), (26, 40, 0, 5, 1, 11), (14, 30, -3, 0, 4, 5)])
 def test_zncc(eng, oracle, integer, H, W, dmin, dmax, sp, win):
