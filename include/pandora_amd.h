@@ -160,6 +160,11 @@ int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const float* lef
  * np.nanmedian over filter_size x filter_size in which invalid pixels are ignored; the frame of filter_size/2
  * pixels and the invalid pixels keep their values.  Host maps in/out, computed on the device. */
 int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, int filter_size);
+/* Replaces filter.BilateralFilter.filter_disparity (src/pandora/filter/bilateral.py:100-255): same in-place protocol as
+ * the median filter; window = min(H, W, int(3*sigma_space + 1)), float64 weighted means over the non-NaN window
+ * elements (results within 1e-6 relative of the reference's float64 numpy arithmetic). */
+int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, double sigma_color,
+                                   double sigma_space);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

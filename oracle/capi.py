@@ -197,3 +197,12 @@ def filter_median_disparity(disp, validity, size):
     v = np.ascontiguousarray(validity, np.int64)
     lib().orc_filter_median_disparity(_p(d), _p(v, C.c_int64), d.shape[0], d.shape[1], int(size))
     return d
+
+
+def filter_bilateral_disparity(disp, validity, sigma_color, sigma_space):
+    """bilateral.py:100-255 -> filtered copy of the disparity map."""
+    d = _f32(disp).copy()
+    v = np.ascontiguousarray(validity, np.int64)
+    lib().orc_filter_bilateral_disparity(_p(d), _p(v, C.c_int64), d.shape[0], d.shape[1], C.c_double(sigma_color),
+                                         C.c_double(sigma_space))
+    return d

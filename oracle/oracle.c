@@ -737,3 +737,53 @@ void orc_filter_median_disparity(float* disp, const int64_t* validity, int H, in
     free(masked);
     free(med);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * filter/bilateral.py:100-255 BilateralFilter.filter_disparity.  win = min(H, W, int(3*sigma_space + 1)), offset =
+ * win / 2; window of the output pixel (r, c) = rows r-offset .. r-offset+win-1 (same for columns), only where it fits.
+ * weight = gauss_spatial(i, j) * gauss_color(w - centre): the spatial kernel in float64 from the distance to
+ * (win/2, win/2), the colour kernel exp() evaluated in float32 on the float32 difference (numpy keeps float32
+ * through (x / sigma) ** 2 * 0.5 and np.exp) then scaled in float64; out = nansum(w * weight) / nansum(weight) with NaN
+ * window elements ignored.  Invalid pixels count as NaN and keep their value; the result is written on finite pixels.
+ * ------------------------------------------------------------------------------------------- */
+void orc_filter_bilateral_disparity(float* disp, const int64_t* validity, int H, int W, double sigma_color,
+                                    double sigma_space) {
+    size_t n = (size_t)H * W;
+    int win = (int)(3 * sigma_space + 1);
+    if (win > H) win = H;
+    if (win > W) win = W;
+    int offset = win / 2;
+    float* masked = (float*)calloc(n, sizeof(float));
+    float* out = (float*)calloc(n, sizeof(float));
+    double* gs = (double*)malloc(sizeof(double) * (size_t)win * win);
+    const double two_pi_root = sqrt(2 * 3.14159265358979323846);
+    for (int i = 0; i < win; ++i)
+        for (int j = 0; j < win; ++j) {
+            double dist = sqrt((double)((i - win / 2) * (i - win / 2) + (j - win / 2) * (j - win / 2)));
+            gs[i * win + j] = exp(-((dist / sigma_space) * (dist / sigma_space)) * 0.5) / (sigma_space * two_pi_root);
+        }
+    for (size_t i = 0; i < n; ++i) masked[i] = (validity[i] & ORC_MSK_INVALID) ? NAN : disp[i];
+    memcpy(out, masked, sizeof(float) * n);
+    const float sc = (float)sigma_color;
+    for (int r = offset; r + win - offset <= H; ++r)
+        for (int c = offset; c + win - offset <= W; ++c) {
+            float ctr = masked[(size_t)r * W + c];
+            double num = 0, den = 0;
+            for (int i = 0; i < win; ++i)
+                for (int j = 0; j < win; ++j) {
+                    float w = masked[(size_t)(r - offset + i) * W + (c - offset + j)];
+                    float t = (w - ctr) / sc;
+                    float g = expf(-(t * t) * 0.5f);
+                    double weight = gs[i * win + j] * ((double)g / (sigma_color * two_pi_root));
+                    if (isnan(weight)) continue; /* np.nansum over both */
+                    num += (double)w * weight;
+                    den += weight;
+                }
+            out[(size_t)r * W + c] = (float)(num / den);
+        }
+    for (size_t i = 0; i < n; ++i)
+        if (isfinite(masked[i])) disp[i] = out[i];
+    free(masked);
+    free(out);
+    free(gs);
+}

@@ -92,6 +92,10 @@ void orc_cross_checking(const float* disp_left, int64_t* validity_left, const fl
 void orc_median_filter(const float* in, int H, int W, int size, float* out);
 void orc_filter_median_disparity(float* disp, const int64_t* validity, int H, int W, int size);
 
+/* filter/bilateral.py:100-255 (BilateralFilter.filter_disparity) */
+void orc_filter_bilateral_disparity(float* disp, const int64_t* validity, int H, int W, double sigma_color,
+                                    double sigma_space);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,3 +95,46 @@ int pmx_launch_median_disparity(pmx_ctx* ctx, const float* in, const int64_t* va
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
+
+
+// filter/bilateral.py:100-255 BilateralFilter.filter_disparity.  Thread per pixel; the spatial gaussian comes from a
+// host-built float64 table, the colour gaussian is expf() of the float32 difference (as numpy evaluates it) scaled in
+// float64; both sums run in float64 over the window's non-NaN elements.
+__global__ __launch_bounds__(kBlock) void bilateral_disparity_kernel(const float* __restrict__ in, const int64_t* __restrict__ validity,
+                                                                     int H, int W, int win, const double* __restrict__ gs,
+                                                                     float sigma_color_f, double color_norm, float* __restrict__ out) {
+    const int c = blockIdx.x * kBlock + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const int offset = win / 2;
+    const size_t i0 = (size_t)r * W + c;
+    const float centre = in[i0];
+    const bool centre_ok = (validity[i0] & FMSK_INVALID) == 0 && isfinite(centre);
+    float res = centre;
+    if (centre_ok && r >= offset && r - offset + win <= H && c >= offset && c - offset + win <= W) {
+        double num = 0.0, den = 0.0;
+        for (int i = 0; i < win; ++i) {
+            const size_t row = (size_t)(r - offset + i) * W + (c - offset);
+            for (int j = 0; j < win; ++j) {
+                const float w = in[row + j];
+                if ((validity[row + j] & FMSK_INVALID) != 0 || w != w) continue;  // NaN window element: ignored (nansum)
+                const float t = (w - centre) / sigma_color_f;
+                const float g = expf(-(t * t) * 0.5f);
+                const double weight = gs[i * win + j] * ((double)g / color_norm);
+                if (weight != weight) continue;
+                num += (double)w * weight;
+                den += weight;
+            }
+        }
+        res = (float)(num / den);
+    }
+    out[i0] = res;
+}
+
+int pmx_launch_bilateral_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int win, const double* gs,
+                                   double sigma_color, float* out) {
+    dim3 grid((W + kBlock - 1) / kBlock, H);
+    hipLaunchKernelGGL(bilateral_disparity_kernel, grid, dim3(kBlock), 0, ctx->stream, in, validity, H, W, win, gs, (float)sigma_color,
+                       sigma_color * sqrt(2 * 3.14159265358979323846), out);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

@@ -717,3 +717,37 @@ extern "C" int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int6
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }
+
+extern "C" int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, double sigma_color,
+                                              double sigma_space) {
+    PMX_CHECK(ctx && disp && validity, PMX_ERR_ARG, "pmx_bilateral_filter_disparity: null argument");
+    PMX_CHECK(H > 0 && W > 0, PMX_ERR_ARG, "pmx_bilateral_filter_disparity: bad shape %dx%d", H, W);
+    PMX_CHECK(sigma_color > 0 && sigma_space > 0, PMX_ERR_ARG, "pmx_bilateral_filter_disparity: sigmas must be > 0 (bilateral.py:92-93)");
+    PMX_HIP(hipSetDevice(ctx->device));
+    int win = (int)(3 * sigma_space + 1);  // bilateral.py:171
+    if (win > H) win = H;
+    if (win > W) win = W;
+    const size_t n = (size_t)H * W, ng = (size_t)win * win;
+    std::vector<double> gs(ng);
+    const double norm = sigma_space * sqrt(2 * 3.14159265358979323846);
+    for (int i = 0; i < win; ++i)
+        for (int j = 0; j < win; ++j) {
+            const double dist = sqrt((double)((i - win / 2) * (i - win / 2) + (j - win / 2) * (j - win / 2)));  // bilateral.py:203-214
+            gs[(size_t)i * win + j] = exp(-((dist / sigma_space) * (dist / sigma_space)) * 0.5) / norm;
+        }
+    int rc = pmx_need_small(ctx, n * (8 + 4 + 4) + ng * 8);
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_val = (int64_t*)base;
+    double* d_gs = (double*)(base + n * 8);
+    float* d_in = (float*)(base + n * 8 + ng * 8);
+    float* d_out = d_in + n;
+    PMX_HIP(hipMemcpyAsync(d_val, validity, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_gs, gs.data(), ng * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_in, disp, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_bilateral_disparity(ctx, d_in, d_val, H, W, win, d_gs, sigma_color, d_out);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(disp, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));  // (also keeps `gs` alive until its copy has left)
+    return PMX_OK;
+}

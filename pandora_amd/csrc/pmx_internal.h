@@ -169,6 +169,8 @@ int pmx_launch_cross_checking(pmx_ctx* ctx, const float* dl, int64_t* validity, 
                               double threshold, float* conf);
 int pmx_launch_reverse_disp_range(pmx_ctx* ctx, const float* lmin, const float* lmax, int H, int W, int gmin, int gmax, float* rmin,
                                   float* rmax);
+int pmx_launch_bilateral_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int win, const double* gs,
+                                   double sigma_color, float* out);
 int pmx_launch_median_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int size, float* out);
 int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared);
 int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);

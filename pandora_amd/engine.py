@@ -228,6 +228,16 @@ class Engine:
                                                      int(filter_size)), "pmx_median_filter_disparity")
         return d
 
+    def bilateral_filter_disparity(self, disp, validity, sigma_color, sigma_space):
+        """bilateral.py:100-255 on the device; returns the filtered float32 map (input untouched)."""
+        d = np.array(disp, np.float32, order="C", copy=True)
+        v = np.ascontiguousarray(validity, np.int64)
+        if d.ndim != 2 or d.shape != v.shape:
+            raise ValueError("bilateral_filter_disparity: disparity map and validity mask must be 2-D and of the same shape")
+        check(_lib.lib().pmx_bilateral_filter_disparity(self.ctx, _p(d, C.c_float), _p(v, C.c_int64), d.shape[0], d.shape[1],
+                                                        float(sigma_color), float(sigma_space)), "pmx_bilateral_filter_disparity")
+        return d
+
     def debug_path_costs(self, cv, raw=False):
         """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation
         (raw=True: the device byte order [8][H][W][Dp] and the (gl, kpl) lane map)."""

@@ -1,3 +1,4 @@
 """Disparity-map filters."""
 from .filter import AbstractFilter  # noqa: F401
 from .median import MedianFilter  # noqa: F401
+from .bilateral import BilateralFilter  # noqa: F401

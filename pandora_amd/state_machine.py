@@ -6,8 +6,8 @@ here): three states ``begin -> cost_volume -> disp_map``; triggers are the pipel
 (matching_cost, aggregation, optimization, disparity, refinement) plus the validation step (SURVEY 8f
 N1: cross_checking_accurate / cross_checking_fast, with the left/right duplication of every step the
 reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
-median disparity filter (N2; state_machine.py:449-473); the others of the reference (bilateral /
-median_for_intervals filters, multiscale, cost_volume_confidence, semantic_segmentation) are outside this
+median / bilateral disparity filters (N2; state_machine.py:449-473); the others of the reference
+(median_for_intervals filter, multiscale, cost_volume_confidence, semantic_segmentation) are outside this
 build's scope: an unknown filter raises the reference's KeyError, an unknown step ``MachineError``.
 """
 import logging

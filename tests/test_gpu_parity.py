@@ -540,3 +540,18 @@ def test_median_filter_random_maps(eng, oracle, size):
     exp = oracle.filter_median_disparity(disp, val, size)
     np.testing.assert_array_equal(got, exp)
     assert not np.array_equal(exp, disp) or size == 1
+
+
+@pytest.mark.parametrize("H,W,sc,ss", [(5, 5, 4.0, 6.0), (40, 61, 2.0, 6.0), (33, 50, 2.0, 1.5), (25, 30, 3.0, 1.0)])
+def test_bilateral_filter(eng, oracle, H, W, sc, ss):
+    """bilateral.py:100-255 on the device against the float64 restatement (window 19 / 5 / even window 4, window clipped
+    to the image, invalid and NaN neighbours ignored, invalid pixels untouched): 1e-6 relative."""
+    rng = np.random.default_rng(H * W)
+    disp = (rng.integers(-30, 5, (H, W)) + rng.random((H, W))).astype(np.float32)
+    val = np.where(rng.random((H, W)) < 0.15, rng.choice([1, 2, 64, 256], (H, W)), 0).astype(np.int64)
+    disp[H // 2, W // 3] = np.nan
+    got = eng.bilateral_filter_disparity(disp, val, sc, ss)
+    exp = oracle.filter_bilateral_disparity(disp, val, sc, ss)
+    np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True)
+    inv = (val & 0x3C3) != 0
+    np.testing.assert_array_equal(got[inv], disp[inv])

@@ -123,8 +123,11 @@ def test_bad_sequencing_is_rejected():
     assert "multiscale" in str(err.value)
     with pytest.raises(KeyError) as err:  # a filter this build does not have: the reference's own error
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
-                                   "filter": {"filter_method": "bilateral"}}})
-    assert "No filter method named bilateral supported" in str(err.value)
+                                   "filter": {"filter_method": "median_for_intervals"}}})
+    assert "No filter method named median_for_intervals supported" in str(err.value)
+    out = PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"},
+                                                    "disparity": {"disparity_method": "wta"}, "filter": {"filter_method": "bilateral"}}})
+    assert out["pipeline"]["filter"]["sigma_color"] == 2.0 and out["pipeline"]["filter"]["sigma_space"] == 6.0  # bilateral.py:47-48
     out = PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"},
                                                     "disparity": {"disparity_method": "wta"}, "filter": {"filter_method": "median"}}})
     assert out["pipeline"]["filter"]["filter_size"] == 3  # median.py:50

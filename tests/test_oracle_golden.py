@@ -149,3 +149,46 @@ def test_cross_checking_known_answers(oracle, case):
         np.testing.assert_array_equal(conf, np.array(case["conf"], np.float32))
     if case["mask"] is not None:
         np.testing.assert_array_equal(val, np.array(case["mask"], np.int64))
+
+
+def _bilateral_numpy(disp, valid, sigma_color, sigma_space):
+    """The recipe of the reference's own tests (tests/test_filter.py:373-470, :472-616, :618-680): explicit float64
+    gaussian weights around every pixel whose window fits, NaN (invalid) window elements dropped."""
+    masked = disp.astype(np.float32).copy()
+    masked[(valid & 0b01111000011) != 0] = np.nan
+    H, W = masked.shape
+    win = min(H, W, int(3 * sigma_space + 1))
+    off = win // 2
+    ii, jj = np.meshgrid(np.arange(win), np.arange(win), indexing="ij")
+    gs = np.exp(-((np.sqrt((ii - win // 2) ** 2 + (jj - win // 2) ** 2) / sigma_space) ** 2) * 0.5) / (sigma_space * np.sqrt(2 * np.pi))
+    out = disp.astype(np.float32).copy()
+    for r in range(off, H - (win - off) + 1):
+        for c in range(off, W - (win - off) + 1):
+            if not np.isfinite(masked[r, c]):
+                continue
+            w = masked[r - off:r - off + win, c - off:c - off + win].astype(np.float64)
+            gi = np.exp(-(((w - w[off, off]) / sigma_color) ** 2) * 0.5) / (sigma_color * np.sqrt(2 * np.pi))
+            wt = gs * gi
+            out[r, c] = np.nansum(w * wt) / np.nansum(wt)
+    return out
+
+
+@pytest.mark.parametrize("case", ["test_on_valid_pixels", "test_with_nans", "test_with_invalid_center", "random"])
+def test_bilateral_filter_formula(oracle, case):
+    disp = np.array([[5, 6, 7, 8, 9], [6, 85, 1, 36, 5], [5, 9, 23, 12, 2], [6, 1, 9, 2, 4], [6, 7, 4, 2, 1]], np.float32)
+    valid = np.zeros((5, 5), np.int64)
+    sc, ss = 4.0, 6.0
+    if case == "test_with_nans":  # test_filter.py:472-616: invalid neighbours are ignored
+        valid[1, 1], valid[2, 1], valid[2, 4], valid[3, 4] = 4, 16, 8, 8  # information bits only ...
+        valid[0, 2], valid[1, 3] = 1, 2                                    # ... and really invalid ones
+    elif case == "test_with_invalid_center":  # test_filter.py:618-680: an invalid centre keeps its value
+        valid[2, 2] = 0b01111000011
+    elif case == "random":
+        rng = np.random.default_rng(8)
+        disp = (rng.integers(-30, 5, (16, 21)) + rng.random((16, 21))).astype(np.float32)
+        valid = np.where(rng.random((16, 21)) < 0.15, 1, 0).astype(np.int64)
+        sc, ss = 2.0, 1.5  # 5x5 window -> many interior pixels
+    got = oracle.filter_bilateral_disparity(disp, valid, sc, ss)
+    np.testing.assert_allclose(got, _bilateral_numpy(disp, valid, sc, ss), rtol=1e-6)
+    if case == "test_with_invalid_center":
+        assert got[2, 2] == disp[2, 2]
