@@ -165,6 +165,13 @@ int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validi
  * elements (results within 1e-6 relative of the reference's float64 numpy arithmetic). */
 int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, double sigma_color,
                                    double sigma_space);
+/* ---- multiscale -----------------------------------------------------------------------------
+ * Replaces the window search of multiscale.FixedZoomPyramid.disparity_range
+ * (src/pandora/multiscale/fixed_zoom_pyramid.py:106-172) before its zoom: per valid pixel whose window fits, the
+ * nanmin - marge / nanmax + marge of the valid disparities of the window; every other pixel gets
+ * [global_min, global_max].  Host maps in/out, computed on the device. */
+int pmx_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity, int H, int W, int window_size, int marge,
+                        int global_min, int global_max, float* range_min, float* range_max);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

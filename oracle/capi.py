@@ -206,3 +206,12 @@ def filter_bilateral_disparity(disp, validity, sigma_color, sigma_space):
     lib().orc_filter_bilateral_disparity(_p(d), _p(v, C.c_int64), d.shape[0], d.shape[1], C.c_double(sigma_color),
                                          C.c_double(sigma_space))
     return d
+
+
+def disparity_range(disp, validity, win, marge, gmin, gmax):
+    d = _f32(disp)
+    v = np.ascontiguousarray(validity, np.int64)
+    lo, hi = np.empty(d.shape, np.float32), np.empty(d.shape, np.float32)
+    lib().orc_disparity_range(_p(d), _p(v, C.c_int64), d.shape[0], d.shape[1], int(win), int(marge), int(gmin), int(gmax),
+                              _p(lo), _p(hi))
+    return lo, hi

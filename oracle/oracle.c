@@ -787,3 +787,35 @@ void orc_filter_bilateral_disparity(float* disp, const int64_t* validity, int H,
     free(out);
     free(gs);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * multiscale/fixed_zoom_pyramid.py:106-172 FixedZoomPyramid.disparity_range before the zoom: invalid pixels -> NaN
+ * (multiscale.py:129-153); interior pixels get nanmin(window) - marge / nanmax(window) + marge in float32; the frame of
+ * window/2 pixels and the pixels that are NaN themselves get the global range (int(nanmin(disp_min)), int(nanmax(disp_max))).
+ * ------------------------------------------------------------------------------------------- */
+void orc_disparity_range(const float* disp, const int64_t* validity, int H, int W, int win, int marge, int gmin, int gmax,
+                         float* out_min, float* out_max) {
+    int off = (win - 1) / 2;
+    size_t n = (size_t)H * W;
+    float* m = (float*)calloc(n, sizeof(float));
+    for (size_t i = 0; i < n; ++i) {
+        m[i] = (validity[i] & ORC_MSK_INVALID) ? NAN : disp[i];
+        out_min[i] = (float)gmin;
+        out_max[i] = (float)gmax;
+    }
+    for (int r = off; r + win - off <= H; ++r)
+        for (int c = off; c + win - off <= W; ++c) {
+            if (isnan(m[(size_t)r * W + c])) continue;
+            float lo = INFINITY, hi = -INFINITY;
+            for (int i = 0; i < win; ++i)
+                for (int j = 0; j < win; ++j) {
+                    float v = m[(size_t)(r - off + i) * W + (c - off + j)];
+                    if (isnan(v)) continue;
+                    if (v < lo) lo = v;
+                    if (v > hi) hi = v;
+                }
+            out_min[(size_t)r * W + c] = lo - (float)marge;
+            out_max[(size_t)r * W + c] = hi + (float)marge;
+        }
+    free(m);
+}

@@ -96,6 +96,10 @@ void orc_filter_median_disparity(float* disp, const int64_t* validity, int H, in
 void orc_filter_bilateral_disparity(float* disp, const int64_t* validity, int H, int W, double sigma_color,
                                     double sigma_space);
 
+/* multiscale/fixed_zoom_pyramid.py:106-172 (FixedZoomPyramid.disparity_range, before the zoom) */
+void orc_disparity_range(const float* disp, const int64_t* validity, int H, int W, int win, int marge, int gmin, int gmax,
+                         float* out_min, float* out_max);
+
 #ifdef __cplusplus
 }
 #endif

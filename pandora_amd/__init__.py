@@ -11,11 +11,17 @@ __version__ = "0.1.0"
 
 
 def run(pandora_machine, img_left, img_right, cfg):
-    """The reference's pandora.run (__init__.py:50-124) for the hot-path steps: runs every key of
-    cfg["pipeline"] in order on the machine and returns (left disparity dataset, None)."""
-    pandora_machine.run_prepare(cfg, img_left, img_right)
-    for step in list(cfg["pipeline"]):
-        pandora_machine.run(step, cfg)
+    """The reference's pandora.run (__init__.py:50-124): every key of cfg["pipeline"] in order on the machine, once per
+    scale (coarse to fine when a multiscale step is configured); returns (left, right) disparity datasets."""
+    from .multiscale import read_multiscale_params
+
+    num_scales, scale_factor = read_multiscale_params(img_left, img_right, cfg)
+    pandora_machine.run_prepare(cfg, img_left, img_right, scale_factor, num_scales)
+    for _ in range(pandora_machine.num_scales):
+        for step in list(cfg["pipeline"]):
+            pandora_machine.run(step, cfg)
+            if pandora_machine.state == "begin":  # the multiscale step moved the machine to the next scale
+                break
     pandora_machine.run_exit()
     return pandora_machine.left_disparity, pandora_machine.right_disparity
 

@@ -82,3 +82,43 @@ int pmx_launch_reverse_disp_range(pmx_ctx* ctx, const float* lmin, const float* 
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
+
+
+// ---- multiscale/fixed_zoom_pyramid.py:106-172 disparity_range (before the zoom) ----------------------
+// Thread per pixel: min / max of the valid, non-NaN disparities of the window -/+ marge; the frame and the pixels that
+// are invalid or NaN themselves keep the global range.
+__global__ __launch_bounds__(kBlock) void disparity_range_kernel(const float* __restrict__ disp, const int64_t* __restrict__ validity,
+                                                                 int H, int W, int win, float marge, float gmin, float gmax,
+                                                                 float* __restrict__ out_min, float* __restrict__ out_max) {
+    const int c = blockIdx.x * kBlock + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const int off = (win - 1) / 2;
+    const size_t i0 = (size_t)r * W + c;
+    float lo = gmin, hi = gmax;
+    const float centre = disp[i0];
+    if ((validity[i0] & VMSK_INVALID) == 0 && centre == centre && r >= off && r - off + win <= H && c >= off && c - off + win <= W) {
+        float mn = v_inf(), mx = -v_inf();
+        for (int i = 0; i < win; ++i) {
+            const size_t row = (size_t)(r - off + i) * W + (c - off);
+            for (int j = 0; j < win; ++j) {
+                const float v = disp[row + j];
+                if ((validity[row + j] & VMSK_INVALID) != 0 || v != v) continue;
+                mn = fminf(mn, v);
+                mx = fmaxf(mx, v);
+            }
+        }
+        lo = mn - marge;
+        hi = mx + marge;
+    }
+    out_min[i0] = lo;
+    out_max[i0] = hi;
+}
+
+int pmx_launch_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity, int H, int W, int win, int marge, int gmin,
+                               int gmax, float* out_min, float* out_max) {
+    dim3 grid((W + kBlock - 1) / kBlock, H);
+    hipLaunchKernelGGL(disparity_range_kernel, grid, dim3(kBlock), 0, ctx->stream, disp, validity, H, W, win, (float)marge, (float)gmin,
+                       (float)gmax, out_min, out_max);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

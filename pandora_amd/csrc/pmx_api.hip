@@ -751,3 +751,28 @@ extern "C" int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const i
     PMX_HIP(hipStreamSynchronize(ctx->stream));  // (also keeps `gs` alive until its copy has left)
     return PMX_OK;
 }
+
+
+// ---- multiscale -------------------------------------------------------------------------------------
+extern "C" int pmx_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity, int H, int W, int window_size, int marge,
+                                   int global_min, int global_max, float* range_min, float* range_max) {
+    PMX_CHECK(ctx && disp && validity && range_min && range_max, PMX_ERR_ARG, "pmx_disparity_range: null argument");
+    PMX_CHECK(H > 0 && W > 0 && window_size >= 1 && marge >= 0, PMX_ERR_ARG, "pmx_disparity_range: bad shape / window / marge");
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W;
+    int rc = pmx_need_small(ctx, n * (8 + 4 + 4 + 4));
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_val = (int64_t*)base;
+    float* d_disp = (float*)(base + n * 8);
+    float* d_lo = d_disp + n;
+    float* d_hi = d_lo + n;
+    PMX_HIP(hipMemcpyAsync(d_val, validity, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_disp, disp, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_disparity_range(ctx, d_disp, d_val, H, W, window_size, marge, global_min, global_max, d_lo, d_hi);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(range_min, d_lo, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(range_max, d_hi, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}

@@ -118,13 +118,16 @@ def make_image(data, disparity=None, msk=None, valid_pixels=0, no_data_mask=1, d
                         "no_data_img": None})
     if msk is not None:
         ds["msk"] = (("row", "col"), np.asarray(msk, np.int16))
+    ds.attrs["disparity_source"] = None
     if disparity is not None:
         dmin, dmax = disparity
+        ds.attrs["disparity_source"] = [dmin, dmax]  # img_tools.py:406-437: the [min, max] list or the grid's file name
         grids = np.stack([np.full((H, W), dmin), np.full((H, W), dmax)]).astype(np.int64)
         ds.coords["band_disp"] = np.array(["min", "max"])
         ds["disparity"] = DataArray(grids, ("band_disp", "row", "col"), {"band_disp": ["min", "max"]})
     if disparity_grids is not None:
         gmin, gmax = disparity_grids
+        ds.attrs["disparity_source"] = "disparity_grids"
         ds.coords["band_disp"] = np.array(["min", "max"])
         ds["disparity"] = DataArray(np.stack([np.asarray(gmin), np.asarray(gmax)]), ("band_disp", "row", "col"),
                                     {"band_disp": ["min", "max"]})

@@ -238,6 +238,19 @@ class Engine:
                                                         float(sigma_color), float(sigma_space)), "pmx_bilateral_filter_disparity")
         return d
 
+    # -- multiscale ----------------------------------------------------------------
+    def disparity_range(self, disp, validity, window_size, marge, global_min, global_max):
+        """fixed_zoom_pyramid.py:106-172 (before the zoom) on the device -> (range_min, range_max) float32."""
+        d = np.ascontiguousarray(disp, np.float32)
+        v = np.ascontiguousarray(validity, np.int64)
+        if d.ndim != 2 or d.shape != v.shape:
+            raise ValueError("disparity_range: disparity map and validity mask must be 2-D and of the same shape")
+        lo, hi = np.empty(d.shape, np.float32), np.empty(d.shape, np.float32)
+        check(_lib.lib().pmx_disparity_range(self.ctx, _p(d, C.c_float), _p(v, C.c_int64), d.shape[0], d.shape[1], int(window_size),
+                                             int(marge), int(global_min), int(global_max), _p(lo, C.c_float), _p(hi, C.c_float)),
+              "pmx_disparity_range")
+        return lo, hi
+
     def debug_path_costs(self, cv, raw=False):
         """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation
         (raw=True: the device byte order [8][H][W][Dp] and the (gl, kpl) lane map)."""

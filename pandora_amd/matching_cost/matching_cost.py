@@ -129,17 +129,6 @@ class AbstractMatchingCost:
 
     # -- right-side helpers of the validation step ---------------------------------
     @staticmethod
-    def reverse_cost_volume(left_cv, min_disp):
-        """matching_cost.py (static wrapper of matching_cost_cpp.reverse_cost_volume, matching_cost.cpp:26-56):
-        right(i, j, d) = left(i, j + d + min_disp, D-1-d).  ``left_cv`` is the cost-volume DATASET VARIABLE
-        (cv["cost_volume"], device resident); returns a new device-resident variable."""
-        if not hasattr(left_cv, "device_cv"):
-            raise TypeError("reverse_cost_volume needs a device-resident cost volume (pandora_amd has no CPU path)")
-        dcv = left_cv.device_cv
-        out = dcv.engine.reverse_cost_volume(dcv, int(min_disp))
-        return DeviceVolumeArray(out, dict(left_cv.coords))
-
-    @staticmethod
     def reverse_disp_range(left_min, left_max):
         """matching_cost_cpp.reverse_disp_range (matching_cost.cpp:59-132) on the device."""
         return runtime.get_engine().reverse_disp_range(np.asarray(left_min, np.float32), np.asarray(left_max, np.float32))
@@ -174,7 +163,10 @@ class AbstractMatchingCost:
 
     @staticmethod
     def reverse_cost_volume(left_cv, disp_min):
-        """matching_cost.py:920-934 -> matching_cost_cpp.reverse_cost_volume; left_cv is a
-        DeviceVolumeArray, the result too."""
+        """matching_cost.py:920-934 -> matching_cost_cpp.reverse_cost_volume (matching_cost.cpp:26-56):
+        right(i, j, d) = left(i, j + d + disp_min, D-1-d).  left_cv is the device-resident cost-volume VARIABLE
+        (cv["cost_volume"]); the result is a new one."""
+        if not hasattr(left_cv, "device_cv"):
+            raise TypeError("reverse_cost_volume needs a device-resident cost volume (pandora_amd has no CPU path)")
         dcv = left_cv.device_cv
         return DeviceVolumeArray(dcv.engine.reverse_cost_volume(dcv, int(disp_min)), dict(left_cv.coords))

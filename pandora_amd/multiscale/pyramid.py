@@ -1,0 +1,89 @@
+"""Image pyramids for the multiscale run (reference: img_tools.py:479-712 prepare_pyramid / get_pyramids / masks_pyramid
+/ convert_pyramid_to_dataset, check_configuration.py:558-582 read_multiscale_params).  Host-side 2-D preparation.
+
+PARITY UNPINNED for the pyramid itself: the reference calls skimage.transform.pyramid_gaussian(sigma=1.2, order=1,
+mode="reflect"), and scikit-image is not installed here.  `_pyramid_reduce` restates what that function does with the
+scipy.ndimage calls scikit-image itself makes (gaussian_filter in 'reflect' mode, then resize = ndimage.zoom with
+grid_mode=True and the 'mirror' boundary that skimage maps 'reflect' to, anti-aliasing off)."""
+import math
+
+import numpy as np
+from scipy import ndimage as ndi
+
+from ..dataset import DataArray, Dataset
+
+
+def _pyramid_reduce(image, downscale, sigma=1.2, order=1, cval=0):
+    out_shape = tuple(math.ceil(d / float(downscale)) for d in image.shape)
+    smoothed = ndi.gaussian_filter(image, sigma, mode="reflect", cval=cval)
+    factors = [o / i for i, o in zip(image.shape, out_shape)]
+    return ndi.zoom(smoothed, factors, order=order, mode="mirror", cval=cval, grid_mode=True)
+
+
+def get_pyramids(data, num_scales, scale_factor):
+    """img_tools.py:479-496: [full resolution, ..., coarsest]"""
+    layers = [np.asarray(data, np.float32)]
+    for _ in range(num_scales - 1):
+        prev = layers[-1]
+        nxt = _pyramid_reduce(prev, scale_factor)
+        if nxt.shape == prev.shape:  # skimage stops when a layer no longer shrinks
+            break
+        layers.append(nxt)
+    return layers
+
+
+def masks_pyramid(msk, scale_factor, num_scales):
+    """img_tools.py:617-635: decimation."""
+    out, tmp = [msk], msk
+    for _ in range(num_scales - 1):
+        tmp = tmp[::scale_factor, ::scale_factor]
+        out.append(tmp)
+    return out
+
+
+def _convert(img_orig, images, masks, disps):
+    """img_tools.py:638-712 (mono-band)"""
+    pyramid = []
+    for index, image in enumerate(images):
+        if index == 0:
+            pyramid.append(img_orig)
+            continue
+        ds = Dataset({"im": (("row", "col"), image.astype(np.float32))},
+                     coords={"row": np.arange(image.shape[0]), "col": np.arange(image.shape[1])})
+        ds["msk"] = (("row", "col"), np.full(image.shape, masks[index]).astype(np.int16))
+        if disps is not None:
+            ds.coords["band_disp"] = np.array(["min", "max"])
+            ds["disparity"] = DataArray(np.array([disps[0][index].astype(np.int64), disps[1][index].astype(np.int64)]),
+                                        ("band_disp", "row", "col"), {"band_disp": ["min", "max"]})
+        ds.attrs = img_orig.attrs  # shared, as in the reference
+        pyramid.append(ds)
+    return pyramid
+
+
+def prepare_pyramid(img_left, img_right, num_scales, scale_factor):
+    """img_tools.py:499-572, for images without a mask (the no-data interpolation of masked images,
+    img_tools_cpp.interpolate_nodata_sgm, is outside this build).  Returns the two pyramids, coarsest first."""
+    for ds in (img_left, img_right):
+        if "msk" in ds.data_vars:
+            raise NotImplementedError("multiscale with image masks (interpolate_nodata_sgm) is outside pandora_amd's scope")
+    out = []
+    for ds in (img_left, img_right):
+        msk = np.full((ds.sizes["row"], ds.sizes["col"]), int(ds.attrs.get("valid_pixels", 0)))
+        images = get_pyramids(ds["im"].data, num_scales, scale_factor)
+        disps = None
+        if "disparity" in ds.data_vars:
+            d = np.asarray(ds["disparity"].data)
+            disps = [get_pyramids(d[0].astype(np.float32), num_scales, scale_factor),
+                     get_pyramids(d[1].astype(np.float32), num_scales, scale_factor)]
+        out.append(_convert(ds, images, masks_pyramid(msk, scale_factor, num_scales), disps)[::-1])
+    return out[0], out[1]
+
+
+def read_multiscale_params(left_img, right_img, cfg):
+    """check_configuration.py:558-582 -> (num_scales, scale_factor)"""
+    from .multiscale import AbstractMultiscale
+
+    if "multiscale" in cfg["pipeline"]:
+        m = AbstractMultiscale(left_img, right_img, **cfg["pipeline"]["multiscale"])
+        return m.cfg["num_scales"], m.cfg["scale_factor"]
+    return 1, 1

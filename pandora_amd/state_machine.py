@@ -6,15 +6,16 @@ here): three states ``begin -> cost_volume -> disp_map``; triggers are the pipel
 (matching_cost, aggregation, optimization, disparity, refinement) plus the validation step (SURVEY 8f
 N1: cross_checking_accurate / cross_checking_fast, with the left/right duplication of every step the
 reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
-median / bilateral disparity filters (N2; state_machine.py:449-473); the others of the reference
-(median_for_intervals filter, multiscale, cost_volume_confidence, semantic_segmentation) are outside this
+median / bilateral disparity filters (N2; state_machine.py:449-473) and the multiscale loop (N3;
+fixed_zoom_pyramid, state_machine.py:521-556, images without masks); the others of the reference
+(median_for_intervals filter, cost_volume_confidence, semantic_segmentation) are outside this
 build's scope: an unknown filter raises the reference's KeyError, an unknown step ``MachineError``.
 """
 import logging
 
 import numpy as np
 
-from . import aggregation, disparity, filter, matching_cost, optimization, refinement, validation
+from . import aggregation, disparity, filter, matching_cost, multiscale, optimization, refinement, validation
 from .criteria import validity_mask
 from .dataset import DataArray, Dataset
 
@@ -33,6 +34,8 @@ class PandoraMachine:
         "refinement": ("disp_map", "disp_map", None, "refinement_run"),
         "validation": ("disp_map", "disp_map", None, "validation_run"),
         "filter": ("disp_map", "disp_map", None, "filter_run"),
+        # conditional: on the last scale the trigger does nothing and the state stays disp_map (state_machine.py:125-133)
+        "multiscale": ("disp_map", "begin", None, "run_multiscale"),
     }
     _transitions_check = {
         "check_matching_cost": ("begin", "cost_volume", "matching_cost_check_conf"),
@@ -42,8 +45,9 @@ class PandoraMachine:
         "check_refinement": ("disp_map", "disp_map", "refinement_check_conf"),
         "check_validation": ("disp_map", "disp_map", "validation_check_conf"),
         "check_filter": ("disp_map", "disp_map", "filter_check_conf"),
+        "check_multiscale": ("disp_map", "disp_map", "multiscale_check_conf"),  # state_machine.py:191-198
     }
-    _out_of_scope = ("multiscale", "cost_volume_confidence", "semantic_segmentation")
+    _out_of_scope = ("cost_volume_confidence", "semantic_segmentation")
 
     def __init__(self):
         self.left_img = None
@@ -77,6 +81,8 @@ class PandoraMachine:
         t = table[name]
         if self.state != t[0]:
             raise MachineError(f"Can't trigger event {name} from state {self.state}!")
+        if self._mode == "run" and name == "multiscale" and not self.is_not_last_scale():
+            return  # condition not met: no callback, no state change
         if self._mode == "run":
             if t[2]:
                 getattr(self, t[2])(cfg, input_step)
@@ -85,11 +91,43 @@ class PandoraMachine:
             getattr(self, t[2])(cfg, input_step)
         self.state = t[1]
 
+    def is_not_last_scale(self):
+        """state_machine.py:1027-1039"""
+        return self.current_scale != 0
+
     def run_prepare(self, cfg, left_img, right_img, scale_factor=None, num_scales=None):
-        """state_machine.py:589-692 (mono-scale branch)."""
-        if num_scales not in (None, 1):
-            raise MachineError("multiscale processing is outside the hot path implemented by pandora_amd (SURVEY 8, N3)")
-        self.num_scales, self.scale_factor, self.current_scale = 1, 1, 0
+        """state_machine.py:589-692"""
+        if num_scales is None or scale_factor is None:
+            self.num_scales, self.scale_factor = 1, 1
+        else:
+            self.num_scales, self.scale_factor = num_scales, scale_factor
+        self.dmin_user = self.dmax_user = self.dmin_user_right = self.dmax_user_right = None
+        if self.num_scales > 1:
+            # coarse-to-fine: pyramids (coarsest first), user ranges divided down to the coarsest scale; every
+            # matching_cost_prepare multiplies them back by scale_factor (state_machine.py:635-657)
+            self.img_left_pyramid, self.img_right_pyramid = multiscale.prepare_pyramid(left_img, right_img, self.num_scales,
+                                                                                      self.scale_factor)
+            self.left_img = self.img_left_pyramid.pop(0)
+            self.right_img = self.img_right_pyramid.pop(0)
+            self.current_scale = self.num_scales - 1
+            shrink = float(self.scale_factor ** self.num_scales)
+            self.disp_min = np.asarray(left_img["disparity"].sel(band_disp="min").data) / shrink
+            self.disp_max = np.asarray(left_img["disparity"].sel(band_disp="max").data) / shrink
+            self.dmin_user, self.dmax_user = self.disp_min, self.disp_max
+            self.right_disp_min, self.right_disp_max = -self.disp_max, -self.disp_min
+            self.dmin_user_right, self.dmax_user_right = self.right_disp_min, self.right_disp_max
+            self.left_disparity, self.right_disparity = Dataset(), Dataset()
+            self.right_cv = None
+            self.right_disp_map = None
+            if "validation" in cfg["pipeline"]:
+                if "interpolated_disparity" in cfg["pipeline"]["validation"]:
+                    raise MachineError("'interpolated_disparity' (validation.AbstractInterpolation) is outside the hot path "
+                                       "implemented by pandora_amd (SURVEY 8)")
+                self.right_disp_map = cfg["pipeline"]["validation"]["validation_method"]
+            self.state = "begin"
+            self._mode = "run"
+            return
+        self.current_scale = 0
         self.left_img, self.right_img = left_img, right_img
         self.disp_min = np.asarray(left_img["disparity"].sel(band_disp="min").data)
         self.disp_max = np.asarray(left_img["disparity"].sel(band_disp="max").data)
@@ -180,6 +218,29 @@ class PandoraMachine:
             self.right_cv.attrs["type_measure"] = self.left_cv.attrs["type_measure"]
             self.right_cv.attrs["cmax"] = self.left_cv.attrs["cmax"]
             self.right_disparity = disparity_.to_disp(self.right_cv, self.right_img, self.left_img)
+
+    def run_multiscale(self, cfg, input_step):
+        """state_machine.py:521-556: disparity ranges of the next (finer) scale from this scale's disparity maps."""
+        logging.info("Disparity range computation...")
+        multiscale_ = multiscale.AbstractMultiscale(self.left_img, self.right_img, **cfg["pipeline"][input_step])
+        self.dmin_user = self.dmin_user * self.scale_factor
+        self.dmax_user = self.dmax_user * self.scale_factor
+        self.disp_min, self.disp_max = multiscale_.disparity_range(self.left_disparity, self.dmin_user, self.dmax_user)
+        self.left_disparity = None
+        if self.right_disp_map is not None:
+            self.dmin_user_right = self.dmin_user_right * self.scale_factor
+            self.dmax_user_right = self.dmax_user_right * self.scale_factor
+            self.right_disp_min, self.right_disp_max = multiscale_.disparity_range(self.right_disparity, self.dmin_user_right,
+                                                                                   self.dmax_user_right)
+            self.right_disparity = None
+        self.left_img = self.img_left_pyramid.pop(0)
+        self.right_img = self.img_right_pyramid.pop(0)
+        self.current_scale = self.current_scale - 1
+
+    def multiscale_check_conf(self, cfg, input_step):
+        """state_machine.py:924-935"""
+        m = multiscale.AbstractMultiscale(self.left_img, self.right_img, **cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = m.cfg
 
     def _image_shape(self):
         return (self.left_img.sizes["row"], self.left_img.sizes["col"]) if self.left_img is not None else None

@@ -237,3 +237,16 @@ CROSS_CHECKING = [
      "validity": [[0, 0, 0, _RND], [0, 0, 0, 0]], "interval": (-2, 2), "threshold": 0.0,
      "conf": None, "mask": [[0, _MIS, 0, _RND], [0, _MIS, 0, _OCC]]},
 ]
+
+
+# ---- multiscale (tests/test_multiscale.py:52-137 test_disparity_range; window 3, marge 0, range [-30, 0]) ------
+_INC, _STOP = 1 << 2, 1 << 3  # information bits (RIGHT_INCOMPLETE_DISPARITY_RANGE, STOPPED_INTERPOLATION): still valid
+DISPARITY_RANGE = {
+    "cite": "test_multiscale.py:52-137",
+    "disp": [[-1, -2, -3, -4, -5, -6], [-7, -8, -9, _nan, -11, -12], [-13, -14, -15, -16, -17, -18],
+             [-19, -20, -21, -22, -23, -24], [_nan, -26, -27, -28, -29, -30]],
+    "validity": [[_INC] * 6, [0] * 6, [0] * 6, [_LBORDER] * 6, [_STOP] * 6],
+    "window_size": 3, "marge": 0, "dmin": -30, "dmax": 0,
+    "range_max": [[0, 0, 0, 0, 0, 0], [0, -1, -2, 0, -4, 0], [0, -7, -8, -9, -11, 0], [0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0]],
+    "range_min": [[-30] * 6, [-30, -15, -16, -30, -18, -30], [-30, -15, -16, -17, -18, -30], [-30] * 6, [-30] * 6],
+}

@@ -555,3 +555,20 @@ def test_bilateral_filter(eng, oracle, H, W, sc, ss):
     np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True)
     inv = (val & 0x3C3) != 0
     np.testing.assert_array_equal(got[inv], disp[inv])
+
+
+def test_disparity_range_reference_vector_and_random(eng, oracle):
+    c = ka.DISPARITY_RANGE
+    lo, hi = eng.disparity_range(np.array(c["disp"], np.float32), np.array(c["validity"], np.int64), c["window_size"], c["marge"],
+                                 c["dmin"], c["dmax"])
+    np.testing.assert_array_equal(lo, np.array(c["range_min"], np.float32))
+    np.testing.assert_array_equal(hi, np.array(c["range_max"], np.float32))
+    rng = np.random.default_rng(4)
+    for H, W, win, marge in ((33, 70, 5, 1), (20, 300, 3, 0), (12, 12, 11, 2)):
+        disp = (rng.integers(-40, 3, (H, W)) + rng.choice([0.0, 0.5, -0.25], (H, W))).astype(np.float32)
+        val = np.where(rng.random((H, W)) < 0.2, rng.choice([1, 2, 256], (H, W)), 0).astype(np.int64)
+        disp[1, 2] = np.nan
+        got = eng.disparity_range(disp, val, win, marge, -41, 3)
+        exp = oracle.disparity_range(disp, val, win, marge, -41, 3)
+        np.testing.assert_array_equal(got[0], exp[0])
+        np.testing.assert_array_equal(got[1], exp[1])

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import pandora_amd
-from pandora_amd import _lib, aggregation, criteria, disparity, matching_cost, optimization, refinement, validation
+from pandora_amd import _lib, aggregation, criteria, disparity, matching_cost, multiscale, optimization, refinement, validation
 from pandora_amd.dataset import DataArray, Dataset, make_image
 from pandora_amd.matching_cost import ConfigError
 from pandora_amd.state_machine import MachineError, PandoraMachine
@@ -119,8 +119,8 @@ def test_bad_sequencing_is_rejected():
                                    "aggregation": {"aggregation_method": "cbca"}}})
     with pytest.raises(MachineError) as err:  # out-of-scope step is named
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
-                                   "multiscale": {"multiscale_method": "fixed_zoom_pyramid"}}})
-    assert "multiscale" in str(err.value)
+                                   "semantic_segmentation": {"segmentation_method": "ARNN"}}})
+    assert "semantic_segmentation" in str(err.value)
     with pytest.raises(KeyError) as err:  # a filter this build does not have: the reference's own error
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
                                    "filter": {"filter_method": "median_for_intervals"}}})
@@ -176,6 +176,45 @@ def test_allocate_confidence_map_appends_an_indicator():  # cost_volume_confiden
     assert list(ds.coords["indicator"]) == ["confidence_from_left_right_consistency", "ambiguity.disp_min"]
     np.testing.assert_array_equal(ds["confidence_measure"].data[:, :, 0], a)
     np.testing.assert_array_equal(ds["confidence_measure"].data[:, :, 1], a + 1)
+
+
+def test_multiscale_configuration_like_the_reference():  # fixed_zoom_pyramid.py:44-98, test_multiscale.py:245-262
+    left, right = make_image(np.zeros((8, 8)), disparity=[-30, 0]), make_image(np.zeros((8, 8)), disparity=[0, 30])
+    m = multiscale.AbstractMultiscale(left, right, multiscale_method="fixed_zoom_pyramid")
+    assert (m.cfg["num_scales"], m.cfg["scale_factor"], m.cfg["marge"]) == (2, 2, 1)
+    with pytest.raises(KeyError) as err:
+        multiscale.AbstractMultiscale(left, right, multiscale_method="nope")
+    assert "No multiscale method named nope supported" in str(err.value)
+    with pytest.raises(ConfigError):
+        multiscale.AbstractMultiscale(left, right, multiscale_method="fixed_zoom_pyramid", num_scales=1)
+    grid = make_image(np.zeros((8, 8)), disparity_grids=(np.full((8, 8), -3), np.full((8, 8), 2)))
+    with pytest.raises(TypeError, match="Multiscale processing does not accept input disparity grids."):
+        multiscale.AbstractMultiscale(grid, right, multiscale_method="fixed_zoom_pyramid")
+    pipe = json.loads(json.dumps(PIPE))
+    pipe["pipeline"]["multiscale"] = {"multiscale_method": "fixed_zoom_pyramid", "num_scales": 3}
+    out = PandoraMachine().check_conf(pipe, left, right)
+    assert out["pipeline"]["multiscale"]["scale_factor"] == 2
+    assert multiscale.read_multiscale_params(left, right, out) == (3, 2)
+    # mask_invalid_disparities (multiscale.py:129-153, test_multiscale.py:139-243)
+    ds = Dataset({"disparity_map": (("row", "col"), np.arange(6, dtype=np.float32).reshape(2, 3)),
+                  "validity_mask": (("row", "col"), np.array([[1, 4, 0], [8, 512, 0]]))})
+    np.testing.assert_array_equal(np.isnan(multiscale.AbstractMultiscale.mask_invalid_disparities(ds)),
+                                  [[True, False, False], [False, True, False]])
+
+
+def test_pyramid_shapes_and_order():
+    """img_tools.py:479-572: coarsest first, the full-resolution dataset is the original object, disparities travel as
+    int64 grids, attrs are shared."""
+    rng = np.random.default_rng(0)
+    left = make_image(rng.random((37, 50)).astype(np.float32) * 255, disparity=[-8, 2])
+    right = make_image(rng.random((37, 50)).astype(np.float32) * 255)
+    pl, pr = multiscale.prepare_pyramid(left, right, 3, 2)
+    assert [p["im"].data.shape for p in pl] == [(10, 13), (19, 25), (37, 50)] and pl[-1] is left and pr[-1] is right
+    assert pl[0]["disparity"].data.dtype == np.int64 and pl[0]["disparity"].data.shape == (2, 10, 13)
+    assert pl[0].attrs is left.attrs and "disparity" not in pr[0].data_vars
+    # a 2x reduction of a constant image is the constant (gaussian + bilinear resize preserve it)
+    flat = multiscale.get_pyramids(np.full((16, 16), 7.0, np.float32), 2, 2)
+    np.testing.assert_allclose(flat[1], 7.0, rtol=1e-6)
 
 
 def test_repeated_steps_use_the_key_prefix():  # state_machine.py:706-717 ("refinement.again" -> refinement)

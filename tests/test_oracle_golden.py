@@ -192,3 +192,11 @@ def test_bilateral_filter_formula(oracle, case):
     np.testing.assert_allclose(got, _bilateral_numpy(disp, valid, sc, ss), rtol=1e-6)
     if case == "test_with_invalid_center":
         assert got[2, 2] == disp[2, 2]
+
+
+def test_disparity_range_known_answer(oracle):
+    c = ka.DISPARITY_RANGE
+    lo, hi = oracle.disparity_range(np.array(c["disp"], np.float32), np.array(c["validity"], np.int64), c["window_size"],
+                                    c["marge"], c["dmin"], c["dmax"])
+    np.testing.assert_array_equal(lo, np.array(c["range_min"], np.float32))
+    np.testing.assert_array_equal(hi, np.array(c["range_max"], np.float32))

@@ -114,3 +114,49 @@ def test_sample_configurations_run_as_written_and_meet_the_reference_gates(name,
     assert np.mean(occlusion != occl) <= 0.16
     assert dl.attrs["validation"] == "cross_checking_accurate"
     assert list(dl.coords["indicator"])[-1] == "confidence_from_left_right_consistency"
+
+
+MULTISCALE_REF = {"pipeline": {  # tests/common.py:177-183 multiscale_pipeline_cfg
+    "matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 2},
+    "disparity": {"disparity_method": "wta", "invalid_disparity": -9999},
+    "refinement": {"refinement_method": "vfit"},
+    "filter": {"filter_method": "median", "filter_size": 3},
+    "multiscale": {"multiscale_method": "fixed_zoom_pyramid", "num_scales": 2, "scale_factor": 2, "marge": 1}}}
+
+MULTISCALE_SGM = {"pipeline": {  # BASELINE configs[4] in small: census + SGM, 2 scales, with the validation step
+    "matching_cost": {"matching_cost_method": "census", "window_size": 5, "subpix": 1},
+    "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+    "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+    "refinement": {"refinement_method": "vfit"},
+    "filter": {"filter_method": "median", "filter_size": 3},
+    "validation": {"validation_method": "cross_checking_accurate"},
+    "multiscale": {"multiscale_method": "fixed_zoom_pyramid", "num_scales": 2, "scale_factor": 2, "marge": 1}}}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg,scales", [("multiscale_pipeline_cfg, 2 scales", MULTISCALE_REF, 2),
+                                             ("multiscale_pipeline_cfg, 3 scales", MULTISCALE_REF, 3),
+                                             ("census+sgm+validation, 2 scales", MULTISCALE_SGM, 2)], ids=lambda x: x if isinstance(x, str) else "")
+def test_multiscale_runs_meet_the_reference_gates(name, cfg, scales):
+    """tests/test_pandora.py:328-394 (test_run_2_scales / test_run_3_scales): coarse-to-fine on cones, left (and right)
+    disparity <= 20 % bad pixels at 1 px; the machine ends on the full-resolution scale."""
+    import json
+
+    from PIL import Image
+
+    import pandora_amd
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, gt_left = load_cones()
+    gt_right = np.array(Image.open(os.path.join(CONES, "disp_right.tif"))).astype(np.float32)
+    left, right = make_image(L, disparity=[-60, 0]), make_image(R, disparity=[0, 60])
+    cfg = json.loads(json.dumps(cfg))
+    cfg["pipeline"]["multiscale"]["num_scales"] = scales
+    machine = PandoraMachine()
+    cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+    dl, dr = pandora_amd.run(machine, left, right, cfg)
+    assert dl["disparity_map"].data.shape == L.shape and machine.current_scale == 0
+    assert error(np.nan_to_num(dl["disparity_map"].data, nan=1e4), gt_left, 1) <= 0.20
+    if "validation" in cfg["pipeline"]:
+        assert error(-1 * np.nan_to_num(dr["disparity_map"].data, nan=1e4), gt_right, 1) <= 0.20
