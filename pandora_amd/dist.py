@@ -63,3 +63,24 @@ def sharded_wta(engine, cv_shard, is_max, index_offset, d0_global, subpix, inval
     engine.wta_from_keys(keys.data_ptr(), d0_global, subpix, invalid_disparity)
     engine.sync()
     return keys
+
+
+# ---- row tiles (the reference's own scaling convention: ROI tiles with a margin, img_tools.get_window /
+# marge.py:86-101; the SGM plugin asks for 40 px, optimization/optimization.py:43) ---------------------------------
+def row_tile(H, world, rank, margin=40):
+    """Rows [own_lo, own_hi) owned by `rank` and the rows [read_lo, read_hi) it has to process so that every owned row
+    sees `margin` rows of context on both sides (clipped at the image).  No data-path collective: every rank computes its
+    tile from the images and keeps the owned rows."""
+    lo, hi = shard_range(H, world, rank)
+    return (lo, hi), (max(0, lo - margin), min(H, hi + margin))
+
+
+def crop_tile(arr, H, world, rank, margin=40):
+    """The owned rows of a per-pixel result computed on the rank's read window."""
+    (lo, hi), (rlo, _) = row_tile(H, world, rank, margin)
+    return arr[lo - rlo:hi - rlo]
+
+
+def stitch_tiles(parts):
+    """Concatenate the owned rows of all ranks (rank order) into the full map."""
+    return np.concatenate(parts, axis=0)

@@ -85,3 +85,22 @@ def test_shard_ranges_cover_everything():
             assert cover == list(range(n))
     own, halo = pdist.disparity_shard(-60, 0, 1, 8, 3, halo=1)
     assert halo[0] == own[0] - 1 and halo[1] == own[1] + 1
+
+
+def test_row_tiles_cover_the_image_with_margins():
+    """Row tiling (BASELINE configs[4]): owned rows partition the image, read windows add the margin and stay
+    inside the image; cropping every rank's window and stitching gives back the full map."""
+    from pandora_amd import dist as pd
+
+    H, W = 1003, 7
+    full = np.arange(H * W, dtype=np.float32).reshape(H, W)
+    for world in (1, 2, 8):
+        owned, parts = [], []
+        for rank in range(world):
+            (lo, hi), (rlo, rhi) = pd.row_tile(H, world, rank, margin=40)
+            assert 0 <= rlo <= lo < hi <= rhi <= H
+            assert lo - rlo == min(40, lo) and rhi - hi == min(40, H - hi)
+            owned.append((lo, hi))
+            parts.append(pd.crop_tile(full[rlo:rhi], H, world, rank, margin=40))
+        assert owned[0][0] == 0 and owned[-1][1] == H and all(a[1] == b[0] for a, b in zip(owned, owned[1:]))
+        np.testing.assert_array_equal(pd.stitch_tiles(parts), full)

@@ -572,3 +572,39 @@ def test_disparity_range_reference_vector_and_random(eng, oracle):
         exp = oracle.disparity_range(disp, val, win, marge, -41, 3)
         np.testing.assert_array_equal(got[0], exp[0])
         np.testing.assert_array_equal(got[1], exp[1])
+
+
+def test_row_tiled_local_pipeline_equals_full_image(eng):
+    """Row tiles with a margin of the window radius reproduce the untiled census -> WTA -> vfit result exactly (no
+    data-path collective; pandora_amd.dist.row_tile / crop_tile / stitch_tiles)."""
+    from pandora_amd import dist as pd
+
+    H, W, dmin, dmax, win = 57, 64, -9, 4, 5
+    D = dmax - dmin + 1
+    L, R = pair(H, W, seed=11)
+
+    def run(left, right):
+        eng.set_images(left, right, 1)
+        cv = eng.alloc_cv(D, dmin)
+        eng.census(cv, win)
+        eng.set_validity(None)
+        eng.wta(cv, False, -9999.0)
+        eng.refine(cv, "vfit", False)
+        return eng.get_disparity(want_itp=True)
+
+    full = run(L, R)
+    world = 3
+    parts = [[], [], []]
+    for rank in range(world):
+        (lo, hi), (rlo, rhi) = pd.row_tile(H, world, rank, margin=win // 2)
+        out = run(L[rlo:rhi], R[rlo:rhi])
+        for k in range(3):
+            parts[k].append(pd.crop_tile(out[k], H, world, rank, margin=win // 2))
+    for k in range(3):
+        got = pd.stitch_tiles(parts[k])
+        if k == 1:  # validity: tile borders inside the image are not image borders
+            inner = np.zeros(H, bool)
+            inner[win // 2:H - win // 2] = True
+            np.testing.assert_array_equal(got[inner], full[k][inner])
+        else:
+            np.testing.assert_array_equal(got[win // 2:H - win // 2], full[k][win // 2:H - win // 2])
