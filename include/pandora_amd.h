@@ -172,6 +172,16 @@ int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* val
  * [global_min, global_max].  Host maps in/out, computed on the device. */
 int pmx_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity, int H, int W, int window_size, int marge,
                         int global_min, int global_max, float* range_min, float* range_max);
+/* ---- cost-volume confidence ---------------------------------------------------------------------
+ * Replaces cost_volume_confidence_cpp.compute_ambiguity_and_sampled_ambiguity(..., sample_ambiguity=False)
+ * (src/pandora/cost_volume_confidence/cpp/src/ambiguity.cpp:28-142): for every pixel the integral over etas of the
+ * number of disparities whose normalised cost is within eta of the pixel's minimum, on the device-resident volume
+ * (materialised to float32 if need be).  etas: float32 [nbr_etas] increasing (np.arange(eta_min, eta_max, eta_step));
+ * grid_min / grid_max: int64 [H][W] per-pixel disparity range (NaN costs inside it count for every eta); negate != 0
+ * for similarity measures (the reference flips the sign of the volume around the call, ambiguity.py:117-119).
+ * ambiguity_out: float32 [H][W], not normalised. */
+int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nbr_etas, const int64_t* grid_min, const int64_t* grid_max,
+                  int negate, float* ambiguity_out);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

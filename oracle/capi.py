@@ -215,3 +215,16 @@ def disparity_range(disp, validity, win, marge, gmin, gmax):
     lib().orc_disparity_range(_p(d), _p(v, C.c_int64), d.shape[0], d.shape[1], int(win), int(marge), int(gmin), int(gmax),
                               _p(lo), _p(hi))
     return lo, hi
+
+
+def ambiguity(cv, etas, grid_min, grid_max, disp_range):
+    """ambiguity.cpp:28-142 -> float32 [H][W] integral of the ambiguity (before normalisation)."""
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    e = _f32(etas)
+    gmin = np.ascontiguousarray(grid_min, np.int64)
+    gmax = np.ascontiguousarray(grid_max, np.int64)
+    dr = _f32(disp_range)
+    out = np.empty((H, W), np.float32)
+    lib().orc_ambiguity(_p(cv), H, W, D, _p(e), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64), _p(dr), _p(out))
+    return out

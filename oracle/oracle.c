@@ -819,3 +819,60 @@ void orc_disparity_range(const float* disp, const int64_t* validity, int H, int 
         }
     free(m);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * cost_volume_confidence/cpp/src/ambiguity.cpp:28-142 compute_ambiguity_and_sampled_ambiguity (integral only) with
+ * min_max_cost / searchsorted of cost_volume_confidence_tools.cpp:22-88.  Costs normalised with the volume's global
+ * min / max (NaN ignored); a NaN cost counts for every eta when its disparity lies inside the pixel's
+ * [grid_min, grid_max] (-inf) and never otherwise (+inf); a pixel without any cost gets nbr_etas * D.
+ * grid_min / grid_max: int64 [H][W].  disp_range: the D float32 disparity samples of the volume.
+ * ------------------------------------------------------------------------------------------- */
+static size_t orc_searchsorted(const float* arr, size_t n, float value) {
+    size_t left = 0, right = n - 1;
+    while (left < right) {
+        size_t mid = left + (right - left) / 2;
+        if (arr[mid] < value) left = mid + 1; else right = mid;
+    }
+    return left;
+}
+
+void orc_ambiguity(const float* cv, int H, int W, int D, const float* etas, int nbr_etas, const int64_t* grid_min,
+                   const int64_t* grid_max, const float* disp_range, float* amb) {
+    size_t npix = (size_t)H * W;
+    float* minimg = (float*)malloc(sizeof(float) * npix);
+    float min_cost = INFINITY, max_cost = -INFINITY;
+    for (size_t p = 0; p < npix; ++p) {
+        float lo = INFINITY, hi = -INFINITY;
+        int any = 0;
+        for (int k = 0; k < D; ++k) {
+            float v = cv[p * D + k];
+            if (!isnan(v)) { any = 1; if (v < lo) lo = v; if (v > hi) hi = v; }
+        }
+        if (!any) { minimg[p] = NAN; continue; }
+        minimg[p] = lo;
+        if (lo < min_cost) min_cost = lo;
+        if (hi > max_cost) max_cost = hi;
+    }
+    float diff = max_cost - min_cost;
+    float* nc = (float*)malloc(sizeof(float) * (size_t)D);
+    for (size_t p = 0; p < npix; ++p) {
+        float ne = (minimg[p] - min_cost) / diff;
+        if (isnan(ne)) { amb[p] = (float)(nbr_etas * D); continue; }
+        size_t i0 = orc_searchsorted(disp_range, (size_t)D, (float)grid_min[p]);
+        size_t i1 = orc_searchsorted(disp_range, (size_t)D, (float)grid_max[p]) + 1;
+        for (int k = 0; k < D; ++k) {
+            float v = cv[p * D + k];
+            if (isnan(v)) nc[k] = ((size_t)k >= i0 && (size_t)k < i1) ? -INFINITY : INFINITY;
+            else nc[k] = (v - min_cost) / diff;
+        }
+        float sum = 0;
+        for (int e = 0; e < nbr_etas; ++e) {
+            float s = 0, thr = ne + etas[e];
+            for (int k = 0; k < D; ++k) s += (nc[k] <= thr) ? 1.f : 0.f;
+            sum += s;
+        }
+        amb[p] = sum;
+    }
+    free(nc);
+    free(minimg);
+}

@@ -100,6 +100,10 @@ void orc_filter_bilateral_disparity(float* disp, const int64_t* validity, int H,
 void orc_disparity_range(const float* disp, const int64_t* validity, int H, int W, int win, int marge, int gmin, int gmax,
                          float* out_min, float* out_max);
 
+/* cost_volume_confidence/cpp/src/ambiguity.cpp:28-142 (integral of the ambiguity) */
+void orc_ambiguity(const float* cv, int H, int W, int D, const float* etas, int nbr_etas, const int64_t* grid_min,
+                   const int64_t* grid_max, const float* disp_range, float* amb);
+
 #ifdef __cplusplus
 }
 #endif

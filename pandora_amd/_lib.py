@@ -60,6 +60,8 @@ SIGNATURES = {
                                                  C.c_double]),
     "pmx_disparity_range": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pmx_ambiguity": (C.c_int, [vp, vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
+                                C.POINTER(C.c_float)]),
     "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmx_reset_stage_times": (C.c_int, [vp]),

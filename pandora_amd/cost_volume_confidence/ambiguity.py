@@ -1,0 +1,81 @@
+"""Ambiguity (reference: cost_volume_confidence/ambiguity.py:38-248); the integral over etas runs on the device-resident
+cost volume (pmx_ambiguity), normalisation and bookkeeping stay on the host."""
+import logging
+
+import numpy as np
+
+from ..matching_cost.matching_cost import ConfigError
+from . import cost_volume_confidence as _cvc
+
+
+@_cvc.AbstractCostVolumeConfidence.register_subclass("ambiguity")
+class Ambiguity(_cvc.AbstractCostVolumeConfidence):
+    _ETA_MIN = 0.0
+    _ETA_MAX = 0.7
+    _ETA_STEP = 0.01
+    _PERCENTILE = 1.0
+    _NORMALIZATION = True
+    _method = "ambiguity"
+
+    def __init__(self, **cfg):
+        self.cfg = self.check_conf(**cfg)
+        self._eta_min = self._ETA_MIN
+        self._percentile = self._PERCENTILE
+        self._normalization = self.cfg["normalization"]
+        self._eta_max = float(self.cfg["eta_max"])
+        self._eta_step = float(self.cfg["eta_step"])
+        self._indicator = self._method + str(self.cfg["indicator"])
+        self._etas = np.arange(self._eta_min, self._eta_max, self._eta_step)
+        self._nbr_etas = self._etas.shape[0]
+
+    def check_conf(self, **cfg):
+        """ambiguity.py:76-104"""
+        cfg.setdefault("eta_max", self._ETA_MAX)
+        cfg.setdefault("eta_step", self._ETA_STEP)
+        cfg.setdefault("indicator", self._indicator)
+        cfg.setdefault("normalization", self._NORMALIZATION)
+        if cfg.get("confidence_method") != "ambiguity":
+            raise ConfigError("confidence_method must be ambiguity")
+        for key in ("eta_max", "eta_step"):
+            if not isinstance(cfg[key], float) or not 0 < cfg[key] < 1:
+                raise ConfigError(f"{key} must be a float in (0, 1)")
+        if not isinstance(cfg["normalization"], bool) or not isinstance(cfg["indicator"], str):
+            raise ConfigError("normalization must be a bool and indicator a str")
+        for key in cfg:
+            if key not in ("confidence_method", "eta_max", "eta_step", "indicator", "normalization"):
+                raise ConfigError(f"unknown confidence key {key!r}")
+        return cfg
+
+    def desc(self):
+        print("Ambiguity confidence method")
+
+    def confidence_prediction(self, disp, img_left=None, img_right=None, cv=None):
+        """ambiguity.py:113-166"""
+        arr = cv["cost_volume"]
+        if not hasattr(arr, "device_cv"):
+            raise TypeError("confidence_prediction needs a device-resident cost volume (pandora_amd has no CPU path)")
+        dcv = arr.device_cv
+        grids = np.array([np.asarray(img_left["disparity"].sel(band_disp="min").data),
+                          np.asarray(img_left["disparity"].sel(band_disp="max").data)], dtype=np.int64)
+        ny_, nx_, _ = dcv.shape
+        ambiguity = dcv.engine.ambiguity(dcv, self._etas, grids[0][:ny_, :nx_], grids[1][:ny_, :nx_],
+                                         negate=cv.attrs["type_measure"] == "max")
+        if self._normalization:
+            if "global_disparity" in img_left.attrs:
+                ambiguity = self.normalize_with_extremum(ambiguity, img_left, self._nbr_etas, cv.attrs["subpixel"])
+                logging.info("You are not using ambiguity normalization by percentile; \\n"
+                             "you are in a specific case with the instantiation of global_disparity.")
+            elif img_right is not None and "global_disparity" in img_right.attrs:
+                ambiguity = self.normalize_with_extremum(ambiguity, img_right, self._nbr_etas, cv.attrs["subpixel"])
+            else:
+                ambiguity = self.normalize_with_percentile(ambiguity)
+        ambiguity = 1 - ambiguity
+        return self.allocate_confidence_map(self._indicator, ambiguity, disp, cv)
+
+    def normalize_with_percentile(self, ambiguity):
+        """ambiguity.py:168-184"""
+        norm_amb = np.copy(ambiguity)
+        perc_min = np.percentile(norm_amb, self._percentile)
+        perc_max = np.percentile(norm_amb, 100 - self._percentile)
+        np.clip(norm_amb, perc_min, perc_max, out=norm_amb)
+        return (norm_amb - np.min(norm_amb)) / (np.max(norm_amb) - np.min(norm_amb))

@@ -1,0 +1,138 @@
+// k_confidence.hip - SURVEY 8f N4: the ambiguity integral of cost_volume_confidence (a reduction over D on the resident
+// float32 volume).  gfx950.
+#include "pmx_internal.h"
+
+static constexpr int kBlock = 256;
+static constexpr int kMaxEtas = 1024;
+
+__device__ __forceinline__ float c_inf() { return __int_as_float(0x7f800000); }
+
+// float <-> unsigned key that orders like the float (for atomicMin / atomicMax on the volume's extrema)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+// cost_volume_confidence_tools.cpp:41-88 min_max_cost, global part: extrema of the non-NaN costs (sign-flipped when the
+// measure is a similarity, ambiguity.py:117-119)
+__global__ __launch_bounds__(kBlock) void volume_minmax_kernel(const float* __restrict__ cv, size_t n, float sign, uint32_t* __restrict__ mm) {
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const float v = cv[i] * sign;
+        if (v == v) {
+            const uint32_t k = f2ord(v);
+            lo = k < lo ? k : lo;
+            hi = k > hi ? k : hi;
+        }
+    }
+    // wave reduce then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+struct amb_args {
+    const float* cv;
+    const float* etas;         // [nbr_etas] device
+    const int64_t* grid_min;   // [H][W] device
+    const int64_t* grid_max;
+    const uint32_t* mm;        // ordered keys of the global min / max
+    float* amb;
+    int H, W, D, d0, subpix, nbr_etas;
+    float sign;
+};
+
+// ambiguity.cpp:28-142.  Four pixels per wavefront (one per 16-lane row), lane `sub` strides over the disparities.
+// The inner double loop "for eta, for d: nc[d] <= ne + eta" is evaluated per d as E - (first eta index that satisfies
+// it): the thresholds fl32(ne + eta_i) are non-decreasing in i, so the count is exact.
+__global__ __launch_bounds__(kBlock) void ambiguity_kernel(amb_args a) {
+    __shared__ float etas_s[kMaxEtas];
+    for (int i = threadIdx.x; i < a.nbr_etas; i += kBlock) etas_s[i] = a.etas[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const size_t npix = (size_t)a.H * a.W;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    const float min_cost = ord2f(a.mm[0]), max_cost = ord2f(a.mm[1]);
+    const float diff = max_cost - min_cost;
+    const int E = a.nbr_etas, D = a.D;
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);
+        const float* row = a.cv + pix * (size_t)D;
+        // per-pixel minimum over the non-NaN costs
+        float lo = c_inf();
+        bool any = false;
+        for (int k = sub; k < D; k += 16) {
+            const float v = row[k] * a.sign;
+            if (v == v) { any = true; lo = fminf(lo, v); }
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, m));
+            any = any | (__shfl_xor((int)any, m) != 0);
+        }
+        float result;
+        const float ne = any ? (lo - min_cost) / diff : __int_as_float(0x7fc00000);
+        if (ne != ne) {
+            result = (float)(E * D);
+        } else {
+            // searchsorted(disparity_range, grid) with right = D - 1 (cost_volume_confidence_tools.cpp:22-39)
+            auto range_at = [&](int k) { return (float)((double)a.d0 + (double)k / (double)a.subpix); };
+            auto search = [&](float value) {
+                int left = 0, right = D - 1;
+                while (left < right) {
+                    const int mid = left + (right - left) / 2;
+                    if (range_at(mid) < value) left = mid + 1; else right = mid;
+                }
+                return left;
+            };
+            const int i0 = search((float)a.grid_min[pix]), i1 = search((float)a.grid_max[pix]) + 1;
+            int count = 0;
+            for (int k = sub; k < D; k += 16) {
+                const float v = row[k] * a.sign;
+                float nc;
+                if (v != v) nc = (k >= i0 && k < i1) ? -c_inf() : c_inf();
+                else nc = (v - min_cost) / diff;
+                // first i with nc <= ne + eta_i
+                int left = 0, right = E;
+                while (left < right) {
+                    const int mid = (left + right) >> 1;
+                    if (nc <= ne + etas_s[mid]) right = mid; else left = mid + 1;
+                }
+                count += E - left;
+            }
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) count += __shfl_xor(count, m);
+            result = (float)count;
+        }
+        if (sub == 0 && quad * 4 + grp < npix) a.amb[pix] = result;
+    }
+}
+
+int pmx_launch_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* d_etas, int nbr_etas, const int64_t* d_gmin, const int64_t* d_gmax,
+                         int negate, uint32_t* d_mm, float* d_amb) {
+    const float sign = negate ? -1.f : 1.f;
+    const size_t n = cv->cells();
+    const uint32_t init[2] = {0xffffffffu, 0u};
+    PMX_HIP(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(volume_minmax_kernel, dim3(4096), dim3(kBlock), 0, ctx->stream, cv->data, n, sign, d_mm);
+    amb_args a;
+    a.cv = cv->data; a.etas = d_etas; a.grid_min = d_gmin; a.grid_max = d_gmax; a.mm = d_mm; a.amb = d_amb;
+    a.H = cv->H; a.W = cv->W; a.D = cv->D; a.d0 = cv->d0; a.subpix = cv->subpix; a.nbr_etas = nbr_etas; a.sign = sign;
+    const size_t want = ((size_t)cv->H * cv->W + 15) / 16;
+    hipLaunchKernelGGL(ambiguity_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

@@ -776,3 +776,32 @@ extern "C" int pmx_disparity_range(pmx_ctx* ctx, const float* disp, const int64_
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }
+
+
+// ---- cost-volume confidence ------------------------------------------------------------------------
+extern "C" int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nbr_etas, const int64_t* grid_min, const int64_t* grid_max,
+                             int negate, float* ambiguity_out) {
+    int rc = check_cv(ctx, cv, "pmx_ambiguity");
+    if (rc) return rc;
+    PMX_CHECK(etas && grid_min && grid_max && ambiguity_out, PMX_ERR_ARG, "pmx_ambiguity: null argument");
+    PMX_CHECK(nbr_etas > 0 && nbr_etas <= 1024, PMX_ERR_ARG, "pmx_ambiguity: nbr_etas must be in 1..1024, got %d", nbr_etas);
+    rc = pmx_cv_materialize(ctx, cv);  // the measure is defined on the float32 costs
+    if (rc) return rc;
+    const size_t n = (size_t)cv->H * cv->W;
+    rc = pmx_need_small(ctx, n * (8 + 8 + 4) + (size_t)nbr_etas * 4 + 64);
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_gmin = (int64_t*)base;
+    int64_t* d_gmax = d_gmin + n;
+    float* d_amb = (float*)(d_gmax + n);
+    float* d_etas = d_amb + n;
+    uint32_t* d_mm = (uint32_t*)(d_etas + nbr_etas);
+    PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_etas, etas, (size_t)nbr_etas * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_ambiguity(ctx, cv, d_etas, nbr_etas, d_gmin, d_gmax, negate, d_mm, d_amb);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(ambiguity_out, d_amb, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}

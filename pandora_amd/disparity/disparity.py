@@ -82,6 +82,7 @@ class WinnerTakesAll(AbstractDisparity):
         cv["disp_indices"] = DataArray(disp.copy(), ("row", "col"))
         disp_map.attrs = dict(cv.attrs)
         if "confidence_measure" in cv.data_vars:
+            disp_map.coords["indicator"] = cv.coords["indicator"]
             disp_map["confidence_measure"] = cv["confidence_measure"]
         disp_map["validity_mask"] = DataArray(validity, ("row", "col"))
         disp_map.attrs["_device_cv"] = dcv  # lets the refinement step stay on the device

@@ -251,6 +251,19 @@ class Engine:
               "pmx_disparity_range")
         return lo, hi
 
+    # -- cost-volume confidence -------------------------------------------------------
+    def ambiguity(self, cv, etas, grid_min, grid_max, negate=False):
+        """ambiguity.cpp:28-142 on the resident volume -> float32 [H][W] integral of the ambiguity (not normalised)."""
+        e = np.ascontiguousarray(etas, np.float32)
+        gmin = np.ascontiguousarray(grid_min, np.int64)
+        gmax = np.ascontiguousarray(grid_max, np.int64)
+        if gmin.shape != (self.H, self.W) or gmax.shape != (self.H, self.W):
+            raise ValueError("ambiguity: the disparity grids must have the image shape")
+        out = np.empty((self.H, self.W), np.float32)
+        check(_lib.lib().pmx_ambiguity(self.ctx, cv.handle, _p(e, C.c_float), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64),
+                                       int(bool(negate)), _p(out, C.c_float)), "pmx_ambiguity")
+        return out
+
     def debug_path_costs(self, cv, raw=False):
         """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation
         (raw=True: the device byte order [8][H][W][Dp] and the (gl, kpl) lane map)."""

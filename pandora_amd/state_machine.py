@@ -8,14 +8,15 @@ N1: cross_checking_accurate / cross_checking_fast, with the left/right duplicati
 reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
 median / bilateral disparity filters (N2; state_machine.py:449-473) and the multiscale loop (N3;
 fixed_zoom_pyramid, state_machine.py:521-556, images without masks); the others of the reference
-(median_for_intervals filter, cost_volume_confidence, semantic_segmentation) are outside this
+(median_for_intervals filter, the risk / interval_bounds confidences, cost_volume_confidence, semantic_segmentation) are outside this
 build's scope: an unknown filter raises the reference's KeyError, an unknown step ``MachineError``.
 """
 import logging
 
 import numpy as np
 
-from . import aggregation, disparity, filter, matching_cost, multiscale, optimization, refinement, validation
+from . import (aggregation, cost_volume_confidence, disparity, filter, matching_cost, multiscale, optimization, refinement,
+               validation)
 from .criteria import validity_mask
 from .dataset import DataArray, Dataset
 
@@ -30,6 +31,7 @@ class PandoraMachine:
         "matching_cost": ("begin", "cost_volume", "matching_cost_prepare", "matching_cost_run"),
         "aggregation": ("cost_volume", "cost_volume", None, "aggregation_run"),
         "optimization": ("cost_volume", "cost_volume", None, "optimization_run"),
+        "cost_volume_confidence": ("cost_volume", "cost_volume", None, "cost_volume_confidence_run"),
         "disparity": ("cost_volume", "disp_map", None, "disparity_run"),
         "refinement": ("disp_map", "disp_map", None, "refinement_run"),
         "validation": ("disp_map", "disp_map", None, "validation_run"),
@@ -41,13 +43,14 @@ class PandoraMachine:
         "check_matching_cost": ("begin", "cost_volume", "matching_cost_check_conf"),
         "check_aggregation": ("cost_volume", "cost_volume", "aggregation_check_conf"),
         "check_optimization": ("cost_volume", "cost_volume", "optimization_check_conf"),
+        "check_cost_volume_confidence": ("cost_volume", "cost_volume", "cost_volume_confidence_check_conf"),
         "check_disparity": ("cost_volume", "disp_map", "disparity_check_conf"),
         "check_refinement": ("disp_map", "disp_map", "refinement_check_conf"),
         "check_validation": ("disp_map", "disp_map", "validation_check_conf"),
         "check_filter": ("disp_map", "disp_map", "filter_check_conf"),
         "check_multiscale": ("disp_map", "disp_map", "multiscale_check_conf"),  # state_machine.py:191-198
     }
-    _out_of_scope = ("cost_volume_confidence", "semantic_segmentation")
+    _out_of_scope = ("semantic_segmentation",)
 
     def __init__(self):
         self.left_img = None
@@ -205,6 +208,19 @@ class PandoraMachine:
         if self.right_disp_map == "cross_checking_accurate":
             self.right_cv = optimization_.optimize_cv(self.right_cv, self.right_img, self.left_img)
 
+    def cost_volume_confidence_run(self, cfg, input_step):
+        """state_machine.py:558-587 (N4: ambiguity on the device, std_intensity on the host)"""
+        logging.info("Cost volume confidence computation...")
+        cfg["pipeline"][input_step]["indicator"] = ""
+        if len(input_step.split(".")) == 2:
+            cfg["pipeline"][input_step]["indicator"] = "." + input_step.split(".")[1]
+        confidence_ = cost_volume_confidence.AbstractCostVolumeConfidence(**cfg["pipeline"][input_step])
+        self.left_disparity, self.left_cv = confidence_.confidence_prediction(self.left_disparity, self.left_img, self.right_img,
+                                                                              self.left_cv)
+        if self.right_disp_map == "cross_checking_accurate":
+            self.right_disparity, self.right_cv = confidence_.confidence_prediction(self.right_disparity, self.right_img,
+                                                                                    self.left_img, self.right_cv)
+
     def disparity_run(self, cfg, input_step):
         logging.info("Disparity computation...")
         disparity_ = disparity.AbstractDisparity(**cfg["pipeline"][input_step])
@@ -289,6 +305,11 @@ class PandoraMachine:
             raise AttributeError("For performing the SGM optimization step, step attribute must be equal to 1")
         o = optimization.AbstractOptimization(self.left_img, **cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = o.cfg
+
+    def cost_volume_confidence_check_conf(self, cfg, input_step):
+        """state_machine.py:937-948"""
+        c = cost_volume_confidence.AbstractCostVolumeConfidence(**cfg[input_step])
+        self.pipeline_cfg["pipeline"][input_step] = c.cfg
 
     def disparity_check_conf(self, cfg, input_step):
         d = disparity.AbstractDisparity(**cfg[input_step])

@@ -32,8 +32,9 @@ def allocate_confidence_map(name_confidence_measure, confidence_map, disp, cv):
             data = layer[:, :, np.newaxis].astype(np.float32)
             indicator = np.array([name_confidence_measure])
         ds.coords["indicator"] = indicator
-        ds.data_vars["confidence_measure"] = DataArray(data, ("row", "col", "indicator"),
-                                                       {"row": ds.coords["row"], "col": ds.coords["col"], "indicator": indicator})
+        coords = {k: ds.coords[k] for k in ("row", "col") if k in ds.coords}  # (the machine's pre-disparity dataset has none)
+        coords["indicator"] = indicator
+        ds.data_vars["confidence_measure"] = DataArray(data, ("row", "col", "indicator"), coords)
 
     if cv is not None:
         extend(cv)

@@ -608,3 +608,26 @@ def test_row_tiled_local_pipeline_equals_full_image(eng):
             np.testing.assert_array_equal(got[inner], full[k][inner])
         else:
             np.testing.assert_array_equal(got[win // 2:H - win // 2], full[k][win // 2:H - win // 2])
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,negate", [(21, 37, -9, 6, 1, False), (12, 30, -3, 4, 2, True), (9, 70, 0, 40, 1, False)])
+def test_ambiguity_integral(eng, oracle, H, W, dmin, dmax, sp, negate):
+    """ambiguity.cpp:28-142 on the device against the restatement pinned by the compiled reference: NaN costs in and out
+    of the per-pixel range, pixels without any cost, similarity measures (sign flip), 70 etas."""
+    rng = np.random.default_rng(H * W)
+    D = (dmax - dmin) * sp + 1
+    L, R = pair(H, W, seed=H)
+    eng.set_images(L, R, sp)
+    cv = eng.alloc_cv(D, dmin)
+    vol = (rng.random((H, W, D)) * 50 - 10).astype(np.float32)
+    vol[rng.random((H, W, D)) < 0.1] = np.nan
+    vol[2, 3, :] = np.nan
+    cv.from_host(vol)
+    gmin = rng.integers(dmin, dmin + 3, (H, W)).astype(np.int64)
+    gmax = (gmin + rng.integers(1, dmax - dmin - 2, (H, W))).astype(np.int64)
+    etas = np.arange(0.0, 0.7, 0.01)
+    got = eng.ambiguity(cv, etas, gmin, gmax, negate)
+    disp_range = (dmin + np.arange(D) / sp).astype(np.float32)
+    exp = oracle.ambiguity(-vol if negate else vol, etas, gmin, gmax, disp_range)
+    np.testing.assert_array_equal(got, exp)
+    assert got[2, 3] == len(etas) * D

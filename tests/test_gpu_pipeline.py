@@ -262,3 +262,29 @@ def test_machine_filter_then_validation(oracle):
     np.testing.assert_array_equal(left_disp["disparity_map"].data, ld)
     np.testing.assert_array_equal(left_disp["validity_mask"].data, lv2)
     assert left_disp.attrs["filter"] == "median" and left_disp.attrs["validation"] == "cross_checking_accurate"
+
+
+def test_machine_confidence_steps(oracle):
+    """cost_volume_confidence steps between the cost volume and the disparity (state_machine.py:558-587): std_intensity
+    (host) and ambiguity (device) land as indicator layers on the disparity dataset; the ambiguity layer equals
+    1 - percentile-normalised integral of the restatement pinned by the compiled reference."""
+    H, W, dmin, dmax = 36, 60, -7, 3
+    L, R = pair(H, W, seed=21)
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                        "cost_volume_confidence": {"confidence_method": "std_intensity"},
+                        "cost_volume_confidence.amb": {"confidence_method": "ambiguity", "eta_max": 0.7, "eta_step": 0.01},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                        "validation": {"validation_method": "cross_checking_fast"}}}
+    machine, left_disp = run_machine(L, R, cfg, dmin, dmax)
+    names = list(left_disp.coords["indicator"])
+    assert names == ["confidence_from_intensity_std", "confidence_from_ambiguity.amb", "confidence_from_left_right_consistency"]
+    conf = left_disp["confidence_measure"].data
+    assert conf.shape == (H, W, 3)
+    cv = oracle.census_cost(L, R, dmax - dmin + 1, dmin, 1, 5)
+    etas = np.arange(0.0, 0.7, 0.01)
+    amb = oracle.ambiguity(cv, etas, np.full((H, W), dmin), np.full((H, W), dmax), (dmin + np.arange(dmax - dmin + 1)).astype(np.float32))
+    lo, hi = np.percentile(amb, 1.0), np.percentile(amb, 99.0)
+    n = np.clip(amb, lo, hi)
+    exp = 1 - (n - n.min()) / (n.max() - n.min())
+    np.testing.assert_allclose(conf[:, :, 1], exp, rtol=1e-6)
+    assert np.isnan(conf[0, 0, 0]) and np.isfinite(conf[5, 5, 0])

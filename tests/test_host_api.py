@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 import pandora_amd
-from pandora_amd import _lib, aggregation, criteria, disparity, matching_cost, multiscale, optimization, refinement, validation
+from pandora_amd import (_lib, aggregation, cost_volume_confidence, criteria, disparity, matching_cost, multiscale, optimization,
+                         refinement, validation)
 from pandora_amd.dataset import DataArray, Dataset, make_image
 from pandora_amd.matching_cost import ConfigError
 from pandora_amd.state_machine import MachineError, PandoraMachine
@@ -215,6 +216,34 @@ def test_pyramid_shapes_and_order():
     # a 2x reduction of a constant image is the constant (gaussian + bilinear resize preserve it)
     flat = multiscale.get_pyramids(np.full((16, 16), 7.0, np.float32), 2, 2)
     np.testing.assert_allclose(flat[1], 7.0, rtol=1e-6)
+
+
+def test_confidence_configuration_like_the_reference():  # ambiguity.py:56-104, std_intensity.py:50-72
+    a = cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="ambiguity")
+    assert (a.cfg["eta_max"], a.cfg["eta_step"], a.cfg["normalization"]) == (0.7, 0.01, True) and a._nbr_etas == 70
+    assert cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="std_intensity").cfg["indicator"] == ""
+    with pytest.raises(KeyError) as err:
+        cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="risk")
+    assert "No confidence method named risk supported" in str(err.value)
+    with pytest.raises(ConfigError):
+        cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="ambiguity", eta_max=1.5)
+    pipe = {"pipeline": {"matching_cost": {"matching_cost_method": "zncc"},
+                         "cost_volume_confidence": {"confidence_method": "std_intensity"},
+                         "cost_volume_confidence.amb": {"confidence_method": "ambiguity", "eta_max": 0.5},
+                         "disparity": {"disparity_method": "wta"}}}
+    out = PandoraMachine().check_conf(pipe)
+    assert out["pipeline"]["cost_volume_confidence.amb"]["eta_step"] == 0.01
+    # normalisation helpers (ambiguity.py:168-184, cost_volume_confidence.py:114-138)
+    amb = np.array([[0.0, 10.0], [20.0, 1000.0]], np.float32)
+    n = a.normalize_with_percentile(amb)
+    assert n.min() == 0.0 and n.max() == 1.0
+    ds = Dataset(attrs={"global_disparity": [-10, 10]})
+    np.testing.assert_allclose(a.normalize_with_extremum(amb, ds, nbr_etas=70, subpix=2), amb / (20 * 70 * 2))
+    # std_intensity's raster: float64 cumulative-sum box statistics (img_tools.py:834-952)
+    from pandora_amd.cost_volume_confidence.std_intensity import compute_std_raster
+    im = np.random.default_rng(1).random((9, 11)).astype(np.float32) * 100
+    ref = np.array([[im[r:r + 3, c:c + 3].astype(np.float64).std() for c in range(9)] for r in range(7)])
+    np.testing.assert_allclose(compute_std_raster(im, 3), ref, rtol=1e-6, atol=1e-4)
 
 
 def test_repeated_steps_use_the_key_prefix():  # state_machine.py:706-717 ("refinement.again" -> refinement)

@@ -142,3 +142,25 @@ def test_reverse_disp_range_matches_reference(oracle):
     rmin, rmax = oracle.reverse_disp_range(np.full((2, 6), -2, np.float32), np.full((2, 6), 1, np.float32))
     np.testing.assert_array_equal(rmin[0], [0, -1, -1, -1, -1, -1])
     np.testing.assert_array_equal(rmax[0], [2, 2, 2, 2, 1, 0])
+
+
+cc = ref.load("cost_volume_confidence_cpp")
+
+
+@pytest.mark.skipif(cc is None, reason="oracle/_ref not built")
+@pytest.mark.parametrize("H,W,D,d0,sp", [(9, 14, 12, -5, 1), (6, 11, 17, -2, 2), (5, 8, 9, 0, 4)])
+def test_ambiguity_matches_reference(oracle, H, W, D, d0, sp):
+    """ambiguity.cpp:28-142: NaN costs inside / outside the per-pixel range, pixels without any cost, variable grids."""
+    rng = np.random.default_rng(H * W + D)
+    cv = (rng.random((H, W, D)) * 30).astype(np.float32)
+    cv[rng.random((H, W, D)) < 0.15] = np.nan
+    cv[1, 2, :] = np.nan
+    disp_range = (d0 + np.arange(D) / sp).astype(np.float32)
+    gmin = rng.integers(d0, d0 + 2, (H, W)).astype(np.int64)
+    gmax = (gmin + rng.integers(1, max(2, (D - 1) // sp), (H, W))).astype(np.int64)
+    etas = np.arange(0.0, 0.7, 0.01)
+    grids = np.array([gmin, gmax], dtype=np.int64)
+    exp = cc.compute_ambiguity_and_sampled_ambiguity(cv, etas, len(etas), grids, disp_range, False)[0]
+    got = oracle.ambiguity(cv, etas, gmin, gmax, disp_range)
+    np.testing.assert_array_equal(got, exp)
+    assert got[1, 2] == len(etas) * D
