@@ -76,8 +76,9 @@ SAMPLE_LOCAL = {"pipeline": {  # data_samples/json_conf_files/a_local_block_matc
     "refinement": {"refinement_method": "quadratic"},
     "validation": {"validation_method": "cross_checking_accurate"}}}
 
-VALIDATION_REF = {"pipeline": {  # tests/common.py:168-175 minus cost_volume_confidence (outside the hot path)
+VALIDATION_REF = {"pipeline": {  # tests/common.py:168-175, as written
     "matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 2},
+    "cost_volume_confidence": {"confidence_method": "std_intensity"},
     "disparity": {"disparity_method": "wta", "invalid_disparity": -9999},
     "refinement": {"refinement_method": "vfit"},
     "filter": {"filter_method": "median", "filter_size": 3},
@@ -114,6 +115,8 @@ def test_sample_configurations_run_as_written_and_meet_the_reference_gates(name,
     assert np.mean(occlusion != occl) <= 0.16
     assert dl.attrs["validation"] == "cross_checking_accurate"
     assert list(dl.coords["indicator"])[-1] == "confidence_from_left_right_consistency"
+    if "cost_volume_confidence" in cfg["pipeline"]:
+        assert list(dl.coords["indicator"])[0] == "confidence_from_intensity_std"
 
 
 MULTISCALE_REF = {"pipeline": {  # tests/common.py:177-183 multiscale_pipeline_cfg
