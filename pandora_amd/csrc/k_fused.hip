@@ -320,79 +320,87 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
                                                        float4* __restrict__ near) {
     constexpr int PPW = 64 / GL;   // pixels per wavefront
     constexpr int M4 = KPL & ~3, NB = M4 / 4, T = KPL & 3;
+    constexpr int SROW = GL * KPL + 4;  // sums of one pixel in LDS (wave-private; +4: slot -1 and slot GL*KPL exist)
     static_assert(T <= 1, "KPL must be 0 or 1 mod 4");
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t sbuf[4][PPW][SROW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane & (GL - 1), grp = lane / GL;
-    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t wave = (size_t)blockIdx.x * 4 + wv;
     const size_t nwaves = (size_t)gridDim.x * 4;
     const int d_first = sub * KPL;
     const bool lane_active = d_first < a.D;
     const size_t vol = (size_t)a.H * a.W * a.Dp;
-    const uint32_t wvalid = (uint32_t)(a.W - 2 * a.o);
+    const int wvalid = a.W - 2 * a.o;
+    const int nown = min(KPL, a.D - d_first);  // real disparities of this lane (<= 0 for idle lanes)
+    // candidate index of slot e with the pad mask folded in: pads get all-ones so that (sum << 16) | idx is never a minimum
+    uint32_t idx[KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) idx[e] = (e < nown) ? (uint32_t)(d_first + e) : 0xffffffffu;
+    uint32_t* const srow = &sbuf[wv][grp][1];  // srow[d] = S(d), d = -1 .. GL*KPL
     for (size_t quad = wave; quad * PPW < npix; quad += nwaves) {
         const size_t pix = min(quad * PPW + grp, npix - 1);  // surplus groups repeat the last pixel (same values)
         const int r = (int)(pix / a.W), c = (int)(pix - (size_t)r * a.W);
-        // ---- sum of the 8 directions: s[e] for the lane's KPL disparities
-        uint32_t lo[NB], hi[NB], tl = 0;
+        // ---- sum of the 8 directions: s[e] for the lane's KPL disparities (byte-select adds)
+        uint32_t s[KPL];
 #pragma unroll
-        for (int q = 0; q < NB; ++q) { lo[q] = 0; hi[q] = 0; }
+        for (int e = 0; e < KPL; ++e) s[e] = 0;
         const uint8_t* base = a.ldir + pix * a.Dp + (lane_active ? sub * M4 : 0);  // idle lanes re-read lane 0
         const uint8_t* tbase = a.ldir + pix * a.Dp + a.nact * M4 + (lane_active ? sub : 0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             uint32_t x[NB];
             __builtin_memcpy(x, base + k * vol, 4 * NB);
-            if (T) tl += tbase[k * vol];
+            if (T) s[KPL - 1] += tbase[k * vol];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                lo[q] += x[q] & 0x00ff00ffu;         // bytes 0 and 2 of the dword
-                hi[q] += (x[q] >> 8) & 0x00ff00ffu;  // bytes 1 and 3
+                s[4 * q] += x[q] & 0xffu;
+                s[4 * q + 1] += (x[q] >> 8) & 0xffu;
+                s[4 * q + 2] += (x[q] >> 16) & 0xffu;
+                s[4 * q + 3] += x[q] >> 24;
             }
         }
-        uint32_t s[KPL];
+        // the sums go to LDS (wave-private row of the pixel) so that the winner's neighbours can be fetched by index
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            s[4 * q] = lo[q] & 0xffffu; s[4 * q + 1] = hi[q] & 0xffffu; s[4 * q + 2] = lo[q] >> 16; s[4 * q + 3] = hi[q] >> 16;
-        }
-        if (T) s[KPL - 1] = tl;
-        // ---- which of the lane's cells are NaN in the census volume (geometry only on this path)
-        const bool pix_ok = (r >= a.o) && (r < a.H - a.o) && (c >= a.o) && (c < a.W - a.o);
-        const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
-        uint32_t okbits = 0, key = 0xffffffffu;
+        for (int e = 0; e < KPL; ++e) srow[d_first + e] = s[e];
+        // ---- validity of the lane's cells (geometry only on this path): slot e is a number iff elo <= e < ehi
+        const bool pix_ok = (r >= a.o) & (r < a.H - a.o) & (c >= a.o) & (c < a.W - a.o);
+        const int us = c + a.d0 + d_first - a.o;  // right column of slot 0, relative to the first valid one
+        const bool interior = (pix_ok & (us >= 0) & (us + nown <= wvalid)) | (nown <= 0);
+        uint32_t key = 0xffffffffu;
+        if (__all(interior)) {
 #pragma unroll
-        for (int e = 0; e < KPL; ++e) {
-            const bool ok = lane_active && pix_ok && (d_first + e < a.D) && (u + (uint32_t)e < wvalid);
-            okbits |= ok ? (1u << e) : 0u;
-            if (ok) key = umin2(key, (s[e] << 16) | (uint32_t)(d_first + e));
-        }
-        key = group_allmin_u<GL>(key);  // every lane of the group now holds the pixel's (min sum, first index)
-        const bool none = key == 0xffffffffu;
-        const int kb = none ? -8 : (int)(key & 0xffffu);
-        // ---- the winner's lane fetches its neighbours (possibly from the adjacent lane) and writes the result
-        const uint32_t s_below = dppu<0x111>(0u, s[KPL - 1]), ok_below = dppu<0x111>(0u, okbits >> (KPL - 1));  // row_shr:1
-        const uint32_t s_above = dppu<0x101>(0u, s[0]), ok_above = dppu<0x101>(0u, okbits & 1u);               // row_shl:1
-        const int eb = kb - d_first;  // winner's slot in this lane, if 0 <= eb < KPL
-        if (eb >= 0 && eb < KPL && lane_active) {
-            uint32_t c0 = 0, c2 = 0;
-            bool v0 = false, v2 = false;
+            for (int e = 0; e < KPL; ++e) key = umin2(key, (s[e] << 16) | idx[e]);
+        } else {
+            const int elo = max(0, -us);
+            const int ehi = pix_ok ? min(nown, wvalid - us) : 0;
 #pragma unroll
             for (int e = 0; e < KPL; ++e) {
-                if (e == eb) {
-                    c0 = (e > 0) ? s[e > 0 ? e - 1 : 0] : s_below;
-                    v0 = (e > 0) ? ((okbits >> (e > 0 ? e - 1 : 0)) & 1u) : (ok_below & 1u);
-                    c2 = (e < KPL - 1) ? s[e < KPL - 1 ? e + 1 : 0] : s_above;
-                    v2 = (e < KPL - 1) ? ((okbits >> (e < KPL - 1 ? e + 1 : 0)) & 1u) : (ok_above & 1u);
-                }
+                const bool ok = (e >= elo) & (e < ehi);
+                key = umin2(key, ok ? ((s[e] << 16) | idx[e]) : 0xffffffffu);
             }
-            near[pix] = make_float4(v0 ? (float)c0 : g_nan(), (float)(key >> 16), v2 ? (float)c2 : g_nan(), __int_as_float(kb));
-            disp[pix] = (float)(d0 + (double)kb);
         }
-        if (none && sub == 0) {
-            near[pix] = make_float4(g_nan(), g_nan(), g_nan(), __int_as_float(-8));
-            disp[pix] = invalid_disparity;  // disparity.py:452-455
-            int64_t m = validity[pix];
-            if ((m & FMSK_INVALID) == 0) validity[pix] = FMSK_INVALID;  // disparity.py:471-474
+        key = group_allmin_u<GL>(key);  // every lane of the group now holds the pixel's (min sum, first index)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- lane 0 of the group writes the result: winner, its neighbours S(k-1), S(k+1) (NaN where they are not numbers)
+        if (sub == 0) {
+            if (key == 0xffffffffu) {
+                near[pix] = make_float4(g_nan(), g_nan(), g_nan(), __int_as_float(-8));
+                disp[pix] = invalid_disparity;  // disparity.py:452-455
+                int64_t m = validity[pix];
+                if ((m & FMSK_INVALID) == 0) validity[pix] = FMSK_INVALID;  // disparity.py:471-474
+            } else {
+                const int kb = (int)(key & 0xffffu);
+                const int q0 = c + a.d0 + kb - a.o;  // right column of the winner, relative
+                const bool v0 = (kb - 1 >= 0) & (q0 - 1 >= 0), v2 = (kb + 1 < a.D) & (q0 + 1 < wvalid);
+                const uint32_t c0 = srow[kb - 1], c2 = srow[kb + 1];
+                near[pix] = make_float4(v0 ? (float)c0 : g_nan(), (float)(key >> 16), v2 ? (float)c2 : g_nan(), __int_as_float(kb));
+                disp[pix] = (float)(d0 + (double)kb);
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the next iteration overwrites the row
     }
 }
 
