@@ -147,7 +147,7 @@ def main():
         # dominant kernel: the fused census->SGM kernel (all 8 paths in ONE launch: 20 B/cell algorithmic)
         # on the integer fast path, else one of the 8 float path passes (20/8 B/cell per launch)
         if stage["sgm_fused"][1] > 0:
-            kernel_name = "sgm_u8_packed_kernel (all 8 SGM paths in one launch, packed u16 arithmetic on byte costs)"
+            kernel_name = "sgm_u8_packed_kernel (all 8 SGM paths in one launch, packed u16 arithmetic on 5-bit / byte costs)"
             sgm_ms, sgm_n = stage["sgm_fused"]
             algo_bytes_per_launch = SGM_ALGO_BYTES_PER_CELL * cells
         else:

@@ -17,6 +17,12 @@
 //     A[q] = (L[4q], L[4q+2]) as (lo16, hi16),  B[q] = (L[4q+1], L[4q+3]).
 // Disparities >= D ("pads") carry kInf16 in their cost, so they never win a minimum; their stored bytes are garbage
 // above the lane's real bytes and are never read.
+//
+// The path kernel is HBM-bound (9.3 GB per launch at C3, 4.4 of them the 8 reads of the cost bytes) with issue slots to
+// spare, so when every cost fits 5 bits (invalid_cost <= 31: census windows up to 5x5) the costs are stored SIX per dword
+// (CBITS = 5): a lane's 12 costs are 8 bytes instead of 12, unpacked with v_bfe_u32 (+15 instructions per step).
+#include <cstdlib>
+
 #include "pmx_internal.h"
 
 static constexpr int kWaves8 = 4;       // wavefronts per workgroup
@@ -53,9 +59,10 @@ struct cost8_args {
 // Four pixels per wavefront (one per 16-lane row), lane `sub` owns the same KPL disparities it owns in the path kernel:
 // KPL right codes come in as 16-byte loads, KPL bytes leave as one store.  Invalid census cells (window outside the
 // image on either side; census.cpp:97-180 leaves them NaN) carry invalid_cost, bytes at d >= D are don't-cares.
-template <int NW, int KPL>
+template <int NW, int KPL, int CBITS>
 __global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
-    constexpr int Q = KPL / 4;
+    constexpr int PER = CBITS == 8 ? 4 : 6;          // costs per dword
+    constexpr int NDW = (KPL + PER - 1) / PER;       // dwords per lane
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15, grp = lane >> 4;
     const size_t npix = (size_t)a.H * a.W;
@@ -72,34 +79,34 @@ __global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
         __builtin_memcpy(lc, a.codeL + pix * NW, sizeof(uint32_t) * NW);
         __builtin_memcpy(rc, a.codeR + ((ptrdiff_t)pix + a.d0 + (lane_active ? d_first : 0)) * NW, sizeof(uint32_t) * KPL * NW);
         const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
-        uint32_t out[Q];
+        uint32_t out[NDW];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            uint32_t v[4];
+        for (int j = 0; j < NDW; ++j) out[j] = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                uint32_t pop = 0;
+        for (int k = 0; k < KPL; ++k) {
+            uint32_t pop = 0;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) pop += __popc(lc[w] ^ rc[(4 * q + e) * NW + w]);
-                v[e] = (pix_ok && (u + (uint32_t)(4 * q + e) < wvalid)) ? pop : a.invalid_cost;
-            }
-            out[q] = (((v[3] << 8) | v[2]) << 16) | ((v[1] << 8) | v[0]);
+            for (int w = 0; w < NW; ++w) pop += __popc(lc[w] ^ rc[k * NW + w]);
+            const uint32_t v = (pix_ok && (u + (uint32_t)k < wvalid)) ? pop : a.invalid_cost;
+            out[k / PER] |= v << (CBITS * (k % PER));
         }
-        if (lane_active) __builtin_memcpy(a.cost + pix * a.Dp + d_first, out, 4 * Q);
+        if (lane_active) __builtin_memcpy(a.cost + pix * a.Dp + (size_t)sub * NDW * 4, out, 4 * NDW);
     }
 }
 
 // ---- the 8 paths ---------------------------------------------------------------------------------------------------
 struct sgm8_args {
-    const uint8_t* cost;  // [H][W][Dp]
+    const uint8_t* cost;  // [H][W][Dc]: costs of a pixel, lane by lane (CBITS = 8: one byte each; 5: six per dword)
     uint8_t* ldir;        // [8][H][W][Dp]
-    int H, W, D, Dp;
+    int H, W, D, Dp, Dc;
     uint32_t P1, P2;
 };
 
-template <int KPL>
+template <int KPL, int CBITS>
 __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_args a) {
     constexpr int Q = KPL / 4;
+    constexpr int PER = CBITS == 8 ? 4 : 6;     // costs per dword of the cost volume
+    constexpr int NDW = (KPL + PER - 1) / PER;  // cost dwords per lane
     static_assert(KPL % 4 == 0, "whole dwords per lane");
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15, grp = lane >> 4;
@@ -131,22 +138,22 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
     int pc = c;
     int pleft = nsteps - 1;
     const int stride = dr * W + dc;  // pixel stride of one step (before wrapping)
-    const uint8_t* pC = a.cost + ((size_t)r * W + c) * a.Dp + (lane_active ? d_first : 0);
+    const uint8_t* pC = a.cost + ((size_t)r * W + c) * a.Dc + (lane_active ? sub * NDW * 4 : 0);
     uint8_t* pO = a.ldir + (size_t)dir * H * W * a.Dp + ((size_t)r * W + c) * a.Dp + d_first;
 
-    struct slot_t { uint32_t x[Q]; };
+    struct slot_t { uint32_t x[NDW]; };
     slot_t ring[kRing8];
     auto prefetch = [&](slot_t& s) {
-        __builtin_memcpy(s.x, pC, 4 * Q);
+        __builtin_memcpy(s.x, pC, 4 * NDW);
         if (pleft > 0) {  // wave-uniform; past the end the last pixel is re-read
             --pleft;
-            pC += (ptrdiff_t)stride * a.Dp;
+            pC += (ptrdiff_t)stride * a.Dc;
             if (diagonal) {
                 pc += dc;
                 const bool hi = pc >= W, lo = pc < 0;
                 const int fix = hi ? -W : (lo ? W : 0);
                 pc += fix;
-                pC += (ptrdiff_t)fix * a.Dp;
+                pC += (ptrdiff_t)fix * a.Dc;
             }
         }
     };
@@ -174,8 +181,15 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
         uint32_t nA[Q], nB[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const uint32_t ccA = (s.x[q] & 0x00ff00ffu) | padA[q];          // costs of d, d+2
-            const uint32_t ccB = ((s.x[q] >> 8) & 0x00ff00ffu) | padB[q];   // costs of d+1, d+3
+            uint32_t ccA, ccB;  // costs of (d, d+2) and of (d+1, d+3)
+            if (CBITS == 8) {
+                ccA = (s.x[q] & 0x00ff00ffu) | padA[q];
+                ccB = ((s.x[q] >> 8) & 0x00ff00ffu) | padB[q];
+            } else {
+                auto cost5 = [&](int k) { return __builtin_amdgcn_ubfe(s.x[k / 6], 5 * (k % 6), 5); };
+                ccA = (cost5(4 * q) | (cost5(4 * q + 2) << 16)) | padA[q];
+                ccB = (cost5(4 * q + 1) | (cost5(4 * q + 3) << 16)) | padB[q];
+            }
             // neighbours: A = (d, d+2) has lo = (d-1, d+1), hi = (d+1, d+3) = B;  B has lo = A, hi = (d+2, d+4)
             const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
             const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
@@ -243,12 +257,19 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     const int nact = (cv->D + kpl - 1) / kpl;
     const int Dp = nact * kpl;  // multiple of 4
     const size_t vol = (size_t)H * W * Dp;
-    if (cv->cost8_bytes < vol) {
+    const int nw = (cv->win * cv->win + 31) / 32;
+    // five-bit costs when they fit (PMX_COST5=0 keeps bytes: test hook)
+    const char* e5 = getenv("PMX_COST5");
+    const bool five = invalid_cost <= 31 && (uint32_t)(cv->win * cv->win) <= 31 && !(e5 && e5[0] == '0');
+    const int ndw = five ? (kpl + 5) / 6 : kpl / 4;
+    const int Dc = nact * ndw * 4;
+    const size_t cvol = (size_t)H * W * Dc;
+    if (cv->cost8_bytes < cvol) {
         pmx_pool_free(ctx, cv->cost8);
         cv->cost8 = nullptr;
         cv->cost8_bytes = 0;
-        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->cost8, vol + 64));
-        cv->cost8_bytes = vol;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->cost8, cvol + 64));
+        cv->cost8_bytes = cvol;
     }
     if (cv->ldir_bytes < 8 * vol) {
         pmx_pool_free(ctx, cv->ldir);
@@ -258,16 +279,17 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         cv->ldir_bytes = 8 * vol;
     }
     cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl;
-    const int nw = (cv->win * cv->win + 31) / 32;
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
         cost8_args c;
         c.codeL = cv->codeL; c.codeR = cv->codeR; c.cost = cv->cost8;
-        c.H = H; c.W = W; c.D = cv->D; c.Dp = Dp; c.d0 = cv->d0; c.o = cv->win / 2;
+        c.H = H; c.W = W; c.D = cv->D; c.Dp = Dc; c.d0 = cv->d0; c.o = cv->win / 2;
         c.invalid_cost = invalid_cost;
         const size_t want = ((size_t)H * W + 15) / 16;  // 4 pixels per wave, 4 waves per block
         const dim3 grid((unsigned)(want < 65536 ? want : 65536));
-#define PMX_COST8(NWV, KPLV) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV>), grid, dim3(256), 0, ctx->stream, c)
+#define PMX_COST8(NWV, KPLV)                                                                                                  \
+    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, 5>), grid, dim3(256), 0, ctx->stream, c);   \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, 8>), grid, dim3(256), 0, ctx->stream, c)
 #define PMX_COST8_KPL(NWV)                 \
     switch (kpl) {                         \
         case 4: PMX_COST8(NWV, 4); break;  \
@@ -283,18 +305,22 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     PMX_HIP(hipGetLastError());
     sgm8_args a;
     a.cost = cv->cost8; a.ldir = cv->ldir;
-    a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.P1 = P1; a.P2 = P2;
+    a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.Dc = Dc; a.P1 = P1; a.P2 = P2;
     const int nwaves = 2 * ((H + kLines8 - 1) / kLines8) + 6 * ((W + kLines8 - 1) / kLines8);
     const dim3 grid((nwaves + kWaves8 - 1) / kWaves8), block(kWaves8 * 64);
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
+#define PMX_SGM8(KPLV)                                                                                                   \
+    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 5>), grid, block, 0, ctx->stream, a);        \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 8>), grid, block, 0, ctx->stream, a)
         switch (kpl) {
-            case 4: hipLaunchKernelGGL(sgm_u8_packed_kernel<4>, grid, block, 0, ctx->stream, a); break;
-            case 8: hipLaunchKernelGGL(sgm_u8_packed_kernel<8>, grid, block, 0, ctx->stream, a); break;
-            case 12: hipLaunchKernelGGL(sgm_u8_packed_kernel<12>, grid, block, 0, ctx->stream, a); break;
-            case 16: hipLaunchKernelGGL(sgm_u8_packed_kernel<16>, grid, block, 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL(sgm_u8_packed_kernel<20>, grid, block, 0, ctx->stream, a); break;
+            case 4: PMX_SGM8(4); break;
+            case 8: PMX_SGM8(8); break;
+            case 12: PMX_SGM8(12); break;
+            case 16: PMX_SGM8(16); break;
+            default: PMX_SGM8(20); break;
         }
+#undef PMX_SGM8
     }
     PMX_HIP(hipGetLastError());
     return PMX_OK;

@@ -379,14 +379,16 @@ def test_fused_lane_maps(eng, oracle, monkeypatch, gl, kpl, dmin, dmax):
     np.testing.assert_array_equal(cv.to_host(), s)
 
 
-@pytest.mark.parametrize("sgm8", ["1", "0"])
+@pytest.mark.parametrize("sgm8", ["1", "bytes", "0"])
 @pytest.mark.parametrize("win,dmin,dmax", [(5, -20, 6), (7, -70, 30), (5, 0, 128), (3, -200, 50), (5, -150, 150)])
 def test_packed_and_popcount_fused_kernels_agree_with_the_oracle(eng, oracle, monkeypatch, sgm8, win, dmin, dmax):
-    """The default integer path (k_sgm8.hip: byte costs + packed 16-bit recurrence, KPL 4..20, one- and two-word census
-    codes) and the popcount-fused kernel behind PMX_SGM8=0 (k_fused.hip), both against the oracle pipeline."""
+    """The default integer path (k_sgm8.hip: packed 16-bit recurrence on five-bit costs for windows up to 5x5, on byte
+    costs otherwise or with PMX_COST5=0; KPL 4..20, one- and two-word census codes) and the popcount-fused kernel behind
+    PMX_SGM8=0 (k_fused.hip), all against the oracle pipeline."""
     if not eng.lazy:
         pytest.skip("fused kernels only exist on the lazy path")
-    monkeypatch.setenv("PMX_SGM8", sgm8)
+    monkeypatch.setenv("PMX_SGM8", "0" if sgm8 == "0" else "1")
+    monkeypatch.setenv("PMX_COST5", "0" if sgm8 == "bytes" else "1")
     H, W = 19, 70
     D = dmax - dmin + 1
     L, R = pair(H, W, seed=win + D, shift=-2)
@@ -395,7 +397,7 @@ def test_packed_and_popcount_fused_kernels_agree_with_the_oracle(eng, oracle, mo
     eng.census(cv, win)
     eng.sgm(cv, 8, 32, False, float(win * win + 1), False)
     raw, gl, kpl = eng.debug_path_costs(cv, raw=True)
-    if sgm8 == "1":
+    if sgm8 != "0":
         assert gl == 16 and kpl == ((D // 16 + 1) + 3) // 4 * 4  # the packed kernels' map
     eng.set_validity(None)
     eng.wta(cv, False, -9999.0)
