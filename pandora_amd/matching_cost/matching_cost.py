@@ -152,8 +152,14 @@ class AbstractMatchingCost:
         ny_, nx_, _ = dcv.shape
         disp_min, disp_max = disp_min[:ny_, :nx_], disp_max[:ny_, :nx_]
         coords = np.asarray(cost_volume.coords["disp"])
-        uniform = (np.nanmin(disp_min) == np.nanmax(disp_min) and np.nanmin(disp_max) == np.nanmax(disp_max)
-                   and disp_min.flat[0] <= coords[0] and disp_max.flat[0] >= coords[-1] and not np.isnan(disp_min).any())
+        # constant grids that cover the whole volume need no per-pixel range test on the device; integer grids (the usual
+        # case) cannot hold NaN, so plain min / max do
+        if disp_min.dtype.kind in "iu" and disp_max.dtype.kind in "iu":
+            lo0, lo1, hi0, hi1 = disp_min.min(), disp_min.max(), disp_max.min(), disp_max.max()
+            uniform = lo0 == lo1 and hi0 == hi1 and lo0 <= coords[0] and hi0 >= coords[-1]
+        else:
+            uniform = (np.nanmin(disp_min) == np.nanmax(disp_min) and np.nanmin(disp_max) == np.nanmax(disp_max)
+                       and disp_min.flat[0] <= coords[0] and disp_max.flat[0] >= coords[-1] and not np.isnan(disp_min).any())
         eng.set_disparity_grids(None, None) if uniform else eng.set_disparity_grids(disp_min, disp_max)
         eng.cv_masked(dcv, self._window_size)
         if "validity_mask" in cost_volume.data_vars:

@@ -172,13 +172,15 @@ class PandoraMachine:
     # -- run callbacks (state_machine.py:292-490) ----------------------------------------------
     def matching_cost_prepare(self, cfg, input_step):
         self.matching_cost_ = matching_cost.AbstractMatchingCost(**cfg["pipeline"][input_step])
-        self.disp_min = self.disp_min * self.scale_factor
-        self.disp_max = self.disp_max * self.scale_factor
+        if self.scale_factor != 1:  # (a 4 M-pixel grid times one is 8 ms of host time for nothing)
+            self.disp_min = self.disp_min * self.scale_factor
+            self.disp_max = self.disp_max * self.scale_factor
         self.left_cv = self.matching_cost_.allocate_cost_volume(self.left_img, (self.disp_min, self.disp_max), cfg)
         self.left_cv = validity_mask(self.left_img, self.right_img, self.left_cv)
         if self.right_disp_map is not None:  # state_machine.py:311-331
-            self.right_disp_min = self.right_disp_min * self.scale_factor
-            self.right_disp_max = self.right_disp_max * self.scale_factor
+            if self.scale_factor != 1:
+                self.right_disp_min = self.right_disp_min * self.scale_factor
+                self.right_disp_max = self.right_disp_max * self.scale_factor
             if self.right_disp_map == "cross_checking_accurate":
                 grids = (self.right_disp_min, self.right_disp_max)
             else:  # fast: sized from the left range so that it matches the reversed left volume
