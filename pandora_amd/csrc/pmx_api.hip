@@ -293,19 +293,28 @@ extern "C" pmx_cv* pmx_cv_alloc(pmx_ctx* ctx, int D, int d0) {
     cv->ctx = ctx;
     cv->H = ctx->H; cv->W = ctx->W; cv->D = D; cv->d0 = d0; cv->subpix = ctx->subpix;
     cv->bytes = cv->cells() * sizeof(float) + 256;  // tail pad: wide per-lane loads of the last pixel stay in bounds
-    hipError_t e = pmx_pool_alloc(ctx, (void**)&cv->data, cv->bytes);
-    if (e != hipSuccess) {
-        pmx_set_error("pmx_cv_alloc: hipMalloc(%zu bytes) failed: %s", cv->bytes, hipGetErrorString(e));
-        delete cv;
-        return nullptr;
-    }
-    cv->repr = PMX_REPR_ALL_NAN;  // allocate_cost_volume's NaN fill is deferred until someone needs it
+    // allocate_cost_volume's NaN fill - and, on the lazy path, the float32 storage itself (2.2 GB at C3, 52 GB at C5) - is
+    // deferred until something needs it: the integer fast path never does
+    cv->repr = PMX_REPR_ALL_NAN;
     if (!ctx->lazy && pmx_cv_materialize(ctx, cv) != PMX_OK) {
         pmx_pool_free(ctx, cv->data);
         delete cv;
         return nullptr;
     }
     return cv;
+}
+
+// the float32 storage of a handle, allocated on first need
+int pmx_cv_ensure_data(pmx_ctx* ctx, pmx_cv* cv) {
+    if (cv->data) return PMX_OK;
+    PMX_HIP(hipSetDevice(ctx->device));
+    hipError_t e = pmx_pool_alloc(ctx, (void**)&cv->data, cv->bytes);
+    if (e != hipSuccess) {
+        cv->data = nullptr;
+        pmx_set_error("cost volume: hipMalloc(%zu bytes) failed: %s", cv->bytes, hipGetErrorString(e));
+        return PMX_ERR_HIP;
+    }
+    return PMX_OK;
 }
 
 extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
@@ -327,6 +336,8 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
 
 // Bring a handle back to a plain float32 [H][W][D] volume, whatever exact form it is held in.
 int pmx_cv_materialize(pmx_ctx* ctx, pmx_cv* cv) {
+    if (cv->repr == PMX_REPR_FLOAT && cv->data) return PMX_OK;
+    if (int rc = pmx_cv_ensure_data(ctx, cv)) return rc;
     switch (cv->repr) {
         case PMX_REPR_FLOAT: return PMX_OK;
         case PMX_REPR_ALL_NAN: {
@@ -360,6 +371,7 @@ extern "C" int pmx_cv_fill_nan(pmx_ctx* ctx, pmx_cv* cv) {
 extern "C" int pmx_cv_upload(pmx_ctx* ctx, pmx_cv* cv, const float* host) {
     PMX_CHECK(ctx && cv && host, PMX_ERR_ARG, "pmx_cv_upload: null argument");
     PMX_HIP(hipSetDevice(ctx->device));
+    if (int rc0 = pmx_cv_ensure_data(ctx, cv)) return rc0;
     PMX_HIP(hipMemcpyAsync(cv->data, host, cv->cells() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     cv->repr = PMX_REPR_FLOAT;
@@ -408,6 +420,10 @@ extern "C" int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
     const int nw = (win * win + 31) / 32;
     const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 2 && cv->D < 320 && abs(cv->d0) + cv->D <= 1024 / nw - 32 && !ctx->bad_left &&
                        !ctx->bad_right && !ctx->grid_min;
+    if (!defer) {
+        rc = pmx_cv_ensure_data(ctx, cv);
+        if (rc) return rc;
+    }
     return pmx_launch_census(ctx, cv, win, defer);
 }
 
@@ -415,6 +431,8 @@ extern "C" int pmx_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared) {
     int rc = check_cv(ctx, cv, "pmx_sad_ssd");
     if (rc) return rc;
     PMX_CHECK(win > 0 && (win & 1), PMX_ERR_ARG, "pmx_sad_ssd: window_size must be odd and > 0 (sad_ssd.py:69), got %d", win);
+    rc = pmx_cv_ensure_data(ctx, cv);
+    if (rc) return rc;
     rc = pmx_launch_sad_ssd(ctx, cv, win, squared);
     if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
     return rc;
@@ -424,6 +442,8 @@ extern "C" int pmx_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
     int rc = check_cv(ctx, cv, "pmx_zncc");
     if (rc) return rc;
     PMX_CHECK(win > 0 && (win & 1), PMX_ERR_ARG, "pmx_zncc: window_size must be odd and > 0, got %d", win);
+    rc = pmx_cv_ensure_data(ctx, cv);
+    if (rc) return rc;
     rc = pmx_launch_zncc(ctx, cv, win);
     if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
     return rc;
@@ -466,6 +486,10 @@ extern "C" pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, 
     if (pmx_cv_materialize(ctx, const_cast<pmx_cv*>(left_cv))) return nullptr;
     pmx_cv* out = pmx_cv_alloc(ctx, left_cv->D, min_disp);
     if (!out) return nullptr;
+    if (pmx_cv_ensure_data(ctx, out) != PMX_OK) {
+        pmx_cv_free(ctx, out);
+        return nullptr;
+    }
     out->repr = PMX_REPR_FLOAT;  // the kernel writes every cell
     if (pmx_launch_reverse(ctx, left_cv, min_disp, out) != PMX_OK) {
         pmx_cv_free(ctx, out);

@@ -157,6 +157,7 @@ int pmx_launch_shift_right(pmx_ctx* ctx, const float* R, int H, int W, int subpi
 int pmx_launch_census(pmx_ctx* ctx, pmx_cv* cv, int win, bool defer_costs);
 int pmx_launch_census_costs(pmx_ctx* ctx, pmx_cv* cv);  // cost kernel from the codes held by cv
 int pmx_cv_materialize(pmx_ctx* ctx, pmx_cv* cv);       // any representation -> float32 volume
+int pmx_cv_ensure_data(pmx_ctx* ctx, pmx_cv* cv);       // allocate the float32 storage on first need
 bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
 int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost);
 int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity);

@@ -36,6 +36,11 @@ def timed(name, stages, fn, reps=3):
 
 
 cv = eng.alloc_cv(D, dmin)
+if os.environ.get("PMX_BENCH_ONLY") == "cbca":
+    eng.census(cv, 5)
+    timed("cbca (d=5, i=30)", ["cbca_arms", "cbca_h", "cbca_v"], lambda: eng.cbca(cv, 2, 30.0, 5), reps=2)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 if os.environ.get("PMX_BENCH_ONLY") == "zncc":
     timed("zncc5", ["zncc"], lambda: eng.zncc(cv, 5), reps=2)
     timed("zncc11", ["zncc"], lambda: eng.zncc(cv, 11), reps=1)
