@@ -10,6 +10,8 @@
 // rows.  H*D and W*D independent scans, disparity innermost -> coalesced.  The prefix values a
 // segment sum needs (at most cbca_distance-1 ahead / behind) live in a per-thread LDS ring.
 // HBM: pass H reads cv, writes E_h; pass V reads E_h + cv (NaN test), writes cv.
+#include <cstdlib>
+
 #include "pmx_internal.h"
 
 static constexpr int kBlock = 256;
@@ -292,6 +294,205 @@ __global__ __launch_bounds__(kBlock) void cbca_v_kernel(cbca_args a) {
     }
 }
 
+// ---- phase-split variants of the two passes ----------------------------------------------------------------------
+// The kernels above spend about a third of their instructions on per-step range tests and clamped 64-bit address
+// arithmetic and are instruction-issue bound (tools/prof_cbca.sh).  When the scanned dimension is long enough the scan is
+// cut into warm-up (prefix only), steady state (prefix + emit, no tests, incrementing pointers, four steps of loads in
+// flight) and drain (emit only); arms are combined with two packed 16-bit minima.  Same arithmetic, same order.
+typedef short cb_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cb_pk_min(uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(cb_s2, x), __builtin_bit_cast(cb_s2, y)));
+}
+struct cb_arms { uint32_t lr, tb; };  // (left | right << 16), (top | bot << 16) as stored: int16 x 4
+__device__ __forceinline__ cb_arms cb_load(const int16_t* base, size_t pixel) {
+    const uint2 v = *reinterpret_cast<const uint2*>(base + pixel * 4);
+    return {v.x, v.y};
+}
+
+__global__ __launch_bounds__(kBlock) void cbca_h_fast_kernel(cbca_args a) {
+    extern __shared__ float ring[];  // [ring][kBlock]
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int total = a.Hc * a.D;
+    const bool live = t < total;
+    const int tt = live ? t : total - 1;
+    const int r = tt / a.D, k = tt - r * a.D;
+    const int kk = k / a.subpix, ph = k - kk * a.subpix, dq = a.d0 + kk;
+    const int mask = a.ring - 1, A = a.A, Wc = a.Wc, D = a.D;
+    const int Wr = ph == 0 ? Wc : Wc - 1;
+    float* my = ring + threadIdx.x;
+    for (int s = 0; s < a.ring; ++s) my[s * kBlock] = 0.f;  // S1 of columns < 0 is 0 (aggregation.cpp:113-114)
+    const size_t row_off = ((size_t)(r + a.o) * a.W + a.o) * D + k;
+    const float* pv = a.cv + row_off;   // cost of column c
+    float* pe = a.eh + row_off;         // segment sum of column ce = c - A
+    const int16_t* aL = a.armsL + (size_t)r * Wc * 4;
+    const int16_t* aR = a.armsR[ph] + (size_t)r * Wr * 4;
+    float acc = 0.f;
+    auto prefix = [&](float v, int c) {
+        acc = (v == v) ? acc + v : acc;  // NaN is skipped, the running sum carries on
+        my[(c & mask) * kBlock] = acc;
+    };
+    auto emit = [&](cb_arms l, cb_arms rr, int ce) {
+        const int q = ce + dq;
+        const bool inside = (q >= 0) & (q <= Wr - 1);
+        const uint32_t lr = cb_pk_min(l.lr, rr.lr);
+        const int left = (int)(lr & 0xffffu), right = (int)(lr >> 16);
+        const float hi_v = my[((ce + right) & mask) * kBlock];
+        const float lo_v = my[((ce - left - 1) & mask) * kBlock];
+        const float e = inside ? hi_v - lo_v : 0.f;
+        if (live) *pe = e;
+        pe += D;
+    };
+    auto right_px = [&](int ce) { return (size_t)min(max(ce + dq, 0), Wr - 1); };
+    int c = 0;
+    for (; c < A; ++c) {  // warm-up: columns whose segment cannot be closed yet
+        prefix(*pv, c);
+        pv += D;
+    }
+    // steady state, four columns per trip, the next four in flight
+    float vb[4];
+    cb_arms lb[4], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        vb[j] = pv[(size_t)min(j, Wc - 1 - c) * D];
+        lb[j] = cb_load(aL, (size_t)(c - A + j));
+        rb[j] = cb_load(aR, right_px(c - A + j));
+    }
+    for (; c + 4 <= Wc; c += 4) {
+        float vn[4];
+        cb_arms ln[4], rn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cn = min(c + 4 + j, Wc - 1);  // (the last trips re-read the last column; its value is not used)
+            vn[j] = pv[(size_t)(cn - c) * D];
+            ln[j] = cb_load(aL, (size_t)min(c + 4 + j - A, Wc - 1));
+            rn[j] = cb_load(aR, right_px(min(c + 4 + j - A, Wc - 1)));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            prefix(vb[j], c + j);
+            emit(lb[j], rb[j], c + j - A);
+        }
+        pv += (size_t)4 * D;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vb[j] = vn[j]; lb[j] = ln[j]; rb[j] = rn[j]; }
+    }
+    for (; c < Wc; ++c) {  // up to three leftover columns
+        prefix(*pv, c);
+        pv += D;
+        emit(cb_load(aL, (size_t)(c - A)), cb_load(aR, right_px(c - A)), c - A);
+    }
+    for (; c < Wc + A; ++c)  // drain
+        emit(cb_load(aL, (size_t)(c - A)), cb_load(aR, right_px(c - A)), c - A);
+}
+
+__global__ __launch_bounds__(kBlock) void cbca_v_fast_kernel(cbca_args a) {
+    extern __shared__ float ring[];  // [2][ring][kBlock]: column prefix sums; packed (N, top, bot)
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int total = a.Wc * a.D;
+    const bool live = t < total;
+    const int tt = live ? t : total - 1;
+    const int c = tt / a.D, k = tt - c * a.D;
+    const int kk = k / a.subpix, ph = k - kk * a.subpix, q = c + a.d0 + kk;
+    const int mask = a.ring - 1, A = a.A, Hc = a.Hc, Wc = a.Wc;
+    const int Wr = ph == 0 ? Wc : Wc - 1;
+    const bool inside = (q >= 0) & (q <= Wr - 1);  // the same right column for every row
+    const int qq = inside ? q : 0;
+    float* s3 = ring + threadIdx.x;
+    uint32_t* info = reinterpret_cast<uint32_t*>(ring) + (size_t)a.ring * kBlock + threadIdx.x;
+    for (int s = 0; s < a.ring; ++s) { s3[s * kBlock] = 0.f; info[s * kBlock] = 0u; }  // row -1: zero sums, zero counts
+    const size_t col_off = ((size_t)a.o * a.W + (c + a.o)) * a.D + k;
+    const size_t row_stride = (size_t)a.W * a.D;
+    const float* pe = a.eh + col_off;   // E_h of row r
+    const float* pin = a.cv + col_off;  // input cost of row re = r - A (only its NaN-ness matters)
+    float* pout = a.cv + col_off;
+    const int16_t* aL = a.armsL + (size_t)c * 4;
+    const int16_t* aR = a.armsR[ph] + (size_t)qq * 4;
+    const size_t strideL = (size_t)Wc, strideR = (size_t)Wr;  // pixels per arms row
+    float acc = 0.f;
+    uint32_t nacc = 0;
+    auto prefix = [&](float e, cb_arms l, cb_arms rr, int r) {
+        acc = (r == 0) ? e : acc + e;
+        s3[(r & mask) * kBlock] = acc;
+        const uint32_t lr = cb_pk_min(l.lr, rr.lr), tb = cb_pk_min(l.tb, rr.tb);
+        // ring word: running count N(r) of n_h = left + right in bits 0..19, top in bits 20..25, bot in bits 26..31
+        // (63, 63 = this cell is outside the right image, n_h = 0)
+        nacc += inside ? (lr & 0xffffu) + (lr >> 16) : 0u;
+        const uint32_t word = inside ? (((tb & 0xffffu) << 20) | ((tb >> 16) << 26)) : ((63u << 20) | (63u << 26));
+        info[(r & mask) * kBlock] = nacc | word;
+    };
+    auto emit = [&](float in, int re) {
+        const uint32_t w = info[(re & mask) * kBlock];
+        const int top = (w >> 20) & 63, bot = w >> 26;
+        const bool cell = top != 63;
+        const int hi_i = cell ? re + bot : re, lo_i = cell ? re - top - 1 : re;
+        const float step = s3[(hi_i & mask) * kBlock] - s3[(lo_i & mask) * kBlock];
+        const uint32_t n = (info[(hi_i & mask) * kBlock] & 0xfffffu) - (info[(lo_i & mask) * kBlock] & 0xfffffu) + (uint32_t)(top + bot);
+        const float step4 = cell ? step : 0.f;
+        const float sum4 = (cell ? (float)n : 0.f) + 1.f;  // small exact integers: any order
+        if (live) *pout = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
+        pout += row_stride;
+    };
+    // every stream advances by one row per step through its own pointer; the loads of the next four rows use the
+    // wave-uniform offsets j * stride (no per-load multiplications), and the steady loop is unrolled over two four-row
+    // buffers so that no register copies are needed between trips
+    const int16_t* pl = aL;
+    const int16_t* pr = aR;
+    const size_t strideL4 = strideL * 4, strideR4 = strideR * 4;  // int16 elements per arms row
+    int r = 0;
+    for (; r < A; ++r) {  // warm-up
+        prefix(*pe, cb_load(pl, 0), cb_load(pr, 0), r);
+        pe += row_stride;
+        pl += strideL4;
+        pr += strideR4;
+    }
+    struct quad { float e[4], in[4]; cb_arms l[4], rr[4]; };
+    auto load_quad = [&](quad& qd, int ahead) {  // rows r+ahead .. r+ahead+3 of the prefix streams, re+ahead.. of the input
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qd.e[j] = pe[(size_t)(ahead + j) * row_stride];
+            qd.in[j] = pin[(size_t)(ahead + j) * row_stride];
+            qd.l[j] = cb_load(pl, (size_t)(ahead + j) * strideL);
+            qd.rr[j] = cb_load(pr, (size_t)(ahead + j) * strideR);
+        }
+    };
+    auto run_quad = [&](const quad& qd) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            prefix(qd.e[j], qd.l[j], qd.rr[j], r + j);
+            emit(qd.in[j], r + j - A);
+        }
+        r += 4;
+        pe += 4 * row_stride;
+        pin += 4 * row_stride;
+        pl += 4 * strideL4;
+        pr += 4 * strideR4;
+    };
+    if (r + 4 <= Hc) {
+        quad qa, qb;
+        load_quad(qa, 0);
+        for (;;) {  // invariant: the buffer about to run holds rows r .. r+3, all inside the image
+            if (r + 8 > Hc) { run_quad(qa); break; }
+            load_quad(qb, 4);
+            run_quad(qa);
+            if (r + 8 > Hc) { run_quad(qb); break; }
+            load_quad(qa, 4);
+            run_quad(qb);
+        }
+    }
+    for (; r < Hc; ++r) {
+        prefix(*pe, cb_load(pl, 0), cb_load(pr, 0), r);
+        pe += row_stride;
+        pl += strideL4;
+        pr += strideR4;
+        emit(*pin, r - A);
+        pin += row_stride;
+    }
+    for (; r < Hc + A; ++r) {
+        emit(*pin, r - A);
+        pin += row_stride;
+    }
+}
+
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance) {
     const int H = cv->H, W = cv->W, o = offset;
     const int Hc = H - 2 * o, Wc = W - 2 * o;
@@ -323,20 +524,31 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     }
     a.H = H; a.W = W; a.D = cv->D; a.d0 = cv->d0; a.subpix = cv->subpix; a.o = o; a.Hc = Hc; a.Wc = Wc;
     a.A = distance - 1 > 1 ? distance - 1 : 1;
-    int ring = 4;
-    while (ring < 2 * a.A + 2) ring <<= 1;
+    int ring = 4;  // 2A+2 live columns + A+1 still-zero slots that stand for the columns before the first (phase-split kernels)
+    while (ring < 3 * a.A + 3) ring <<= 1;
     a.ring = ring;
+    // the phase-split kernels need a scan much longer than the arms (PMX_CBCA_FAST=0: test hook for the generic ones)
+    const char* ef = getenv("PMX_CBCA_FAST");
+    const bool fast_ok = !(ef && ef[0] == '0');
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_H);
         int total = Hc * cv->D;
-        hipLaunchKernelGGL(cbca_h_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), (size_t)ring * kBlock * sizeof(float),
-                           ctx->stream, a);
+        if (fast_ok && Wc >= 2 * a.A + 8)
+            hipLaunchKernelGGL(cbca_h_fast_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), (size_t)ring * kBlock * sizeof(float),
+                               ctx->stream, a);
+        else
+            hipLaunchKernelGGL(cbca_h_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), (size_t)ring * kBlock * sizeof(float),
+                               ctx->stream, a);
     }
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
         int total = Wc * cv->D;
-        hipLaunchKernelGGL(cbca_v_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
-                           (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
+        if (fast_ok && Hc >= 2 * a.A + 8)
+            hipLaunchKernelGGL(cbca_v_fast_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+                               (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
+        else
+            hipLaunchKernelGGL(cbca_v_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+                               (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
     }
     PMX_HIP(hipGetLastError());
     return PMX_OK;

@@ -633,3 +633,35 @@ def test_ambiguity_integral(eng, oracle, H, W, dmin, dmax, sp, negate):
     exp = oracle.ambiguity(-vol if negate else vol, etas, gmin, gmax, disp_range)
     np.testing.assert_array_equal(got, exp)
     assert got[2, 3] == len(etas) * D
+
+
+@pytest.mark.parametrize("fast", ["1", "0"])
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,dist", [(70, 150, -12, 5, 1, 5), (45, 90, -4, 3, 2, 9), (40, 61, 0, 9, 1, 2)])
+def test_cbca_phase_split_and_generic_kernels(eng, oracle, monkeypatch, fast, H, W, dmin, dmax, sp, dist):
+    """CBCA on images large enough for the phase-split kernels (warm-up / steady / drain, four steps in flight) and,
+    with PMX_CBCA_FAST=0, through the generic ones: both bit-exact against the reference-pinned oracle (sequential fp32
+    prefix sums), with masks, sub-pixel volumes, long arms."""
+    monkeypatch.setenv("PMX_CBCA_FAST", fast)
+    L, R = pair(H, W, seed=H + dist, integer=True)
+    rng = np.random.default_rng(dist)
+    mskL = rng.choice([0, 0, 0, 0, 0, 0, 1], (H, W)).astype(np.int16)
+    mskR = rng.choice([0, 0, 0, 0, 0, 0, 2], (H, W)).astype(np.int16)
+    win, off = 5, 2
+    cv = gpu_cv(eng, "census", L, R, dmin, dmax, sp, win, masks=(mskL, mskR, 0, 1))
+    eng.cbca(cv, off, 30.0, dist)
+    got = cv.to_host()
+    exp = cpu_cv(oracle, "census", L, R, dmin, dmax, sp, win, masks=(mskL, mskR, 0, 1))
+
+    def arms(im, msk, shifted):
+        m = im.copy()
+        bad = msk != 0
+        if shifted:
+            bad = bad[:, :-1] | bad[:, 1:]
+        m[bad] = np.nan
+        m = np.nan_to_num(oracle.median3(m), nan=np.inf)[off:-off, off:-off]
+        return oracle.cross_support(np.ascontiguousarray(m), dist, 30.0)
+
+    cl = arms(L, mskL, False)
+    crs = [arms(im, mskR, k > 0) for k, im in enumerate(oracle.shift_right(R, sp))]
+    oracle.cbca(exp, dmin, sp, off, cl, crs)
+    np.testing.assert_array_equal(got, exp)
