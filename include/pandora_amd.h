@@ -165,8 +165,14 @@ int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validi
  * elements (results within 1e-6 relative of the reference's float64 numpy arithmetic). */
 int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, double sigma_color,
                                    double sigma_space);
-/* ---- multiscale -----------------------------------------------------------------------------
- * Replaces the window search of multiscale.FixedZoomPyramid.disparity_range
+/* ---- multiscale ---------------------------------------------------------------------------- */
+/* Replaces img_tools_cpp.interpolate_nodata_sgm (src/pandora/cpp/src/img_tools.cpp:99-155, called by
+ * img_tools.fill_nodata_image, src/pandora/img_tools.py:578-613, before the pyramid is built): every pixel whose mask
+ * has a bit of invalid_bits becomes the median of the first valid pixels along the 8 directions (NaN if none) and takes
+ * the mask value filled_value; the others are copied.  Host maps in/out (int32 masks), computed on the device. */
+int pmx_interpolate_nodata(pmx_ctx* ctx, const float* img, const int32_t* msk, int H, int W, int invalid_bits, int filled_value,
+                           float* out_img, int32_t* out_msk);
+/* Replaces the window search of multiscale.FixedZoomPyramid.disparity_range
  * (src/pandora/multiscale/fixed_zoom_pyramid.py:106-172) before its zoom: per valid pixel whose window fits, the
  * nanmin - marge / nanmax + marge of the valid disparities of the window; every other pixel gets
  * [global_min, global_max].  Host maps in/out, computed on the device. */

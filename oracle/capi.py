@@ -228,3 +228,13 @@ def ambiguity(cv, etas, grid_min, grid_max, disp_range):
     out = np.empty((H, W), np.float32)
     lib().orc_ambiguity(_p(cv), H, W, D, _p(e), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64), _p(dr), _p(out))
     return out
+
+
+def interpolate_nodata(img, msk, invalid_bits, filled_value):
+    """img_tools.cpp:99-155 -> (filled image float32, mask int32)."""
+    im = _f32(img)
+    mk = np.ascontiguousarray(msk, np.int32)
+    out_i, out_m = np.empty_like(im), np.empty_like(mk)
+    lib().orc_interpolate_nodata(_p(im), _p(mk, C.c_int32), im.shape[0], im.shape[1], int(invalid_bits), int(filled_value),
+                                 _p(out_i), _p(out_m, C.c_int32))
+    return out_i, out_m

@@ -876,3 +876,41 @@ void orc_ambiguity(const float* cv, int H, int W, int D, const float* etas, int 
     free(nc);
     free(minimg);
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * cpp/src/img_tools.cpp:27-155 interpolate_nodata_sgm (+ find_valid_neighbors, compute_median): every pixel whose mask
+ * has a bit of `invalid_bits` becomes the median of the first valid pixels met along the 8 directions (paths that leave
+ * the image contribute nothing; no valid neighbour at all -> NaN) and gets the mask value `filled_value`.
+ * ------------------------------------------------------------------------------------------- */
+void orc_interpolate_nodata(const float* img, const int32_t* msk, int H, int W, int invalid_bits, int filled_value,
+                            float* out_img, int32_t* out_msk) {
+    static const int dcol[8] = {0, -1, -1, -1, 0, 1, 1, 1}, drow[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            size_t i = (size_t)r * W + c;
+            if (!(msk[i] & invalid_bits)) { out_img[i] = img[i]; out_msk[i] = msk[i]; continue; }
+            float v[8];
+            int n = 0;
+            for (int d = 0; d < 8; ++d) {
+                int rr = r + drow[d], cc = c + dcol[d];
+                while (rr >= 0 && rr < H && cc >= 0 && cc < W) {
+                    if (!(msk[(size_t)rr * W + cc] & invalid_bits)) {
+                        float x = img[(size_t)rr * W + cc];
+                        if (!isnan(x)) v[n++] = x;
+                        break;
+                    }
+                    rr += drow[d];
+                    cc += dcol[d];
+                }
+            }
+            for (int a = 1; a < n; ++a) {
+                float x = v[a];
+                int b = a - 1;
+                while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
+                v[b + 1] = x;
+            }
+            out_img[i] = n == 0 ? NAN : ((n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.f);
+            out_msk[i] = filled_value;
+        }
+}

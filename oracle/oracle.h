@@ -104,6 +104,10 @@ void orc_disparity_range(const float* disp, const int64_t* validity, int H, int 
 void orc_ambiguity(const float* cv, int H, int W, int D, const float* etas, int nbr_etas, const int64_t* grid_min,
                    const int64_t* grid_max, const float* disp_range, float* amb);
 
+/* cpp/src/img_tools.cpp:27-155 (interpolate_nodata_sgm) */
+void orc_interpolate_nodata(const float* img, const int32_t* msk, int H, int W, int invalid_bits, int filled_value,
+                            float* out_img, int32_t* out_msk);
+
 #ifdef __cplusplus
 }
 #endif

@@ -778,6 +778,28 @@ extern "C" int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const i
 
 
 // ---- multiscale -------------------------------------------------------------------------------------
+extern "C" int pmx_interpolate_nodata(pmx_ctx* ctx, const float* img, const int32_t* msk, int H, int W, int invalid_bits,
+                                      int filled_value, float* out_img, int32_t* out_msk) {
+    PMX_CHECK(ctx && img && msk && out_img && out_msk, PMX_ERR_ARG, "pmx_interpolate_nodata: null argument");
+    PMX_CHECK(H > 0 && W > 0, PMX_ERR_ARG, "pmx_interpolate_nodata: bad shape %dx%d", H, W);
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W;
+    int rc = pmx_need_small(ctx, n * 16);
+    if (rc) return rc;
+    float* d_img = (float*)ctx->small;
+    int* d_msk = (int*)(d_img + n);
+    float* d_oimg = (float*)(d_msk + n);
+    int* d_omsk = (int*)(d_oimg + n);
+    PMX_HIP(hipMemcpyAsync(d_img, img, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_msk, msk, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_interpolate_nodata(ctx, d_img, d_msk, H, W, invalid_bits, filled_value, d_oimg, d_omsk);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(out_img, d_oimg, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(out_msk, d_omsk, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
 extern "C" int pmx_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity, int H, int W, int window_size, int marge,
                                    int global_min, int global_max, float* range_min, float* range_max) {
     PMX_CHECK(ctx && disp && validity && range_min && range_max, PMX_ERR_ARG, "pmx_disparity_range: null argument");

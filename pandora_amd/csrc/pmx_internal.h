@@ -176,6 +176,8 @@ int pmx_launch_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* v
                                int gmax, float* out_min, float* out_max);
 int pmx_launch_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* d_etas, int nbr_etas, const int64_t* d_gmin, const int64_t* d_gmax,
                          int negate, uint32_t* d_mm, float* d_amb);
+int pmx_launch_interpolate_nodata(pmx_ctx* ctx, const float* img, const int* msk, int H, int W, int invalid_bits, int filled,
+                                  float* out_img, int* out_msk);
 int pmx_launch_median_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int size, float* out);
 int pmx_launch_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared);
 int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);

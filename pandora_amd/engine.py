@@ -239,6 +239,18 @@ class Engine:
         return d
 
     # -- multiscale ----------------------------------------------------------------
+    def interpolate_nodata(self, img, msk, invalid_bits, filled_value):
+        """img_tools.cpp:99-155 (interpolate_nodata_sgm) on the device -> (filled float32 image, int32 mask)."""
+        im = np.ascontiguousarray(img, np.float32)
+        mk = np.ascontiguousarray(msk, np.int32)
+        if im.ndim != 2 or im.shape != mk.shape:
+            raise ValueError("interpolate_nodata: image and mask must be 2-D and of the same shape")
+        out_i, out_m = np.empty_like(im), np.empty_like(mk)
+        check(_lib.lib().pmx_interpolate_nodata(self.ctx, _p(im, C.c_float), _p(mk, C.c_int32), im.shape[0], im.shape[1],
+                                                int(invalid_bits), int(filled_value), _p(out_i, C.c_float), _p(out_m, C.c_int32)),
+              "pmx_interpolate_nodata")
+        return out_i, out_m
+
     def disparity_range(self, disp, validity, window_size, marge, global_min, global_max):
         """fixed_zoom_pyramid.py:106-172 (before the zoom) on the device -> (range_min, range_max) float32."""
         d = np.ascontiguousarray(disp, np.float32)

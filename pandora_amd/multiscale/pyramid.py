@@ -60,16 +60,28 @@ def _convert(img_orig, images, masks, disps):
     return pyramid
 
 
+def fill_nodata_image(ds):
+    """img_tools.py:578-613 (mono-band): masked images get their no-data / invalid pixels interpolated on the device
+    (pmx_interpolate_nodata replaces img_tools_cpp.interpolate_nodata_sgm) so that the Gaussian reduction does not smear
+    them; images without a mask get an all-valid one."""
+    if "msk" in ds.data_vars:
+        from .. import runtime
+        from ..constants import PANDORA_MSK_PIXEL_FILLED_NODATA, PANDORA_MSK_PIXEL_INVALID
+
+        if np.asarray(ds["im"].data).ndim != 2:
+            raise NotImplementedError("multiscale on multiband images is outside pandora_amd's scope")
+        return runtime.get_engine().interpolate_nodata(ds["im"].data, ds["msk"].data, PANDORA_MSK_PIXEL_INVALID,
+                                                       PANDORA_MSK_PIXEL_FILLED_NODATA)
+    return ds["im"].data, np.full((ds.sizes["row"], ds.sizes["col"]), int(ds.attrs.get("valid_pixels", 0)))
+
+
 def prepare_pyramid(img_left, img_right, num_scales, scale_factor):
-    """img_tools.py:499-572, for images without a mask (the no-data interpolation of masked images,
-    img_tools_cpp.interpolate_nodata_sgm, is outside this build).  Returns the two pyramids, coarsest first."""
-    for ds in (img_left, img_right):
-        if "msk" in ds.data_vars:
-            raise NotImplementedError("multiscale with image masks (interpolate_nodata_sgm) is outside pandora_amd's scope")
+    """img_tools.py:499-572.  Returns the two pyramids, coarsest first; the full-resolution level is the original
+    dataset (image and mask untouched), the coarser ones come from the filled image and the decimated filled mask."""
     out = []
     for ds in (img_left, img_right):
-        msk = np.full((ds.sizes["row"], ds.sizes["col"]), int(ds.attrs.get("valid_pixels", 0)))
-        images = get_pyramids(ds["im"].data, num_scales, scale_factor)
+        img, msk = fill_nodata_image(ds)
+        images = get_pyramids(img, num_scales, scale_factor)
         disps = None
         if "disparity" in ds.data_vars:
             d = np.asarray(ds["disparity"].data)

@@ -576,6 +576,32 @@ def test_disparity_range_reference_vector_and_random(eng, oracle):
         np.testing.assert_array_equal(got[1], exp[1])
 
 
+def test_interpolate_nodata_equals_oracle(eng, oracle):
+    """pmx_interpolate_nodata == img_tools.cpp:99-155 restated (pinned against the compiled reference in
+    test_oracle_vs_reference.py): sparse and dense masks, ragged widths, all-invalid and all-valid images, NaN values among
+    the neighbours, paths that leave the image."""
+    rng = np.random.default_rng(8)
+    for H, W, p in ((9, 13, 0.3), (33, 300, 0.05), (64, 257, 0.7), (5, 5, 1.0), (7, 9, 0.0), (1, 40, 0.5), (40, 1, 0.5)):
+        img = (rng.random((H, W)) * 255).astype(np.float32)
+        msk = np.where(rng.random((H, W)) < p, rng.choice([1, 2, 64, 3], (H, W)), rng.choice([0, 4, 1024], (H, W))).astype(np.int32)
+        if H > 3 and W > 3:
+            img[1, 2] = np.nan
+            msk[1, 2] = 0
+        got = eng.interpolate_nodata(img, msk, 0b01111000011, 1 << 10)
+        exp = oracle.interpolate_nodata(img, msk, 0b01111000011, 1 << 10)
+        np.testing.assert_array_equal(got[0], exp[0])
+        np.testing.assert_array_equal(got[1], exp[1])
+    blob = np.zeros((50, 70), np.int32)
+    blob[10:40, 20:60] = 1                       # a large hole: long walks, even/odd neighbour counts
+    blob[:, 0] = 2
+    img = (rng.random((50, 70)) * 255).astype(np.float32)
+    got, exp = eng.interpolate_nodata(img, blob, 0b01111000011, 1 << 10), oracle.interpolate_nodata(img, blob, 0b01111000011, 1 << 10)
+    np.testing.assert_array_equal(got[0], exp[0])
+    np.testing.assert_array_equal(got[1], exp[1])
+    with pytest.raises(ValueError):
+        eng.interpolate_nodata(img, blob[:, :5], 1, 2)
+
+
 def test_row_tiled_local_pipeline_equals_full_image(eng):
     """Row tiles with a margin of the window radius reproduce the untiled census -> WTA -> vfit result exactly (no
     data-path collective; pandora_amd.dist.row_tile / crop_tile / stitch_tiles)."""

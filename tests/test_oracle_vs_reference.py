@@ -164,3 +164,23 @@ def test_ambiguity_matches_reference(oracle, H, W, D, d0, sp):
     got = oracle.ambiguity(cv, etas, gmin, gmax, disp_range)
     np.testing.assert_array_equal(got, exp)
     assert got[1, 2] == len(etas) * D
+
+
+it = ref.load("img_tools_cpp")
+
+
+@pytest.mark.skipif(it is None, reason="oracle/_ref not built")
+def test_interpolate_nodata_matches_reference(oracle):
+    """img_tools.cpp:99-155: median of the first valid pixel along 8 directions, isolated invalid regions, an image
+    without any valid pixel on some paths, NaN values among the neighbours."""
+    rng = np.random.default_rng(3)
+    for H, W in ((9, 13), (20, 31)):
+        img = (rng.random((H, W)) * 200).astype(np.float32)
+        msk = rng.choice([0, 0, 0, 1, 2], (H, W)).astype(np.int32)
+        msk[:, 0] = 1
+        msk[3:7, 4:9] = 2
+        img[1, 1] = np.nan
+        exp_i, exp_m = it.interpolate_nodata_sgm(img, msk, 0b01111000011, 1 << 10)
+        got_i, got_m = oracle.interpolate_nodata(img, msk, 0b01111000011, 1 << 10)
+        np.testing.assert_array_equal(got_i, exp_i)
+        np.testing.assert_array_equal(got_m, exp_m)

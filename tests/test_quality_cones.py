@@ -163,3 +163,47 @@ def test_multiscale_runs_meet_the_reference_gates(name, cfg, scales):
     assert error(np.nan_to_num(dl["disparity_map"].data, nan=1e4), gt_left, 1) <= 0.20
     if "validation" in cfg["pipeline"]:
         assert error(-1 * np.nan_to_num(dr["disparity_map"].data, nan=1e4), gt_right, 1) <= 0.20
+
+
+@pytest.mark.gpu
+def test_multiscale_with_image_masks(oracle):
+    """img_tools.py:508-613: masked images go through the pyramid with their invalid / no-data pixels interpolated
+    (device kernel == the oracle's interpolate_nodata_sgm), the coarse masks are the decimated filled masks, the full
+    resolution keeps the original image and mask; the coarse-to-fine run still meets the reference's 20 % gate on the
+    pixels that are not masked and flags the masked ones."""
+    import json
+
+    import pandora_amd
+    from pandora_amd import multiscale
+    from pandora_amd.constants import (PANDORA_MSK_PIXEL_FILLED_NODATA, PANDORA_MSK_PIXEL_IN_VALIDITY_MASK_LEFT,
+                                       PANDORA_MSK_PIXEL_INVALID, PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER)
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, gt_left = load_cones()
+    rng = np.random.default_rng(5)
+    ml, mr = np.zeros(L.shape, np.int16), np.zeros(R.shape, np.int16)
+    ml[100:140, 200:260] = 2                     # an invalid block (neither valid_pixels 0 nor no_data 1)
+    ml[rng.random(L.shape) < 0.01] = 1           # scattered no-data
+    mr[:, :7] = 1
+    Lm, Rm = L.copy(), R.copy()
+    Lm[ml != 0] = -7777.0                        # whatever sits under the mask must not leak into the coarse scales
+    Rm[mr != 0] = -7777.0
+    left, right = make_image(Lm, disparity=[-60, 0], msk=ml), make_image(Rm, disparity=[0, 60], msk=mr)
+    pl, pr = multiscale.prepare_pyramid(left, right, 2, 2)
+    assert pl[-1] is left and pr[-1] is right
+    for ds, img, msk in ((pl[0], Lm, ml), (pr[0], Rm, mr)):
+        fi, fm = oracle.interpolate_nodata(img, msk.astype(np.int32), PANDORA_MSK_PIXEL_INVALID, PANDORA_MSK_PIXEL_FILLED_NODATA)
+        np.testing.assert_array_equal(ds["im"].data, multiscale.get_pyramids(fi, 2, 2)[1])
+        np.testing.assert_array_equal(ds["msk"].data, fm[::2, ::2].astype(np.int16))
+        assert ds["im"].data.min() > -1.0 and ds["msk"].data.dtype == np.int16
+    cfg = json.loads(json.dumps(MULTISCALE_REF))
+    machine = PandoraMachine()
+    cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+    dl, _ = pandora_amd.run(machine, left, right, cfg)
+    vm = dl["validity_mask"].data
+    assert np.all(vm[ml == 2] & PANDORA_MSK_PIXEL_IN_VALIDITY_MASK_LEFT) and np.all(vm[ml == 1] & PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER)
+    ok = (vm & PANDORA_MSK_PIXEL_INVALID) == 0
+    d = np.nan_to_num(dl["disparity_map"].data, nan=1e4)
+    bad = (np.abs(d + gt_left) > 1) & ok & (gt_left != 0)
+    assert bad.sum() / ok.sum() <= 0.20
