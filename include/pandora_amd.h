@@ -150,6 +150,13 @@ int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size
  * "disparity_interval" (disparity.py:334-347).  mask_border (:368-369) stays with the caller. */
 int pmx_cross_checking(pmx_ctx* ctx, const float* disp_left, int64_t* validity_left, const float* disp_right, int H, int W,
                        int dmin, int dmax, double threshold, float* conf_out);
+/* Replaces validation_cpp.interpolate_occlusion_mc_cnn / interpolate_mismatch_mc_cnn / interpolate_occlusion_sgm /
+ * interpolate_mismatch_sgm (src/pandora/validation/cpp/src/interpolated_disparity.cpp:232-296, :298-393, :101-139, :166-230),
+ * the passes of AbstractInterpolation.interpolated_disparity (src/pandora/validation/interpolated_disparity.py:200-233 "mc-cnn":
+ * occlusions then mismatches; :318-330 "sgm": mismatches then occlusions).  The n_passes passes run in the given order, each one
+ * gathering from the maps the previous one produced; disp / validity: host maps, updated in place. */
+enum { PMX_INTERP_OCCLUSION_MC_CNN = 0, PMX_INTERP_MISMATCH_MC_CNN = 1, PMX_INTERP_OCCLUSION_SGM = 2, PMX_INTERP_MISMATCH_SGM = 3 };
+int pmx_interpolate_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, int H, int W, const int* passes, int n_passes);
 /* Replaces matching_cost_cpp.reverse_disp_range (matching_cost/cpp/src/matching_cost.cpp:59-132): per-pixel right
  * disparity ranges from the left ones; [global_min, global_max] must bracket every (int)left_min / (int)left_max. */
 int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const float* left_max, int H, int W, int global_min,

@@ -238,3 +238,16 @@ def interpolate_nodata(img, msk, invalid_bits, filled_value):
     lib().orc_interpolate_nodata(_p(im), _p(mk, C.c_int32), im.shape[0], im.shape[1], int(invalid_bits), int(filled_value),
                                  _p(out_i), _p(out_m, C.c_int32))
     return out_i, out_m
+
+
+INTERP_PASSES = {"occlusion_mc_cnn": 0, "mismatch_mc_cnn": 1, "occlusion_sgm": 2, "mismatch_sgm": 3}
+
+
+def interpolate_disparity(which, disp, valid):
+    """interpolated_disparity.cpp, one pass -> (disparity float32, validity int32)."""
+    d = _f32(disp)
+    v = np.ascontiguousarray(valid, np.int32)
+    out_d, out_v = np.empty_like(d), np.empty_like(v)
+    lib().orc_interpolate_disparity(INTERP_PASSES[which], _p(d), _p(v, C.c_int32), d.shape[0], d.shape[1], _p(out_d),
+                                    _p(out_v, C.c_int32))
+    return out_d, out_v

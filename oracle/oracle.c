@@ -914,3 +914,104 @@ void orc_interpolate_nodata(const float* img, const int32_t* msk, int H, int W, 
             out_msk[i] = filled_value;
         }
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * validation/cpp/src/interpolated_disparity.cpp: the four gather passes of AbstractInterpolation ("mc-cnn" / "sgm").
+ * All read the input maps only (outputs are separate), so every pixel is independent.
+ * pass 0 = interpolate_occlusion_mc_cnn (:232-296), 1 = interpolate_mismatch_mc_cnn (:298-393),
+ *      2 = interpolate_occlusion_sgm (:101-139),    3 = interpolate_mismatch_sgm (:166-230).
+ * Mask constants: constants.py (INVALID 0x3C3, OCCLUSION 1<<8, MISMATCH 1<<9, FILLED_OCCLUSION 1<<4, FILLED_MISMATCH 1<<5).
+ * ------------------------------------------------------------------------------------------- */
+#define ORC_INVALID 0x3C3
+#define ORC_OCC (1 << 8)
+#define ORC_MIS (1 << 9)
+#define ORC_FILLED_OCC (1 << 4)
+#define ORC_FILLED_MIS (1 << 5)
+
+static float orc_median_nan_free(float* v, int count) { /* compute_median :141-163 */
+    int n = 0;
+    for (int a = 0; a < count; ++a)
+        if (!isnan(v[a])) v[n++] = v[a];
+    if (n == 0) return NAN;
+    for (int a = 1; a < n; ++a) {
+        float x = v[a];
+        int b = a - 1;
+        while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
+        v[b + 1] = x;
+    }
+    return (n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.f;
+}
+
+/* find_valid_neighbors :28-75: (drow, dcol) in this order; leaving the image gives NaN */
+static void orc_valid_neighbors8(const float* disp, const int32_t* valid, int H, int W, int r, int c, float* out) {
+    static const int drow[8] = {0, -1, -1, -1, 0, 1, 1, 1}, dcol[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    for (int d = 0; d < 8; ++d) {
+        int rr = r + drow[d], cc = c + dcol[d];
+        out[d] = NAN;
+        while (rr >= 0 && rr < H && cc >= 0 && cc < W) {
+            if (!(valid[(size_t)rr * W + cc] & ORC_INVALID)) { out[d] = disp[(size_t)rr * W + cc]; break; }
+            rr += drow[d];
+            cc += dcol[d];
+        }
+    }
+}
+
+void orc_interpolate_disparity(int pass, const float* disp, const int32_t* valid, int H, int W, float* out_disp, int32_t* out_valid) {
+    /* :318-335, (dcol, drow) pairs: the first factor is applied to the column (:347-348) */
+    static const float d16[32] = {0.0f, 1.0f, -0.5f, 1.0f, -1.0f, 1.0f, -1.0f, 0.5f, -1.0f, 0.0f, -1.0f, -0.5f, -1.0f, -1.0f, -0.5f, -1.0f,
+                                  0.0f, -1.0f, 0.5f, -1.0f, 1.0f, -1.0f, 1.0f, -0.5f, 1.0f, 0.0f, 1.0f, 0.5f, 1.0f, 1.0f, 0.5f, 1.0f};
+    const int maxlen = H > W ? H : W;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const size_t i = (size_t)r * W + c;
+            const int32_t m = valid[i];
+            out_disp[i] = disp[i];
+            out_valid[i] = m;
+            if (pass == 0 && (m & ORC_OCC)) {
+                int found = -1;
+                for (int k = c; k >= 0 && found < 0; --k)
+                    if (!(valid[(size_t)r * W + k] & ORC_INVALID)) found = k;
+                for (int k = c; k < W && found < 0; ++k)
+                    if (!(valid[(size_t)r * W + k] & ORC_INVALID)) found = k;
+                if (found >= 0) { /* nothing valid on the row: the pixel keeps its value and its flag (:276-287 with msk == col) */
+                    out_disp[i] = disp[(size_t)r * W + found];
+                    out_valid[i] = m - ORC_OCC + ORC_FILLED_OCC;
+                }
+            } else if (pass == 1 && (m & ORC_MIS)) {
+                float v[16];
+                for (int d = 0; d < 16; ++d) {
+                    v[d] = 0.f;
+                    for (int k = 0; k < maxlen; ++k) {
+                        const int cc = c + (int)(d16[2 * d] * (float)k), rr = r + (int)(d16[2 * d + 1] * (float)k);
+                        if (rr < 0 || rr >= H || cc < 0 || cc >= W) { v[d] = NAN; break; }
+                        if (!(valid[(size_t)rr * W + cc] & ORC_INVALID)) { v[d] = disp[(size_t)rr * W + cc]; break; }
+                    }
+                }
+                out_disp[i] = orc_median_nan_free(v, 16);
+                out_valid[i] = m + ORC_FILLED_MIS - ORC_MIS;
+            } else if (pass == 2 && (m & ORC_OCC)) {
+                float v[8];
+                orc_valid_neighbors8(disp, valid, H, W, r, c, v);
+                /* get_second_min_val_abs :77-99: the value of second smallest magnitude (strict <, first come first), +inf if < 2 */
+                float mn = INFINITY, mna = INFINITY, sm = INFINITY, sma = INFINITY;
+                for (int d = 0; d < 8; ++d) {
+                    const float a = fabsf(v[d]);
+                    if (a < mna) { sma = mna; sm = mn; mna = a; mn = v[d]; }
+                    else if (a < sma) { sma = a; sm = v[d]; }
+                }
+                out_disp[i] = sm;
+                out_valid[i] = m + ORC_FILLED_OCC - ORC_OCC;
+            } else if (pass == 3 && (m & ORC_MIS)) {
+                int near_occ = 0; /* a mismatch that touches an occlusion becomes an occlusion (:189-209) */
+                for (int rr = (r > 0 ? r - 1 : 0); rr <= (r + 1 < H ? r + 1 : H - 1); ++rr)
+                    for (int cc = (c > 0 ? c - 1 : 0); cc <= (c + 1 < W ? c + 1 : W - 1); ++cc)
+                        near_occ |= (valid[(size_t)rr * W + cc] & ORC_OCC) != 0;
+                if (near_occ) { out_valid[i] = m - ORC_MIS + ORC_OCC; continue; }
+                float v[8];
+                orc_valid_neighbors8(disp, valid, H, W, r, c, v);
+                out_disp[i] = orc_median_nan_free(v, 8);
+                out_valid[i] = m + ORC_FILLED_MIS - ORC_MIS;
+            }
+        }
+}

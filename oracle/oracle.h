@@ -108,6 +108,9 @@ void orc_ambiguity(const float* cv, int H, int W, int D, const float* etas, int 
 void orc_interpolate_nodata(const float* img, const int32_t* msk, int H, int W, int invalid_bits, int filled_value,
                             float* out_img, int32_t* out_msk);
 
+/* validation/cpp/src/interpolated_disparity.cpp: pass 0/1 = occlusion/mismatch mc-cnn, 2/3 = occlusion/mismatch sgm */
+void orc_interpolate_disparity(int pass, const float* disp, const int32_t* valid, int H, int W, float* out_disp, int32_t* out_valid);
+
 #ifdef __cplusplus
 }
 #endif

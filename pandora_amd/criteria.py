@@ -33,7 +33,7 @@ def validity_mask(img_left, img_right, cv):
     """criteria.py:66-158: allocate cv["validity_mask"] (int64, row x col) from the disparity range,
     the image borders and the input masks."""
     H, W = cv.sizes["row"], cv.sizes["col"]
-    vm = np.full((H, W), 0, dtype=np.int64)
+    line = np.zeros(W, dtype=np.int64)  # the range tests depend on the column only: build one line, then replicate it
     disp = np.asarray(cv.coords["disp"])
     d_min, d_max = disp[0], disp[-1]
     col = np.asarray(cv.coords["col"])
@@ -41,16 +41,16 @@ def validity_mask(img_left, img_right, cv):
     if d_max < 0:  # criteria.py:114-120
         bit_1 = np.where((col + d_max) < (col[0] + offset))
         sel = np.where(((col + d_max) >= (col[0] + offset)) & ((col + d_min) < (col[0] + offset)))
-        vm[:, sel[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_INCOMPLETE_DISPARITY_RANGE
     elif d_min > 0:  # criteria.py:123-129
         bit_1 = np.where((col + d_min) > (col[-1] - offset))
         sel = np.where(((col + d_min) <= (col[-1] - offset)) & ((col + d_max) > (col[-1] - offset)))
-        vm[:, sel[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_INCOMPLETE_DISPARITY_RANGE
     else:  # criteria.py:132-138
         bit_1 = (np.array([], dtype=np.int64),)
         sel = np.where(((col + d_min) < (col[0] + offset)) | (col + d_max > (col[-1]) - offset))
-        vm[:, sel[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_INCOMPLETE_DISPARITY_RANGE
-    vm[:, bit_1[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING
+    line[sel[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_INCOMPLETE_DISPARITY_RANGE
+    line[bit_1[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING
+    vm = np.empty((H, W), np.int64)
+    vm[:] = line
     cv["validity_mask"] = DataArray(vm, ("row", "col"))
     if "msk" in img_left.data_vars:
         allocate_left_mask(cv, img_left)
@@ -139,8 +139,9 @@ def mask_invalid_variable_disparity_range(cv, missing_disparity_range=None):
         else:
             missing_disparity_range = np.min(np.isnan(arr.data), axis=2)
     vm = cv["validity_mask"].data
-    sel = missing_disparity_range & ((vm & cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING) == 0)
-    vm[sel] += cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING
+    # "+= where the bit is not set yet" (criteria.py:317-322) is an OR
+    np.bitwise_or(vm, cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING, out=vm,
+                  where=np.asarray(missing_disparity_range, bool))
 
 
 def mask_border(dataset):

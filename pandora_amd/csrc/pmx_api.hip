@@ -697,6 +697,31 @@ extern "C" int pmx_cross_checking(pmx_ctx* ctx, const float* disp_left, int64_t*
     return PMX_OK;
 }
 
+extern "C" int pmx_interpolate_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, int H, int W, const int* passes, int n_passes) {
+    PMX_CHECK(ctx && disp && validity && passes, PMX_ERR_ARG, "pmx_interpolate_disparity: null argument");
+    PMX_CHECK(H > 0 && W > 0 && n_passes > 0, PMX_ERR_ARG, "pmx_interpolate_disparity: bad shape %dx%d or pass count %d", H, W, n_passes);
+    for (int k = 0; k < n_passes; ++k)
+        PMX_CHECK(passes[k] >= PMX_INTERP_OCCLUSION_MC_CNN && passes[k] <= PMX_INTERP_MISMATCH_SGM, PMX_ERR_ARG,
+                  "pmx_interpolate_disparity: unknown pass %d", passes[k]);
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W;
+    int rc = pmx_need_small(ctx, n * 24);
+    if (rc) return rc;
+    int64_t* d_val[2] = {(int64_t*)ctx->small, (int64_t*)ctx->small + n};
+    float* d_disp[2] = {(float*)(d_val[1] + n), (float*)(d_val[1] + n) + n};
+    PMX_HIP(hipMemcpyAsync(d_val[0], validity, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_disp[0], disp, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int cur = 0;
+    for (int k = 0; k < n_passes; ++k, cur ^= 1) {  // every pass reads the previous pass' maps only
+        rc = pmx_launch_interpolate_disparity(ctx, passes[k], d_disp[cur], d_val[cur], H, W, d_disp[cur ^ 1], d_val[cur ^ 1]);
+        if (rc) return rc;
+    }
+    PMX_HIP(hipMemcpyAsync(validity, d_val[cur], n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(disp, d_disp[cur], n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
 extern "C" int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const float* left_max, int H, int W, int global_min,
                                       int global_max, float* right_min, float* right_max) {
     PMX_CHECK(ctx && left_min && left_max && right_min && right_max, PMX_ERR_ARG, "pmx_reverse_disp_range: null argument");

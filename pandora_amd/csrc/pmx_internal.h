@@ -168,6 +168,8 @@ int pmx_launch_sum8_to_float(pmx_ctx* ctx, pmx_cv* cv);
 int pmx_launch_census_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
 int pmx_launch_cross_checking(pmx_ctx* ctx, const float* dl, int64_t* validity, const float* dr, int H, int W, int dmin, int dmax,
                               double threshold, float* conf);
+int pmx_launch_interpolate_disparity(pmx_ctx* ctx, int pass, const float* disp, const int64_t* valid, int H, int W, float* out_disp,
+                                     int64_t* out_valid);
 int pmx_launch_reverse_disp_range(pmx_ctx* ctx, const float* lmin, const float* lmax, int H, int W, int gmin, int gmax, float* rmin,
                                   float* rmax);
 int pmx_launch_bilateral_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int win, const double* gs,

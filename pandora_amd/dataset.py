@@ -37,7 +37,7 @@ class DataArray:
         axis = self.dims.index(dim)
         labels = list(self.coords[dim])
         idx = labels.index(label)
-        data = np.take(self.data, idx, axis=axis)
+        data = self.data[(slice(None),) * axis + (idx,)]  # a view, like xarray's .sel
         dims = tuple(d for d in self.dims if d != dim)
         return DataArray(data, dims, {k: v for k, v in self.coords.items() if k != dim})
 
@@ -122,7 +122,8 @@ def make_image(data, disparity=None, msk=None, valid_pixels=0, no_data_mask=1, d
     if disparity is not None:
         dmin, dmax = disparity
         ds.attrs["disparity_source"] = [dmin, dmax]  # img_tools.py:406-437: the [min, max] list or the grid's file name
-        grids = np.stack([np.full((H, W), dmin), np.full((H, W), dmax)]).astype(np.int64)
+        grids = np.empty((2, H, W), np.int64)
+        grids[0], grids[1] = dmin, dmax
         ds.coords["band_disp"] = np.array(["min", "max"])
         ds["disparity"] = DataArray(grids, ("band_disp", "row", "col"), {"band_disp": ["min", "max"]})
     if disparity_grids is not None:

@@ -217,6 +217,20 @@ class Engine:
                                                 _p(rmin, C.c_float), _p(rmax, C.c_float)), "pmx_reverse_disp_range")
         return rmin, rmax
 
+    INTERPOLATION_PASSES = {"occlusion_mc_cnn": 0, "mismatch_mc_cnn": 1, "occlusion_sgm": 2, "mismatch_sgm": 3}
+
+    def interpolate_disparity(self, disp, validity, passes):
+        """interpolated_disparity.cpp on the device; ``passes``: names of INTERPOLATION_PASSES, run in order.
+        Returns (disparity float32, validity int64), inputs untouched."""
+        d = np.array(disp, np.float32, order="C", copy=True)
+        v = np.array(validity, np.int64, order="C", copy=True)
+        if d.ndim != 2 or d.shape != v.shape:
+            raise ValueError("interpolate_disparity: disparity map and validity mask must be 2-D and of the same shape")
+        codes = (C.c_int * len(passes))(*[self.INTERPOLATION_PASSES[p] for p in passes])
+        check(_lib.lib().pmx_interpolate_disparity(self.ctx, _p(d, C.c_float), _p(v, C.c_int64), d.shape[0], d.shape[1], codes,
+                                                   len(passes)), "pmx_interpolate_disparity")
+        return d, v
+
     # -- disparity filters (SURVEY 8f N2) -------------------------------------------------------
     def median_filter_disparity(self, disp, validity, filter_size):
         """median.py:94-179 on the device; returns the filtered float32 map (input untouched)."""

@@ -123,9 +123,6 @@ class PandoraMachine:
             self.right_cv = None
             self.right_disp_map = None
             if "validation" in cfg["pipeline"]:
-                if "interpolated_disparity" in cfg["pipeline"]["validation"]:
-                    raise MachineError("'interpolated_disparity' (validation.AbstractInterpolation) is outside the hot path "
-                                       "implemented by pandora_amd (SURVEY 8)")
                 self.right_disp_map = cfg["pipeline"]["validation"]["validation_method"]
             self.state = "begin"
             self._mode = "run"
@@ -148,9 +145,6 @@ class PandoraMachine:
         self.right_cv = None
         self.right_disp_map = None
         if "validation" in cfg["pipeline"]:
-            if "interpolated_disparity" in cfg["pipeline"]["validation"]:
-                raise MachineError("'interpolated_disparity' (validation.AbstractInterpolation) is outside the hot path "
-                                   "implemented by pandora_amd (SURVEY 8)")
             self.right_disp_map = cfg["pipeline"]["validation"]["validation_method"]
         self.state = "begin"
         self._mode = "run"
@@ -287,6 +281,10 @@ class PandoraMachine:
         self.left_disparity = validation_.disparity_checking(self.left_disparity, self.right_disparity)
         if self.right_disp_map is not None:
             self.right_disparity = validation_.disparity_checking(self.right_disparity, self.left_disparity)
+            if "interpolated_disparity" in cfg["pipeline"][input_step]:  # mismatches and occlusions get a value
+                interpolate_ = validation.AbstractInterpolation(**cfg["pipeline"][input_step])
+                interpolate_.interpolated_disparity(self.left_disparity)
+                interpolate_.interpolated_disparity(self.right_disparity)
         if self.right_disp_map == "cross_checking_fast":
             # do not hand incomplete right-side data to the user
             self.right_disparity = Dataset()
@@ -331,8 +329,7 @@ class PandoraMachine:
         v = validation.AbstractValidation(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = v.cfg
         if "interpolated_disparity" in v.cfg:
-            raise MachineError("'interpolated_disparity' (validation.AbstractInterpolation) is outside the hot path "
-                               "implemented by pandora_amd (SURVEY 8)")
+            validation.AbstractInterpolation(**cfg[input_step])
         self.right_disp_map = v.cfg["validation_method"]
         if self.left_img is not None and self.right_img is not None:
             ds_left = self.left_img.attrs.get("disparity_source")

@@ -1,8 +1,7 @@
 """AbstractValidation + CrossCheckingAccurate (reference: validation/validation.py:40-371).
 
 Same registry mechanics, configuration keys and dataset protocol as the reference; the consistency check itself
-runs on the GPU (pmx_cross_checking).  The interpolation of rejected pixels (AbstractInterpolation, mc-cnn / sgm
-variants, validation.py:374-770) is outside this build's scope.
+runs on the GPU (pmx_cross_checking).  The interpolation of rejected pixels lives in interpolated_disparity.py.
 """
 from abc import ABCMeta, abstractmethod
 

@@ -250,3 +250,43 @@ DISPARITY_RANGE = {
     "range_max": [[0, 0, 0, 0, 0, 0], [0, -1, -2, 0, -4, 0], [0, -7, -8, -9, -11, 0], [0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0]],
     "range_min": [[-30] * 6, [-30, -15, -16, -30, -18, -30], [-30, -15, -16, -17, -18, -30], [-30] * 6, [-30] * 6],
 }
+
+
+# ---- interpolation of rejected pixels (tests/test_validation.py:310-704; validity flags as constants.py) ----------
+_FOCC, _FMIS, _INVL = 1 << 4, 1 << 5, 1 << 6   # FILLED_OCCLUSION, FILLED_MISMATCH, IN_VALIDITY_MASK_LEFT
+_D45 = [[0, 1.2, -2, -1, -2], [1, 0, 1, 0, 0], [2, 1, -1, -2, -1], [1, -1, 1, -1, -1.3]]
+
+
+def _m45(flag, corner=0, last=0):
+    return [[_LBORDER, _INC, 0, _STOP, corner], [0, 0, flag, 0, 0], [0, _STOP, flag, _INVL, flag], [last, flag, 0, 0, 0]]
+
+
+def _med(*v):
+    import numpy as _np
+    return float(_np.float32(_np.median(v)))   # the expected maps are float32 arrays of np.median values
+
+
+INTERPOLATION = [
+    {"cite": "test_validation.py:310-371 test_interpolate_occlusion_mc_cnn", "method": "mc-cnn",
+     "disp": [[0, -1, 1, -2.1], [2, 2, -1.7, 0]], "validity": [[_RND, _OCC, _RND, 0], [_OCC, _INVL, 0, _OCC]],
+     "out_disp": [[0, -2.1, 1, -2.1], [-1.7, 2, -1.7, -1.7]], "out_validity": [[_RND, _FOCC, _RND, 0], [_FOCC, _INVL, 0, _FOCC]]},
+    {"cite": "test_validation.py:374-460 test_interpolate_mismatch_mc_cnn", "method": "mc-cnn",
+     "disp": _D45, "validity": _m45(_MIS), "out_validity": _m45(_FMIS),
+     "out_disp": [[0, 1.2, -2, -1, -2],
+                  [1, 0, _med(1.2, 1, 0, 0, 0, 1, -2, -2, -2, -1, 0, 0, 0, -1, -1.3), 0, 0],
+                  [2, 1, _med(1, 1, 1, 1, 1, 0, 1, -2, -1, 0, 0, -1, -1, 1), -2, _med(-1, -1, -1, 1, 1, 0, 0, 0, 0, 0)],
+                  [1, _med(1, 1, 1, 2, 1, 1, 1, 0, 1, 1, 1), 1, -1, -1.3]]},
+    {"cite": "test_validation.py:462-533 test_interpolate_occlusion_sgm", "method": "sgm",
+     "disp": _D45, "validity": _m45(_OCC), "out_validity": _m45(_FOCC),
+     "out_disp": [[0, 1.2, -2, -1, -2], [1, 0, 0, 0, 0], [2, 1, 0, -2, 0], [1, 1, 1, -1, -1.3]]},
+    {"cite": "test_validation.py:536-613 test_interpolate_mismatch_sgm", "method": "sgm",
+     "disp": _D45, "validity": _m45(_MIS), "out_validity": _m45(_FMIS),
+     "out_disp": [[0, 1.2, -2, -1, -2], [1, 0, _med(1.2, -2, -1, 0, 0, 1, 1, -1.3), 0, 0],
+                  [2, 1, _med(-2, 0, -1, -1, 1, 1, 0), -2, _med(0, -1.3, -1, 1, 0)], [1, _med(2, 1, 0, 1, 1), 1, -1, -1.3]]},
+    {"cite": "test_validation.py:616-704 test_interpolate_mismatch_and_occlusion_sgm", "method": "sgm",
+     "disp": [[0, 1, -2, -1, -2], [1, 0, 1, 0, 0], [2, 1, -1, -2, -1], [1, -1, 1, -1, -1]],
+     "validity": _m45(_MIS, corner=_OCC, last=_OCC),
+     "out_validity": [[_LBORDER, _INC, 0, _STOP, _FOCC], [0, 0, _FMIS, 0, 0], [0, _STOP, _FMIS, _INVL, _FMIS], [_FOCC, _FOCC, 0, 0, 0]],
+     "out_disp": [[0, 1, -2, -1, 0], [1, 0, _med(1, 1, 0, 1, -2, -1, 0, -1), 0, 0],
+                  [2, 1, _med(1, 1, 0, -2, 0, -1), -2, _med(-1, -1, 1, 0, 0)], [1, 1, 1, -1, -1]]},
+]

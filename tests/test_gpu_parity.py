@@ -576,6 +576,50 @@ def test_disparity_range_reference_vector_and_random(eng, oracle):
         np.testing.assert_array_equal(got[1], exp[1])
 
 
+@pytest.mark.parametrize("case", ka.INTERPOLATION, ids=lambda c: c["cite"])
+def test_interpolation_reference_vectors(eng, case):
+    """validation.AbstractInterpolation on the reference's own five cases (tests/test_validation.py:310-704), through the
+    plugin classes."""
+    from pandora_amd import validation
+    from pandora_amd.dataset import Dataset
+
+    left = Dataset({"disparity_map": (("row", "col"), np.array(case["disp"], np.float32)),
+                    "validity_mask": (("row", "col"), np.array(case["validity"], np.uint16))},
+                   coords={"row": np.arange(len(case["disp"])), "col": np.arange(len(case["disp"][0]))})
+    left.attrs["offset_row_col"] = 0
+    validation.AbstractInterpolation(interpolated_disparity=case["method"]).interpolated_disparity(left)
+    np.testing.assert_array_equal(left["validity_mask"].data, np.array(case["out_validity"]))
+    np.testing.assert_array_equal(left["disparity_map"].data, np.array(case["out_disp"], np.float32))
+    assert left.attrs["interpolated_disparity"] == case["method"]
+
+
+@pytest.mark.parametrize("which", ["occlusion_mc_cnn", "mismatch_mc_cnn", "occlusion_sgm", "mismatch_sgm"])
+def test_interpolation_passes_equal_oracle(eng, oracle, which):
+    """Each pass of pmx_interpolate_disparity == its restatement (diffed against the compiled validation_cpp in
+    test_oracle_vs_reference.py): dense / sparse rejections, rows without a valid pixel, NaN on valid pixels, 1-wide maps."""
+    OCC, MIS = 1 << 8, 1 << 9
+    rng = np.random.default_rng(13)
+    for H, W, p in ((6, 9, 0.3), (33, 300, 0.6), (64, 257, 0.1), (1, 40, 0.5), (40, 1, 0.5), (8, 8, 1.0), (50, 70, 0.0)):
+        disp = (rng.integers(-20, 20, (H, W)) + rng.choice([0, 0.25, -0.5], (H, W))).astype(np.float32)
+        valid = np.where(rng.random((H, W)) < p, rng.choice([OCC, MIS, 1, 2, 64, OCC + 4, MIS + 8], (H, W)),
+                         rng.choice([0, 4, 8, 16, 32, 2048], (H, W))).astype(np.int64)
+        if H > 2 and W > 2:
+            valid[2, :] = OCC
+            disp[1, 1], valid[1, 1] = np.nan, 0
+        if p == 0.0:
+            valid[10:40, 20:60] = MIS            # a large hole: long walks
+            valid[12, 18] = OCC
+        got = eng.interpolate_disparity(disp, valid, [which])
+        exp = oracle.interpolate_disparity(which, disp, valid)
+        np.testing.assert_array_equal(got[0], exp[0])
+        np.testing.assert_array_equal(got[1], exp[1])
+    # two passes in one call == two calls
+    a = eng.interpolate_disparity(disp, valid, ["mismatch_sgm", "occlusion_sgm"])
+    b = eng.interpolate_disparity(*eng.interpolate_disparity(disp, valid, ["mismatch_sgm"]), ["occlusion_sgm"])
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
 def test_interpolate_nodata_equals_oracle(eng, oracle):
     """pmx_interpolate_nodata == img_tools.cpp:99-155 restated (pinned against the compiled reference in
     test_oracle_vs_reference.py): sparse and dense masks, ragged widths, all-invalid and all-valid images, NaN values among

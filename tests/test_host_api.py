@@ -156,10 +156,11 @@ def test_validation_step_is_sequenced_after_the_disparity_map():
     with pytest.raises(MachineError):  # no disparity map yet
         PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"},
                                                   "validation": {"validation_method": "cross_checking_fast"}}})
-    pipe["pipeline"]["validation"]["interpolated_disparity"] = "sgm"  # interpolation is not part of the hot path
-    with pytest.raises(MachineError) as err:
-        PandoraMachine().check_conf(pipe)
-    assert "interpolated_disparity" in str(err.value)
+    pipe["pipeline"]["validation"]["interpolated_disparity"] = "sgm"  # state_machine.py:907-908: the plugin is instantiated
+    assert PandoraMachine().check_conf(pipe)["pipeline"]["validation"]["interpolated_disparity"] == "sgm"
+    assert isinstance(validation.AbstractInterpolation(interpolated_disparity="mc-cnn"), validation.McCnnInterpolation)
+    with pytest.raises(KeyError):
+        validation.AbstractInterpolation(interpolated_disparity="linear")
     # disparity_source consistency (state_machine.py:912-918)
     left = make_image(np.zeros((4, 6)), disparity=[-2, 1])
     right = make_image(np.zeros((4, 6)), disparity=[-1, 3])

@@ -200,3 +200,14 @@ def test_disparity_range_known_answer(oracle):
                                     c["marge"], c["dmin"], c["dmax"])
     np.testing.assert_array_equal(lo, np.array(c["range_min"], np.float32))
     np.testing.assert_array_equal(hi, np.array(c["range_max"], np.float32))
+
+
+@pytest.mark.parametrize("case", ka.INTERPOLATION, ids=lambda c: c["cite"])
+def test_interpolation_reference_vectors(oracle, case):
+    """AbstractInterpolation.interpolated_disparity (interpolated_disparity.py:200-233 mc-cnn: occlusions then mismatches;
+    :318-330 sgm: mismatches then occlusions) on the reference's own five cases."""
+    d, v = np.array(case["disp"], np.float32), np.array(case["validity"], np.int32)
+    for which in (("occlusion_mc_cnn", "mismatch_mc_cnn") if case["method"] == "mc-cnn" else ("mismatch_sgm", "occlusion_sgm")):
+        d, v = oracle.interpolate_disparity(which, d, v)
+    np.testing.assert_array_equal(v, np.array(case["out_validity"], np.int32))
+    np.testing.assert_array_equal(d, np.array(case["out_disp"], np.float32))

@@ -184,3 +184,33 @@ def test_interpolate_nodata_matches_reference(oracle):
         got_i, got_m = oracle.interpolate_nodata(img, msk, 0b01111000011, 1 << 10)
         np.testing.assert_array_equal(got_i, exp_i)
         np.testing.assert_array_equal(got_m, exp_m)
+
+
+vc = ref.load("validation_cpp")
+
+
+@pytest.mark.skipif(vc is None, reason="oracle/_ref not built")
+@pytest.mark.parametrize("which", ["occlusion_mc_cnn", "mismatch_mc_cnn", "occlusion_sgm", "mismatch_sgm"])
+def test_interpolation_passes_match_reference(oracle, which):
+    """interpolated_disparity.cpp: random maps with every validity flag, dense and sparse rejections, rows without any
+    valid pixel, NaN disparities on valid pixels, 1-pixel-wide maps."""
+    OCC, MIS, FOCC, FMIS, INV = 1 << 8, 1 << 9, 1 << 4, 1 << 5, 0b01111000011
+    rng = np.random.default_rng(12)
+    for H, W, p in ((6, 9, 0.3), (17, 23, 0.6), (30, 41, 0.1), (1, 12, 0.5), (12, 1, 0.5), (8, 8, 1.0)):
+        disp = (rng.integers(-20, 20, (H, W)) + rng.choice([0, 0.25, -0.5], (H, W))).astype(np.float32)
+        valid = np.where(rng.random((H, W)) < p, rng.choice([OCC, MIS, 1, 2, 64, OCC + 4, MIS + 8], (H, W)),
+                         rng.choice([0, 4, 8, 16, 32, 2048], (H, W))).astype(np.int32)
+        if H > 2 and W > 2:
+            valid[2, :] = OCC
+            disp[1, 1], valid[1, 1] = np.nan, 0
+        if which == "occlusion_mc_cnn":
+            exp = vc.interpolate_occlusion_mc_cnn(disp, valid, OCC, FOCC, INV)
+        elif which == "mismatch_mc_cnn":
+            exp = vc.interpolate_mismatch_mc_cnn(disp, valid, MIS, FMIS, INV)
+        elif which == "occlusion_sgm":
+            exp = vc.interpolate_occlusion_sgm(disp, valid, OCC, FOCC, INV)
+        else:
+            exp = vc.interpolate_mismatch_sgm(disp, valid, MIS, FMIS, OCC, INV)
+        got = oracle.interpolate_disparity(which, disp, valid)
+        np.testing.assert_array_equal(got[0], exp[0])
+        np.testing.assert_array_equal(got[1], exp[1])

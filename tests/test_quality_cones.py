@@ -207,3 +207,43 @@ def test_multiscale_with_image_masks(oracle):
     d = np.nan_to_num(dl["disparity_map"].data, nan=1e4)
     bad = (np.abs(d + gt_left) > 1) & ok & (gt_left != 0)
     assert bad.sum() / ok.sum() <= 0.20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["mc-cnn", "sgm"])
+def test_validation_with_interpolated_disparity(oracle, method):
+    """state_machine.py:505-511: after the cross-checking both maps have their occlusions / mismatches filled.  The
+    machine's result == the oracle's passes applied to the result of the same pipeline without the interpolation, no
+    rejection flag is left (mc-cnn: except on rows without a valid pixel), and the 20 % gate still holds."""
+    import json
+
+    import pandora_amd
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, gt_left = load_cones()
+    outs = {}
+    for interp in (None, method):
+        left, right = make_image(L, disparity=[-60, 0]), make_image(R, disparity=[0, 60])
+        cfg = json.loads(json.dumps(VALIDATION_REF))
+        if interp:
+            cfg["pipeline"]["validation"]["interpolated_disparity"] = interp
+        machine = PandoraMachine()
+        cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+        outs[interp] = pandora_amd.run(machine, left, right, cfg)
+    passes = ("occlusion_mc_cnn", "mismatch_mc_cnn") if method == "mc-cnn" else ("mismatch_sgm", "occlusion_sgm")
+    for side in (0, 1):
+        d, v = outs[None][side]["disparity_map"].data, outs[None][side]["validity_mask"].data
+        for which in passes:
+            d, v = oracle.interpolate_disparity(which, d, v)
+        got = outs[method][side]
+        if method == "mc-cnn":  # mask_border re-marks the frame (interpolated_disparity.py:229-231)
+            o = got.attrs["offset_row_col"]
+            v[:o, :] = v[-o:, :] = 1
+            v[:, :o] = v[:, -o:] = 1
+        np.testing.assert_array_equal(got["disparity_map"].data, d)
+        np.testing.assert_array_equal(got["validity_mask"].data, v)
+        assert got.attrs["interpolated_disparity"] == method
+    vm = outs[method][0]["validity_mask"].data
+    assert (outs[None][0]["validity_mask"].data & 0x300).any() and not (vm & 0x300).any() and (vm & 0x30).any()
+    assert error(np.nan_to_num(outs[method][0]["disparity_map"].data, nan=1e4), gt_left, 1) <= 0.20
