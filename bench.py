@@ -10,7 +10,8 @@ collective; "weak" scaling), launched by torch.distributed.run, barrier + max ov
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = one SGM path pass, HIP-event
 timed on the engine's stream inside the timed region) and `cpu_baseline` (the C oracle, kind
-"port", on a bounded row strip of the same workload, 1 thread).
+"port", on a bounded row strip of the same workload, 1 thread; `cpu_baseline_all_cores` is the same
+strip with OpenMP on every host core).
 """
 import argparse
 import json
@@ -55,11 +56,13 @@ def run_pipeline(eng, cv, win, P1, P2):
     eng.refine(cv, "vfit", False)
 
 
-def cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows):
-    """The C oracle (kind 'port') on a row strip; single thread."""
+def cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows, threads=1):
+    """The C oracle (kind 'port') on a row strip: threads=1 is the reference's serial execution, threads=0 the same loops
+    with OpenMP over rows / columns on every host core (the fair CPU ceiling); same results either way."""
     from oracle import capi
 
     capi.lib()
+    cores = capi.set_threads(threads)
     Ls, Rs = np.ascontiguousarray(L[:rows]), np.ascontiguousarray(R[:rows])
     D = dmax - dmin + 1
     t0 = time.perf_counter()
@@ -69,9 +72,10 @@ def cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows):
     capi.refine(cv, disp, val, dmin, dmax, 1, False, "vfit")
     dt = time.perf_counter() - t0
     cells = rows * L.shape[1] * D
-    return {"value": round(cells / dt / 1e6, 3), "unit": "Mdisp/s", "cores": 1, "kind": "port",
+    capi.set_threads(1)
+    return {"value": round(cells / dt / 1e6, 3), "unit": "Mdisp/s", "cores": cores, "kind": "port",
             "sample": f"first {rows} rows of the {L.shape[0]}x{L.shape[1]} pair, D={D}, census{win}+sgm8+wta+vfit, "
-                      f"{dt:.1f} s of oracle/liboracle.so (gcc -O2), 1 thread"}, (disp, val)
+                      f"{dt:.1f} s of oracle/liboracle.so (gcc -O2 -fopenmp), {cores} thread{'s' if cores > 1 else ''}"}, (disp, val)
 
 
 def main():
@@ -205,6 +209,8 @@ def main():
             rows = min(args.cpu_rows, H)
             base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)
             out["cpu_baseline"] = base
+            out["cpu_baseline_all_cores"], (mdisp, mval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows, threads=0)
+            assert np.array_equal(mdisp, cdisp, equal_nan=True) and np.array_equal(mval, cval)  # thread count changes nothing
             # parity in the same run: the same strip through the GPU path (vertical paths see only
             # the strip, so the GPU is re-run on the strip alone)
             eng2 = Engine(local_rank)

@@ -251,3 +251,9 @@ def interpolate_disparity(which, disp, valid):
     lib().orc_interpolate_disparity(INTERP_PASSES[which], _p(d), _p(v, C.c_int32), d.shape[0], d.shape[1], _p(out_d),
                                     _p(out_v, C.c_int32))
     return out_d, out_v
+
+
+def set_threads(n):
+    """OpenMP threads of the census / SGM / WTA / refinement loops (results do not depend on it): 1 = the reference's serial
+    execution, 0 = all cores.  Returns the count in effect."""
+    return int(lib().orc_set_threads(int(n)))

@@ -17,6 +17,7 @@
 #include "oracle.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -62,6 +63,7 @@ void orc_census_transform(const float* img, int H, int W, int win, uint8_t* out)
     int h = win / 2;
     int nb = orc_census_nb_chars(win);
     memset(out, 0, (size_t)H * W * nb);
+#pragma omp parallel for schedule(static)
     for (int x = h; x < H - h; ++x)
         for (int y = h; y < W - h; ++y) {
             float val = img[(size_t)x * W + y];
@@ -73,6 +75,14 @@ void orc_census_transform(const float* img, int H, int W, int win, uint8_t* out)
                     if (++bit >= 8) { ++chr; bit = 0; }
                 }
         }
+}
+
+/* The loops above and below marked `omp parallel for` touch disjoint outputs per iteration, so results do not depend on the
+ * thread count; orc_set_threads(1) gives the reference's serial execution (the 1-core CPU baseline), orc_set_threads(0) all cores. */
+int orc_set_threads(int n) {
+    if (n <= 0) n = omp_get_num_procs();
+    omp_set_num_threads(n);
+    return n;
 }
 
 static inline int popcount8(uint8_t v) { return __builtin_popcount((unsigned)v); }
@@ -90,6 +100,7 @@ void orc_census_cost(const float* L, const float* Rs, int H, int W, int D, int d
         cr[k] = (uint8_t*)malloc((size_t)H * Wk * nb);
         orc_census_transform(shifted_ptr(Rs, H, W, k), H, Wk, win, cr[k]);
     }
+#pragma omp parallel for schedule(static)
     for (int row = h; row < H - h; ++row)
         for (int col = h; col < W - h; ++col) {
             const uint8_t* lp = cl + ((size_t)row * W + col) * nb;
@@ -455,43 +466,64 @@ void orc_cbca(float* cv, int H, int W, int D, int d0, int subpix, int offset, co
  *   output    = S (negated back for "max"); NaN wherever the input was NaN.
  * All arithmetic is float32, in exactly the operation order written above.
  * ------------------------------------------------------------------------------------------- */
+/* one pixel of one path: p-r = (pr, pc) holds Lq (or lies outside the image) */
+static inline void sgm_pixel(const float* Cc, const float* Lq, int D, float P1, float P2, float* Lo, float* So) {
+    if (!Lq) {
+        for (int d = 0; d < D; ++d) { Lo[d] = Cc[d]; So[d] = So[d] + Cc[d]; }
+        return;
+    }
+    float M = Lq[0];
+    for (int d = 1; d < D; ++d) if (Lq[d] < M) M = Lq[d];
+    float mp2 = M + P2;
+    for (int d = 0; d < D; ++d) {
+        float a = d > 0 ? Lq[d - 1] : INFINITY;
+        float b = d < D - 1 ? Lq[d + 1] : INFINITY;
+        float nb = (a < b ? a : b) + P1;
+        float t = Lq[d] < nb ? Lq[d] : nb;
+        t = t < mp2 ? t : mp2;
+        float l = Cc[d] + (t - M);
+        Lo[d] = l;
+        So[d] = So[d] + l;
+    }
+}
+
+/* Pixels are visited so that p-r comes before p.  Every cell sees exactly the operations written in the header, in
+ * that order, whatever the thread count: horizontal paths run their rows in parallel (a private two-pixel buffer per
+ * row), the others run the columns of a row in parallel against the finished previous row (rolling buffers prev / cur,
+ * [W][D] each). */
 static void sgm_path(const float* Cp, int H, int W, int D, int dr, int dc, float P1, float P2,
                      float* S, float* prev, float* cur) {
-    /* iterate pixels so that p-r is always visited before p */
-    int r0 = dr >= 0 ? 0 : H - 1, r1 = dr >= 0 ? H : -1, rs = dr >= 0 ? 1 : -1;
     int c0 = dc >= 0 ? 0 : W - 1, c1 = dc >= 0 ? W : -1, cs = dc >= 0 ? 1 : -1;
-    /* L of the previous row (or previous pixel for horizontal paths) is kept in a rolling buffer:
-     * Lbuf[2][W][D] */
+    if (dr == 0) {
+#pragma omp parallel
+        {
+            float* two = (float*)malloc(sizeof(float) * 2 * (size_t)D);
+#pragma omp for schedule(static)
+            for (int r = 0; r < H; ++r) {
+                int which = 0;
+                for (int c = c0; c != c1; c += cs, which ^= 1) {
+                    int pc = c - dc;
+                    sgm_pixel(Cp + IDX3(r, c, 0, W, D), (pc < 0 || pc >= W) ? NULL : two + (size_t)(which ^ 1) * D, D, P1, P2,
+                              two + (size_t)which * D, S + IDX3(r, c, 0, W, D));
+                }
+            }
+            free(two);
+        }
+        return;
+    }
+    int r0 = dr >= 0 ? 0 : H - 1, r1 = dr >= 0 ? H : -1, rs = dr >= 0 ? 1 : -1;
     float* Lrow[2] = {prev, cur};
     int which = 0;
-    for (int r = r0; r != r1; r += rs) {
+    for (int r = r0; r != r1; r += rs, which ^= 1) {
         float* Lc = Lrow[which];
-        float* Lp = Lrow[which ^ 1];
-        for (int c = c0; c != c1; c += cs) {
-            int pr = r - dr, pc = c - dc;
-            const float* Cc = Cp + IDX3(r, c, 0, W, D);
-            float* Lo = Lc + (size_t)c * D;
-            float* So = S + IDX3(r, c, 0, W, D);
-            if (pr < 0 || pr >= H || pc < 0 || pc >= W) {
-                for (int d = 0; d < D; ++d) { Lo[d] = Cc[d]; So[d] = So[d] + Cc[d]; }
-                continue;
-            }
-            const float* Lq = (dr == 0 ? Lc : Lp) + (size_t)pc * D;
-            float M = Lq[0];
-            for (int d = 1; d < D; ++d) if (Lq[d] < M) M = Lq[d];
-            float mp2 = M + P2;
-            for (int d = 0; d < D; ++d) {
-                float a = d > 0 ? Lq[d - 1] : INFINITY;
-                float b = d < D - 1 ? Lq[d + 1] : INFINITY;
-                float nb = (a < b ? a : b) + P1;
-                float t = Lq[d] < nb ? Lq[d] : nb;
-                t = t < mp2 ? t : mp2;
-                float l = Cc[d] + (t - M);
-                Lo[d] = l;
-                So[d] = So[d] + l;
-            }
+        const float* Lp = Lrow[which ^ 1];
+        int pr = r - dr;
+#pragma omp parallel for schedule(static)
+        for (int c = 0; c < W; ++c) {
+            int pc = c - dc;
+            sgm_pixel(Cp + IDX3(r, c, 0, W, D), (pr < 0 || pr >= H || pc < 0 || pc >= W) ? NULL : Lp + (size_t)pc * D, D, P1, P2,
+                      Lc + (size_t)c * D, S + IDX3(r, c, 0, W, D));
         }
-        if (dr != 0) which ^= 1;
     }
 }
 
@@ -502,6 +534,7 @@ void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_ma
     float* S = (float*)calloc(n, sizeof(float));
     float* b0 = (float*)malloc(sizeof(float) * (size_t)W * D);
     float* b1 = (float*)malloc(sizeof(float) * (size_t)W * D);
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float v = cv[i];
         if (isnan(v)) v = invalid_cost; else if (is_max) v = -v;
@@ -509,6 +542,7 @@ void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_ma
     }
     static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}, {1, 1}, {-1, -1}, {1, -1}, {-1, 1}};
     for (int k = 0; k < 8; ++k) sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, S, b0, b1);
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float s = S[i];
         if (overcounting) s = s - 7.0f * Cp[i];
@@ -528,6 +562,7 @@ void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_ma
 
 void orc_wta(const float* cv, int H, int W, int D, double d0, int subpix, int is_max,
              float invalid_disparity, float* disp, int64_t* validity) {
+#pragma omp parallel for schedule(static)
     for (int r = 0; r < H; ++r)
         for (int c = 0; c < W; ++c) {
             const float* p = cv + IDX3(r, c, 0, W, D);
@@ -589,6 +624,7 @@ static void quadratic(float c0, float c1, float c2, int is_max, float* sd, float
 /* refinement.cpp:28-99 loop_refinement */
 void orc_refine(const float* cv, int H, int W, int D, double d_min, double d_max, int subpix, int is_max,
                 int method, float* disp, int64_t* validity, float* itp) {
+#pragma omp parallel for schedule(static)
     for (int r = 0; r < H; ++r)
         for (int c = 0; c < W; ++c) {
             size_t i = (size_t)r * W + c;

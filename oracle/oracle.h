@@ -111,6 +111,9 @@ void orc_interpolate_nodata(const float* img, const int32_t* msk, int H, int W, 
 /* validation/cpp/src/interpolated_disparity.cpp: pass 0/1 = occlusion/mismatch mc-cnn, 2/3 = occlusion/mismatch sgm */
 void orc_interpolate_disparity(int pass, const float* disp, const int32_t* valid, int H, int W, float* out_disp, int32_t* out_valid);
 
+/* OpenMP thread count of the census / SGM / WTA / refinement loops: n <= 0 = all cores; returns the count set */
+int orc_set_threads(int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,22 @@ def test_interpolation_reference_vectors(oracle, case):
         d, v = oracle.interpolate_disparity(which, d, v)
     np.testing.assert_array_equal(v, np.array(case["out_validity"], np.int32))
     np.testing.assert_array_equal(d, np.array(case["out_disp"], np.float32))
+
+
+def test_oracle_results_do_not_depend_on_the_thread_count(oracle):
+    """The OpenMP loops of the oracle (census, SGM, WTA, refinement) give identical bits with 1 thread (the reference's
+    serial order) and with every core (bench.py's cpu_baseline_all_cores)."""
+    rng = np.random.default_rng(21)
+    L = rng.integers(0, 255, (37, 61)).astype(np.float32)
+    R = np.roll(L, 3, 1) + rng.integers(-2, 3, L.shape).astype(np.float32)
+    outs = []
+    for threads in (1, 0, 3):
+        oracle.set_threads(threads)
+        cv = oracle.census_cost(L, R, 13, -6, 1, 5)
+        s = oracle.sgm(cv, 8.0, 32.0, False, 26.0, False)
+        disp, val = oracle.wta(s, -6, 1, False, -9999.0)
+        outs.append((cv, s, disp, val) + tuple(oracle.refine(s, disp, val, -6, 6, 1, False, "vfit")))
+    oracle.set_threads(1)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
