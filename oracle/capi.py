@@ -20,8 +20,29 @@ def lib():
         path = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # idle OpenMP threads sleep instead of spinning
         _LIB = C.CDLL(path)
+        _LIB.orc_set_threads(1)  # serial, like the reference, unless a caller asks for more (set_threads)
     return _LIB
+
+
+def usable_cores(cap=64):
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    n = min(n, max(1, int(int(fields[0]) / int(fields[1]))))
+            elif int(fields[0]) > 0:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    n = min(n, max(1, int(int(fields[0]) / int(f.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, cap))
 
 
 def _f32(a):
@@ -255,5 +276,5 @@ def interpolate_disparity(which, disp, valid):
 
 def set_threads(n):
     """OpenMP threads of the census / SGM / WTA / refinement loops (results do not depend on it): 1 = the reference's serial
-    execution, 0 = all cores.  Returns the count in effect."""
-    return int(lib().orc_set_threads(int(n)))
+    execution, 0 = every core this process may use (usable_cores()).  Returns the count in effect."""
+    return int(lib().orc_set_threads(int(n) if n > 0 else usable_cores()))
