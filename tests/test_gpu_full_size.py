@@ -1,0 +1,129 @@
+"""BASELINE.json's FULL sizes through size-independent properties (the oracle cannot run them in seconds):
+C3 2048x2048x129, C4 4096x4096x257 (4.31e9 cells: float32 volume offsets beyond 2^32 elements), C5 10000x10000x129
+(1.29e10 cells, 51.6 GB float32 volume).
+  * the integer fast path and the general float32 kernels are two independent implementations of census -> SGM -> WTA ->
+    vfit: their disparity, validity and interpolated-cost maps must be identical bit for bit at full size;
+  * every step without long-range vertical coupling (matching costs, CBCA, WTA, refinement) must equal the oracle on the
+    bottom rows of the image, computed by the oracle on a strip (where the 64-bit indexing matters most);
+  * a vertically periodic pair gives vertically periodic maps away from the borders (SGM included)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = {"C3": (2048, 2048, 0, 128), "C4": (4096, 4096, 0, 256), "C5": (10000, 10000, -64, 64)}
+P1, P2, WIN = 8.0, 32.0, 5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pandora_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.set_lazy(True)
+    e.close()
+
+
+_PAIRS = {}
+
+
+def big_pair(name):
+    """Periodic in the rows (period 16) so that one small tile defines the whole pair: cheap to build at 10000^2."""
+    if name not in _PAIRS:
+        H, W, dmin, dmax = SIZES[name]
+        rng = np.random.default_rng(len(name) + H)
+        base = rng.integers(0, 256, (16, W + 24)).astype(np.float32)
+        base = np.floor((base + np.roll(base, 1, 1) + np.roll(base, 1, 0)) / 3.0)
+        shift = 7 if dmax > 7 else -7
+        L = base[:, 12:12 + W]
+        R = base[:, 12 - shift:12 - shift + W] + rng.integers(-2, 3, (16, W))
+        reps = -(-H // 16)
+        _PAIRS.clear()  # one full-size pair in host memory at a time
+        _PAIRS[name] = (np.ascontiguousarray(np.tile(L, (reps, 1))[:H], np.float32),
+                        np.ascontiguousarray(np.tile(R, (reps, 1))[:H], np.float32))
+    return _PAIRS[name]
+
+
+def census_sgm_maps(eng, L, R, dmin, dmax, lazy):
+    eng.set_lazy(lazy)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(dmax - dmin + 1, dmin)
+    eng.census(cv, WIN)
+    eng.sgm(cv, P1, P2, False, float(WIN * WIN + 1), False)
+    eng.set_validity(None)
+    eng.wta(cv, False, -9999.0)
+    eng.refine(cv, "vfit", False)
+    out = eng.get_disparity(want_itp=True)
+    cv.free()
+    return out
+
+
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+def test_integer_and_float_paths_agree_at_full_size(eng, name):
+    H, W, dmin, dmax = SIZES[name]
+    L, R = big_pair(name)
+    fast = census_sgm_maps(eng, L, R, dmin, dmax, lazy=True)
+    try:
+        general = census_sgm_maps(eng, L, R, dmin, dmax, lazy=False)
+    except RuntimeError as err:  # two float32 volumes of 51.6 GB each at C5: only if the device has the room
+        if "memory" in str(err).lower():
+            pytest.skip(f"float32 path does not fit at {name}: {err}")
+        raise
+    for a, b in zip(fast, general):
+        np.testing.assert_array_equal(a, b)
+    disp = fast[0]
+    inner = disp[WIN:-WIN, WIN:-WIN]
+    assert np.isfinite(inner).all() and inner.min() >= dmin and inner.max() <= dmax
+    # vertical period 16: the maps repeat away from the top / bottom borders (all eight SGM paths included)
+    lo = 16 * (H // 64)
+    np.testing.assert_array_equal(disp[lo:lo + 160], disp[lo + 160:lo + 320])
+    np.testing.assert_array_equal(fast[2][lo:lo + 160], fast[2][lo + 160:lo + 320])
+
+
+@pytest.mark.parametrize("method,win", [("census", 5), ("sad", 5), ("ssd", 3), ("zncc", 11), ("census+cbca", 5)])
+def test_bottom_strip_equals_oracle_at_c4_size(eng, oracle, method, win):
+    """Local steps at 4096x4096x257 (float32 volume, 17.3 GB): the bottom rows -- the cells beyond 2^32 elements -- equal the
+    oracle run on a strip of the last rows.  Rows closer than `skip` to the strip's artificial top border are left out."""
+    H, W, dmin, dmax = SIZES["C4"]
+    L, R = big_pair("C4")
+    D = dmax - dmin + 1
+    strip, skip = 48, 20
+    eng.set_lazy(False)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(D, dmin)
+    Ls, Rs = np.ascontiguousarray(L[-strip:]), np.ascontiguousarray(R[-strip:])
+    is_max = method == "zncc"
+    if method.startswith("census"):
+        eng.census(cv, win)
+        ocv = oracle.census_cost(Ls, Rs, D, dmin, 1, win)
+    elif method in ("sad", "ssd"):
+        eng.sad_ssd(cv, win, method == "ssd")
+        ocv = oracle.sad_ssd(Ls, Rs, D, dmin, 1, win, method == "ssd")
+    else:
+        eng.zncc(cv, win)
+        ocv = oracle.zncc(Ls, Rs, D, dmin, 1, win)
+    if method.endswith("cbca"):
+        off = win // 2
+        eng.cbca(cv, off, 30.0, 5)
+
+        def arms(im):  # cbca.py:217-282 without masks: 3x3 nanmedian, crop by the offset, cross supports
+            return oracle.cross_support(np.ascontiguousarray(oracle.median3(im)[off:-off, off:-off]), 5, 30.0)
+
+        oracle.cbca(ocv, dmin, 1, off, arms(Ls), [arms(Rs)])
+    eng.set_validity(None)
+    eng.wta(cv, is_max, -9999.0)
+    eng.refine(cv, "quadratic", is_max)
+    disp, val, itp = eng.get_disparity(want_itp=True)
+    cv.free()
+    odisp, oval = oracle.wta(ocv, dmin, 1, is_max, -9999.0)
+    oitp, odisp, oval = oracle.refine(ocv, odisp, oval, dmin, dmax, 1, is_max, "quadratic")
+    got, exp = (disp[-strip + skip:], val[-strip + skip:], itp[-strip + skip:]), (odisp[skip:], oval[skip:], oitp[skip:])
+    if method == "zncc":  # float64 sliding sums: costs within 1e-5, so near-ties may pick another disparity
+        same = got[0] == exp[0]
+        assert same.mean() > 0.999
+        np.testing.assert_allclose(got[2][same], exp[2][same], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(got[1][same], exp[1][same])
+    else:
+        for a, b in zip(got, exp):
+            np.testing.assert_array_equal(a, b)
