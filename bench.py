@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--dmin", type=int, default=0)
     ap.add_argument("--dmax", type=int, default=128)
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline strip (0 = skip)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the informational 4096x4096x257 leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,6 +206,26 @@ def main():
         out["pcie_inclusive"] = {"ms_per_step": round(pcie_s * 1e3, 3), "value": round(cells / pcie_s / 1e6, 1), "unit": "Mdisp/s",
                                  "note": "pmx_set_images (2 float32 images up, pageable host memory) + pipeline + "
                                          "pmx_get_disparity (disp, validity int64, itp down); informational only"}
+        if world == 1 and (H, W, dmax - dmin) == (2048, 2048, 128) and not args.no_north_star:
+            # informational: BASELINE.json's north_star quotes its target on 4096x4096 Census+SGM at 1 GPU (configs[3]'s shape)
+            cv.free()
+            H4, W4, d4 = 4096, 4096, 256
+            L4, R4 = synthetic_pair(H4, W4, 0, d4, seed=20260929)
+            eng.set_images(L4, R4, 1)
+            cv4 = eng.alloc_cv(d4 + 1, 0)
+            run_pipeline(eng, cv4, win, P1, P2)
+            eng.sync()
+            t4 = time.perf_counter()
+            for _ in range(3):
+                run_pipeline(eng, cv4, win, P1, P2)
+            eng.sync()
+            ms4 = (time.perf_counter() - t4) / 3 * 1e3
+            cells4 = H4 * W4 * (d4 + 1)
+            out["north_star_shape"] = {"workload": "4096x4096 synthetic pair, d=[0,256] (D=257), same pipeline, 1 GPU, 3 steps",
+                                       "ms_per_step": round(ms4, 3), "value": round(cells4 / ms4 / 1e3, 1), "unit": "Mdisp/s",
+                                       "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells4 / (ms4 * 1e-3) / 1e9
+                                                                  / HBM_PEAK_GBS, 4)}
+            cv4.free()
         if args.cpu_rows > 0:
             rows = min(args.cpu_rows, H)
             base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)
