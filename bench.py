@@ -99,8 +99,14 @@ def main():
         import torch
         import torch.distributed as dist_mod
 
+        # test hooks only (two ranks on a 1-GPU box): PANDORA_BENCH_BACKEND=gloo, PANDORA_BENCH_DEVICE=<index>
+        backend = os.environ.get("PANDORA_BENCH_BACKEND", "nccl")
+        local_rank = int(os.environ.get("PANDORA_BENCH_DEVICE", local_rank))
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
 
     from pandora_amd.engine import Engine
@@ -137,7 +143,7 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     barrier()
@@ -226,7 +232,7 @@ def main():
                                        "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells4 / (ms4 * 1e-3) / 1e9
                                                                   / HBM_PEAK_GBS, 4)}
             cv4.free()
-        if args.cpu_rows > 0:
+        if args.cpu_rows > 0 and world == 1:  # the CPU legs belong to the N=1 line only
             rows = min(args.cpu_rows, H)
             base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)
             out["cpu_baseline"] = base
