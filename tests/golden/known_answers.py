@@ -290,3 +290,123 @@ INTERPOLATION = [
      "out_disp": [[0, 1, -2, -1, 0], [1, 0, _med(1, 1, 0, 1, -2, -1, 0, -1), 0, 0],
                   [2, 1, _med(1, 1, 0, -2, 0, -1), -2, _med(-1, -1, 1, 0, 0)], [1, 1, 1, -1, -1]]},
 ]
+
+
+# ---- more CBCA vectors (tests/test_aggregation.py) -------------------------------------------------------------
+# arms are (left, right, top, bottom) per pixel, as aggregation_cpp.cross_support returns them
+_AL3 = [[5, 1, 15, 7, 3], [10, 9, 11, 9, 6], [1, 18, 4, 5, 9]]
+_AR3 = [[1, 5, 1, 15, 7], [2, 10, 9, 11, 9], [3, 1, 18, 4, 5]]
+_AL4 = _AL3 + [[5, 1, 15, 7, 3]]
+_AR4 = _AR3 + [[1, 5, 1, 15, 7]]
+
+
+def _stack(left, right, top, bottom):
+    return [[[left[r][c], right[r][c], top[r][c], bottom[r][c]] for c in range(len(left[0]))] for r in range(len(left))]
+
+
+CROSS_SUPPORTS = [
+    dict(cite="test_aggregation.py:485-562 test_computes_cross_support (no masks)", left=_AL3, right=_AR3, msk_left=None,
+         msk_right=None, win=1, subpix=1, intensity=5.0, distance=3,
+         arms_left=_stack([[0, 1, 1, 1, 1], [0, 1, 2, 2, 2], [0, 1, 1, 1, 1]], [[1, 1, 1, 1, 0], [2, 2, 2, 1, 0], [1, 1, 1, 1, 0]],
+                          [[0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 2, 1]], [[1, 1, 1, 2, 1], [1, 1, 1, 1, 1], [0, 0, 0, 0, 0]]),
+         right_index=0,
+         arms_right=_stack([[0, 1, 2, 1, 1], [0, 1, 1, 1, 2], [0, 1, 1, 1, 1]], [[2, 1, 1, 1, 0], [1, 1, 2, 1, 0], [1, 1, 1, 1, 0]],
+                           [[0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [2, 2, 1, 1, 2]], [[2, 2, 1, 1, 2], [1, 1, 1, 1, 1], [0, 0, 0, 0, 0]])),
+    dict(cite="test_aggregation.py:564-666 test_computes_cross_support (invalid / no-data pixels)", left=_AL3, right=_AR3,
+         msk_left=[[2, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 3, 0, 0, 0]], msk_right=[[0, 0, 0, 0, 0], [0, 1, 0, 3, 0], [0, 0, 0, 0, 0]],
+         win=1, subpix=1, intensity=6.0, distance=3,
+         arms_left=_stack([[0, 0, 1, 1, 1], [0, 1, 2, 0, 0], [0, 0, 0, 1, 2]], [[0, 1, 1, 1, 0], [2, 1, 0, 0, 0], [0, 0, 2, 1, 0]],
+                          [[0, 0, 0, 0, 0], [0, 1, 1, 0, 1], [1, 0, 1, 0, 1]], [[0, 1, 1, 0, 1], [1, 0, 1, 0, 1], [0, 0, 0, 0, 0]]),
+         right_index=0,
+         arms_right=_stack([[0, 1, 2, 1, 1], [0, 0, 0, 0, 0], [0, 1, 1, 1, 1]], [[2, 1, 1, 1, 0], [0, 0, 0, 0, 0], [1, 1, 1, 1, 0]],
+                           [[0, 0, 0, 0, 0], [1, 0, 1, 0, 1], [2, 0, 1, 0, 2]], [[2, 0, 1, 0, 2], [1, 0, 1, 0, 1], [0, 0, 0, 0, 0]])),
+    dict(cite="test_aggregation.py:668-735 test_computes_cross_support_with_subpixel (half-pixel right image)", left=_AL3, right=_AR3,
+         msk_left=None, msk_right=None, win=1, subpix=2, intensity=5.0, distance=3, arms_left=None, right_index=1,
+         arms_right=_stack([[0, 1, 1, 1], [0, 1, 2, 2], [0, 1, 1, 1]], [[1, 1, 1, 0], [2, 2, 1, 0], [1, 1, 1, 0]],
+                           [[0, 0, 0, 0], [1, 1, 1, 1], [2, 1, 2, 1]], [[2, 1, 2, 1], [1, 1, 1, 1], [0, 0, 0, 0]])),
+    dict(cite="test_aggregation.py:737-808 test_computes_cross_support_with_subpixel (masks)", left=_AL3, right=_AR3,
+         msk_left=[[0, 0, 0, 0, 0], [0, 1, 0, 3, 0], [0, 0, 0, 0, 0]], msk_right=[[2, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 3, 0, 0, 0]],
+         win=1, subpix=2, intensity=6.0, distance=3, arms_left=None, right_index=1,
+         arms_right=_stack([[0, 0, 1, 1], [0, 1, 0, 0], [0, 0, 0, 1]], [[0, 1, 1, 0], [1, 0, 0, 0], [0, 0, 1, 0]],
+                           [[0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0]], [[0, 1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]])),
+    dict(cite="test_aggregation.py:810-897 test_computes_cross_support_with_offset (window 3)", left=_AL4, right=_AR4,
+         msk_left=None, msk_right=None, win=3, subpix=1, intensity=5.0, distance=3,
+         arms_left=_stack([[0, 1, 2], [0, 1, 2]], [[2, 1, 0], [2, 1, 0]], [[0, 0, 0], [1, 1, 1]], [[1, 1, 1], [0, 0, 0]]),
+         right_index=0,
+         arms_right=_stack([[0, 1, 1], [0, 1, 1]], [[1, 1, 0], [1, 1, 0]], [[0, 0, 0], [1, 1, 1]], [[1, 1, 1], [0, 0, 0]])),
+]
+
+# SAD (window `win`, `subpix`) -> cv_masked -> CBCA(intensity 5, distance 3), disparities [-1, 1]; rtol 1e-7 as in the reference
+CBCA_PIPELINES = [
+    dict(cite="test_aggregation.py:91-212 test_compute_cbca_subpixel", left=_AL3, right=_AR3, msk_left=None, msk_right=None,
+         win=1, subpix=2, disp_index=None,
+         expected=[
+             [[n, n, (4 + 4 + 8 + 1) / 4, (2 + 2 + 4 + 0.5 + 1) / 5, 0.0],
+              [(0 + 7 + 10 + 1) / 4, (2 + 12 + 3 + 1.5 + 1) / 5, (4 + 4 + 14 + 8 + 1 + 2) / 6, (2 + 2 + 7 + 4 + 0.5 + 1 + 1) / 7, 0.0],
+              [(0 + 10 + 6 + 7 + 1 + 0) / 6, (2 + 12 + 1 + 3 + 1.5 + 1 + 4) / 7, (14 + 4 + 8 + 1 + 2 + 2 + 3) / 7,
+               (2 + 7 + 4 + 4 + 0.5 + 1 + 1) / 7, 0.0],
+              [(10 + 6 + 12 + 1 + 0 + 5) / 6, (12 + 1 + 8 + 3 + 1.5 + 1 + 4 + 6 + 5.5 + 4.5) / 10, (14 + 8 + 4 + 2 + 2 + 3) / 6,
+               (7 + 4 + 0.5 + 1 + 1) / 5, 0.0],
+              [(6 + 12 + 0 + 5) / 4, (1 + 8 + 1.5 + 1 + 4) / 5, (8 + 4 + 2 + 3 + 2) / 5, n, n]],
+             [[n, n, (4 + 4 + 8 + 1 + 2 + 17) / 6, (2 + 2 + 4 + 0.5 + 1 + 1 + 8.5) / 7, 0.0],
+              [(0 + 10 + 7 + 1 + 15 + 3) / 6, (2 + 12 + 3 + 1.5 + 1 + 16 + 5.5) / 7, (4 + 4 + 14 + 8 + 1 + 2 + 2 + 17 + 14) / 9,
+               (2 + 2 + 7 + 4 + 0.5 + 1 + 1 + 1 + 8.5 + 7) / 10, 0.0],
+              [(0 + 10 + 6 + 7 + 1 + 0 + 15 + 3 + 13) / 9, (2 + 12 + 1 + 3 + 1.5 + 1 + 4 + 16 + 5.5 + 6) / 10,
+               (4 + 14 + 8 + 1 + 2 + 2 + 3 + 17 + 14 + 1) / 10, (2 + 7 + 4 + 4 + 0.5 + 1 + 1 + 8.5 + 7 + 0.5) / 10, 0.0],
+              [(10 + 6 + 12 + 1 + 0 + 5 + 3 + 13 + 5) / 9, (12 + 1 + 8 + 3 + 1.5 + 1 + 4 + 5.5 + 6 + 4.5) / 10,
+               (14 + 8 + 4 + 2 + 2 + 3 + 14 + 1 + 4) / 9, (7 + 4 + 0.5 + 1 + 1 + 7 + 0.5) / 7, 0.0],
+              [(6 + 12 + 0 + 5 + 13 + 5) / 6, (1 + 8 + 1.5 + 1 + 4 + 6 + 4.5) / 7, (2 + 8 + 4 + 2 + 3 + 1 + 4) / 7, n, n]],
+             [[n, n, (2 + 8 + 1 + 17) / 4, (4 + 0.5 + 1 + 1 + 8.5) / 5, 0.0],
+              [(7 + 1 + 15 + 3) / 4, (3 + 1.5 + 1 + 16 + 5.5) / 5, (8 + 1 + 2 + 2 + 17 + 14) / 6, (4 + 0.5 + 1 + 1 + 1 + 8.5 + 7) / 7, 0.0],
+              [(7 + 1 + 0 + 15 + 3 + 13) / 6, (3 + 1.5 + 1 + 4 + 16 + 5.5 + 6) / 7, (1 + 2 + 2 + 17 + 14 + 1 + 3) / 7,
+               (4 + 0.5 + 1 + 1 + 8.5 + 7 + 0.5) / 7, 0.0],
+              [(1 + 0 + 5 + 3 + 13 + 5) / 6, (1 + 8 + 3 + 1.5 + 1 + 4 + 5.5 + 6 + 4.5 + 12) / 10, (2 + 2 + 3 + 14 + 1 + 4) / 6,
+               (0.5 + 1 + 1 + 7 + 0.5) / 5, 0.0],
+              [(0 + 5 + 13 + 5) / 4, (1.5 + 1 + 4 + 6 + 4.5) / 5, (2 + 2 + 3 + 1 + 4) / 5, n, n]]]),
+    dict(cite="test_aggregation.py:305-390 test_compute_cbca_with_invalid_cost (slice d=0)", left=_AL4, right=_AR4,
+         msk_left=[[0, 1, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 1, 0], [3, 0, 0, 0, 0]],
+         msk_right=[[0, 0, 0, 0, 0], [0, 0, 5, 1, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]], win=1, subpix=1, disp_index=1,
+         expected=[[(4 + 8 + 1) / 3, n, (14 + 8) / 2, (8 + 14 + 4) / 3, (4 + 8 + 3) / 3],
+                   [(8 + 4 + 1 + 2 + 17) / 5, (8 + 1 + 2 + 17 + 14) / 5, n, n, (8 + 4 + 3 + 4 + 4 + 8) / 6.0],
+                   [(2 + 8 + 1 + 17) / 4, (8 + 1 + 2 + 17 + 14 + 4 + 14) / 7, (17 + 14 + 4 + 14 + 8) / 5, n, (4 + 3 + 4 + 8) / 4],
+                   [n, (4 + 2 + 17 + 14 + 14) / 5, (14 + 17 + 14 + 4 + 8) / 5, (14 + 8 + 4) / 3, (4 + 4 + 8) / 3]]),
+    dict(cite="test_aggregation.py:392-483 test_compute_cbca_with_offset (window 3)", left=_AL4, right=_AR4, msk_left=None,
+         msk_right=None, win=3, subpix=1, disp_index=None,
+         expected=[[[n, n, n]] * 5,
+                   [[n, n, n], [n, (66.0 + 63 + 66 + 63) / 4, 0.0], [55.0, (66 + 63 + 52 + 66 + 63 + 52) / 6, 0.0],
+                    [55.0, (63 + 63 + 52 + 52) / 4, n], [n, n, n]],
+                   [[n, n, n], [n, (66.0 + 63 + 66 + 63) / 4, 0.0], [55.0, (66 + 63 + 52 + 66 + 63 + 52) / 6, 0.0],
+                    [55.0, (63 + 63 + 52 + 52) / 4, n], [n, n, n]],
+                   [[n, n, n]] * 5]),
+]
+
+# ---- refinement (tests/test_refinement.py) ---------------------------------------------------------------------
+_RCV = [[[39, 32.5, 28, 34.5, 41], [49, 41.5, 37, 34, 35.5], [42.5, 40, 45, 40.5, 41], [22, 30, 45, 50, 31]]]
+_RCV_NAN = [[[39, 32.5, 28, 34.5, 41], [49, 41.5, n, 34, 35.5], [42.5, 40, n, 40.5, 41], [22, 30, 45, 50, 31]]]
+_STOP_R = 1 << 3
+_x0, _x1, _x2 = -((34.5 - 32.5) / (2 * (32.5 + 34.5 - 2 * 28))), -((35.5 - 37) / (2 * (37 + 35.5 - 2 * 34))), -((45 - 42.5) / (2 * (42.5 + 45 - 2 * 40)))
+_Q = [((32.5 + 34.5 - 2 * 28) / 2) * _x0 * _x0 + ((34.5 - 32.5) / 2) * _x0 + 28,
+      ((37 + 35.5 - 2 * 34) / 2) * _x1 * _x1 + ((35.5 - 37) / 2) * _x1 + 34,
+      ((42.5 + 45 - 2 * 40) / 2) * _x2 * _x2 + ((45 - 42.5) / 2) * _x2 + 40]
+_v0, _v1, _v2 = (32.5 - 34.5) / (2 * (34.5 - 28)), (37 - 35.5) / (2 * (37 - 34)), (42.5 - 45) / (2 * (45 - 40))
+_V = [34.5 + (_v0 - 1) * (34.5 - 28), 35.5 + (_v1 - 1) * (37 - 34), 45 + (_v2 - 1) * (45 - 40)]
+REFINEMENT = [
+    dict(cite="test_refinement.py:87-140 test_quadratic", method="quadratic", cv=_RCV, d_min=-2, d_max=2, subpix=1, disp=[[0, 1, -1, -2]],
+         out_disp=[[0 + _x0, 1 + _x1, -1 + _x2, -2]], itp=[[_Q[0], _Q[1], _Q[2], 22]], mask=[[0, 0, 0, _STOP_R]]),
+    dict(cite="test_refinement.py:142-225 test_quadratic_subpix", method="quadratic", cv=_RCV, d_min=-1, d_max=1, subpix=2,
+         disp=[[0, 0.5, -0.5, -1]], out_disp=[[0 + _x0 / 2, 0.5 + _x1 / 2, -0.5 + _x2 / 2, -1]], itp=[[_Q[0], _Q[1], _Q[2], 22]],
+         mask=[[0, 0, 0, _STOP_R]]),
+    dict(cite="test_refinement.py:227-318 test_quadratic_with_nan_and_subpix", method="quadratic", cv=_RCV_NAN, d_min=-1, d_max=1, subpix=2,
+         disp=[[0, 0.5, -0.5, -1]], out_disp=[[0 + _x0 / 2, 0.5, -0.5, -1]], itp=[[_Q[0], 34, 40, 22]],
+         mask=[[0, _STOP_R, _STOP_R, _STOP_R]]),
+    dict(cite="test_refinement.py:320-367 test_vfit", method="vfit", cv=_RCV, d_min=-2, d_max=2, subpix=1, disp=[[0, 1, -1, -2]],
+         out_disp=[[0 + _v0, 1 + _v1, -1 + _v2, -2]], itp=[[_V[0], _V[1], _V[2], 22]], mask=[[0, 0, 0, _STOP_R]]),
+    dict(cite="test_refinement.py:369-446 test_vfit_subpix", method="vfit", cv=_RCV, d_min=-1, d_max=1, subpix=2, disp=[[0, 0.5, -0.5, -1]],
+         out_disp=[[0 + _v0 / 2, 0.5 + _v1 / 2, -0.5 + _v2 / 2, -1]], itp=[[_V[0], _V[1], _V[2], 22]], mask=[[0, 0, 0, _STOP_R]]),
+    dict(cite="test_refinement.py:514-566 test_vfit_with_nan", method="vfit", cv=[[[n, n, n], [n, 2, 4], [3, 1, 4]]], d_min=-1, d_max=1,
+         subpix=1, disp=[[0, 0, 0]], out_disp=[[0, 0, 0 + ((3 - 4) / (2 * (4 - 1)))]],
+         itp=[[n, 2, 4 + (((3 - 4) / (2 * (4 - 1))) - 1) * (4 - 1)]], mask=[[0, _STOP_R, 0]]),
+    dict(cite="test_refinement.py:568-655 test_vfit_with_nan_and_subpix", method="vfit", cv=_RCV_NAN, d_min=-1, d_max=1, subpix=2,
+         disp=[[0, 0.5, -0.5, -1]], out_disp=[[0 + _v0 / 2, 0.5, -0.5, -1]], itp=[[_V[0], 34, 40, 22]],
+         mask=[[0, _STOP_R, _STOP_R, _STOP_R]]),
+]

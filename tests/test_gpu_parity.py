@@ -272,6 +272,54 @@ def test_cbca_reference_known_answer(eng):
     np.testing.assert_allclose(cv.to_host(), np.array(c["aggregated"], np.float32), rtol=1e-7)
 
 
+@pytest.mark.parametrize("case", ka.CROSS_SUPPORTS, ids=lambda c: c["cite"])
+def test_cross_supports_reference_vectors(eng, case):
+    """tests/test_aggregation.py:485-897 (computes_cross_supports): masks, half-pixel right image, window offset."""
+    L, R = np.asarray(case["left"], np.float32), np.asarray(case["right"], np.float32)
+    eng.set_images(L, R, case["subpix"])
+    if case["msk_left"] is not None:
+        eng.set_masks(np.array(case["msk_left"], np.int16), np.array(case["msk_right"], np.int16), 0, 1)
+    off = case["win"] // 2
+    if case["arms_left"] is not None:
+        np.testing.assert_array_equal(eng.cross_support(0, off, case["intensity"], case["distance"]), np.array(case["arms_left"]))
+    np.testing.assert_array_equal(eng.cross_support(1 + case["right_index"], off, case["intensity"], case["distance"]),
+                                  np.array(case["arms_right"]))
+    eng.set_masks(None, None)
+
+
+@pytest.mark.parametrize("case", ka.CBCA_PIPELINES, ids=lambda c: c["cite"])
+def test_cbca_pipeline_reference_vectors(eng, case):
+    """tests/test_aggregation.py:91-212, 305-483: SAD -> cv_masked -> CBCA with sub-pixel volumes, masks and a window offset."""
+    masks = None
+    if case["msk_left"] is not None:
+        masks = (np.array(case["msk_left"], np.int16), np.array(case["msk_right"], np.int16), 0, 1)
+    cv = gpu_cv(eng, "sad", np.array(case["left"], np.float32), np.array(case["right"], np.float32), -1, 1, case["subpix"], case["win"],
+                masks=masks)
+    eng.cbca(cv, case["win"] // 2, 5.0, 3)
+    got = cv.to_host()
+    got = got if case["disp_index"] is None else got[:, :, case["disp_index"]]
+    np.testing.assert_allclose(got, np.array(case["expected"], np.float32), rtol=1e-7)
+    eng.set_masks(None, None)
+
+
+@pytest.mark.parametrize("case", ka.REFINEMENT, ids=lambda c: c["cite"])
+def test_refinement_reference_vectors(eng, case):
+    """tests/test_refinement.py:87-655: quadratic and vfit, sub-pixel volumes, NaN neighbours, range borders."""
+    cvh = np.array(case["cv"], np.float32)
+    H, W, D = cvh.shape
+    z = np.zeros((H, W), np.float32)
+    eng.set_images(z, z, case["subpix"])
+    cv = eng.alloc_cv(D, case["d_min"])
+    cv.from_host(cvh)
+    eng.set_disparity(np.array(case["disp"], np.float32), np.zeros((H, W), np.int64))
+    eng.refine(cv, case["method"], False)
+    disp, val, itp = eng.get_disparity(want_itp=True)
+    np.testing.assert_array_equal(val, np.array(case["mask"]))
+    np.testing.assert_allclose(disp, np.array(case["out_disp"], np.float32), rtol=2e-7, atol=0)
+    np.testing.assert_allclose(itp, np.array(case["itp"], np.float32), rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(cv.to_host(), cvh)  # the volume is left untouched
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7

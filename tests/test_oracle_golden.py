@@ -230,3 +230,39 @@ def test_oracle_results_do_not_depend_on_the_thread_count(oracle):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("case", ka.CROSS_SUPPORTS, ids=lambda c: c["cite"])
+def test_cross_supports_reference_vectors(oracle, case):
+    from tests.cbca_helpers import oracle_cross_supports
+
+    L, R = np.asarray(case["left"], np.float32), np.asarray(case["right"], np.float32)
+    cl, crs = oracle_cross_supports(oracle, L, R, case["msk_left"], case["msk_right"], case["subpix"], case["win"] // 2,
+                                    case["distance"], case["intensity"])
+    assert len(crs) == case["subpix"]
+    if case["arms_left"] is not None:
+        np.testing.assert_array_equal(cl, np.array(case["arms_left"]))
+    np.testing.assert_array_equal(crs[case["right_index"]], np.array(case["arms_right"]))
+
+
+@pytest.mark.parametrize("case", ka.CBCA_PIPELINES, ids=lambda c: c["cite"])
+def test_cbca_pipeline_reference_vectors(oracle, case):
+    from tests.cbca_helpers import oracle_sad_cbca
+
+    cv = oracle_sad_cbca(oracle, case["left"], case["right"], case["msk_left"], case["msk_right"], case["win"], case["subpix"], -1, 1, 3, 5.0)
+    exp = np.array(case["expected"], np.float32)
+    got = cv if case["disp_index"] is None else cv[:, :, case["disp_index"]]
+    assert exp.shape == got.shape
+    np.testing.assert_allclose(got, exp, rtol=1e-7)
+
+
+@pytest.mark.parametrize("case", ka.REFINEMENT, ids=lambda c: c["cite"])
+def test_refinement_reference_vectors(oracle, case):
+    """tests/test_refinement.py: the expected maps are float64 formulas (the reference compares the quadratic ones with a
+    meaningless tolerance of 1e10 - 7 and the vfit ones exactly); here both within float32 rounding."""
+    cv = np.array(case["cv"], np.float32)
+    disp, val = np.array(case["disp"], np.float32), np.zeros(np.shape(case["disp"]), np.int64)
+    itp, out_disp, out_val = oracle.refine(cv, disp, val, case["d_min"], case["d_max"], case["subpix"], False, case["method"])
+    np.testing.assert_array_equal(out_val, np.array(case["mask"]))
+    np.testing.assert_allclose(out_disp, np.array(case["out_disp"], np.float32), rtol=2e-7, atol=0)
+    np.testing.assert_allclose(itp, np.array(case["itp"], np.float32), rtol=2e-7, atol=0)
