@@ -320,6 +320,27 @@ def test_refinement_reference_vectors(eng, case):
     np.testing.assert_array_equal(cv.to_host(), cvh)  # the volume is left untouched
 
 
+from tests.test_oracle_golden import CENSUS_CASES, CV_MASKED_CASES, census_case_arrays, cv_masked_case_arrays  # noqa: E402
+
+
+@pytest.mark.parametrize("case", CENSUS_CASES, ids=lambda c: c["id"])
+def test_census_parametrised_reference_cases(eng, case):
+    """tests/test_matching_cost/test_matching_cost_census.py:379-729 on the device (windows 3..13, sub-pixel volume)."""
+    L, R, dmin, dmax, exp, layer = census_case_arrays(case)
+    got = gpu_cv(eng, "census", L, R, dmin, dmax, case["subpix"], case["window_size"]).to_host()
+    np.testing.assert_array_equal(got if layer is None else got[:, :, layer], exp)
+
+
+@pytest.mark.parametrize("case", CV_MASKED_CASES, ids=lambda c: f"{c['id']}-{c['method']}")
+def test_cv_masked_parametrised_reference_cases(eng, case):
+    """tests/test_matching_cost/test_matching_cost.py:699-1786 on the device."""
+    L, R, dmin, dmax, masks, grids, exp = cv_masked_case_arrays(case)
+    cv = gpu_cv(eng, case["method"], L, R, dmin, dmax, case["subpix"], case["window_size"], masks=masks, grids=grids)
+    np.testing.assert_array_equal(np.isnan(cv.to_host()), exp)
+    eng.set_masks(None, None)
+    eng.set_disparity_grids(None, None)
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7

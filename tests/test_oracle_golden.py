@@ -266,3 +266,73 @@ def test_refinement_reference_vectors(oracle, case):
     np.testing.assert_array_equal(out_val, np.array(case["mask"]))
     np.testing.assert_allclose(out_disp, np.array(case["out_disp"], np.float32), rtol=2e-7, atol=0)
     np.testing.assert_allclose(itp, np.array(case["itp"], np.float32), rtol=2e-7, atol=0)
+
+
+import json as _json
+import os as _os
+
+with open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "census_cases.json")) as _f:
+    CENSUS_CASES = _json.load(_f)["cases"]
+
+
+def census_case_arrays(case):
+    """-> (left, right, dmin, dmax, expected [H][W] or [H][W][D], layer index or None)"""
+    exp = np.array([[[np.nan if v is None else v for v in col] if isinstance(col, list) else (np.nan if col is None else col)
+                     for col in row] for row in case["expected"]], np.float32)
+    dmin, dmax = case["disp_interval"]
+    layer = None if case["tested_layer"] == "all" else int(round((case["tested_layer"] - dmin) * case["subpix"]))
+    return np.array(case["left"], np.float32), np.array(case["right"], np.float32), dmin, dmax, exp, layer
+
+
+@pytest.mark.parametrize("case", CENSUS_CASES, ids=lambda c: c["id"])
+def test_census_parametrised_reference_cases(oracle, case):
+    """tests/test_matching_cost/test_matching_cost_census.py:379-729 (test_census): every window size 3..13, the zero-cost case
+    and the full sub-pixel volume; census -> cv_masked as in the reference test."""
+    L, R, dmin, dmax, exp, layer = census_case_arrays(case)
+    D = (dmax - dmin) * case["subpix"] + 1
+    cv = oracle.census_cost(L, R, D, dmin, case["subpix"], case["window_size"])
+    oracle.cv_masked(cv, dmin, case["subpix"], case["window_size"])
+    np.testing.assert_array_equal(cv if layer is None else cv[:, :, layer], exp)
+
+
+with open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "cv_masked_cases.json")) as _f:
+    CV_MASKED_CASES = [dict(c, method=m) for c in _json.load(_f)["cases"] for m in c["methods"]]
+
+
+def cv_masked_case_arrays(case):
+    """-> (left, right, dmin, dmax, masks tuple or None, grids tuple or None, expected NaN mask bool [H][W][D])"""
+    L, R = np.array(case["left"], np.float32), np.array(case["right"], np.float32)
+    masks = None
+    if case["left_mask"] is not None or case["right_mask"] is not None:
+        masks = (None if case["left_mask"] is None else np.array(case["left_mask"], np.int16),
+                 None if case["right_mask"] is None else np.array(case["right_mask"], np.int16), case["valid_pixels"], case["no_data_mask"])
+    grids = None
+    if "disparity_grids" in case:
+        g = np.array(case["disparity_grids"])
+        grids = (g[0].astype(np.float64), g[1].astype(np.float64))
+        dmin, dmax = int(g[0].min()), int(g[1].max())  # matching_cost.py:604-616 get_min_max_from_grid
+    else:
+        dmin, dmax = case["disparity"]
+    return L, R, dmin, dmax, masks, grids, np.array(case["expected_nan_mask"], bool)
+
+
+@pytest.mark.parametrize("case", CV_MASKED_CASES, ids=lambda c: f"{c['id']}-{c['method']}")
+def test_cv_masked_parametrised_reference_cases(oracle, case):
+    """tests/test_matching_cost/test_matching_cost.py:699-1786: every cv_masked case of the reference (window 1/3/5, subpix 1/2/4,
+    both mask conventions, per-pixel disparity grids) for every matching cost the reference runs it with."""
+    L, R, dmin, dmax, masks, grids, exp = cv_masked_case_arrays(case)
+    sp, win = case["subpix"], case["window_size"]
+    D = (dmax - dmin) * sp + 1
+    if case["method"] == "census":
+        cv = oracle.census_cost(L, R, D, dmin, sp, win)
+    elif case["method"] in ("sad", "ssd"):
+        cv = oracle.sad_ssd(L, R, D, dmin, sp, win, case["method"] == "ssd")
+    else:
+        cv = oracle.zncc(L, R, D, dmin, sp, win)
+    kw = {}
+    if masks:
+        kw.update(mskL=masks[0], mskR=masks[1], valid=masks[2], nodata=masks[3])
+    if grids:
+        kw.update(dmin=grids[0], dmax=grids[1])
+    oracle.cv_masked(cv, dmin, sp, win, **kw)
+    np.testing.assert_array_equal(np.isnan(cv), exp)
