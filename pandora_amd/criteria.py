@@ -66,9 +66,9 @@ def allocate_left_mask(cv, img_left):
     vm = cv["validity_mask"].data
     msk = img_left["msk"].data
     dil = binary_dilation_msk(img_left, cv.attrs["window_size"])
-    vm += dil.astype(np.int64) * cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
+    vm += dil.astype(vm.dtype) * vm.dtype.type(cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER)  # whatever integer type the mask has
     vm += np.where((msk != img_left.attrs["no_data_mask"]) & (msk != img_left.attrs["valid_pixels"]),
-                   cst.PANDORA_MSK_PIXEL_IN_VALIDITY_MASK_LEFT, 0).astype(np.int64)
+                   cst.PANDORA_MSK_PIXEL_IN_VALIDITY_MASK_LEFT, 0).astype(vm.dtype)
 
 
 def allocate_right_mask(cv, img_right, bit_1):
@@ -97,8 +97,8 @@ def allocate_right_mask(cv, img_right, bit_1):
         no_data_right[:, bit_1[0]] = 0
         # the reference adds the flag inside the loop (criteria.py:279-288); the counters only reach
         # n at the last iteration, so adding once here is identical
-    vm[b_2_7 == n] += cst.PANDORA_MSK_PIXEL_IN_VALIDITY_MASK_RIGHT
-    vm[no_data_right == n] += cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING
+    vm[b_2_7 == n] += vm.dtype.type(cst.PANDORA_MSK_PIXEL_IN_VALIDITY_MASK_RIGHT)
+    vm[no_data_right == n] += vm.dtype.type(cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING)
 
 
 def partially_missing_variable_ranges(disps, img_mask):

@@ -410,3 +410,19 @@ REFINEMENT = [
          disp=[[0, 0.5, -0.5, -1]], out_disp=[[0 + _v0 / 2, 0.5, -0.5, -1]], itp=[[_V[0], 34, 40, 22]],
          mask=[[0, _STOP_R, _STOP_R, _STOP_R]]),
 ]
+
+
+# ---- more WTA vectors (tests/test_disparity.py; images of its setUp = WTA["left"] / WTA["right"]) --------------------
+_B = -99
+WTA_MORE = [
+    dict(cite="test_disparity.py:255-292 test_to_disp_with_offset [-3, 1]", method="sad", win=3, subpix=1, dmin=-3, dmax=1, masked=True,
+         is_max=False, invalid=-99, disp=[[_B, _B, _B, _B], [_B, 1, 0, _B], [_B, _B, _B, _B]]),
+    dict(cite="test_disparity.py:294-323 test_to_disp_with_offset [-3, -1]", method="sad", win=3, subpix=1, dmin=-3, dmax=-1, masked=True,
+         is_max=False, invalid=-99, disp=[[_B, _B, _B, _B], [_B, _B, -1, _B], [_B, _B, _B, _B]]),
+    dict(cite="test_disparity.py:325-365 test_to_disp_with_offset [1, 3]", method="sad", win=3, subpix=1, dmin=1, dmax=3, masked=True,
+         is_max=False, invalid=-99, disp=[[_B, _B, _B, _B], [_B, 1, _B, _B], [_B, _B, _B, _B]]),
+    dict(cite="test_disparity.py:372-399 test_argmin_split (sub-pixel volume, NaN as +inf)", method="sad", win=1, subpix=2, dmin=-3, dmax=1,
+         masked=False, is_max=False, invalid=0, disp=[[1.0, 1.0, 1.0, -3.0], [1.0, -0.5, 1.0, -3.0], [1.0, 1.0, -1.5, -3]]),
+    dict(cite="test_disparity.py:401-430 test_argmax_split (zncc, NaN as -inf, first maximum)", method="zncc", win=1, subpix=2, dmin=-3,
+         dmax=1, masked=False, is_max=True, invalid=0, disp=[[0.0, -1.0, -2.0, -3.0]] * 3),
+]

@@ -341,6 +341,17 @@ def test_cv_masked_parametrised_reference_cases(eng, case):
     eng.set_disparity_grids(None, None)
 
 
+@pytest.mark.parametrize("case", ka.WTA_MORE, ids=lambda c: c["cite"])
+def test_wta_more_reference_vectors(eng, case):
+    """tests/test_disparity.py:255-430: window offset (invalid frame), sub-pixel volumes, first minimum / first maximum."""
+    L, R = np.array(ka.WTA["left"], np.float32), np.array(ka.WTA["right"], np.float32)
+    cv = gpu_cv(eng, case["method"], L, R, case["dmin"], case["dmax"], case["subpix"], case["win"], masked=case["masked"])
+    eng.set_validity(None)
+    eng.wta(cv, case["is_max"], float(case["invalid"]))
+    disp, _ = eng.get_disparity()
+    np.testing.assert_array_equal(disp, np.array(case["disp"], np.float32))
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7

@@ -336,3 +336,15 @@ def test_cv_masked_parametrised_reference_cases(oracle, case):
         kw.update(dmin=grids[0], dmax=grids[1])
     oracle.cv_masked(cv, dmin, sp, win, **kw)
     np.testing.assert_array_equal(np.isnan(cv), exp)
+
+
+@pytest.mark.parametrize("case", ka.WTA_MORE, ids=lambda c: c["cite"])
+def test_wta_more_reference_vectors(oracle, case):
+    L, R = np.array(ka.WTA["left"], np.float32), np.array(ka.WTA["right"], np.float32)
+    sp, win, dmin, dmax = case["subpix"], case["win"], case["dmin"], case["dmax"]
+    D = (dmax - dmin) * sp + 1
+    cv = oracle.zncc(L, R, D, dmin, sp, win) if case["method"] == "zncc" else oracle.sad_ssd(L, R, D, dmin, sp, win, False)
+    if case["masked"]:
+        oracle.cv_masked(cv, dmin, sp, win)
+    disp, _ = oracle.wta(cv, dmin, sp, case["is_max"], float(case["invalid"]))
+    np.testing.assert_array_equal(disp, np.array(case["disp"], np.float32))
