@@ -134,6 +134,18 @@ class AbstractMatchingCost:
         return runtime.get_engine().reverse_disp_range(np.asarray(left_min, np.float32), np.asarray(left_max, np.float32))
 
     @abstractmethod
+    def point_interval(self, img_left, img_right, disp):
+        """matching_cost.py:429-482: the column ranges ((p0, p1), (q0, q1)) of the left / right image over which the measure is
+        applied for the disparity ``disp`` (floating disparities round away from the image, an out-of-image disparity gives the
+        empty range (nx, nx)).  The kernels apply the same overlap rule per cell; this is the host-side statement of it."""
+        from math import ceil, floor
+
+        nx_left, nx_right = int(img_left.sizes["col"]), int(img_right.sizes["col"])
+        point_p = (nx_left, nx_left) if abs(disp) > nx_left else (max(0 - disp, 0), min(nx_left - disp, nx_left))
+        point_q = (nx_right, nx_right) if abs(disp) > nx_right else (max(0 + disp, 0), min(nx_right + disp, nx_right))
+        rnd = ceil if disp < 0 else floor
+        return (int(rnd(point_p[0])), int(rnd(point_p[1]))), (int(rnd(point_q[0])), int(rnd(point_q[1])))
+
     def compute_cost_volume(self, img_left, img_right, cost_volume):
         """Fill cost_volume["cost_volume"] for the pair; returns the dataset."""
 

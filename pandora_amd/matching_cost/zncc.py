@@ -13,6 +13,14 @@ class Zncc(AbstractMatchingCost):
             raise ConfigError("window_size must be an odd positive int")
         return cfg
 
+    def point_interval(self, img_left, img_right, disp):
+        """zncc.py:73-112: empty ranges as soon as abs(disp) > nb_col - 2 * (window_size // 2)"""
+        point_p, point_q = super().point_interval(img_left, img_right, disp)
+        nx_left, nx_right = int(img_left.sizes["col"]), int(img_right.sizes["col"])
+        if abs(disp) > nx_right - (int(self._window_size / 2) * 2):
+            point_p, point_q = (nx_left, nx_left), (nx_right, nx_right)
+        return point_p, point_q
+
     def compute_cost_volume(self, img_left, img_right, cost_volume):
         eng, dcv = self._bind_device_volume(img_left, img_right, cost_volume)
         cost_volume.attrs.update({"type_measure": "max", "cmax": 1})  # zncc.py:171-176

@@ -326,3 +326,17 @@ def test_product_never_touches_the_oracle():
                     bad.append(os.path.join(dirpath, fn))
     assert not bad, f"product files reference the oracle: {bad}"
     assert "pandora_amd" in pandora_amd.__name__
+
+
+# test_matching_cost.py:110-195 (census / sad / ssd) and test_matching_cost_zncc.py:315-397 (zncc), 6-column images, window 3
+_PI = [(0, (0, 6), (0, 6)), (-2, (2, 6), (0, 4)), (2, (0, 4), (2, 6)), (-2.5, (3, 6), (0, 4)), (2.5, (0, 3), (2, 6)),
+       (7, (6, 6), (6, 6)), (-7, (6, 6), (6, 6))]
+
+
+@pytest.mark.parametrize("method", ["census", "sad", "ssd", "zncc"])
+def test_point_interval_like_the_reference(method):
+    img = make_image(np.zeros((5, 6)), disparity=[-2, 2])
+    m = matching_cost.AbstractMatchingCost(matching_cost_method=method, window_size=3, subpix=1)
+    last = [(5, (6, 6), (6, 6)), (-5, (6, 6), (6, 6))] if method == "zncc" else [(5, (0, 1), (5, 6)), (-5, (5, 6), (0, 1))]
+    for disp, p, q in _PI + last:
+        assert m.point_interval(img, img, disp) == (p, q), (method, disp)
