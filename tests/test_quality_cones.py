@@ -247,3 +247,50 @@ def test_validation_with_interpolated_disparity(oracle, method):
     vm = outs[method][0]["validity_mask"].data
     assert (outs[None][0]["validity_mask"].data & 0x300).any() and not (vm & 0x300).any() and (vm & 0x30).any()
     assert error(np.nan_to_num(outs[method][0]["disparity_map"].data, nan=1e4), gt_left, 1) <= 0.20
+
+
+FUNCTIONAL_RANGES = [  # tests/test_matching_cost/test_matching_cost_functional.py:47-125 (cones is 450 columns wide)
+    ([-60, 0], 5), ([0, 60], 5), ([-452, -445], 5), ([445, 452], 5), ([445, 448], 5), ([-448, -445], 5),
+    ([-60, 0], 3), ([0, 60], 3), ([-452, -445], 3), ([445, 452], 3), ([445, 449], 3), ([-449, -445], 3)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["census", "sad", "ssd", "zncc"])
+@pytest.mark.parametrize("subpix", [1, 2, 4])
+def test_functional_matching_cost_matrix(oracle, method, subpix):
+    """The reference's functional matrix of the matching-cost step: every measure x subpix x disparity ranges inside, across and
+    entirely outside the image, through PandoraMachine (matching_cost + wta).  The reference only asserts that it runs; here
+    the narrow ranges (cheap for the oracle) are also compared with the oracle, the wide ones checked for range and shape."""
+    import pandora_amd
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, _ = load_cones()
+    for disp, win in FUNCTIONAL_RANGES:
+        left, right = make_image(L, disparity=disp), make_image(R)
+        cfg = {"pipeline": {"matching_cost": {"matching_cost_method": method, "window_size": win, "subpix": subpix},
+                            "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"}}}
+        machine = PandoraMachine()
+        cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+        dl, _ = pandora_amd.run(machine, left, right, cfg)
+        d = dl["disparity_map"].data
+        assert d.shape == L.shape and dl["validity_mask"].data.shape == L.shape
+        ok = np.isfinite(d)
+        assert np.all(d[ok] >= disp[0]) and np.all(d[ok] <= disp[1])
+        if disp[1] - disp[0] > 10:
+            assert ok[win:-win, 70:-70].all()
+            continue
+        D = (disp[1] - disp[0]) * subpix + 1
+        if method == "census":
+            cv = oracle.census_cost(L, R, D, disp[0], subpix, win)
+        elif method == "zncc":
+            cv = oracle.zncc(L, R, D, disp[0], subpix, win)
+        else:
+            cv = oracle.sad_ssd(L, R, D, disp[0], subpix, win, method == "ssd")
+        oracle.cv_masked(cv, disp[0], subpix, win)
+        exp, _ = oracle.wta(cv, disp[0], subpix, method == "zncc", np.nan)
+        np.testing.assert_array_equal(np.isnan(d), np.isnan(exp))
+        same = d[ok] == exp[ok]
+        assert same.all() if method != "zncc" else same.mean() > 0.999, (method, subpix, disp, win)
+        if abs(disp[0]) > 450 - 2 * (win // 2) and abs(disp[1]) > 450 - 2 * (win // 2):
+            assert not ok.any() and np.all(dl["validity_mask"].data & 0x3C3)   # nothing to match: every pixel invalid
