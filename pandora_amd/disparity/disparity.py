@@ -40,6 +40,24 @@ class AbstractDisparity:
         """Disparity computation and validity mask; returns the disparity dataset."""
 
 
+def extract_disparity_interval_from_cost_volume(cost_volume):
+    """disparity.py:301-315: DataArray [min, max] of the cost volume's disparity coordinates."""
+    d = np.asarray(cost_volume.coords["disp"])
+    return DataArray(np.array([d[0], d[-1]]), ("disparity",), {"disparity": ["min", "max"]})
+
+
+def extract_interval_from_disparity_map(disparity_map):
+    """disparity.py:318-331 -> (int min, int max)"""
+    disparity_min, disparity_max = np.asarray(disparity_map["disparity_interval"].data)
+    return int(disparity_min), int(disparity_max)
+
+
+def extract_disparity_range_from_disparity_map(disparity_map):
+    """disparity.py:334-348: np.arange(min, max + 1)"""
+    disparity_min, disparity_max = extract_interval_from_disparity_map(disparity_map)
+    return np.arange(disparity_min, disparity_max + 1)
+
+
 @AbstractDisparity.register_subclass("wta")
 class WinnerTakesAll(AbstractDisparity):
     _INVALID_DISPARITY = -9999
@@ -77,8 +95,7 @@ class WinnerTakesAll(AbstractDisparity):
         disp, validity = eng.get_disparity()
         coords = {"row": cv.coords["row"], "col": cv.coords["col"]}
         disp_map = Dataset({"disparity_map": (("row", "col"), disp)}, coords=coords)
-        d = np.asarray(cv.coords["disp"])
-        disp_map["disparity_interval"] = DataArray(np.array([d[0], d[-1]]), ("disparity",))  # disparity.py:301-315
+        disp_map["disparity_interval"] = extract_disparity_interval_from_cost_volume(cv)
         cv["disp_indices"] = DataArray(disp.copy(), ("row", "col"))
         disp_map.attrs = dict(cv.attrs)
         if "confidence_measure" in cv.data_vars:

@@ -340,3 +340,16 @@ def test_point_interval_like_the_reference(method):
     last = [(5, (6, 6), (6, 6)), (-5, (6, 6), (6, 6))] if method == "zncc" else [(5, (0, 1), (5, 6)), (-5, (5, 6), (0, 1))]
     for disp, p, q in _PI + last:
         assert m.point_interval(img, img, disp) == (p, q), (method, disp)
+
+
+def test_disparity_interval_helpers():  # tests/test_disparity.py:642-740
+    from pandora_amd.dataset import Dataset
+    from pandora_amd.disparity import disparity as dmod
+
+    cv = Dataset({}, coords={"row": np.arange(2), "col": np.arange(3), "disp": np.array([-2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0])})
+    interval = dmod.extract_disparity_interval_from_cost_volume(cv)
+    np.testing.assert_array_equal(interval.data, [-2.0, 1.0])
+    assert list(interval.coords["disparity"]) == ["min", "max"]
+    disp = Dataset({"disparity_interval": interval})
+    assert dmod.extract_interval_from_disparity_map(disp) == (-2, 1)
+    np.testing.assert_array_equal(dmod.extract_disparity_range_from_disparity_map(disp), [-2, -1, 0, 1])
