@@ -101,23 +101,29 @@ class AbstractMatchingCost:
         rng = np.arange(disparity_min, disparity_max, 1 / float(subpix), dtype=np.float64)
         return np.append(rng, [disparity_max])
 
-    def allocate_cost_volume(self, image, disparity_grids, cfg=None):
-        """matching_cost.py:377-407: dataset with a NaN-filled float32 (row, col, disp) volume -
-        allocated in HBM - plus the attrs later steps read."""
+    def grid_estimation(self, img, cfg, disparity_grids):
+        """matching_cost.py:330-375: the dataset (coords row / col / disp, the image's attrs, sampling_interval,
+        col_to_compute) that will hold the cost volume."""
         if cfg and "ROI" in cfg:
             raise ConfigError("ROI tiling is out of scope of pandora_amd (SURVEY 8: margins/ROI are caller-side)")
-        dmin, dmax = self.get_min_max_from_grid(np.asarray(disparity_grids[0].data if hasattr(disparity_grids[0], "data") else disparity_grids[0]),
-                                                np.asarray(disparity_grids[1].data if hasattr(disparity_grids[1], "data") else disparity_grids[1]))
-        disparity_range = self.get_disparity_range(dmin, dmax, self._subpix)
-        c_col = np.asarray(image.coords["col"])
+        c_col = np.asarray(img.coords["col"])
         index_compute_col = np.arange(c_col[0], c_col[-1] + 1, self._step_col)
-        cv = Dataset(coords={"row": image.coords["row"], "col": index_compute_col, "disp": disparity_range}, attrs=dict(image.attrs))
-        cv.attrs["sampling_interval"] = self._step_col
-        cv.attrs["col_to_compute"] = index_compute_col
+        grids = [np.asarray(g.data if hasattr(g, "data") and not isinstance(g, np.ndarray) else g) for g in disparity_grids]
+        disparity_min, disparity_max = self.get_min_max_from_grid(grids[0], grids[1])
+        disparity_range = self.get_disparity_range(disparity_min, disparity_max, self._subpix)
+        grid = Dataset(coords={"row": img.coords["row"], "col": index_compute_col, "disp": disparity_range}, attrs=dict(img.attrs))
+        grid.attrs["sampling_interval"] = self._step_col
+        grid.attrs["col_to_compute"] = index_compute_col
+        return grid
+
+    def allocate_cost_volume(self, image, disparity_grids, cfg=None):
+        """matching_cost.py:377-407: grid_estimation + the attrs later steps read.  The reference fills a NaN float32
+        (row, col, disp) array here; this build allocates the volume in HBM when compute_cost_volume binds it to the pair."""
+        cv = self.grid_estimation(image, cfg, disparity_grids)
         cv.attrs.update({"window_size": self._window_size, "subpixel": self._subpix, "band_correl": self._band,
                          "offset_row_col": int((self._window_size - 1) / 2), "measure": self._method})
-        # the device volume is bound to the engine in compute_cost_volume (it needs the pair resident)
-        cv.attrs["_d0"] = dmin
+        disparity_range = np.asarray(cv.coords["disp"])
+        cv.attrs["_d0"] = int(disparity_range[0])
         cv.attrs["_D"] = len(disparity_range)
         return cv
 
