@@ -386,41 +386,6 @@ def test_full_size_properties(eng, oracle):
     np.testing.assert_array_equal(mid[:64], mid[64:])
 
 
-@pytest.mark.parametrize("is_max", [False, True])
-def test_d_sharded_wta_keys_equal_full_wta(eng, oracle, is_max):
-    """per-shard packed (cost, global index) keys merged with MIN == WTA on the full volume
-    (here the two shards are reduced on one GPU; the RCCL all_reduce(MIN) does the same across GPUs)."""
-    pytest.skip("moved to tests/test_gpu_dist.py (torch must be imported before libpandora_amd.so)")
-    torch = pytest.importorskip("torch")
-    from pandora_amd import dist as pdist
-
-    rng = np.random.default_rng(12)
-    H, W, dmin, dmax = 17, 29, -9, 6
-    D = dmax - dmin + 1
-    cvh = rng.integers(0, 4, (H, W, D)).astype(np.float32) - 1.0  # negative, zero and positive costs with ties
-    cvh[rng.random(cvh.shape) < 0.2] = np.nan
-    cvh[3, 4] = np.nan
-    z = np.zeros((H, W), np.float32)
-    eng.set_images(z, z, 1)
-    merged = None
-    for rank in range(2):
-        (lo, hi), _ = pdist.disparity_shard(dmin, dmax, 1, 2, rank)
-        shard = eng.alloc_cv(hi - lo + 1, lo)
-        shard.from_host(np.ascontiguousarray(cvh[:, :, lo - dmin:hi - dmin + 1]))
-        keys = torch.empty(H * W, dtype=torch.int64, device="cuda:0")
-        torch.cuda.synchronize()
-        eng.wta_minkey(shard, is_max, lo - dmin, keys.data_ptr())
-        eng.sync()
-        merged = keys if merged is None else torch.minimum(merged, keys)
-    torch.cuda.synchronize()
-    eng.set_validity(None)
-    eng.wta_from_keys(merged.data_ptr(), dmin, 1, -9999.0)
-    disp, val = eng.get_disparity()
-    edisp, eval_ = oracle.wta(cvh, dmin, 1, is_max, -9999.0)
-    np.testing.assert_array_equal(disp, edisp)
-    np.testing.assert_array_equal(val, eval_)
-
-
 @pytest.mark.parametrize("gl,kpl,dmin,dmax", [
     (16, 4, -20, 6), (16, 5, -40, 30), (16, 8, -3, 100), (16, 9, 0, 128), (16, 12, -100, 80), (16, 13, -97, 100),
     (16, 16, -120, 120), (16, 17, 0, 256), (16, 20, -150, 150),
