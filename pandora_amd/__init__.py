@@ -35,3 +35,57 @@ def import_plugin():
     group = eps.select(group="pandora.plugin") if hasattr(eps, "select") else eps.get("pandora.plugin", [])
     for ep in group:
         ep.load()
+
+
+def check_datasets(left, right):
+    """check_configuration.py:112-167: images present, a disparity range on the left with min <= max, same shapes."""
+    import numpy as np
+
+    for ds in (left, right):
+        if "im" not in ds.data_vars:
+            raise AttributeError("User must provide an image im")
+        if "msk" in ds.data_vars and np.asarray(ds["im"].data).shape[-2:] != np.asarray(ds["msk"].data).shape[-2:]:
+            raise ValueError(" im and msk must have the same shape")
+        missing = {"no_data_img", "valid_pixels", "no_data_mask", "crs", "transform"} - set(ds.attrs)
+        if missing:
+            raise AttributeError(f"User must provide the {missing} attribute(s)")
+    if "disparity" not in left.data_vars:
+        raise AttributeError("left dataset must have disparity DataArray")
+    grids = np.asarray(left["disparity"].data)
+    if (grids[0] > grids[1]).any():
+        raise AttributeError("Disp_max grid must be bigger than Disp_min grid for each pixel")
+    if np.asarray(left["im"].data).shape[-2:] != np.asarray(right["im"].data).shape[-2:]:
+        raise AttributeError("left and right datasets must have the same shape")
+
+
+def main(cfg_path, output, verbose=False):
+    """The reference's pandora.main (__init__.py:151-202) for single-band inputs: read the JSON configuration, build the
+    two image datasets, check, run the pipeline on the GPU, write left_/right_ disparity.tif, validity_mask.tif,
+    confidence_measure.tif and cfg/config.json into ``output``."""
+    import json
+    import logging
+
+    from . import common
+    from .img_tools import create_dataset_from_inputs
+    from .state_machine import PandoraMachine
+
+    with open(cfg_path) as f:
+        user_cfg = json.load(f)
+    logging.basicConfig(level=logging.INFO if verbose else logging.WARNING)
+    import_plugin()
+    inputs = {"left": {"nodata": -9999, "mask": None, "classif": None, "segm": None, "edges": None},
+              "right": {"nodata": -9999, "mask": None, "classif": None, "segm": None, "edges": None, "disp": None}}
+    for side in inputs:  # check_configuration.py:634-652 default_short_configuration_input
+        inputs[side].update(user_cfg["input"][side])
+    if inputs["right"]["disp"] is None and not isinstance(inputs["left"]["disp"], str):
+        inputs["right"]["disp"] = [-inputs["left"]["disp"][1], -inputs["left"]["disp"][0]]
+    img_left = create_dataset_from_inputs(input_config=inputs["left"])
+    img_right = create_dataset_from_inputs(input_config=inputs["right"])
+    check_datasets(img_left, img_right)
+    machine = PandoraMachine()
+    cfg = {"input": inputs, "pipeline": user_cfg["pipeline"]}
+    cfg["pipeline"] = machine.check_conf(cfg, img_left, img_right)["pipeline"]
+    left, right = run(machine, img_left, img_right, cfg)
+    common.save_results(left, right, output)
+    common.save_config(output, cfg)
+    return left, right

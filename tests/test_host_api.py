@@ -353,3 +353,56 @@ def test_disparity_interval_helpers():  # tests/test_disparity.py:642-740
     disp = Dataset({"disparity_interval": interval})
     assert dmod.extract_interval_from_disparity_map(disp) == (-2, 1)
     np.testing.assert_array_equal(dmod.extract_disparity_range_from_disparity_map(disp), [-2, -1, 0, 1])
+
+
+# ---- image datasets from files (tests/test_pandora_image.py:369-461) ---------------------------------------
+def test_create_dataset_from_inputs_reference_vectors():
+    from pandora_amd import check_datasets, img_tools
+
+    gold = os.path.join(ROOT, "tests", "golden", "image")
+    mask_gt = np.array([[1, 0, 2, 2, 1], [0, 0, 0, 0, 2], [1, 1, 0, 0, 2], [0, 0, 2, 0, 1]])
+    left_img = np.array([[-9999.0, 1.0, 2.0, 3.0, -9999.0], [5.0, 6.0, 7.0, 8.0, 9.0], [-9999.0, -9999.0, 23.0, 5.0, 6.0],
+                         [12.0, 5.0, 6.0, 3.0, -9999.0]], np.float32)
+    for name, nodata in (("left_img.tif", -9999), ("left_img_nan.tif", np.nan)):
+        ds = img_tools.create_dataset_from_inputs({"img": os.path.join(gold, name), "nodata": nodata,
+                                                   "mask": os.path.join(gold, "mask_left.tif"), "disp": [-60, 0]})
+        np.testing.assert_array_equal(ds["msk"].data, mask_gt)
+        np.testing.assert_array_equal(ds["im"].data, left_img)
+        assert ds["msk"].data.dtype == np.int16 and ds["im"].data.dtype == np.float32
+        assert ds.attrs["no_data_img"] == -9999 and ds.attrs["disparity_source"] == [-60, 0]
+        assert ds["disparity"].data.shape == (2, 4, 5) and (ds["disparity"].data[0] == -60).all() and (ds["disparity"].data[1] == 0).all()
+        check_datasets(ds, ds)
+    # no mask and no no-data pixel: no msk at all (img_tools.py:283-285); inf as no-data (test_pandora_image.py:631-668)
+    ds = img_tools.create_dataset_from_inputs({"img": os.path.join(gold, "left_img.tif"), "nodata": 12345, "disp": [0, 2]})
+    assert "msk" not in ds.data_vars
+    with pytest.raises(NotImplementedError):
+        img_tools.create_dataset_from_inputs({"img": os.path.join(gold, "left_img.tif"), "nodata": 0, "classif": "x.tif"})
+    with pytest.raises(AttributeError):
+        check_datasets(img_tools.create_dataset_from_inputs({"img": os.path.join(gold, "left_img.tif"), "nodata": 0}), ds)
+
+
+def test_save_results_writes_the_reference_tree(tmp_path):
+    from PIL import Image
+
+    from pandora_amd import common
+    from pandora_amd.dataset import Dataset
+
+    rng = np.random.default_rng(0)
+    disp = rng.normal(size=(6, 7)).astype(np.float32)
+    disp[0, 0] = np.nan
+    conf = rng.random((6, 7, 2)).astype(np.float32)
+    left = Dataset({"disparity_map": (("row", "col"), disp), "validity_mask": (("row", "col"), rng.integers(0, 4096, (6, 7))),
+                    "confidence_measure": (("row", "col", "indicator"), conf)},
+                   coords={"row": np.arange(6), "col": np.arange(7), "indicator": ["a", "b"]}, attrs={"crs": None, "transform": None})
+    common.save_results(left, Dataset(), str(tmp_path))
+    common.save_config(str(tmp_path), {"pipeline": {"x": {"y": np.int64(3)}}})
+    assert sorted(os.listdir(tmp_path)) == ["cfg", "left_confidence_measure.tif", "left_disparity.tif", "left_validity_mask.tif"]
+    np.testing.assert_array_equal(np.array(Image.open(tmp_path / "left_disparity.tif")), disp)
+    vm = np.array(Image.open(tmp_path / "left_validity_mask.tif"))
+    assert vm.dtype == np.uint16
+    np.testing.assert_array_equal(vm, left["validity_mask"].data)
+    with Image.open(tmp_path / "left_confidence_measure.tif") as im:
+        assert im.n_frames == 2
+        im.seek(1)
+        np.testing.assert_array_equal(np.array(im), conf[:, :, 1])
+    assert json.load(open(tmp_path / "cfg" / "config.json"))["pipeline"]["x"]["y"] == 3

@@ -294,3 +294,33 @@ def test_functional_matching_cost_matrix(oracle, method, subpix):
         assert same.all() if method != "zncc" else same.mean() > 0.999, (method, subpix, disp, win)
         if abs(disp[0]) > 450 - 2 * (win // 2) and abs(disp[1]) > 450 - 2 * (win // 2):
             assert not ok.any() and np.all(dl["validity_mask"].data & 0x3C3)   # nothing to match: every pixel invalid
+
+
+@pytest.mark.gpu
+def test_main_runs_the_sample_configuration_from_files(tmp_path):
+    """The reference's command line flow (pandora.main, __init__.py:151-202) on data_samples/json_conf_files/
+    a_local_block_matching.json as written (BASELINE configs[0]): images read from files, results and the checked
+    configuration written in the reference's output tree; the maps read back meet the reference's 20 % gate."""
+    import json
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    cfg = {"input": {"left": {"img": os.path.join(CONES, "left.png"), "disp": [-60, 0]}, "right": {"img": os.path.join(CONES, "right.png")}},
+           "pipeline": SAMPLE_LOCAL["pipeline"]}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    out = tmp_path / "out"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-m", "pandora_amd", str(tmp_path / "cfg.json"), str(out)], cwd=root, capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert sorted(os.listdir(out)) == ["cfg", "left_confidence_measure.tif", "left_disparity.tif", "left_validity_mask.tif",
+                                       "right_confidence_measure.tif", "right_disparity.tif", "right_validity_mask.tif"]
+    _, _, gt_left = load_cones()
+    left = np.array(Image.open(out / "left_disparity.tif"))
+    assert left.dtype == np.float32 and np.array(Image.open(out / "left_validity_mask.tif")).dtype == np.uint16
+    assert error(np.nan_to_num(left, nan=1e4), gt_left, 1) <= 0.20
+    saved = json.load(open(out / "cfg" / "config.json"))
+    assert saved["pipeline"]["validation"]["cross_checking_threshold"] == 1.0 and saved["input"]["right"]["disp"] == [0, 60]
+    assert saved["pipeline"]["matching_cost"]["subpix"] == 4 and saved["input"]["left"]["nodata"] == -9999
