@@ -20,7 +20,8 @@
 //
 // The path kernel is HBM-bound (9.3 GB per launch at C3, 4.4 of them the 8 reads of the cost bytes) with issue slots to
 // spare, so when every cost fits 5 bits (invalid_cost <= 31: census windows up to 5x5) the costs are stored SIX per dword
-// (CBITS = 5): a lane's 12 costs are 8 bytes instead of 12, unpacked with v_bfe_u32 (+15 instructions per step).
+// (CBITS = 5): a lane's 12 costs are 8 bytes instead of 12, laid out so that one shift + v_and_or_b32 yields a (lo16, hi16)
+// register of the recurrence (three such pairs per dword).
 #include <cstdlib>
 
 #include "pmx_internal.h"
@@ -88,7 +89,14 @@ __global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) pop += __popc(lc[w] ^ rc[k * NW + w]);
             const uint32_t v = (pix_ok && (u + (uint32_t)k < wvalid)) ? pop : a.invalid_cost;
-            out[k / PER] |= v << (CBITS * (k % PER));
+            if (CBITS == 8) {
+                out[k / 4] |= v << (8 * (k % 4));
+            } else {
+                // five-bit costs sit where the path kernel wants them: pair j = (cost 4q+i, cost 4q+i+2), i = j & 1, is the
+                // (lo16, hi16) couple of one register, three pairs per dword at bits 0 / 5 / 10 of each half
+                const int j = 2 * (k / 4) + (k & 1), half = (k >> 1) & 1;
+                out[j / 3] |= v << (5 * (j % 3) + 16 * half);
+            }
         }
         if (lane_active) __builtin_memcpy(a.cost + pix * a.Dp + (size_t)sub * NDW * 4, out, 4 * NDW);
     }
@@ -185,10 +193,10 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
             if (CBITS == 8) {
                 ccA = (s.x[q] & 0x00ff00ffu) | padA[q];
                 ccB = ((s.x[q] >> 8) & 0x00ff00ffu) | padB[q];
-            } else {
-                auto cost5 = [&](int k) { return __builtin_amdgcn_ubfe(s.x[k / 6], 5 * (k % 6), 5); };
-                ccA = (cost5(4 * q) | (cost5(4 * q + 2) << 16)) | padA[q];
-                ccB = (cost5(4 * q + 1) | (cost5(4 * q + 3) << 16)) | padB[q];
+            } else {  // pair j of the lane: bits 5*(j%3) of both halves of dword j/3 (see census_cost_u8_kernel)
+                constexpr uint32_t m5 = 0x001f001fu;
+                ccA = ((s.x[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
+                ccB = ((s.x[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
             }
             // neighbours: A = (d, d+2) has lo = (d-1, d+1), hi = (d+1, d+3) = B;  B has lo = A, hi = (d+2, d+4)
             const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
