@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
-BENCH="python bench.py --steps 5 --warmup 2 --cpu-rows 0"
+BENCH="python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-north-star"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o kt -- $BENCH > $OUT/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write -- $BENCH > $OUT/write.log 2>&1
