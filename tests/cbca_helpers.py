@@ -2,13 +2,13 @@
 import numpy as np
 
 
-def oracle_cross_supports(oracle, L, R, msk_left, msk_right, subpix, offset, distance, intensity):
-    """-> (left arms, [right arms per sub-pixel phase]); masked pixels (msk != valid_pixels = 0) become NaN before the 3x3
+def oracle_cross_supports(oracle, L, R, msk_left, msk_right, subpix, offset, distance, intensity, valid=0):
+    """-> (left arms, [right arms per sub-pixel phase]); masked pixels (msk != valid_pixels) become NaN before the 3x3
     nanmedian, a half-pixel sample is masked when either neighbour is (cbca.py:246-262)."""
     def arms(im, msk, shifted):
         m = np.array(im, np.float32, copy=True)
         if msk is not None:
-            bad = np.asarray(msk) != 0
+            bad = np.asarray(msk) != valid
             if shifted:
                 bad = bad[:, :-1] | bad[:, 1:]
             m[bad] = np.nan
