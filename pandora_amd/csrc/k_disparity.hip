@@ -170,6 +170,9 @@ __global__ __launch_bounds__(kBlock) void refine_kernel(const float* __restrict_
     int64_t m = validity[i];
     if ((m & MSK_INVALID) != 0) { itp[i] = d_nan(); return; }
     float raw = disp[i];
+    // a disparity outside the volume (a map edited by the caller; the reference would read out of bounds, refinement.cpp:56-60)
+    // is left alone, with a NaN coefficient
+    if (!((double)raw >= d_min && (double)raw <= d_max)) { itp[i] = d_nan(); return; }
     int k = (int)(((double)raw - d_min) * (double)subpix);
     const float* p = cv + i * (size_t)D;
     float c1 = p[k];

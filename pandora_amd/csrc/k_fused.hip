@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256) void sum8_refine_kernel(sum8_args a, size_t np
     if ((m & FMSK_INVALID) != 0) { itp[i] = g_nan(); return; }
     const int r = (int)(i / a.W), c = (int)(i - (size_t)r * a.W);
     float raw = disp[i];
+    if (!((double)raw >= d_min && (double)raw <= d_max)) { itp[i] = g_nan(); return; }  // as refine_kernel: never index outside the volume
     int k = (int)(((double)raw - d_min) * 1.0);
     // the WTA step left (S[k-1], S[k], S[k+1], k) of its winner; if the disparity map was edited on
     // the host since (a filter), fall back to gathering from the eight volumes

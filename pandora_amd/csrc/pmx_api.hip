@@ -206,6 +206,7 @@ extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* righ
         PMX_HIP(hipMalloc(&ctx->near, n * 16));
     }
     ctx->near_owner = nullptr;
+    ctx->disp_ready = false;
     PMX_HIP(hipMemcpyAsync(ctx->left, left, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipMemcpyAsync(ctx->right[0], right, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     for (int k = 1; k < subpix; ++k) {
@@ -558,6 +559,7 @@ extern "C" int pmx_set_validity(pmx_ctx* ctx, const int64_t* validity) {
 extern "C" int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity) {
     int rc = check_cv(ctx, cv, "pmx_wta");
     if (rc) return rc;
+    ctx->disp_ready = true;
     if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_wta(ctx, cv, invalid_disparity);
     rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
     if (rc) return rc;
@@ -569,6 +571,7 @@ extern "C" int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max
     if (rc) return rc;
     PMX_CHECK(method == PMX_REFINE_VFIT || method == PMX_REFINE_QUADRATIC, PMX_ERR_ARG,
               "pmx_refine: unknown refinement method %d", method);
+    PMX_CHECK(ctx->disp_ready, PMX_ERR_STATE, "pmx_refine: no disparity map for this pair yet (run pmx_wta or pmx_set_disparity first)");
     if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_refine(ctx, cv, method);
     rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
     if (rc) return rc;
@@ -590,7 +593,10 @@ extern "C" int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t*
     PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_disparity: call pmx_set_images first");
     PMX_HIP(hipSetDevice(ctx->device));
     size_t n = (size_t)ctx->H * ctx->W;
-    if (disp) PMX_HIP(hipMemcpyAsync(ctx->disp, disp, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (disp) {
+        PMX_HIP(hipMemcpyAsync(ctx->disp, disp, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        ctx->disp_ready = true;
+    }
     if (validity) PMX_HIP(hipMemcpyAsync(ctx->validity, validity, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
@@ -609,6 +615,7 @@ extern "C" int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double 
                                  float invalid_disparity) {
     PMX_CHECK(ctx && ctx->left && dev_keys, PMX_ERR_ARG, "pmx_wta_from_keys: bad argument");
     PMX_HIP(hipSetDevice(ctx->device));
+    ctx->disp_ready = true;
     return pmx_launch_from_keys(ctx, dev_keys, d0_global, subpix, invalid_disparity);
 }
 

@@ -63,6 +63,7 @@ struct pmx_ctx {
     float* itp = nullptr;
     int64_t* validity = nullptr;
     void* near = nullptr;  // float4 [H][W]: (S[k-1], S[k], S[k+1], k) of the last WTA winner (fast path)
+    bool disp_ready = false;  // a disparity map is resident for the current pair (pmx_wta / pmx_wta_from_keys / pmx_set_disparity)
     const void* near_owner = nullptr;  // the volume handle that cache was computed from (nullptr = stale)
     // scratch volume reused across calls (SGM accumulator, CBCA intermediate)
     float* scratch = nullptr;

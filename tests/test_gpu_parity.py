@@ -352,6 +352,31 @@ def test_wta_more_reference_vectors(eng, case):
     np.testing.assert_array_equal(disp, np.array(case["disp"], np.float32))
 
 
+def test_refine_needs_a_disparity_map_and_never_indexes_outside_the_volume(eng, oracle):
+    """pmx_refine before any WTA on the pair is a state error; a caller-provided map with disparities outside the volume
+    (or NaN) keeps them and reports a NaN coefficient instead of reading out of bounds."""
+    from pandora_amd.engine import PmxError
+
+    L, R = pair(12, 20, seed=3)
+    cv = gpu_cv(eng, "census", L, R, -3, 2, 1, 5)
+    with pytest.raises(PmxError) as err:
+        eng.refine(cv, "vfit", False)
+    assert "no disparity map" in str(err.value)
+    eng.sgm(cv, 8, 32, False, 26.0, False)
+    with pytest.raises(PmxError):
+        eng.refine(cv, "vfit", False)
+    disp = np.full((12, 20), -1.0, np.float32)
+    disp[0, 0], disp[1, 1], disp[2, 2], disp[3, 3] = 7.0, -40.0, np.nan, 2.0
+    for _ in range(2):  # on the byte volumes, then on the materialised float32 volume
+        eng.set_disparity(disp, np.zeros((12, 20), np.int64))
+        eng.refine(cv, "quadratic", False)
+        d, v, itp = eng.get_disparity(want_itp=True)
+        for r in range(3):
+            assert np.isnan(itp[r, r]) and v[r, r] == 0 and (d[r, r] == disp[r, r] or np.isnan(disp[r, r]))
+        assert v[3, 3] == 8 and d[3, 3] == 2.0  # the range border stops the interpolation (refinement.cpp:62-67)
+        cv.to_host()
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
