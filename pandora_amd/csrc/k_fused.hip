@@ -293,12 +293,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void sgm_census_fused_kerne
 // ---- consumers of the 8 byte volumes ---------------------------------------------------------------
 struct sum8_args {
     const uint8_t* ldir;  // [8][H][W][Dp], bytes of a pixel in fused_pos() order
+    const uint32_t* range;  // [H][W] lo | hi << 16: the disparity indices that are numbers (cv_masked ran), or nullptr
     int H, W, D, Dp, d0, o;
     int gl, kpl, nact;    // lane map the volumes were written with (nact = ceil(D / kpl) lanes own a disparity)
 };
 
-// is cell (r, c, k) a NaN of the census volume? (geometry only: no masks on this path)
+// is cell (r, c, k) a NaN of the census volume?  Geometry alone, or the snapshot cv_masked took (grids, left mask)
 __device__ __forceinline__ bool cell_is_nan(const sum8_args& a, int r, int c, int k) {
+    if (a.range) {
+        const uint32_t rg = a.range[(size_t)r * a.W + c];
+        return !(k >= (int)(rg & 0xffffu) && k < (int)(rg >> 16));
+    }
     const int q = c + a.d0 + k;
     return !((r >= a.o) && (r < a.H - a.o) && (c >= a.o) && (c < a.W - a.o) && (q >= a.o) && (q < a.W - a.o));
 }
@@ -365,14 +370,16 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
         // ---- validity of the lane's cells (geometry only on this path): slot e is a number iff elo <= e < ehi
         const bool pix_ok = (r >= a.o) & (r < a.H - a.o) & (c >= a.o) & (c < a.W - a.o);
         const int us = c + a.d0 + d_first - a.o;  // right column of slot 0, relative to the first valid one
-        const bool interior = (pix_ok & (us >= 0) & (us + nown <= wvalid)) | (nown <= 0);
+        const bool interior = ((pix_ok & (us >= 0) & (us + nown <= wvalid)) | (nown <= 0)) & (a.range == nullptr);
+        const uint32_t rg = a.range ? a.range[pix] : 0u;
+        const int rlo = (int)(rg & 0xffffu), rhi = (int)(rg >> 16);
         uint32_t key = 0xffffffffu;
         if (__all(interior)) {
 #pragma unroll
             for (int e = 0; e < KPL; ++e) key = umin2(key, (s[e] << 16) | idx[e]);
         } else {
-            const int elo = max(0, -us);
-            const int ehi = pix_ok ? min(nown, wvalid - us) : 0;
+            const int elo = a.range ? max(0, rlo - d_first) : max(0, -us);
+            const int ehi = a.range ? min(nown, rhi - d_first) : (pix_ok ? min(nown, wvalid - us) : 0);
 #pragma unroll
             for (int e = 0; e < KPL; ++e) {
                 const bool ok = (e >= elo) & (e < ehi);
@@ -393,7 +400,8 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
             } else {
                 const int kb = (int)(key & 0xffffu);
                 const int q0 = c + a.d0 + kb - a.o;  // right column of the winner, relative
-                const bool v0 = (kb - 1 >= 0) & (q0 - 1 >= 0), v2 = (kb + 1 < a.D) & (q0 + 1 < wvalid);
+                const bool v0 = a.range ? (kb - 1 >= rlo) : ((kb - 1 >= 0) & (q0 - 1 >= 0));
+                const bool v2 = a.range ? (kb + 1 < rhi) : ((kb + 1 < a.D) & (q0 + 1 < wvalid));
                 const uint32_t c0 = srow[kb - 1], c2 = srow[kb + 1];
                 near[pix] = make_float4(v0 ? (float)c0 : g_nan(), (float)(key >> 16), v2 ? (float)c2 : g_nan(), __int_as_float(kb));
                 disp[pix] = (float)(d0 + (double)kb);
@@ -475,10 +483,66 @@ __global__ __launch_bounds__(256) void census_nan_pixels_kernel(sum8_args a, uin
     out[(size_t)r * a.W + c] = any ? 0 : 1;
 }
 
+// ---- cv_masked on the integer path: snapshot of the cells that are numbers --------------------------------------------------
+// matching_cost.py:815-860 for subpix 1 without a right mask: a cell is a number iff the census geometry allows it, the
+// left pixel is not masked (invalid or dilated no-data) and disp_min[r,c] <= d <= disp_max[r,c] (NaN grids compare false, as
+// in numpy).  All three are intervals of the disparity index, so their intersection [lo, hi) describes the pixel.
+__global__ __launch_bounds__(256) void build_range_kernel(int H, int W, int D, int d0, int o, const uint8_t* __restrict__ bad_left,
+                                                          const double* __restrict__ gmin, const double* __restrict__ gmax,
+                                                          uint32_t* __restrict__ range) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const size_t i = (size_t)r * W + c;
+    int lo = max(0, o - c - d0), hi = min(D, W - o - c - d0);
+    if (!((r >= o) && (r < H - o) && (c >= o) && (c < W - o))) hi = lo;
+    if (bad_left && bad_left[i]) hi = lo;
+    if (gmin) {
+        const double a = gmin[i] - (double)d0, b = gmax[i] - (double)d0;  // k >= a and k <= b
+        if (a == a && a > (double)lo) lo = a >= (double)D ? D : (int)ceil(a);
+        if (b == b && b < (double)(hi - 1)) hi = b < 0.0 ? 0 : (int)floor(b) + 1;
+    }
+    if (hi < lo) hi = lo;
+    range[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+}
+
+__global__ __launch_bounds__(256) void range_nan_kernel(int W, int D, const uint32_t* __restrict__ range, float* __restrict__ cv) {
+    const int r = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= W * D) return;
+    const int c = j / D, k = j - c * D;
+    const uint32_t rg = range[(size_t)r * W + c];
+    if (!(k >= (int)(rg & 0xffffu) && k < (int)(rg >> 16))) cv[(size_t)r * W * D + j] = g_nan();
+}
+
+int pmx_launch_build_range(pmx_ctx* ctx, pmx_cv* cv) {
+    const size_t need = (size_t)cv->H * cv->W * sizeof(uint32_t);
+    if (cv->range_bytes < need) {
+        pmx_pool_free(ctx, cv->range);
+        cv->range = nullptr;
+        cv->range_bytes = 0;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->range, need));
+        cv->range_bytes = need;
+    }
+    dim3 grid((cv->W + 255) / 256, cv->H);
+    hipLaunchKernelGGL(build_range_kernel, grid, dim3(256), 0, ctx->stream, cv->H, cv->W, cv->D, cv->d0, cv->win / 2,
+                       (const uint8_t*)ctx->bad_left, (const double*)ctx->grid_min, (const double*)ctx->grid_max, cv->range);
+    PMX_HIP(hipGetLastError());
+    cv->has_range = true;
+    return PMX_OK;
+}
+
+int pmx_launch_range_nan(pmx_ctx* ctx, pmx_cv* cv) {
+    dim3 grid((cv->W * cv->D + 255) / 256, cv->H);
+    hipLaunchKernelGGL(range_nan_kernel, grid, dim3(256), 0, ctx->stream, cv->W, cv->D, cv->range, cv->data);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 static sum8_args make_sum8(const pmx_cv* cv) {
     sum8_args s;
     s.ldir = cv->ldir;
+    s.range = cv->has_range ? cv->range : nullptr;
     s.H = cv->H; s.W = cv->W; s.D = cv->D; s.Dp = cv->Dp; s.d0 = cv->d0; s.o = cv->win / 2;
     s.gl = cv->gl; s.kpl = cv->kpl; s.nact = cv->kpl ? (cv->D + cv->kpl - 1) / cv->kpl : 0;  // (no map before the SGM step)
     return s;
@@ -494,6 +558,10 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
     auto is_int = [](float x) { return x == floorf(x); };
     if (!is_int(P1) || !is_int(P2) || !is_int(invalid_cost)) return false;
     if (invalid_cost < 0 || invalid_cost + P2 > 255.f) return false;
+    if (cv->has_range) {  // the snapshot of cv_masked is honoured by the packed kernels only (k_sgm8.hip)
+        const char* e8 = getenv("PMX_SGM8");
+        if (getenv("PMX_FUSED_MAP") || (e8 && e8[0] == '0')) return false;
+    }
     return true;
 }
 

@@ -53,6 +53,7 @@ struct cost8_args {
     const uint32_t* codeL;  // [H][W][NW]
     const uint32_t* codeR;  // [H][W][NW], guard dwords on both sides
     uint8_t* cost;          // [H][W][Dp]
+    const uint32_t* range;  // [H][W] lo | hi << 16 (cv_masked on this path) or nullptr = census geometry
     int H, W, D, Dp, d0, o;
     uint32_t invalid_cost;
 };
@@ -80,6 +81,8 @@ __global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
         __builtin_memcpy(lc, a.codeL + pix * NW, sizeof(uint32_t) * NW);
         __builtin_memcpy(rc, a.codeR + ((ptrdiff_t)pix + a.d0 + (lane_active ? d_first : 0)) * NW, sizeof(uint32_t) * KPL * NW);
         const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
+        const uint32_t rg = a.range ? a.range[pix] : 0u;
+        const int rlo = (int)(rg & 0xffffu) - d_first, rhi = (int)(rg >> 16) - d_first;  // the lane's slots that are numbers
         uint32_t out[NDW];
 #pragma unroll
         for (int j = 0; j < NDW; ++j) out[j] = 0;
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
             uint32_t pop = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) pop += __popc(lc[w] ^ rc[k * NW + w]);
-            const uint32_t v = (pix_ok && (u + (uint32_t)k < wvalid)) ? pop : a.invalid_cost;
+            const bool ok = a.range ? (k >= rlo && k < rhi) : (pix_ok && (u + (uint32_t)k < wvalid));
+            const uint32_t v = ok ? pop : a.invalid_cost;
             if (CBITS == 8) {
                 out[k / 4] |= v << (8 * (k % 4));
             } else {
@@ -291,6 +295,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
         cost8_args c;
         c.codeL = cv->codeL; c.codeR = cv->codeR; c.cost = cv->cost8;
+        c.range = cv->has_range ? cv->range : nullptr;
         c.H = H; c.W = W; c.D = cv->D; c.Dp = Dc; c.d0 = cv->d0; c.o = cv->win / 2;
         c.invalid_cost = invalid_cost;
         const size_t want = ((size_t)H * W + 15) / 16;  // 4 pixels per wave, 4 waves per block

@@ -327,6 +327,7 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
         pmx_pool_free(ctx, cv->codes);
         pmx_pool_free(ctx, cv->ldir);
         pmx_pool_free(ctx, cv->cost8);
+        pmx_pool_free(ctx, cv->range);
     } else {
         hipFree(cv->data);
         hipFree(cv->codes);
@@ -346,7 +347,11 @@ int pmx_cv_materialize(pmx_ctx* ctx, pmx_cv* cv) {
             if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
             return rc;
         }
-        case PMX_REPR_CENSUS_DEFERRED: return pmx_launch_census_costs(ctx, cv);  // sets FLOAT
+        case PMX_REPR_CENSUS_DEFERRED: {
+            int rc = pmx_launch_census_costs(ctx, cv);  // sets FLOAT
+            if (rc == PMX_OK && cv->has_range) rc = pmx_launch_range_nan(ctx, cv);  // cv_masked had run on the codes
+            return rc;
+        }
         case PMX_REPR_SGM_U8X8: {
             int rc = pmx_launch_sum8_to_float(ctx, cv);
             if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
@@ -419,8 +424,9 @@ extern "C" int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
     // the Hamming costs can stay implicit (codes only) while nothing needs the float volume; only
     // worth it where the fused SGM path can consume them
     const int nw = (win * win + 31) / 32;
-    const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 2 && cv->D < 320 && abs(cv->d0) + cv->D <= 1024 / nw - 32 && !ctx->bad_left &&
-                       !ctx->bad_right && !ctx->grid_min;
+    // (a right mask makes cv_masked a per-cell pattern: float volume; grids and a left mask are intervals per pixel and stay lazy)
+    const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 2 && cv->D < 320 && abs(cv->d0) + cv->D <= 1024 / nw - 32 && !ctx->msk_right;
+    cv->has_range = false;
     if (!defer) {
         rc = pmx_cv_ensure_data(ctx, cv);
         if (rc) return rc;
@@ -456,6 +462,8 @@ extern "C" int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win) {
     if (!ctx->msk_left && !ctx->msk_right && !ctx->grid_min) return PMX_OK;  // nothing to inject: NaN pattern is complete
     rc = pmx_update_bad_masks(ctx, win);
     if (rc) return rc;
+    if (cv->repr == PMX_REPR_CENSUS_DEFERRED && !ctx->msk_right && win == cv->win)
+        return pmx_launch_build_range(ctx, cv);  // stays on the integer path: the kernels take the valid interval of each pixel
     rc = pmx_cv_materialize(ctx, cv);
     if (rc) return rc;
     return pmx_launch_cv_masked(ctx, cv, win);
@@ -470,7 +478,7 @@ extern "C" int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out)
     if (rc) return rc;
     pmx_cv* mcv = const_cast<pmx_cv*>(cv);
     if (cv->repr == PMX_REPR_CENSUS_DEFERRED || cv->repr == PMX_REPR_SGM_U8X8) {
-        rc = pmx_launch_census_nan_pixels(ctx, cv, (uint8_t*)ctx->small);  // NaN pattern = census geometry
+        rc = pmx_launch_census_nan_pixels(ctx, cv, (uint8_t*)ctx->small);  // NaN pattern = census geometry (x cv_masked's snapshot)
     } else {
         rc = pmx_cv_materialize(ctx, mcv);
         if (rc) return rc;

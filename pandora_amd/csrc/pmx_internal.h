@@ -109,6 +109,12 @@ struct pmx_cv {
     // uint8 matching costs [H][W][Dp] in the same lane-map order (packed-arithmetic SGM path, k_sgm8.hip)
     uint8_t* cost8 = nullptr;
     size_t cost8_bytes = 0;
+    // cv_masked on the integer fast path (per-pixel disparity grids and / or a left mask): the cells that are numbers are the
+    // index interval [lo, hi) of each pixel, snapshot of geometry x grids x left mask taken when pmx_cv_masked ran;
+    // range[pixel] = lo | hi << 16.  nullptr = census geometry alone.
+    uint32_t* range = nullptr;
+    size_t range_bytes = 0;
+    bool has_range = false;
     size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
 };
 
@@ -163,6 +169,8 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
 int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost);
 int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity);
 bool pmx_sgm8_supported(int gl, int kpl, int nw);
+int pmx_launch_build_range(pmx_ctx* ctx, pmx_cv* cv);        // geometry x ctx grids x ctx bad_left -> cv->range
+int pmx_launch_range_nan(pmx_ctx* ctx, pmx_cv* cv);          // float volume: NaN outside cv->range
 int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2, uint32_t invalid_cost);  // cost8 + 8 path volumes
 int pmx_launch_sum8_refine(pmx_ctx* ctx, const pmx_cv* cv, int method);
 int pmx_launch_sum8_to_float(pmx_ctx* ctx, pmx_cv* cv);

@@ -50,6 +50,8 @@ def draw(seed):
         valid, nodata = (0, 1) if rng.random() < 0.5 else (5, 7)
         pool = [valid] * 7 + [nodata, valid + nodata + 1]
         masks = (rng.choice(pool, (H, W)).astype(np.int16), rng.choice(pool, (H, W)).astype(np.int16), valid, nodata)
+        if rng.random() < 0.4:  # a left mask alone keeps census volumes on the integer fast path (per-pixel intervals)
+            masks = (masks[0], None, valid, nodata)
     grids = None
     if rng.random() < 0.3 and span > 0:
         lo = rng.integers(dmin, dmax + 1, (H, W))

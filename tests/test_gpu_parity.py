@@ -377,6 +377,52 @@ def test_refine_needs_a_disparity_map_and_never_indexes_outside_the_volume(eng, 
         cv.to_host()
 
 
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_variable_disparity_ranges_stay_on_the_integer_path(eng, oracle, with_mask):
+    """cv_masked with per-pixel disparity grids (the multiscale case) and / or a left mask on a deferred census volume keeps
+    the integer fast path: the byte path volumes exist after SGM, and volume, disparity, validity and coefficient equal the
+    oracle (NaN grids = no restriction, empty ranges, ranges that leave the volume, masked and dilated pixels)."""
+    if not eng.lazy:
+        pytest.skip("the integer fast path only exists in lazy mode")
+    H, W, dmin, dmax, win = 31, 57, -14, 6, 5
+    D = dmax - dmin + 1
+    L, R = pair(H, W, seed=21)
+    rng = np.random.default_rng(22)
+    lo = rng.integers(dmin - 2, dmax + 1, (H, W)).astype(np.float64)
+    hi = np.minimum(dmax + 3, lo + rng.integers(0, 9, (H, W)))
+    lo[3, 3], hi[3, 3] = 4.0, 1.0             # empty
+    lo[4, 4], hi[4, 4] = np.nan, np.nan       # no restriction
+    lo[5, 5], hi[5, 5] = dmax + 5.0, dmax + 9.0  # beyond the volume
+    lo[6, 6], hi[6, 6] = -2.5, 1.5            # fractional bounds: -2 .. 1
+    mL = np.where(rng.random((H, W)) < 0.06, rng.choice([1, 2], (H, W)), 0).astype(np.int16) if with_mask else None
+    eng.set_images(L, R, 1)
+    eng.set_masks(mL, None, 0, 1)
+    eng.set_disparity_grids(lo, hi)
+    cv = eng.alloc_cv(D, dmin)
+    eng.census(cv, win)
+    eng.cv_masked(cv, win)
+    nanpix = eng.nan_pixels(cv)
+    eng.sgm(cv, 8, 32, False, 26.0, False)
+    raw, _, _ = eng.debug_path_costs(cv, raw=True)  # raises unless the eight byte volumes exist: the fast path ran
+    assert raw.shape[0] == 8
+    eng.set_validity(None)
+    eng.wta(cv, False, np.nan)
+    eng.refine(cv, "vfit", False)
+    disp, val, itp = eng.get_disparity(want_itp=True)
+    ocv = oracle.census_cost(L, R, D, dmin, 1, win)
+    oracle.cv_masked(ocv, dmin, 1, win, mskL=mL, mskR=None, valid=0, nodata=1, dmin=lo, dmax=hi)
+    np.testing.assert_array_equal(nanpix.astype(bool), np.isnan(ocv).all(axis=2))
+    ocv = oracle.sgm(ocv, 8, 32, False, 26.0, False)
+    odisp, oval = oracle.wta(ocv, dmin, 1, False, np.nan)
+    oitp, odisp, oval = oracle.refine(ocv, odisp, oval, dmin, dmax, 1, False, "vfit")
+    np.testing.assert_array_equal(disp, odisp)
+    np.testing.assert_array_equal(val, oval)
+    np.testing.assert_array_equal(itp, oitp)
+    np.testing.assert_array_equal(cv.to_host(), ocv)
+    eng.set_masks(None, None)
+    eng.set_disparity_grids(None, None)
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
