@@ -612,12 +612,13 @@ constexpr int kZnccOutStride = kZnccDB + 4;     // floats per staged pixel row (
 
 struct zncc_march_params {
     const float* left;
-    const float* right;
-    const double *lmean, *lisd, *rmean, *risd;
+    const float* right[PMX_MAX_SUBPIX];                   // shifted right images (phase k > 0 is one column narrower)
+    const double *lmean, *lisd;
+    const double *rmean[PMX_MAX_SUBPIX], *risd[PMX_MAX_SUBPIX];
     float* cv;
     int H, W, D, d0, win;
     int ntile, ndblock, nstrip, strip_rows;
-    uint32_t img_bytes, stat_bytes;
+    uint32_t img_bytes, stat_bytes;                       // of the full-width images; phase > 0: H * (W-1) * 4 etc.
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -629,7 +630,10 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, uint32
     return __hiloint2double((int)v.y, (int)v.x);
 }
 
-template <int WIN_T>  // window known at compile time (0: any)
+// SUBPIX 2 / 4 (img_tools.py:713-752 shifted right images, cost index k = shift * subpix + phase): the four wavefronts of a
+// workgroup still produce 32 consecutive cost indices of the same columns, but as phases x integer shifts - subpix 4: wave =
+// phase, 8 shifts; subpix 2: 2 phases x 2 chunks of 8 shifts - each wave marching over ITS phase's right image and statistics.
+template <int WIN_T, int SUBPIX>  // window known at compile time (0: any)
 __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_params q) {
     constexpr int ND = kZnccND;
     __shared__ double colbuf[kZnccWaves][ND][64];
@@ -647,19 +651,24 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
     const int wo = W - 2 * o;                      // width of the statistics rasters
     const int tile_c0 = tile * (64 - 2 * o);       // first output column of the tile
     const int c = tile_c0 - o + lane;              // image column of this lane (halo lanes included)
-    const int k0 = dblock * kZnccDB + wv * ND;     // first disparity index of this wavefront's chunk
-    const bool chunk_live = k0 < q.D;
-    const int x0 = c + q.d0 + k0;                  // right-image column matched at e = 0
+    const int ph = SUBPIX == 1 ? 0 : (SUBPIX == 2 ? (wv & 1) : wv);                                   // sub-pixel phase of this wave
+    const int kk0 = SUBPIX == 1 ? dblock * kZnccDB + wv * ND : (SUBPIX == 2 ? dblock * 16 + (wv >> 1) * ND : dblock * ND);
+    const bool chunk_live = kk0 * SUBPIX + ph < q.D;  // first cost index of this wavefront's chunk
+    const int Wp = ph ? W - 1 : W;                 // width of this phase's right image
+    const int wop = Wp - 2 * o;                    // ... and of its statistics rasters
+    const int x0 = c + q.d0 + kk0;                 // right-image column matched at e = 0
     const int r0 = strip * q.strip_rows;
     const int r1 = min(r0 + q.strip_rows, H);
 
     const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)q.left, 0, q.img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)q.right - kImgGuardBytes), 0,
-                                                                          q.img_bytes + 2 * (uint32_t)kImgGuardBytes, 0x00020000);
+    const uint32_t img_bytes_p = ph ? (uint32_t)((size_t)H * Wp * 4) : q.img_bytes;
+    const uint32_t stat_bytes_p = ph ? (uint32_t)((size_t)(H - 2 * o) * wop * 8) : q.stat_bytes;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)q.right[ph] - kImgGuardBytes), 0,
+                                                                          img_bytes_p + 2 * (uint32_t)kImgGuardBytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsLM = __builtin_amdgcn_make_buffer_rsrc((void*)q.lmean, 0, q.stat_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsLI = __builtin_amdgcn_make_buffer_rsrc((void*)q.lisd, 0, q.stat_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsRM = __builtin_amdgcn_make_buffer_rsrc((void*)q.rmean, 0, q.stat_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsRI = __builtin_amdgcn_make_buffer_rsrc((void*)q.risd, 0, q.stat_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsRM = __builtin_amdgcn_make_buffer_rsrc((void*)q.rmean[ph], 0, stat_bytes_p, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsRI = __builtin_amdgcn_make_buffer_rsrc((void*)q.risd[ph], 0, stat_bytes_p, 0x00020000);
     constexpr uint32_t kOob = 0xfffffff0u;
 
     // raw loads of one image row for this lane's ND cells (zeros outside the image rows)
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
     auto load_row = [&](int row, row_vals& v) {
         const bool in = chunk_live && (row >= 0) && (row < H);
         const uint32_t offL = in ? (uint32_t)((row * W + c) * 4) : kOob;
-        const uint32_t offR = in ? (uint32_t)((row * W + x0) * 4 + (int)kImgGuardBytes) : kOob;  // (guarded: pmx_api img_alloc)
+        const uint32_t offR = in ? (uint32_t)((row * Wp + x0) * 4 + (int)kImgGuardBytes) : kOob;  // (guarded: pmx_api img_alloc)
         v.lv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsL, offL, 0, 0));
 #pragma unroll
         for (int i = 0; i < ND / 4; ++i) {
@@ -690,13 +699,14 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
         s.mL = buf_load_f64(rsLM, offLs);
         s.iL = buf_load_f64(rsLI, offLs);
         const int xs = x0 - o;  // statistics column of right pixel x0
-        const bool ok0 = row_ok && (xs >= 0) && (xs < wo);
-        const uint32_t off0 = ok0 ? (srow + (uint32_t)xs) * 8u : kOob;
+        const uint32_t srowp = row_ok ? (uint32_t)((r - o) * wop) : 0u;
+        const bool ok0 = row_ok && (xs >= 0) && (xs < wop);
+        const uint32_t off0 = ok0 ? (srowp + (uint32_t)xs) * 8u : kOob;
         s.rm0 = buf_load_f64(rsRM, off0);
         s.ri0 = buf_load_f64(rsRI, off0);
         const int xe = xs + 64;  // the ND columns past the tile's last lane
-        const bool ok1 = (lane < ND) && row_ok && (xe >= 0) && (xe < wo);
-        const uint32_t off1 = ok1 ? (srow + (uint32_t)xe) * 8u : kOob;
+        const bool ok1 = (lane < ND) && row_ok && (xe >= 0) && (xe < wop);
+        const uint32_t off1 = ok1 ? (srowp + (uint32_t)xe) * 8u : kOob;
         s.rm1 = buf_load_f64(rsRM, off1);
         s.ri1 = buf_load_f64(rsRI, off1);
     };
@@ -771,10 +781,15 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
                 double z = box[e] * inv_n - mL * rstat[wv][0][lane + e];
                 z = z * iL * rstat[wv][1][lane + e];
                 const int x = x0 + e;
-                const bool ok = row_ok && col_ok && (x - o >= 0) && (x + o < W);
+                const bool ok = row_ok && col_ok && (x - o >= 0) && (x + o < Wp);
                 out[e] = ok ? (float)z : qnan();
             }
-            __builtin_memcpy(&ostage[par][lane][wv * ND], out, sizeof(float) * ND);
+            if (SUBPIX == 1) {
+                __builtin_memcpy(&ostage[par][lane][wv * ND], out, sizeof(float) * ND);
+            } else {  // cost index inside the workgroup's 32: (shift) * SUBPIX + phase
+#pragma unroll
+                for (int e = 0; e < ND; ++e) ostage[par][lane][((SUBPIX == 2 ? (wv >> 1) * ND : 0) + e) * SUBPIX + ph] = out[e];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -827,12 +842,16 @@ int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
         hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, win,
                            (double*)st.rmean[k], (double*)st.rsd[k], risd[k]);
     }
-    const bool march = cv->subpix == 1 && 2 * o < 32 && (size_t)H * W * 4 < (1ull << 31) &&
+    const bool march = (cv->subpix == 1 || cv->subpix == 2 || cv->subpix == 4) && 2 * o < 32 && (size_t)H * W * 4 < (1ull << 31) &&
                        (size_t)H * W * 8 < (1ull << 32);
     if (march) {
         zncc_march_params q;
-        q.left = ctx->left; q.right = ctx->right[0];
-        q.lmean = st.lmean; q.lisd = lisd; q.rmean = st.rmean[0]; q.risd = risd[0];
+        q.left = ctx->left;
+        q.lmean = st.lmean; q.lisd = lisd;
+        for (int k = 0; k < PMX_MAX_SUBPIX; ++k) {
+            const int kk = k < cv->subpix ? k : 0;
+            q.right[k] = ctx->right[kk]; q.rmean[k] = st.rmean[kk]; q.risd[k] = risd[kk];
+        }
         q.cv = cv->data;
         q.H = H; q.W = W; q.D = cv->D; q.d0 = cv->d0; q.win = win;
         q.strip_rows = 64;
@@ -843,12 +862,17 @@ int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
         q.stat_bytes = (uint32_t)per;
         const uint32_t grid = (uint32_t)q.ntile * q.ndblock * q.nstrip;
         const dim3 block(64 * kZnccWaves);
+#define PMX_ZNCC_LAUNCH(WN)                                                                                                  \
+    if (cv->subpix == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(zncc_march_kernel<WN, 1>), dim3(grid), block, 0, ctx->stream, q);     \
+    else if (cv->subpix == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(zncc_march_kernel<WN, 2>), dim3(grid), block, 0, ctx->stream, q); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(zncc_march_kernel<WN, 4>), dim3(grid), block, 0, ctx->stream, q)
         switch (win) {
-#define PMX_ZNCC_CASE(WN) case WN: hipLaunchKernelGGL(zncc_march_kernel<WN>, dim3(grid), block, 0, ctx->stream, q); break;
+#define PMX_ZNCC_CASE(WN) case WN: PMX_ZNCC_LAUNCH(WN); break;
             PMX_ZNCC_CASE(1) PMX_ZNCC_CASE(3) PMX_ZNCC_CASE(5) PMX_ZNCC_CASE(7) PMX_ZNCC_CASE(9) PMX_ZNCC_CASE(11) PMX_ZNCC_CASE(13)
 #undef PMX_ZNCC_CASE
-            default: hipLaunchKernelGGL(zncc_march_kernel<0>, dim3(grid), block, 0, ctx->stream, q); break;
+            default: PMX_ZNCC_LAUNCH(0); break;
         }
+#undef PMX_ZNCC_LAUNCH
     } else {
         dim3 grid((W * cv->D + kBlock - 1) / kBlock, H);
         hipLaunchKernelGGL(zncc_kernel, grid, dim3(kBlock), 0, ctx->stream, p, st, cv->data);
