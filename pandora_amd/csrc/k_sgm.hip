@@ -17,6 +17,8 @@
 //
 // Per pass the kernel reads C (4 B/cell), reads S (4) and writes S (4); the first pass skips the
 // S read, the last pass also restores NaN / un-negates.  No MFMA: this is an HBM-bound scan.
+#include <cstdlib>
+
 #include "pmx_internal.h"
 
 static constexpr int kWavesPerBlock = 4;
@@ -57,6 +59,10 @@ struct sgm_args {
     int dr, dc;      // step from p-r to p
     float P1, P2, invalid_cost;
     int is_max, overcounting;
+    // all eight directions in ONE launch (blockIdx.y = direction), each writing its own path-cost volume S + y * vol:
+    // for volumes too small to fill the GPU one direction at a time (see pmx_launch_sgm)
+    int multi;
+    size_t vol;
 };
 
 template <int KPL>
@@ -76,6 +82,12 @@ __device__ __forceinline__ lane_vals<KPL> load_vals(const float* p) {
 // and must store element-wise; without a tail every active lane does one KPL-wide store.
 template <int KPL, int MODE, bool TAIL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args a) {
+    if (a.multi) {  // direction order of the definition above
+        const int k = blockIdx.y;
+        a.dr = (k < 2) ? 0 : ((k & 1) ? -1 : 1);
+        a.dc = (k == 0) ? 1 : (k == 1) ? -1 : (k < 4) ? 0 : ((k == 4 || k == 7) ? 1 : -1);
+        a.S += (size_t)k * a.vol;
+    }
     const int lane = threadIdx.x & 63;
     const int line = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const bool horizontal = (a.dr == 0);
@@ -215,6 +227,52 @@ static int sgm_run(pmx_ctx* ctx, const sgm_args& base) {
     return PMX_OK;
 }
 
+// S = L0 + L1 + ... + L7 accumulated in float32 in the definition's order (exactly what the eight sequential passes
+// compute), then the epilogue of the last pass: overcounting, sign, NaN where the input was NaN.
+__global__ __launch_bounds__(256) void sgm_sum_paths_kernel(const float* __restrict__ C, const float* __restrict__ L, size_t n,
+                                                            float invalid_cost, int is_max, int overcounting,
+                                                            float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i < n; i += step) {
+        float s = L[i];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s = s + L[(size_t)k * n + i];
+        const float cr = C[i];
+        const float cc = (cr != cr) ? invalid_cost : (is_max ? -cr : cr);
+        if (overcounting) s = s - 7.0f * cc;
+        if (is_max) s = -s;
+        if (cr != cr) s = f_nan();
+        out[i] = s;
+    }
+}
+
+// the eight directions side by side (one launch), then the ordered sum
+template <int KPL>
+static int sgm_run_parallel(pmx_ctx* ctx, sgm_args a, float* paths, size_t cells) {
+    a.multi = 1;
+    a.vol = cells;
+    a.S = paths;
+    const int nlines = a.H > a.W ? a.H : a.W;
+    dim3 grid((nlines + kWavesPerBlock - 1) / kWavesPerBlock, 8);
+    dim3 block(kWavesPerBlock * 64);
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
+        if ((a.D % KPL) != 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, SGM_FIRST, true>), grid, block, 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, SGM_FIRST, false>), grid, block, 0, ctx->stream, a);
+    }
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
+        const size_t want = (cells + 255) / 256;
+        hipLaunchKernelGGL(sgm_sum_paths_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, ctx->stream, a.C, paths,
+                           cells, a.invalid_cost, a.is_max, a.overcounting, ctx->scratch);
+    }
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting) {
     // accumulator volume: the context's scratch; +64 B so the over-read of a lane's tail is in bounds
     size_t bytes = cv->cells() * sizeof(float) + 256;
@@ -237,7 +295,37 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     a.dr = 0; a.dc = 0;
     a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
     a.is_max = is_max; a.overcounting = overcounting;
+    a.multi = 0; a.vol = 0;
     int kpl = (cv->D + 63) / 64;
+    // Small volumes cannot fill the GPU one direction at a time (a wave per scanline: 375 - 450 waves on cones, each a chain
+    // of dependent steps): run the eight directions side by side into eight path volumes and add them in the definition's
+    // order - the same float32 operations, 104 instead of 92 B/cell of traffic, 8 volumes of scratch.  Above the
+    // threshold the passes are HBM-bound and the sequential schedule wins.  PMX_SGM_PAR=0/1 forces either (test hook).
+    bool parallel = cv->cells() <= ((size_t)128 << 20);  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
+    if (const char* e = getenv("PMX_SGM_PAR")) parallel = e[0] == '1';
+    if (parallel && kpl <= 8) {
+        float* paths = nullptr;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&paths, 8 * cv->cells() * sizeof(float) + 256));
+        switch (kpl) {
+            case 1: rc = sgm_run_parallel<1>(ctx, a, paths, cv->cells()); break;
+            case 2: rc = sgm_run_parallel<2>(ctx, a, paths, cv->cells()); break;
+            case 3: rc = sgm_run_parallel<3>(ctx, a, paths, cv->cells()); break;
+            case 4: rc = sgm_run_parallel<4>(ctx, a, paths, cv->cells()); break;
+            case 5: rc = sgm_run_parallel<5>(ctx, a, paths, cv->cells()); break;
+            case 6: rc = sgm_run_parallel<6>(ctx, a, paths, cv->cells()); break;
+            case 7: rc = sgm_run_parallel<7>(ctx, a, paths, cv->cells()); break;
+            default: rc = sgm_run_parallel<8>(ctx, a, paths, cv->cells()); break;
+        }
+        pmx_pool_free(ctx, paths);  // stream-ordered reuse: the kernels above are queued on ctx->stream
+        if (rc) return rc;
+        float* old = cv->data;
+        size_t old_bytes = cv->bytes;
+        cv->data = ctx->scratch;
+        cv->bytes = ctx->scratch_bytes;
+        ctx->scratch = old;
+        ctx->scratch_bytes = old_bytes;
+        return PMX_OK;
+    }
     switch (kpl) {
         case 1: rc = sgm_run<1>(ctx, a); break;
         case 2: rc = sgm_run<2>(ctx, a); break;

@@ -423,6 +423,28 @@ def test_variable_disparity_ranges_stay_on_the_integer_path(eng, oracle, with_ma
     eng.set_disparity_grids(None, None)
 
 
+@pytest.mark.parametrize("is_max,P1,P2", [(False, 8.0, 32.0), (True, 0.3, 1.7)])
+def test_float_sgm_schedules_agree(eng, oracle, monkeypatch, is_max, P1, P2):
+    """The float32 SGM runs its eight directions one after the other (large volumes) or side by side with an ordered sum
+    (small ones): both schedules (PMX_SGM_PAR=0 / 1) give the oracle's bits, overcounting and "max" measures included."""
+    rng = np.random.default_rng(30)
+    H, W, D = 23, 37, 70
+    cvh = (rng.random((H, W, D)).astype(np.float32) * 3 - 1) if is_max else (rng.random((H, W, D)) * 40).astype(np.float32)
+    cvh[rng.random(cvh.shape) < 0.1] = np.nan
+    cvh[2, 3] = np.nan
+    z = np.zeros((H, W), np.float32)
+    eng.set_images(z, z, 1)
+    for over in (False, True):
+        exp = oracle.sgm(cvh, P1, P2, is_max, 45.0, over)
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PMX_SGM_PAR", mode)
+            cv = eng.alloc_cv(D, -9)
+            cv.from_host(cvh)
+            eng.sgm(cv, P1, P2, is_max, 45.0, over)
+            np.testing.assert_array_equal(cv.to_host(), exp)
+            cv.free()
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
