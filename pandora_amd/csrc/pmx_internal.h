@@ -124,18 +124,27 @@ struct pmx_stage_scope {
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
     pmx_stage_scope(pmx_ctx* c, int s) : ctx(c), stage(s) {
-        if (ctx->profiling) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
-            hipEventRecord(a, ctx->stream);
+        // a failed event only loses a timing sample: pmx_stage_time skips null events
+        if (ctx->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+            if (hipEventRecord(a, ctx->stream) != hipSuccess) drop();
+        } else {
+            drop();
         }
     }
     ~pmx_stage_scope() {
-        if (ctx->profiling) {
-            hipEventRecord(b, ctx->stream);
-            ctx->stages[stage].ev.push_back(a);
-            ctx->stages[stage].ev.push_back(b);
+        if (a && b) {
+            if (hipEventRecord(b, ctx->stream) == hipSuccess) {
+                ctx->stages[stage].ev.push_back(a);
+                ctx->stages[stage].ev.push_back(b);
+            } else {
+                drop();
+            }
         }
+    }
+    void drop() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        a = b = nullptr;
     }
 };
 
