@@ -93,7 +93,8 @@ __host__ __device__ __forceinline__ int fused_pos(int d, int nact, int kpl) {
 struct fused_args {
     const uint32_t* codeL;  // [H][W][NW]
     const uint32_t* codeR;  // [H][W][NW], readable 1024 dwords before / after
-    uint8_t* ldir;          // [8][H][W][Dp]
+    uint8_t* ldir;          // [8][H][W][Dp], direction volumes dstride bytes apart
+    size_t dstride;
     int H, W, D, Dp, d0, o;
     int nact;               // lanes of a group that own at least one disparity (ceil(D / KPL))
     uint32_t P1, P2, invalid_cost;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void sgm_census_fused_kerne
     const int stride = dr * W + dc;  // pixel stride of one step (before wrapping)
     const uint32_t* pR = a.codeR + ((ptrdiff_t)r * W + c + a.d0 + d_load) * NW;
     const uint32_t* pL = a.codeL + ((ptrdiff_t)r * W + c) * NW;
-    uint8_t* pO = a.ldir + (size_t)dir * H * W * a.Dp + ((size_t)r * W + c) * a.Dp + sub * M4;
+    uint8_t* pO = a.ldir + (size_t)dir * a.dstride + ((size_t)r * W + c) * a.Dp + sub * M4;
     const int tail_delta = a.nact * M4 + sub - sub * M4;  // from the lane's wide store to its trailing byte
 
     code_slot<NW, KPL> ring[kRing];
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 2) void sgm_census_fused_kerne
 struct sum8_args {
     const uint8_t* ldir;  // [8][H][W][Dp], bytes of a pixel in fused_pos() order
     const uint32_t* range;  // [H][W] lo | hi << 16: the disparity indices that are numbers (cv_masked ran), or nullptr
+    size_t dstride;         // bytes between the direction volumes
     int H, W, D, Dp, d0, o;
     int gl, kpl, nact;    // lane map the volumes were written with (nact = ceil(D / kpl) lanes own a disparity)
 };
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
     const size_t nwaves = (size_t)gridDim.x * 4;
     const int d_first = sub * KPL;
     const bool lane_active = d_first < a.D;
-    const size_t vol = (size_t)a.H * a.W * a.Dp;
+    const size_t vol = a.dstride;
     const int wvalid = a.W - 2 * a.o;
     const int nown = min(KPL, a.D - d_first);  // real disparities of this lane (<= 0 for idle lanes)
     // candidate index of slot e with the pad mask folded in: pads get all-ones so that (sum << 16) | idx is never a minimum
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
 
 __device__ __forceinline__ float sum8_cell(const sum8_args& a, size_t pix, int r, int c, int k) {
     if (cell_is_nan(a, r, c, k)) return g_nan();
-    const size_t vol = (size_t)a.H * a.W * a.Dp;
+    const size_t vol = a.dstride;
     uint32_t s = 0;
     const int pos = fused_pos(k, a.nact, a.kpl);
 #pragma unroll
@@ -543,6 +545,7 @@ static sum8_args make_sum8(const pmx_cv* cv) {
     sum8_args s;
     s.ldir = cv->ldir;
     s.range = cv->has_range ? cv->range : nullptr;
+    s.dstride = cv->dstride;
     s.H = cv->H; s.W = cv->W; s.D = cv->D; s.Dp = cv->Dp; s.d0 = cv->d0; s.o = cv->win / 2;
     s.gl = cv->gl; s.kpl = cv->kpl; s.nact = cv->kpl ? (cv->D + cv->kpl - 1) / cv->kpl : 0;  // (no map before the SGM step)
     return s;
@@ -649,7 +652,8 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
     }
     const int nact = (cv->D + kpl - 1) / kpl;
     const int Dp = (nact * kpl + 3) & ~3;
-    size_t need = (size_t)8 * H * W * Dp;
+    const size_t dstride = pmx_dir_stride(H, W, Dp);
+    size_t need = 8 * dstride;
     if (cv->ldir_bytes < need) {
         PMX_HIP(hipStreamSynchronize(ctx->stream));
         pmx_pool_free(ctx, cv->ldir);
@@ -658,12 +662,13 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
         PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->ldir, need + 64));
         cv->ldir_bytes = need;
     }
-    cv->Dp = Dp; cv->gl = gl; cv->kpl = kpl;
+    cv->Dp = Dp; cv->gl = gl; cv->kpl = kpl; cv->dstride = dstride;
     const int nw = (cv->win * cv->win + 31) / 32;
     fused_args a;
     a.codeL = cv->codeL;
     a.codeR = cv->codeR;
     a.ldir = cv->ldir;
+    a.dstride = dstride;
     a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.d0 = cv->d0; a.o = cv->win / 2;
     a.P1 = (uint32_t)P1; a.P2 = (uint32_t)P2; a.invalid_cost = (uint32_t)invalid_cost;
     a.nact = nact;

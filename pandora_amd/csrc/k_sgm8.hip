@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
 // ---- the 8 paths ---------------------------------------------------------------------------------------------------
 struct sgm8_args {
     const uint8_t* cost;  // [H][W][Dc]: costs of a pixel, lane by lane (CBITS = 8: one byte each; 5: six per dword)
-    uint8_t* ldir;        // [8][H][W][Dp]
+    uint8_t* ldir;        // [8][H][W][Dp], direction volumes dstride bytes apart
+    size_t dstride;
     int H, W, D, Dp, Dc;
     uint32_t P1, P2;
 };
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
     int pleft = nsteps - 1;
     const int stride = dr * W + dc;  // pixel stride of one step (before wrapping)
     const uint8_t* pC = a.cost + ((size_t)r * W + c) * a.Dc + (lane_active ? sub * NDW * 4 : 0);
-    uint8_t* pO = a.ldir + (size_t)dir * H * W * a.Dp + ((size_t)r * W + c) * a.Dp + d_first;
+    uint8_t* pO = a.ldir + (size_t)dir * a.dstride + ((size_t)r * W + c) * a.Dp + d_first;
 
     struct slot_t { uint32_t x[NDW]; };
     slot_t ring[kRing8];
@@ -262,13 +263,24 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
+// Spacing of the eight path volumes.  They are written (and read back by the WTA) at the same pixel offset at the same time;
+// measured at C3 (tools/skew_probe.sh, r01): exactly H*W*Dp apart - 16 MB-aligned to each other - the path kernel takes
+// 1.70-1.76 ms and the WTA 0.86-0.91 ms; with a skew of 4 KB ... 1 MB between them 1.82 ms and 0.95 ms, every time.  That is
+// also the "slow" state fresh processes sometimes land in with no skew (physical placement), so alignment is kept and
+// PMX_DIR_SKEW=<bytes> (multiples of 4) stays as an experiment hook only.
+size_t pmx_dir_stride(int H, int W, int Dp) {
+    size_t skew = 0;
+    if (const char* e = getenv("PMX_DIR_SKEW")) skew = (size_t)strtoul(e, nullptr, 10) & ~(size_t)3;
+    return (((size_t)H * W * Dp + 255) & ~(size_t)255) + skew;
+}
+
 bool pmx_sgm8_supported(int gl, int kpl, int nw) { return gl == 16 && (kpl % 4) == 0 && kpl >= 4 && kpl <= 20 && nw <= 2; }
 
 int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2, uint32_t invalid_cost) {
     const int H = cv->H, W = cv->W;
     const int nact = (cv->D + kpl - 1) / kpl;
     const int Dp = nact * kpl;  // multiple of 4
-    const size_t vol = (size_t)H * W * Dp;
+    const size_t vol = pmx_dir_stride(H, W, Dp);
     const int nw = (cv->win * cv->win + 31) / 32;
     // five-bit costs when they fit (PMX_COST5=0 keeps bytes: test hook)
     const char* e5 = getenv("PMX_COST5");
@@ -290,7 +302,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->ldir, 8 * vol + 64));
         cv->ldir_bytes = 8 * vol;
     }
-    cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl;
+    cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl; cv->dstride = vol;
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
         cost8_args c;
@@ -317,7 +329,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     }
     PMX_HIP(hipGetLastError());
     sgm8_args a;
-    a.cost = cv->cost8; a.ldir = cv->ldir;
+    a.cost = cv->cost8; a.ldir = cv->ldir; a.dstride = cv->dstride;
     a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.Dc = Dc; a.P1 = P1; a.P2 = P2;
     const int nwaves = 2 * ((H + kLines8 - 1) / kLines8) + 6 * ((W + kLines8 - 1) / kLines8);
     const dim3 grid((nwaves + kWaves8 - 1) / kWaves8), block(kWaves8 * 64);

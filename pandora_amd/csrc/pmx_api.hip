@@ -638,7 +638,8 @@ extern "C" int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* hos
     if (!host_out) return PMX_OK;
     PMX_CHECK(host_bytes >= n, PMX_ERR_ARG, "pmx_debug_path_costs: host buffer too small (%zu < %zu)", host_bytes, n);
     PMX_HIP(hipSetDevice(ctx->device));
-    PMX_HIP(hipMemcpyAsync(host_out, cv->ldir, n, hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = 0; k < 8; ++k)  // the device volumes are dstride apart, the host copy is dense
+        PMX_HIP(hipMemcpyAsync(host_out + (size_t)k * (n / 8), cv->ldir + (size_t)k * cv->dstride, n / 8, hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }

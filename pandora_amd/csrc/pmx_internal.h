@@ -105,6 +105,7 @@ struct pmx_cv {
     uint8_t* ldir = nullptr;
     size_t ldir_bytes = 0;
     int Dp = 0;
+    size_t dstride = 0;  // bytes from one direction's volume to the next (H*W*Dp + a skew, see pmx_dir_stride)
     int gl = 0, kpl = 0;  // lane map of the fused kernels: gl lanes per scanline/pixel, kpl disparities per lane
     // uint8 matching costs [H][W][Dp] in the same lane-map order (packed-arithmetic SGM path, k_sgm8.hip)
     uint8_t* cost8 = nullptr;
@@ -178,6 +179,7 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
 int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost);
 int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity);
 bool pmx_sgm8_supported(int gl, int kpl, int nw);
+size_t pmx_dir_stride(int H, int W, int Dp);  // spacing of the eight path volumes
 int pmx_launch_build_range(pmx_ctx* ctx, pmx_cv* cv);        // geometry x ctx grids x ctx bad_left -> cv->range
 int pmx_launch_range_nan(pmx_ctx* ctx, pmx_cv* cv);          // float volume: NaN outside cv->range
 int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2, uint32_t invalid_cost);  // cost8 + 8 path volumes
