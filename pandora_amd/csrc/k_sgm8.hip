@@ -22,6 +22,7 @@
 // spare, so when every cost fits 5 bits (invalid_cost <= 31: census windows up to 5x5) the costs are stored SIX per dword
 // (CBITS = 5): a lane's 12 costs are 8 bytes instead of 12, laid out so that one shift + v_and_or_b32 yields a (lo16, hi16)
 // register of the recurrence (three such pairs per dword).
+#include <cstdio>
 #include <cstdlib>
 
 #include "pmx_internal.h"
@@ -263,11 +264,9 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-// Spacing of the eight path volumes.  They are written (and read back by the WTA) at the same pixel offset at the same time;
-// measured at C3 (tools/skew_probe.sh, r01): exactly H*W*Dp apart - 16 MB-aligned to each other - the path kernel takes
-// 1.70-1.76 ms and the WTA 0.86-0.91 ms; with a skew of 4 KB ... 1 MB between them 1.82 ms and 0.95 ms, every time.  That is
-// also the "slow" state fresh processes sometimes land in with no skew (physical placement), so alignment is kept and
-// PMX_DIR_SKEW=<bytes> (multiples of 4) stays as an experiment hook only.
+// Spacing of the eight path volumes: H*W*Dp rounded to 256 bytes.  PMX_DIR_SKEW=<bytes> (multiples of 4) adds a skew between
+// them - an experiment hook: skews of 4 KB ... 1 MB showed no benefit at C3 (tools/skew_probe.sh; the 7 % differences seen
+// between runs follow the box's clock state, not the placement of the buffers).
 size_t pmx_dir_stride(int H, int W, int Dp) {
     size_t skew = 0;
     if (const char* e = getenv("PMX_DIR_SKEW")) skew = (size_t)strtoul(e, nullptr, 10) & ~(size_t)3;
@@ -303,6 +302,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         cv->ldir_bytes = 8 * vol;
     }
     cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl; cv->dstride = vol;
+    if (getenv("PMX_DEBUG_PTRS")) fprintf(stderr, "PMX_PTRS cost8=%p ldir=%p codes=%p vol=%zu cvol=%zu\n", (void*)cv->cost8, (void*)cv->ldir, (void*)cv->codes, vol, cvol);
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
         cost8_args c;
