@@ -30,7 +30,7 @@ class CrossBasedCostAggregation(AbstractAggregation):
 
     def cost_volume_aggregation(self, img_left, img_right, cv, **cfg):
         subpix = cv.attrs["subpixel"]
-        eng = runtime.ensure_pair(img_left, img_right, subpix)
+        eng = runtime.ensure_pair(img_left, img_right, subpix, band=cv.attrs.get("band_correl"))
         dcv = cv["cost_volume"].device_cv
         eng.cbca(dcv, int(cv.attrs["offset_row_col"]), float(self._cbca_intensity), int(self._cbca_distance))
         cv.attrs["aggregation"] = "cbca"

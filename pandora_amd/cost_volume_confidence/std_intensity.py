@@ -51,7 +51,9 @@ class StdIntensity(_cvc.AbstractCostVolumeConfidence):
         window_size = cv.attrs["window_size"]
         conf = np.full((nb_row, nb_col), np.nan, dtype=np.float32)
         off = int((window_size - 1) / 2)
-        std = compute_std_raster(np.asarray(img_left["im"].data), window_size)
+        from .. import runtime
+
+        std = compute_std_raster(np.asarray(runtime.select_band(img_left, cv.attrs.get("band_correl"))), window_size)  # std_intensity.py:110-121
         if off != 0:
             conf[off:-off, off:-off] = std
         else:

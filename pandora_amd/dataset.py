@@ -106,16 +106,23 @@ class Dataset:
         return ds
 
 
-def make_image(data, disparity=None, msk=None, valid_pixels=0, no_data_mask=1, disparity_grids=None):
+def make_image(data, disparity=None, msk=None, valid_pixels=0, no_data_mask=1, disparity_grids=None, band_names=None):
     """Image dataset as produced by img_tools.create_dataset_from_inputs (img_tools.py:345-437):
-    ``im`` float32 (row, col), optional ``msk`` int16, ``disparity`` (band_disp=[min,max], row, col)."""
+    ``im`` float32 (row, col) - or (band_im, row, col) with ``band_names`` as the band_im coordinate -, optional ``msk``
+    int16, ``disparity`` (band_disp=[min,max], row, col)."""
     data = np.asarray(data)
-    if data.ndim != 2:
-        raise ValueError("only mono-band images are supported by pandora_amd (band selection is host-side glue)")
-    H, W = data.shape
-    ds = Dataset({"im": (("row", "col"), data.astype(np.float32))}, coords={"row": np.arange(H), "col": np.arange(W)},
-                 attrs={"valid_pixels": valid_pixels, "no_data_mask": no_data_mask, "crs": None, "transform": None,
-                        "no_data_img": None})
+    if data.ndim == 3:
+        if band_names is None or len(band_names) != data.shape[0]:
+            raise ValueError("a multiband image (band_im, row, col) needs one band name per band")
+        H, W = data.shape[1:]
+        ds = Dataset({"im": (("band_im", "row", "col"), data.astype(np.float32))},
+                     coords={"band_im": np.asarray(band_names), "row": np.arange(H), "col": np.arange(W)})
+    elif data.ndim == 2:
+        H, W = data.shape
+        ds = Dataset({"im": (("row", "col"), data.astype(np.float32))}, coords={"row": np.arange(H), "col": np.arange(W)})
+    else:
+        raise ValueError("an image is (row, col) or (band_im, row, col)")
+    ds.attrs.update({"valid_pixels": valid_pixels, "no_data_mask": no_data_mask, "crs": None, "transform": None, "no_data_img": None})
     if msk is not None:
         ds["msk"] = (("row", "col"), np.asarray(msk, np.int16))
     ds.attrs["disparity_source"] = None

@@ -79,9 +79,23 @@ class AbstractMatchingCost:
             raise ConfigError("spline_order must be an int in [1, 5]")
         if cfg["spline_order"] != 1 and cfg["subpix"] != 1:
             raise ConfigError("pandora_amd resamples the right image with spline_order 1 only")
-        if cfg["band"] is not None:
-            raise ConfigError("pandora_amd handles mono-band images only (select the band before the engine)")
         return cfg
+
+    def check_band_input_mc(self, img_left, img_right):
+        """matching_cost.py:186-231: the "band" parameter against the bands of the two images."""
+        def bands(ds):
+            return list(ds.coords["band_im"]) if "band_im" in ds.coords else None
+
+        left, right = bands(img_left), bands(img_right)
+        if self._band is not None:
+            if right is None:
+                raise AttributeError(f"Right dataset is monoband: {self._band} band cannot be selected")
+            if left is None:
+                raise AttributeError(f"Left dataset is monoband: {self._band} band cannot be selected")
+            if self._band not in right or self._band not in left:
+                raise AttributeError(f"Wrong band instantiate : {self._band} not in img_left or img_right")
+        elif left is not None and right is not None:
+            raise AttributeError("Band must be instantiated in matching cost step")
 
     @property
     def margins_value(self):
@@ -128,7 +142,8 @@ class AbstractMatchingCost:
         return cv
 
     def _bind_device_volume(self, img_left, img_right, cost_volume):
-        eng = runtime.ensure_pair(img_left, img_right, self._subpix)
+        self.check_band_input_mc(img_left, img_right)
+        eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band)
         dcv = eng.alloc_cv(cost_volume.attrs["_D"], cost_volume.attrs["_d0"])
         cost_volume.data_vars["cost_volume"] = DeviceVolumeArray(dcv, {k: cost_volume.coords[k] for k in ("row", "col", "disp")})
         return eng, dcv
@@ -159,7 +174,7 @@ class AbstractMatchingCost:
     def cv_masked(self, img_left, img_right, cost_volume, disp_min, disp_max):
         """In place: NaN for invalid / (dilated) no-data pixels and for disparities outside the
         per-pixel [disp_min, disp_max]; then the validity-mask updates of criteria.py:291-353."""
-        eng = runtime.ensure_pair(img_left, img_right, self._subpix)
+        eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band)
         dcv = cost_volume["cost_volume"].device_cv
         for side in (img_left, img_right):
             if "msk" in side.data_vars and (side.attrs.get("valid_pixels", 0) != img_left.attrs.get("valid_pixels", 0)

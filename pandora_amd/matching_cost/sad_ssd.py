@@ -1,6 +1,8 @@
 """SAD / SSD matching costs (reference: matching_cost/sad_ssd.py:39-368)."""
 import numpy as np
 
+from .. import runtime
+
 from .matching_cost import AbstractMatchingCost, ConfigError
 
 
@@ -19,7 +21,7 @@ class SadSsd(AbstractMatchingCost):
 
     def compute_cost_volume(self, img_left, img_right, cost_volume):
         eng, dcv = self._bind_device_volume(img_left, img_right, cost_volume)
-        left, right = img_left["im"].data, img_right["im"].data
+        left, right = runtime.select_band(img_left, self._band), runtime.select_band(img_right, self._band)  # sad_ssd.py:115-122
         min_left, max_left, min_right, max_right = np.amin(left), np.amax(left), np.amin(right), np.amax(right)
         if self._method == "sad":  # sad_ssd.py:132-137
             cmax = int(max(abs(max_left - min_right), abs(max_right - min_left)) * (self._window_size ** 2))

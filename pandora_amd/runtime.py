@@ -22,22 +22,32 @@ def get_engine(device=None):
     return _ENGINES[device]
 
 
-def _key(img_left, img_right, subpix):
+def _key(img_left, img_right, subpix, band):
     def ident(ds):
         im = ds["im"].data
         msk = ds["msk"].data if "msk" in ds.data_vars else None
         return (id(im), im.shape, None if msk is None else id(msk))
 
     return (ident(img_left), ident(img_right), int(subpix), img_left.attrs.get("valid_pixels", 0),
-            img_left.attrs.get("no_data_mask", 1))
+            img_left.attrs.get("no_data_mask", 1), band)
 
 
-def ensure_pair(img_left, img_right, subpix, device=None):
-    """Make (img_left, img_right) the resident pair of the engine (uploads images and masks once)."""
+def select_band(ds, band):
+    """The 2-D image the steps work on: the image itself, or the band named ``band`` of a (band_im, row, col) image
+    (census.py:124-131, sad_ssd.py / zncc.py alike; img_tools.py:735, :790)."""
+    im = np.asarray(ds["im"].data)
+    if im.ndim == 2:
+        return im
+    return im[list(ds.coords["band_im"]).index(band)]
+
+
+def ensure_pair(img_left, img_right, subpix, device=None, band=None):
+    """Make (img_left, img_right) the resident pair of the engine (uploads images and masks once); ``band`` names the
+    band of multiband images that is matched (matching_cost's "band" parameter, kept in cv.attrs["band_correl"])."""
     eng = get_engine(device)
-    key = _key(img_left, img_right, subpix)
+    key = _key(img_left, img_right, subpix, band)
     if _RESIDENT.get(eng.device) != key:
-        eng.set_images(np.asarray(img_left["im"].data, np.float32), np.asarray(img_right["im"].data, np.float32), subpix)
+        eng.set_images(np.asarray(select_band(img_left, band), np.float32), np.asarray(select_band(img_right, band), np.float32), subpix)
         ml = img_left["msk"].data if "msk" in img_left.data_vars else None
         mr = img_right["msk"].data if "msk" in img_right.data_vars else None
         # the reference keeps one mask convention per image; they are the same in practice

@@ -295,6 +295,26 @@ class PandoraMachine:
         m = matching_cost.AbstractMatchingCost(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = m.cfg
         self.step = m._step_col
+        for img in (self.left_img, self.right_img):  # state_machine.py:748-759
+            if img is not None:
+                bands = list(img.coords["band_im"]) if "band_im" in img.coords else [None]
+                self.check_band_pipeline(bands, cfg[input_step]["matching_cost_method"], m.cfg["band"])
+
+    @staticmethod
+    def check_band_pipeline(band_list, step, band_used):
+        """state_machine.py:1042-1072: a step's band parameter against the bands of an input image"""
+        if not band_used:
+            if len(band_list) != 1:
+                raise AttributeError(f"Missing band instantiate on {step} step : input image is multiband")
+        elif isinstance(band_used, (list, dict)):
+            for band in (band_used.values() if isinstance(band_used, dict) else band_used):
+                if band not in band_list:
+                    raise AttributeError(f"Wrong band instantiate on {step} step: {band} not in input image")
+        elif isinstance(band_used, str):
+            if band_used not in band_list:
+                raise AttributeError(f"Wrong band instantiate on {step} step: {band_used} not in input image")
+        else:
+            raise TypeError(f"Wrong type for band {band_used} used in {step}")
 
     def aggregation_check_conf(self, cfg, input_step):
         a = aggregation.AbstractAggregation(**cfg[input_step])
@@ -351,10 +371,10 @@ class PandoraMachine:
             trig = "check_" + input_step.split(".")[0]
             try:
                 self.trigger(trig, cfg["pipeline"], input_step)
-            except (MachineError, KeyError, AttributeError):
+            except (MachineError, KeyError, AttributeError) as err:  # state_machine.py:992-993: one error type, one message
                 logging.error("Problem during Pandora checking configuration steps sequencing. "
                               "Check your configuration file.")
-                raise
+                raise MachineError(f"A problem occurs during Pandora checking. Be sure of your sequencing ({err})") from err
         self.state = "begin"
         self._mode = None
         return self.pipeline_cfg

@@ -122,7 +122,7 @@ def test_bad_sequencing_is_rejected():
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
                                    "semantic_segmentation": {"segmentation_method": "ARNN"}}})
     assert "semantic_segmentation" in str(err.value)
-    with pytest.raises(KeyError) as err:  # a filter this build does not have: the reference's own error
+    with pytest.raises(MachineError) as err:  # a filter this build does not have: the plugin's KeyError, wrapped as the reference does
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
                                    "filter": {"filter_method": "median_for_intervals"}}})
     assert "No filter method named median_for_intervals supported" in str(err.value)
@@ -166,7 +166,7 @@ def test_validation_step_is_sequenced_after_the_disparity_map():
     right = make_image(np.zeros((4, 6)), disparity=[-1, 3])
     left.attrs["disparity_source"], right.attrs["disparity_source"] = [-2, 1], [-1, 3]
     del pipe["pipeline"]["validation"]["interpolated_disparity"]
-    with pytest.raises(AttributeError):
+    with pytest.raises(MachineError, match="A problem occurs during Pandora checking. Be sure of your sequencing"):  # test_config.py:266
         PandoraMachine().check_conf(pipe, left, right)
 
 
@@ -406,3 +406,42 @@ def test_save_results_writes_the_reference_tree(tmp_path):
         im.seek(1)
         np.testing.assert_array_equal(np.array(im), conf[:, :, 1])
     assert json.load(open(tmp_path / "cfg" / "config.json"))["pipeline"]["x"]["y"] == 3
+
+
+# ---- multiband images and the matching-cost "band" parameter ------------------------------------------------------------------
+def _two_band_pair():
+    data_l = np.zeros((2, 4, 4))
+    data_l[0] = [[1, 1, 1, 3], [1, 3, 2, 5], [2, 1, 0, 1], [1, 5, 4, 3]]
+    data_l[1] = [[2, 3, 4, 6], [8, 7, 0, 4], [4, 9, 1, 5], [6, 5, 2, 1]]
+    data_r = np.zeros((2, 4, 4))
+    data_r[0] = [[5, 1, 2, 3], [1, 3, 0, 2], [2, 3, 5, 0], [1, 6, 7, 5]]
+    data_r[1] = [[6, 5, 2, 7], [8, 7, 6, 5], [5, 2, 3, 6], [0, 3, 4, 7]]
+    return (make_image(data_l, disparity=[-1, 1], band_names=["red", "green"]), make_image(data_r, band_names=["red", "green"]))
+
+
+def test_band_errors_like_the_reference():
+    """test_matching_cost_census.py:226-376 (test_check_band_census, test_instantiate_band_with_monoband), same messages for
+    every measure; state_machine.py:1042-1072 check_band_pipeline."""
+    left, right = _two_band_pair()
+    grids = (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max"))
+    for method in ("census", "sad", "zncc"):
+        m = matching_cost.AbstractMatchingCost(matching_cost_method=method, window_size=3, subpix=1, band="blue")
+        with pytest.raises(AttributeError, match="Wrong band instantiate : blue not in img_left or img_right"):
+            m.compute_cost_volume(left, right, m.allocate_cost_volume(left, grids))
+        m = matching_cost.AbstractMatchingCost(matching_cost_method=method, window_size=3, subpix=1)
+        with pytest.raises(AttributeError, match="Band must be instantiated in matching cost step"):
+            m.compute_cost_volume(left, right, m.allocate_cost_volume(left, grids))
+    mono = make_image(np.zeros((4, 4)), disparity=[-1, 1])
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="census", window_size=3, subpix=1, band="red")
+    with pytest.raises(AttributeError, match="Right dataset is monoband: red band cannot be selected"):
+        m.compute_cost_volume(left, mono, m.allocate_cost_volume(left, grids))
+    with pytest.raises(AttributeError, match="Left dataset is monoband: red band cannot be selected"):
+        m.compute_cost_volume(mono, right, m.allocate_cost_volume(mono, grids))
+    pipe = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 3}, "disparity": {"disparity_method": "wta"}}}
+    with pytest.raises(MachineError):  # "Missing band instantiate on census step : input image is multiband"
+        PandoraMachine().check_conf(json.loads(json.dumps(pipe)), left, right)
+    pipe["pipeline"]["matching_cost"]["band"] = "green"
+    assert PandoraMachine().check_conf(json.loads(json.dumps(pipe)), left, right)["pipeline"]["matching_cost"]["band"] == "green"
+    pipe["pipeline"]["matching_cost"]["band"] = "blue"
+    with pytest.raises(MachineError):
+        PandoraMachine().check_conf(json.loads(json.dumps(pipe)), left, right)

@@ -324,3 +324,35 @@ def test_main_runs_the_sample_configuration_from_files(tmp_path):
     saved = json.load(open(out / "cfg" / "config.json"))
     assert saved["pipeline"]["validation"]["cross_checking_threshold"] == 1.0 and saved["input"]["right"]["disp"] == [0, 60]
     assert saved["pipeline"]["matching_cost"]["subpix"] == 4 and saved["input"]["left"]["nodata"] == -9999
+
+
+@pytest.mark.gpu
+def test_multiband_images_match_the_selected_band():
+    """matching_cost's "band" parameter (census.py:109-131, sad_ssd.py:110-122, cbca / std_intensity via cv.attrs["band_correl"]):
+    a pipeline on a two-band pair with band="green" gives exactly the maps of the same pipeline on the green band alone."""
+    import json
+
+    import pandora_amd
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, _ = load_cones()
+    Lb, Rb = np.stack([L[:, ::-1], L]), np.stack([R[:, ::-1], R])   # band 0 is a decoy
+    pipe = {"pipeline": {"matching_cost": {"matching_cost_method": "sad", "window_size": 3},
+                         "cost_volume_confidence": {"confidence_method": "std_intensity"},
+                         "aggregation": {"aggregation_method": "cbca"},
+                         "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                         "refinement": {"refinement_method": "vfit"}}}
+    outs = []
+    for multiband in (False, True):
+        left = make_image(Lb, disparity=[-60, 0], band_names=["red", "green"]) if multiband else make_image(L, disparity=[-60, 0])
+        right = make_image(Rb, band_names=["red", "green"]) if multiband else make_image(R)
+        cfg = json.loads(json.dumps(pipe))
+        if multiband:
+            cfg["pipeline"]["matching_cost"]["band"] = "green"
+        machine = PandoraMachine()
+        cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+        outs.append(pandora_amd.run(machine, left, right, cfg)[0])
+    for key in ("disparity_map", "validity_mask", "interpolated_coeff", "confidence_measure"):
+        np.testing.assert_array_equal(outs[0][key].data, outs[1][key].data)
+    assert outs[1].attrs["band_correl"] == "green" and outs[0].attrs["cmax"] == outs[1].attrs["cmax"]
