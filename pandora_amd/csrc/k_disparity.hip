@@ -314,7 +314,43 @@ int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out) {
     return PMX_OK;
 }
 
-// ---- reverse_cost_volume (matching_cost.cpp:26-56): (i,j,d) -> (i, j+d, -d) ---------------------
+// ---- reverse_cost_volume (matching_cost.cpp:26-56): out(i, j, d) = in(i, j + d + min_disp, D-1-d) ---------------------
+// An output tile of TC columns x D disparities reads a parallelogram of the input: from input column q it needs the
+// run of (at most TC) consecutive disparities D-1-d, d = q - min_disp - c, c in the tile - contiguous in memory.  The runs go
+// through an LDS tile laid out as the output (row pitch D+1 or D+2 floats, odd stride across the lanes of a run: no bank
+// conflicts), which then leaves as ONE contiguous block of TC*D floats.  Both sides of the re-index are coalesced.
+template <int TC>
+__global__ __launch_bounds__(kBlock) void reverse_tiled_kernel(const float* __restrict__ in, int W, int D, int min_disp,
+                                                               float* __restrict__ out) {
+    extern __shared__ float tile[];  // [TC][pitch]
+    const int pitch = D + 1 + (D & 1);  // even, so that pitch - 1 is odd
+    const int r = blockIdx.y, c0 = blockIdx.x * TC;
+    const size_t base = (size_t)r * W * D;
+    const int t = threadIdx.x % TC, slot = threadIdx.x / TC;
+    constexpr int QPI = kBlock / TC;    // input columns handled per iteration
+    const int q0 = c0 + min_disp;       // first input column of the band (d = 0 for the tile's first column)
+    const int nq = TC + D - 1;
+    const int c = c0 + t;
+    for (int iq = slot; iq < nq; iq += QPI) {
+        const int q = q0 + iq;
+        const int d = q - min_disp - c;  // = iq - t
+        if (d >= 0 && d < D) {
+            float v = d_nan();
+            if (q >= 0 && q < W && c < W) v = in[base + (size_t)q * D + (D - 1 - d)];
+            tile[t * pitch + d] = v;
+        }
+    }
+    __syncthreads();
+    const int ncol = min(TC, W - c0);
+    const int n = ncol * D;
+    float* dst = out + base + (size_t)c0 * D;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const int tc = i / D, d = i - tc * D;
+        dst[i] = tile[tc * pitch + d];
+    }
+}
+
+// plain gather for disparity ranges too wide for the LDS tile
 __global__ __launch_bounds__(kBlock) void reverse_kernel(const float* __restrict__ in, int W, int D, int min_disp,
                                                          float* __restrict__ out) {
     const int r = blockIdx.y;
@@ -328,8 +364,19 @@ __global__ __launch_bounds__(kBlock) void reverse_kernel(const float* __restrict
 
 int pmx_launch_reverse(pmx_ctx* ctx, const pmx_cv* in, int min_disp, pmx_cv* out) {
     pmx_stage_scope t(ctx, PMX_STAGE_REVERSE);
-    dim3 grid((in->W * in->D + kBlock - 1) / kBlock, in->H);
-    hipLaunchKernelGGL(reverse_kernel, grid, dim3(kBlock), 0, ctx->stream, in->data, in->W, in->D, min_disp, out->data);
+    const int pitch = in->D + 1 + (in->D & 1);
+    if (in->D <= 256) {
+        dim3 grid((in->W + 31) / 32, in->H);
+        hipLaunchKernelGGL(reverse_tiled_kernel<32>, grid, dim3(kBlock), 32 * pitch * sizeof(float), ctx->stream, in->data, in->W, in->D,
+                           min_disp, out->data);
+    } else if (in->D > 900) {
+        dim3 grid((in->W * in->D + kBlock - 1) / kBlock, in->H);
+        hipLaunchKernelGGL(reverse_kernel, grid, dim3(kBlock), 0, ctx->stream, in->data, in->W, in->D, min_disp, out->data);
+    } else {
+        dim3 grid((in->W + 15) / 16, in->H);
+        hipLaunchKernelGGL(reverse_tiled_kernel<16>, grid, dim3(kBlock), 16 * pitch * sizeof(float), ctx->stream, in->data, in->W, in->D,
+                           min_disp, out->data);
+    }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

@@ -445,6 +445,21 @@ def test_float_sgm_schedules_agree(eng, oracle, monkeypatch, is_max, P1, P2):
             cv.free()
 
 
+@pytest.mark.parametrize("H,W,D,md", [(5, 100, 129, -128), (4, 70, 300, -150), (3, 33, 1, 0), (6, 47, 64, 10), (2, 40, 950, -400)])
+def test_reverse_cost_volume_tiles(eng, oracle, H, W, D, md):
+    """pmx_reverse_cost_volume through its LDS-tiled kernel (32 or 16 columns per tile, partial last tile, ranges leaving the
+    image on both sides) and the plain gather kept for very wide ranges == matching_cost.cpp:26-56 restated."""
+    rng = np.random.default_rng(H * W + D)
+    cvh = rng.random((H, W, D)).astype(np.float32)
+    cvh[rng.random(cvh.shape) < 0.1] = np.nan
+    z = np.zeros((H, W), np.float32)
+    eng.set_images(z, z, 1)
+    cv = eng.alloc_cv(D, -D + 1)
+    cv.from_host(cvh)
+    out = eng.reverse_cost_volume(cv, md)
+    np.testing.assert_array_equal(out.to_host(), oracle.reverse_cost_volume(cvh, md))
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
