@@ -3,6 +3,9 @@
 #include <cstdarg>
 #include <cstring>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "pmx_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -92,6 +95,11 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     pmx_pool_free(ctx, ctx->scratch);
     hipFree(ctx->small);
     pmx_pool_release(ctx);
+    if (getenv("PMX_DEBUG_PTRS")) {
+        size_t live = 0;
+        for (auto& kv : ctx->pool_live) live += kv.second;
+        fprintf(stderr, "PMX_DESTROY live pool buffers: %zu (%zu MB)\n", ctx->pool_live.size(), live >> 20);
+    }
     for (auto& s : ctx->stages)
         for (auto e : s.ev) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
