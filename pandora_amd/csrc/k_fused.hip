@@ -557,7 +557,10 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
     if (is_max || overcounting) return false;
     if (cv->subpix != 1 || cv->D >= 16 * 20) return false;
     const int nw = (cv->win * cv->win + 31) / 32;
-    if (nw > 2) return false;
+    if (nw > 2) {  // wider census codes exist for the packed kernels only (k_sgm8.hip)
+        const char* e8 = getenv("PMX_SGM8");
+        if (nw > 6 || nw == 5 || getenv("PMX_FUSED_MAP") || (e8 && e8[0] == '0')) return false;
+    }
     auto is_int = [](float x) { return x == floorf(x); };
     if (!is_int(P1) || !is_int(P2) || !is_int(invalid_cost)) return false;
     if (invalid_cost < 0 || invalid_cost + P2 > 255.f) return false;

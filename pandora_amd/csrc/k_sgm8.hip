@@ -273,7 +273,7 @@ size_t pmx_dir_stride(int H, int W, int Dp) {
     return (((size_t)H * W * Dp + 255) & ~(size_t)255) + skew;
 }
 
-bool pmx_sgm8_supported(int gl, int kpl, int nw) { return gl == 16 && (kpl % 4) == 0 && kpl >= 4 && kpl <= 20 && nw <= 2; }
+bool pmx_sgm8_supported(int gl, int kpl, int nw) { return gl == 16 && (kpl % 4) == 0 && kpl >= 4 && kpl <= 20 && nw <= 6 && nw != 5; }
 
 int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2, uint32_t invalid_cost) {
     const int H = cv->H, W = cv->W;
@@ -313,7 +313,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         const size_t want = ((size_t)H * W + 15) / 16;  // 4 pixels per wave, 4 waves per block
         const dim3 grid((unsigned)(want < 65536 ? want : 65536));
 #define PMX_COST8(NWV, KPLV)                                                                                                  \
-    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, 5>), grid, dim3(256), 0, ctx->stream, c);   \
+    if (five && NWV == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, (NWV == 1 ? 5 : 8)>), grid, dim3(256), 0, ctx->stream, c); \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, 8>), grid, dim3(256), 0, ctx->stream, c)
 #define PMX_COST8_KPL(NWV)                 \
     switch (kpl) {                         \
@@ -323,7 +323,13 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         case 16: PMX_COST8(NWV, 16); break;\
         default: PMX_COST8(NWV, 20); break;\
     }
-        if (nw == 1) { PMX_COST8_KPL(1) } else { PMX_COST8_KPL(2) }
+        switch (nw) {  // census windows 3x3 / 5x5: one code word, 7x7: two, 9x9: three, 11x11: four, 13x13: six
+            case 1: PMX_COST8_KPL(1) break;
+            case 2: PMX_COST8_KPL(2) break;
+            case 3: PMX_COST8_KPL(3) break;
+            case 4: PMX_COST8_KPL(4) break;
+            default: PMX_COST8_KPL(6) break;
+        }
 #undef PMX_COST8_KPL
 #undef PMX_COST8
     }

@@ -433,7 +433,7 @@ extern "C" int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
     // worth it where the fused SGM path can consume them
     const int nw = (win * win + 31) / 32;
     // (a right mask makes cv_masked a per-cell pattern: float volume; grids and a left mask are intervals per pixel and stay lazy)
-    const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 2 && cv->D < 320 && abs(cv->d0) + cv->D <= 1024 / nw - 32 && !ctx->msk_right;
+    const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 6 && cv->D < 320 && abs(cv->d0) + cv->D <= 1024 / nw - 32 && !ctx->msk_right;
     cv->has_range = false;
     if (!defer) {
         rc = pmx_cv_ensure_data(ctx, cv);

@@ -460,6 +460,32 @@ def test_reverse_cost_volume_tiles(eng, oracle, H, W, D, md):
     np.testing.assert_array_equal(out.to_host(), oracle.reverse_cost_volume(cvh, md))
 
 
+@pytest.mark.parametrize("win", [7, 9, 11, 13])
+def test_wide_census_windows_stay_on_the_integer_path(eng, oracle, win):
+    """Census windows of 2, 3, 4 and 6 code words (7x7 ... 13x13) -> SGM -> WTA -> vfit on the packed integer kernels (byte
+    costs; the eight byte path volumes exist afterwards) == the oracle."""
+    if not eng.lazy:
+        pytest.skip("the integer fast path only exists in lazy mode")
+    H, W, dmin, dmax = 29, 61, -11, 7
+    D = dmax - dmin + 1
+    L, R = pair(H, W, seed=win)
+    cv = gpu_cv(eng, "census", L, R, dmin, dmax, 1, win)
+    eng.sgm(cv, 5, 40, False, float(win * win + 1), False)
+    raw, gl, kpl = eng.debug_path_costs(cv, raw=True)   # raises unless the fast path ran
+    assert raw.shape[0] == 8 and gl == 16
+    eng.set_validity(None)
+    eng.wta(cv, False, -9999.0)
+    eng.refine(cv, "vfit", False)
+    disp, val, itp = eng.get_disparity(want_itp=True)
+    ocv = oracle.sgm(cpu_cv(oracle, "census", L, R, dmin, dmax, 1, win), 5, 40, False, float(win * win + 1), False)
+    odisp, oval = oracle.wta(ocv, dmin, 1, False, -9999.0)
+    oitp, odisp, oval = oracle.refine(ocv, odisp, oval, dmin, dmax, 1, False, "vfit")
+    np.testing.assert_array_equal(disp, odisp)
+    np.testing.assert_array_equal(val, oval)
+    np.testing.assert_array_equal(itp, oitp)
+    np.testing.assert_array_equal(cv.to_host(), ocv)
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
