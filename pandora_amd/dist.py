@@ -84,3 +84,65 @@ def crop_tile(arr, H, world, rank, margin=40):
 def stitch_tiles(parts):
     """Concatenate the owned rows of all ranks (rank order) into the full map."""
     return np.concatenate(parts, axis=0)
+
+
+def tile_dataset(ds, rlo, rhi):
+    """Rows [rlo, rhi) of an image dataset (im, msk, disparity grids), attrs shared."""
+    from .dataset import DataArray, Dataset
+
+    im = np.asarray(ds["im"].data)
+    rows = slice(rlo, rhi)
+    out = Dataset({"im": (ds["im"].dims, np.ascontiguousarray(im[..., rows, :]))},
+                  coords={k: (np.asarray(v)[rows] if k == "row" else v) for k, v in ds.coords.items()}, attrs=dict(ds.attrs))
+    if "msk" in ds.data_vars:
+        out["msk"] = (("row", "col"), np.ascontiguousarray(np.asarray(ds["msk"].data)[rows]))
+    if "disparity" in ds.data_vars:
+        out["disparity"] = DataArray(np.ascontiguousarray(np.asarray(ds["disparity"].data)[:, rows]), ("band_disp", "row", "col"),
+                                     {"band_disp": ["min", "max"]})
+    return out
+
+
+def run_row_tiled(img_left, img_right, cfg, margin=40, group=None):
+    """One stereo pair over all ranks, the reference's way (ROI tiles with a margin, marge.py:86-101; 40 px is what the SGM
+    plugin asks for, optimization/optimization.py:43): every rank runs the whole pipeline of ``cfg`` on its rows plus the
+    margin on its own GPU, keeps the rows it owns, and the owned rows of all ranks are gathered on every rank (the only
+    exchange: the 2-D results).  Local pipelines are exact with a margin of at least the window radius; SGM paths are cut at
+    the tile margin, as in the reference.  Returns (left, right) dicts of full-size arrays: disparity_map, validity_mask and,
+    when present, interpolated_coeff.  Works without torch.distributed (one tile)."""
+    from . import run as run_pipeline
+    from .state_machine import PandoraMachine
+
+    world, rank, dist = 1, 0, None
+    try:
+        import torch.distributed as dist_mod
+
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            dist = dist_mod
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+    except ImportError:
+        pass
+    H = img_left.sizes["row"]
+    (lo, hi), (rlo, rhi) = row_tile(H, world, rank, margin)
+    tile_l, tile_r = tile_dataset(img_left, rlo, rhi), tile_dataset(img_right, rlo, rhi)
+    machine = PandoraMachine()
+    tcfg = {"pipeline": machine.check_conf({"pipeline": cfg["pipeline"]}, tile_l, tile_r)["pipeline"]}
+    out_l, out_r = run_pipeline(machine, tile_l, tile_r, tcfg)
+
+    def owned(ds):
+        if len(ds.sizes) == 0:
+            return None
+        return {k: np.ascontiguousarray(np.asarray(ds[k].data)[lo - rlo:hi - rlo])
+                for k in ("disparity_map", "validity_mask", "interpolated_coeff") if k in ds.data_vars}
+
+    mine = (owned(out_l), owned(out_r))
+    if dist is None:
+        return mine
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+
+    def stitch(side):
+        if parts[0][side] is None:
+            return None
+        return {k: stitch_tiles([p[side][k] for p in parts]) for k in parts[0][side]}
+
+    return stitch(0), stitch(1)

@@ -1,0 +1,69 @@
+"""GPU: pandora_amd.dist.run_row_tiled with TWO ranks (gloo rendezvous, both on the box's one GPU) against the untiled
+run: a local pipeline must be identical everywhere; a census+SGM pipeline is cut at the 40-row margin like the reference's
+own ROI tiling, so it may differ on a few pixels but must stay within the cones gate."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist          # torch first (its HIP runtime), then libpandora_amd.so
+sys.path.insert(0, %(root)r)
+from PIL import Image
+import pandora_amd
+from pandora_amd import dist as pdist
+from pandora_amd.dataset import make_image
+from pandora_amd.state_machine import PandoraMachine
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+cones = os.path.join(%(root)r, "tests", "golden", "cones")
+L = np.array(Image.open(os.path.join(cones, "left.png"))).astype(np.float32)
+R = np.array(Image.open(os.path.join(cones, "right.png"))).astype(np.float32)
+gt = np.array(Image.open(os.path.join(cones, "disp_left.tif"))).astype(np.float32)
+LOCAL = {"pipeline": {"matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 2},
+                      "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                      "refinement": {"refinement_method": "vfit"}}}
+SGM = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                    "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                    "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                    "refinement": {"refinement_method": "vfit"},
+                    "validation": {"validation_method": "cross_checking_accurate"}}}
+for name, cfg in (("local", LOCAL), ("sgm", SGM)):
+    left, right = make_image(L, disparity=[-60, 0]), make_image(R, disparity=[0, 60])
+    tl, tr = pdist.run_row_tiled(left, right, cfg, margin=40)
+    if rank == 0:
+        m = PandoraMachine()
+        full_cfg = {"pipeline": m.check_conf({"pipeline": cfg["pipeline"]}, left, right)["pipeline"]}
+        fl, fr = pandora_amd.run(m, left, right, full_cfg)
+        assert tl["disparity_map"].shape == L.shape
+        same = np.isclose(tl["disparity_map"], fl["disparity_map"].data, equal_nan=True)
+        if name == "local":
+            assert same.all() and np.array_equal(tl["validity_mask"], fl["validity_mask"].data) and tr is None
+            assert np.array_equal(tl["interpolated_coeff"], fl["interpolated_coeff"].data, equal_nan=True)
+        else:
+            bad = (np.abs(np.nan_to_num(tl["disparity_map"], nan=1e4) + gt) > 1) & (gt != 0)
+            assert bad.sum() / gt.size <= 0.20 and tr is not None and tr["disparity_map"].shape == L.shape
+            print("SGM_TILED_SAME_FRACTION", same.mean())
+            assert same.mean() > 0.97
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print("TILED_OK")
+'''
+
+
+def test_row_tiled_pair_over_two_ranks(tmp_path):
+    pytest.importorskip("torch")
+    script = tmp_path / "tiled.py"
+    script.write_text(SCRIPT % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0")  # both ranks on the box's one GPU
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert "TILED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
