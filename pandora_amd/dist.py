@@ -33,7 +33,12 @@ def allreduce_min_keys(keys, group=None):
     """In-place MIN all-reduce of an int64 key tensor (any device)."""
     import torch.distributed as dist
 
-    dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+    if keys.is_cuda and dist.get_backend(group) != "nccl":  # gloo (tests): through the host
+        host = keys.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+        keys.copy_(host)
+    else:
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
     return keys
 
 
@@ -146,3 +151,89 @@ def run_row_tiled(img_left, img_right, cfg, margin=40, group=None):
         return {k: stitch_tiles([p[side][k] for p in parts]) for k in parts[0][side]}
 
     return stitch(0), stitch(1)
+
+
+def run_d_sharded(img_left, img_right, cfg, group=None):
+    """One stereo pair, the cost volume sharded over D across the ranks (pipelines WITHOUT optimization): every
+    rank builds and aggregates the costs of its disparity slice (one integer disparity of halo on each side), the slices meet
+    in ONE all_reduce(MIN) of a packed (cost, global index) key per pixel (RCCL over xGMI with the nccl backend), and the
+    rank that owns a pixel's winner refines it.  Small 2-D exchanges besides the keys: the all-NaN pixel flags (for the
+    validity mask) and the refined values.  The maps equal the unsharded run bit for bit.  Supported steps: matching_cost,
+    aggregation, disparity, refinement; uniform disparity ranges.  Returns {"disparity_map", "validity_mask"
+    [, "interpolated_coeff"]} on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    from . import criteria, matching_cost, runtime
+    from .dataset import make_image
+    from .state_machine import PandoraMachine
+
+    pipe = cfg["pipeline"]
+    extra = [k for k in pipe if k.split(".")[0] not in ("matching_cost", "aggregation", "disparity", "refinement")]
+    if extra or "disparity" not in pipe:
+        raise NotImplementedError(f"run_d_sharded handles matching_cost / aggregation / disparity / refinement only (got {extra})")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    grids = np.asarray(img_left["disparity"].data)
+    dmin, dmax = int(grids[0].min()), int(grids[1].max())
+    if grids[0].max() != dmin or grids[1].min() != dmax:
+        raise NotImplementedError("run_d_sharded needs one disparity range for the whole image")
+    if dmax - dmin + 1 < world:
+        raise ValueError("fewer disparities than ranks")
+    (olo, ohi), (wlo, whi) = disparity_shard(dmin, dmax, 1, world, rank, halo=1)
+    left_w = make_image(np.asarray(img_left["im"].data), disparity=[wlo, whi], msk=img_left["msk"].data if "msk" in img_left.data_vars else None,
+                        valid_pixels=img_left.attrs.get("valid_pixels", 0), no_data_mask=img_left.attrs.get("no_data_mask", 1),
+                        band_names=list(img_left.coords["band_im"]) if "band_im" in img_left.coords else None)
+    machine = PandoraMachine()
+    head = {"pipeline": {k: pipe[k] for k in pipe if k.split(".")[0] in ("matching_cost", "aggregation")}}
+    head["pipeline"]["disparity"] = pipe["disparity"]  # (checked for the sequencing, not run here)
+    checked = machine.check_conf(head, left_w, img_right)["pipeline"]
+    machine.run_prepare({"pipeline": checked}, left_w, img_right)
+    for step in checked:
+        if step.split(".")[0] != "disparity":
+            machine.run(step, {"pipeline": checked})
+    cv = machine.left_cv
+    dcv = cv["cost_volume"].device_cv
+    eng = dcv.engine
+    subpix = int(cv.attrs["subpixel"])
+    is_max = cv.attrs["type_measure"] == "max"
+    dev = torch.device("cuda", eng.device)
+
+    def reduce_(t, op):
+        if dist.get_backend(group) != "nccl":
+            host = t.cpu()
+            dist.all_reduce(host, op=op, group=group)
+            return host.to(t.device) if t.is_cuda else host
+        dist.all_reduce(t, op=op, group=group)
+        return t
+
+    # ---- the validity mask of the WHOLE range (criteria.py:66-158, :291-353), with the all-NaN pixels of the whole volume
+    mc = matching_cost.AbstractMatchingCost(**{k: v for k, v in checked["matching_cost"].items()})
+    grid = mc.allocate_cost_volume(img_left, (img_left["disparity"].sel(band_disp="min"), img_left["disparity"].sel(band_disp="max")))
+    grid = criteria.validity_mask(img_left, img_right, grid)
+    missing = torch.from_numpy(eng.nan_pixels(dcv).astype(np.uint8)).to(dev)
+    missing = reduce_(missing, dist.ReduceOp.MIN).cpu().numpy().astype(bool)  # NaN for every disparity of every shard
+    criteria.mask_invalid_variable_disparity_range(grid, missing)
+    if grid.attrs["offset_row_col"] > 0:
+        criteria.mask_border(grid)
+    eng.set_validity(np.asarray(grid["validity_mask"].data, np.int64))
+    # ---- winner-takes-all over the shards: one all-reduce of 8 bytes per pixel
+    invalid = pipe["disparity"].get("invalid_disparity", -9999)
+    invalid = float("nan") if isinstance(invalid, str) else float(invalid)
+    sharded_wta(eng, dcv, is_max, (wlo - dmin) * subpix, dmin, subpix, invalid, group)
+    disp, val = eng.get_disparity()
+    out = {"disparity_map": disp, "validity_mask": val}
+    if "refinement" in pipe:
+        eng.refine(dcv, pipe["refinement"]["refinement_method"], is_max)
+        rdisp, rval, ritp = eng.get_disparity(want_itp=True)
+        last = rank == world - 1
+        owner = (disp >= olo) & ((disp <= ohi) if last else (disp < ohi + 1)) & ((val & 0x3C3) == 0)
+        pack = torch.from_numpy(np.stack([np.where(owner, rdisp, 0.0), np.where(owner, np.nan_to_num(ritp, nan=0.0), 0.0),
+                                          np.where(owner & np.isnan(ritp), 1.0, 0.0), owner.astype(np.float32)]).astype(np.float32)).to(dev)
+        pack = reduce_(pack, dist.ReduceOp.SUM).cpu().numpy()    # exactly one owner per valid pixel: value + zeros is exact
+        flags = torch.from_numpy(np.where(owner, rval - val, 0).astype(np.int64)).to(dev)
+        flags = reduce_(flags, dist.ReduceOp.SUM).cpu().numpy()
+        owned = pack[3] > 0
+        itp = np.where(owned, np.where(pack[2] > 0, np.nan, pack[1]), np.nan).astype(np.float32)
+        out = {"disparity_map": np.where(owned, pack[0], disp).astype(np.float32), "validity_mask": val + flags, "interpolated_coeff": itp}
+    runtime.invalidate(eng.device)
+    return out

@@ -67,3 +67,55 @@ def test_row_tiled_pair_over_two_ranks(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert "TILED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+DSHARD = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from PIL import Image
+import pandora_amd
+from pandora_amd import dist as pdist
+from pandora_amd.dataset import make_image
+from pandora_amd.state_machine import PandoraMachine
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+cones = os.path.join(%(root)r, "tests", "golden", "cones")
+L = np.array(Image.open(os.path.join(cones, "left.png"))).astype(np.float32)[40:200, 30:330]
+R = np.array(Image.open(os.path.join(cones, "right.png"))).astype(np.float32)[40:200, 30:330]
+msk = np.zeros(L.shape, np.int16); msk[50:60, 100:130] = 2; msk[5, 7] = 1
+CASES = [
+    ({"matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 2},
+      "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"}, "refinement": {"refinement_method": "vfit"}}, None),
+    ({"matching_cost": {"matching_cost_method": "sad", "window_size": 3}, "aggregation": {"aggregation_method": "cbca"},
+      "disparity": {"disparity_method": "wta", "invalid_disparity": -9999}, "refinement": {"refinement_method": "quadratic"}}, msk),
+    ({"matching_cost": {"matching_cost_method": "census", "window_size": 5}, "disparity": {"disparity_method": "wta", "invalid_disparity": -9999}}, None),
+]
+for pipe, m in CASES:
+    left, right = make_image(L, disparity=[-37, 3], msk=m), make_image(R, msk=m)
+    got = pdist.run_d_sharded(left, right, {"pipeline": pipe})
+    if rank == 0:
+        left, right = make_image(L, disparity=[-37, 3], msk=m), make_image(R, msk=m)
+        mach = PandoraMachine()
+        cfg = {"pipeline": mach.check_conf({"pipeline": pipe}, left, right)["pipeline"]}
+        full, _ = pandora_amd.run(mach, left, right, cfg)
+        for key in got:
+            np.testing.assert_array_equal(got[key], np.asarray(full[key].data), err_msg=key + " " + pipe["matching_cost"]["matching_cost_method"])
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print("DSHARD_OK")
+'''
+
+
+def test_d_sharded_pair_over_two_ranks(tmp_path):
+    """pandora_amd.dist.run_d_sharded (costs sharded over D, one all_reduce(MIN) of packed keys, owner-rank refinement) with two
+    ranks == the unsharded machine run, bit for bit: ZNCC sub-pixel + vfit, SAD + CBCA + quadratic with masks, census."""
+    pytest.importorskip("torch")
+    script = tmp_path / "dshard.py"
+    script.write_text(DSHARD % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29543", str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert "DSHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-6000:]
