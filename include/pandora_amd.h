@@ -85,6 +85,11 @@ int pmx_zncc(pmx_ctx* ctx, pmx_cv* cv, int win);
 /* AbstractMatchingCost.cv_masked NaN injection (matching_cost/matching_cost.py:770-872) using the
  * masks / grids set on the context. */
 int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);
+/* The "use_confidence" option of the SGM step (docs/source/userguide/plugins/plugin_libsgm.rst:38-47; the arithmetic is in the
+ * un-vendored pandora_plugin_libsgm): E(D) = sum_p C(p, D_p) * Confidence(p) + penalties, i.e. every cost of pixel p is multiplied
+ * by the pixel's confidence before the optimisation.  weights: float32 [H][W] host (NaN = no confidence for that pixel = 1);
+ * the volume is brought to float32 and scaled in place, NaN costs stay NaN. */
+int pmx_cv_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* weights);
 /* Pixels whose cost is NaN for every disparity (np.min(np.isnan(cv), axis=2)), uint8 [H][W] on the
  * host: input of criteria.mask_invalid_variable_disparity_range (criteria.py:291-322). */
 int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out);

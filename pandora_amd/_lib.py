@@ -55,6 +55,7 @@ SIGNATURES = {
                                      C.c_int, C.c_double, C.POINTER(C.c_float)]),
     "pmx_reverse_disp_range": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pmx_cv_scale_pixels": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     "pmx_interpolate_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, c_int_p, C.c_int]),
     "pmx_median_filter_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int]),
     "pmx_bilateral_filter_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_double,

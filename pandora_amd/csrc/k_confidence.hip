@@ -136,3 +136,21 @@ int pmx_launch_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* d_etas, int nbr_
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
+
+
+// ---- use_confidence of the SGM step (docs/source/userguide/plugins/plugin_libsgm.rst:38-47): E(D) takes C(p, d) * Confidence(p).
+// One weight per pixel; NaN weights (pixels without a confidence) count as 1, NaN costs stay NaN.
+__global__ __launch_bounds__(kBlock) void scale_pixels_kernel(float* __restrict__ cv, const float* __restrict__ w, int W, int D) {
+    const int r = blockIdx.y;
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= W * D) return;
+    const float wp = w[(size_t)r * W + j / D];
+    if (wp == wp) cv[(size_t)r * W * D + j] *= wp;
+}
+
+int pmx_launch_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* d_weights) {
+    dim3 grid((cv->W * cv->D + kBlock - 1) / kBlock, cv->H);
+    hipLaunchKernelGGL(scale_pixels_kernel, grid, dim3(kBlock), 0, ctx->stream, cv->data, d_weights, cv->W, cv->D);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

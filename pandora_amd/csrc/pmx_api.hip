@@ -477,6 +477,22 @@ extern "C" int pmx_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win) {
     return pmx_launch_cv_masked(ctx, cv, win);
 }
 
+extern "C" int pmx_cv_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* weights) {
+    int rc = check_cv(ctx, cv, "pmx_cv_scale_pixels");
+    if (rc) return rc;
+    PMX_CHECK(weights, PMX_ERR_ARG, "pmx_cv_scale_pixels: null weights");
+    const size_t n = (size_t)cv->H * cv->W;
+    rc = pmx_need_small(ctx, n * sizeof(float));
+    if (rc) return rc;
+    rc = pmx_cv_materialize(ctx, cv);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(ctx->small, weights, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_scale_pixels(ctx, cv, (const float*)ctx->small);
+    if (rc) return rc;
+    PMX_HIP(hipStreamSynchronize(ctx->stream));  // the host weights may be released by the caller
+    return PMX_OK;
+}
+
 extern "C" int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out) {
     int rc = check_cv(ctx, cv, "pmx_nan_pixels");
     if (rc) return rc;

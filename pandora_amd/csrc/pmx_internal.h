@@ -196,6 +196,7 @@ int pmx_launch_bilateral_disparity(pmx_ctx* ctx, const float* in, const int64_t*
                                    double sigma_color, float* out);
 int pmx_launch_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity, int H, int W, int win, int marge, int gmin,
                                int gmax, float* out_min, float* out_max);
+int pmx_launch_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* d_weights);
 int pmx_launch_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* d_etas, int nbr_etas, const int64_t* d_gmin, const int64_t* d_gmax,
                          int negate, uint32_t* d_mm, float* d_amb);
 int pmx_launch_interpolate_nodata(pmx_ctx* ctx, const float* img, const int* msk, int H, int W, int invalid_bits, int filled,

@@ -122,6 +122,13 @@ class Engine:
     def cv_masked(self, cv, win):
         check(_lib.lib().pmx_cv_masked(self.ctx, cv.handle, int(win)), "pmx_cv_masked")
 
+    def scale_pixels(self, cv, weights):
+        """cost(p, d) *= weights[p] (SGM's use_confidence, plugin_libsgm.rst:38-47); NaN weights leave the pixel alone."""
+        w = np.ascontiguousarray(weights, np.float32)
+        if w.shape != (self.H, self.W):
+            raise ValueError("scale_pixels: one weight per pixel")
+        check(_lib.lib().pmx_cv_scale_pixels(self.ctx, cv.handle, _p(w, C.c_float)), "pmx_cv_scale_pixels")
+
     def nan_pixels(self, cv):
         out = np.empty((self.H, self.W), np.uint8)
         check(_lib.lib().pmx_nan_pixels(self.ctx, cv.handle, _p(out, C.c_uint8)), "pmx_nan_pixels")

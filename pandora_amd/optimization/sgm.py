@@ -25,6 +25,7 @@ class Sgm(AbstractOptimization):
         pen = self.cfg["penalty"]
         self._p1, self._p2 = float(pen["P1"]), float(pen["P2"])
         self._overcounting = bool(self.cfg["overcounting"])
+        self._use_confidence = self.cfg.get("use_confidence") or None
 
     def check_conf(self, **cfg):
         cfg.setdefault("overcounting", self._OVERCOUNTING)
@@ -43,9 +44,12 @@ class Sgm(AbstractOptimization):
             raise ConfigError("penalties must satisfy 0 < P1 < P2 (plugin_libsgm.rst:170-185)")
         if cfg["min_cost_paths"]:
             raise ConfigError("min_cost_paths is not implemented")
-        for k in ("use_confidence", "geometric_prior"):
-            if cfg.get(k) not in (None, False, {"source": "internal"}):
-                raise ConfigError(f"{k} is out of scope of pandora_amd")
+        if cfg.get("geometric_prior") not in (None, False, {"source": "internal"}):
+            raise ConfigError("geometric_prior (piecewise optimisation) is out of scope of pandora_amd")
+        use = cfg.get("use_confidence")
+        if use not in (None, False) and not (isinstance(use, str) and use.split(".")[0] == "cost_volume_confidence"):
+            raise ConfigError("use_confidence names the cost_volume_confidence step whose ambiguity is applied, "
+                              "e.g. 'cost_volume_confidence' or 'cost_volume_confidence.before'")
         return cfg
 
     def desc(self):
@@ -59,6 +63,15 @@ class Sgm(AbstractOptimization):
         is_max = cv.attrs["type_measure"] == "max"
         cmax = float(cv.attrs["cmax"])
         invalid_cost = cmax + 1.0  # this build's convention: NaN cells cost "worse than the worst"
+        if self._use_confidence:
+            # plugin_libsgm.rst:38-47: E(D) = sum_p C(p, D_p) * Confidence(p) + ...; the ambiguity confidence computed by the
+            # named step (indicator suffix = what follows "cost_volume_confidence" in the step's name).  "If not [computed],
+            # default confidence values equal to 1 will be used"
+            suffix = self._use_confidence[len("cost_volume_confidence"):]
+            name = "confidence_from_ambiguity" + suffix
+            if "confidence_measure" in cv.data_vars and name in list(cv.coords.get("indicator", [])):
+                layer = list(cv.coords["indicator"]).index(name)
+                dcv.engine.scale_pixels(dcv, np.asarray(cv["confidence_measure"].data)[:, :, layer])
         dcv.engine.sgm(dcv, self._p1, self._p2, is_max, invalid_cost, self._overcounting)
         cv.attrs["optimization"] = "sgm"
         cv.attrs["cmax"] = 8.0 * (cmax + self._p2)  # upper bound of the 8-path sum

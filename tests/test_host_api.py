@@ -445,3 +445,15 @@ def test_band_errors_like_the_reference():
     pipe["pipeline"]["matching_cost"]["band"] = "blue"
     with pytest.raises(MachineError):
         PandoraMachine().check_conf(json.loads(json.dumps(pipe)), left, right)
+
+
+def test_sgm_use_confidence_configuration():  # plugin_libsgm.rst:38-47, :88-209
+    from pandora_amd import optimization
+
+    o = optimization.AbstractOptimization(None, optimization_method="sgm", use_confidence="cost_volume_confidence.before")
+    assert o.cfg["use_confidence"] == "cost_volume_confidence.before"
+    assert optimization.AbstractOptimization(None, optimization_method="sgm", use_confidence=False).cfg["use_confidence"] is False
+    with pytest.raises(ConfigError):
+        optimization.AbstractOptimization(None, optimization_method="sgm", use_confidence="ambiguity")
+    with pytest.raises(ConfigError):
+        optimization.AbstractOptimization(None, optimization_method="sgm", geometric_prior={"source": "segm"})

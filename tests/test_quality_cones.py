@@ -70,6 +70,17 @@ SAMPLE_SGM = {"pipeline": {  # data_samples/json_conf_files/a_semi_global_matchi
     "validation": {"validation_method": "cross_checking_accurate", "cross_checking_threshold": 1},
     "filter.this_time_after_validation": {"filter_method": "median", "filter_size": 3}}}
 
+SAMPLE_SGM_CONF = {"pipeline": {  # data_samples/json_conf_files/a_semi_global_matching_with_confidence.json, as written
+    "matching_cost": {"matching_cost_method": "census", "window_size": 5, "subpix": 1},
+    "cost_volume_confidence.before": {"confidence_method": "ambiguity", "eta_max": 0.7, "eta_step": 0.01},
+    "optimization": {"optimization_method": "sgm", "use_confidence": "cost_volume_confidence.before", "overcounting": False,
+                     "penalty": {"penalty_method": "sgm_penalty", "P1": 8, "P2": 32, "p2_method": "constant"}},
+    "cost_volume_confidence.after": {"confidence_method": "ambiguity", "eta_max": 0.7, "eta_step": 0.01},
+    "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+    "refinement": {"refinement_method": "vfit"},
+    "filter": {"filter_method": "median", "filter_size": 3},
+    "validation": {"validation_method": "cross_checking_accurate", "cross_checking_threshold": 1}}}
+
 SAMPLE_LOCAL = {"pipeline": {  # data_samples/json_conf_files/a_local_block_matching.json:11-27, as written (BASELINE configs[0])
     "matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 4},
     "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
@@ -87,6 +98,7 @@ VALIDATION_REF = {"pipeline": {  # tests/common.py:168-175, as written
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,cfg", [("a_semi_global_matching.json", SAMPLE_SGM), ("a_local_block_matching.json", SAMPLE_LOCAL),
+                                      ("a_semi_global_matching_with_confidence.json", SAMPLE_SGM_CONF),
                                       ("tests/common.py validation_pipeline_cfg", VALIDATION_REF)], ids=lambda x: x if isinstance(x, str) else "")
 def test_sample_configurations_run_as_written_and_meet_the_reference_gates(name, cfg):
     """The reference's sample pipelines, every step on the device, with the acceptance thresholds of
@@ -117,6 +129,8 @@ def test_sample_configurations_run_as_written_and_meet_the_reference_gates(name,
     assert list(dl.coords["indicator"])[-1] == "confidence_from_left_right_consistency"
     if "cost_volume_confidence" in cfg["pipeline"]:
         assert list(dl.coords["indicator"])[0] == "confidence_from_intensity_std"
+    if "cost_volume_confidence.before" in cfg["pipeline"]:
+        assert list(dl.coords["indicator"])[:2] == ["confidence_from_ambiguity.before", "confidence_from_ambiguity.after"]
 
 
 MULTISCALE_REF = {"pipeline": {  # tests/common.py:177-183 multiscale_pipeline_cfg
@@ -356,3 +370,38 @@ def test_multiband_images_match_the_selected_band():
     for key in ("disparity_map", "validity_mask", "interpolated_coeff", "confidence_measure"):
         np.testing.assert_array_equal(outs[0][key].data, outs[1][key].data)
     assert outs[1].attrs["band_correl"] == "green" and outs[0].attrs["cmax"] == outs[1].attrs["cmax"]
+
+
+@pytest.mark.gpu
+def test_use_confidence_scales_the_costs_before_sgm(oracle):
+    """plugin_libsgm.rst:38-47: with use_confidence the SGM step optimises C(p, d) * Confidence(p).  The machine's volume after
+    the optimisation == the oracle's SGM of the scaled census costs; naming a step that computed nothing is a no-op."""
+    import json
+
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, _ = load_cones()
+    L, R = L[100:180, 50:250], R[100:180, 50:250]
+    vols = {}
+    for use in ("cost_volume_confidence.before", "cost_volume_confidence.never_computed", None):
+        left, right = make_image(L, disparity=[-40, 0]), make_image(R, disparity=[0, 40])
+        pipe = {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                "cost_volume_confidence.before": {"confidence_method": "ambiguity"},
+                "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"}}
+        if use:
+            pipe["optimization"]["use_confidence"] = use
+        machine = PandoraMachine()
+        cfg = {"pipeline": machine.check_conf({"pipeline": json.loads(json.dumps(pipe))}, left, right)["pipeline"]}
+        machine.run_prepare(cfg, left, right)
+        for step in ("matching_cost", "cost_volume_confidence.before", "optimization"):
+            machine.run(step, cfg)
+        vols[use] = machine.left_cv["cost_volume"].data
+        conf = np.asarray(machine.left_cv["confidence_measure"].data)[:, :, 0]
+    np.testing.assert_array_equal(vols["cost_volume_confidence.never_computed"], vols[None])
+    cv = oracle.census_cost(L, R, 41, -40, 1, 5)
+    w = np.where(np.isnan(conf), 1.0, conf).astype(np.float32)
+    exp = oracle.sgm(cv * w[:, :, None], 8.0, 32.0, False, 26.0, False)
+    np.testing.assert_array_equal(vols["cost_volume_confidence.before"], exp)
+    assert not np.array_equal(vols["cost_volume_confidence.before"], vols[None], equal_nan=True)
