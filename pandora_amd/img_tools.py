@@ -1,20 +1,34 @@
 """Image datasets from files (reference: img_tools.py:101-162 add_disparity / add_disparity_grid, :234-316
 add_no_data / add_mask, :345-437 create_dataset_from_inputs).  Host-side I/O: the reference reads with rasterio, which is
-not in this image; Pillow reads the single-band PNG / TIFF files the reference's own tests and samples use.  Multi-band
-images, classification / segmentation layers, ROI windows and georeferencing (crs / transform stay None) need rasterio and
-are refused loudly."""
+not in this image; Pillow reads the single-band PNG / TIFF files, tiff_reader.py the multi-sample TIFFs (multiband images,
+two-band disparity grids).  Classification / segmentation layers, ROI windows and georeferencing (crs / transform stay None)
+are outside this build and refused loudly."""
 import numpy as np
 
 from .dataset import DataArray, Dataset
 
 
-def _read_band(path):
-    from PIL import Image
+def _read_raster(path):
+    """-> (array (row, col) or (band, row, col), band descriptions or None): Pillow for the single-band PNG / TIFF files,
+    the small baseline-TIFF reader of tiff_reader.py for multi-sample rasters as GDAL writes them."""
+    from PIL import Image, UnidentifiedImageError
 
-    with Image.open(path) as im:
-        if getattr(im, "n_frames", 1) != 1 or im.mode not in ("F", "L", "I", "I;16", "I;16B", "1", "P"):
-            raise NotImplementedError(f"{path}: only single-band images are read without rasterio (mode {im.mode})")
-        return np.array(im)
+    try:
+        with Image.open(path) as im:
+            if getattr(im, "n_frames", 1) == 1 and im.mode in ("F", "L", "I", "I;16", "I;16B", "1", "P"):
+                return np.array(im), None
+    except (UnidentifiedImageError, ValueError, OSError, SyntaxError):  # a layout Pillow cannot decode: try the TIFF reader below
+        pass
+    from .tiff_reader import read_tiff
+
+    return read_tiff(path)
+
+
+def _read_band(path):
+    data, _ = _read_raster(path)
+    if data.ndim != 2:
+        raise ValueError(f"{path}: a single-band raster is expected")
+    return data
 
 
 def add_disparity_grid(dataset, disparity_grid=None, disparity_source="xr.Dataset"):
@@ -34,9 +48,11 @@ def add_disparity(dataset, disparity, window=None):
     if disparity is None:
         dataset.attrs["disparity_source"] = None
         return dataset
-    if isinstance(disparity, str):
-        raise NotImplementedError("disparity grids from a file need rasterio (two-band GeoTIFF); pass the grids with "
-                                  "add_disparity_grid / make_image(disparity_grids=...) instead")
+    if isinstance(disparity, str):  # a two-band raster: band 1 = minimum, band 2 = maximum (img_tools.py:124-125)
+        grids, _ = _read_raster(disparity)
+        if grids.ndim != 3 or grids.shape[0] != 2 or grids.shape[1:] != (dataset.sizes["row"], dataset.sizes["col"]):
+            raise ValueError(f"{disparity}: a disparity grid file holds two bands (min, max) of the image's size")
+        return add_disparity_grid(dataset, grids.astype(np.float32), disparity)
     H, W = dataset.sizes["row"], dataset.sizes["col"]
     grids = np.array([np.full((H, W), disparity[0]), np.full((H, W), disparity[1])])
     return add_disparity_grid(dataset, grids, disparity)
@@ -80,10 +96,15 @@ def create_dataset_from_inputs(input_config, roi=None):
     for layer in ("classif", "segm", "edges"):
         if params[layer] is not None:
             raise NotImplementedError(f"the '{layer}' layer is out of scope of pandora_amd")
-    data = _read_band(params["img"]).astype(np.float32)
-    ny_, nx_ = data.shape
-    dataset = Dataset({"im": (("row", "col"), data)}, coords={"row": np.arange(ny_), "col": np.arange(nx_)},
-                      attrs={"crs": None, "transform": None, "valid_pixels": 0, "no_data_mask": 1})
+    data, names = _read_raster(params["img"])
+    data = data.astype(np.float32)
+    ny_, nx_ = data.shape[-2:]
+    if data.ndim == 2:
+        dataset = Dataset({"im": (("row", "col"), data)}, coords={"row": np.arange(ny_), "col": np.arange(nx_)})
+    else:  # img_tools.py:388-398: band names come from the image metadata
+        dataset = Dataset({"im": (("band_im", "row", "col"), data)},
+                          coords={"band_im": np.asarray(names if names else [None] * data.shape[0], dtype=object), "row": np.arange(ny_), "col": np.arange(nx_)})
+    dataset.attrs.update({"crs": None, "transform": None, "valid_pixels": 0, "no_data_mask": 1})
     dataset.attrs["disparity_source"] = None
     if "disp" in params:
         add_disparity(dataset, params["disp"])

@@ -1,0 +1,69 @@
+"""Minimal baseline-TIFF reader for what Pillow refuses: multi-sample float / integer rasters as GDAL writes them (the
+reference's multiband images, two-band disparity grids, classification layers).  Classic TIFF (not BigTIFF), strips,
+uncompressed or deflate, 8/16/32/64-bit unsigned / signed / float samples, chunky or planar layout; band descriptions from
+GDAL's metadata tag.  Host-side I/O glue (the reference reads through rasterio, which is not in this image)."""
+import re
+import struct
+import zlib
+
+import numpy as np
+
+_TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 8: "h", 9: "i", 11: "f", 12: "d", 16: "Q"}
+_SIZES = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 8: 2, 9: 4, 11: 4, 12: 8, 16: 8}
+
+
+def read_tiff(path):
+    """-> (array (row, col) or (band, row, col) in the file's sample type, list of band descriptions or None)"""
+    with open(path, "rb") as f:
+        b = f.read()
+    if b[:2] not in (b"II", b"MM"):
+        raise ValueError(f"{path}: not a TIFF file")
+    bo = "<" if b[:2] == b"II" else ">"
+    if struct.unpack(bo + "H", b[2:4])[0] != 42:
+        raise NotImplementedError(f"{path}: BigTIFF is not read by pandora_amd")
+    off = struct.unpack(bo + "I", b[4:8])[0]
+    n = struct.unpack(bo + "H", b[off:off + 2])[0]
+    tags = {}
+    for i in range(n):
+        tag, typ, cnt, raw = struct.unpack(bo + "HHI4s", b[off + 2 + 12 * i:off + 14 + 12 * i])
+        size = _SIZES.get(typ, 1) * cnt
+        data = raw[:size] if size <= 4 else b[struct.unpack(bo + "I", raw)[0]:struct.unpack(bo + "I", raw)[0] + size]
+        if typ == 2:
+            tags[tag] = data.split(b"\0")[0].decode("latin-1")
+        elif typ in _TYPES and typ != 5:
+            tags[tag] = list(struct.unpack(bo + _TYPES[typ] * cnt, data))
+    if 322 in tags:
+        raise NotImplementedError(f"{path}: tiled TIFF is not read by pandora_amd")
+    W, H = tags[256][0], tags[257][0]
+    spp = tags.get(277, [1])[0]
+    bits = tags.get(258, [1])
+    fmt = tags.get(339, [1] * spp)
+    if len(set(bits)) != 1 or len(set(fmt)) != 1:
+        raise NotImplementedError(f"{path}: samples of different types")
+    kind = {1: "u", 2: "i", 3: "f"}.get(fmt[0])
+    if kind is None or bits[0] not in (8, 16, 32, 64):
+        raise NotImplementedError(f"{path}: sample format {fmt[0]} / {bits[0]} bits")
+    dtype = np.dtype(f"{bo}{kind}{bits[0] // 8}")
+    comp = tags.get(259, [1])[0]
+    if comp not in (1, 8, 32946):
+        raise NotImplementedError(f"{path}: compression {comp}")
+    if tags.get(317, [1])[0] != 1:
+        raise NotImplementedError(f"{path}: predictor")
+    planar = tags.get(284, [1])[0]
+    rps = min(tags.get(278, [H])[0], H)
+    strips = [b[o:o + c] for o, c in zip(tags[273], tags[279])]
+    if comp != 1:
+        strips = [zlib.decompress(s) for s in strips]
+    spi = (H + rps - 1) // rps  # strips per image (per plane when planar)
+    if planar == 1:
+        data = np.frombuffer(b"".join(strips), dtype, H * W * spp).reshape(H, W, spp)
+        data = np.moveaxis(data, 2, 0)
+    else:
+        data = np.stack([np.frombuffer(b"".join(strips[p * spi:(p + 1) * spi]), dtype, H * W).reshape(H, W) for p in range(spp)])
+    data = np.ascontiguousarray(data.astype(dtype.newbyteorder("=")))
+    names = None
+    if 42112 in tags:  # GDAL metadata: <Item name="DESCRIPTION" sample="k" role="description">name</Item>
+        found = dict((int(k), v) for k, v in re.findall(r'<Item name="DESCRIPTION" sample="(\d+)" role="description">([^<]*)</Item>', tags[42112]))
+        if found:
+            names = [found.get(k) for k in range(spp)]
+    return (data[0] if spp == 1 else data), names

@@ -457,3 +457,38 @@ def test_sgm_use_confidence_configuration():  # plugin_libsgm.rst:38-47, :88-209
         optimization.AbstractOptimization(None, optimization_method="sgm", use_confidence="ambiguity")
     with pytest.raises(ConfigError):
         optimization.AbstractOptimization(None, optimization_method="sgm", geometric_prior={"source": "segm"})
+
+
+def test_tiff_reader_and_multiband_inputs(tmp_path):
+    """pandora_amd/tiff_reader.py on the reference's tiny two-band grid (tests/pandora/tiny_left_disparity_grid.tif), on a
+    multi-sample TIFF with GDAL band descriptions, and - when the reference tree is here - on its multiband / grid rasters;
+    create_dataset_from_inputs with a multiband image and with a disparity-grid file (img_tools.py:388-398, :124-125)."""
+    from PIL import Image
+
+    from pandora_amd import img_tools
+    from pandora_amd.tiff_reader import read_tiff
+
+    gold = os.path.join(ROOT, "tests", "golden", "image")
+    grid, names = read_tiff(os.path.join(gold, "tiny_left_disparity_grid.tif"))
+    assert grid.shape == (2, 4, 4) and names == ["min", "max"] and (grid[0] == -27).all() and (grid[1] == -7).all()
+    one, names = read_tiff(os.path.join(gold, "left_img.tif"))
+    np.testing.assert_array_equal(one, np.array(Image.open(os.path.join(gold, "left_img.tif"))))
+    assert names is None
+    rgb = np.random.default_rng(0).integers(0, 255, (4, 4, 3)).astype(np.uint8)
+    xml = ('<GDALMetadata>\n  <Item name="DESCRIPTION" sample="0" role="description">r</Item>\n  <Item name="DESCRIPTION" sample="1" '
+           'role="description">g</Item>\n  <Item name="DESCRIPTION" sample="2" role="description">b</Item>\n</GDALMetadata>\n')
+    Image.fromarray(rgb, mode="RGB").save(tmp_path / "rgb.tif", tiffinfo={42112: xml})
+    ds = img_tools.create_dataset_from_inputs({"img": str(tmp_path / "rgb.tif"), "nodata": -9999,
+                                               "disp": os.path.join(gold, "tiny_left_disparity_grid.tif")})
+    assert ds["im"].dims == ("band_im", "row", "col") and list(ds.coords["band_im"]) == ["r", "g", "b"]
+    np.testing.assert_array_equal(ds["im"].data, np.moveaxis(rgb, 2, 0).astype(np.float32))
+    assert ds.attrs["disparity_source"].endswith("tiny_left_disparity_grid.tif") and ds["disparity"].data.dtype == np.float32
+    np.testing.assert_array_equal(ds["disparity"].data, grid)
+    ref = "/root/reference/tests/pandora"
+    if os.path.exists(ref):  # build container only
+        a, names = read_tiff(os.path.join(ref, "left_rgb.tif"))
+        assert a.shape == (3, 375, 450) and names == ["red", "green", "blue"] and a.dtype == np.float32
+        d, names = read_tiff(os.path.join(ref, "left_disparity_grid.tif"))
+        assert d.shape == (2, 375, 450) and names == ["min", "max"] and d.min() == -65 and d.max() == 10
+        for f in ("disp_left.tif", "disp_min_grid.tif", "mask_from_occlusion_left.tif"):
+            np.testing.assert_array_equal(read_tiff(os.path.join(ref, f))[0], np.array(Image.open(os.path.join(ref, f))))

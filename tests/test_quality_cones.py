@@ -405,3 +405,37 @@ def test_use_confidence_scales_the_costs_before_sgm(oracle):
     exp = oracle.sgm(cv * w[:, :, None], 8.0, 32.0, False, 26.0, False)
     np.testing.assert_array_equal(vols["cost_volume_confidence.before"], exp)
     assert not np.array_equal(vols["cost_volume_confidence.before"], vols[None], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_main_on_multiband_files(tmp_path):
+    """data_samples/json_conf_files/a_local_block_matching_for_multiband_img.json: three-band TIFFs with GDAL band descriptions
+    (written here with Pillow from the cones pair, the green band holding it), matching_cost band "g"; the maps written by
+    `python -m pandora_amd` equal those of the mono-band sample configuration on the same pair."""
+    import json
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    L, R, _ = load_cones()
+    xml = "<GDALMetadata>\n" + "".join(f'  <Item name="DESCRIPTION" sample="{k}" role="description">{n}</Item>\n'
+                                        for k, n in enumerate("rgb")) + "</GDALMetadata>\n"
+    for name, img in (("left_rgb.tif", L), ("right_rgb.tif", R)):
+        rgb = np.stack([img[::-1], img, img[:, ::-1]], axis=2).astype(np.uint8)
+        Image.fromarray(rgb, mode="RGB").save(tmp_path / name, tiffinfo={42112: xml})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, inputs, band in (("multi", ("left_rgb.tif", "right_rgb.tif"), "g"), ("mono", (os.path.join(CONES, "left.png"), os.path.join(CONES, "right.png")), None)):
+        pipe = json.loads(json.dumps(SAMPLE_LOCAL["pipeline"]))
+        if band:
+            pipe["matching_cost"]["band"] = band
+        cfg = {"input": {"left": {"img": str(tmp_path / inputs[0]) if band else inputs[0], "disp": [-60, 0]},
+                         "right": {"img": str(tmp_path / inputs[1]) if band else inputs[1]}}, "pipeline": pipe}
+        (tmp_path / f"{tag}.json").write_text(json.dumps(cfg))
+        run = subprocess.run([sys.executable, "-m", "pandora_amd", str(tmp_path / f"{tag}.json"), str(tmp_path / tag)], cwd=root,
+                             capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-3000:]
+        outs[tag] = {f: np.array(Image.open(tmp_path / tag / f)) for f in ("left_disparity.tif", "left_validity_mask.tif", "right_disparity.tif")}
+    for f in outs["mono"]:
+        np.testing.assert_array_equal(outs["multi"][f], outs["mono"][f])
