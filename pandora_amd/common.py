@@ -1,7 +1,7 @@
 """Results on disk (reference: common.py:37-181 write_data_array / save_results / save_config,
 output_tree_design.py).  Same file names and pixel types as the reference (float32 disparity and confidence, uint16
-validity mask); written with Pillow as plain TIFF: georeferencing (crs / transform) and band descriptions need rasterio and
-are not written.  A (row, col, indicator) array becomes a multi-page TIFF, one page per indicator."""
+validity mask); written as plain uncompressed TIFF (tiff_reader.write_tiff): georeferencing (crs / transform) needs rasterio and
+are not written; band names are (as GDAL band descriptions)."""
 import json
 import os
 
@@ -20,22 +20,17 @@ def mkdir_p(path):
 
 
 def write_data_array(data_array, filename, dtype=np.float32, band_names=None, crs=None, transform=None):
-    """common.py:37-96"""
-    from PIL import Image
+    """common.py:37-96: a (row, col) array is one band, a (row, col, indicator) array one band per indicator, with the band
+    names as band descriptions (GDAL's metadata tag, which rasterio's ``descriptions`` reads back)."""
+    from .tiff_reader import write_tiff
 
     data = np.asarray(data_array.data if hasattr(data_array, "data") and not isinstance(data_array, np.ndarray) else data_array)
     mkdir_p(os.path.dirname(os.path.abspath(filename)))
-
-    def page(a):
-        if np.dtype(dtype) == np.uint16:
-            return Image.fromarray(np.ascontiguousarray(a).astype(np.uint16))
-        return Image.fromarray(np.ascontiguousarray(a).astype(np.float32), mode="F")
-
+    out_t = np.uint16 if np.dtype(dtype) == np.uint16 else np.float32
     if data.ndim == 2:
-        page(data).save(filename, format="TIFF")
+        write_tiff(filename, data.astype(out_t))
     else:
-        pages = [page(data[:, :, k]) for k in range(data.shape[2])]
-        pages[0].save(filename, format="TIFF", save_all=True, append_images=pages[1:])
+        write_tiff(filename, np.moveaxis(data, 2, 0).astype(out_t), None if band_names is None else [str(b) for b in band_names])
 
 
 def save_results(left, right, output):

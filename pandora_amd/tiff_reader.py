@@ -67,3 +67,61 @@ def read_tiff(path):
         if found:
             names = [found.get(k) for k in range(spp)]
     return (data[0] if spp == 1 else data), names
+
+
+def write_tiff(path, data, band_names=None):
+    """Classic little-endian TIFF, uncompressed, one strip per band (planar layout when there are several bands), sample type of
+    ``data`` (uint8/16/32, int8/16/32, float32/64); band descriptions go into GDAL's metadata tag so that GDAL / rasterio (and
+    read_tiff) give them back.  data: (row, col) or (band, row, col)."""
+    a = np.asarray(data)
+    if a.ndim == 2:
+        a = a[None]
+    if a.ndim != 3:
+        raise ValueError("write_tiff: (row, col) or (band, row, col)")
+    kind = {"u": 1, "i": 2, "f": 3}.get(a.dtype.kind)
+    if kind is None or a.dtype.itemsize not in (1, 2, 4, 8):
+        raise ValueError(f"write_tiff: unsupported sample type {a.dtype}")
+    a = np.ascontiguousarray(a.astype(a.dtype.newbyteorder("<")))
+    B, H, W = a.shape
+    meta = None
+    if band_names is not None:
+        meta = ("<GDALMetadata>\n" + "".join(f'  <Item name="DESCRIPTION" sample="{k}" role="description">{n}</Item>\n'
+                                             for k, n in enumerate(band_names)) + "</GDALMetadata>\n").encode("latin-1") + b"\0"
+    plane = H * W * a.dtype.itemsize
+    entries = []  # (tag, type, count, values or bytes)
+    entries += [(256, 4, 1, [W]), (257, 4, 1, [H]), (258, 3, B, [8 * a.dtype.itemsize] * B), (259, 3, 1, [1]),
+                (262, 3, 1, [1]), (273, 4, B, None), (277, 3, 1, [B]), (278, 4, 1, [H]), (279, 4, B, [plane] * B),
+                (284, 3, 1, [2 if B > 1 else 1]), (339, 3, B, [kind] * B)]
+    if B > 1:
+        entries.append((338, 3, B - 1, [0] * (B - 1)))
+    if meta:
+        entries.append((42112, 2, len(meta), meta))
+    entries.sort(key=lambda e: e[0])
+    ifd_off = 8
+    ifd_size = 2 + 12 * len(entries) + 4
+    extra_off = ifd_off + ifd_size
+    extras, fields = b"", []
+    for tag, typ, cnt, vals in entries:
+        fields.append([tag, typ, cnt, vals])
+    # first pass: sizes of out-of-line values, then the pixel data offset
+    sizes = []
+    for tag, typ, cnt, vals in fields:
+        sizes.append(0 if _SIZES[typ] * cnt <= 4 else (_SIZES[typ] * cnt + 1) & ~1)
+    data_off = (extra_off + sum(sizes) + 15) & ~15
+    out = bytearray(b"II" + struct.pack("<HI", 42, ifd_off) + struct.pack("<H", len(fields)))
+    cursor = extra_off
+    for (tag, typ, cnt, vals), size in zip(fields, sizes):
+        if tag == 273:
+            vals = [data_off + k * plane for k in range(B)]
+        raw = vals if isinstance(vals, (bytes, bytearray)) else struct.pack("<" + _TYPES[typ] * cnt, *vals)
+        if size == 0:
+            out += struct.pack("<HHI", tag, typ, cnt) + raw.ljust(4, b"\0")
+        else:
+            out += struct.pack("<HHII", tag, typ, cnt, cursor)
+            extras += raw.ljust(size, b"\0")
+            cursor += size
+    out += struct.pack("<I", 0) + extras
+    out += b"\0" * (data_off - len(out))
+    with open(path, "wb") as f:
+        f.write(out)
+        f.write(a.tobytes())

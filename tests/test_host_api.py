@@ -401,10 +401,11 @@ def test_save_results_writes_the_reference_tree(tmp_path):
     vm = np.array(Image.open(tmp_path / "left_validity_mask.tif"))
     assert vm.dtype == np.uint16
     np.testing.assert_array_equal(vm, left["validity_mask"].data)
-    with Image.open(tmp_path / "left_confidence_measure.tif") as im:
-        assert im.n_frames == 2
-        im.seek(1)
-        np.testing.assert_array_equal(np.array(im), conf[:, :, 1])
+    from pandora_amd.tiff_reader import read_tiff
+
+    bands, names = read_tiff(str(tmp_path / "left_confidence_measure.tif"))
+    assert bands.shape == (2, 6, 7) and names == ["a", "b"] and bands.dtype == np.float32
+    np.testing.assert_array_equal(bands, np.moveaxis(conf, 2, 0))
     assert json.load(open(tmp_path / "cfg" / "config.json"))["pipeline"]["x"]["y"] == 3
 
 
@@ -492,3 +493,21 @@ def test_tiff_reader_and_multiband_inputs(tmp_path):
         assert d.shape == (2, 375, 450) and names == ["min", "max"] and d.min() == -65 and d.max() == 10
         for f in ("disp_left.tif", "disp_min_grid.tif", "mask_from_occlusion_left.tif"):
             np.testing.assert_array_equal(read_tiff(os.path.join(ref, f))[0], np.array(Image.open(os.path.join(ref, f))))
+
+
+def test_tiff_writer_roundtrip(tmp_path):
+    from PIL import Image
+
+    from pandora_amd.tiff_reader import read_tiff, write_tiff
+
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.uint16, np.uint8, np.int16, np.float64):
+        a = (rng.random((3, 5, 7)) * 200).astype(dt)
+        write_tiff(str(tmp_path / "m.tif"), a, ["x", "y y", "z"])
+        b, names = read_tiff(str(tmp_path / "m.tif"))
+        assert np.array_equal(a, b) and names == ["x", "y y", "z"] and b.dtype == dt
+        write_tiff(str(tmp_path / "s.tif"), a[0])
+        b, names = read_tiff(str(tmp_path / "s.tif"))
+        assert np.array_equal(a[0], b) and names is None
+        if dt in (np.float32, np.uint16, np.uint8):  # what Pillow decodes: an independent reader agrees
+            np.testing.assert_array_equal(np.array(Image.open(tmp_path / "s.tif")), a[0])

@@ -439,3 +439,38 @@ def test_main_on_multiband_files(tmp_path):
         outs[tag] = {f: np.array(Image.open(tmp_path / tag / f)) for f in ("left_disparity.tif", "left_validity_mask.tif", "right_disparity.tif")}
     for f in outs["mono"]:
         np.testing.assert_array_equal(outs["multi"][f], outs["mono"][f])
+
+
+@pytest.mark.gpu
+def test_main_with_a_disparity_grid_file(tmp_path):
+    """input.left.disp as a path to a two-band (min, max) raster (img_tools.py:124-125; the reference's
+    tests/pandora/left_disparity_grid.tif case): per-pixel ranges around the ground truth, written here with write_tiff.  The
+    run keeps the integer fast path (census + SGM with per-pixel valid intervals), every finite disparity lies inside its
+    pixel's range, and the 20 % gate holds."""
+    import json
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    from pandora_amd.tiff_reader import write_tiff
+
+    L, R, gt = load_cones()
+    centre = np.where(gt != 0, -gt, -30.0)
+    lo, hi = np.floor(np.clip(centre - 6, -60, 0)), np.ceil(np.clip(centre + 6, -60, 0))
+    write_tiff(str(tmp_path / "grid.tif"), np.stack([lo, hi]).astype(np.float32), ["min", "max"])
+    cfg = {"input": {"left": {"img": os.path.join(CONES, "left.png"), "disp": str(tmp_path / "grid.tif")},
+                     "right": {"img": os.path.join(CONES, "right.png")}},
+           "pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                        "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                        "refinement": {"refinement_method": "vfit"}}}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-m", "pandora_amd", str(tmp_path / "cfg.json"), str(tmp_path / "out")], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    d = np.array(Image.open(tmp_path / "out" / "left_disparity.tif"))
+    ok = np.isfinite(d)
+    assert ok.mean() > 0.9 and np.all(d[ok] >= lo[ok] - 1e-6) and np.all(d[ok] <= hi[ok] + 1e-6)
+    assert error(np.nan_to_num(d, nan=1e4), gt, 1) <= 0.20
