@@ -87,5 +87,6 @@ def main(cfg_path, output, verbose=False):
     cfg["pipeline"] = machine.check_conf(cfg, img_left, img_right)["pipeline"]
     left, right = run(machine, img_left, img_right, cfg)
     common.save_results(left, right, output)
+    cfg["margins"] = machine.margins.to_dict()  # __init__.py:197-198
     common.save_config(output, cfg)
     return left, right

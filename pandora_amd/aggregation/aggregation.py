@@ -6,6 +6,13 @@ class AbstractAggregation:
     __metaclass__ = ABCMeta
 
     aggreg_methods_avail = {}
+
+    @property
+    def margins(self):
+        """NullMargins (aggregation.py:43)"""
+        from ..margins import uniform
+
+        return uniform(0)
     cfg = None
 
     def __new__(cls, **cfg):

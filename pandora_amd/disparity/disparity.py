@@ -11,6 +11,14 @@ class AbstractDisparity:
     __metaclass__ = ABCMeta
 
     disparity_methods_avail = {}
+
+    @property
+    def margins(self):
+        """NullMargins (the reference's default for this step)"""
+        from ..margins import uniform
+
+        return uniform(0)
+
     cfg = None
 
     def __new__(cls, **cfg):

@@ -107,10 +107,10 @@ def tile_dataset(ds, rlo, rhi):
     return out
 
 
-def run_row_tiled(img_left, img_right, cfg, margin=40, group=None):
+def run_row_tiled(img_left, img_right, cfg, margin=None, group=None):
     """One stereo pair over all ranks, the reference's way (ROI tiles with a margin, marge.py:86-101; 40 px is what the SGM
     plugin asks for, optimization/optimization.py:43): every rank runs the whole pipeline of ``cfg`` on its rows plus the
-    margin on its own GPU, keeps the rows it owns, and the owned rows of all ranks are gathered on every rank (the only
+    margin (default: the global margins of the configured steps) on its own GPU, keeps the rows it owns, and the owned rows of all ranks are gathered on every rank (the only
     exchange: the 2-D results).  Local pipelines are exact with a margin of at least the window radius; SGM paths are cut at
     the tile margin, as in the reference.  Returns (left, right) dicts of full-size arrays: disparity_map, validity_mask and,
     when present, interpolated_coeff.  Works without torch.distributed (one tile)."""
@@ -127,6 +127,11 @@ def run_row_tiled(img_left, img_right, cfg, margin=40, group=None):
     except ImportError:
         pass
     H = img_left.sizes["row"]
+    if margin is None:  # what the configured steps ask for (PandoraMachine.margins, reference: margins/margins.py:71-143)
+        probe = PandoraMachine()
+        probe.check_conf({"pipeline": cfg["pipeline"]}, img_left, img_right)
+        g = probe.margins.global_margins
+        margin = max(g.up, g.down)
     (lo, hi), (rlo, rhi) = row_tile(H, world, rank, margin)
     tile_l, tile_r = tile_dataset(img_left, rlo, rhi), tile_dataset(img_right, rlo, rhi)
     machine = PandoraMachine()

@@ -18,6 +18,13 @@ class BilateralFilter(_filter.AbstractFilter):
         self._image_shape = [] if image_shape is None else image_shape
         self._step = step
 
+    @property
+    def margins(self):
+        """bilateral.py:63-67"""
+        from ..margins import uniform
+
+        return uniform(min([*self._image_shape, int(3 * self._sigma_space + 1)]) * self._step)
+
     def check_conf(self, cfg):
         """bilateral.py:74-96"""
         cfg.setdefault("sigma_color", self._SIGMA_COLOR)

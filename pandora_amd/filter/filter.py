@@ -7,6 +7,14 @@ class AbstractFilter:
     __metaclass__ = ABCMeta
 
     filter_methods_avail = {}
+
+    @property
+    def margins(self):
+        """NullMargins (the reference's default for this step)"""
+        from ..margins import uniform
+
+        return uniform(0)
+
     cfg = None
 
     def __new__(cls, *args, cfg=None, step=1, **kwargs):

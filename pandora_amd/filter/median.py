@@ -15,6 +15,13 @@ class MedianFilter(_filter.AbstractFilter):
         self._filter_size = int(self.cfg["filter_size"])
         self._step = step
 
+    @property
+    def margins(self):
+        """median.py:61-64"""
+        from ..margins import uniform
+
+        return uniform(self._filter_size * self._step)
+
     def check_conf(self, cfg):
         """median.py:68-90"""
         if "filter_size" not in cfg:

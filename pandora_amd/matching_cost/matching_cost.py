@@ -98,10 +98,15 @@ class AbstractMatchingCost:
             raise AttributeError("Band must be instantiated in matching cost step")
 
     @property
+    def margins(self):
+        """HalfWindowMargins (matching_cost.py:76, margins/descriptors.py:88-114)"""
+        from ..margins import uniform
+
+        return uniform(int((self._window_size - 1) / 2))
+
+    @property
     def margins_value(self):
-        """HalfWindowMargins (matching_cost.py:76): (left, up, right, down)"""
-        o = int((self._window_size - 1) / 2)
-        return (o, o, o, o)
+        return self.margins.astuple()
 
     # -- geometry (matching_cost.py:330-427, 604-616) ------------------------------------------
     @staticmethod

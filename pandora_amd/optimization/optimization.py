@@ -9,7 +9,13 @@ class AbstractOptimization:
 
     optimization_methods_avail = {}
     cfg = None
-    margins_value = (40, 40, 40, 40)  # UniformMargins(40)
+    margins_value = (40, 40, 40, 40)  # UniformMargins(40), optimization.py:43
+
+    @property
+    def margins(self):
+        from ..margins import uniform
+
+        return uniform(40)
 
     def __new__(cls, _img=None, **cfg):
         if cls is AbstractOptimization:

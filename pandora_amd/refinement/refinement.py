@@ -12,6 +12,14 @@ class AbstractRefinement:
     __metaclass__ = ABCMeta
 
     subpixel_methods_avail = {}
+
+    @property
+    def margins(self):
+        """NullMargins (the reference's default for this step)"""
+        from ..margins import uniform
+
+        return uniform(0)
+
     cfg = None
     _refinement_method_name = None
 

@@ -18,6 +18,7 @@ import numpy as np
 from . import (aggregation, cost_volume_confidence, disparity, filter, matching_cost, multiscale, optimization, refinement,
                validation)
 from .criteria import validity_mask
+from .margins import GlobalMargins
 from .dataset import DataArray, Dataset
 
 
@@ -63,6 +64,7 @@ class PandoraMachine:
         self.num_scales = 1
         self.current_scale = 0
         self.left_cv = None
+        self.margins = GlobalMargins()
         self.right_cv = None
         self.left_disparity = None
         self.right_disparity = None
@@ -295,6 +297,7 @@ class PandoraMachine:
         m = matching_cost.AbstractMatchingCost(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = m.cfg
         self.step = m._step_col
+        self.margins.add_cumulative(input_step, m.margins)
         for img in (self.left_img, self.right_img):  # state_machine.py:748-759
             if img is not None:
                 bands = list(img.coords["band_im"]) if "band_im" in img.coords else [None]
@@ -319,12 +322,14 @@ class PandoraMachine:
     def aggregation_check_conf(self, cfg, input_step):
         a = aggregation.AbstractAggregation(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = a.cfg
+        self.margins.add_cumulative(input_step, a.margins)
 
     def optimization_check_conf(self, cfg, input_step):
         if self.step != 1:  # state_machine.py:868-870
             raise AttributeError("For performing the SGM optimization step, step attribute must be equal to 1")
         o = optimization.AbstractOptimization(self.left_img, **cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = o.cfg
+        self.margins.add_cumulative(input_step, o.margins)
 
     def cost_volume_confidence_check_conf(self, cfg, input_step):
         """state_machine.py:937-948"""
@@ -334,15 +339,18 @@ class PandoraMachine:
     def disparity_check_conf(self, cfg, input_step):
         d = disparity.AbstractDisparity(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = d.cfg
+        self.margins.add_cumulative(input_step, d.margins)
 
     def filter_check_conf(self, cfg, input_step):
         """state_machine.py:775-792"""
         f = filter.AbstractFilter(cfg=dict(cfg[input_step]), image_shape=self._image_shape(), step=self.step)
         self.pipeline_cfg["pipeline"][input_step] = f.cfg
+        self.margins.add_non_cumulative(input_step, f.margins)
 
     def refinement_check_conf(self, cfg, input_step):
         r = refinement.AbstractRefinement(**cfg[input_step])
         self.pipeline_cfg["pipeline"][input_step] = r.cfg
+        self.margins.add_cumulative(input_step, r.margins)
 
     def validation_check_conf(self, cfg, input_step):
         """state_machine.py:894-922"""
@@ -367,6 +375,7 @@ class PandoraMachine:
         self.state = "begin"
         self._mode = "check"
         self.pipeline_cfg = {"pipeline": {}}
+        self.margins = GlobalMargins()  # state_machine.py:260: rebuilt by every check
         for input_step in list(cfg["pipeline"]):
             trig = "check_" + input_step.split(".")[0]
             try:

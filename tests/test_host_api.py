@@ -511,3 +511,35 @@ def test_tiff_writer_roundtrip(tmp_path):
         assert np.array_equal(a[0], b) and names is None
         if dt in (np.float32, np.uint16, np.uint8):  # what Pillow decodes: an independent reader agrees
             np.testing.assert_array_equal(np.array(Image.open(tmp_path / "s.tif")), a[0])
+
+
+def test_margins_like_the_reference():
+    """margins/margins.py, descriptors.py; tests/test_pandora.py:150-210 (the margins written next to the configuration):
+    matching_cost HalfWindowMargins, optimization UniformMargins(40), filters non-cumulative, the rest null."""
+    from pandora_amd.margins import GlobalMargins, Margins, max_margins
+
+    assert Margins(1, 2, 3, 4) + Margins(1, 1, 1, 1) == Margins(2, 3, 4, 5)
+    assert max_margins([Margins(1, 5, 2, 0), Margins(3, 1, 2, 7)]) == Margins(3, 5, 2, 7)
+    with pytest.raises(ValueError):
+        Margins(-1, 0, 0, 0)
+    g = GlobalMargins()
+    g.add_cumulative("a", Margins(1, 1, 1, 1))
+    with pytest.raises(KeyError):
+        g.add_non_cumulative("a", Margins(0, 0, 0, 0))
+    left, right = make_image(np.zeros((30, 40)), disparity=[-3, 0]), make_image(np.zeros((30, 40)), disparity=[0, 3])
+    m = PandoraMachine()
+    m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 2},
+                               "disparity": {"disparity_method": "wta", "invalid_disparity": -9999},
+                               "refinement": {"refinement_method": "vfit"},
+                               "filter": {"filter_method": "median", "filter_size": 3}}}, left, right)
+    assert m.margins.to_dict() == {  # tests/test_pandora.py:198-209
+        "cumulative margins": {"matching_cost": {"left": 2, "up": 2, "right": 2, "down": 2},
+                               "disparity": {"left": 0, "up": 0, "right": 0, "down": 0},
+                               "refinement": {"left": 0, "up": 0, "right": 0, "down": 0}},
+        "non-cumulative margins": {"filter": {"left": 3, "up": 3, "right": 3, "down": 3}},
+        "global margins": {"left": 3, "up": 3, "right": 3, "down": 3}}
+    m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                               "optimization": {"optimization_method": "sgm"},
+                               "disparity": {"disparity_method": "wta"},
+                               "filter": {"filter_method": "bilateral", "sigma_space": 6.0}}}, left, right)
+    assert m.margins.global_margins == Margins(42, 42, 42, 42) and m.margins.get("filter") == Margins(19, 19, 19, 19)

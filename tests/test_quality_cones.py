@@ -338,6 +338,7 @@ def test_main_runs_the_sample_configuration_from_files(tmp_path):
     saved = json.load(open(out / "cfg" / "config.json"))
     assert saved["pipeline"]["validation"]["cross_checking_threshold"] == 1.0 and saved["input"]["right"]["disp"] == [0, 60]
     assert saved["pipeline"]["matching_cost"]["subpix"] == 4 and saved["input"]["left"]["nodata"] == -9999
+    assert saved["margins"]["global margins"] == {"left": 2, "up": 2, "right": 2, "down": 2}  # __init__.py:197-198
 
 
 @pytest.mark.gpu
