@@ -43,6 +43,19 @@ class AbstractDisparity:
     def desc(self):
         """Describes the disparity method"""
 
+    @staticmethod
+    def coefficient_map(cv):
+        """disparity.py:143-164: the cost of the winner of every pixel, cv["cost_volume"].sel(disp=cv["disp_indices"])."""
+        vol = np.asarray(cv["cost_volume"].data)
+        disp = np.asarray(cv.coords["disp"])
+        idx = np.searchsorted(disp, np.asarray(cv["disp_indices"].data))
+        idx = np.clip(idx, 0, len(disp) - 1)
+        out = np.take_along_axis(vol, idx[:, :, None], axis=2)[:, :, 0].astype(np.float32)
+        da = DataArray(out, ("row", "col"), {"row": cv.coords["row"], "col": cv.coords["col"]})
+        da.name = "Coefficient Map"
+        da.attrs = cv.attrs
+        return da
+
     @abstractmethod
     def to_disp(self, cv, img_left=None, img_right=None):
         """Disparity computation and validity mask; returns the disparity dataset."""
@@ -87,6 +100,27 @@ class WinnerTakesAll(AbstractDisparity):
 
     def desc(self):
         print("Winner takes all method")
+
+    @staticmethod
+    def _extremum_split(cost_volume, is_max):
+        arr = cost_volume["cost_volume"]
+        if not hasattr(arr, "device_cv"):
+            raise TypeError("a device-resident cost volume is needed (pandora_amd has no CPU path)")
+        dcv = arr.device_cv
+        dcv.engine.set_validity(None)
+        dcv.engine.wta(dcv, is_max, float("nan"))
+        return dcv.engine.get_disparity()[0]
+
+    @staticmethod
+    def argmin_split(cost_volume):
+        """disparity.py:482-516: disparity of the first minimum over D for every pixel (NaN costs never win; the reference
+        expects them replaced by +inf beforehand, which is how the device kernel treats them anyway)."""
+        return WinnerTakesAll._extremum_split(cost_volume, False)
+
+    @staticmethod
+    def argmax_split(cost_volume):
+        """disparity.py:518-553"""
+        return WinnerTakesAll._extremum_split(cost_volume, True)
 
     def to_disp(self, cv, img_left=None, img_right=None):
         """disparity.py:399-480: first arg-extremum over D with NaN -> +/-inf; pixels NaN for every d

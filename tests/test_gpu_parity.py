@@ -486,6 +486,30 @@ def test_wide_census_windows_stay_on_the_integer_path(eng, oracle, win):
     np.testing.assert_array_equal(cv.to_host(), ocv)
 
 
+def test_argmin_argmax_split_and_coefficient_map(eng):
+    """tests/test_disparity.py:372-473 through the plugin's static methods (argmin_split / argmax_split on sub-pixel volumes,
+    coefficient_map = the winner's cost)."""
+    from pandora_amd import disparity, matching_cost
+    from pandora_amd.dataset import make_image
+
+    L, R = np.array(ka.WTA["left"], np.float32), np.array(ka.WTA["right"], np.float32)
+    for case in ka.WTA_MORE[3:]:
+        left, right = make_image(L, disparity=[case["dmin"], case["dmax"]]), make_image(R)
+        m = matching_cost.AbstractMatchingCost(matching_cost_method=case["method"], window_size=case["win"], subpix=case["subpix"])
+        grids = (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max"))
+        cv = m.compute_cost_volume(left, right, m.allocate_cost_volume(left, grids))
+        fn = disparity.WinnerTakesAll.argmax_split if case["is_max"] else disparity.WinnerTakesAll.argmin_split
+        np.testing.assert_array_equal(fn(cv), np.array(case["disp"], np.float32))
+    left, right = make_image(L, disparity=[-3, 1]), make_image(R)
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="sad", window_size=1, subpix=1)
+    grids = (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max"))
+    cv = m.compute_cost_volume(left, right, m.allocate_cost_volume(left, grids))
+    m.cv_masked(left, right, cv, *grids)
+    d = disparity.AbstractDisparity(disparity_method="wta", invalid_disparity=0)
+    d.to_disp(cv)
+    np.testing.assert_array_equal(d.coefficient_map(cv).data, np.zeros((3, 4)))  # test_disparity.py:432-473
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
