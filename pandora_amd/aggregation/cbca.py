@@ -35,3 +35,12 @@ class CrossBasedCostAggregation(AbstractAggregation):
         eng.cbca(dcv, int(cv.attrs["offset_row_col"]), float(self._cbca_intensity), int(self._cbca_distance))
         cv.attrs["aggregation"] = "cbca"
         cv.attrs["cmax"] = cv.attrs["cmax"] * ((self._cbca_distance * 2) - 1) ** 2  # cbca.py:181-182
+
+    def computes_cross_supports(self, img_left, img_right, cv):
+        """cbca.py:184-295: the cross support regions (left, right, top, bottom arms, int16) of the left image and of every
+        sub-pixel phase of the right image, on the images cropped by the matching-cost offset -> (cross_left, [cross_right...])"""
+        subpix = cv.attrs["subpixel"]
+        eng = runtime.ensure_pair(img_left, img_right, subpix, band=cv.attrs.get("band_correl"))
+        off = int(cv.attrs["offset_row_col"])
+        args = (off, float(self._cbca_intensity), int(self._cbca_distance))
+        return eng.cross_support(0, *args), [eng.cross_support(1 + k, *args) for k in range(subpix)]

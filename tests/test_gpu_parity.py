@@ -510,6 +510,25 @@ def test_argmin_argmax_split_and_coefficient_map(eng):
     np.testing.assert_array_equal(d.coefficient_map(cv).data, np.zeros((3, 4)))  # test_disparity.py:432-473
 
 
+@pytest.mark.parametrize("case", ka.CROSS_SUPPORTS, ids=lambda c: c["cite"])
+def test_computes_cross_supports_plugin_method(eng, case):
+    """CrossBasedCostAggregation.computes_cross_supports (cbca.py:184-295) called as the reference's tests call it."""
+    from pandora_amd import aggregation, matching_cost
+    from pandora_amd.dataset import make_image
+
+    mk = lambda im, msk: make_image(np.array(im, np.float32), disparity=[-1, 1], msk=None if msk is None else np.array(msk, np.int16))
+    left, right = mk(case["left"], case["msk_left"]), mk(case["right"], case["msk_right"])
+    m = matching_cost.AbstractMatchingCost(matching_cost_method="sad", window_size=case["win"], subpix=case["subpix"])
+    grids = (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max"))
+    cv = m.compute_cost_volume(left, right, m.allocate_cost_volume(left, grids))
+    cbca = aggregation.AbstractAggregation(aggregation_method="cbca", cbca_intensity=case["intensity"], cbca_distance=case["distance"])
+    cross_left, cross_right = cbca.computes_cross_supports(left, right, cv)
+    assert len(cross_right) == case["subpix"]
+    if case["arms_left"] is not None:
+        np.testing.assert_array_equal(cross_left, np.array(case["arms_left"]))
+    np.testing.assert_array_equal(cross_right[case["right_index"]], np.array(case["arms_right"]))
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
