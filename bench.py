@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--dmin", type=int, default=0)
     ap.add_argument("--dmax", type=int, default=128)
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline strip (0 = skip)")
+    ap.add_argument("--placement-trials", type=int, default=4,
+                    help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials; 1 = plain hipMalloc)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the informational 4096x4096x257 leg")
     args = ap.parse_args()
 
@@ -116,6 +118,8 @@ def main():
     # one independent pair per rank (different seed per rank; same shape -> weak scaling)
     L, R = synthetic_pair(H, W, dmin, dmax, seed=20260928 + rank)
     eng = Engine(local_rank)
+    if args.placement_trials > 1:
+        eng.set_placement_trials(args.placement_trials)  # well-placed volumes, chosen once before the warm-up
     eng.set_images(L, R, 1)
     cv = eng.alloc_cv(D, dmin)
 

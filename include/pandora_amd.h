@@ -58,6 +58,11 @@ int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_t* msk_righ
  * matching_cost/matching_cost.py:845-860. */
 int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, const double* disp_max);
 
+/* Opt-in placement-aware allocation (no reference counterpart: the reference works in host memory).  For every NEW buffer of 256 MB
+ * or more the context allocates up to `trials` candidates, times one streaming read of each and keeps the fastest: on MI355X the
+ * bandwidth of a hipMalloc'd buffer depends on where the driver placed it.  One-time cost of a few hundred ms per
+ * buffer size; cached buffers are reused as they are.  trials = 1 (default) switches it off. */
+int pmx_set_placement_trials(pmx_ctx* ctx, int trials);
 /* Lazy evaluation (default ON).  A cost volume handle may hold the volume in a cheaper exact form
  * than float32 [H][W][D] - "all NaN", "census codes, costs not yet written", "eight uint8 SGM path
  * volumes" - and only materialises float32 when a step or the caller needs it.  With census costs

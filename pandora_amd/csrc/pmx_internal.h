@@ -73,6 +73,8 @@ struct pmx_ctx {
     size_t small_bytes = 0;
     bool profiling = false;
     bool lazy = true;
+    void* probe_sink = nullptr;   // 64 bytes the placement probe may write to
+    int placement_trials = 1;  // pmx_set_placement_trials: candidates probed for every new volume-sized buffer
     pmx_stage_rec stages[PMX_STAGE_COUNT];
     // caching allocator for the big per-volume buffers (a hipMalloc / hipFree of a few GB costs ~100 ms each on this
     // stack; a stream of pairs allocates and frees the same sizes over and over).  Single stream per context, so a

@@ -98,6 +98,10 @@ class Engine:
         b = None if dmax is None else np.ascontiguousarray(dmax, np.float64)
         check(_lib.lib().pmx_set_disparity_grids(self.ctx, _p(a, C.c_double), _p(b, C.c_double)), "pmx_set_disparity_grids")
 
+    def set_placement_trials(self, trials):
+        """Probe up to `trials` candidates for every new volume-sized buffer and keep the fastest (pmx_set_placement_trials)."""
+        check(_lib.lib().pmx_set_placement_trials(self.ctx, int(trials)), "pmx_set_placement_trials")
+
     def set_lazy(self, on):
         """Lazy exact representations of the volume (default on); off = always float32 (reference-like)."""
         check(_lib.lib().pmx_set_lazy(self.ctx, int(bool(on))), "pmx_set_lazy")

@@ -529,6 +529,37 @@ def test_computes_cross_supports_plugin_method(eng, case):
     np.testing.assert_array_equal(cross_right[case["right_index"]], np.array(case["arms_right"]))
 
 
+def test_placement_trials_change_nothing_but_the_buffers():
+    """pmx_set_placement_trials: volumes chosen among probed candidates (>= 256 MB) - same results, argument checked."""
+    from pandora_amd.engine import Engine, PmxError
+
+    e = Engine(0)
+    with pytest.raises(PmxError):
+        e.set_placement_trials(0)
+    e.set_placement_trials(3)
+    H, W, dmin, dmax = 512, 1024, -300, 0          # 8 byte path volumes of 159 MB each: one 1.27 GB buffer goes through the probe
+    L, R = pair(H, W, seed=5)
+    e.set_images(L, R, 1)
+    cv = e.alloc_cv(dmax - dmin + 1, dmin)
+    e.census(cv, 5)
+    e.sgm(cv, 8, 32, False, 26.0, False)
+    e.set_validity(None)
+    e.wta(cv, False, -9999.0)
+    disp, val = e.get_disparity()
+    e2 = Engine(0)  # the same pipeline on plain hipMalloc buffers
+    e2.set_images(L, R, 1)
+    cv2 = e2.alloc_cv(dmax - dmin + 1, dmin)
+    e2.census(cv2, 5)
+    e2.sgm(cv2, 8, 32, False, 26.0, False)
+    e2.set_validity(None)
+    e2.wta(cv2, False, -9999.0)
+    disp2, val2 = e2.get_disparity()
+    np.testing.assert_array_equal(disp, disp2)
+    np.testing.assert_array_equal(val, val2)
+    e.close()
+    e2.close()
+
+
 def test_reverse_cost_volume(eng, oracle):
     rng = np.random.default_rng(2)
     H, W, D = 9, 21, 7
