@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--dmin", type=int, default=0)
     ap.add_argument("--dmax", type=int, default=128)
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline strip (0 = skip)")
-    ap.add_argument("--placement-trials", type=int, default=4,
+    ap.add_argument("--placement-trials", type=int, default=6,
                     help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials; 1 = plain hipMalloc)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the informational 4096x4096x257 leg")
     args = ap.parse_args()
