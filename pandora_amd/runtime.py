@@ -22,14 +22,29 @@ def get_engine(device=None):
     return _ENGINES[device]
 
 
+def _sample(a):
+    """A cheap content fingerprint (about 64K elements spread over the array) so that an array edited in place between
+    two runs is uploaded again; identity alone decides for everything the sample does not see."""
+    a = np.asarray(a)
+    flat = a.reshape(-1) if a.flags.c_contiguous else np.ascontiguousarray(a).reshape(-1)
+    step = max(1, flat.size // 65536)
+    return hash(flat[::step].tobytes())
+
+
 def _key(img_left, img_right, subpix, band):
     def ident(ds):
         im = ds["im"].data
         msk = ds["msk"].data if "msk" in ds.data_vars else None
-        return (id(im), im.shape, None if msk is None else id(msk))
+        return (id(im), im.shape, _sample(im), None if msk is None else (id(msk), _sample(msk)))
 
     return (ident(img_left), ident(img_right), int(subpix), img_left.attrs.get("valid_pixels", 0),
             img_left.attrs.get("no_data_mask", 1), band)
+
+
+def _holders(img_left, img_right):
+    """Strong references to the arrays the key names: while a pair is resident its arrays cannot be freed, so their id()
+    cannot be handed to a different array of the same shape (which would look resident and skip the upload)."""
+    return [ds[v].data for ds in (img_left, img_right) for v in ("im", "msk") if v in ds.data_vars]
 
 
 def select_band(ds, band):
@@ -46,14 +61,14 @@ def ensure_pair(img_left, img_right, subpix, device=None, band=None):
     band of multiband images that is matched (matching_cost's "band" parameter, kept in cv.attrs["band_correl"])."""
     eng = get_engine(device)
     key = _key(img_left, img_right, subpix, band)
-    if _RESIDENT.get(eng.device) != key:
+    if _RESIDENT.get(eng.device, (None,))[0] != key:
         eng.set_images(np.asarray(select_band(img_left, band), np.float32), np.asarray(select_band(img_right, band), np.float32), subpix)
         ml = img_left["msk"].data if "msk" in img_left.data_vars else None
         mr = img_right["msk"].data if "msk" in img_right.data_vars else None
         # the reference keeps one mask convention per image; they are the same in practice
         eng.set_masks(ml, mr, img_left.attrs.get("valid_pixels", 0), img_left.attrs.get("no_data_mask", 1))
         eng.set_disparity_grids(None, None)
-        _RESIDENT[eng.device] = key
+        _RESIDENT[eng.device] = (key, _holders(img_left, img_right))
     return eng
 
 

@@ -475,3 +475,38 @@ def test_main_with_a_disparity_grid_file(tmp_path):
     ok = np.isfinite(d)
     assert ok.mean() > 0.9 and np.all(d[ok] >= lo[ok] - 1e-6) and np.all(d[ok] <= hi[ok] + 1e-6)
     assert error(np.nan_to_num(d, nan=1e4), gt, 1) <= 0.20
+
+
+@pytest.mark.gpu
+def test_resident_pair_is_refreshed_when_arrays_are_replaced_or_edited(oracle):
+    """The engine keeps the last pair on the GPU between plugin calls (pandora_amd/runtime.py). A new pair whose arrays
+    land on the addresses the previous pair's arrays had, and a pair edited in place, must both be uploaded again."""
+    import pandora_amd
+    from pandora_amd.dataset import make_image
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R, _ = load_cones()
+    L, R = L[:96, :160], R[:96, :160]
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5, "subpix": 1},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"}}}
+
+    def run_once(shift):
+        # fresh arrays of the same shape on every call: the allocator is free to hand the previous addresses out again
+        left, right = make_image(np.roll(L, shift, axis=1).copy(), disparity=[-20, 0]), make_image(np.roll(R, shift, axis=0).copy())
+        machine = PandoraMachine()
+        c = {"pipeline": machine.check_conf(cfg, left, right)["pipeline"]}
+        disp, _ = pandora_amd.run(machine, left, right, c)
+        want, _ = oracle.wta(oracle.census_cost(left["im"].data, right["im"].data, 21, -20, 1, 5), -20, 1, False, np.nan)
+        np.testing.assert_array_equal(disp["disparity_map"].data, want)
+
+    for shift in (0, 3, 7, 1, 0, 5):
+        run_once(shift)
+
+    left, right = make_image(L.copy(), disparity=[-20, 0]), make_image(R.copy())
+    machine = PandoraMachine()
+    c = {"pipeline": machine.check_conf(cfg, left, right)["pipeline"]}
+    for k in range(3):
+        right["im"].data[...] = np.roll(R, k, axis=1)  # same array object, new content
+        disp, _ = pandora_amd.run(machine, left, right, c)
+        want, _ = oracle.wta(oracle.census_cost(L, np.roll(R, k, axis=1), 21, -20, 1, 5), -20, 1, False, np.nan)
+        np.testing.assert_array_equal(disp["disparity_map"].data, want)
