@@ -205,6 +205,26 @@ int pmx_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity
  * ambiguity_out: float32 [H][W], not normalised. */
 int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nbr_etas, const int64_t* grid_min, const int64_t* grid_max,
                   int negate, float* ambiguity_out);
+
+/* Replaces cost_volume_confidence_cpp.compute_ambiguity_and_sampled_ambiguity(..., True) followed by
+ * compute_risk_and_sampled_risk(..., sample_risk=False), i.e. Risk.confidence_prediction's computation
+ * (src/pandora/cost_volume_confidence/risk.py:139-166, cpp/src/risk.cpp:28-197): per pixel, the mean over etas of the span
+ * of disparity indices whose normalised cost lies within eta of the pixel's minimum (risk_max), of
+ * 1 + span - sampled ambiguity (risk_min), and of the disparities at the two ends of the span (disp_sup, disp_inf).
+ * etas: float64, ascending, etas[0] >= 0 (the reference compares the risk in double and the ambiguity with float32 etas;
+ * both are reproduced).  negate != 0 for similarity measures (risk.py:139-141).  Outputs: float32 [H][W]; NaN where
+ * the pixel has no cost. */
+int pmx_risk(pmx_ctx* ctx, pmx_cv* cv, const double* etas, int nbr_etas, const int64_t* grid_min, const int64_t* grid_max,
+             int negate, float* risk_max, float* risk_min, float* disp_sup, float* disp_inf);
+
+/* Replaces cost_volume_confidence_cpp.compute_interval_bounds (src/pandora/cost_volume_confidence/cpp/src/
+ * interval_bounds.cpp:28-161; called by interval_bounds.py:158-170 with disp_interval == disparity_range == the volume's
+ * disparities): the interval of disparities whose possibility type_factor * norm + 1 - max(type_factor * norm), taken
+ * inside the pixel's [grid_min, grid_max], reaches possibility_threshold; type_factor is -1 for "min" measures and +1
+ * for "max".  Outputs: float32 [H][W] disparities; NaN where the range holds no cost.  (The optional graph
+ * regularisation of interval_tools.py is host-side work on the two maps and is not part of this library.) */
+int pmx_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float possibility_threshold, float type_factor, const int64_t* grid_min,
+                        const int64_t* grid_max, float* interval_inf, float* interval_sup);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

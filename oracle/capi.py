@@ -238,6 +238,32 @@ def disparity_range(disp, validity, win, marge, gmin, gmax):
     return lo, hi
 
 
+def risk(cv, etas, grid_min, grid_max, disp_range):
+    """risk.cpp:28-197 as risk.py:144-166 calls it -> (risk_max, risk_min, disp_sup, disp_inf), float32 [H][W] each."""
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    e = np.ascontiguousarray(etas, np.float64)
+    gmin = np.ascontiguousarray(grid_min, np.int64)
+    gmax = np.ascontiguousarray(grid_max, np.int64)
+    dr = _f32(disp_range)
+    outs = [np.empty((H, W), np.float32) for _ in range(4)]
+    lib().orc_risk(_p(cv), H, W, D, _p(e, C.c_double), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64), _p(dr), *[_p(o) for o in outs])
+    return tuple(outs)
+
+
+def interval_bounds(cv, possibility_threshold, type_factor, grid_min, grid_max, disp_range):
+    """interval_bounds.cpp:28-161 -> (interval_inf, interval_sup), float32 [H][W]."""
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    gmin = np.ascontiguousarray(grid_min, np.int64)
+    gmax = np.ascontiguousarray(grid_max, np.int64)
+    dr = _f32(disp_range)
+    lo, hi = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+    lib().orc_interval_bounds(_p(cv), H, W, D, _p(dr), C.c_float(possibility_threshold), C.c_float(type_factor),
+                              _p(gmin, C.c_int64), _p(gmax, C.c_int64), _p(dr), _p(lo), _p(hi))
+    return lo, hi
+
+
 def ambiguity(cv, etas, grid_min, grid_max, disp_range):
     """ambiguity.cpp:28-142 -> float32 [H][W] integral of the ambiguity (before normalisation)."""
     cv = _f32(cv)

@@ -915,6 +915,122 @@ void orc_ambiguity(const float* cv, int H, int W, int D, const float* etas, int 
 
 
 /* ---------------------------------------------------------------------------------------------
+ * cost_volume_confidence/cpp/src/risk.cpp:28-197 compute_risk_and_sampled_risk as risk.py:144-166 calls it: the sampled
+ * ambiguity comes from ambiguity.cpp (float32 etas, float comparison), the risk itself compares in double
+ * (float cost > float extremum + double eta).  For every eta the span of disparity indices whose normalised cost is
+ * within eta of the pixel's minimum: risk_max = mean span, risk_min = mean (1 + span - sampled ambiguity),
+ * disp_sup / disp_inf = mean of the disparities at the two ends.  Pixels without any cost get NaN.
+ * The cost volume is the one of a "min" measure (callers negate similarity volumes, risk.py:139-141).
+ * ------------------------------------------------------------------------------------------- */
+void orc_risk(const float* cv, int H, int W, int D, const double* etas, int nbr_etas, const int64_t* grid_min,
+              const int64_t* grid_max, const float* disp_range, float* risk_max, float* risk_min, float* disp_sup,
+              float* disp_inf) {
+    size_t npix = (size_t)H * W;
+    float* minimg = (float*)malloc(sizeof(float) * npix);
+    float min_cost = INFINITY, max_cost = -INFINITY;
+    for (size_t p = 0; p < npix; ++p) {
+        float lo = INFINITY, hi = -INFINITY;
+        int any = 0;
+        for (int k = 0; k < D; ++k) {
+            float v = cv[p * D + k];
+            if (!isnan(v)) { any = 1; if (v < lo) lo = v; if (v > hi) hi = v; }
+        }
+        if (!any) { minimg[p] = NAN; continue; }
+        minimg[p] = lo;
+        if (lo < min_cost) min_cost = lo;
+        if (hi > max_cost) max_cost = hi;
+    }
+    float diff = max_cost - min_cost;
+    float* nc = (float*)malloc(sizeof(float) * (size_t)D);
+    for (size_t p = 0; p < npix; ++p) {
+        float ne = (minimg[p] - min_cost) / diff;
+        if (isnan(ne)) { risk_max[p] = risk_min[p] = disp_sup[p] = disp_inf[p] = NAN; continue; }
+        size_t i0 = orc_searchsorted(disp_range, (size_t)D, (float)grid_min[p]);
+        size_t i1 = orc_searchsorted(disp_range, (size_t)D, (float)grid_max[p]) + 1;
+        for (int k = 0; k < D; ++k) {
+            float v = cv[p * D + k];
+            if (isnan(v)) nc[k] = ((size_t)k >= i0 && (size_t)k < i1) ? -INFINITY : INFINITY;
+            else nc[k] = (v - min_cost) / diff;
+        }
+        float s_min = 0, s_max = 0, s_inf = 0, s_sup = 0;
+        for (int e = 0; e < nbr_etas; ++e) {
+            /* ambiguity.cpp:120-128, float32 eta */
+            float samp = 0, thr = ne + (float)etas[e];
+            for (int k = 0; k < D; ++k) samp += (nc[k] <= thr) ? 1.f : 0.f;
+            /* risk.cpp:137-151, double eta */
+            double thr_d = (double)ne + etas[e];
+            int lo_k = -1, hi_k = -1;
+            for (int k = 0; k < D; ++k) {
+                if ((double)nc[k] > thr_d) continue;
+                if (lo_k < 0) lo_k = k;
+                hi_k = k;
+            }
+            if (lo_k < 0) { lo_k = 0; hi_k = 0; } /* cannot happen for eta >= 0: the minimum always qualifies */
+            float span = (float)hi_k - (float)lo_k;
+            s_sup += disp_range[hi_k];
+            s_inf += disp_range[lo_k];
+            s_min += 1 + span - samp;
+            s_max += span;
+        }
+        risk_min[p] = s_min / nbr_etas;
+        risk_max[p] = s_max / nbr_etas;
+        disp_sup[p] = s_sup / nbr_etas;
+        disp_inf[p] = s_inf / nbr_etas;
+    }
+    free(nc);
+    free(minimg);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * cost_volume_confidence/cpp/src/interval_bounds.cpp:28-161 compute_interval_bounds: inside the pixel's
+ * [grid_min, grid_max] the normalised costs become a possibility  type_factor * norm + 1 - max(type_factor * norm)
+ * (type_factor -1 for "min" measures, +1 for "max"); the interval is the span of disparities whose possibility reaches
+ * the threshold, widened by one sample on a side whose end has possibility exactly 1 (room for the refinement).
+ * No cost in the range -> NaN bounds.  disp_interval: the D float32 disparities written as bounds (== disp_range in
+ * interval_bounds.py:163-170).
+ * ------------------------------------------------------------------------------------------- */
+void orc_interval_bounds(const float* cv, int H, int W, int D, const float* disp_interval, float possibility_threshold,
+                         float type_factor, const int64_t* grid_min, const int64_t* grid_max, const float* disp_range,
+                         float* interval_inf, float* interval_sup) {
+    size_t npix = (size_t)H * W;
+    float min_cost = INFINITY, max_cost = -INFINITY;
+    for (size_t i = 0; i < npix * (size_t)D; ++i) {
+        float v = cv[i];
+        if (!isnan(v)) { if (v < min_cost) min_cost = v; if (v > max_cost) max_cost = v; }
+    }
+    float diff = max_cost - min_cost;
+    float* poss = (float*)malloc(sizeof(float) * (size_t)D);
+    for (size_t p = 0; p < npix; ++p) {
+        size_t i0 = orc_searchsorted(disp_range, (size_t)D, (float)grid_min[p]);
+        size_t i1 = orc_searchsorted(disp_range, (size_t)D, (float)grid_max[p]) + 1;
+        float max_pix = -INFINITY;
+        for (size_t k = i0; k < i1; ++k) {
+            float v = cv[p * D + k];
+            poss[k] = (v - min_cost) / diff;
+            if (!isnan(v)) { float t = type_factor * poss[k]; if (t > max_pix) max_pix = t; }
+        }
+        interval_inf[p] = interval_sup[p] = NAN;
+        if (isinf(max_pix)) continue;
+        int lo_k = -1, hi_k = -1;
+        for (size_t k = i0; k < i1; ++k) {
+            if (!isnan(poss[k])) {
+                volatile float t = type_factor * poss[k];
+                volatile float u = t + 1.f;
+                poss[k] = u - max_pix;
+            }
+            if (poss[k] >= possibility_threshold) { if (lo_k < 0) lo_k = (int)k; hi_k = (int)k; }
+        }
+        if (lo_k < 0) continue;
+        if (lo_k > 0 && (int)poss[lo_k] == 1) --lo_k;
+        if (hi_k < D - 1 && (int)poss[hi_k] == 1) ++hi_k;
+        interval_inf[p] = disp_interval[lo_k];
+        interval_sup[p] = disp_interval[hi_k];
+    }
+    free(poss);
+}
+
+
+/* ---------------------------------------------------------------------------------------------
  * cpp/src/img_tools.cpp:27-155 interpolate_nodata_sgm (+ find_valid_neighbors, compute_median): every pixel whose mask
  * has a bit of `invalid_bits` becomes the median of the first valid pixels met along the 8 directions (paths that leave
  * the image contribute nothing; no valid neighbour at all -> NaN) and gets the mask value `filled_value`.

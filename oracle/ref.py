@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def load(name):
-    """name in {'matching_cost_cpp','aggregation_cpp','refinement_cpp','cost_volume_confidence_cpp','img_tools_cpp','validation_cpp'}; None when not built."""
+    """name in {'matching_cost_cpp','aggregation_cpp','refinement_cpp','cost_volume_confidence_cpp','img_tools_cpp','validation_cpp','interval_tools_cpp'}; None when not built."""
     path = os.path.join(_HERE, "_ref", name + sysconfig.get_config_var("EXT_SUFFIX"))
     if not os.path.exists(path):
         return None

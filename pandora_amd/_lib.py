@@ -66,6 +66,10 @@ SIGNATURES = {
                                       C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pmx_ambiguity": (C.c_int, [vp, vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
                                 C.POINTER(C.c_float)]),
+    "pmx_risk": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
+                           C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pmx_interval_bounds": (C.c_int, [vp, vp, C.c_float, C.c_float, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float)]),
     "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
     "pmx_set_placement_trials": (C.c_int, [vp, C.c_int]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),

@@ -154,3 +154,247 @@ int pmx_launch_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* d_weights) {
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
+
+// ---- risk (cost_volume_confidence/cpp/src/risk.cpp:28-197 driven as risk.py:144-166) ------------------------------------
+// For every eta the reference scans the D normalised costs of a pixel for the first and the last disparity index within
+// eta of the pixel's minimum (double comparison: float cost > float extremum + double eta) and averages, over the etas,
+// the span, 1 + span - sampled ambiguity (float comparison with float32 etas, ambiguity.cpp:120-128) and the disparities
+// at the two ends.  Here every disparity k gets r(k) = the first eta index that admits it (the thresholds grow with
+// the eta index); k is the FIRST admitted index exactly for the etas in [r(k), min r(k' < k)) and the LAST one for the
+// etas in [r(k), min r(k' > k)), so the sums over etas are sums over k of k times an interval length: one ascending and
+// one descending sweep in chunks of 16 disparities with a running prefix / suffix minimum.  Every term is an integer
+// (or a multiple of 1/subpix), far below 2^24: the reference's float32 running sums are exact, and so is this.
+struct risk_args {
+    const float* cv;
+    const double* etas;        // [nbr_etas] device, ascending, etas[0] >= 0
+    const int64_t* grid_min;
+    const int64_t* grid_max;
+    const uint32_t* mm;
+    float* risk_max;
+    float* risk_min;
+    float* disp_sup;
+    float* disp_inf;
+    int H, W, D, d0, subpix, nbr_etas;
+    float sign;
+};
+
+__global__ __launch_bounds__(kBlock) void risk_kernel(risk_args a) {
+    __shared__ double etas_d[kMaxEtas];
+    __shared__ float etas_f[kMaxEtas];
+    for (int i = threadIdx.x; i < a.nbr_etas; i += kBlock) { etas_d[i] = a.etas[i]; etas_f[i] = (float)a.etas[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const size_t npix = (size_t)a.H * a.W;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    const float min_cost = ord2f(a.mm[0]), max_cost = ord2f(a.mm[1]);
+    const float diff = max_cost - min_cost;
+    const int E = a.nbr_etas, D = a.D;
+    const float qnan = __int_as_float(0x7fc00000);
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);
+        const float* row = a.cv + pix * (size_t)D;
+        float lo = c_inf();
+        bool any = false;
+        for (int k = sub; k < D; k += 16) {
+            const float v = row[k] * a.sign;
+            if (v == v) { any = true; lo = fminf(lo, v); }
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, m));
+            any = any | (__shfl_xor((int)any, m) != 0);
+        }
+        const float ne = any ? (lo - min_cost) / diff : qnan;
+        const bool dead = ne != ne;  // uniform over the 16 lanes of the pixel
+        auto range_at = [&](int k) { return (float)((double)a.d0 + (double)k / (double)a.subpix); };
+        auto search = [&](float value) {
+            int left = 0, right = D - 1;
+            while (left < right) {
+                const int mid = left + (right - left) / 2;
+                if (range_at(mid) < value) left = mid + 1; else right = mid;
+            }
+            return left;
+        };
+        const int i0 = search((float)a.grid_min[pix]), i1 = search((float)a.grid_max[pix]) + 1;
+        const double ne_d = (double)ne;
+        // normalised cost of disparity k (+inf past the end of the volume: never admitted)
+        auto norm_at = [&](int k) {
+            if (k >= D) return c_inf();
+            const float v = row[k] * a.sign;
+            if (v != v) return (k >= i0 && k < i1) ? -c_inf() : c_inf();
+            return (v - min_cost) / diff;
+        };
+        auto first_eta_d = [&](float nc) {  // first i with !(nc > ne + eta_i), in double (risk.cpp:140)
+            int left = 0, right = E;
+            while (left < right) {
+                const int mid = (left + right) >> 1;
+                if (!((double)nc > ne_d + etas_d[mid])) right = mid; else left = mid + 1;
+            }
+            return left;
+        };
+        long long s_lo = 0, s_hi = 0;
+        int amb = 0;
+        // ascending sweep: first admitted index per eta, and the ambiguity integral on the way
+        int cur = E;
+        for (int base = 0; base < D; base += 16) {
+            const int k = base + sub;
+            const float nc = norm_at(k);
+            const int r = dead ? E : first_eta_d(nc);
+            {
+                int left = 0, right = E;  // first i with nc <= ne + eta_i, in float (ambiguity.cpp:123)
+                while (left < right) {
+                    const int mid = (left + right) >> 1;
+                    if (nc <= ne + etas_f[mid]) right = mid; else left = mid + 1;
+                }
+                amb += E - left;
+            }
+            int pm = r;  // inclusive prefix minimum over the 16 lanes of the pixel
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                const int o = __shfl_up(pm, m, 16);
+                if (sub >= m) pm = min(pm, o);
+            }
+            int excl = __shfl_up(pm, 1, 16);
+            excl = min(sub == 0 ? E : excl, cur);
+            if (r < excl) s_lo += (long long)k * (excl - r);
+            cur = min(cur, __shfl(pm, 15, 16));
+        }
+        // descending sweep: last admitted index per eta
+        cur = E;
+        for (int base = ((D - 1) / 16) * 16; base >= 0; base -= 16) {
+            const int k = base + sub;
+            const int r = dead ? E : first_eta_d(norm_at(k));
+            int sm = r;  // inclusive suffix minimum
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                const int o = __shfl_down(sm, m, 16);
+                if (sub + m < 16) sm = min(sm, o);
+            }
+            int excl = __shfl_down(sm, 1, 16);
+            excl = min(sub == 15 ? E : excl, cur);
+            if (r < excl) s_hi += (long long)k * (excl - r);
+            cur = min(cur, __shfl(sm, 0, 16));
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {
+            s_lo += __shfl_xor(s_lo, m);
+            s_hi += __shfl_xor(s_hi, m);
+            amb += __shfl_xor(amb, m);
+        }
+        if (sub == 0 && quad * 4 + grp < npix) {
+            if (dead) {
+                a.risk_max[pix] = qnan; a.risk_min[pix] = qnan; a.disp_sup[pix] = qnan; a.disp_inf[pix] = qnan;
+            } else {
+                const float fe = (float)E;
+                const float span = (float)(s_hi - s_lo);
+                a.risk_max[pix] = span / fe;
+                a.risk_min[pix] = (float)((long long)E + (s_hi - s_lo) - (long long)amb) / fe;
+                a.disp_sup[pix] = (float)((double)a.d0 * E + (double)s_hi / a.subpix) / fe;
+                a.disp_inf[pix] = (float)((double)a.d0 * E + (double)s_lo / a.subpix) / fe;
+            }
+        }
+    }
+}
+
+int pmx_launch_risk(pmx_ctx* ctx, pmx_cv* cv, const double* d_etas, int nbr_etas, const int64_t* d_gmin, const int64_t* d_gmax,
+                    int negate, uint32_t* d_mm, float* d_out4) {
+    const float sign = negate ? -1.f : 1.f;
+    const size_t n = cv->cells(), npix = (size_t)cv->H * cv->W;
+    const uint32_t init[2] = {0xffffffffu, 0u};
+    PMX_HIP(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(volume_minmax_kernel, dim3(4096), dim3(kBlock), 0, ctx->stream, cv->data, n, sign, d_mm);
+    risk_args a;
+    a.cv = cv->data; a.etas = d_etas; a.grid_min = d_gmin; a.grid_max = d_gmax; a.mm = d_mm;
+    a.risk_max = d_out4; a.risk_min = d_out4 + npix; a.disp_sup = d_out4 + 2 * npix; a.disp_inf = d_out4 + 3 * npix;
+    a.H = cv->H; a.W = cv->W; a.D = cv->D; a.d0 = cv->d0; a.subpix = cv->subpix; a.nbr_etas = nbr_etas; a.sign = sign;
+    const size_t want = (npix + 15) / 16;
+    hipLaunchKernelGGL(risk_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// ---- interval bounds (cost_volume_confidence/cpp/src/interval_bounds.cpp:28-161) ---------------------------------------
+// Inside the pixel's [grid_min, grid_max]: possibility = type_factor * norm + 1 - max(type_factor * norm); the bounds are
+// the first and last disparity whose possibility reaches the threshold, moved out by one sample where the end's
+// possibility truncates to 1.  The float operations keep the reference's order (no contraction: *_rn intrinsics).
+struct ivb_args {
+    const float* cv;
+    const int64_t* grid_min;
+    const int64_t* grid_max;
+    const uint32_t* mm;
+    float* inf;
+    float* sup;
+    int H, W, D, d0, subpix;
+    float threshold, type_factor;
+};
+
+__global__ __launch_bounds__(kBlock) void interval_bounds_kernel(ivb_args a) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const size_t npix = (size_t)a.H * a.W;
+    const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * (kBlock / 64);
+    const float min_cost = ord2f(a.mm[0]), max_cost = ord2f(a.mm[1]);
+    const float diff = max_cost - min_cost;
+    const int D = a.D;
+    const float qnan = __int_as_float(0x7fc00000);
+    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
+        const size_t pix = min(quad * 4 + grp, npix - 1);
+        const float* row = a.cv + pix * (size_t)D;
+        auto range_at = [&](int k) { return (float)((double)a.d0 + (double)k / (double)a.subpix); };
+        auto search = [&](float value) {
+            int left = 0, right = D - 1;
+            while (left < right) {
+                const int mid = left + (right - left) / 2;
+                if (range_at(mid) < value) left = mid + 1; else right = mid;
+            }
+            return left;
+        };
+        const int i0 = search((float)a.grid_min[pix]), i1 = search((float)a.grid_max[pix]) + 1;
+        auto norm_at = [&](int k) { return __fdiv_rn(__fsub_rn(row[k], min_cost), diff); };
+        float mx = -c_inf();
+        for (int k = i0 + sub; k < i1; k += 16) {
+            const float nrm = norm_at(k);
+            if (nrm == nrm) mx = fmaxf(mx, __fmul_rn(a.type_factor, nrm));
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+        auto poss_at = [&](int k) { return __fsub_rn(__fadd_rn(__fmul_rn(a.type_factor, norm_at(k)), 1.f), mx); };  // NaN stays NaN
+        int lo_k = 0x7fffffff, hi_k = -1;
+        if (mx > -c_inf() && mx < c_inf()) {
+            for (int k = i0 + sub; k < i1; k += 16)
+                if (poss_at(k) >= a.threshold) { lo_k = min(lo_k, k); hi_k = max(hi_k, k); }
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {
+            lo_k = min(lo_k, __shfl_xor(lo_k, m));
+            hi_k = max(hi_k, __shfl_xor(hi_k, m));
+        }
+        if (sub == 0 && quad * 4 + grp < npix) {
+            float lo = qnan, hi = qnan;
+            if (hi_k >= 0) {
+                if (lo_k > 0 && (int)poss_at(lo_k) == 1) --lo_k;
+                if (hi_k < D - 1 && (int)poss_at(hi_k) == 1) ++hi_k;
+                lo = range_at(lo_k);
+                hi = range_at(hi_k);
+            }
+            a.inf[pix] = lo;
+            a.sup[pix] = hi;
+        }
+    }
+}
+
+int pmx_launch_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float threshold, float type_factor, const int64_t* d_gmin,
+                               const int64_t* d_gmax, uint32_t* d_mm, float* d_out2) {
+    const size_t n = cv->cells(), npix = (size_t)cv->H * cv->W;
+    const uint32_t init[2] = {0xffffffffu, 0u};
+    PMX_HIP(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(volume_minmax_kernel, dim3(4096), dim3(kBlock), 0, ctx->stream, cv->data, n, 1.f, d_mm);
+    ivb_args a;
+    a.cv = cv->data; a.grid_min = d_gmin; a.grid_max = d_gmax; a.mm = d_mm; a.inf = d_out2; a.sup = d_out2 + npix;
+    a.H = cv->H; a.W = cv->W; a.D = cv->D; a.d0 = cv->d0; a.subpix = cv->subpix; a.threshold = threshold; a.type_factor = type_factor;
+    const size_t want = (npix + 15) / 16;
+    hipLaunchKernelGGL(interval_bounds_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

@@ -995,3 +995,59 @@ extern "C" int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nb
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }
+
+extern "C" int pmx_risk(pmx_ctx* ctx, pmx_cv* cv, const double* etas, int nbr_etas, const int64_t* grid_min, const int64_t* grid_max,
+                        int negate, float* risk_max, float* risk_min, float* disp_sup, float* disp_inf) {
+    int rc = check_cv(ctx, cv, "pmx_risk");
+    if (rc) return rc;
+    PMX_CHECK(etas && grid_min && grid_max && risk_max && risk_min && disp_sup && disp_inf, PMX_ERR_ARG, "pmx_risk: null argument");
+    PMX_CHECK(nbr_etas > 0 && nbr_etas <= 1024, PMX_ERR_ARG, "pmx_risk: nbr_etas must be in 1..1024, got %d", nbr_etas);
+    PMX_CHECK(etas[0] >= 0, PMX_ERR_ARG, "pmx_risk: etas must start at >= 0 (the reference's scan is undefined otherwise), got %g", etas[0]);
+    for (int i = 1; i < nbr_etas; ++i)
+        PMX_CHECK(etas[i] >= etas[i - 1], PMX_ERR_ARG, "pmx_risk: etas must be ascending (etas[%d] = %g < %g)", i, etas[i], etas[i - 1]);
+    rc = pmx_cv_materialize(ctx, cv);
+    if (rc) return rc;
+    const size_t n = (size_t)cv->H * cv->W;
+    rc = pmx_need_small(ctx, n * (8 + 8 + 16) + (size_t)nbr_etas * 8 + 64);
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_gmin = (int64_t*)base;
+    int64_t* d_gmax = d_gmin + n;
+    double* d_etas = (double*)(d_gmax + n);
+    float* d_out = (float*)(d_etas + nbr_etas);
+    uint32_t* d_mm = (uint32_t*)(d_out + 4 * n);
+    PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_etas, etas, (size_t)nbr_etas * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_risk(ctx, cv, d_etas, nbr_etas, d_gmin, d_gmax, negate, d_mm, d_out);
+    if (rc) return rc;
+    float* outs[4] = {risk_max, risk_min, disp_sup, disp_inf};
+    for (int k = 0; k < 4; ++k) PMX_HIP(hipMemcpyAsync(outs[k], d_out + k * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+extern "C" int pmx_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float possibility_threshold, float type_factor, const int64_t* grid_min,
+                                   const int64_t* grid_max, float* interval_inf, float* interval_sup) {
+    int rc = check_cv(ctx, cv, "pmx_interval_bounds");
+    if (rc) return rc;
+    PMX_CHECK(grid_min && grid_max && interval_inf && interval_sup, PMX_ERR_ARG, "pmx_interval_bounds: null argument");
+    rc = pmx_cv_materialize(ctx, cv);
+    if (rc) return rc;
+    const size_t n = (size_t)cv->H * cv->W;
+    rc = pmx_need_small(ctx, n * (8 + 8 + 8) + 64);
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_gmin = (int64_t*)base;
+    int64_t* d_gmax = d_gmin + n;
+    float* d_out = (float*)(d_gmax + n);
+    uint32_t* d_mm = (uint32_t*)(d_out + 2 * n);
+    PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_interval_bounds(ctx, cv, possibility_threshold, type_factor, d_gmin, d_gmax, d_mm, d_out);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(interval_inf, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(interval_sup, d_out + n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}

@@ -201,6 +201,10 @@ int pmx_launch_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* v
 int pmx_launch_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* d_weights);
 int pmx_launch_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* d_etas, int nbr_etas, const int64_t* d_gmin, const int64_t* d_gmax,
                          int negate, uint32_t* d_mm, float* d_amb);
+int pmx_launch_risk(pmx_ctx* ctx, pmx_cv* cv, const double* d_etas, int nbr_etas, const int64_t* d_gmin, const int64_t* d_gmax,
+                    int negate, uint32_t* d_mm, float* d_out4);
+int pmx_launch_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float threshold, float type_factor, const int64_t* d_gmin,
+                               const int64_t* d_gmax, uint32_t* d_mm, float* d_out2);
 int pmx_launch_interpolate_nodata(pmx_ctx* ctx, const float* img, const int* msk, int H, int W, int invalid_bits, int filled,
                                   float* out_img, int* out_msk);
 int pmx_launch_median_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int size, float* out);

@@ -31,9 +31,10 @@ class DataArray:
     def shape(self):
         return self.data.shape
 
-    def sel(self, **kw):
-        """Label selection along one coordinate (used as img["disparity"].sel(band_disp="min"))."""
-        (dim, label), = kw.items()
+    def sel(self, indexers=None, **kw):
+        """Label selection along one coordinate (img["disparity"].sel(band_disp="min"), or xarray's dict form
+        cv["confidence_measure"].sel({"indicator": name}))."""
+        (dim, label), = {**(indexers or {}), **kw}.items()
         axis = self.dims.index(dim)
         labels = list(self.coords[dim])
         idx = labels.index(label)

@@ -301,6 +301,30 @@ class Engine:
                                        int(bool(negate)), _p(out, C.c_float)), "pmx_ambiguity")
         return out
 
+    def _grids(self, what, grid_min, grid_max):
+        gmin = np.ascontiguousarray(grid_min, np.int64)
+        gmax = np.ascontiguousarray(grid_max, np.int64)
+        if gmin.shape != (self.H, self.W) or gmax.shape != (self.H, self.W):
+            raise ValueError(f"{what}: the disparity grids must have the image shape")
+        return gmin, gmax
+
+    def risk(self, cv, etas, grid_min, grid_max, negate=False):
+        """risk.cpp:28-197 as risk.py:144-166 drives it, on the resident volume -> (risk_max, risk_min, disp_sup, disp_inf)."""
+        e = np.ascontiguousarray(etas, np.float64)
+        gmin, gmax = self._grids("risk", grid_min, grid_max)
+        outs = [np.empty((self.H, self.W), np.float32) for _ in range(4)]
+        check(_lib.lib().pmx_risk(self.ctx, cv.handle, _p(e, C.c_double), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64),
+                                  int(bool(negate)), *[_p(o, C.c_float) for o in outs]), "pmx_risk")
+        return tuple(outs)
+
+    def interval_bounds(self, cv, possibility_threshold, type_factor, grid_min, grid_max):
+        """interval_bounds.cpp:28-161 on the resident volume -> (interval_inf, interval_sup) float32 [H][W]."""
+        gmin, gmax = self._grids("interval_bounds", grid_min, grid_max)
+        lo, hi = np.empty((self.H, self.W), np.float32), np.empty((self.H, self.W), np.float32)
+        check(_lib.lib().pmx_interval_bounds(self.ctx, cv.handle, float(possibility_threshold), float(type_factor), _p(gmin, C.c_int64),
+                                             _p(gmax, C.c_int64), _p(lo, C.c_float), _p(hi, C.c_float)), "pmx_interval_bounds")
+        return lo, hi
+
     def debug_path_costs(self, cv, raw=False):
         """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation
         (raw=True: the device byte order [8][H][W][Dp] and the (gl, kpl) lane map)."""

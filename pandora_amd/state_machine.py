@@ -8,7 +8,7 @@ N1: cross_checking_accurate / cross_checking_fast, with the left/right duplicati
 reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
 median / bilateral disparity filters (N2; state_machine.py:449-473) and the multiscale loop (N3;
 fixed_zoom_pyramid, state_machine.py:521-556, images without masks); the others of the reference
-(median_for_intervals filter, the risk / interval_bounds confidences, cost_volume_confidence, semantic_segmentation) are outside this
+(median_for_intervals filter, semantic_segmentation) are outside this
 build's scope: an unknown filter raises the reference's KeyError, an unknown step ``MachineError``.
 """
 import logging
@@ -207,7 +207,7 @@ class PandoraMachine:
             self.right_cv = optimization_.optimize_cv(self.right_cv, self.right_img, self.left_img)
 
     def cost_volume_confidence_run(self, cfg, input_step):
-        """state_machine.py:558-587 (N4: ambiguity on the device, std_intensity on the host)"""
+        """state_machine.py:558-587 (N4: ambiguity, risk and interval_bounds on the device, std_intensity on the host)"""
         logging.info("Cost volume confidence computation...")
         cfg["pipeline"][input_step]["indicator"] = ""
         if len(input_step.split(".")) == 2:

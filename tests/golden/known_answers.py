@@ -426,3 +426,37 @@ WTA_MORE = [
     dict(cite="test_disparity.py:401-430 test_argmax_split (zncc, NaN as -inf, first maximum)", method="zncc", win=1, subpix=2, dmin=-3,
          dmax=1, masked=False, is_max=True, invalid=0, disp=[[0.0, -1.0, -2.0, -3.0]] * 3),
 ]
+
+
+# ---- cost-volume confidence: risk and interval bounds (tests/test_confidence/) ---------------------------------------
+# variable-disparity volume of tests/test_confidence/conftest.py:92-113 ([disp][row][col] there, [row][col][disp] here)
+_CVV = [[[n, 5, n], [1, n, 2], [3, n, 4], [2, n, 5]],
+        [[4, 6.2, n], [1, n, 5], [1, n, 0], [1, n, 1]],
+        [[n, 0, 0], [n, n, 0], [n, 0, 2], [n, 0, n]],
+        [[n, 5, n], [1, n, 2], [3, n, 4], [2, n, 5]]]
+_GRIDS_VAR = [[[-1, 0, -1, 0], [0, -1, 0, -1], [0, 0, 0, -1], [-1, -1, -1, -1]],
+              [[1, 1, 1, 1], [1, 0, 1, 1], [1, 1, 1, 0], [0, 0, 0, 1]]]  # conftest.py:76-84
+RISK = [
+    # risk_min of these tests is computed from hand-written sampled ambiguities; the maps that do not depend on them:
+    {"cite": "test_risk.py:32-160 test_compute_risk", "cv": [[[39, 28.03, 28, 34.5], [49, 34, 41.5, 34.1], [n, n, n, n]]],
+     "disp_range": [-1, 0, 1, 2], "grid_min": [[-1, -1, -1]], "grid_max": [[1, 1, 1]], "etas": [0.0, 0.3],
+     "risk_max": [[0.5, 1.0, n]], "disp_sup": [[1.0, 1.0, n]], "disp_inf": [[0.5, 0.0, n]]},
+    {"cite": "test_risk.py:270-319 test_compute_risk_with_variable_disparity", "cv": _CVV, "disp_range": [-1, 0, 1],
+     "grid_min": _GRIDS_VAR[0], "grid_max": _GRIDS_VAR[1], "etas": [0.0, 0.3],
+     "risk_max": [[2.0, 1.5, 1.5, 1.0], [2.0, 1.0, 1.5, 2.0], [1.0, 1.0, 0.0, 1.0], [1.0, 1.5, 1.5, 1.0]],
+     "disp_sup": [[1.0, 0.5, 0.5, 0.0], [1.0, 0.0, 1.0, 1.0], [1.0, 1.0, 0.0, 0.0], [0.0, 0.5, 0.5, 0.0]],
+     "disp_inf": [[-1.0, -1.0, -1.0, -1.0], [-1.0, -1.0, -0.5, -1.0], [0.0, 0.0, 0.0, -1.0], [-1.0, -1.0, -1.0, -1.0]]},
+]
+
+# test_interval_bounds.py:30-116: SAD window 1 on the confidence pair (conftest.py:34-89, range [-1, 1], left mask on
+# (1,1) and (3,3)), possibility threshold 0.7, "min" measure; the cost volume is the one the test's comment spells out
+CONFIDENCE_LEFT = [[2, 5, 3, 1], [5, 3, 2, 1], [4, 2, 3, 2], [4, 5, 3, 2]]
+CONFIDENCE_RIGHT = [[1, 2, 1, 2], [2, 3, 5, 3], [0, 2, 4, 2], [5, 3, 1, 4]]
+CONFIDENCE_LEFT_MASK = [[0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 1]]
+INTERVAL_BOUNDS = {
+    "cite": "test_interval_bounds.py:30-116", "threshold": 0.7, "type_factor": -1.0, "disp_range": [-1, 0, 1],
+    "cv": [[[n, 1, 0], [4, 3, 4], [1, 2, 1], [0, 1, n]], [[n, 3, 2], [n, n, n], [1, 3, 1], [4, 2, n]],
+           [[n, 4, 2], [2, 0, 2], [1, 1, 1], [2, 0, n]], [[n, 1, 1], [0, 2, 4], [0, 2, 1], [n, n, n]]],
+    "inf": [[0, -1, -1, -1], [0, n, -1, -1], [0, -1, -1, -1], [-1, -1, -1, n]],
+    "sup": [[1, 1, 1, 0], [1, n, 1, 1], [1, 1, 1, 1], [1, 0, 1, n]],
+}

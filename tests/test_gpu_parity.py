@@ -958,6 +958,76 @@ def test_ambiguity_integral(eng, oracle, H, W, dmin, dmax, sp, negate):
     assert got[2, 3] == len(etas) * D
 
 
+def _confidence_volume(eng, H, W, dmin, dmax, sp, quantised, seed):
+    rng = np.random.default_rng(seed)
+    D = (dmax - dmin) * sp + 1
+    L, R = pair(H, W, seed=H)
+    eng.set_images(L, R, sp)
+    cv = eng.alloc_cv(D, dmin)
+    vol = rng.integers(0, 14, (H, W, D)).astype(np.float32) if quantised else (rng.random((H, W, D)) * 50 - 10).astype(np.float32)
+    vol[rng.random((H, W, D)) < 0.1] = np.nan
+    vol[2, 3, :] = np.nan
+    vol[4, 5, 1:] = np.nan
+    cv.from_host(vol)
+    gmin = rng.integers(dmin, dmin + 3, (H, W)).astype(np.int64)
+    gmax = (gmin + rng.integers(1, dmax - dmin - 2, (H, W))).astype(np.int64)
+    return cv, vol, gmin, gmax, (dmin + np.arange(D) / sp).astype(np.float32)
+
+
+@pytest.mark.parametrize("quantised", [False, True])
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,negate", [(21, 37, -9, 6, 1, False), (12, 30, -3, 4, 2, True), (9, 70, 0, 40, 1, False),
+                                                     (8, 33, -70, 66, 1, False), (7, 19, -5, 4, 4, True)])
+def test_risk(eng, oracle, H, W, dmin, dmax, sp, negate, quantised):
+    """risk.cpp:28-197 (+ the sampled ambiguity of ambiguity.cpp it consumes) on the device against the restatement pinned by
+    the compiled reference: four maps, bit for bit; D not a multiple of the 16-disparity chunks, ties, NaN in and out of range."""
+    cv, vol, gmin, gmax, disp_range = _confidence_volume(eng, H, W, dmin, dmax, sp, quantised, H * W)
+    etas = np.arange(0.0, 0.7, 0.01)
+    got = eng.risk(cv, etas, gmin, gmax, negate)
+    exp = oracle.risk(-vol if negate else vol, etas, gmin, gmax, disp_range)
+    for g, e, name in zip(got, exp, ("risk_max", "risk_min", "disp_sup", "disp_inf")):
+        np.testing.assert_array_equal(g, e, err_msg=name)
+    assert np.isnan(got[0][2, 3])
+    with pytest.raises(Exception, match="ascending"):
+        eng.risk(cv, [0.0, 0.2, 0.1], gmin, gmax)
+
+
+@pytest.mark.parametrize("case", ka.RISK, ids=lambda c: c["cite"])
+def test_risk_reference_vectors(eng, case):
+    vol, etas = np.array(case["cv"], np.float32), np.array(case["etas"])
+    H, W, D = vol.shape
+    eng.set_images(np.zeros((H, W), np.float32), np.zeros((H, W), np.float32), 1)
+    cv = eng.alloc_cv(D, int(case["disp_range"][0]))
+    cv.from_host(vol)
+    risk_max, _, sup, inf = eng.risk(cv, etas, np.array(case["grid_min"]), np.array(case["grid_max"]))
+    np.testing.assert_allclose(risk_max, np.array(case["risk_max"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(sup, np.array(case["disp_sup"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(inf, np.array(case["disp_inf"], np.float32), rtol=1e-6)
+
+
+@pytest.mark.parametrize("quantised", [False, True])
+@pytest.mark.parametrize("thr,tf", [(0.9, -1.0), (0.5, 1.0), (1.0, -1.0), (0.0, 1.0)])
+@pytest.mark.parametrize("H,W,dmin,dmax,sp", [(21, 37, -9, 6, 1), (12, 30, -3, 4, 2), (9, 70, 0, 40, 1), (7, 19, -5, 4, 4)])
+def test_interval_bounds(eng, oracle, H, W, dmin, dmax, sp, thr, tf, quantised):
+    """interval_bounds.cpp:28-161 on the device, bit for bit against the pinned restatement."""
+    cv, vol, gmin, gmax, disp_range = _confidence_volume(eng, H, W, dmin, dmax, sp, quantised, H + W)
+    got = eng.interval_bounds(cv, thr, tf, gmin, gmax)
+    exp = oracle.interval_bounds(vol, thr, tf, gmin, gmax, disp_range)
+    np.testing.assert_array_equal(got[0], exp[0])
+    np.testing.assert_array_equal(got[1], exp[1])
+
+
+def test_interval_bounds_reference_vector(eng):
+    c = ka.INTERVAL_BOUNDS
+    vol = np.array(c["cv"], np.float32)
+    eng.set_images(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), 1)
+    cv = eng.alloc_cv(3, -1)
+    cv.from_host(vol)
+    g = np.ones((4, 4), np.int64)
+    lo, hi = eng.interval_bounds(cv, c["threshold"], c["type_factor"], -g, g)
+    np.testing.assert_allclose(lo, np.array(c["inf"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(hi, np.array(c["sup"], np.float32), rtol=1e-6)
+
+
 @pytest.mark.parametrize("fast", ["1", "0"])
 @pytest.mark.parametrize("H,W,dmin,dmax,sp,dist", [(70, 150, -12, 5, 1, 5), (45, 90, -4, 3, 2, 9), (40, 61, 0, 9, 1, 2)])
 def test_cbca_phase_split_and_generic_kernels(eng, oracle, monkeypatch, fast, H, W, dmin, dmax, sp, dist):

@@ -288,3 +288,51 @@ def test_machine_confidence_steps(oracle):
     exp = 1 - (n - n.min()) / (n.max() - n.min())
     np.testing.assert_allclose(conf[:, :, 1], exp, rtol=1e-6)
     assert np.isnan(conf[0, 0, 0]) and np.isfinite(conf[5, 5, 0])
+
+
+def test_interval_bounds_pipeline_of_the_reference():
+    """tests/test_confidence/test_interval_bounds.py:30-116 as written: SAD window 1 on the confidence pair (left mask on two
+    pixels), interval_bounds at possibility 0.7, WTA, median filter -> the two layers and their expected maps."""
+    from tests.golden import known_answers as ka
+
+    L, R = np.array(ka.CONFIDENCE_LEFT, np.float32), np.array(ka.CONFIDENCE_RIGHT, np.float32)
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "sad", "window_size": 1, "subpix": 1},
+                        "cost_volume_confidence": {"confidence_method": "interval_bounds", "possibility_threshold": 0.7},
+                        "disparity": {"disparity_method": "wta"},
+                        "filter": {"filter_method": "median"}}}
+    _, left = run_machine(L, R, cfg, -1, 1, mskL=np.array(ka.CONFIDENCE_LEFT_MASK, np.int16), mskR=np.zeros((4, 4), np.int16))
+    assert list(left.coords["indicator"]) == ["confidence_from_interval_bounds_inf", "confidence_from_interval_bounds_sup"]
+    np.testing.assert_allclose(left["confidence_measure"].data[:, :, 0], np.array(ka.INTERVAL_BOUNDS["inf"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(left["confidence_measure"].data[:, :, 1], np.array(ka.INTERVAL_BOUNDS["sup"], np.float32), rtol=1e-6)
+
+
+def test_machine_risk_and_regularized_interval_bounds(oracle):
+    """ambiguity, then interval_bounds regularised with that ambiguity (interval_bounds.py:171-189), then risk, after a Census
+    volume: layer names in the reference's order and every layer equal to the pinned restatements."""
+    from pandora_amd import interval_tools
+
+    H, W, dmin, dmax = 40, 70, -8, 3
+    L, R = pair(H, W, seed=5)
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                        "cost_volume_confidence.amb": {"confidence_method": "ambiguity", "eta_max": 0.7, "eta_step": 0.01},
+                        "cost_volume_confidence.int": {"confidence_method": "interval_bounds", "regularization": True,
+                                                       "ambiguity_indicator": "amb", "vertical_depth": 2, "quantile_regularization": 0.9},
+                        "cost_volume_confidence.risk": {"confidence_method": "risk", "eta_max": 0.5, "eta_step": 0.02},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"}}}
+    _, left = run_machine(L, R, cfg, dmin, dmax)
+    assert list(left.coords["indicator"]) == [
+        "confidence_from_ambiguity.amb", "confidence_from_interval_bounds_inf.int", "confidence_from_interval_bounds_sup.int",
+        "confidence_from_risk_max.risk", "confidence_from_risk_min.risk", "confidence_from_disp_sup_from_risk.risk",
+        "confidence_from_disp_inf_from_risk.risk"]
+    conf = left["confidence_measure"].data
+    cv = oracle.census_cost(L, R, dmax - dmin + 1, dmin, 1, 5)
+    gmin, gmax = np.full((H, W), dmin, np.int64), np.full((H, W), dmax, np.int64)
+    disp_range = (dmin + np.arange(dmax - dmin + 1)).astype(np.float32)
+    lo, hi = oracle.interval_bounds(cv, 0.9, -1.0, gmin, gmax, disp_range)
+    lo, hi, mask = interval_tools.interval_regularization(lo, hi, conf[:, :, 0], 0.6, 5, 2, 0.9)
+    assert mask.any()
+    np.testing.assert_array_equal(conf[:, :, 1], lo)
+    np.testing.assert_array_equal(conf[:, :, 2], hi)
+    exp = oracle.risk(cv, np.arange(0.0, 0.5, 0.02), gmin, gmax, disp_range)
+    for k in range(4):
+        np.testing.assert_array_equal(conf[:, :, 3 + k], exp[k])

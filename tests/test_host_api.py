@@ -224,8 +224,16 @@ def test_confidence_configuration_like_the_reference():  # ambiguity.py:56-104, 
     assert (a.cfg["eta_max"], a.cfg["eta_step"], a.cfg["normalization"]) == (0.7, 0.01, True) and a._nbr_etas == 70
     assert cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="std_intensity").cfg["indicator"] == ""
     with pytest.raises(KeyError) as err:
-        cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="risk")
-    assert "No confidence method named risk supported" in str(err.value)
+        cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="mc_cnn_confidence")
+    assert "No confidence method named mc_cnn_confidence supported" in str(err.value)
+    r = cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="risk", eta_max=0.5, eta_step=0.1)  # risk.py:56-104
+    assert r._nbr_etas == 5 and r._indicator_max == "risk_max" and r._indicator_disp_inf == "disp_inf_from_risk"
+    ib = cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="interval_bounds")  # interval_bounds.py:54-120
+    assert (ib.cfg["possibility_threshold"], ib.cfg["regularization"], ib.cfg["ambiguity_kernel_size"], ib.cfg["vertical_depth"],
+            ib.cfg["quantile_regularization"]) == (0.9, False, 5, 0, 1.0)
+    for bad in ({"possibility_threshold": 1.5}, {"ambiguity_kernel_size": 4}, {"vertical_depth": -1}, {"regularization": 1}):
+        with pytest.raises(ConfigError):
+            cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="interval_bounds", **bad)
     with pytest.raises(ConfigError):
         cost_volume_confidence.AbstractCostVolumeConfidence(confidence_method="ambiguity", eta_max=1.5)
     pipe = {"pipeline": {"matching_cost": {"matching_cost_method": "zncc"},

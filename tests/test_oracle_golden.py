@@ -213,6 +213,35 @@ def test_interpolation_reference_vectors(oracle, case):
     np.testing.assert_array_equal(d, np.array(case["out_disp"], np.float32))
 
 
+@pytest.mark.parametrize("case", ka.RISK, ids=lambda c: c["cite"])
+def test_risk_reference_vectors(oracle, case):
+    """risk.cpp:28-197; risk_min is tied to the other maps through the ambiguity integral (risk.cpp:166-167:
+    risk_min = mean(1 + span - sampled ambiguity) = 1 + risk_max - integral / nbr_etas)."""
+    cv, etas = np.array(case["cv"], np.float32), np.array(case["etas"])
+    gmin, gmax, dr = np.array(case["grid_min"], np.int64), np.array(case["grid_max"], np.int64), np.array(case["disp_range"], np.float32)
+    risk_max, risk_min, sup, inf = oracle.risk(cv, etas, gmin, gmax, dr)
+    np.testing.assert_allclose(risk_max, np.array(case["risk_max"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(sup, np.array(case["disp_sup"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(inf, np.array(case["disp_inf"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(risk_max, sup - inf, rtol=1e-6)  # test_risk.py:159-160
+    amb = oracle.ambiguity(cv, etas, gmin, gmax, dr)
+    ok = ~np.isnan(risk_max)
+    np.testing.assert_allclose(risk_min[ok], (1 + risk_max - amb / len(etas))[ok], rtol=1e-6)
+
+
+def test_interval_bounds_reference_vector(oracle):
+    c = ka.INTERVAL_BOUNDS
+    cv, dr = np.array(c["cv"], np.float32), np.array(c["disp_range"], np.float32)
+    g = np.ones(cv.shape[:2], np.int64)
+    lo, hi = oracle.interval_bounds(cv, c["threshold"], c["type_factor"], -g, g, dr)
+    np.testing.assert_allclose(lo, np.array(c["inf"], np.float32), rtol=1e-6)
+    np.testing.assert_allclose(hi, np.array(c["sup"], np.float32), rtol=1e-6)
+    # and the volume itself is SAD window 1 of the confidence pair with the left mask applied
+    sad = oracle.sad_ssd(np.array(ka.CONFIDENCE_LEFT, np.float32), np.array(ka.CONFIDENCE_RIGHT, np.float32), 3, -1, 1, 1, False)
+    m = np.array(ka.CONFIDENCE_LEFT_MASK, bool)
+    np.testing.assert_array_equal(np.nan_to_num(sad[~m], nan=-1), np.nan_to_num(cv[~m], nan=-1))
+
+
 def test_oracle_results_do_not_depend_on_the_thread_count(oracle):
     """The OpenMP loops of the oracle (census, SGM, WTA, refinement) give identical bits with 1 thread (the reference's
     serial order) and with every core (bench.py's cpu_baseline_all_cores)."""

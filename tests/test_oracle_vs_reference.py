@@ -166,6 +166,51 @@ def test_ambiguity_matches_reference(oracle, H, W, D, d0, sp):
     assert got[1, 2] == len(etas) * D
 
 
+def _confidence_case(H, W, D, d0, sp, seed, quantised):
+    rng = np.random.default_rng(seed)
+    if quantised:  # census-like integer costs: many exact ties with the extremum
+        cv = rng.integers(0, 12, (H, W, D)).astype(np.float32)
+    else:
+        cv = (rng.random((H, W, D)) * 30 - 8).astype(np.float32)
+    cv[rng.random((H, W, D)) < 0.15] = np.nan
+    cv[1, 2, :] = np.nan
+    cv[2, 3, 1:] = np.nan  # a single cost
+    disp_range = (d0 + np.arange(D) / sp).astype(np.float32)
+    gmin = rng.integers(d0, d0 + 2, (H, W)).astype(np.int64)
+    gmax = (gmin + rng.integers(1, max(2, (D - 1) // sp), (H, W))).astype(np.int64)
+    return cv, disp_range, gmin, gmax
+
+
+@pytest.mark.skipif(cc is None, reason="oracle/_ref not built")
+@pytest.mark.parametrize("quantised", [False, True])
+@pytest.mark.parametrize("H,W,D,d0,sp", [(9, 14, 12, -5, 1), (6, 11, 17, -2, 2), (5, 8, 9, 0, 4), (7, 9, 33, -30, 1)])
+def test_risk_matches_reference(oracle, H, W, D, d0, sp, quantised):
+    """risk.cpp:28-197 driven like risk.py:144-166 (sampled ambiguity from ambiguity.cpp, then the risk)."""
+    cv, disp_range, gmin, gmax = _confidence_case(H, W, D, d0, sp, H * W + D, quantised)
+    etas = np.arange(0.0, 0.7, 0.01)
+    grids = np.array([gmin, gmax], dtype=np.int64)
+    _, samp = cc.compute_ambiguity_and_sampled_ambiguity(cv, etas, len(etas), grids, disp_range, True)
+    exp = cc.compute_risk_and_sampled_risk(cv, samp, etas, len(etas), grids, disp_range, False)
+    got = oracle.risk(cv, etas, gmin, gmax, disp_range)
+    for g, e in zip(got, exp):  # risk_max, risk_min, disp_sup, disp_inf
+        np.testing.assert_array_equal(g, e)
+    assert np.isnan(got[0][1, 2])  # no cost at all
+
+
+@pytest.mark.skipif(cc is None, reason="oracle/_ref not built")
+@pytest.mark.parametrize("quantised", [False, True])
+@pytest.mark.parametrize("thr,tf", [(0.9, -1.0), (0.5, 1.0), (1.0, -1.0), (0.0, 1.0)])
+@pytest.mark.parametrize("H,W,D,d0,sp", [(9, 14, 12, -5, 1), (6, 11, 17, -2, 2), (5, 8, 9, 0, 4), (7, 9, 33, -30, 1)])
+def test_interval_bounds_match_reference(oracle, H, W, D, d0, sp, thr, tf, quantised):
+    """interval_bounds.cpp:28-161: both measure types, thresholds at the ends of [0, 1], NaN holes, empty ranges."""
+    cv, disp_range, gmin, gmax = _confidence_case(H, W, D, d0, sp, H + W + D, quantised)
+    grids = np.array([gmin, gmax], dtype=np.int64)
+    exp = cc.compute_interval_bounds(cv, disp_range, thr, tf, grids, disp_range)
+    got = oracle.interval_bounds(cv, thr, tf, gmin, gmax, disp_range)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+
+
 it = ref.load("img_tools_cpp")
 
 
@@ -214,3 +259,40 @@ def test_interpolation_passes_match_reference(oracle, which):
         got = oracle.interpolate_disparity(which, disp, valid)
         np.testing.assert_array_equal(got[0], exp[0])
         np.testing.assert_array_equal(got[1], exp[1])
+
+
+itv = ref.load("interval_tools_cpp")
+
+
+@pytest.mark.skipif(itv is None, reason="oracle/_ref not built")
+@pytest.mark.parametrize("depth", [0, 1, 2, 5])
+@pytest.mark.parametrize("quantile", [1.0, 0.9, 0.5, 0.0])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_interval_regularization_matches_reference(seed, depth, quantile):
+    """pandora_amd.interval_tools (host side of interval_bounds' regularisation) against the reference's compiled
+    create_connected_graph / graph_regularization (cpp/src/interval_tools.cpp:32-234) on random ambiguous zones."""
+    from pandora_amd import interval_tools as mine
+
+    rng = np.random.default_rng(seed)
+    H, W = 14, 40
+    amb = rng.random((H, W))
+    amb[rng.random((H, W)) < 0.05] = np.nan
+    inf = rng.integers(-9, 0, (H, W)).astype(np.float32) / 2
+    sup = inf + rng.integers(0, 9, (H, W)).astype(np.float32) / 4
+    hole = rng.random((H, W)) < 0.1
+    inf[hole], sup[hole] = np.nan, np.nan
+    inf[3], sup[3] = np.nan, np.nan  # whole segments without any bound
+    got = mine.interval_regularization(inf, sup, amb, 0.6, 5, depth, quantile)
+    # the reference's driver (interval_tools.py:36-96) restated on its compiled functions
+    pad = 2
+    conf = np.nanmin(np.lib.stride_tricks.sliding_window_view(np.hstack((np.ones((H, pad)), amb, np.ones((H, pad)))), 5, axis=1), axis=-1)
+    conf[:, -1] = 1
+    steps = np.diff(np.hstack([np.ones((H, 1)), conf >= 0.6]), axis=-1)
+    bl, br = np.argwhere(steps == -1), np.argwhere(steps == 1)
+    br[:, 1] -= 1
+    graph = itv.create_connected_graph(bl, br, depth)
+    np.testing.assert_array_equal(mine.create_connected_graph(bl, br, depth), graph)
+    exp = itv.graph_regularization(inf, sup, bl, br, graph, quantile)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+    assert got[2].any() and not got[2].all()
