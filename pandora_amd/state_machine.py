@@ -8,7 +8,7 @@ N1: cross_checking_accurate / cross_checking_fast, with the left/right duplicati
 reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
 median / bilateral disparity filters (N2; state_machine.py:449-473) and the multiscale loop (N3;
 fixed_zoom_pyramid, state_machine.py:521-556, images without masks); the others of the reference
-(median_for_intervals filter, semantic_segmentation) are outside this
+(semantic_segmentation, the disparity_denoiser filter) are outside this
 build's scope: an unknown filter raises the reference's KeyError, an unknown step ``MachineError``.
 """
 import logging

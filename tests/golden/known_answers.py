@@ -460,3 +460,21 @@ INTERVAL_BOUNDS = {
     "inf": [[0, -1, -1, -1], [0, n, -1, -1], [0, -1, -1, -1], [-1, -1, -1, n]],
     "sup": [[1, 1, 1, 0], [1, n, 1, 1], [1, 1, 1, 1], [1, 0, 1, n]],
 }
+
+
+# ---- median_for_intervals filter (tests/test_filter.py:662-800) -----------------------------------------------------------
+_IREG = 1 << 11  # PANDORA_MSK_PIXEL_INTERVAL_REGULARIZED
+MEDIAN_FOR_INTERVALS = {
+    "inf": [[4, 5, 7, 7, 8], [5, 84, 0, 35, 4], [2, 7, 21, 10, 1], [5, 0, 8, 1, 3]],
+    "sup": [[6, 7, 9, 9, 10], [7, 86, 2, 37, 6], [4, 10, 23, 12, 3], [7, 2, 10, 3, 5]],
+    "plain": {"cite": "test_filter.py:696-727", "cfg": {"filter_method": "median_for_intervals", "filter_size": 3},
+              "inf": [[4, 5, 7, 7, 8], [5, 5, 7, 7, 4], [2, 5, 8, 4, 1], [5, 0, 8, 1, 3]],
+              "sup": [[6, 7, 9, 9, 10], [7, 7, 10, 9, 6], [4, 7, 10, 6, 3], [7, 2, 10, 3, 5]]},
+    "regularized": {"cite": "test_filter.py:729-800",
+                    "cfg": {"filter_method": "median_for_intervals", "filter_size": 3, "regularization": True, "ambiguity_kernel_size": 3,
+                            "ambiguity_threshold": 0.8, "vertical_depth": 2, "quantile_regularization": 0.8},
+                    "ambiguity": [[1.0, 0.7, 1.0, 1.0, 1.0], [0.7, 1.0, 1.0, 1.0, 1.0], [1.0, 1.0, 1.0, 1.0, 0.7], [1.0, 1.0, 1.0, 0.7, 1.0]],
+                    "inf": [[4.8, 4.8, 4.8, 7, 8], [4.8, 4.8, 7, 7, 4], [2, 5, 8, 2.2, 1], [5, 0, 2.2, 2.2, 3]],
+                    "sup": [[7.4, 7.4, 7.4, 9, 10], [7.4, 7.4, 10, 9, 6], [4, 7, 10, 8.4, 3], [7, 2, 8.4, 8.4, 5]],
+                    "validity": [[_IREG, _IREG, _IREG, 0, 0], [_IREG, _IREG, 0, 0, 0], [0, 0, 0, _IREG, 0], [0, 0, _IREG, _IREG, 0]]},
+}

@@ -336,3 +336,60 @@ def test_machine_risk_and_regularized_interval_bounds(oracle):
     exp = oracle.risk(cv, np.arange(0.0, 0.5, 0.02), gmin, gmax, disp_range)
     for k in range(4):
         np.testing.assert_array_equal(conf[:, :, 3 + k], exp[k])
+
+
+def _interval_dataset(layers, names):
+    from pandora_amd.dataset import DataArray, Dataset
+
+    H, W = np.shape(layers[0])
+    ds = Dataset(coords={"row": np.arange(H), "col": np.arange(W), "indicator": np.array(names)})
+    ds["disparity_map"] = (("row", "col"), np.zeros((H, W), np.float32))
+    ds["validity_mask"] = (("row", "col"), np.zeros((H, W), np.int16))
+    ds["confidence_measure"] = DataArray(np.stack([np.array(x, np.float32) for x in layers], axis=2), ("row", "col", "indicator"),
+                                         {"indicator": list(names)})
+    return ds
+
+
+def test_median_for_intervals_reference_vectors():
+    """tests/test_filter.py:662-800: the filter on the two bound layers, plain and with the regularisation of ambiguous segments
+    (expected bounds, and the INTERVAL_REGULARIZED bit on the regularised pixels)."""
+    from pandora_amd import filter as flt
+    from pandora_amd.margins import Margins
+    from tests.golden import known_answers as ka
+
+    c = ka.MEDIAN_FOR_INTERVALS
+    names = ["confidence_from_interval_bounds_inf", "confidence_from_interval_bounds_sup"]
+    ds = _interval_dataset([c["inf"], c["sup"]], names)
+    f = flt.AbstractFilter(cfg=dict(c["plain"]["cfg"]))
+    assert f.margins == Margins(3, 3, 3, 3) and flt.AbstractFilter(cfg=dict(c["plain"]["cfg"]), step=2).margins == Margins(6, 6, 6, 6)
+    f.filter_disparity(ds)
+    np.testing.assert_array_equal(ds["confidence_measure"].sel({"indicator": names[0]}).data, np.array(c["plain"]["inf"], np.float32))
+    np.testing.assert_array_equal(ds["confidence_measure"].sel({"indicator": names[1]}).data, np.array(c["plain"]["sup"], np.float32))
+
+    r = c["regularized"]
+    ds = _interval_dataset([r["ambiguity"], c["inf"], c["sup"]], ["confidence_from_ambiguity"] + names)
+    flt.AbstractFilter(cfg=dict(r["cfg"])).filter_disparity(ds)
+    np.testing.assert_allclose(ds["confidence_measure"].sel({"indicator": names[0]}).data, np.array(r["inf"], np.float32), 1e-7, 1e-7)
+    np.testing.assert_allclose(ds["confidence_measure"].sel({"indicator": names[1]}).data, np.array(r["sup"], np.float32), 1e-7, 1e-7)
+    np.testing.assert_array_equal(ds["validity_mask"].data, np.array(r["validity"], np.int16))
+
+
+def test_machine_with_interval_filter_after_cross_checking(oracle):
+    """A pipeline with interval bounds and the median_for_intervals filter under cross_checking_fast (the right side skips this
+    filter, state_machine.py:466-473): the left layers equal the device median of the pinned bounds."""
+    H, W, dmin, dmax = 30, 52, -6, 2
+    L, R = pair(H, W, seed=9)
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                        "cost_volume_confidence": {"confidence_method": "interval_bounds"},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                        "filter": {"filter_method": "median_for_intervals", "filter_size": 3},
+                        "validation": {"validation_method": "cross_checking_fast"}}}
+    _, left = run_machine(L, R, cfg, dmin, dmax)
+    cv = oracle.census_cost(L, R, dmax - dmin + 1, dmin, 1, 5)
+    lo, hi = oracle.interval_bounds(cv, 0.9, -1.0, np.full((H, W), dmin, np.int64), np.full((H, W), dmax, np.int64),
+                                    (dmin + np.arange(dmax - dmin + 1)).astype(np.float32))
+    conf = left["confidence_measure"].data
+    for k, m in enumerate((lo, hi)):
+        # NaN bounds (the census frame) stay NaN, the others are NaN-ignoring 3x3 medians of the pinned bounds
+        np.testing.assert_array_equal(conf[:, :, k], oracle.filter_median_disparity(m, np.zeros((H, W), np.int64), 3))
+    assert list(left.coords["indicator"])[:2] == ["confidence_from_interval_bounds_inf", "confidence_from_interval_bounds_sup"]

@@ -124,8 +124,8 @@ def test_bad_sequencing_is_rejected():
     assert "semantic_segmentation" in str(err.value)
     with pytest.raises(MachineError) as err:  # a filter this build does not have: the plugin's KeyError, wrapped as the reference does
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
-                                   "filter": {"filter_method": "median_for_intervals"}}})
-    assert "No filter method named median_for_intervals supported" in str(err.value)
+                                   "filter": {"filter_method": "disparity_denoiser"}}})
+    assert "No filter method named disparity_denoiser supported" in str(err.value)
     out = PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"},
                                                     "disparity": {"disparity_method": "wta"}, "filter": {"filter_method": "bilateral"}}})
     assert out["pipeline"]["filter"]["sigma_color"] == 2.0 and out["pipeline"]["filter"]["sigma_space"] == 6.0  # bilateral.py:47-48
