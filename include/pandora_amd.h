@@ -202,7 +202,9 @@ int pmx_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity
  * (materialised to float32 if need be).  etas: float32 [nbr_etas] increasing (np.arange(eta_min, eta_max, eta_step));
  * grid_min / grid_max: int64 [H][W] per-pixel disparity range (NaN costs inside it count for every eta); negate != 0
  * for similarity measures (the reference flips the sign of the volume around the call, ambiguity.py:117-119).
- * ambiguity_out: float32 [H][W], not normalised. */
+ * ambiguity_out: float32 [H][W], not normalised.  grid_min == grid_max == NULL (here and in pmx_risk / pmx_interval_bounds)
+ * means every pixel searches the volume's whole disparity range, which is what constant [min, max] inputs give; it saves the
+ * upload of two int64 maps. */
 int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nbr_etas, const int64_t* grid_min, const int64_t* grid_max,
                   int negate, float* ambiguity_out);
 

@@ -6,6 +6,7 @@ import numpy as np
 
 from ..matching_cost.matching_cost import ConfigError
 from . import cost_volume_confidence as _cvc
+from .risk import _device_volume_and_grids
 
 
 @_cvc.AbstractCostVolumeConfidence.register_subclass("ambiguity")
@@ -51,15 +52,8 @@ class Ambiguity(_cvc.AbstractCostVolumeConfidence):
 
     def confidence_prediction(self, disp, img_left=None, img_right=None, cv=None):
         """ambiguity.py:113-166"""
-        arr = cv["cost_volume"]
-        if not hasattr(arr, "device_cv"):
-            raise TypeError("confidence_prediction needs a device-resident cost volume (pandora_amd has no CPU path)")
-        dcv = arr.device_cv
-        grids = np.array([np.asarray(img_left["disparity"].sel(band_disp="min").data),
-                          np.asarray(img_left["disparity"].sel(band_disp="max").data)], dtype=np.int64)
-        ny_, nx_, _ = dcv.shape
-        ambiguity = dcv.engine.ambiguity(dcv, self._etas, grids[0][:ny_, :nx_], grids[1][:ny_, :nx_],
-                                         negate=cv.attrs["type_measure"] == "max")
+        dcv, gmin, gmax = _device_volume_and_grids(cv, img_left)
+        ambiguity = dcv.engine.ambiguity(dcv, self._etas, gmin, gmax, negate=cv.attrs["type_measure"] == "max")
         if self._normalization:
             if "global_disparity" in img_left.attrs:
                 ambiguity = self.normalize_with_extremum(ambiguity, img_left, self._nbr_etas, cv.attrs["subpixel"])

@@ -7,14 +7,19 @@ from . import cost_volume_confidence as _cvc
 
 
 def _device_volume_and_grids(cv, img_left):
+    """The resident volume and the per-pixel [min, max] grids cropped to it; (None, None) when both grids are constant and equal
+    to the volume's own range - the device then searches the whole range and two int64 maps need not be uploaded."""
     arr = cv["cost_volume"]
     if not hasattr(arr, "device_cv"):
         raise TypeError("confidence_prediction needs a device-resident cost volume (pandora_amd has no CPU path)")
     dcv = arr.device_cv
     ny_, nx_, _ = dcv.shape
-    gmin = np.asarray(img_left["disparity"].sel(band_disp="min").data).astype(np.int64)[:ny_, :nx_]
-    gmax = np.asarray(img_left["disparity"].sel(band_disp="max").data).astype(np.int64)[:ny_, :nx_]
-    return dcv, gmin, gmax
+    gmin = np.asarray(img_left["disparity"].sel(band_disp="min").data)[:ny_, :nx_]
+    gmax = np.asarray(img_left["disparity"].sel(band_disp="max").data)[:ny_, :nx_]
+    disp = np.asarray(cv.coords["disp"])
+    if gmin.flat[0] == disp[0] and gmax.flat[0] == disp[-1] and (gmin == disp[0]).all() and (gmax == disp[-1]).all():
+        return dcv, None, None
+    return dcv, gmin.astype(np.int64), gmax.astype(np.int64)
 
 
 @_cvc.AbstractCostVolumeConfidence.register_subclass("risk")

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void ambiguity_kernel(amb_args a) {
                 }
                 return left;
             };
-            const int i0 = search((float)a.grid_min[pix]), i1 = search((float)a.grid_max[pix]) + 1;
+            const int i0 = a.grid_min ? search((float)a.grid_min[pix]) : 0, i1 = a.grid_max ? search((float)a.grid_max[pix]) + 1 : D;  // no grids: the whole range
             int count = 0;
             for (int k = sub; k < D; k += 16) {
                 const float v = row[k] * a.sign;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void risk_kernel(risk_args a) {
             }
             return left;
         };
-        const int i0 = search((float)a.grid_min[pix]), i1 = search((float)a.grid_max[pix]) + 1;
+        const int i0 = a.grid_min ? search((float)a.grid_min[pix]) : 0, i1 = a.grid_max ? search((float)a.grid_max[pix]) + 1 : D;  // no grids: the whole range
         const double ne_d = (double)ne;
         // normalised cost of disparity k (+inf past the end of the volume: never admitted)
         auto norm_at = [&](int k) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void interval_bounds_kernel(ivb_args a) {
             }
             return left;
         };
-        const int i0 = search((float)a.grid_min[pix]), i1 = search((float)a.grid_max[pix]) + 1;
+        const int i0 = a.grid_min ? search((float)a.grid_min[pix]) : 0, i1 = a.grid_max ? search((float)a.grid_max[pix]) + 1 : D;  // no grids: the whole range
         auto norm_at = [&](int k) { return __fdiv_rn(__fsub_rn(row[k], min_cost), diff); };
         float mx = -c_inf();
         for (int k = i0 + sub; k < i1; k += 16) {

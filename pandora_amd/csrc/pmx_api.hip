@@ -973,7 +973,7 @@ extern "C" int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nb
                              int negate, float* ambiguity_out) {
     int rc = check_cv(ctx, cv, "pmx_ambiguity");
     if (rc) return rc;
-    PMX_CHECK(etas && grid_min && grid_max && ambiguity_out, PMX_ERR_ARG, "pmx_ambiguity: null argument");
+    PMX_CHECK(etas && ambiguity_out && !grid_min == !grid_max, PMX_ERR_ARG, "pmx_ambiguity: null argument (grids: both or neither)");
     PMX_CHECK(nbr_etas > 0 && nbr_etas <= 1024, PMX_ERR_ARG, "pmx_ambiguity: nbr_etas must be in 1..1024, got %d", nbr_etas);
     rc = pmx_cv_materialize(ctx, cv);  // the measure is defined on the float32 costs
     if (rc) return rc;
@@ -986,8 +986,12 @@ extern "C" int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nb
     float* d_amb = (float*)(d_gmax + n);
     float* d_etas = d_amb + n;
     uint32_t* d_mm = (uint32_t*)(d_etas + nbr_etas);
-    PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (grid_min) {
+        PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        d_gmin = d_gmax = nullptr;  // the volume's whole disparity range for every pixel
+    }
     PMX_HIP(hipMemcpyAsync(d_etas, etas, (size_t)nbr_etas * 4, hipMemcpyHostToDevice, ctx->stream));
     rc = pmx_launch_ambiguity(ctx, cv, d_etas, nbr_etas, d_gmin, d_gmax, negate, d_mm, d_amb);
     if (rc) return rc;
@@ -1000,7 +1004,7 @@ extern "C" int pmx_risk(pmx_ctx* ctx, pmx_cv* cv, const double* etas, int nbr_et
                         int negate, float* risk_max, float* risk_min, float* disp_sup, float* disp_inf) {
     int rc = check_cv(ctx, cv, "pmx_risk");
     if (rc) return rc;
-    PMX_CHECK(etas && grid_min && grid_max && risk_max && risk_min && disp_sup && disp_inf, PMX_ERR_ARG, "pmx_risk: null argument");
+    PMX_CHECK(etas && risk_max && risk_min && disp_sup && disp_inf && !grid_min == !grid_max, PMX_ERR_ARG, "pmx_risk: null argument (grids: both or neither)");
     PMX_CHECK(nbr_etas > 0 && nbr_etas <= 1024, PMX_ERR_ARG, "pmx_risk: nbr_etas must be in 1..1024, got %d", nbr_etas);
     PMX_CHECK(etas[0] >= 0, PMX_ERR_ARG, "pmx_risk: etas must start at >= 0 (the reference's scan is undefined otherwise), got %g", etas[0]);
     for (int i = 1; i < nbr_etas; ++i)
@@ -1016,8 +1020,12 @@ extern "C" int pmx_risk(pmx_ctx* ctx, pmx_cv* cv, const double* etas, int nbr_et
     double* d_etas = (double*)(d_gmax + n);
     float* d_out = (float*)(d_etas + nbr_etas);
     uint32_t* d_mm = (uint32_t*)(d_out + 4 * n);
-    PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (grid_min) {
+        PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        d_gmin = d_gmax = nullptr;  // the volume's whole disparity range for every pixel
+    }
     PMX_HIP(hipMemcpyAsync(d_etas, etas, (size_t)nbr_etas * 8, hipMemcpyHostToDevice, ctx->stream));
     rc = pmx_launch_risk(ctx, cv, d_etas, nbr_etas, d_gmin, d_gmax, negate, d_mm, d_out);
     if (rc) return rc;
@@ -1031,7 +1039,7 @@ extern "C" int pmx_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float possibility_t
                                    const int64_t* grid_max, float* interval_inf, float* interval_sup) {
     int rc = check_cv(ctx, cv, "pmx_interval_bounds");
     if (rc) return rc;
-    PMX_CHECK(grid_min && grid_max && interval_inf && interval_sup, PMX_ERR_ARG, "pmx_interval_bounds: null argument");
+    PMX_CHECK(interval_inf && interval_sup && !grid_min == !grid_max, PMX_ERR_ARG, "pmx_interval_bounds: null argument (grids: both or neither)");
     rc = pmx_cv_materialize(ctx, cv);
     if (rc) return rc;
     const size_t n = (size_t)cv->H * cv->W;
@@ -1042,8 +1050,12 @@ extern "C" int pmx_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float possibility_t
     int64_t* d_gmax = d_gmin + n;
     float* d_out = (float*)(d_gmax + n);
     uint32_t* d_mm = (uint32_t*)(d_out + 2 * n);
-    PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (grid_min) {
+        PMX_HIP(hipMemcpyAsync(d_gmin, grid_min, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(d_gmax, grid_max, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        d_gmin = d_gmax = nullptr;  // the volume's whole disparity range for every pixel
+    }
     rc = pmx_launch_interval_bounds(ctx, cv, possibility_threshold, type_factor, d_gmin, d_gmax, d_mm, d_out);
     if (rc) return rc;
     PMX_HIP(hipMemcpyAsync(interval_inf, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -292,16 +292,15 @@ class Engine:
     def ambiguity(self, cv, etas, grid_min, grid_max, negate=False):
         """ambiguity.cpp:28-142 on the resident volume -> float32 [H][W] integral of the ambiguity (not normalised)."""
         e = np.ascontiguousarray(etas, np.float32)
-        gmin = np.ascontiguousarray(grid_min, np.int64)
-        gmax = np.ascontiguousarray(grid_max, np.int64)
-        if gmin.shape != (self.H, self.W) or gmax.shape != (self.H, self.W):
-            raise ValueError("ambiguity: the disparity grids must have the image shape")
+        gmin, gmax = self._grids("ambiguity", grid_min, grid_max)
         out = np.empty((self.H, self.W), np.float32)
         check(_lib.lib().pmx_ambiguity(self.ctx, cv.handle, _p(e, C.c_float), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64),
                                        int(bool(negate)), _p(out, C.c_float)), "pmx_ambiguity")
         return out
 
     def _grids(self, what, grid_min, grid_max):
+        if grid_min is None and grid_max is None:  # every pixel searches the volume's whole range
+            return None, None
         gmin = np.ascontiguousarray(grid_min, np.int64)
         gmax = np.ascontiguousarray(grid_max, np.int64)
         if gmin.shape != (self.H, self.W) or gmax.shape != (self.H, self.W):

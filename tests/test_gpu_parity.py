@@ -991,6 +991,22 @@ def test_risk(eng, oracle, H, W, dmin, dmax, sp, negate, quantised):
         eng.risk(cv, [0.0, 0.2, 0.1], gmin, gmax)
 
 
+@pytest.mark.parametrize("sp", [1, 2])
+def test_confidence_without_grids_searches_the_whole_range(eng, oracle, sp):
+    """grid_min == grid_max == NULL (what the plugins pass for constant [min, max] inputs) == grids holding the volume's range."""
+    H, W, dmin, dmax = 11, 29, -7, 5
+    cv, vol, _, _, disp_range = _confidence_volume(eng, H, W, dmin, dmax, sp, True, 77)
+    gmin, gmax = np.full((H, W), dmin, np.int64), np.full((H, W), dmax, np.int64)
+    etas = np.arange(0.0, 0.7, 0.01)
+    np.testing.assert_array_equal(eng.ambiguity(cv, etas, None, None), oracle.ambiguity(vol, etas, gmin, gmax, disp_range))
+    for g, e in zip(eng.risk(cv, etas, None, None), oracle.risk(vol, etas, gmin, gmax, disp_range)):
+        np.testing.assert_array_equal(g, e)
+    for g, e in zip(eng.interval_bounds(cv, 0.9, -1.0, None, None), oracle.interval_bounds(vol, 0.9, -1.0, gmin, gmax, disp_range)):
+        np.testing.assert_array_equal(g, e)
+    with pytest.raises(Exception):  # one grid without the other
+        eng.risk(cv, etas, gmin, None)
+
+
 @pytest.mark.parametrize("case", ka.RISK, ids=lambda c: c["cite"])
 def test_risk_reference_vectors(eng, case):
     vol, etas = np.array(case["cv"], np.float32), np.array(case["etas"])

@@ -20,10 +20,14 @@ eng.census(cv, 5)
 eng.cv_masked(cv, 5)
 gmin, gmax = np.full((H, W), -(D - 1), np.int64), np.zeros((H, W), np.int64)
 etas = np.arange(0.0, 0.7, 0.01)
-for name, fn in (("ambiguity", lambda: eng.ambiguity(cv, etas, gmin, gmax)), ("risk", lambda: eng.risk(cv, etas, gmin, gmax)),
-                 ("interval_bounds", lambda: eng.interval_bounds(cv, 0.9, -1.0, gmin, gmax))):
+CALLS = []
+for label, g0, g1 in (("per-pixel grids", gmin, gmax), ("constant range (no grids)", None, None)):
+    CALLS += [(f"ambiguity, {label}", lambda g0=g0, g1=g1: eng.ambiguity(cv, etas, g0, g1)),
+              (f"risk, {label}", lambda g0=g0, g1=g1: eng.risk(cv, etas, g0, g1)),
+              (f"interval_bounds, {label}", lambda g0=g0, g1=g1: eng.interval_bounds(cv, 0.9, -1.0, g0, g1))]
+for name, fn in CALLS:
     fn()
     t = time.perf_counter()
     for _ in range(3):
         fn()
-    print(f"{name:16s} {1e3 * (time.perf_counter() - t) / 3:8.2f} ms per call ({H}x{W}x{D})")
+    print(f"{name:44s} {1e3 * (time.perf_counter() - t) / 3:8.2f} ms per call ({H}x{W}x{D})")
