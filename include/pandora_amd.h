@@ -33,7 +33,7 @@ enum {
     PMX_STAGE_CENSUS_TRANSFORM = 0, PMX_STAGE_CENSUS_COST = 1, PMX_STAGE_SAD_SSD = 2, PMX_STAGE_ZNCC = 3,
     PMX_STAGE_MASK = 4, PMX_STAGE_CBCA_ARMS = 5, PMX_STAGE_CBCA_H = 6, PMX_STAGE_CBCA_V = 7,
     PMX_STAGE_SGM_PATH = 8, PMX_STAGE_SGM_FINAL = 9, PMX_STAGE_WTA = 10, PMX_STAGE_REFINE = 11,
-    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_SGM_FUSED = 14, PMX_STAGE_COUNT = 16
+    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_SGM_FUSED = 14, PMX_STAGE_SGM_FAMILY = 15, PMX_STAGE_COUNT = 16
 };
 
 const char* pmx_last_error(void);
@@ -113,6 +113,12 @@ int pmx_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int d
 /* AbstractOptimization.optimize_cv (optimization/optimization.py:104-123) for method "sgm"; the
  * arithmetic is external to the reference (pandora_plugin_libsgm==1.5.7): see DESIGN.md. */
 int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
+
+/* Debug / test hook: restrict the following pmx_sgm calls of this context to a subset of the eight paths.  Bit k of mask =
+ * the k-th path of the definition's order (drow, dcol of the step towards the pixel): (0,+1) (0,-1) (+1,0) (+1,+1) (+1,-1)
+ * (-1,0) (-1,+1) (-1,-1); 0xff (default) = all.  A strip of a full-size image can then be checked against the CPU oracle path
+ * family by family (the horizontal paths of a row depend on that row alone).  A subset always runs the float32 kernels. */
+int pmx_debug_sgm_directions(pmx_ctx* ctx, int mask);
 
 /* ---- disparity / refinement ----------------------------------------------------------------- */
 /* Upload the int64 validity mask computed by criteria.validity_mask (criteria.py:66-158);

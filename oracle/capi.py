@@ -147,12 +147,16 @@ def cbca(cv, d0, subpix, offset, crossL, crossRs):
     return cv
 
 
-def sgm(cv, P1, P2, is_max=False, invalid_cost=None, overcounting=False):
+# the definition's path order, (drow, dcol) of the step from p-r to p; bit k of a direction mask = SGM_DIRECTIONS[k]
+SGM_DIRECTIONS = ((0, 1), (0, -1), (1, 0), (1, 1), (1, -1), (-1, 0), (-1, 1), (-1, -1))
+
+
+def sgm(cv, P1, P2, is_max=False, invalid_cost=None, overcounting=False, dir_mask=0xFF):
     cv = _f32(cv)
     H, W, D = cv.shape
     out = np.empty_like(cv)
-    lib().orc_sgm(_p(cv), H, W, D, C.c_float(P1), C.c_float(P2), int(is_max), C.c_float(invalid_cost),
-                  int(overcounting), _p(out))
+    lib().orc_sgm_dirs(_p(cv), H, W, D, C.c_float(P1), C.c_float(P2), int(is_max), C.c_float(invalid_cost),
+                       int(overcounting), int(dir_mask), _p(out))
     return out
 
 

@@ -460,8 +460,14 @@ void orc_cbca(float* cv, int H, int W, int D, int d0, int subpix, int offset, co
  *   L_r(p,d)  = C'(p,d) + ( min( L_r(p-r,d), min(L_r(p-r,d-1), L_r(p-r,d+1)) + P1, M + P2 ) - M )
  *               with M = min_k L_r(p-r,k); L_r(p,d) = C'(p,d) when p-r is outside the image;
  *               d-1 / d+1 outside [0,D) count as +inf
- *   S(p,d)    = sum over r in order (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)
- *               [(drow,dcol) of the step from p-r to p], accumulated in float32 in that order
+ *   S(p,d)    = sum over r in order (0,+1) (0,-1) | (+1,0) (+1,+1) (+1,-1) | (-1,0) (-1,+1) (-1,-1)
+ *               [(drow,dcol) of the step from p-r to p], accumulated in float32 in that order: the two
+ *               horizontal paths, then the three downward ones, then the three upward ones (the order in
+ *               which the direction families of the GPU schedule finish; round 2 - before that the
+ *               order was (0,+1)(0,-1)(+1,0)(-1,0)(+1,+1)(-1,-1)(+1,-1)(-1,+1); the choice is this
+ *               build's own since nothing pins it, and it is invisible for integer-valued costs)
+ *   dir_mask  : bit k set = the k-th path of that list contributes (0xff = the definition; subsets
+ *               are a test hook that lets a strip of a large image be checked path family by family)
  *   overcounting: S -= 7*C'
  *   output    = S (negated back for "max"); NaN wherever the input was NaN.
  * All arithmetic is float32, in exactly the operation order written above.
@@ -527,8 +533,8 @@ static void sgm_path(const float* Cp, int H, int W, int D, int dr, int dc, float
     }
 }
 
-void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
-             int overcounting, float* out) {
+void orc_sgm_dirs(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
+                  int overcounting, int dir_mask, float* out) {
     size_t n = (size_t)H * W * D;
     float* Cp = (float*)malloc(sizeof(float) * n);
     float* S = (float*)calloc(n, sizeof(float));
@@ -540,8 +546,9 @@ void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_ma
         if (isnan(v)) v = invalid_cost; else if (is_max) v = -v;
         Cp[i] = v;
     }
-    static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}, {1, 1}, {-1, -1}, {1, -1}, {-1, 1}};
-    for (int k = 0; k < 8; ++k) sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, S, b0, b1);
+    static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {1, 1}, {1, -1}, {-1, 0}, {-1, 1}, {-1, -1}};
+    for (int k = 0; k < 8; ++k)
+        if (dir_mask >> k & 1) sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, S, b0, b1);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float s = S[i];
@@ -550,6 +557,11 @@ void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_ma
         out[i] = isnan(cv[i]) ? NAN : s;
     }
     free(Cp); free(S); free(b0); free(b1);
+}
+
+void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
+             int overcounting, float* out) {
+    orc_sgm_dirs(cv, H, W, D, P1, P2, is_max, invalid_cost, overcounting, 0xff, out);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -67,6 +67,9 @@ void orc_cbca(float* cv, int H, int W, int D, int d0, int subpix, int offset, co
  * Conventions documented in oracle.c and DESIGN.md. out may alias cv. */
 void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
              int overcounting, float* out);
+/* the same with a subset of the eight paths (bit k = k-th path of the definition's order; 0xff = orc_sgm) */
+void orc_sgm_dirs(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
+                  int overcounting, int dir_mask, float* out);
 
 /* disparity.py:399-516: WTA.  disp float32 [H][W], valid int64 [H][W] updated in place */
 void orc_wta(const float* cv, int H, int W, int D, double d0, int subpix, int is_max,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pmx_cbca": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int]),
     "pmx_cross_support": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, c_i16_p]),
     "pmx_sgm": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int]),
+    "pmx_debug_sgm_directions": (C.c_int, [vp, C.c_int]),
     "pmx_set_validity": (C.c_int, [vp, c_i64_p]),
     "pmx_wta": (C.c_int, [vp, vp, C.c_int, C.c_float]),
     "pmx_refine": (C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -80,7 +81,7 @@ SIGNATURES = {
 
 STAGES = {
     "census_transform": 0, "census_cost": 1, "sad_ssd": 2, "zncc": 3, "mask": 4, "cbca_arms": 5, "cbca_h": 6,
-    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13, "sgm_fused": 14,
+    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13, "sgm_fused": 14, "sgm_family": 15,
 }
 
 

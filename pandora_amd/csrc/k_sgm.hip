@@ -5,7 +5,13 @@
 //   C'(p,d) = C(p,d) (negated for "max" measures), NaN -> invalid_cost
 //   L_r(p,d) = C' + ( min( L_r(p-r,d), min(L_r(p-r,d-1), L_r(p-r,d+1)) + P1, M + P2 ) - M ),
 //              M = min_k L_r(p-r,k);  L_r = C' on the first pixel of a path
-//   S = sum_r L_r in the order (0,+1) (0,-1) (+1,0) (-1,0) (+1,+1) (-1,-1) (+1,-1) (-1,+1)
+//   S = sum_r L_r in the order (0,+1) (0,-1) | (+1,0) (+1,+1) (+1,-1) | (-1,0) (-1,+1) (-1,-1)
+//       (horizontal, downward, upward paths: the order in which the direction families of k_sgmfam.hip finish)
+//
+// Three schedules compute that definition bit for bit (pmx_launch_sgm picks one by size, PMX_SGM_SCHED=seq|par|fam forces):
+//   seq  one launch per direction, accumulating into S (this file): 92 B/cell of HBM traffic
+//   par  the eight directions side by side into eight path volumes + an ordered sum (this file): small volumes
+//   fam  two horizontal passes (this file) + two fused three-direction marching passes (k_sgmfam.hip): ~46 B/cell
 //
 // Execution model: ONE WAVEFRONT PER SCANLINE.  The 64 lanes of a wave hold the D path costs of the
 // current pixel, KPL consecutive disparities per lane (blocked layout -> the d-1/d+1 neighbours are
@@ -50,7 +56,8 @@ __device__ __forceinline__ float wave_min(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-enum { SGM_FIRST = 0, SGM_MID = 1, SGM_LAST = 2 };
+// MODE bits of a pass: it adds to what S already holds / it is the last pass and finishes S (overcounting, sign, NaN)
+enum { SGM_READS_S = 1, SGM_EPILOGUE = 2 };
 
 struct sgm_args {
     const float* C;  // raw cost volume (NaN = invalid)
@@ -63,6 +70,7 @@ struct sgm_args {
     // for volumes too small to fill the GPU one direction at a time (see pmx_launch_sgm)
     int multi;
     size_t vol;
+    int mask;  // multi: directions (bits, definition order) that are wanted; the others' blocks exit at once
 };
 
 template <int KPL>
@@ -84,9 +92,10 @@ template <int KPL, int MODE, bool TAIL>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args a) {
     if (a.multi) {  // direction order of the definition above
         const int k = blockIdx.y;
-        a.dr = (k < 2) ? 0 : ((k & 1) ? -1 : 1);
-        a.dc = (k == 0) ? 1 : (k == 1) ? -1 : (k < 4) ? 0 : ((k == 4 || k == 7) ? 1 : -1);
+        a.dr = (k < 2) ? 0 : (k < 5 ? 1 : -1);
+        a.dc = (k == 0) ? 1 : (k == 1) ? -1 : (k == 2 || k == 5) ? 0 : ((k == 3 || k == 6) ? 1 : -1);
         a.S += (size_t)k * a.vol;
+        if (!(a.mask >> k & 1)) return;
     }
     const int lane = threadIdx.x & 63;
     const int line = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
     auto prefetch = [&](lane_vals<KPL>& cslot, lane_vals<KPL>& sslot) {
         size_t poff = ((size_t)pr * a.W + pc) * pix_stride + d_load;
         cslot = load_vals<KPL>(a.C + poff);
-        if (MODE != SGM_FIRST) sslot = load_vals<KPL>(a.S + poff);
+        if (MODE & SGM_READS_S) sslot = load_vals<KPL>(a.S + poff);
         if (pleft > 0) {
             --pleft;
             pr += a.dr;
@@ -153,8 +162,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
             bool valid = lane_active && (!TAIL || d_first + k < D);
             Ln[k] = valid ? l : f_inf();
             lmin = fmin2(lmin, Ln[k]);
-            float s = (MODE == SGM_FIRST) ? l : (sslot.v[k] + l);
-            if (MODE == SGM_LAST) {
+            float s = (MODE & SGM_READS_S) ? (sslot.v[k] + l) : l;
+            if (MODE & SGM_EPILOGUE) {
                 if (a.overcounting) s = s - 7.0f * cc;
                 if (a.is_max) s = -s;
                 if (cr != cr) s = f_nan();
@@ -196,18 +205,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         if (i + j < nsteps) step(cbuf[j], sbuf[j]);
 }
 
+// (drow, dcol) of the step from p-r to p, in the definition's order
+static const int kSgmDirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {1, 1}, {1, -1}, {-1, 0}, {-1, 1}, {-1, -1}};
+
+// one launch of the line kernel: direction k, MODE bits chosen by the caller
 template <int KPL>
-static int sgm_run(pmx_ctx* ctx, const sgm_args& base) {
-    static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}, {1, 1}, {-1, -1}, {1, -1}, {-1, 1}};
-    for (int k = 0; k < 8; ++k) {
-        sgm_args a = base;
-        a.dr = dirs[k][0];
-        a.dc = dirs[k][1];
-        int nlines = a.dr == 0 ? a.H : a.W;
-        dim3 grid((nlines + kWavesPerBlock - 1) / kWavesPerBlock);
-        dim3 block(kWavesPerBlock * 64);
-        pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
-        const bool tail = (a.D % KPL) != 0;
+static void sgm_launch_direction(pmx_ctx* ctx, const sgm_args& base, int k, int mode) {
+    sgm_args a = base;
+    a.dr = kSgmDirs[k][0];
+    a.dc = kSgmDirs[k][1];
+    int nlines = a.dr == 0 ? a.H : a.W;
+    dim3 grid((nlines + kWavesPerBlock - 1) / kWavesPerBlock);
+    dim3 block(kWavesPerBlock * 64);
+    pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
+    const bool tail = (a.D % KPL) != 0;
 #define PMX_SGM_LAUNCH(MODE)                                                                                       \
     do {                                                                                                           \
         if (tail)                                                                                                  \
@@ -215,29 +226,55 @@ static int sgm_run(pmx_ctx* ctx, const sgm_args& base) {
         else                                                                                                       \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, MODE, false>), grid, block, 0, ctx->stream, a); \
     } while (0)
-        if (k == 0)
-            PMX_SGM_LAUNCH(SGM_FIRST);
-        else if (k == 7)
-            PMX_SGM_LAUNCH(SGM_LAST);
-        else
-            PMX_SGM_LAUNCH(SGM_MID);
-#undef PMX_SGM_LAUNCH
+    switch (mode) {
+        case 0: PMX_SGM_LAUNCH(0); break;
+        case SGM_READS_S: PMX_SGM_LAUNCH(SGM_READS_S); break;
+        case SGM_EPILOGUE: PMX_SGM_LAUNCH(SGM_EPILOGUE); break;
+        default: PMX_SGM_LAUNCH(SGM_READS_S | SGM_EPILOGUE); break;
     }
+#undef PMX_SGM_LAUNCH
+}
+
+// MODE bits of the pass for direction k when the directions of `mask` run one after the other in the definition's order
+static int sgm_pass_mode(int mask, int k) {
+    const int before = mask & ((1 << k) - 1), after = mask >> (k + 1);
+    return (before ? SGM_READS_S : 0) | (after ? 0 : SGM_EPILOGUE);
+}
+
+template <int KPL>
+static int sgm_run(pmx_ctx* ctx, const sgm_args& base, int mask) {
+    for (int k = 0; k < 8; ++k)
+        if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
-// S = L0 + L1 + ... + L7 accumulated in float32 in the definition's order (exactly what the eight sequential passes
+// the horizontal pair of the family schedule (k_sgmfam.hip runs the six others)
+template <int KPL>
+static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask) {
+    for (int k = 0; k < 2; ++k)
+        if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// S = sum of the enabled path volumes, accumulated in float32 in the definition's order (exactly what the sequential passes
 // compute), then the epilogue of the last pass: overcounting, sign, NaN where the input was NaN.
 __global__ __launch_bounds__(256) void sgm_sum_paths_kernel(const float* __restrict__ C, const float* __restrict__ L, size_t n,
-                                                            float invalid_cost, int is_max, int overcounting,
+                                                            float invalid_cost, int is_max, int overcounting, int mask,
                                                             float* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t step = (size_t)gridDim.x * 256;
     for (; i < n; i += step) {
-        float s = L[i];
+        float s = 0.f;
+        bool any = false;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) s = s + L[(size_t)k * n + i];
+        for (int k = 0; k < 8; ++k)
+            if (mask >> k & 1) {
+                const float v = L[(size_t)k * n + i];
+                s = any ? s + v : v;
+                any = true;
+            }
         const float cr = C[i];
         const float cc = (cr != cr) ? invalid_cost : (is_max ? -cr : cr);
         if (overcounting) s = s - 7.0f * cc;
@@ -249,32 +286,50 @@ __global__ __launch_bounds__(256) void sgm_sum_paths_kernel(const float* __restr
 
 // the eight directions side by side (one launch), then the ordered sum
 template <int KPL>
-static int sgm_run_parallel(pmx_ctx* ctx, sgm_args a, float* paths, size_t cells) {
+static int sgm_run_parallel(pmx_ctx* ctx, sgm_args a, float* paths, size_t cells, int mask) {
     a.multi = 1;
     a.vol = cells;
     a.S = paths;
+    a.mask = mask;
     const int nlines = a.H > a.W ? a.H : a.W;
     dim3 grid((nlines + kWavesPerBlock - 1) / kWavesPerBlock, 8);
     dim3 block(kWavesPerBlock * 64);
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
         if ((a.D % KPL) != 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, SGM_FIRST, true>), grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, 0, true>), grid, block, 0, ctx->stream, a);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, SGM_FIRST, false>), grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, 0, false>), grid, block, 0, ctx->stream, a);
     }
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
         const size_t want = (cells + 255) / 256;
         hipLaunchKernelGGL(sgm_sum_paths_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, ctx->stream, a.C, paths,
-                           cells, a.invalid_cost, a.is_max, a.overcounting, ctx->scratch);
+                           cells, a.invalid_cost, a.is_max, a.overcounting, mask, ctx->scratch);
     }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
+#define PMX_KPL_SWITCH(kpl, CALL)                                                        \
+    switch (kpl) {                                                                       \
+        case 1: rc = CALL(1); break;                                                     \
+        case 2: rc = CALL(2); break;                                                     \
+        case 3: rc = CALL(3); break;                                                     \
+        case 4: rc = CALL(4); break;                                                     \
+        case 5: rc = CALL(5); break;                                                     \
+        case 6: rc = CALL(6); break;                                                     \
+        case 7: rc = CALL(7); break;                                                     \
+        case 8: rc = CALL(8); break;                                                     \
+        default:                                                                         \
+            pmx_set_error("pmx_sgm: D = %d not supported (max 512)", cv->D);             \
+            return PMX_ERR_UNSUPPORTED;                                                  \
+    }
+
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting) {
-    // accumulator volume: the context's scratch; +64 B so the over-read of a lane's tail is in bounds
+    const int mask = ctx->sgm_dir_mask & 0xff;
+    PMX_CHECK(mask != 0, PMX_ERR_ARG, "pmx_sgm: empty direction mask");
+    // accumulator volume: the context's scratch; +256 B so the over-read of a lane's tail is in bounds
     size_t bytes = cv->cells() * sizeof(float) + 256;
     int rc = pmx_need_scratch(ctx, bytes);
     if (rc) return rc;
@@ -295,49 +350,42 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     a.dr = 0; a.dc = 0;
     a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
     a.is_max = is_max; a.overcounting = overcounting;
-    a.multi = 0; a.vol = 0;
-    int kpl = (cv->D + 63) / 64;
-    // Small volumes cannot fill the GPU one direction at a time (a wave per scanline: 375 - 450 waves on cones, each a chain
-    // of dependent steps): run the eight directions side by side into eight path volumes and add them in the definition's
-    // order - the same float32 operations, 104 instead of 92 B/cell of traffic, 8 volumes of scratch.  Above the
-    // threshold the passes are HBM-bound and the sequential schedule wins.  PMX_SGM_PAR=0/1 forces either (test hook).
-    bool parallel = cv->cells() <= ((size_t)128 << 20);  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
-    if (const char* e = getenv("PMX_SGM_PAR")) parallel = e[0] == '1';
-    if (parallel && kpl <= 8) {
+    a.multi = 0; a.vol = 0; a.mask = mask;
+    const int kpl = (cv->D + 63) / 64;
+    // Schedule.  Small volumes cannot fill the GPU one direction at a time (a wave per scanline: 375 - 450 waves on cones, each a
+    // chain of dependent steps): "par" runs the eight directions side by side into eight path volumes and adds them in the
+    // definition's order - the same float32 operations, 104 B/cell of traffic, 8 volumes of scratch.  Large volumes are HBM-bound:
+    // "fam" reads the costs four times instead of eight and rewrites S three times instead of seven (~46 B/cell against the 92
+    // of "seq", one launch per direction).  PMX_SGM_SCHED=seq|par|fam forces one (test hook; PMX_SGM_PAR=0/1 is the round-1 spelling).
+    enum { SEQ, PAR, FAM } sched = SEQ;
+    if (cv->cells() <= ((size_t)128 << 20)) sched = PAR;  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
+    else if (pmx_sgm_family_supported(cv)) sched = FAM;
+    if (const char* e = getenv("PMX_SGM_PAR")) sched = e[0] == '1' ? PAR : SEQ;
+    if (const char* e = getenv("PMX_SGM_SCHED")) {
+        if (e[0] == 's') sched = SEQ;
+        else if (e[0] == 'p') sched = PAR;
+        else if (e[0] == 'f') sched = FAM;
+    }
+    if (sched == PAR && kpl > 8) sched = SEQ;
+    if (sched == FAM && !pmx_sgm_family_supported(cv)) sched = SEQ;
+    if (sched == PAR) {
         float* paths = nullptr;
         PMX_HIP(pmx_pool_alloc(ctx, (void**)&paths, 8 * cv->cells() * sizeof(float) + 256));
-        switch (kpl) {
-            case 1: rc = sgm_run_parallel<1>(ctx, a, paths, cv->cells()); break;
-            case 2: rc = sgm_run_parallel<2>(ctx, a, paths, cv->cells()); break;
-            case 3: rc = sgm_run_parallel<3>(ctx, a, paths, cv->cells()); break;
-            case 4: rc = sgm_run_parallel<4>(ctx, a, paths, cv->cells()); break;
-            case 5: rc = sgm_run_parallel<5>(ctx, a, paths, cv->cells()); break;
-            case 6: rc = sgm_run_parallel<6>(ctx, a, paths, cv->cells()); break;
-            case 7: rc = sgm_run_parallel<7>(ctx, a, paths, cv->cells()); break;
-            default: rc = sgm_run_parallel<8>(ctx, a, paths, cv->cells()); break;
-        }
+#define PMX_CALL(K) sgm_run_parallel<K>(ctx, a, paths, cv->cells(), mask)
+        PMX_KPL_SWITCH(kpl, PMX_CALL)
+#undef PMX_CALL
         pmx_pool_free(ctx, paths);  // stream-ordered reuse: the kernels above are queued on ctx->stream
+    } else if (sched == FAM) {
+        // horizontal pair with the line kernel, then the downward and the upward family (k_sgmfam.hip)
+#define PMX_CALL(K) sgm_run_horizontal<K>(ctx, a, mask)
+        PMX_KPL_SWITCH(kpl, PMX_CALL)
+#undef PMX_CALL
         if (rc) return rc;
-        float* old = cv->data;
-        size_t old_bytes = cv->bytes;
-        cv->data = ctx->scratch;
-        cv->bytes = ctx->scratch_bytes;
-        ctx->scratch = old;
-        ctx->scratch_bytes = old_bytes;
-        return PMX_OK;
-    }
-    switch (kpl) {
-        case 1: rc = sgm_run<1>(ctx, a); break;
-        case 2: rc = sgm_run<2>(ctx, a); break;
-        case 3: rc = sgm_run<3>(ctx, a); break;
-        case 4: rc = sgm_run<4>(ctx, a); break;
-        case 5: rc = sgm_run<5>(ctx, a); break;
-        case 6: rc = sgm_run<6>(ctx, a); break;
-        case 7: rc = sgm_run<7>(ctx, a); break;
-        case 8: rc = sgm_run<8>(ctx, a); break;
-        default:
-            pmx_set_error("pmx_sgm: D = %d not supported (max 512)", cv->D);
-            return PMX_ERR_UNSUPPORTED;
+        rc = pmx_launch_sgm_families(ctx, cv, ctx->scratch, P1, P2, is_max, invalid_cost, overcounting, mask);
+    } else {
+#define PMX_CALL(K) sgm_run<K>(ctx, a, mask)
+        PMX_KPL_SWITCH(kpl, PMX_CALL)
+#undef PMX_CALL
     }
     if (rc) return rc;
     // the accumulator becomes the volume; the old volume becomes the scratch

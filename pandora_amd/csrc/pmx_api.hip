@@ -96,6 +96,9 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     pmx_pool_free(ctx, ctx->scratch);
     hipFree(ctx->small);
     hipFree(ctx->probe_sink);
+    hipFree(ctx->fam_halo);
+    hipFree(ctx->fam_ctl);
+    if (ctx->fam_err_host) hipHostFree(ctx->fam_err_host);
     pmx_pool_release(ctx);
     if (getenv("PMX_DEBUG_PTRS")) {
         size_t live = 0;
@@ -108,9 +111,29 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     delete ctx;
 }
 
+// Reads the error word of the in-kernel hand-offs (k_sgmfam.hip) once the stream is idle.  A hand-off only gives up after seconds
+// of polling, which means a broken build or a dying device, never a property of the data: the results on the device are then
+// incomplete and every synchronising entry point reports it.
+int pmx_check_async_error(pmx_ctx* ctx, const char* where) {
+    if (!ctx->fam_err_host || *ctx->fam_err_host == 0) return PMX_OK;
+    const unsigned code = *ctx->fam_err_host;
+    *ctx->fam_err_host = 0;
+    (void)hipMemsetAsync(ctx->fam_ctl + 1, 0, sizeof(unsigned), ctx->stream);
+    pmx_set_error("%s: the float32 SGM family kernel gave up waiting for a neighbouring window (code %u): results are incomplete", where,
+                  code);
+    return PMX_ERR_STATE;
+}
+
 extern "C" int pmx_sync(pmx_ctx* ctx) {
     PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_sync: null context");
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return pmx_check_async_error(ctx, "pmx_sync");
+}
+
+extern "C" int pmx_debug_sgm_directions(pmx_ctx* ctx, int mask) {
+    PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_debug_sgm_directions: null context");
+    PMX_CHECK(mask > 0 && mask <= 0xff, PMX_ERR_ARG, "pmx_debug_sgm_directions: mask must be in 1..255, got %d", mask);
+    ctx->sgm_dir_mask = mask;
     return PMX_OK;
 }
 
@@ -480,7 +503,7 @@ extern "C" int pmx_cv_download(pmx_ctx* ctx, pmx_cv* cv, float* host) {
     }
     PMX_HIP(hipMemcpyAsync(host, cv->data, cv->cells() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
-    return PMX_OK;
+    return pmx_check_async_error(ctx, "pmx_cv_download");
 }
 
 extern "C" int pmx_cv_dims(const pmx_cv* cv, int* H, int* W, int* D, int* d0, int* subpix) {
@@ -647,7 +670,7 @@ extern "C" int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max,
     if (rc) return rc;
     PMX_CHECK(P1 > 0.f && P2 > P1, PMX_ERR_ARG, "pmx_sgm: need 0 < P1 < P2 (plugin_libsgm.rst:170-185), got %g %g", P1, P2);
     PMX_CHECK(cv->D <= 512, PMX_ERR_UNSUPPORTED, "pmx_sgm: D = %d > 512 disparities not supported", cv->D);
-    if (ctx->lazy && pmx_fused_sgm_eligible(ctx, cv, P1, P2, is_max, invalid_cost, overcounting))
+    if (ctx->lazy && ctx->sgm_dir_mask == 0xff && pmx_fused_sgm_eligible(ctx, cv, P1, P2, is_max, invalid_cost, overcounting))
         return pmx_launch_sgm_fused(ctx, cv, P1, P2, invalid_cost);  // integer fast path, bit-identical
     rc = pmx_cv_materialize(ctx, cv);
     if (rc) return rc;
@@ -697,7 +720,7 @@ extern "C" int pmx_get_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, f
     if (validity) PMX_HIP(hipMemcpyAsync(validity, ctx->validity, n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     if (itp) PMX_HIP(hipMemcpyAsync(itp, ctx->itp, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
-    return PMX_OK;
+    return pmx_check_async_error(ctx, "pmx_get_disparity");
 }
 
 extern "C" int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t* validity) {

@@ -82,7 +82,19 @@ struct pmx_ctx {
     std::unordered_map<void*, size_t> pool_live;       // blocks handed out -> their true size
     std::vector<std::pair<size_t, void*>> pool_free;   // cached blocks
     size_t pool_free_bytes = 0;
+    // float32 SGM, family schedule (k_sgmfam.hip): the strip-to-strip hand-off buffer of tagged granules.  It belongs to the
+    // context, is zeroed when (re)allocated and never lent to anything else, so a tag equal to the current epoch can only have
+    // been written by the current launch; fam_epoch counts launches.  fam_ctl: [0] ticket counter, [1] error word (device).
+    unsigned long long* fam_halo = nullptr;
+    size_t fam_halo_bytes = 0;
+    unsigned fam_epoch = 0;
+    unsigned* fam_ctl = nullptr;
+    unsigned* fam_err_host = nullptr;  // pinned copy of the error word, filled behind every family launch
+    int sgm_dir_mask = 0xff;           // pmx_debug_sgm_directions
 };
+
+// an in-kernel hand-off that gave up (k_sgmfam.hip) is reported by the next call that synchronises the stream
+int pmx_check_async_error(pmx_ctx* ctx, const char* where);
 
 hipError_t pmx_pool_alloc(pmx_ctx* ctx, void** p, size_t bytes);
 void pmx_pool_free(pmx_ctx* ctx, void* p);
@@ -214,6 +226,10 @@ int pmx_launch_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);
 int pmx_launch_mask_dilate(pmx_ctx* ctx, const int16_t* msk, int H, int W, int win, int valid, int nodata, uint8_t* bad);
 int pmx_launch_fill_nan(pmx_ctx* ctx, float* p, size_t n);
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
+bool pmx_sgm_family_supported(const pmx_cv* cv);
+// the six non-horizontal paths of `mask` as two fused marching passes adding into S (which already holds the horizontal ones)
+int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
+                            int mask);
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
 int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance);

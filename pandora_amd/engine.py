@@ -154,9 +154,16 @@ class Engine:
                                            _p(out, C.c_int16)), "pmx_cross_support")
         return out
 
-    def sgm(self, cv, P1, P2, is_max=False, invalid_cost=0.0, overcounting=False):
-        check(_lib.lib().pmx_sgm(self.ctx, cv.handle, float(P1), float(P2), int(bool(is_max)), float(invalid_cost),
-                                 int(bool(overcounting))), "pmx_sgm")
+    def sgm(self, cv, P1, P2, is_max=False, invalid_cost=0.0, overcounting=False, dir_mask=0xFF):
+        """dir_mask: test hook (pmx_debug_sgm_directions), bit k = k-th path of the definition's order; 0xff = all eight."""
+        if dir_mask != 0xFF:
+            check(_lib.lib().pmx_debug_sgm_directions(self.ctx, int(dir_mask)), "pmx_debug_sgm_directions")
+        try:
+            check(_lib.lib().pmx_sgm(self.ctx, cv.handle, float(P1), float(P2), int(bool(is_max)), float(invalid_cost),
+                                     int(bool(overcounting))), "pmx_sgm")
+        finally:
+            if dir_mask != 0xFF:
+                check(_lib.lib().pmx_debug_sgm_directions(self.ctx, 0xFF), "pmx_debug_sgm_directions")
 
     def set_validity(self, validity=None):
         v = None if validity is None else np.ascontiguousarray(validity, np.int64)

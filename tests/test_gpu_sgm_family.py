@@ -1,0 +1,108 @@
+"""float32 SGM: the three schedules of pmx_sgm (one launch per path "seq", eight paths side by side "par", the horizontal pair +
+two fused three-path marching passes "fam", csrc/k_sgmfam.hip) against the CPU oracle, bit for bit, through the C ABI.
+The family schedule hands path costs from one workgroup window to the next inside a launch: shapes are chosen so that windows
+start inside / outside the image, finish early, are a single column wide at the image border, and so that both lane maps
+(16 and 32 lanes per pixel) and every instantiated disparities-per-lane count run; costs are non-integers so that the float32
+summation order of the definition is visible."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pandora_amd.engine import Engine
+
+    e = Engine(0)
+    e.set_lazy(False)
+    yield e
+    e.close()
+
+
+def volume(rng, H, W, D, is_max=False, nan_frac=0.05):
+    cv = (rng.random((H, W, D)).astype(np.float32) * 3 - 1) if is_max else (rng.random((H, W, D)) * 40).astype(np.float32)
+    if nan_frac:
+        cv[rng.random(cv.shape) < nan_frac] = np.nan
+        cv[H // 2, W // 3] = np.nan
+    return cv
+
+
+def run(eng, cvh, P1, P2, is_max, inv, over, mask=0xFF):
+    H, W, D = cvh.shape
+    z = np.zeros((H, W), np.float32)
+    eng.set_images(z, z, 1)
+    cv = eng.alloc_cv(D, 0)
+    cv.from_host(cvh)
+    eng.sgm(cv, P1, P2, is_max, inv, over, dir_mask=mask)
+    out = cv.to_host()
+    cv.free()
+    return out
+
+
+SHAPES = [
+    (40, 70, 30),    # 16 lanes x 3
+    (33, 100, 61),   # cones' D: 16 x 5
+    (70, 41, 100),   # taller than wide: most windows start below the first row; 16 x 7
+    (25, 130, 129),  # C3 / C5 D: 16 x 9, last lane owns 3 disparities
+    (30, 64, 144),   # 16 x 9, no tail
+    (20, 90, 150),   # 32 lanes x 6
+    (37, 50, 257),   # C4 D: 32 x 9
+    (12, 45, 300),   # 32 x 12
+    (9, 33, 512),    # 32 x 16, the largest D
+    (2, 17, 20),     # two rows
+    (50, 3, 40),     # narrower than any window
+]
+
+
+@pytest.mark.parametrize("H,W,D", SHAPES)
+def test_family_schedule_equals_oracle(eng, oracle, monkeypatch, H, W, D):
+    rng = np.random.default_rng(H * 1000 + W)
+    cvh = volume(rng, H, W, D)
+    exp = oracle.sgm(cvh, 1.5, 7.25, False, 45.0, False)
+    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    np.testing.assert_array_equal(run(eng, cvh, 1.5, 7.25, False, 45.0, False), exp)
+
+
+@pytest.mark.parametrize("is_max,over", [(False, True), (True, False), (True, True)])
+def test_family_schedule_max_measures_and_overcounting(eng, oracle, monkeypatch, is_max, over):
+    rng = np.random.default_rng(5)
+    cvh = volume(rng, 31, 77, 129, is_max)
+    exp = oracle.sgm(cvh, 0.3, 1.7, is_max, 45.0, over)
+    for sched in ("seq", "par", "fam"):
+        monkeypatch.setenv("PMX_SGM_SCHED", sched)
+        np.testing.assert_array_equal(run(eng, cvh, 0.3, 1.7, is_max, 45.0, over), exp)
+
+
+@pytest.mark.parametrize("mask", [0x01, 0x02, 0x03, 0x04, 0x08, 0x10, 0x1C, 0x20, 0x40, 0x80, 0xE0, 0xFC, 0x5A, 0xA5, 0x1F])
+def test_direction_masks_every_schedule(eng, oracle, monkeypatch, mask):
+    """pmx_debug_sgm_directions: any subset of the eight paths, same bits from every schedule (the first path of a subset starts the
+    sum, the last one applies the epilogue, whatever kernel it runs in)."""
+    rng = np.random.default_rng(mask)
+    cvh = volume(rng, 27, 53, 129)
+    exp = oracle.sgm(cvh, 2.5, 9.0, False, 45.0, False, dir_mask=mask)
+    for sched in ("seq", "par", "fam"):
+        monkeypatch.setenv("PMX_SGM_SCHED", sched)
+        np.testing.assert_array_equal(run(eng, cvh, 2.5, 9.0, False, 45.0, False, mask), exp)
+
+
+def test_family_schedule_many_windows(eng, oracle, monkeypatch):
+    """Wide enough for 8 compute waves per workgroup (32-column windows) and hundreds of windows in flight: the hand-off chain is
+    as long as at full size.  Integer costs keep the oracle fast; the result must still be exact."""
+    rng = np.random.default_rng(77)
+    H, W, D = 96, 7200, 33
+    cvh = rng.integers(0, 30, (H, W, D)).astype(np.float32)
+    exp = oracle.sgm(cvh, 8.0, 32.0, False, 45.0, False)
+    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    np.testing.assert_array_equal(run(eng, cvh, 8.0, 32.0, False, 45.0, False), exp)
+
+
+def test_family_schedule_repeated_launches(eng, oracle, monkeypatch):
+    """The hand-off buffer is recycled from launch to launch (tags = launch epochs): a second and third volume through the same
+    context must not see the first one's granules."""
+    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    for seed in (1, 2, 3):
+        rng = np.random.default_rng(seed)
+        cvh = volume(rng, 45, 200, 129)
+        exp = oracle.sgm(cvh, 3.0, 11.0, False, 45.0, False)
+        np.testing.assert_array_equal(run(eng, cvh, 3.0, 11.0, False, 45.0, False), exp)
