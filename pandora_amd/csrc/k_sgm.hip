@@ -359,7 +359,9 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     // of "seq", one launch per direction).  PMX_SGM_SCHED=seq|par|fam forces one (test hook; PMX_SGM_PAR=0/1 is the round-1 spelling).
     enum { SEQ, PAR, FAM } sched = SEQ;
     if (cv->cells() <= ((size_t)128 << 20)) sched = PAR;  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
-    else if (pmx_sgm_family_supported(cv)) sched = FAM;
+    // the marching passes advance one image row per ~2.5 - 4 us whatever the width: they pay from ~3500 columns on (a window
+    // for every CU); measured 4096^2 x 257: 55 ms against 96, 10000^2 x 129: 131 against 265, 2048^2 x 129: 12.4 against 11.3
+    else if (cv->W >= 3584 && cv->H >= 512 && pmx_sgm_family_supported(cv)) sched = FAM;
     if (const char* e = getenv("PMX_SGM_PAR")) sched = e[0] == '1' ? PAR : SEQ;
     if (const char* e = getenv("PMX_SGM_SCHED")) {
         if (e[0] == 's') sched = SEQ;

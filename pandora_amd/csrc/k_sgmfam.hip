@@ -34,31 +34,25 @@
 
 namespace {
 
-typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
+// This translation unit is compiled with -fno-honor-nans (v_min_f32 without the canonicalising v_max that IEEE mode otherwise
+// asks for, DPP operands folded into the minimum): no floating-point instruction may see a NaN whose result matters.  The
+// NaN costs of the input are recognised by their bits and replaced before any arithmetic.
 __device__ __forceinline__ float f_inf() { return __int_as_float(0x7f800000); }
-__device__ __forceinline__ float f_nan() { return __int_as_float(0x7fc00000); }
-__device__ __forceinline__ float fmin2(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ bool is_nan_bits(float v) { return (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u; }
+__device__ __forceinline__ float fmin2(float a, float b) { return __builtin_fminf(a, b); }
 
 template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float oldv, float src) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oldv), __float_as_int(src), CTRL, 0xf, 0xf, false));
+__device__ __forceinline__ float dpp(float src) {  // lanes without a source lane read 0
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), CTRL, 0xf, 0xf, true));
 }
 
-// minimum over the GL lanes of a pixel, returned in every lane of the group
-template <int GL>
-__device__ __forceinline__ float group_min(float v) {
-    v = fmin2(v, dpp_mov<0x121>(v, v));  // row_ror:1
-    v = fmin2(v, dpp_mov<0x122>(v, v));  // row_ror:2
-    v = fmin2(v, dpp_mov<0x124>(v, v));  // row_ror:4
-    v = fmin2(v, dpp_mov<0x128>(v, v));  // row_ror:8 -> every lane of the 16-lane row holds the row minimum
-    if (GL == 32) {                      // the other row of the pixel: lane ^ 16 (ds_swizzle bit mode, no LDS storage)
-        const float o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f));
-        v = fmin2(v, o);
-    }
-    return v;
-}
+constexpr unsigned kRsrcWord3 = 0x00020000;  // raw buffer: out-of-range loads return 0, out-of-range stores are dropped
+constexpr unsigned kOob = 0x80000000u;       // a byte offset beyond every row: lanes that must not touch memory use it
+constexpr int kSc1 = 16;                     // aux bit of the buffer instructions: write-through store / L1-bypassing load
 
 struct fam_args {
     const float* C;  // raw cost volume [H][W][D] (NaN = invalid)
@@ -69,8 +63,8 @@ struct fam_args {
     int is_max, overcounting;
     int has_sin;     // S already holds earlier paths (else this pass starts the sum)
     int epilogue;    // last pass: overcounting, sign, NaN restore
-    int dmask;       // bit 0 vertical path, bit 1 diagonal with predecessor column c-1, bit 2 diagonal with predecessor c+1
-    unsigned long long* halo;  // granules [H][NB][NGP]
+    int dmask;       // paths that are added to S: bit 0 vertical, bit 1 predecessor column c-1, bit 2 predecessor column c+1
+    u32x4* halo;     // hand-off blocks [H][NB][NGP] of 16 bytes {value, tag, value, tag}
     int NB;          // window borders per row = ceil(W / CW)
     unsigned epoch;
     unsigned* ctl;   // [0] ticket counter (zero at launch), [1] error word
@@ -78,31 +72,102 @@ struct fam_args {
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls before a hand-off gives up (seconds; a healthy wait is microseconds)
 
+// A lane's KPL consecutive floats move as 16-byte pieces, then an 8-byte one, then a 4-byte one (4-byte alignment is enough
+// for buffer instructions).  piece i = [piece_start(i), piece_start(i) + piece_width(i)).
 template <int KPL>
-struct lvals {
-    float v[KPL];
+struct pieces {
+    static constexpr int N4 = KPL / 4, N = N4 + ((KPL & 2) ? 1 : 0) + (KPL & 1);
+    static constexpr int start(int i) { return i < N4 ? 4 * i : (i == N4 && (KPL & 2)) ? 4 * N4 : KPL - 1; }
+    static constexpr int width(int i) { return i < N4 ? 4 : (i == N4 && (KPL & 2)) ? 2 : 1; }
 };
 
 template <int KPL>
-__device__ __forceinline__ lvals<KPL> load_vals(const float* p) {
-    lvals<KPL> r;
-    __builtin_memcpy(&r, p, sizeof(float) * KPL);
-    return r;
+__device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, float (&dst)[KPL]) {
+    using P = pieces<KPL>;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int k = P::start(i);
+        if (P::width(i) == 4) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 4 * k, 0, 0);
+            dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y);
+            dst[k + 2] = __uint_as_float(t.z); dst[k + 3] = __uint_as_float(t.w);
+        } else if (P::width(i) == 2) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 4 * k, 0, 0);
+            dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y);
+        } else {
+            dst[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * k, 0, 0));
+        }
+    }
 }
 
-// One path, one pixel.  Lp: path costs of the predecessor pixel (+inf on padded disparities), M their minimum.
-// Returns the minimum of the new costs over the pixel's lanes.
-template <int GL, int KPL>
-__device__ __forceinline__ float path_update(float (&Lp)[KPL], float M, bool restart, int nvalid, int l, const float (&cc)[KPL],
-                                             float P1, float P2, float (&Ln)[KPL]) {
-    if (restart) {  // predecessor outside the image: (Lp, M) = (0, 0) reproduces L = C' exactly
+// Stores v[0 .. nv) of every lane: nv = KPL on most lanes, tailn on the pixel's last lane when D is not a multiple of KPL, 0 on
+// lanes without disparities.  No branch on lane-varying data: a lane takes part in a piece when the piece lies inside its
+// nv, otherwise its offset is kOob and the buffer bounds check drops the write.  What the pieces leave of the tail lane (fewer
+// than 4 values, starting at `cov`; cov and rem are the same for every pixel) goes out as single dwords.
+template <int KPL>
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned base_off, int nv, bool is_tail, int cov, int rem,
+                                          const float (&v)[KPL]) {
+    using P = pieces<KPL>;
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) Lp[k] = k < nvalid ? 0.f : f_inf();
-        M = 0.f;
+    for (int i = 0; i < P::N; ++i) {
+        const int k = P::start(i);
+        const unsigned off = (nv >= k + P::width(i)) ? base_off + 4 * k : kOob;
+        if (P::width(i) == 4) {
+            u32x4 t;
+            t.x = __float_as_uint(v[k]); t.y = __float_as_uint(v[k + 1]); t.z = __float_as_uint(v[k + 2]); t.w = __float_as_uint(v[k + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
+        } else if (P::width(i) == 2) {
+            u32x2 t;
+            t.x = __float_as_uint(v[k]); t.y = __float_as_uint(v[k + 1]);
+            __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[k]), rs, off, 0, 0);
+        }
     }
-    float below = dpp_mov<0x138>(f_inf(), Lp[KPL - 1]);  // wave_shr:1  lane l <- lane l-1
-    float above = dpp_mov<0x130>(f_inf(), Lp[0]);        // wave_shl:1  lane l <- lane l+1
-    if (l == 0) below = f_inf();                         // the neighbouring lane belongs to another pixel
+    // the tail's leftover (rem < 4 values from `cov`, uniform): one 8-byte and one 4-byte store, masked by their offsets - no
+    // branch around a memory instruction, which would make the compiler's vmcnt bookkeeping wait for the youngest stores
+    float t0 = v[0], t1 = v[0], t2 = v[0];
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const int k = P::start(i);
+        if (cov == k) {
+            t0 = v[k];
+            t1 = v[k + 1 < KPL ? k + 1 : k];
+            t2 = v[k + 2 < KPL ? k + 2 : k];
+        }
+    }
+    const unsigned toff = is_tail ? base_off + 4u * (unsigned)cov : kOob;
+    u32x2 t01;
+    t01.x = __float_as_uint(t0); t01.y = __float_as_uint(t1);
+    __builtin_amdgcn_raw_buffer_store_b64(t01, rs, rem >= 2 ? toff : kOob, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rem == 3 ? t2 : t0), rs, (rem & 1) ? toff + (rem == 3 ? 8u : 0u) : kOob, 0, 0);
+}
+
+// minimum over the GL lanes of a pixel for three independent values at once (the chains interleave, which fills the wait
+// states a DPP operand needs behind the instruction that wrote it); every lane of the pixel receives the results
+template <int GL>
+__device__ __forceinline__ void group_min3(float& a, float& b, float& c) {
+    a = fmin2(a, dpp<0x121>(a)); b = fmin2(b, dpp<0x121>(b)); c = fmin2(c, dpp<0x121>(c));  // row_ror:1
+    a = fmin2(a, dpp<0x122>(a)); b = fmin2(b, dpp<0x122>(b)); c = fmin2(c, dpp<0x122>(c));  // row_ror:2
+    a = fmin2(a, dpp<0x124>(a)); b = fmin2(b, dpp<0x124>(b)); c = fmin2(c, dpp<0x124>(c));  // row_ror:4
+    a = fmin2(a, dpp<0x128>(a)); b = fmin2(b, dpp<0x128>(b)); c = fmin2(c, dpp<0x128>(c));  // row_ror:8: the 16-lane row is done
+    if (GL == 32) {  // the pixel's other row: lane ^ 16 (ds_swizzle bit mode, no LDS storage involved)
+        a = fmin2(a, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a), 0x401f)));
+        b = fmin2(b, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(b), 0x401f)));
+        c = fmin2(c, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(c), 0x401f)));
+    }
+}
+
+// One path, one pixel: new path costs from the predecessor's (Lp, M); padded disparities carry cc = +inf and come out +inf.
+// restart (predecessor outside the image): L = C'.  Returns the lane's minimum of the new costs.
+template <int GL, int KPL>
+__device__ __forceinline__ float path_costs(const float (&Lp)[KPL], float M, bool restart, int l, const float (&cc)[KPL], float P1,
+                                            float P2, float (&Ln)[KPL]) {
+    float below = dpp<0x138>(Lp[KPL - 1]);  // wave_shr:1  lane l <- lane l-1
+    float above = dpp<0x130>(Lp[0]);        // wave_shl:1  lane l <- lane l+1
+    if (l == 0) below = f_inf();            // the neighbouring lane belongs to another pixel (or does not exist)
     if (l == GL - 1) above = f_inf();
     const float mp2 = M + P2;
     float lmin = f_inf();
@@ -114,10 +179,10 @@ __device__ __forceinline__ float path_update(float (&Lp)[KPL], float M, bool res
         float t = fmin2(Lp[k], nb);
         t = fmin2(t, mp2);
         const float lv = cc[k] + (t - M);
-        Ln[k] = k < nvalid ? lv : f_inf();
+        Ln[k] = restart ? cc[k] : lv;
         lmin = fmin2(lmin, Ln[k]);
     }
-    return group_min<GL>(lmin);
+    return lmin;
 }
 
 template <int GL, int KPL, int NW, int PF>
@@ -128,61 +193,85 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     constexpr int ES = GL * KS + 4;        // LDS floats per (path, column): slices + the minimum
     constexpr int EDIR = (CW + 2) * ES;    // one path: column slots -2 .. CW-1
     constexpr int EBUF = 2 * EDIR;         // one row parity: vertical path, diagonal path
-    constexpr int NV = GL * KPL;           // values per handed-off vector
-    constexpr int NG = 3 * NV + 3;         // granules per (row, border): V[CW-1], A[CW-1], A[CW-2] + their minima
+    constexpr int K2 = (KPL + 1) / 2;      // 16-byte hand-off blocks per lane and vector: two {value, tag} halves each
+    constexpr int NVB = GL * K2;           // blocks per handed-off vector
+    constexpr int NG = 3 * NVB + 2;        // blocks per (row, border): V[CW-1], A[CW-1], A[CW-2], then their three minima
     constexpr int NQ = (NG + 63) / 64;
     constexpr int NGP = NQ * 64;
+    constexpr int KH = NQ > 10 ? 2 : 4;   // hand-off look-ahead in rows (register ring of the hand-off wave)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     volatile int* ctl = (volatile int*)(lds + 2 * EBUF);  // [0] window index, [1], [2] abort flag by row parity
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform values live in scalar registers: buffer
+    if (threadIdx.x == 0) {                                              // descriptors built from them need no waterfall loop
         ctl[0] = (int)atomicAdd(a.ctl, 1u);
         ctl[1] = 0;
         ctl[2] = 0;
     }
     __syncthreads();
-    const int s = ctl[0];
+    const int s = __builtin_amdgcn_readfirstlane(ctl[0]);
     const int H = a.H, W = a.W, D = a.D;
     const int base = s * CW;
     const int r_lo = base - W + 1 > 0 ? base - W + 1 : 0;
     const int r_hi = base + CW - 1 < H - 1 ? base + CW - 1 : H - 1;
     if (r_lo > r_hi) return;
     gu32* errw = (gu32*)(a.ctl + 1);
+    constexpr unsigned kBlockBytes = (unsigned)NGP * 16u;
 
     if (wave == NW) {
         // ---- hand-off wave: brings the left neighbour's columns CW-2, CW-1 of row t into column slots -2, -1 ----
         int ldsoff[NQ];
-        bool real[NQ];
+        int nreal[NQ];  // how many of the block's two values exist (0: padding block)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int idx = q * 64 + lane;
-            int vec, off;
-            if (idx < 3 * NV) {
-                vec = idx / NV;
-                const int rem = idx - vec * NV;
-                off = (rem / KPL) * KS + rem % KPL;
+            int vec, off, n;
+            if (idx < 3 * NVB) {
+                vec = idx / NVB;
+                const int rem = idx - vec * NVB;  // block rem = k2 * GL + l: the lanes of one store are contiguous
+                const int k2 = rem / GL;
+                off = (rem - k2 * GL) * KS + 2 * k2;
+                n = (2 * k2 + 1 < KPL) ? 2 : 1;
+            } else if (idx == 3 * NVB) {  // minima of vectors 0 and 1: both live in column slot -1, paths V and A
+                vec = 3; off = GL * KS; n = 2;
+            } else if (idx == 3 * NVB + 1) {
+                vec = 2; off = GL * KS; n = 1;
             } else {
-                vec = idx - 3 * NV;
-                off = GL * KS;
+                vec = 0; off = 0; n = 0;
             }
             // vec 0: vertical path of column CW-1 -> slot -1;  1: diagonal of CW-1 -> slot -1;  2: diagonal of CW-2 -> slot -2
-            ldsoff[q] = (vec == 0 ? 0 : EDIR) + (vec == 2 ? 0 : ES) + off;
-            // only the vectors of paths that run are ever published
-            real[q] = idx < NG && (a.dmask & (vec == 0 ? 1 : 2)) != 0;
+            ldsoff[q] = (vec == 0 || vec == 3 ? 0 : EDIR) + (vec == 2 ? 0 : ES) + off;
+            nreal[q] = vec == 3 ? 3 : n;  // 3: the two values go to different paths (V minimum, A minimum of slot -1)
         }
-        auto fetch_row = [&](int t) -> bool {
-            const int cb = base - (t + 1);  // image column of the neighbour's last pixel on row t (0 <= cb < W here)
-            const gu64* g = (const gu64*)(a.halo + ((size_t)t * a.NB + cb / CW) * NGP) + lane;
-            unsigned long long x[NQ];
+        // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
+        // Their loads are issued KH barriers ahead into a register ring, so that in the steady state - the neighbour a few rows
+        // ahead - the round trip of a row's blocks is hidden behind KH steps of the compute waves; a row that had not been
+        // published yet when its load was issued is re-read (bounded spin) when it is due, which also pushes this window
+        // further behind its neighbour until the look-ahead always hits.
+        const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
+        const int tB = (r_hi < base ? r_hi : base) - 1;
+        u32x4 x[KH][NQ];
+        // descriptor of the neighbour's block for row t; an empty one (every access out of range: loads give 0, no traffic) when
+        // the row is not needed, so that no memory instruction sits under a branch
+        auto in_rsrc = [&](int t) {
+            const bool need = t >= tA && t <= tB;
+            const int cb = base - (t + 1);  // image column of the neighbour's last pixel on row t (0 <= cb < W when needed)
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0,
+                                                     need ? kBlockBytes : 0u, kRsrcWord3);
+        };
+        auto issue = [&](int t, u32x4 (&slot)[NQ]) {
+            const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
+        };
+        auto consume = [&](int t, u32x4 (&slot)[NQ]) -> bool {
+            if (t < tA || t > tB) return true;
+            const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    x[q] = __hip_atomic_load(g + q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok &= !real[q] || (unsigned)(x[q] >> 32) == a.epoch;
-                }
+                for (int q = 0; q < NQ; ++q) ok &= nreal[q] == 0 || (slot[q].y == a.epoch && slot[q].w == a.epoch);
                 if (__all(ok)) break;
                 if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
                 if (spins > kSpinLimit) {
@@ -190,22 +279,72 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                     return false;
                 }
                 __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
             }
             float* Eb = lds + (t & 1) * EBUF;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (real[q]) Eb[ldsoff[q]] = __uint_as_float((unsigned)x[q]);
+            for (int q = 0; q < NQ; ++q) {
+                if (nreal[q] == 2) {
+                    float2 v;
+                    v.x = __uint_as_float(slot[q].x);
+                    v.y = __uint_as_float(slot[q].z);
+                    *(float2*)(Eb + ldsoff[q]) = v;
+                } else if (nreal[q] == 1) {
+                    Eb[ldsoff[q]] = __uint_as_float(slot[q].x);
+                } else if (nreal[q] == 3) {
+                    Eb[ldsoff[q]] = __uint_as_float(slot[q].x);
+                    Eb[ldsoff[q] + EDIR] = __uint_as_float(slot[q].z);
+                }
+            }
             return true;
         };
-        // row r of this window needs the neighbour's row r-1 iff 1 <= r <= base (then 0 <= base - r < W)
-        if (r_lo >= 1 && r_lo <= base && !fetch_row(r_lo - 1)) ctl[1 + ((r_lo - 1) & 1)] = 1;
-        __syncthreads();
-        if (ctl[1 + ((r_lo - 1) & 1)]) return;
-        for (int r = r_lo; r <= r_hi; ++r) {
-            if (r + 1 <= r_hi && r + 1 <= base && !fetch_row(r)) ctl[1 + (r & 1)] = 1;
-            __syncthreads();
-            if (ctl[1 + (r & 1)]) return;
+        // Publishes row t of this window for window s+1: the compute waves left the path costs of local columns CW-2, CW-1 in LDS
+        // (column slots CW, CW+1 of row parity t & 1 - the same layout, CW slots further, as the incoming columns), complete
+        // once barrier t is passed and untouched until barrier t+1.  Window s+1 computes row t+1 at image column cb = base+CW-1-t:
+        // it exists and needs the row iff cb < W and t < H-1 (else an empty descriptor drops the stores).
+        auto publish = [&](int t) {
+            const int cb = base + CW - 1 - t;
+            const bool need = t >= r_lo && cb < W && t < H - 1;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
+            const float* Eb = lds + (t & 1) * EBUF + CW * ES;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                u32x4 b;
+                b.y = a.epoch;
+                b.w = a.epoch;
+                if (nreal[q] == 3) {
+                    b.x = __float_as_uint(Eb[ldsoff[q]]);
+                    b.z = __float_as_uint(Eb[ldsoff[q] + EDIR]);
+                } else if (nreal[q] == 2) {
+                    const float2 v = *(const float2*)(Eb + ldsoff[q]);
+                    b.x = __float_as_uint(v.x);
+                    b.z = __float_as_uint(v.y);
+                } else {
+                    b.x = __float_as_uint(Eb[ldsoff[q]]);
+                    b.z = b.x;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(b, rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
+            }
+        };
+        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi; ring slot of row t = (t - (r_lo-1)) % KH
+#pragma unroll
+        for (int u = 0; u < KH; ++u) issue(r_lo - 1 + u, x[u]);
+        for (int t = r_lo - 1; t <= r_hi; t += KH) {
+#pragma unroll
+            for (int u = 0; u < KH; ++u) {
+                const int tt = t + u;
+                if (tt <= r_hi) {
+                    if (!consume(tt, x[u])) ctl[1 + (tt & 1)] = 1;
+                    issue(tt + KH, x[u]);
+                    publish(tt - 1);
+                    __syncthreads();
+                    if (__builtin_amdgcn_readfirstlane(ctl[1 + (tt & 1)])) return;
+                }
+            }
         }
+        publish(r_hi);
         return;
     }
 
@@ -214,24 +353,39 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     const int l = lane - g * GL;
     const int j = wave * NPW + g;
     const int d0 = l * KPL;
-    const bool lane_active = d0 < D;
-    const int nvalid = lane_active ? (D - d0 < KPL ? D - d0 : KPL) : 0;
-    const int dload = lane_active ? d0 : 0;  // lanes without a disparity read the pixel's d = 0 (loads stay unconditional)
-    const bool full = nvalid == KPL;
+    const int nv = d0 >= D ? 0 : (D - d0 < KPL ? D - d0 : KPL);  // disparities this lane owns
+    const bool is_tail = nv > 0 && nv < KPL;
+    const int tailn = D % KPL;  // uniform: what the pixel's last lane owns (0: every lane is full)
+    using P = pieces<KPL>;
+    int cov = 0;                // uniform: what the wide pieces cover of the tail lane
+#pragma unroll
+    for (int i = 0; i < P::N; ++i)
+        if (P::start(i) + P::width(i) <= tailn) cov = P::start(i) + P::width(i);
+    const int rem = tailn - cov;
+    const unsigned lane_off = (unsigned)(d0 < D ? d0 : 0) * 4u;  // lanes without a disparity read the pixel's d = 0
+    const unsigned row_bytes = (unsigned)W * (unsigned)D * 4u;
+    const unsigned pix_bytes = (unsigned)D * 4u;
+    float padv[KPL];  // -inf on owned disparities, +inf on padding: cc = max(cc, padv) leaves the former alone
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) padv[k] = k < nv ? -f_inf() : f_inf();
 
-    // prefetch cursor
-    int pr = r_lo;
-    auto elem_off = [&](int r, int dd) -> size_t {
-        int c = base - r + j;
-        c = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+    auto row_rsrc = [&](const float* vol, int r) {
         const int rimg = a.flip ? H - 1 - r : r;
-        return ((size_t)rimg * W + c) * (size_t)D + dd;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (size_t)rimg * W * D), 0, row_bytes, kRsrcWord3);
     };
-    lvals<KPL> cbuf[PF], sbuf[PF];
-    auto prefetch = [&](lvals<KPL>& cslot, lvals<KPL>& sslot) {
-        const size_t off = elem_off(pr, dload);
-        cslot = load_vals<KPL>(a.C + off);
-        if (a.has_sin) sslot = load_vals<KPL>(a.S + off);
+    // byte offset of this lane's pixel inside row r: outside the image -> kOob (loads return 0, stores are dropped)
+    auto pix_off = [&](int r) -> unsigned {
+        const int c = base - r + j;
+        return (c >= 0 && c < W) ? (unsigned)c * pix_bytes : kOob;
+    };
+
+    // loads of C and S run PF rows ahead in a register ring
+    int pr = r_lo;
+    float cbuf[PF][KPL], sbuf[PF][KPL];
+    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
+        const unsigned off = pix_off(pr) + lane_off;
+        buf_load<KPL>(row_rsrc(a.C, pr), off, cslot);
+        buf_load<KPL>(row_rsrc(a.S, pr), a.has_sin ? off : kOob, sslot);  // first pass of a sum: out of range = zeros, no traffic
         if (pr < r_hi) ++pr;
     };
 #pragma unroll
@@ -242,145 +396,92 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 #pragma unroll
     for (int k = 0; k < KPL; ++k) LB[k] = f_inf();
 
-    // hand-off target: this window's columns CW-1 (vectors 0, 1) and CW-2 (vector 2) go to window s+1
-    const bool prod_hi = (j == CW - 1), prod_lo = (j == CW - 2);
-
     __syncthreads();
-    if (ctl[1 + ((r_lo - 1) & 1)]) return;
+    if (__builtin_amdgcn_readfirstlane(ctl[1 + ((r_lo - 1) & 1)])) return;
 
-    auto step = [&](int r, lvals<KPL>& cslot, lvals<KPL>& sslot) {
+    auto step = [&](int r, float (&cslot)[KPL], float (&sslot)[KPL]) {
         const int c = base - r + j;
-        const bool pix = c >= 0 && c < W;
         const float* Ep = lds + ((r - 1) & 1) * EBUF;
         float* En = lds + (r & 1) * EBUF;
+        // predecessors: vertical path (r-1, c) = local column j-1, diagonal (r-1, c-1) = local column j-2 (LDS, previous row
+        // parity), diagonal (r-1, c+1) = this lane group (registers)
+        float LV[KPL], LA[KPL];
+        const float* srcV = Ep + (j + 1) * ES + l * KS;
+        const float* srcA = Ep + EDIR + j * ES + l * KS;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const float4 t = *(const float4*)(srcV + 4 * q);
+            const float4 u = *(const float4*)(srcA + 4 * q);
+            if (4 * q + 0 < KPL) { LV[4 * q + 0] = t.x; LA[4 * q + 0] = u.x; }
+            if (4 * q + 1 < KPL) { LV[4 * q + 1] = t.y; LA[4 * q + 1] = u.y; }
+            if (4 * q + 2 < KPL) { LV[4 * q + 2] = t.z; LA[4 * q + 2] = u.z; }
+            if (4 * q + 3 < KPL) { LV[4 * q + 3] = t.w; LA[4 * q + 3] = u.w; }
+        }
+        const float MV = Ep[(j + 1) * ES + GL * KS];
+        const float MA = Ep[EDIR + j * ES + GL * KS];
+        // costs: NaN -> invalid_cost, sign for "max" measures, +inf on padded disparities
         float cc[KPL];
+        unsigned nanmask = 0;
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
-            const float cr = cslot.v[k];
-            cc[k] = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
+            const float cr = cslot[k];
+            const bool isn = is_nan_bits(cr);
+            nanmask |= isn ? (1u << k) : 0u;
+            const float sg = __uint_as_float(__float_as_uint(cr) ^ (a.is_max ? 0x80000000u : 0u));
+            cc[k] = __builtin_fmaxf(isn ? a.invalid_cost : sg, padv[k]);
         }
+        const bool r0 = (r == 0);
+        float nV[KPL], nA[KPL], nB[KPL];
+        float mV = path_costs<GL, KPL>(LV, MV, r0, l, cc, a.P1, a.P2, nV);
+        float mA = path_costs<GL, KPL>(LA, MA, r0 || c == 0, l, cc, a.P1, a.P2, nA);
+        float mB = path_costs<GL, KPL>(LB, MB, r0 || c == W - 1, l, cc, a.P1, a.P2, nB);
+        group_min3<GL>(mV, mA, mB);
+        MB = mB;
+        // next row's predecessors
+        float* dstV = En + (j + 2) * ES + l * KS;
+        float* dstA = En + EDIR + (j + 2) * ES + l * KS;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            float4 t, u;
+            t.x = 4 * q + 0 < KPL ? nV[4 * q + 0] : 0.f; u.x = 4 * q + 0 < KPL ? nA[4 * q + 0] : 0.f;
+            t.y = 4 * q + 1 < KPL ? nV[4 * q + 1] : 0.f; u.y = 4 * q + 1 < KPL ? nA[4 * q + 1] : 0.f;
+            t.z = 4 * q + 2 < KPL ? nV[4 * q + 2] : 0.f; u.z = 4 * q + 2 < KPL ? nA[4 * q + 2] : 0.f;
+            t.w = 4 * q + 3 < KPL ? nV[4 * q + 3] : 0.f; u.w = 4 * q + 3 < KPL ? nA[4 * q + 3] : 0.f;
+            *(float4*)(dstV + 4 * q) = t;
+            *(float4*)(dstA + 4 * q) = u;
+        }
+        if (l == 0) {
+            En[(j + 2) * ES + GL * KS] = mV;
+            En[EDIR + (j + 2) * ES + GL * KS] = mA;
+        }
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) LB[k] = nB[k];
+        // S
         float acc[KPL];
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) acc[k] = a.has_sin ? sslot.v[k] : 0.f;
-        const bool r0 = (r == 0);
-        float Ln[KPL];
-        // vertical path: predecessor (r-1, c) = local column j-1 of the previous row
+        for (int k = 0; k < KPL; ++k) acc[k] = sslot[k];
         if (a.dmask & 1) {
-            float Lp[KPL];
-            const float* src = Ep + (j + 1) * ES;
 #pragma unroll
-            for (int q = 0; q < KS / 4; ++q) {
-                const float4 t = *(const float4*)(src + l * KS + 4 * q);
-                if (4 * q + 0 < KPL) Lp[4 * q + 0] = t.x;
-                if (4 * q + 1 < KPL) Lp[4 * q + 1] = t.y;
-                if (4 * q + 2 < KPL) Lp[4 * q + 2] = t.z;
-                if (4 * q + 3 < KPL) Lp[4 * q + 3] = t.w;
-            }
-            const float M = src[GL * KS];
-            const float mn = path_update<GL, KPL>(Lp, M, r0, nvalid, l, cc, a.P1, a.P2, Ln);
-            float* dst = En + (j + 2) * ES;
-#pragma unroll
-            for (int q = 0; q < KS / 4; ++q) {
-                float4 t;
-                t.x = 4 * q + 0 < KPL ? Ln[4 * q + 0] : 0.f;
-                t.y = 4 * q + 1 < KPL ? Ln[4 * q + 1] : 0.f;
-                t.z = 4 * q + 2 < KPL ? Ln[4 * q + 2] : 0.f;
-                t.w = 4 * q + 3 < KPL ? Ln[4 * q + 3] : 0.f;
-                *(float4*)(dst + l * KS + 4 * q) = t;
-            }
-            if (l == 0) dst[GL * KS] = mn;
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + Ln[k];
-            if (prod_hi) {
-                const int cb = base + CW - 1 - r;
-                if (cb < W && r < H - 1) {
-                    gu64* gp = (gu64*)(a.halo + ((size_t)r * a.NB + cb / CW) * NGP);
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        __hip_atomic_store(gp + l * KPL + k, ((unsigned long long)a.epoch << 32) | __float_as_uint(Ln[k]),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (l == 0)
-                        __hip_atomic_store(gp + 3 * NV, ((unsigned long long)a.epoch << 32) | __float_as_uint(mn), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + nV[k];
         }
-        // diagonal path with predecessor (r-1, c-1) = local column j-2 of the previous row
         if (a.dmask & 2) {
-            float Lp[KPL];
-            const float* src = Ep + EDIR + j * ES;
 #pragma unroll
-            for (int q = 0; q < KS / 4; ++q) {
-                const float4 t = *(const float4*)(src + l * KS + 4 * q);
-                if (4 * q + 0 < KPL) Lp[4 * q + 0] = t.x;
-                if (4 * q + 1 < KPL) Lp[4 * q + 1] = t.y;
-                if (4 * q + 2 < KPL) Lp[4 * q + 2] = t.z;
-                if (4 * q + 3 < KPL) Lp[4 * q + 3] = t.w;
-            }
-            const float M = src[GL * KS];
-            const float mn = path_update<GL, KPL>(Lp, M, r0 || c == 0, nvalid, l, cc, a.P1, a.P2, Ln);
-            float* dst = En + EDIR + (j + 2) * ES;
-#pragma unroll
-            for (int q = 0; q < KS / 4; ++q) {
-                float4 t;
-                t.x = 4 * q + 0 < KPL ? Ln[4 * q + 0] : 0.f;
-                t.y = 4 * q + 1 < KPL ? Ln[4 * q + 1] : 0.f;
-                t.z = 4 * q + 2 < KPL ? Ln[4 * q + 2] : 0.f;
-                t.w = 4 * q + 3 < KPL ? Ln[4 * q + 3] : 0.f;
-                *(float4*)(dst + l * KS + 4 * q) = t;
-            }
-            if (l == 0) dst[GL * KS] = mn;
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + Ln[k];
-            if (prod_hi || prod_lo) {
-                const int cb = base + CW - 1 - r;
-                if (cb < W && r < H - 1) {
-                    const int vec = prod_hi ? 1 : 2;
-                    gu64* gp = (gu64*)(a.halo + ((size_t)r * a.NB + cb / CW) * NGP);
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        __hip_atomic_store(gp + vec * NV + l * KPL + k, ((unsigned long long)a.epoch << 32) | __float_as_uint(Ln[k]),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (l == 0)
-                        __hip_atomic_store(gp + 3 * NV + vec, ((unsigned long long)a.epoch << 32) | __float_as_uint(mn),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + nA[k];
         }
-        // diagonal path with predecessor (r-1, c+1): same local column, stays in registers
         if (a.dmask & 4) {
-            MB = path_update<GL, KPL>(LB, MB, r0 || c == W - 1, nvalid, l, cc, a.P1, a.P2, Ln);
 #pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                LB[k] = Ln[k];
-                acc[k] = acc[k] + Ln[k];
-            }
+            for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + nB[k];
         }
         if (a.epilogue) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
                 float sv = acc[k];
                 if (a.overcounting) sv = sv - 7.0f * cc[k];
-                if (a.is_max) sv = -sv;
-                const float cr = cslot.v[k];
-                if (cr != cr) sv = f_nan();
-                acc[k] = sv;
+                if (a.is_max) sv = __uint_as_float(__float_as_uint(sv) ^ 0x80000000u);
+                acc[k] = (nanmask >> k & 1) ? __uint_as_float(0x7fc00000u) : sv;
             }
         }
-        if (pix) {
-            const int rimg = a.flip ? H - 1 - r : r;
-            float* dst = a.S + ((size_t)rimg * W + c) * (size_t)D + d0;
-            if (full) {
-                lvals<KPL> out;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) out.v[k] = acc[k];
-                __builtin_memcpy(dst, &out, sizeof(float) * KPL);
-            } else {
-#pragma unroll
-                for (int k = 0; k < KPL; ++k)
-                    if (k < nvalid) dst[k] = acc[k];
-            }
-        }
+        buf_store<KPL>(row_rsrc(a.S, r), pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
         // refill this ring slot with row r + PF (issued after the slot's last use: same registers, no copy)
         prefetch(cslot, sslot);
         __syncthreads();
@@ -393,7 +494,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         for (int u = 0; u < PF; ++u) {
             if (!dead) {
                 step(r + u, cbuf[u], sbuf[u]);
-                dead = ctl[1 + ((r + u) & 1)] != 0;
+                dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
             }
         }
     }
@@ -402,7 +503,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     for (int u = 0; u < PF - 1; ++u) {
         if (r + u <= r_hi && !dead) {
             step(r + u, cbuf[u], sbuf[u]);
-            dead = ctl[1 + ((r + u) & 1)] != 0;
+            dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
         }
     }
 }
@@ -411,24 +512,33 @@ struct fam_shape {
     int gl, kpl, nw;
 };
 
-// lane maps that are instantiated: GL 16 up to 144 disparities, GL 32 up to 512
+// Lane maps that are instantiated: 16 lanes per pixel up to 144 disparities, 32 up to 512.  The window width CW = nw * 64 / gl sets
+// both the hand-off volume per cell (3 vectors per CW columns) and the number of windows in flight (W / CW): every CU wants a
+// window, so narrow images take the 32-lane map (twice the waves per column) and 4 compute waves per workgroup.
 bool pick_shape(int D, int W, fam_shape* out) {
-    static const int k16[] = {3, 5, 7, 9}, k32[] = {6, 9, 12, 16};
+    static const int k16[] = {3, 5, 7, 9}, k32[] = {3, 5, 6, 9, 12, 16};
     fam_shape f{0, 0, 0};
-    if (D <= 144) {
+    if (D <= 144 && W >= 16 * 224) {
         f.gl = 16;
         for (int k : k16)
             if (16 * k >= D) { f.kpl = k; break; }
+        f.nw = W >= 32 * 224 ? 8 : 4;
     } else if (D <= 512) {
         f.gl = 32;
         for (int k : k32)
             if (32 * k >= D) { f.kpl = k; break; }
+        f.nw = W >= 16 * 224 ? 8 : 4;
     }
     if (!f.kpl) return false;
-    // window width CW = nw * 64 / gl: the widest one that still gives every CU a window (the hand-off volume per cell
-    // falls with CW, the number of busy CUs with W / CW)
-    const int npw = 64 / f.gl;
-    f.nw = (W / (8 * npw) >= 224) ? 8 : 4;
+    if (const char* e = getenv("PMX_SGM_FAM_SHAPE")) {  // test hook: "gl,kpl,nw" forces an instantiated lane map that fits D
+        int gl = 0, kpl = 0, nw = 0;
+        if (sscanf(e, "%d,%d,%d", &gl, &kpl, &nw) == 3 && gl * kpl >= D && (nw == 4 || nw == 8)) {
+            bool known = false;
+            if (gl == 16) for (int k : k16) known |= k == kpl;
+            if (gl == 32) for (int k : k32) known |= k == kpl;
+            if (known) f = fam_shape{gl, kpl, nw};
+        }
+    }
     if (out) *out = f;
     return true;
 }
@@ -453,6 +563,8 @@ int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg
     PMX_FAM(16, 5)
     PMX_FAM(16, 7)
     PMX_FAM(16, 9)
+    PMX_FAM(32, 3)
+    PMX_FAM(32, 5)
     PMX_FAM(32, 6)
     PMX_FAM(32, 9)
     PMX_FAM(32, 12)
@@ -472,8 +584,8 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
     PMX_CHECK(pick_shape(cv->D, cv->W, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (family schedule): D = %d not supported", cv->D);
     const int npw = 64 / f.gl, CW = f.nw * npw;
     const int NB = (cv->W + CW - 1) / CW;
-    const int NG = 3 * f.gl * f.kpl + 3, NGP = (NG + 63) / 64 * 64;
-    const size_t halo_bytes = (size_t)cv->H * NB * NGP * sizeof(unsigned long long);
+    const int NG = 3 * f.gl * ((f.kpl + 1) / 2) + 2, NGP = (NG + 63) / 64 * 64;  // 16-byte blocks per (row, border)
+    const size_t halo_bytes = (size_t)cv->H * NB * NGP * 16;
     if (ctx->fam_halo_bytes < halo_bytes) {
         if (ctx->fam_halo) PMX_HIP(hipFree(ctx->fam_halo));
         ctx->fam_halo = nullptr;
@@ -508,7 +620,7 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
         a.has_sin = (mask & ((1 << (2 + 3 * fam)) - 1)) != 0;
         a.epilogue = (mask >> (5 + 3 * fam)) == 0;
         a.dmask = bits;
-        a.halo = ctx->fam_halo;
+        a.halo = (u32x4*)ctx->fam_halo;
         a.NB = NB;
         a.epoch = ++ctx->fam_epoch;
         a.ctl = ctx->fam_ctl;

@@ -40,27 +40,36 @@ def run(eng, cvh, P1, P2, is_max, inv, over, mask=0xFF):
     return out
 
 
+# (H, W, D, lane map "lanes per pixel, disparities per lane, compute waves per workgroup" forced through PMX_SGM_FAM_SHAPE; None =
+# the library's own choice, which for images this narrow is always a 32-lane map with 4 waves)
 SHAPES = [
-    (40, 70, 30),    # 16 lanes x 3
-    (33, 100, 61),   # cones' D: 16 x 5
-    (70, 41, 100),   # taller than wide: most windows start below the first row; 16 x 7
-    (25, 130, 129),  # C3 / C5 D: 16 x 9, last lane owns 3 disparities
-    (30, 64, 144),   # 16 x 9, no tail
-    (20, 90, 150),   # 32 lanes x 6
-    (37, 50, 257),   # C4 D: 32 x 9
-    (12, 45, 300),   # 32 x 12
-    (9, 33, 512),    # 32 x 16, the largest D
-    (2, 17, 20),     # two rows
-    (50, 3, 40),     # narrower than any window
+    (40, 70, 30, "16,3,4"),
+    (33, 100, 61, "16,5,8"),    # cones' D
+    (70, 41, 100, "16,7,4"),    # taller than wide: most windows start below the first row
+    (25, 130, 129, "16,9,4"),   # C3 / C5 D: the last lane owns 3 disparities
+    (25, 130, 129, "16,9,8"),   # C5's map
+    (25, 130, 129, None),       # C3's map: 32 x 5
+    (30, 64, 144, "16,9,4"),    # no tail
+    (28, 60, 90, "32,3,8"),
+    (20, 90, 150, "32,6,4"),
+    (37, 50, 257, None),        # C4 D: 32 x 9
+    (37, 50, 257, "32,9,8"),    # C4's map
+    (12, 45, 300, "32,12,8"),
+    (9, 33, 512, None),         # 32 x 16, the largest D
+    (9, 33, 512, "32,16,8"),
+    (2, 17, 20, None),          # two rows
+    (50, 3, 40, "16,3,8"),      # narrower than any window
 ]
 
 
-@pytest.mark.parametrize("H,W,D", SHAPES)
-def test_family_schedule_equals_oracle(eng, oracle, monkeypatch, H, W, D):
+@pytest.mark.parametrize("H,W,D,lanes", SHAPES)
+def test_family_schedule_equals_oracle(eng, oracle, monkeypatch, H, W, D, lanes):
     rng = np.random.default_rng(H * 1000 + W)
     cvh = volume(rng, H, W, D)
     exp = oracle.sgm(cvh, 1.5, 7.25, False, 45.0, False)
     monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    if lanes:
+        monkeypatch.setenv("PMX_SGM_FAM_SHAPE", lanes)
     np.testing.assert_array_equal(run(eng, cvh, 1.5, 7.25, False, 45.0, False), exp)
 
 
@@ -94,6 +103,8 @@ def test_family_schedule_many_windows(eng, oracle, monkeypatch):
     cvh = rng.integers(0, 30, (H, W, D)).astype(np.float32)
     exp = oracle.sgm(cvh, 8.0, 32.0, False, 45.0, False)
     monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    np.testing.assert_array_equal(run(eng, cvh, 8.0, 32.0, False, 45.0, False), exp)  # the library's choice: 16 x 3, 8 waves
+    monkeypatch.setenv("PMX_SGM_FAM_SHAPE", "32,3,4")                                  # 8-column windows: 900 of them
     np.testing.assert_array_equal(run(eng, cvh, 8.0, 32.0, False, 45.0, False), exp)
 
 
