@@ -40,6 +40,9 @@ class Ambiguity(_cvc.AbstractCostVolumeConfidence):
         for key in ("eta_max", "eta_step"):
             if not isinstance(cfg[key], float) or not 0 < cfg[key] < 1:
                 raise ConfigError(f"{key} must be a float in (0, 1)")
+        # the device kernels keep the eta table in LDS (1024 entries); refuse at configuration time, not mid-pipeline
+        if len(np.arange(0.0, cfg["eta_max"], cfg["eta_step"])) > 1024:
+            raise ConfigError("pandora_amd supports at most 1024 etas: raise eta_step or lower eta_max")
         if not isinstance(cfg["normalization"], bool) or not isinstance(cfg["indicator"], str):
             raise ConfigError("normalization must be a bool and indicator a str")
         for key in cfg:

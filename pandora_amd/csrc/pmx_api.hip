@@ -998,6 +998,8 @@ extern "C" int pmx_ambiguity(pmx_ctx* ctx, pmx_cv* cv, const float* etas, int nb
     if (rc) return rc;
     PMX_CHECK(etas && ambiguity_out && !grid_min == !grid_max, PMX_ERR_ARG, "pmx_ambiguity: null argument (grids: both or neither)");
     PMX_CHECK(nbr_etas > 0 && nbr_etas <= 1024, PMX_ERR_ARG, "pmx_ambiguity: nbr_etas must be in 1..1024, got %d", nbr_etas);
+    for (int i = 1; i < nbr_etas; ++i)  // the kernel counts admitted etas with a binary search: exact only for sorted thresholds
+        PMX_CHECK(etas[i] >= etas[i - 1], PMX_ERR_ARG, "pmx_ambiguity: etas must be ascending (etas[%d] = %g < %g)", i, etas[i], etas[i - 1]);
     rc = pmx_cv_materialize(ctx, cv);  // the measure is defined on the float32 costs
     if (rc) return rc;
     const size_t n = (size_t)cv->H * cv->W;

@@ -308,6 +308,8 @@ class Engine:
     def _grids(self, what, grid_min, grid_max):
         if grid_min is None and grid_max is None:  # every pixel searches the volume's whole range
             return None, None
+        if (grid_min is None) != (grid_max is None):
+            raise ValueError(f"{what}: give both disparity grids or neither")
         gmin = np.ascontiguousarray(grid_min, np.int64)
         gmax = np.ascontiguousarray(grid_max, np.int64)
         if gmin.shape != (self.H, self.W) or gmax.shape != (self.H, self.W):

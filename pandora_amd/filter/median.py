@@ -31,6 +31,8 @@ class MedianFilter(_filter.AbstractFilter):
         fs = cfg["filter_size"]
         if isinstance(fs, bool) or not isinstance(fs, int) or fs < 1 or fs % 2 == 0:
             raise ConfigError("filter_size must be an odd integer >= 1")
+        if fs > 15:  # pmx_median_filter_disparity sorts the window in registers
+            raise ConfigError("pandora_amd supports median filter_size up to 15")
         for key in cfg:
             if key not in ("filter_method", "filter_size"):
                 raise ConfigError(f"unknown filter key {key!r}")

@@ -44,6 +44,8 @@ class MedianForIntervalsFilter(_filter.AbstractFilter):
 
         if not is_int(cfg["filter_size"]) or cfg["filter_size"] < 1 or cfg["filter_size"] % 2 == 0:
             raise ConfigError("filter_size must be an odd integer >= 1")
+        if cfg["filter_size"] > 15:  # pmx_median_filter_disparity sorts the window in registers
+            raise ConfigError("pandora_amd supports median filter_size up to 15")
         if not isinstance(cfg["interval_indicator"], str) or not isinstance(cfg["ambiguity_indicator"], str):
             raise ConfigError("interval_indicator and ambiguity_indicator must be str")
         if not isinstance(cfg["regularization"], bool):

@@ -2,6 +2,7 @@
 stereo pair is resident so that successive plugin calls (compute_cost_volume, cv_masked,
 cost_volume_aggregation, ...) do not re-upload the images."""
 import os
+import zlib
 
 import numpy as np
 
@@ -23,12 +24,11 @@ def get_engine(device=None):
 
 
 def _sample(a):
-    """A cheap content fingerprint (about 64K elements spread over the array) so that an array edited in place between
-    two runs is uploaded again; identity alone decides for everything the sample does not see."""
-    a = np.asarray(a)
-    flat = a.reshape(-1) if a.flags.c_contiguous else np.ascontiguousarray(a).reshape(-1)
-    step = max(1, flat.size // 65536)
-    return hash(flat[::step].tobytes())
+    """Content fingerprint of the WHOLE buffer (CRC-32, about a millisecond per 4 Mpx image): an array edited in place between
+    two runs - any pixel of it - is uploaded again.  (A strided sample misses edits: with power-of-two widths a stride
+    divides the width and only a comb of columns is ever looked at.)"""
+    a = np.ascontiguousarray(a)
+    return zlib.crc32(memoryview(a).cast("B"))
 
 
 def _key(img_left, img_right, subpix, band):

@@ -2,6 +2,7 @@
 reference's multiband images, two-band disparity grids, classification layers).  Classic TIFF (not BigTIFF), strips,
 uncompressed or deflate, 8/16/32/64-bit unsigned / signed / float samples, chunky or planar layout; band descriptions from
 GDAL's metadata tag.  Host-side I/O glue (the reference reads through rasterio, which is not in this image)."""
+from xml.sax.saxutils import escape
 import re
 import struct
 import zlib
@@ -85,7 +86,7 @@ def write_tiff(path, data, band_names=None):
     B, H, W = a.shape
     meta = None
     if band_names is not None:
-        meta = ("<GDALMetadata>\n" + "".join(f'  <Item name="DESCRIPTION" sample="{k}" role="description">{n}</Item>\n'
+        meta = ("<GDALMetadata>\n" + "".join(f'  <Item name="DESCRIPTION" sample="{k}" role="description">{escape(str(n))}</Item>\n'
                                              for k, n in enumerate(band_names)) + "</GDALMetadata>\n").encode("latin-1") + b"\0"
     plane = H * W * a.dtype.itemsize
     entries = []  # (tag, type, count, values or bytes)

@@ -551,3 +551,32 @@ def test_margins_like_the_reference():
                                "disparity": {"disparity_method": "wta"},
                                "filter": {"filter_method": "bilateral", "sigma_space": 6.0}}}, left, right)
     assert m.margins.global_margins == Margins(42, 42, 42, 42) and m.margins.get("filter") == Margins(19, 19, 19, 19)
+
+
+def test_resident_pair_fingerprint_sees_every_pixel():
+    """runtime._sample covers the whole buffer: an in-place edit of ONE pixel, anywhere (e.g. a column a strided sample with a
+    power-of-two width never visits), changes the key, so ensure_pair uploads the pair again."""
+    from pandora_amd import runtime
+
+    a = np.zeros((2048, 2048), np.float32)
+    before = runtime._sample(a)
+    a[1234, 777] = 1.0  # 777 is not a multiple of 64
+    assert runtime._sample(a) != before
+    m = np.zeros((64, 64), np.int16)
+    before = runtime._sample(m)
+    m[63, 63] = 1
+    assert runtime._sample(m) != before
+
+
+def test_configuration_limits_of_the_device_kernels_are_refused_at_check_conf():
+    """What the kernels cannot do is refused when the configuration is checked, not in the middle of a pipeline."""
+    from pandora_amd import cost_volume_confidence as cvc
+    from pandora_amd import filter as flt
+    from pandora_amd.matching_cost.matching_cost import ConfigError
+
+    with pytest.raises(ConfigError, match="1024 etas"):
+        cvc.AbstractCostVolumeConfidence(**{"confidence_method": "risk", "eta_max": 0.7, "eta_step": 0.0005})
+    with pytest.raises(ConfigError, match="1024 etas"):
+        cvc.AbstractCostVolumeConfidence(**{"confidence_method": "ambiguity", "eta_max": 0.9, "eta_step": 0.0005})
+    with pytest.raises(ConfigError, match="up to 15"):
+        flt.AbstractFilter(cfg={"filter_method": "median", "filter_size": 17})
