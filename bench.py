@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the stereo hot path on MI355X.
 
-Metric (BASELINE.json): Mdisparities/s = H*W*D / seconds / 1e6 for Census 5x5 -> 8-path SGM
-(P1=8, P2=32) -> WTA -> vfit on one synthetic stereo pair, inputs already resident in HBM.
+Metric (BASELINE.json): Mdisparities/s = H*W*D / seconds / 1e6 for Census 5x5 -> 8-path SGM (P1=8, P2=32) -> WTA -> vfit on one
+synthetic stereo pair, inputs already resident in HBM.
 
-One "step" = one pass of that pipeline over one pair.  Workload = BASELINE.json configs[2]
-(2048x2048, d=[0,128]); N>1 = one independent pair per rank (row-tile / pair sharding, no data-path
-collective; "weak" scaling), launched by torch.distributed.run, barrier + max over ranks.
+One "step" = one pass of that pipeline over ONE pair, at every N.  Workload = the shape BASELINE.json's north_star quotes its
+target on: 4096x4096, d=[0,256] (D=257; configs[3]'s size with the metric's Census+SGM pipeline; it fits one GPU).  N>1 = the same
+pair over N ranks (strong scaling): row tiles with the 40-pixel margin the reference's SGM step asks of ROI runs
+(optimization/optimization.py:43, marge.py:86-101), every rank runs the pipeline on its rows + margin, and ONE RCCL all-gather of
+the owned rows of the three result maps (inside libpandora_amd.so, on the engine's stream) leaves the full maps on every GPU.  One
+process per GPU, launched by `python -m torch.distributed.run` (only its environment variables are used: no PyTorch in this file).
 
-Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = one SGM path pass, HIP-event
-timed on the engine's stream inside the timed region) and `cpu_baseline` (the C oracle, kind
-"port", on a bounded row strip of the same workload, 1 thread; `cpu_baseline_all_cores` is the same
-strip with OpenMP on every host core).
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the 8-path SGM kernel, HIP-event timed on the engine's stream
+inside the timed region), `cpu_baseline` (the C oracle, kind "port", 1 thread, on a bounded row strip of the same pair),
+`cpu_baseline_all_cores` (same strip, OpenMP), `cpu_baseline_reference_compiled` (the reference's OWN census C++, oracle/_ref,
+census stage only) and, at N=1, `c3_shape` (BASELINE configs[2], 2048x2048x129, the round-1 headline, same protocol).
 """
 import argparse
 import json
@@ -28,6 +31,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SGM_ALGO_BYTES_PER_CELL = 20.0  # two-sweep minimum for 8 paths
 PIPELINE_ALGO_BYTES_PER_CELL = 28.0  # census 4 + sgm 20 + wta 4
+SGM_MARGIN = 40  # rows of context an SGM tile carries on each side (reference: UniformMargins(40))
+STAGES = ("census_transform", "census_cost", "sgm_path", "sgm_family", "sgm_fused", "wta", "refine", "collective")
 
 
 def synthetic_pair(H, W, dmin, dmax, seed=20260928):
@@ -78,109 +83,164 @@ def cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows, threads=1):
                       f"{dt:.1f} s of oracle/liboracle.so (gcc -O2 -fopenmp), {cores} thread{'s' if cores > 1 else ''}"}, (disp, val)
 
 
+def cpu_reference_compiled(L, R, dmin, dmax, win, rows):
+    """The reference's OWN C++ (matching_cost/cpp/src/census.cpp:97-180, compiled by oracle/Makefile into oracle/_ref) on the same
+    strip: the census stage only - it is the only stage of this pipeline the reference holds as compiled code (SGM is an
+    un-vendored plugin, WTA is numpy, refinement calls back into Python per pixel).  None when oracle/_ref is not built."""
+    from oracle import ref
+
+    mc = ref.load("matching_cost_cpp")
+    if mc is None:
+        return None
+    Ls, Rs = np.ascontiguousarray(L[:rows]), np.ascontiguousarray(R[:rows])
+    D = dmax - dmin + 1
+    cv = np.full((rows, L.shape[1], D), np.nan, np.float32)
+    t0 = time.perf_counter()
+    mc.compute_matching_costs(Ls, [Rs], cv, np.arange(D, dtype=np.float32) + dmin, win, win)
+    dt = time.perf_counter() - t0
+    return {"value": round(rows * L.shape[1] * D / dt / 1e6, 3), "unit": "Mdisp/s", "cores": 1, "kind": "reference-compiled",
+            "sample": f"census stage only (matching_cost_cpp.compute_matching_costs, g++ -O2), first {rows} rows of the "
+                      f"{L.shape[0]}x{L.shape[1]} pair, D={D}, {dt:.1f} s"}
+
+
+def roofline_block(stage, steps, cells):
+    """The dominant kernel of the step: all 8 SGM paths in ONE launch on the integer path (20 B/cell algorithmic), else the
+    float32 schedule's path launches together (20 B/cell over the launches of one step)."""
+    if stage["sgm_fused"][1] > 0:
+        name = "sgm_u8_packed_kernel (all 8 SGM paths in one launch, packed u16 arithmetic on 5-bit / byte costs)"
+        ms, n = stage["sgm_fused"]
+        algo = SGM_ALGO_BYTES_PER_CELL * cells
+        avg = ms / max(n, 1)
+    else:
+        name = "float32 SGM schedule (sgm_path_kernel + sgm_family_kernel launches of one step)"
+        ms = stage["sgm_path"][0] + stage["sgm_family"][0]
+        n = stage["sgm_path"][1] + stage["sgm_family"][1]
+        algo = SGM_ALGO_BYTES_PER_CELL * cells
+        avg = ms / max(steps, 1)
+    achieved = algo / (avg * 1e-3) / 1e9 if n else 0.0
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg, 4), "launches": n,
+            "algorithmic_bytes_per_launch": algo}
+
+
+def pmc_traffic(H, W, D):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (they cannot run inside bench.py);
+    None when no pass exists for this shape."""
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                for w in pmc if isinstance(pmc, list) else [pmc]:
+                    wl = w["workload"]
+                    if (wl["H"], wl["W"], wl["D"]) == (H, W, D):
+                        return w["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError, TypeError):
+                continue
+    return None
+
+
+def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed):
+    """One pair on one GPU through the whole protocol; returns (ms per step, stage times, (L, R))."""
+    L, R = synthetic_pair(H, W, dmin, dmax, seed=seed)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(dmax - dmin + 1, dmin)
+    for _ in range(warmup):
+        run_pipeline(eng, cv, 5, 8.0, 32.0)
+    eng.sync()
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_pipeline(eng, cv, 5, 8.0, 32.0)
+    eng.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    stage = {name: eng.stage_time(name) for name in STAGES}
+    eng.set_profiling(False)
+    cv.free()
+    return ms, stage, (L, R)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--height", type=int, default=2048)
-    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=4096)
+    ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--dmin", type=int, default=0)
-    ap.add_argument("--dmax", type=int, default=128)
-    ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline strip (0 = skip)")
+    ap.add_argument("--dmax", type=int, default=256)
+    ap.add_argument("--cpu-rows", type=int, default=512, help="rows of the CPU-baseline strip (0 = skip)")
     ap.add_argument("--placement-trials", type=int, default=6,
                     help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials; 1 = plain hipMalloc)")
-    ap.add_argument("--no-north-star", action="store_true", help="skip the informational 4096x4096x257 leg")
+    ap.add_argument("--no-c3", action="store_true", help="skip the 2048x2048x129 leg (BASELINE configs[2])")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or os.environ.get("PANDORA_BENCH_FORCE_DIST") == "1":
-        import torch
-        import torch.distributed as dist_mod
-
-        # test hooks only (two ranks on a 1-GPU box): PANDORA_BENCH_BACKEND=gloo, PANDORA_BENCH_DEVICE=<index>
-        backend = os.environ.get("PANDORA_BENCH_BACKEND", "nccl")
-        local_rank = int(os.environ.get("PANDORA_BENCH_DEVICE", local_rank))
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist_mod.init_process_group(backend=backend)
-        dist = dist_mod
-
+    from pandora_amd.comm import Comm, env_world
+    from pandora_amd.dist import row_tile
     from pandora_amd.engine import Engine
 
+    rank, world, local_rank, _, _ = env_world()
+    # test hooks only (two ranks on a 1-GPU box): PANDORA_COMM_BACKEND=tcp, PANDORA_BENCH_DEVICE=<index>
+    local_rank = int(os.environ.get("PANDORA_BENCH_DEVICE", local_rank))
     H, W, dmin, dmax, win, P1, P2 = args.height, args.width, args.dmin, args.dmax, 5, 8.0, 32.0
     D = dmax - dmin + 1
-    # one independent pair per rank (different seed per rank; same shape -> weak scaling)
-    L, R = synthetic_pair(H, W, dmin, dmax, seed=20260928 + rank)
     eng = Engine(local_rank)
+    comm = Comm(eng) if world > 1 else None
     if args.placement_trials > 1:
         eng.set_placement_trials(args.placement_trials)  # well-placed volumes, chosen once before the warm-up (DESIGN 4)
-    eng.set_images(L, R, 1)
+
+    # the SAME pair on every rank (strong scaling); a rank keeps its rows + margin resident
+    L, R = synthetic_pair(H, W, dmin, dmax)
+    (own_lo, own_hi), (tile_lo, tile_hi) = row_tile(H, world, rank, SGM_MARGIN if world > 1 else 0)
+    eng.set_images(np.ascontiguousarray(L[tile_lo:tile_hi]), np.ascontiguousarray(R[tile_lo:tile_hi]), 1)
     cv = eng.alloc_cv(D, dmin)
 
-    for _ in range(args.warmup):
+    def step():
         run_pipeline(eng, cv, win, P1, P2)
+        if comm is not None:
+            eng.tile_place(H, own_lo, own_hi, tile_lo, True)
+            comm.allgather_rows(H, True)
+
+    for _ in range(args.warmup):
+        step()
     eng.sync()
     eng.set_profiling(True)
     eng.reset_stage_times()
 
     def barrier():
         eng.sync()
-        if dist is not None:
-            import torch
-
-            torch.cuda.synchronize()
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
         eng.sync()
 
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_pipeline(eng, cv, win, P1, P2)
+        step()
     eng.sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = float(comm.host_allreduce(np.array([elapsed]), "max")[0])
     barrier()
 
     cells = H * W * D
-    stage = {name: eng.stage_time(name) for name in ("census_transform", "census_cost", "sgm_path", "sgm_fused", "wta", "refine")}
+    stage = {name: eng.stage_time(name) for name in STAGES}
     eng.set_profiling(False)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * cells / (elapsed / args.steps) / 1e6
-        # dominant kernel: the fused census->SGM kernel (all 8 paths in ONE launch: 20 B/cell algorithmic)
-        # on the integer fast path, else one of the 8 float path passes (20/8 B/cell per launch)
-        if stage["sgm_fused"][1] > 0:
-            kernel_name = "sgm_u8_packed_kernel (all 8 SGM paths in one launch, packed u16 arithmetic on 5-bit / byte costs)"
-            sgm_ms, sgm_n = stage["sgm_fused"]
-            algo_bytes_per_launch = SGM_ALGO_BYTES_PER_CELL * cells
+        value = cells / (elapsed / args.steps) / 1e6
+        tile_cells = (tile_hi - tile_lo) * W * D  # what this rank's kernels worked on
+        roof = roofline_block(stage, args.steps, tile_cells)
+        if stage["sgm_fused"][1] > 0 and world == 1:
+            roof["traffic"] = pmc_traffic(H, W, D)
+        if world == 1:
+            parallelism = "1 GPU, no collective"
         else:
-            kernel_name = "sgm_path_kernel (one of 8 direction passes)"
-            sgm_ms, sgm_n = stage["sgm_path"]
-            algo_bytes_per_launch = SGM_ALGO_BYTES_PER_CELL / 8.0 * cells
-        avg_launch_ms = sgm_ms / max(sgm_n, 1)
-        achieved = algo_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if sgm_n else 0.0
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            w = pmc["workload"]
-            if stage["sgm_fused"][1] > 0 and (w["H"], w["W"], w["D"]) == (H, W, D):
-                traffic = pmc["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
+            parallelism = (f"one pair over {world} GPUs: row tiles of {H // world} rows + {SGM_MARGIN}-row margin (the reference's ROI "
+                           f"convention for SGM, paths cut at the margin), one RCCL all-gather of the owned rows of disparity / validity / "
+                           f"coefficient maps per step; strong scaling")
         out = {
             "metric": "Mdisparities/s (HxWxD/s) Census5x5+SGM",
             "value": round(value, 1),
@@ -190,81 +250,76 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "u32" if stage["sgm_fused"][1] > 0 else "f32",
+            "dtype": ("u8 storage / packed u16 arithmetic (exact; float32-identical)" if stage["sgm_fused"][1] > 0 else "f32"),
             "data": "synthetic",
-            "config": {"workload": f"{H}x{W} synthetic pair, d=[{dmin},{dmax}] (D={D}), Census5x5 + SGM 8-path "
-                                   f"(P1=8,P2=32) + WTA + vfit; one independent pair per GPU",
-                       "parallelism": f"pair-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kernel_name,
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "avg_launch_ms": round(avg_launch_ms, 4), "launches": sgm_n,
-                         "algorithmic_bytes_per_launch": algo_bytes_per_launch},
+            "config": {"workload": f"{H}x{W} synthetic pair, d=[{dmin},{dmax}] (D={D}), Census5x5 + SGM 8-path (P1=8,P2=32) + WTA + vfit; "
+                                   f"ONE pair per step at every N", "parallelism": parallelism},
+            "roofline": roof,
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
-            "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4),
         }
-        # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
-        host_out = eng.get_disparity(want_itp=True)  # (also faults the host pages in once, as a streaming caller would)
-        eng.sync()
-        t1 = time.perf_counter()
-        eng.set_images(L, R, 1)
-        run_pipeline(eng, cv, win, P1, P2)
-        eng.get_disparity(want_itp=True, out=host_out)
-        pcie_s = time.perf_counter() - t1
-        out["pcie_inclusive"] = {"ms_per_step": round(pcie_s * 1e3, 3), "value": round(cells / pcie_s / 1e6, 1), "unit": "Mdisp/s",
-                                 "note": "pmx_set_images (2 float32 images up, pageable host memory) + pipeline + "
-                                         "pmx_get_disparity (disp, validity int64, itp down); informational only"}
-        if world == 1 and (H, W, dmax - dmin) == (2048, 2048, 128) and not args.no_north_star:
-            # informational: BASELINE.json's north_star quotes its target on 4096x4096 Census+SGM at 1 GPU (configs[3]'s shape)
+        if world > 1:
+            out["collective"] = {"kind": "ncclAllGather of owned rows (3 maps, 16 B/pixel)", "ms_per_step": round(stage["collective"][0] / args.steps, 4),
+                                 "bytes_per_step": H * W * 16}
+        else:
+            # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
+            host_out = eng.get_disparity(want_itp=True)  # (also faults the host pages in once, as a streaming caller would)
+            eng.sync()
+            t1 = time.perf_counter()
+            eng.set_images(L, R, 1)
+            run_pipeline(eng, cv, win, P1, P2)
+            eng.get_disparity(want_itp=True, out=host_out)
+            pcie_s = time.perf_counter() - t1
+            out["pcie_inclusive"] = {"ms_per_step": round(pcie_s * 1e3, 3), "value": round(cells / pcie_s / 1e6, 1), "unit": "Mdisp/s",
+                                     "note": "pmx_set_images (2 float32 images up) + pipeline + pmx_get_disparity (disp, validity "
+                                             "int64, itp down); informational only"}
             cv.free()
-            H4, W4, d4 = 4096, 4096, 256
-            L4, R4 = synthetic_pair(H4, W4, 0, d4, seed=20260929)
-            eng.set_images(L4, R4, 1)
-            cv4 = eng.alloc_cv(d4 + 1, 0)
-            run_pipeline(eng, cv4, win, P1, P2)
-            eng.sync()
-            t4 = time.perf_counter()
-            for _ in range(3):
-                run_pipeline(eng, cv4, win, P1, P2)
-            eng.sync()
-            ms4 = (time.perf_counter() - t4) / 3 * 1e3
-            cells4 = H4 * W4 * (d4 + 1)
-            out["north_star_shape"] = {"workload": "4096x4096 synthetic pair, d=[0,256] (D=257), same pipeline, 1 GPU, 3 steps",
-                                       "ms_per_step": round(ms4, 3), "value": round(cells4 / ms4 / 1e3, 1), "unit": "Mdisp/s",
-                                       "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells4 / (ms4 * 1e-3) / 1e9
-                                                                  / HBM_PEAK_GBS, 4)}
-            cv4.free()
-        if args.cpu_rows > 0 and world == 1:  # the CPU legs belong to the N=1 line only
-            rows = min(args.cpu_rows, H)
-            base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)
-            out["cpu_baseline"] = base
-            # all host cores: probe on a short strip first, so that a box whose cores are not really available (container
-            # quota, oversubscription) costs seconds, not minutes; the full strip only when the threads pay off
-            probe_rows = min(rows, 64)
-            probe, _ = cpu_baseline(L, R, dmin, dmax, win, P1, P2, probe_rows, threads=0)
-            if probe["value"] > 1.5 * base["value"]:
-                out["cpu_baseline_all_cores"], (mdisp, mval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows, threads=0)
-                assert np.array_equal(mdisp, cdisp, equal_nan=True) and np.array_equal(mval, cval)  # thread count changes nothing
-            else:
-                out["cpu_baseline_all_cores"] = probe
-            # parity in the same run: the same strip through the GPU path (vertical paths see only
-            # the strip, so the GPU is re-run on the strip alone)
-            eng2 = Engine(local_rank)
-            eng2.set_images(L[:rows], R[:rows], 1)
-            cv2 = eng2.alloc_cv(D, dmin)
-            eng2.census(cv2, win)
-            eng2.sgm(cv2, P1, P2, False, float(win * win + 1), False)
-            eng2.set_validity(None)
-            eng2.wta(cv2, False, -9999.0)
-            gdisp, gval = eng2.get_disparity()
-            out["disparity_linf_vs_cpu"] = float(np.max(np.abs(gdisp - cdisp)))
-            eng2.close()
+            if not args.no_c3 and (H, W, D) != (2048, 2048, 129):
+                ms3, st3, _ = measure_shape(eng, 2048, 2048, 0, 128, args.steps, args.warmup, 20260928)
+                c3 = 2048 * 2048 * 129
+                r3 = roofline_block(st3, args.steps, c3)
+                if st3["sgm_fused"][1] > 0:
+                    r3["traffic"] = pmc_traffic(2048, 2048, 129)
+                out["c3_shape"] = {"workload": "2048x2048 synthetic pair, d=[0,128] (D=129): BASELINE configs[2], the round-1 headline; same "
+                                               "pipeline and protocol", "steps": args.steps, "ms_per_step": round(ms3, 3),
+                                   "value": round(c3 / ms3 / 1e3, 1), "unit": "Mdisp/s", "roofline": r3,
+                                   "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in st3.items()},
+                                   "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if args.cpu_rows > 0:  # the CPU legs belong to the N=1 line only
+                rows = min(args.cpu_rows, H)
+                base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)
+                out["cpu_baseline"] = base
+                # all host cores: probe on a short strip first, so that a box whose cores are not really available (container
+                # quota, oversubscription) costs seconds, not minutes; the full strip only when the threads pay off
+                probe_rows = min(rows, 64)
+                probe, _ = cpu_baseline(L, R, dmin, dmax, win, P1, P2, probe_rows, threads=0)
+                if probe["value"] > 1.5 * base["value"]:
+                    out["cpu_baseline_all_cores"], (mdisp, mval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows, threads=0)
+                    assert np.array_equal(mdisp, cdisp, equal_nan=True) and np.array_equal(mval, cval)  # thread count changes nothing
+                else:
+                    out["cpu_baseline_all_cores"] = probe
+                refc = cpu_reference_compiled(L, R, dmin, dmax, win, min(rows, 256))
+                if refc is not None:
+                    out["cpu_baseline_reference_compiled"] = refc
+                # parity in the same run: the same strip through the GPU path (vertical paths see only the strip, so the GPU is
+                # re-run on the strip alone)
+                eng2 = Engine(local_rank)
+                eng2.set_images(L[:rows], R[:rows], 1)
+                cv2 = eng2.alloc_cv(D, dmin)
+                eng2.census(cv2, win)
+                eng2.sgm(cv2, P1, P2, False, float(win * win + 1), False)
+                eng2.set_validity(None)
+                eng2.wta(cv2, False, -9999.0)
+                gdisp, gval = eng2.get_disparity()
+                out["disparity_linf_vs_cpu"] = float(np.max(np.abs(gdisp - cdisp)))
+                eng2.close()
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ enum {
     PMX_STAGE_CENSUS_TRANSFORM = 0, PMX_STAGE_CENSUS_COST = 1, PMX_STAGE_SAD_SSD = 2, PMX_STAGE_ZNCC = 3,
     PMX_STAGE_MASK = 4, PMX_STAGE_CBCA_ARMS = 5, PMX_STAGE_CBCA_H = 6, PMX_STAGE_CBCA_V = 7,
     PMX_STAGE_SGM_PATH = 8, PMX_STAGE_SGM_FINAL = 9, PMX_STAGE_WTA = 10, PMX_STAGE_REFINE = 11,
-    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_SGM_FUSED = 14, PMX_STAGE_SGM_FAMILY = 15, PMX_STAGE_COUNT = 16
+    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_SGM_FUSED = 14, PMX_STAGE_SGM_FAMILY = 15, PMX_STAGE_COLLECTIVE = 16, PMX_STAGE_COUNT = 24
 };
 
 const char* pmx_last_error(void);
@@ -144,6 +144,58 @@ int pmx_wta_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int global_index_
 /* Decode reduced keys into the context's disparity/validity (d0_global = first disparity of the
  * full range). */
 int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double d0_global, int subpix, float invalid_disparity);
+
+/* ---- one pair over several GPUs: RCCL inside the library -------------------------- */
+/* The reference has no collective; its only scaling convention is ROI tiles with a margin (optimization/optimization.py:43,
+ * marge.py:86-101, img_tools.get_window img_tools.py:61-98).  One process per GPU; the communicator is RCCL's
+ * (librccl.so, loaded on first use), created from a 128-byte id that rank 0 obtains with pmx_comm_unique_id and the launcher
+ * hands to every rank (pandora_amd/comm.py does it over a TCP socket at MASTER_ADDR).  Collectives run on the context's stream
+ * and touch only device buffers owned by the context ("exchange buffers"). */
+enum { PMX_XBUF_KEYS = 0,          /* uint64 [H][W]   packed (cost, global index) keys of pmx_shard_minkey */
+       PMX_XBUF_NANPIX = 1,        /* uint8  [H][W]   1 = the pixel is NaN for every disparity of this shard */
+       PMX_XBUF_REFINE_PACK = 2,   /* float  [4][H][W] value-or-zero maps of pmx_shard_refine_pack */
+       PMX_XBUF_REFINE_FLAGS = 3,  /* int64  [H][W]   validity bits the owner's refinement added */
+       PMX_XBUF_FULL_DISP = 4,     /* float  [full_H][W]  row-tiled runs: the whole image's maps */
+       PMX_XBUF_FULL_VALIDITY = 5, /* int64  [full_H][W] */
+       PMX_XBUF_FULL_ITP = 6,      /* float  [full_H][W] */
+       PMX_XBUF_SCALARS = 7,       /* double [8] */
+       PMX_XBUF_COUNT = 8 };
+enum { PMX_OP_MIN = 0, PMX_OP_SUM = 1, PMX_OP_MAX = 2 };
+int pmx_comm_unique_id(void* id_out, size_t bytes);                                  /* ncclGetUniqueId; bytes >= 128 */
+int pmx_comm_init(pmx_ctx* ctx, const void* id, size_t bytes, int world, int rank);  /* ncclCommInitRank on the context's GPU */
+int pmx_comm_destroy(pmx_ctx* ctx);
+int pmx_comm_info(const pmx_ctx* ctx, int* world, int* rank);                        /* (1, 0) without a communicator */
+/* In-place ncclAllReduce of an exchange buffer over all ranks (keys: MIN = np.argmin over the full volume, ties to the lowest
+ * index; NaN flags: MIN = NaN in every shard; refinement packs: SUM with exactly one non-zero contributor per pixel = exact). */
+int pmx_comm_allreduce(pmx_ctx* ctx, int which, int op);
+/* Eight host doubles through the same path (timings: MAX over ranks).  Identity without a communicator. */
+int pmx_comm_allreduce_scalars(pmx_ctx* ctx, double* inout8, int op);
+/* D shards (pipelines without SGM): per-pixel keys of this rank's disparity slice -> PMX_XBUF_KEYS (= pmx_wta_minkey); after the
+ * MIN all-reduce pmx_shard_from_keys decodes the winners into the context's disparity / validity (= pmx_wta_from_keys). */
+int pmx_shard_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int global_index_offset);
+int pmx_shard_from_keys(pmx_ctx* ctx, double d0_global, int subpix, float invalid_disparity);
+/* np.min(np.isnan(cv), axis=2) of this shard -> PMX_XBUF_NANPIX (input of criteria.mask_invalid_variable_disparity_range,
+ * criteria.py:291-322, once MIN-reduced over the shards and downloaded). */
+int pmx_shard_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv);
+/* Sub-pixel refinement of a D-sharded volume (refinement/refinement.py:77-122 needs the winner's two neighbours: each shard
+ * carries one disparity of halo): the rank whose owned disparities [own_lo, own_hi] hold a pixel's winner refines it; pack,
+ * SUM all-reduce PMX_XBUF_REFINE_PACK and PMX_XBUF_REFINE_FLAGS, unpack -> the context's disparity / validity / coefficient. */
+int pmx_shard_refine_pack(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max, double own_lo, double own_hi, int last_rank);
+int pmx_shard_refine_unpack(pmx_ctx* ctx);
+/* Row tiles (any pipeline; SGM paths are cut at the tile margin exactly as the reference's ROI runs cut them): the context's
+ * maps are those of a tile starting at image row tile_lo; rows [own_lo, own_hi) go to their place in the full-size maps,
+ * pmx_comm_allgather_rows (rows owned = contiguous split of full_H over the ranks, first full_H % world ranks one more) makes
+ * every rank hold all rows, pmx_get_full_maps downloads them (any pointer may be NULL). */
+int pmx_tile_place(pmx_ctx* ctx, int full_H, int own_lo, int own_hi, int tile_lo, int with_itp);
+/* the same from host rows (a PandoraMachine run ends with its maps on the host: filters, validation); itp may be NULL */
+int pmx_set_full_rows(pmx_ctx* ctx, int full_H, int own_lo, int own_hi, const float* disp, const int64_t* validity, const float* itp);
+int pmx_comm_allgather_rows(pmx_ctx* ctx, int with_itp);
+int pmx_get_full_maps(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp);
+/* TEST TRANSPORT ONLY: host copies of an exchange buffer, so that two ranks sharing the one GPU of a test box (RCCL refuses that)
+ * can reduce through the host.  *count = elements, *elem_bytes = bytes per element. */
+int pmx_xbuf_info(pmx_ctx* ctx, int which, size_t* count, int* elem_bytes);
+int pmx_xbuf_download(pmx_ctx* ctx, int which, void* host);
+int pmx_xbuf_upload(pmx_ctx* ctx, int which, const void* host);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */

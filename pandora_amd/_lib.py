@@ -77,11 +77,32 @@ SIGNATURES = {
     "pmx_reset_stage_times": (C.c_int, [vp]),
     "pmx_stage_time": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),
     "pmx_stream": (vp, [vp]),
+    "pmx_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
+    "pmx_comm_init": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int]),
+    "pmx_comm_destroy": (C.c_int, [vp]),
+    "pmx_comm_info": (C.c_int, [vp, c_int_p, c_int_p]),
+    "pmx_comm_allreduce": (C.c_int, [vp, C.c_int, C.c_int]),
+    "pmx_comm_allreduce_scalars": (C.c_int, [vp, c_double_p, C.c_int]),
+    "pmx_comm_allgather_rows": (C.c_int, [vp, C.c_int]),
+    "pmx_shard_minkey": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "pmx_shard_from_keys": (C.c_int, [vp, C.c_double, C.c_int, C.c_float]),
+    "pmx_shard_nan_pixels": (C.c_int, [vp, vp]),
+    "pmx_shard_refine_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "pmx_shard_refine_unpack": (C.c_int, [vp]),
+    "pmx_tile_place": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pmx_get_full_maps": (C.c_int, [vp, vp, vp, vp]),
+    "pmx_set_full_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "pmx_xbuf_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t), c_int_p]),
+    "pmx_xbuf_download": (C.c_int, [vp, C.c_int, vp]),
+    "pmx_xbuf_upload": (C.c_int, [vp, C.c_int, vp]),
 }
+
+XBUFS = {"keys": (0, "uint64"), "nanpix": (1, "uint8"), "refine_pack": (2, "float32"), "refine_flags": (3, "int64"),
+         "full_disp": (4, "float32"), "full_validity": (5, "int64"), "full_itp": (6, "float32"), "scalars": (7, "float64")}
 
 STAGES = {
     "census_transform": 0, "census_cost": 1, "sad_ssd": 2, "zncc": 3, "mask": 4, "cbca_arms": 5, "cbca_h": 6,
-    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13, "sgm_fused": 14, "sgm_family": 15,
+    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13, "sgm_fused": 14, "sgm_family": 15, "collective": 16,
 }
 
 

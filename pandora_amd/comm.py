@@ -1,0 +1,267 @@
+"""One process per GPU: how the ranks of a multi-GPU run find each other and exchange.
+
+The data path is RCCL over xGMI INSIDE libpandora_amd.so (csrc/pmx_comm.hip: ncclAllReduce / ncclAllGather on device buffers the
+context owns).  This module only bootstraps it - rank 0 draws the 128-byte RCCL id (pmx_comm_unique_id) and hands it to the other
+ranks over a TCP socket at MASTER_ADDR (the launcher's rendezvous address; any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK /
+MASTER_ADDR / MASTER_PORT works, `python -m torch.distributed.run` included) - and offers the same exchange steps over two TEST
+transports for boxes where RCCL cannot run the ranks (two ranks on one GPU, or no GPU at all):
+
+  "rccl"  the product: collectives on the device exchange buffers, on the engine's stream
+  "tcp"   test transport: the exchange buffer visits the host (pmx_xbuf_download / _upload) and is reduced through rank 0's socket
+  "gloo"  test transport: the same through an initialised torch.distributed gloo group (CPU tests)
+
+No PyTorch is imported unless the gloo transport is asked for."""
+import os
+import socket
+import struct
+import time
+
+import numpy as np
+
+ID_BYTES = 128
+OPS = {"min": 0, "sum": 1, "max": 2}
+_NP_OPS = {"min": np.minimum, "sum": np.add, "max": np.maximum}
+
+
+def env_world():
+    """(rank, world, local_rank, master_addr, master_port) from the launcher's environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")),
+            os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")))
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(1 << 20, n - len(buf)))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf += chunk
+    return bytes(buf)
+
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class Rendezvous:
+    """Star of TCP connections through rank 0 (listening at addr:port): enough to hand out the RCCL id, to run a barrier and, for
+    the "tcp" test transport, to reduce host arrays.  Not a data path."""
+
+    def __init__(self, rank, world, addr, port, timeout=120.0):
+        self.rank, self.world = rank, world
+        self.peers = []  # rank 0: sockets of ranks 1..world-1 (index = rank - 1); others: [socket to rank 0]
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            by_rank = {}
+            while len(by_rank) < world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                by_rank[r] = conn
+            srv.close()
+            self.peers = [by_rank[r] for r in range(1, world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack("<I", rank))
+            self.peers = [s]
+
+    def broadcast(self, payload=None):
+        """rank 0's bytes to everyone"""
+        if self.world == 1:
+            return payload
+        if self.rank == 0:
+            for p in self.peers:
+                _send_msg(p, payload)
+            return payload
+        return _recv_msg(self.peers[0])
+
+    def allreduce(self, arr, op):
+        """host array reduced over the ranks (test transport)"""
+        if self.world == 1:
+            return arr
+        a = np.ascontiguousarray(arr)
+        if self.rank == 0:
+            acc = a.copy()
+            for p in self.peers:
+                other = np.frombuffer(_recv_msg(p), a.dtype).reshape(a.shape)
+                acc = _NP_OPS[op](acc, other)
+            raw = acc.tobytes()
+            for p in self.peers:
+                _send_msg(p, raw)
+            return acc
+        _send_msg(self.peers[0], a.tobytes())
+        return np.frombuffer(_recv_msg(self.peers[0]), a.dtype).reshape(a.shape).copy()
+
+    def allgather(self, payload):
+        """list of every rank's bytes, in rank order"""
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(p) for p in self.peers]
+            blob = b"".join(struct.pack("<Q", len(x)) + x for x in parts)
+            for p in self.peers:
+                _send_msg(p, blob)
+            return parts
+        _send_msg(self.peers[0], payload)
+        blob, parts, pos = _recv_msg(self.peers[0]), [], 0
+        while pos < len(blob):
+            (n,) = struct.unpack_from("<Q", blob, pos)
+            parts.append(blob[pos + 8:pos + 8 + n])
+            pos += 8 + n
+        return parts
+
+    def barrier(self):
+        self.allreduce(np.zeros(1, np.int32), "sum")
+
+    def close(self):
+        for p in self.peers:
+            try:
+                p.close()
+            except OSError:
+                pass
+        self.peers = []
+
+
+class _StdoutToStderr:
+    """RCCL prints a version banner on file descriptor 1 when a communicator is created; a caller whose stdout is a protocol
+    (bench.py: ONE JSON line) gets it on stderr instead."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+class Comm:
+    """The ranks of one run.  `engine` may be None for host-only use (CPU tests of the merge arithmetic)."""
+
+    def __init__(self, engine=None, backend=None, rank=None, world=None, addr=None, port=None, always=False):
+        erank, eworld, _, eaddr, eport = env_world()
+        self.rank = erank if rank is None else rank
+        self.world = eworld if world is None else world
+        self.engine = engine
+        self.always = always  # run the collectives even with one rank (tests of the RCCL path on a one-GPU box)
+        self.backend = backend or os.environ.get("PANDORA_COMM_BACKEND", "rccl")
+        if self.backend not in ("rccl", "tcp", "gloo"):
+            raise ValueError(f"unknown transport {self.backend!r}")
+        self._torch_dist = None
+        self.rdv = None
+        if self.backend == "gloo":
+            import torch.distributed as dist  # test transport only
+
+            if not dist.is_initialized():
+                raise RuntimeError("the gloo test transport needs an initialised torch.distributed group")
+            self._torch_dist = dist
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+            return
+        # the launcher's port belongs to the launcher (torch.distributed.run keeps its store there): rendezvous one above
+        port = int(os.environ.get("PANDORA_COMM_PORT", (eport if port is None else port) + 1))
+        self.rdv = Rendezvous(self.rank, self.world, eaddr if addr is None else addr, port)
+        if self.backend == "rccl":
+            if engine is None:
+                raise ValueError("the RCCL transport works on an engine's device buffers")
+            with _StdoutToStderr():
+                uid = self.rdv.broadcast(engine.comm_unique_id() if self.rank == 0 else None)
+                engine.comm_init(uid, self.world, self.rank)
+
+    # ---- host values ---------------------------------------------------------------------------------------------
+    def host_allreduce(self, arr, op):
+        """small host arrays (timings, test vectors).  RCCL: eight doubles at a time through the device."""
+        if self.world == 1:
+            return np.asarray(arr)
+        if self.backend == "gloo":
+            import torch
+
+            t = torch.from_numpy(np.ascontiguousarray(arr).copy())
+            red = {"min": self._torch_dist.ReduceOp.MIN, "sum": self._torch_dist.ReduceOp.SUM, "max": self._torch_dist.ReduceOp.MAX}[op]
+            self._torch_dist.all_reduce(t, op=red)
+            return t.numpy()
+        if self.backend == "tcp":
+            return self.rdv.allreduce(np.asarray(arr), op)
+        a = np.asarray(arr, np.float64).ravel()
+        out = np.empty_like(a)
+        for i in range(0, a.size, 8):
+            chunk = np.zeros(8, np.float64)
+            chunk[:a[i:i + 8].size] = a[i:i + 8]
+            red = self.engine.comm_allreduce_scalars(chunk, op)
+            out[i:i + 8] = red[:a[i:i + 8].size]
+        return out.reshape(np.shape(arr))
+
+    def barrier(self):
+        if self.world == 1:
+            return
+        if self.engine is not None:
+            self.engine.sync()
+        if self.backend == "gloo":
+            self._torch_dist.barrier()
+        elif self.backend == "tcp":
+            self.rdv.barrier()
+        else:
+            self.host_allreduce(np.zeros(1), "sum")  # a collective on the stream + the download that waits for it
+
+    # ---- device exchange buffers -------------------------------------------------------------------------------------
+    def allreduce_xbuf(self, which, op):
+        """In-place reduction of one of the engine's exchange buffers over the ranks."""
+        if self.world == 1 and not self.always:
+            return
+        if self.backend == "rccl":
+            self.engine.comm_allreduce(which, op)
+            return
+        host = self.engine.xbuf_download(which)  # test transports: through the host
+        self.engine.xbuf_upload(which, self.host_allreduce(host, op).astype(host.dtype, copy=False))
+
+    def allgather_rows(self, H, with_itp):
+        """Every rank placed its owned rows in the engine's full-size maps; afterwards every rank holds all rows."""
+        if self.world == 1 and not self.always:
+            return
+        if self.backend == "rccl":
+            self.engine.comm_allgather_rows(with_itp)
+            return
+        from .dist import shard_range
+
+        lo, hi = shard_range(H, self.world, self.rank)
+        for which in ("full_disp", "full_validity") + (("full_itp",) if with_itp else ()):
+            full = self.engine.xbuf_download(which).reshape(H, -1)
+            raw = np.ascontiguousarray(full[lo:hi]).tobytes()
+            if self.backend == "gloo":
+                parts = [None] * self.world
+                self._torch_dist.all_gather_object(parts, raw)
+            else:
+                parts = self.rdv.allgather(raw)
+            for r, blob in enumerate(parts):
+                rlo, rhi = shard_range(H, self.world, r)
+                full[rlo:rhi] = np.frombuffer(blob, full.dtype).reshape(rhi - rlo, -1)
+            self.engine.xbuf_upload(which, full)
+
+    def close(self):
+        if self.backend == "rccl" and self.engine is not None:
+            self.engine.comm_destroy()
+        if self.rdv is not None:
+            self.rdv.close()

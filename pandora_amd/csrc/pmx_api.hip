@@ -96,6 +96,8 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     pmx_pool_free(ctx, ctx->scratch);
     hipFree(ctx->small);
     hipFree(ctx->probe_sink);
+    pmx_comm_destroy(ctx);
+    pmx_comm_release(ctx);
     hipFree(ctx->fam_halo);
     hipFree(ctx->fam_ctl);
     if (ctx->fam_err_host) hipHostFree(ctx->fam_err_host);

@@ -91,7 +91,16 @@ struct pmx_ctx {
     unsigned* fam_ctl = nullptr;
     unsigned* fam_err_host = nullptr;  // pinned copy of the error word, filled behind every family launch
     int sgm_dir_mask = 0xff;           // pmx_debug_sgm_directions
+    // one pair over several GPUs (pmx_comm.hip): RCCL communicator and the device buffers the collectives work on
+    struct pmx_comm* comm = nullptr;
+    void* xbuf[PMX_XBUF_COUNT] = {};
+    size_t xbuf_bytes[PMX_XBUF_COUNT] = {};
+    int full_H = 0;                    // rows of the whole image in a row-tiled run (pmx_tile_place)
+    void* refine_saved[2] = {nullptr, nullptr};  // merged disparity / validity before the owner's refinement
+    size_t refine_saved_bytes = 0;
 };
+
+void pmx_comm_release(pmx_ctx* ctx);  // frees the exchange buffers
 
 // an in-kernel hand-off that gave up (k_sgmfam.hip) is reported by the next call that synchronises the stream
 int pmx_check_async_error(pmx_ctx* ctx, const char* where);

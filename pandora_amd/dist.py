@@ -1,11 +1,11 @@
-"""Multi-GPU (one process per GPU, torch.distributed: backend "nccl" = RCCL over xGMI; "gloo" in CPU
-tests).  SURVEY 8e:
+"""One stereo pair over several GPUs (one process per GPU; the exchanges are RCCL collectives inside libpandora_amd.so,
+csrc/pmx_comm.hip, bootstrapped by pandora_amd.comm.Comm - no PyTorch anywhere).  SURVEY 8e:
 
-* pair / row-tile sharding needs no collective (bench.py --gpus N);
-* for pipelines WITHOUT SGM the cost volume shards over D exactly: every rank builds the costs of
-  its disparity slice, reduces them to one packed (cost, global index) key per pixel
-  (pmx_wta_minkey), a single all_reduce(MIN) of 8 B x H*W merges the shards and pmx_wta_from_keys
-  decodes the winner - identical to np.argmin over the full volume, ties to the lowest index.
+* row tiles with the steps' margin - the reference's own convention (optimization/optimization.py:43, marge.py:86-101) - for
+  any pipeline, SGM included: no data-path collective, one all-gather of the owned rows of the 2-D results;
+* for pipelines WITHOUT SGM the cost volume shards over D exactly: every rank builds the costs of its disparity slice, reduces
+  them to one packed (cost, global index) key per pixel, a single all-reduce(MIN) of 8 B x H*W merges the shards and the decode
+  is identical to np.argmin over the full volume, ties to the lowest index; the rank owning a pixel's winner refines it.
   SGM cannot shard over D: its recurrence needs min_k over all k at every pixel.
 """
 import numpy as np
@@ -29,19 +29,6 @@ def disparity_shard(dmin, dmax, subpix, world, rank, halo=0):
     return own, (max(dmin, own[0] - halo), min(dmax, own[1] + halo))
 
 
-def allreduce_min_keys(keys, group=None):
-    """In-place MIN all-reduce of an int64 key tensor (any device)."""
-    import torch.distributed as dist
-
-    if keys.is_cuda and dist.get_backend(group) != "nccl":  # gloo (tests): through the host
-        host = keys.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
-        keys.copy_(host)
-    else:
-        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
-    return keys
-
-
 def decode_keys_numpy(keys, d0_global, subpix, invalid_disparity):
     """Host decode (tests / CPU tooling): int64 keys -> float32 disparity map + all-invalid mask."""
     keys = np.asarray(keys, np.int64)
@@ -52,22 +39,13 @@ def decode_keys_numpy(keys, d0_global, subpix, invalid_disparity):
     return disp, none
 
 
-def sharded_wta(engine, cv_shard, is_max, index_offset, d0_global, subpix, invalid_disparity, group=None):
-    """D-sharded winner-takes-all on the GPU.  `cv_shard` holds this rank's disparity slice whose
-    first sample has GLOBAL index `index_offset`.  The merged disparity / validity end up in the
-    engine exactly as after Engine.wta on the full volume."""
-    import torch
-
-    npix = engine.H * engine.W
-    keys = torch.empty(npix, dtype=torch.int64, device=torch.device("cuda", engine.device))
-    torch.cuda.synchronize(engine.device)
-    engine.wta_minkey(cv_shard, is_max, index_offset, keys.data_ptr())
-    engine.sync()  # the engine has its own HIP stream
-    allreduce_min_keys(keys, group)
-    torch.cuda.synchronize(engine.device)
-    engine.wta_from_keys(keys.data_ptr(), d0_global, subpix, invalid_disparity)
-    engine.sync()
-    return keys
+def sharded_wta(engine, comm, cv_shard, is_max, index_offset, d0_global, subpix, invalid_disparity):
+    """D-sharded winner-takes-all.  `cv_shard` holds this rank's disparity slice whose first sample has GLOBAL index
+    `index_offset`.  Keys, reduction and decode stay on the device (pmx_shard_minkey -> ncclAllReduce(min) ->
+    pmx_shard_from_keys); the merged disparity / validity end up in the engine exactly as after Engine.wta on the full volume."""
+    engine.shard_minkey(cv_shard, is_max, index_offset)
+    comm.allreduce_xbuf("keys", "min")
+    engine.shard_from_keys(d0_global, subpix, invalid_disparity)
 
 
 # ---- row tiles (the reference's own scaling convention: ROI tiles with a margin, img_tools.get_window /
@@ -107,68 +85,64 @@ def tile_dataset(ds, rlo, rhi):
     return out
 
 
-def run_row_tiled(img_left, img_right, cfg, margin=None, group=None):
-    """One stereo pair over all ranks, the reference's way (ROI tiles with a margin, marge.py:86-101; 40 px is what the SGM
-    plugin asks for, optimization/optimization.py:43): every rank runs the whole pipeline of ``cfg`` on its rows plus the
-    margin (default: the global margins of the configured steps) on its own GPU, keeps the rows it owns, and the owned rows of all ranks are gathered on every rank (the only
-    exchange: the 2-D results).  Local pipelines are exact with a margin of at least the window radius; SGM paths are cut at
-    the tile margin, as in the reference.  Returns (left, right) dicts of full-size arrays: disparity_map, validity_mask and,
-    when present, interpolated_coeff.  Works without torch.distributed (one tile)."""
-    from . import run as run_pipeline
+def _global_margin(img_left, img_right, cfg):
+    """what the configured steps ask for (PandoraMachine.margins; reference: margins/margins.py:71-143)"""
     from .state_machine import PandoraMachine
 
-    world, rank, dist = 1, 0, None
-    try:
-        import torch.distributed as dist_mod
+    probe = PandoraMachine()
+    probe.check_conf({"pipeline": cfg["pipeline"]}, img_left, img_right)
+    g = probe.margins.global_margins
+    return max(g.up, g.down)
 
-        if dist_mod.is_available() and dist_mod.is_initialized():
-            dist = dist_mod
-            world, rank = dist.get_world_size(group), dist.get_rank(group)
-    except ImportError:
-        pass
+
+def run_row_tiled(img_left, img_right, cfg, margin=None, comm=None):
+    """One stereo pair over all ranks, the reference's way (ROI tiles with a margin, marge.py:86-101; 40 px is what the SGM plugin
+    asks for, optimization/optimization.py:43): every rank runs the whole pipeline of ``cfg`` on its rows plus the margin (default:
+    the global margins of the configured steps) on its own GPU and keeps the rows it owns; the owned rows of the 2-D results are
+    all-gathered (RCCL, the only exchange) so that every rank holds the full maps.  Local pipelines are exact with a margin of at
+    least the window radius; SGM paths are cut at the tile margin, as in the reference.  Returns (left, right) dicts of full-size
+    arrays: disparity_map, validity_mask and, when present, interpolated_coeff.  comm=None: one rank."""
+    from . import run as run_pipeline
+    from . import runtime
+    from .state_machine import PandoraMachine
+
+    world, rank = (comm.world, comm.rank) if comm is not None else (1, 0)
     H = img_left.sizes["row"]
-    if margin is None:  # what the configured steps ask for (PandoraMachine.margins, reference: margins/margins.py:71-143)
-        probe = PandoraMachine()
-        probe.check_conf({"pipeline": cfg["pipeline"]}, img_left, img_right)
-        g = probe.margins.global_margins
-        margin = max(g.up, g.down)
+    if margin is None:
+        margin = _global_margin(img_left, img_right, cfg)
     (lo, hi), (rlo, rhi) = row_tile(H, world, rank, margin)
     tile_l, tile_r = tile_dataset(img_left, rlo, rhi), tile_dataset(img_right, rlo, rhi)
     machine = PandoraMachine()
     tcfg = {"pipeline": machine.check_conf({"pipeline": cfg["pipeline"]}, tile_l, tile_r)["pipeline"]}
     out_l, out_r = run_pipeline(machine, tile_l, tile_r, tcfg)
+    eng = comm.engine if comm is not None and comm.engine is not None else runtime.get_engine()
 
-    def owned(ds):
+    def gathered(ds):
         if len(ds.sizes) == 0:
             return None
-        return {k: np.ascontiguousarray(np.asarray(ds[k].data)[lo - rlo:hi - rlo])
-                for k in ("disparity_map", "validity_mask", "interpolated_coeff") if k in ds.data_vars}
+        keys = [k for k in ("disparity_map", "validity_mask", "interpolated_coeff") if k in ds.data_vars]
+        own = {k: np.ascontiguousarray(np.asarray(ds[k].data)[lo - rlo:hi - rlo]) for k in keys}
+        if world == 1:
+            return own
+        # the machine's final maps live on the host (filters, validation): the owned rows go up into the engine's full-size
+        # maps, one all-gather over xGMI, and the full maps come down
+        itp = own.get("interpolated_coeff")
+        eng.set_full_rows(H, lo, hi, own["disparity_map"], own["validity_mask"], itp)
+        comm.allgather_rows(H, itp is not None)
+        full = eng.get_full_maps(H, want_itp=itp is not None)
+        return dict(zip(keys, full))
 
-    mine = (owned(out_l), owned(out_r))
-    if dist is None:
-        return mine
-    parts = [None] * world
-    dist.all_gather_object(parts, mine, group=group)
-
-    def stitch(side):
-        if parts[0][side] is None:
-            return None
-        return {k: stitch_tiles([p[side][k] for p in parts]) for k in parts[0][side]}
-
-    return stitch(0), stitch(1)
+    return gathered(out_l), gathered(out_r)
 
 
-def run_d_sharded(img_left, img_right, cfg, group=None):
-    """One stereo pair, the cost volume sharded over D across the ranks (pipelines WITHOUT optimization): every
-    rank builds and aggregates the costs of its disparity slice (one integer disparity of halo on each side), the slices meet
-    in ONE all_reduce(MIN) of a packed (cost, global index) key per pixel (RCCL over xGMI with the nccl backend), and the
-    rank that owns a pixel's winner refines it.  Small 2-D exchanges besides the keys: the all-NaN pixel flags (for the
-    validity mask) and the refined values.  The maps equal the unsharded run bit for bit.  Supported steps: matching_cost,
-    aggregation, disparity, refinement; uniform disparity ranges.  Returns {"disparity_map", "validity_mask"
-    [, "interpolated_coeff"]} on every rank."""
-    import torch
-    import torch.distributed as dist
-
+def run_d_sharded(img_left, img_right, cfg, comm):
+    """One stereo pair, the cost volume sharded over D across the ranks (pipelines WITHOUT optimization): every rank
+    builds and aggregates the costs of its disparity slice (one integer disparity of halo on each side), the slices meet in ONE
+    all-reduce(MIN) of a packed (cost, global index) key per pixel (ncclAllReduce over xGMI), and the rank that owns a pixel's
+    winner refines it (one all-reduce(SUM) of value-or-zero maps: exact).  Keys, winner maps and refinement packs never leave the
+    device; the one host hop is the validity mask, which the host computes as in the single-GPU flow (criteria.py) from the
+    reduced all-NaN flags.  The maps equal the unsharded run bit for bit.  Supported steps: matching_cost, aggregation,
+    disparity, refinement; uniform disparity ranges.  Returns {"disparity_map", "validity_mask"[, "interpolated_coeff"]}."""
     from . import criteria, matching_cost, runtime
     from .dataset import make_image
     from .state_machine import PandoraMachine
@@ -177,7 +151,7 @@ def run_d_sharded(img_left, img_right, cfg, group=None):
     extra = [k for k in pipe if k.split(".")[0] not in ("matching_cost", "aggregation", "disparity", "refinement")]
     if extra or "disparity" not in pipe:
         raise NotImplementedError(f"run_d_sharded handles matching_cost / aggregation / disparity / refinement only (got {extra})")
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    world, rank = comm.world, comm.rank
     grids = np.asarray(img_left["disparity"].data)
     dmin, dmax = int(grids[0].min()), int(grids[1].max())
     if grids[0].max() != dmin or grids[1].min() != dmax:
@@ -199,24 +173,17 @@ def run_d_sharded(img_left, img_right, cfg, group=None):
     cv = machine.left_cv
     dcv = cv["cost_volume"].device_cv
     eng = dcv.engine
+    if comm.engine is not eng:
+        raise ValueError("the communicator belongs to another engine than the one the machine runs on")
     subpix = int(cv.attrs["subpixel"])
     is_max = cv.attrs["type_measure"] == "max"
-    dev = torch.device("cuda", eng.device)
-
-    def reduce_(t, op):
-        if dist.get_backend(group) != "nccl":
-            host = t.cpu()
-            dist.all_reduce(host, op=op, group=group)
-            return host.to(t.device) if t.is_cuda else host
-        dist.all_reduce(t, op=op, group=group)
-        return t
-
     # ---- the validity mask of the WHOLE range (criteria.py:66-158, :291-353), with the all-NaN pixels of the whole volume
     mc = matching_cost.AbstractMatchingCost(**{k: v for k, v in checked["matching_cost"].items()})
     grid = mc.allocate_cost_volume(img_left, (img_left["disparity"].sel(band_disp="min"), img_left["disparity"].sel(band_disp="max")))
     grid = criteria.validity_mask(img_left, img_right, grid)
-    missing = torch.from_numpy(eng.nan_pixels(dcv).astype(np.uint8)).to(dev)
-    missing = reduce_(missing, dist.ReduceOp.MIN).cpu().numpy().astype(bool)  # NaN for every disparity of every shard
+    eng.shard_nan_pixels(dcv)
+    comm.allreduce_xbuf("nanpix", "min")  # NaN for every disparity of every shard
+    missing = eng.xbuf_download("nanpix").reshape(eng.H, eng.W).astype(bool)
     criteria.mask_invalid_variable_disparity_range(grid, missing)
     if grid.attrs["offset_row_col"] > 0:
         criteria.mask_border(grid)
@@ -224,21 +191,16 @@ def run_d_sharded(img_left, img_right, cfg, group=None):
     # ---- winner-takes-all over the shards: one all-reduce of 8 bytes per pixel
     invalid = pipe["disparity"].get("invalid_disparity", -9999)
     invalid = float("nan") if isinstance(invalid, str) else float(invalid)
-    sharded_wta(eng, dcv, is_max, (wlo - dmin) * subpix, dmin, subpix, invalid, group)
-    disp, val = eng.get_disparity()
-    out = {"disparity_map": disp, "validity_mask": val}
+    sharded_wta(eng, comm, dcv, is_max, (wlo - dmin) * subpix, dmin, subpix, invalid)
     if "refinement" in pipe:
-        eng.refine(dcv, pipe["refinement"]["refinement_method"], is_max)
-        rdisp, rval, ritp = eng.get_disparity(want_itp=True)
-        last = rank == world - 1
-        owner = (disp >= olo) & ((disp <= ohi) if last else (disp < ohi + 1)) & ((val & 0x3C3) == 0)
-        pack = torch.from_numpy(np.stack([np.where(owner, rdisp, 0.0), np.where(owner, np.nan_to_num(ritp, nan=0.0), 0.0),
-                                          np.where(owner & np.isnan(ritp), 1.0, 0.0), owner.astype(np.float32)]).astype(np.float32)).to(dev)
-        pack = reduce_(pack, dist.ReduceOp.SUM).cpu().numpy()    # exactly one owner per valid pixel: value + zeros is exact
-        flags = torch.from_numpy(np.where(owner, rval - val, 0).astype(np.int64)).to(dev)
-        flags = reduce_(flags, dist.ReduceOp.SUM).cpu().numpy()
-        owned = pack[3] > 0
-        itp = np.where(owned, np.where(pack[2] > 0, np.nan, pack[1]), np.nan).astype(np.float32)
-        out = {"disparity_map": np.where(owned, pack[0], disp).astype(np.float32), "validity_mask": val + flags, "interpolated_coeff": itp}
+        eng.shard_refine_pack(dcv, pipe["refinement"]["refinement_method"], is_max, olo, ohi, rank == world - 1)
+        comm.allreduce_xbuf("refine_pack", "sum")   # exactly one owner per valid pixel: value + zeros is exact
+        comm.allreduce_xbuf("refine_flags", "sum")
+        eng.shard_refine_unpack()
+        disp, val, itp = eng.get_disparity(want_itp=True)
+        out = {"disparity_map": disp, "validity_mask": val, "interpolated_coeff": itp}
+    else:
+        disp, val = eng.get_disparity()
+        out = {"disparity_map": disp, "validity_mask": val}
     runtime.invalidate(eng.device)
     return out

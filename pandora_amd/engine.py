@@ -349,6 +349,83 @@ class Engine:
         pos = np.where(k < m4, s * m4 + k, nact * m4 + s)
         return out[:, :, :, pos]
 
+    # -- one pair over several GPUs (csrc/pmx_comm.hip; pandora_amd.comm.Comm bootstraps it) ----------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().pmx_comm_unique_id(buf, 128), "pmx_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, uid, world, rank):
+        check(_lib.lib().pmx_comm_init(self.ctx, C.c_char_p(bytes(uid)), len(uid), int(world), int(rank)), "pmx_comm_init")
+
+    def comm_destroy(self):
+        check(_lib.lib().pmx_comm_destroy(self.ctx), "pmx_comm_destroy")
+
+    def comm_allreduce(self, which, op):
+        from .comm import OPS
+
+        check(_lib.lib().pmx_comm_allreduce(self.ctx, _lib.XBUFS[which][0], OPS[op]), "pmx_comm_allreduce")
+
+    def comm_allreduce_scalars(self, eight, op):
+        from .comm import OPS
+
+        a = np.ascontiguousarray(eight, np.float64).copy()
+        assert a.size == 8
+        check(_lib.lib().pmx_comm_allreduce_scalars(self.ctx, _p(a, C.c_double), OPS[op]), "pmx_comm_allreduce_scalars")
+        return a
+
+    def comm_allgather_rows(self, with_itp):
+        check(_lib.lib().pmx_comm_allgather_rows(self.ctx, int(bool(with_itp))), "pmx_comm_allgather_rows")
+
+    def xbuf_download(self, which):
+        """TEST TRANSPORT ONLY (two ranks on one GPU): host copy of an exchange buffer."""
+        idx, dtype = _lib.XBUFS[which]
+        n = C.c_size_t(0)
+        check(_lib.lib().pmx_xbuf_info(self.ctx, idx, C.byref(n), None), "pmx_xbuf_info")
+        out = np.empty(n.value, dtype)
+        check(_lib.lib().pmx_xbuf_download(self.ctx, idx, out.ctypes.data_as(C.c_void_p)), "pmx_xbuf_download")
+        return out
+
+    def xbuf_upload(self, which, arr):
+        idx, dtype = _lib.XBUFS[which]
+        a = np.ascontiguousarray(arr, dtype).ravel()
+        check(_lib.lib().pmx_xbuf_upload(self.ctx, idx, a.ctypes.data_as(C.c_void_p)), "pmx_xbuf_upload")
+
+    def shard_minkey(self, cv, is_max, index_offset):
+        check(_lib.lib().pmx_shard_minkey(self.ctx, cv.handle, int(bool(is_max)), int(index_offset)), "pmx_shard_minkey")
+
+    def shard_from_keys(self, d0_global, subpix, invalid_disparity):
+        check(_lib.lib().pmx_shard_from_keys(self.ctx, float(d0_global), int(subpix), float(invalid_disparity)), "pmx_shard_from_keys")
+
+    def shard_nan_pixels(self, cv):
+        check(_lib.lib().pmx_shard_nan_pixels(self.ctx, cv.handle), "pmx_shard_nan_pixels")
+
+    def shard_refine_pack(self, cv, method, is_max, own_lo, own_hi, last_rank):
+        check(_lib.lib().pmx_shard_refine_pack(self.ctx, cv.handle, {"vfit": 0, "quadratic": 1}[method], int(bool(is_max)), float(own_lo), float(own_hi),
+                                               int(bool(last_rank))), "pmx_shard_refine_pack")
+
+    def shard_refine_unpack(self):
+        check(_lib.lib().pmx_shard_refine_unpack(self.ctx), "pmx_shard_refine_unpack")
+
+    def tile_place(self, full_H, own_lo, own_hi, tile_lo, with_itp):
+        check(_lib.lib().pmx_tile_place(self.ctx, int(full_H), int(own_lo), int(own_hi), int(tile_lo), int(bool(with_itp))), "pmx_tile_place")
+
+    def set_full_rows(self, full_H, own_lo, own_hi, disp, validity, itp=None):
+        d = np.ascontiguousarray(disp, np.float32)
+        v = np.ascontiguousarray(validity, np.int64)
+        t = None if itp is None else np.ascontiguousarray(itp, np.float32)
+        assert d.shape == (own_hi - own_lo, self.W) == v.shape
+        check(_lib.lib().pmx_set_full_rows(self.ctx, int(full_H), int(own_lo), int(own_hi), d.ctypes.data_as(C.c_void_p),
+                                           v.ctypes.data_as(C.c_void_p), None if t is None else t.ctypes.data_as(C.c_void_p)), "pmx_set_full_rows")
+
+    def get_full_maps(self, full_H, want_itp=False):
+        disp = np.empty((full_H, self.W), np.float32)
+        val = np.empty((full_H, self.W), np.int64)
+        itp = np.empty((full_H, self.W), np.float32) if want_itp else None
+        check(_lib.lib().pmx_get_full_maps(self.ctx, disp.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p),
+                                           itp.ctypes.data_as(C.c_void_p) if want_itp else None), "pmx_get_full_maps")
+        return (disp, val, itp) if want_itp else (disp, val)
+
     # -- measurement -------------------------------------------------------------------------
     def sync(self):
         check(_lib.lib().pmx_sync(self.ctx), "pmx_sync")

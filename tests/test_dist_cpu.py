@@ -1,7 +1,8 @@
-"""world_size-2 gloo test (CPU) of the D-sharded WTA merge: two processes each reduce their
-disparity slice to packed keys (numpy restatement of the kernel's packing, test-only), one
-all_reduce(MIN) merges them, and the decode equals np.argmin over the full volume (first minimum on
-ties, NaN = +inf, all-NaN -> invalid)."""
+"""world_size-2 tests (CPU) of the multi-GPU exchange logic.  The product exchanges are RCCL collectives inside the library; here
+the same merge arithmetic runs through pandora_amd.comm.Comm's two test transports: "gloo" (torch.distributed on CPU) and "tcp"
+(the launcher-independent socket rendezvous that also hands out the RCCL id).  D-sharded WTA: two processes each reduce their
+disparity slice to packed keys (numpy restatement of the kernel's packing, test-only), one all-reduce(MIN) merges them, and the
+decode equals np.argmin over the full volume (first minimum on ties, NaN = +inf, all-NaN -> invalid)."""
 import os
 import socket
 import sys
@@ -28,13 +29,14 @@ def pack_keys_numpy(cv, is_max, index_offset):
 
 def _worker(rank, world, port, is_max, q):
     sys.path.insert(0, ROOT)
-    import torch
     import torch.distributed as dist
 
     from pandora_amd import dist as pdist
+    from pandora_amd.comm import Comm
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = Comm(backend="gloo")
     rng = np.random.default_rng(0)  # same volume on both ranks
     H, W, dmin, dmax = 9, 13, -7, 5
     D = dmax - dmin + 1
@@ -43,9 +45,8 @@ def _worker(rank, world, port, is_max, q):
     cv[0, 0] = np.nan
     (lo, hi), _ = pdist.disparity_shard(dmin, dmax, 1, world, rank)
     shard = cv[:, :, lo - dmin:hi - dmin + 1]
-    keys = torch.from_numpy(pack_keys_numpy(shard, is_max, lo - dmin).ravel().copy())
-    pdist.allreduce_min_keys(keys)
-    disp, none = pdist.decode_keys_numpy(keys.numpy().reshape(H, W), dmin, 1, -9999.0)
+    keys = comm.host_allreduce(pack_keys_numpy(shard, is_max, lo - dmin).ravel().copy(), "min")
+    disp, none = pdist.decode_keys_numpy(keys.reshape(H, W), dmin, 1, -9999.0)
     if rank == 0:
         q.put((disp, none, cv))
     dist.barrier()
@@ -104,3 +105,47 @@ def test_row_tiles_cover_the_image_with_margins():
             parts.append(pd.crop_tile(full[rlo:rhi], H, world, rank, margin=40))
         assert owned[0][0] == 0 and owned[-1][1] == H and all(a[1] == b[0] for a, b in zip(owned, owned[1:]))
         np.testing.assert_array_equal(pd.stitch_tiles(parts), full)
+
+
+def _tcp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from pandora_amd import dist as pdist
+    from pandora_amd.comm import Comm
+
+    comm = Comm(backend="tcp", rank=rank, world=world, addr="127.0.0.1", port=port)
+    uid = comm.rdv.broadcast(bytes(range(128)) if rank == 0 else None)  # how the RCCL id travels
+    rng = np.random.default_rng(5)
+    H, W, dmin, dmax = 11, 17, -20, 12
+    D = dmax - dmin + 1
+    cv = rng.integers(0, 6, (H, W, D)).astype(np.float32)
+    cv[rng.random(cv.shape) < 0.3] = np.nan
+    (lo, hi), _ = pdist.disparity_shard(dmin, dmax, 1, world, rank)
+    keys = comm.host_allreduce(pack_keys_numpy(cv[:, :, lo - dmin:hi - dmin + 1], False, lo - dmin), "min")
+    disp, _ = pdist.decode_keys_numpy(keys, dmin, 1, -9999.0)
+    tmax = comm.host_allreduce(np.array([float(rank + 1)]), "max")
+    rows = comm.rdv.allgather(bytes([rank]) * (rank + 2))
+    comm.barrier()
+    if rank == world - 1:
+        q.put((uid, disp, cv, float(tmax[0]), rows))
+    comm.close()
+
+
+def test_tcp_rendezvous_world3(oracle):
+    """Three processes, no torch: the socket star broadcasts rank 0's bytes, reduces and gathers host arrays."""
+    import multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    uid, disp, cv, tmax, rows = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert uid == bytes(range(128)) and tmax == 3.0 and rows == [b"\x00" * 2, b"\x01" * 3, b"\x02" * 4]
+    edisp, _ = oracle.wta(cv, -20, 1, False, -9999.0)
+    np.testing.assert_array_equal(disp, edisp)

@@ -23,7 +23,7 @@ def test_bench_prints_one_contract_line():
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["scaling"] == "strong" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
@@ -31,3 +31,22 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     assert d["disparity_linf_vs_cpu"] == 0.0  # the GPU strip equals the CPU oracle strip, same run
     assert d["value"] > c["value"]
+    assert d["cpu_baseline_reference_compiled"]["kind"] == "reference-compiled"  # the reference's own census C++, same strip
+
+
+def test_bench_runs_one_pair_over_two_ranks():
+    """--gpus 2 = ONE pair over two ranks (row tiles + 40-row margin, all-gather of the owned rows), launched with the launcher's
+    environment variables; both ranks share the box's one GPU, so the gather goes through the tcp test transport."""
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
+                   PANDORA_COMM_BACKEND="tcp", PANDORA_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--height", "300", "--width", "256", "--dmax", "40", "--placement-trials", "1"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines) == 1 and not outs[1][0].strip(), outs
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"] and d["collective"]["bytes_per_step"] == 300 * 256 * 16

@@ -1,68 +1,91 @@
-"""GPU: the D-sharded WTA through pandora_amd.dist.sharded_wta with a real RCCL process group
-(1 rank - the GPU box has one GPU; the merge itself is covered at world_size 2 by
-tests/test_dist_cpu.py).  Runs in a subprocess because torch (which bundles its own HIP runtime)
-must be imported BEFORE libpandora_amd.so in a process."""
-import os
-import subprocess
-import sys
-
+"""GPU: the exchange steps of csrc/pmx_comm.hip through a real RCCL communicator.  The GPU box has one GPU, so the communicator
+has one rank (the collectives are identities but every call goes through librccl.so on the engine's stream); merges over two
+ranks are covered by tests/test_gpu_tiled.py (two ranks on the one GPU, test transport) and tests/test_dist_cpu.py."""
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SCRIPT = r'''
-import os, sys
-import numpy as np
-import torch, torch.distributed as dist          # torch first
-sys.path.insert(0, %(root)r)
-from pandora_amd.engine import Engine
-from pandora_amd import dist as pdist
-from oracle import capi
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-rng = np.random.default_rng(12)
-H, W, dmin, dmax = 17, 29, -9, 6
-D = dmax - dmin + 1
-cv = rng.integers(0, 4, (H, W, D)).astype(np.float32) - 1.0
-cv[rng.random(cv.shape) < 0.2] = np.nan
-cv[3, 4] = np.nan
-eng = Engine(0)
-z = np.zeros((H, W), np.float32)
-eng.set_images(z, z, 1)
-for is_max in (False, True):
-    merged = None
-    for rank in range(2):                         # two disparity shards, reduced on this GPU
-        (lo, hi), _ = pdist.disparity_shard(dmin, dmax, 1, 2, rank)
-        shard = eng.alloc_cv(hi - lo + 1, lo)
-        shard.from_host(np.ascontiguousarray(cv[:, :, lo - dmin:hi - dmin + 1]))
-        keys = torch.empty(H * W, dtype=torch.int64, device="cuda:0")
-        torch.cuda.synchronize()
-        eng.wta_minkey(shard, is_max, lo - dmin, keys.data_ptr())
-        eng.sync()
-        merged = keys if merged is None else torch.minimum(merged, keys)
-    pdist.allreduce_min_keys(merged)              # RCCL all_reduce(MIN), world 1
-    torch.cuda.synchronize()
-    eng.set_validity(None)
-    eng.wta_from_keys(merged.data_ptr(), dmin, 1, -9999.0)
-    disp, val = eng.get_disparity()
-    edisp, eval_ = capi.wta(cv, dmin, 1, is_max, -9999.0)
-    np.testing.assert_array_equal(disp, edisp)
-    np.testing.assert_array_equal(val, eval_)
-    # and the one-call helper on the full volume
+
+@pytest.fixture(scope="module")
+def world1():
+    from pandora_amd.comm import Comm
+    from pandora_amd.engine import Engine
+
+    eng = Engine(0)
+    comm = Comm(eng, backend="rccl", rank=0, world=1, always=True)
+    yield eng, comm
+    comm.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("is_max", [False, True])
+def test_sharded_wta_and_refinement_through_rccl(world1, oracle, is_max):
+    from pandora_amd import dist as pdist
+
+    eng, comm = world1
+    rng = np.random.default_rng(12)
+    H, W, dmin, dmax = 17, 29, -9, 6
+    D = dmax - dmin + 1
+    cv = rng.integers(0, 4, (H, W, D)).astype(np.float32) - 1.0
+    cv[rng.random(cv.shape) < 0.2] = np.nan
+    cv[3, 4] = np.nan
+    z = np.zeros((H, W), np.float32)
+    eng.set_images(z, z, 1)
     full = eng.alloc_cv(D, dmin)
     full.from_host(cv)
+    # all-NaN flags: shard -> exchange buffer -> ncclAllReduce(min) -> host
+    eng.shard_nan_pixels(full)
+    comm.allreduce_xbuf("nanpix", "min")
+    np.testing.assert_array_equal(eng.xbuf_download("nanpix").reshape(H, W).astype(bool), np.isnan(cv).all(axis=2))
+    # keys -> ncclAllReduce(min, uint64) -> decode
     eng.set_validity(None)
-    pdist.sharded_wta(eng, full, is_max, 0, dmin, 1, -9999.0)
-    disp2, val2 = eng.get_disparity()
-    np.testing.assert_array_equal(disp2, edisp)
-dist.destroy_process_group()
-print("DIST_OK")
-'''
+    pdist.sharded_wta(eng, comm, full, is_max, 0, dmin, 1, -9999.0)
+    disp, val = eng.get_disparity()
+    edisp, eval_ = oracle.wta(cv, dmin, 1, is_max, -9999.0)
+    np.testing.assert_array_equal(disp, edisp)
+    np.testing.assert_array_equal(val, eval_)
+    # owner refinement: pack -> ncclAllReduce(sum) x2 -> unpack; one rank owns every winner
+    eng.shard_refine_pack(full, "vfit", is_max, dmin, dmax, True)
+    comm.allreduce_xbuf("refine_pack", "sum")
+    comm.allreduce_xbuf("refine_flags", "sum")
+    eng.shard_refine_unpack()
+    rdisp, rval, ritp = eng.get_disparity(want_itp=True)
+    oitp, odisp, oval = oracle.refine(cv, edisp, eval_, dmin, dmax, 1, is_max, "vfit")
+    np.testing.assert_array_equal(rdisp, odisp)
+    np.testing.assert_array_equal(rval, oval)
+    np.testing.assert_array_equal(ritp, oitp)
+    full.free()
 
 
-def test_sharded_wta_with_rccl():
-    pytest.importorskip("torch")
-    out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
-    assert "DIST_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+@pytest.mark.parametrize("H", [64, 61])
+def test_row_tile_gather_through_rccl(world1, H):
+    """pmx_tile_place + ncclAllGather (in place when the rows divide evenly, staged otherwise) + pmx_get_full_maps."""
+    eng, comm = world1
+    rng = np.random.default_rng(H)
+    W, margin = 40, 7
+    tile = rng.random((H + margin, W)).astype(np.float32)
+    eng.set_images(tile, tile, 1)
+    val = rng.integers(0, 4096, (H + margin, W)).astype(np.int64)
+    eng.set_disparity(tile * 3, val)
+    cv = eng.alloc_cv(3, 0)
+    cv.from_host(rng.random((H + margin, W, 3)).astype(np.float32))
+    eng.refine(cv, "vfit", False)  # fills the coefficient map
+    d, v, t = eng.get_disparity(want_itp=True)
+    eng.tile_place(H, 0, H, 0, True)   # the tile starts at image row 0 and owns rows [0, H)
+    comm.allgather_rows(H, True)
+    fd, fv, ft = eng.get_full_maps(H, want_itp=True)
+    np.testing.assert_array_equal(fd, d[:H])
+    np.testing.assert_array_equal(fv, v[:H])
+    np.testing.assert_array_equal(ft, t[:H])
+    # a tile that starts above its owned rows
+    eng.tile_place(H + margin - 5, 5, H + margin - 5, 0, False)
+    fd, fv = eng.get_full_maps(H + margin - 5)
+    np.testing.assert_array_equal(fd[5:], d[5:H + margin - 5])
+    cv.free()
+
+
+def test_host_scalars_through_rccl(world1):
+    _, comm = world1
+    out = comm.engine.comm_allreduce_scalars(np.arange(8, dtype=np.float64), "max")
+    np.testing.assert_array_equal(out, np.arange(8.0))

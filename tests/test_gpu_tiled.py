@@ -1,4 +1,5 @@
-"""GPU: pandora_amd.dist.run_row_tiled with TWO ranks (gloo rendezvous, both on the box's one GPU) against the untiled
+"""GPU: pandora_amd.dist.run_row_tiled / run_d_sharded with TWO ranks, both on the box's one GPU (RCCL refuses two ranks on one
+device, so the exchange buffers travel through pandora_amd.comm's "tcp" test transport; no PyTorch involved) against the untiled
 run: a local pipeline must be identical everywhere; a census+SGM pipeline is cut at the 40-row margin like the reference's
 own ROI tiling, so it may differ on a few pixels but must stay within the cones gate."""
 import os
@@ -14,15 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = r'''
 import os, sys
 import numpy as np
-import torch, torch.distributed as dist          # torch first (its HIP runtime), then libpandora_amd.so
 sys.path.insert(0, %(root)r)
 from PIL import Image
 import pandora_amd
-from pandora_amd import dist as pdist
+from pandora_amd import dist as pdist, runtime
+from pandora_amd.comm import Comm
 from pandora_amd.dataset import make_image
 from pandora_amd.state_machine import PandoraMachine
-dist.init_process_group("gloo")
-rank = dist.get_rank()
+comm = Comm(runtime.get_engine(), backend="tcp")
+rank = comm.rank
 cones = os.path.join(%(root)r, "tests", "golden", "cones")
 L = np.array(Image.open(os.path.join(cones, "left.png"))).astype(np.float32)
 R = np.array(Image.open(os.path.join(cones, "right.png"))).astype(np.float32)
@@ -37,7 +38,7 @@ SGM = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_
                     "validation": {"validation_method": "cross_checking_accurate"}}}
 for name, cfg in (("local", LOCAL), ("sgm", SGM)):
     left, right = make_image(L, disparity=[-60, 0]), make_image(R, disparity=[0, 60])
-    tl, tr = pdist.run_row_tiled(left, right, cfg, margin=40)
+    tl, tr = pdist.run_row_tiled(left, right, cfg, margin=40, comm=comm)
     if rank == 0:
         m = PandoraMachine()
         full_cfg = {"pipeline": m.check_conf({"pipeline": cfg["pipeline"]}, left, right)["pipeline"]}
@@ -52,35 +53,43 @@ for name, cfg in (("local", LOCAL), ("sgm", SGM)):
             assert bad.sum() / gt.size <= 0.20 and tr is not None and tr["disparity_map"].shape == L.shape
             print("SGM_TILED_SAME_FRACTION", same.mean())
             assert same.mean() > 0.97
-dist.barrier()
-dist.destroy_process_group()
+comm.barrier()
+comm.close()
 if rank == 0:
     print("TILED_OK")
 '''
 
 
+def two_ranks(script, port):
+    """Both ranks on the box's one GPU, launched as plain processes with the launcher's environment variables."""
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    outs = [p.communicate(timeout=900) for p in procs]
+    return outs[0][0], "".join(o[0][-2000:] + o[1][-4000:] for o in outs)
+
+
 def test_row_tiled_pair_over_two_ranks(tmp_path):
-    pytest.importorskip("torch")
     script = tmp_path / "tiled.py"
     script.write_text(SCRIPT % {"root": ROOT})
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0")  # both ranks on the box's one GPU
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert "TILED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    out, log = two_ranks(script, 29541)
+    assert "TILED_OK" in out, log
 
 
 DSHARD = r'''
 import os, sys
 import numpy as np
-import torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)
 from PIL import Image
 import pandora_amd
-from pandora_amd import dist as pdist
+from pandora_amd import dist as pdist, runtime
+from pandora_amd.comm import Comm
 from pandora_amd.dataset import make_image
 from pandora_amd.state_machine import PandoraMachine
-dist.init_process_group("gloo")
-rank = dist.get_rank()
+comm = Comm(runtime.get_engine(), backend="tcp")
+rank = comm.rank
 cones = os.path.join(%(root)r, "tests", "golden", "cones")
 L = np.array(Image.open(os.path.join(cones, "left.png"))).astype(np.float32)[40:200, 30:330]
 R = np.array(Image.open(os.path.join(cones, "right.png"))).astype(np.float32)[40:200, 30:330]
@@ -94,7 +103,7 @@ CASES = [
 ]
 for pipe, m in CASES:
     left, right = make_image(L, disparity=[-37, 3], msk=m), make_image(R, msk=m)
-    got = pdist.run_d_sharded(left, right, {"pipeline": pipe})
+    got = pdist.run_d_sharded(left, right, {"pipeline": pipe}, comm)
     if rank == 0:
         left, right = make_image(L, disparity=[-37, 3], msk=m), make_image(R, msk=m)
         mach = PandoraMachine()
@@ -102,8 +111,8 @@ for pipe, m in CASES:
         full, _ = pandora_amd.run(mach, left, right, cfg)
         for key in got:
             np.testing.assert_array_equal(got[key], np.asarray(full[key].data), err_msg=key + " " + pipe["matching_cost"]["matching_cost_method"])
-dist.barrier()
-dist.destroy_process_group()
+comm.barrier()
+comm.close()
 if rank == 0:
     print("DSHARD_OK")
 '''
@@ -112,10 +121,7 @@ if rank == 0:
 def test_d_sharded_pair_over_two_ranks(tmp_path):
     """pandora_amd.dist.run_d_sharded (costs sharded over D, one all_reduce(MIN) of packed keys, owner-rank refinement) with two
     ranks == the unsharded machine run, bit for bit: ZNCC sub-pixel + vfit, SAD + CBCA + quadratic with masks, census."""
-    pytest.importorskip("torch")
     script = tmp_path / "dshard.py"
     script.write_text(DSHARD % {"root": ROOT})
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29543", str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert "DSHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-6000:]
+    out, log = two_ranks(script, 29543)
+    assert "DSHARD_OK" in out, log

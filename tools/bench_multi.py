@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""ONE stereo pair over the GPUs of a node (strong scaling), the two layouts of SURVEY 8e:
-  --mode tiled   row tiles with a 40-row margin, any pipeline (BASELINE configs[4]'s layout; default census + SGM)
-  --mode dshard  cost volume sharded over D, one all_reduce(MIN) of packed keys (BASELINE configs[3]'s layout without the SGM
-                 step: ZNCC 11x11 + WTA + vfit)
-Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_multi.py --mode tiled
-(one rank per GPU, backend nccl = RCCL; PANDORA_BENCH_BACKEND=gloo PANDORA_AMD_DEVICE=0 runs several ranks on one GPU for tests).
-Rank 0 prints one JSON line: wall time per pair (max over ranks) and Mdisp/s of the whole pair."""
+"""ONE stereo pair over the GPUs of a node with the cost volume sharded over D (BASELINE configs[3]'s layout for the
+steps that shard exactly: ZNCC 11x11 + WTA + vfit; the SGM step of that configuration does not shard over D, bench.py --gpus N
+runs SGM pipelines over row tiles).  Every exchange is a RCCL collective inside libpandora_amd.so on device buffers:
+ncclAllReduce(min, uint64) of the packed keys, ncclAllReduce(sum) of the owner-refined maps.
+Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_multi.py
+(only the launcher's environment variables are used; PANDORA_COMM_BACKEND=tcp PANDORA_BENCH_DEVICE=0 runs several ranks on one GPU).
+Rank 0 prints one JSON line: wall time per pair (max over ranks), Mdisp/s of the whole pair, ms spent in the collectives."""
 import argparse
 import json
 import os
@@ -16,60 +16,57 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from pandora_amd import dist as pdist  # noqa: E402
+from pandora_amd.comm import Comm, env_world  # noqa: E402
+from pandora_amd.engine import Engine  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["tiled", "dshard"], default="tiled")
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)
-    ap.add_argument("--dmin", type=int, default=-128)
-    ap.add_argument("--dmax", type=int, default=0)
+    ap.add_argument("--dmin", type=int, default=0)
+    ap.add_argument("--dmax", type=int, default=256)
+    ap.add_argument("--win", type=int, default=11)
     ap.add_argument("--steps", type=int, default=3)
     args = ap.parse_args()
-    import torch
-    import torch.distributed as dist
-
-    backend = os.environ.get("PANDORA_BENCH_BACKEND", "nccl")
-    local = int(os.environ.get("PANDORA_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group(backend)
-    import bench
-    from pandora_amd import dist as pdist
-    from pandora_amd.dataset import make_image
-
+    rank, world, local_rank, _, _ = env_world()
+    eng = Engine(int(os.environ.get("PANDORA_BENCH_DEVICE", local_rank)))
+    comm = Comm(eng, always=True)
     H, W, dmin, dmax = args.height, args.width, args.dmin, args.dmax
-    R, L = bench.synthetic_pair(H, W, 0, dmax - dmin)  # (swapped: Pandora's convention wants negative disparities here)
-    left, right = make_image(L, disparity=[dmin, dmax]), make_image(R, disparity=[-dmax, -dmin])
-    if args.mode == "tiled":
-        cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
-                            "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
-                            "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
-                            "refinement": {"refinement_method": "vfit"}}}
-        run = lambda: pdist.run_row_tiled(left, right, cfg, margin=40)[0]
-    else:
-        cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "zncc", "window_size": 11},
-                            "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
-                            "refinement": {"refinement_method": "vfit"}}}
-        run = lambda: pdist.run_d_sharded(left, right, cfg)
-    out = run()
-    dist.barrier()
+    L, R = bench.synthetic_pair(H, W, dmin, dmax)
+    eng.set_images(L, R, 1)
+    (olo, ohi), (wlo, whi) = pdist.disparity_shard(dmin, dmax, 1, world, rank, halo=1)
+    cv = eng.alloc_cv(whi - wlo + 1, wlo)
+
+    def step():
+        eng.zncc(cv, args.win)
+        eng.set_validity(None)
+        pdist.sharded_wta(eng, comm, cv, True, wlo - dmin, dmin, 1, -9999.0)
+        eng.shard_refine_pack(cv, "vfit", True, olo, ohi, rank == world - 1)
+        comm.allreduce_xbuf("refine_pack", "sum")
+        comm.allreduce_xbuf("refine_flags", "sum")
+        eng.shard_refine_unpack()
+
+    step()
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    if dist.get_rank() == 0:
-        ms = float(t.item()) / args.steps * 1e3
+        step()
+    eng.sync()
+    dt = float(comm.host_allreduce(np.array([time.perf_counter() - t0]), "max")[0]) / args.steps
+    coll = eng.stage_time("collective")[0] / args.steps
+    if rank == 0:
         cells = H * W * (dmax - dmin + 1)
-        print(json.dumps({"mode": args.mode, "n_gpus": dist.get_world_size(), "shape": [H, W, dmax - dmin + 1], "ms_per_pair": round(ms, 2),
-                          "value": round(cells / ms / 1e3, 1), "unit": "Mdisp/s", "scaling": "strong",
-                          "note": "functional flow through the Python plugin API: the time is dominated by host-side numpy and by gathering the 2-D maps on every rank, not by the kernels (bench.py measures those)",
-                          "finite_fraction": float(np.isfinite(out["disparity_map"]).mean())}), flush=True)
-    dist.destroy_process_group()
+        print(json.dumps({"mode": "D-sharded ZNCC + WTA + vfit", "n_gpus": world, "shape": [H, W, dmax - dmin + 1], "ms_per_pair": round(dt * 1e3, 3),
+                          "Mdisp/s": round(cells / dt / 1e6, 1), "collective_ms_per_pair": round(coll, 3),
+                          "collective_bytes_per_pair": H * W * (8 + 16 + 8)}))
+    comm.barrier()
+    comm.close()
+    eng.close()
 
 
 if __name__ == "__main__":
