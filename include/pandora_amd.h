@@ -77,6 +77,8 @@ void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv);
 int pmx_cv_fill_nan(pmx_ctx* ctx, pmx_cv* cv);
 int pmx_cv_upload(pmx_ctx* ctx, pmx_cv* cv, const float* host);   /* cv["cost_volume"].data = ... */
 int pmx_cv_download(pmx_ctx* ctx, pmx_cv* cv, float* host);       /* ... = cv["cost_volume"].data */
+/* rows [row_lo, row_hi) of the volume only (cv["cost_volume"].data[row_lo:row_hi]): a 17 GB volume need not cross PCIe whole */
+int pmx_cv_download_rows(pmx_ctx* ctx, pmx_cv* cv, int row_lo, int row_hi, float* host);
 int pmx_cv_dims(const pmx_cv* cv, int* H, int* W, int* D, int* d0, int* subpix);
 
 /* ---- matching cost -------------------------------------------------------------------------- */

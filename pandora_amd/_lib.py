@@ -34,6 +34,7 @@ SIGNATURES = {
     "pmx_cv_fill_nan": (C.c_int, [vp, vp]),
     "pmx_cv_upload": (C.c_int, [vp, vp, c_float_p]),
     "pmx_cv_download": (C.c_int, [vp, vp, c_float_p]),
+    "pmx_cv_download_rows": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "pmx_cv_dims": (C.c_int, [vp, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "pmx_census": (C.c_int, [vp, vp, C.c_int]),
     "pmx_sad_ssd": (C.c_int, [vp, vp, C.c_int, C.c_int]),

@@ -508,6 +508,21 @@ extern "C" int pmx_cv_download(pmx_ctx* ctx, pmx_cv* cv, float* host) {
     return pmx_check_async_error(ctx, "pmx_cv_download");
 }
 
+extern "C" int pmx_cv_download_rows(pmx_ctx* ctx, pmx_cv* cv, int row_lo, int row_hi, float* host) {
+    PMX_CHECK(ctx && cv && host, PMX_ERR_ARG, "pmx_cv_download_rows: null argument");
+    PMX_CHECK(0 <= row_lo && row_lo < row_hi && row_hi <= cv->H, PMX_ERR_ARG, "pmx_cv_download_rows: rows [%d, %d) of %d", row_lo, row_hi, cv->H);
+    PMX_HIP(hipSetDevice(ctx->device));
+    {
+        int rc = pmx_cv_materialize(ctx, cv);
+        if (rc) return rc;
+    }
+    const size_t row = (size_t)cv->W * cv->D;
+    PMX_HIP(hipMemcpyAsync(host, cv->data + (size_t)row_lo * row, (size_t)(row_hi - row_lo) * row * sizeof(float), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return pmx_check_async_error(ctx, "pmx_cv_download_rows");
+}
+
 extern "C" int pmx_cv_dims(const pmx_cv* cv, int* H, int* W, int* D, int* d0, int* subpix) {
     PMX_CHECK(cv, PMX_ERR_ARG, "pmx_cv_dims: null cv");
     if (H) *H = cv->H;

@@ -30,6 +30,13 @@ class DeviceCostVolume:
         check(_lib.lib().pmx_cv_download(self.engine.ctx, self.handle, _p(out, C.c_float)), "pmx_cv_download")
         return out
 
+    def rows_to_host(self, row_lo, row_hi):
+        """cost_volume[row_lo:row_hi] (float32 [rows][W][D])"""
+        H, W, D = self.shape
+        out = np.empty((row_hi - row_lo, W, D), np.float32)
+        check(_lib.lib().pmx_cv_download_rows(self.engine.ctx, self.handle, int(row_lo), int(row_hi), _p(out, C.c_float)), "pmx_cv_download_rows")
+        return out
+
     def from_host(self, arr):
         arr = np.ascontiguousarray(arr, np.float32)
         if arr.shape != self.shape:
