@@ -67,8 +67,11 @@ __global__ __launch_bounds__(kBlock) void median3_inf_kernel(const float* __rest
 }
 
 // aggregation.cpp:224-321 on the image cropped by `o` on every side
+// (pitch, xoff): pixels per output row and where column 0 sits in it (dense: Wc, 0; the four-disparity kernels read the right
+// image's arms 4 pixels at a time from rows padded by 4 zeroed pixels on either side)
 __global__ __launch_bounds__(kBlock) void cross_support_kernel(const float* __restrict__ img, int Wd, int o, int Hc, int Wc,
-                                                               int len_arms, float intensity, int16_t* __restrict__ cross) {
+                                                               int len_arms, float intensity, int16_t* __restrict__ cross, int pitch,
+                                                               int xoff) {
     int col = blockIdx.x * kBlock + threadIdx.x;
     int row = blockIdx.y;
     if (col >= Wc) return;
@@ -90,11 +93,11 @@ __global__ __launch_bounds__(kBlock) void cross_support_kernel(const float* __re
         dn = max((int)dn, (int)(row < Hc - 1 && isfinite(at(row + 1, col))));
     }
     short4 v = make_short4(l, rt, up, dn);
-    *reinterpret_cast<short4*>(cross + ((size_t)row * Wc + col) * 4) = v;
+    *reinterpret_cast<short4*>(cross + ((size_t)row * pitch + col + xoff) * 4) = v;
 }
 
 // builds the arms of image `side` (0 = left, k+1 = k-th shifted right) into dev_out; tmp = 2 images
-static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int distance, float* tmp, int16_t* dev_out) {
+static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int distance, float* tmp, int16_t* dev_out, int pad = 0) {
     const int H = ctx->H, W = ctx->W;
     const float* img = side == 0 ? ctx->left : ctx->right[side - 1];
     const int16_t* msk = side == 0 ? ctx->msk_left : ctx->msk_right;
@@ -108,7 +111,8 @@ static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int d
     int Hc = H - 2 * offset, Wc = Wd - 2 * offset;
     if (Hc <= 0 || Wc <= 0) return PMX_OK;
     dim3 g2((Wc + kBlock - 1) / kBlock, Hc);
-    hipLaunchKernelGGL(cross_support_kernel, g2, dim3(kBlock), 0, ctx->stream, med, Wd, offset, Hc, Wc, distance, intensity, dev_out);
+    hipLaunchKernelGGL(cross_support_kernel, g2, dim3(kBlock), 0, ctx->stream, med, Wd, offset, Hc, Wc, distance, intensity, dev_out,
+                       Wc + 2 * pad, pad);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
@@ -131,6 +135,11 @@ struct cbca_args {
     int H, W, D, d0, subpix, o, Hc, Wc;
     int A;       // longest possible arm
     int ring;    // power of two >= 2A+2
+    // four-disparity kernels (subpix 1): right arms in rows of Wc + 8 pixels (pixel q at index q + 4, pads zero), NaN flags of
+    // the input costs as 4 bits per (row, column, group of 4 disparities): uint32 [Hc][ceil(Wc/8)][G], column c in bits 4*(c%8)..
+    const int16_t* armsRpad;
+    uint32_t* nanbits;
+    int G;       // groups of 4 disparities per pixel
 };
 
 // combined arm lengths of the support cross at (r, c, k) packed as left | right<<8 | top<<16 | bot<<24;
@@ -493,43 +502,370 @@ __global__ __launch_bounds__(kBlock) void cbca_v_fast_kernel(cbca_args a) {
     }
 }
 
+// ---- four disparities per thread (subpix 1, cbca_distance <= 5) -----------------------------------------------------------
+// The scans above move 4 bytes per lane per memory instruction and are bound by the texture addresser (~30 cycles per vector
+// memory instruction per CU whatever its width: 4 - 5 of them per 64 cells).  Here a thread owns FOUR consecutive disparities of
+// its row / column: 16-byte loads and stores, the left image's arms loaded once for the four, the right image's four arms as
+// two 16-byte loads from rows padded by 4 pixels.  Per cell the arithmetic and its order are unchanged.  Both passes work IN
+// PLACE on the volume (a scan's output cell was read by the same thread A steps earlier), so no second volume is needed, and
+// pass V learns which input costs were NaN from 4 bits per cell group written by pass H instead of re-reading the costs.
+static constexpr int kBlock4 = 128;
+static constexpr int kRing4 = 16;  // >= 3A+3 for A <= 4
+static constexpr int kPF4 = 8;     // columns / rows of read-ahead
+
+typedef unsigned int cb_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cb_u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kCbRsrc3 = 0x00020000;  // raw buffer descriptor word 3 (as k_sgmfam.hip): 4-byte alignment is enough for 16-byte accesses
+constexpr unsigned kCbOob = 0x80000000u;   // an offset past every buffer: the store is dropped
+
+struct cb_arms4 { uint32_t lr[4], tb[4]; };
+// 4 consecutive pixels of an arms row = 32 bytes at byte offset `off` of the buffer
+__device__ __forceinline__ cb_arms4 cb_load4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    const cb_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+    return {{a.x, a.z, b.x, b.z}, {a.y, a.w, b.y, b.w}};
+}
+__device__ __forceinline__ float4 cb_loadf4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    const cb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+typedef unsigned int cb_u3 __attribute__((ext_vector_type(3)));
+// stores the first nk of four values (nk = 4, or tailn = D % 4 on a pixel's last group): one 16-byte store for the full groups
+// and ONE narrower store (tailn is the same for every pixel) for the last ones; lanes a store does not concern give it an
+// out-of-range offset - no branch on lane-varying data around a memory instruction
+__device__ __forceinline__ void cb_storef4(__amdgpu_buffer_rsrc_t rs, unsigned off, int nk, int tailn, bool live, const float (&v)[4]) {
+    cb_u4 t;
+    t.x = __float_as_uint(v[0]); t.y = __float_as_uint(v[1]); t.z = __float_as_uint(v[2]); t.w = __float_as_uint(v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, (live && nk == 4) ? off : kCbOob, 0, 0);
+    const unsigned toff = (live && nk < 4) ? off : kCbOob;
+    if (tailn == 1) {  // uniform
+        __builtin_amdgcn_raw_buffer_store_b32(t.x, rs, toff, 0, 0);
+    } else if (tailn == 2) {
+        cb_u2 h; h.x = t.x; h.y = t.y;
+        __builtin_amdgcn_raw_buffer_store_b64(h, rs, toff, 0, 0);
+    } else if (tailn == 3) {
+        cb_u3 h; h.x = t.x; h.y = t.y; h.z = t.z;
+        __builtin_amdgcn_raw_buffer_store_b96(h, rs, toff, 0, 0);
+    }
+}
+__device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ unsigned cb_span(size_t bytes) { return bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes; }
+
+__global__ __launch_bounds__(kBlock4) void cbca_h4_kernel(cbca_args a) {
+    __shared__ float ring[kRing4 * kBlock4 * 4];  // [slot][disparity of the four][thread]: lanes on consecutive banks
+    const int t = blockIdx.x * kBlock4 + threadIdx.x;
+    const int total = a.Hc * a.G;
+    const bool live = t < total;
+    const int tt = live ? t : total - 1;
+    const int r = tt / a.G, g = tt - r * a.G, k0 = 4 * g;
+    const int nk = a.D - k0 < 4 ? a.D - k0 : 4;  // disparities this thread owns (the last group of a pixel may own fewer)
+    const int tailn = a.D & 3;
+    const int dq = a.d0 + k0;
+    constexpr int mask = kRing4 - 1;
+    const int A = a.A, Wc = a.Wc, D = a.D;
+    float* my = ring + threadIdx.x;
+    for (int s = 0; s < kRing4 * 4; ++s) my[s * kBlock4] = 0.f;  // S1 of columns < 0
+    // buffer descriptors: the volume from the block's first row on (a block spans a few rows: 32-bit offsets), the arms images
+    const int r0 = (blockIdx.x * kBlock4) / a.G;
+    const size_t vol_bytes = (size_t)a.H * a.W * D * 4 + 256;
+    const size_t base_el = ((size_t)(r0 + a.o) * a.W + a.o) * D;
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cv + base_el), 0, cb_span(vol_bytes - base_el * 4), kCbRsrc3);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsL, 0, cb_span((size_t)a.Hc * Wc * 8), kCbRsrc3);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsRpad, 0, cb_span((size_t)a.Hc * (Wc + 8) * 8), kCbRsrc3);
+    unsigned ov = (unsigned)(((size_t)(r - r0) * a.W * D + k0) * 4);  // cost of column c
+    unsigned oe = ov;                                                   // segment sum of column ce = c - A (in place)
+    const unsigned step_b = (unsigned)D * 4;
+    const unsigned oL = (unsigned)((size_t)r * Wc * 8);
+    const unsigned oR = (unsigned)(((size_t)r * (Wc + 8) + 4) * 8);  // pixel q at oR + 8 q
+    uint32_t* pn = a.nanbits + ((size_t)r * ((Wc + 7) / 8)) * a.G + g;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t nanword = 0;
+    auto prefix = [&](const float4& v, int c) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = comp(v, i);
+            acc[i] = (x == x) ? acc[i] + x : acc[i];  // NaN is skipped, the running sum carries on
+            bits |= (fabsf(x) < c_inf()) ? 0u : (1u << i);  // what pass V needs of the input: is `in * 0` a NaN (NaN or infinite cost)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) my[((c & mask) * 4 + i) * kBlock4] = acc[i];
+        nanword |= bits << (4 * (c & 7));
+        if ((c & 7) == 7 || c == Wc - 1) {
+            if (live) pn[(size_t)(c >> 3) * a.G] = nanword;
+            nanword = 0;
+        }
+    };
+    auto right_off = [&](int ce) {  // first of the four right-image pixels of column ce, clamped into the padded row
+        const int q0 = ce + dq;
+        return oR + (unsigned)((q0 < -4 ? -4 : (q0 > Wc ? Wc : q0)) * 8);
+    };
+    auto left_arms = [&](int ce) { return __builtin_amdgcn_raw_buffer_load_b64(rsL, oL + (unsigned)ce * 8, 0, 0); };
+    auto emit = [&](cb_u2 l, const cb_arms4& rr, int ce) {
+        float e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = ce + dq + i;
+            const bool inside = (q >= 0) & (q <= Wc - 1);
+            const uint32_t lr = cb_pk_min(l.x, rr.lr[i]);
+            const int left = (int)(lr & 0xffffu), right = (int)(lr >> 16);
+            const float hi_v = my[(((ce + right) & mask) * 4 + i) * kBlock4];
+            const float lo_v = my[(((ce - left - 1) & mask) * 4 + i) * kBlock4];
+            e[i] = inside ? hi_v - lo_v : 0.f;
+        }
+        cb_storef4(rsV, oe, nk, tailn, live, e);
+        oe += step_b;
+    };
+    int c = 0;
+    for (; c < A; ++c) {  // warm-up: columns whose segment cannot be closed yet
+        prefix(cb_loadf4(rsV, ov), c);
+        ov += step_b;
+    }
+    // steady state: a register ring of kPF4 columns in flight (a thread is nearly alone on its SIMD: nothing else hides HBM
+    // latency); slot j holds column c + j, is consumed and refilled with column c + j + kPF4 (clamped: surplus loads re-read
+    // the last column)
+    float4 vb[kPF4];
+    cb_u2 lb[kPF4];
+    cb_arms4 rb[kPF4];
+    auto fill = [&](int j, int col) {
+        const int cc = min(col, Wc - 1);
+        vb[j] = cb_loadf4(rsV, ov + (unsigned)(cc - c) * step_b);
+        const int ce = min(col - A, Wc - 1);
+        lb[j] = left_arms(ce);
+        rb[j] = cb_load4(rsR, right_off(ce));
+    };
+#pragma unroll
+    for (int j = 0; j < kPF4; ++j) fill(j, c + j);
+    for (; c + kPF4 <= Wc; c += kPF4) {
+#pragma unroll
+        for (int j = 0; j < kPF4; ++j) {
+            const float4 v = vb[j];
+            const cb_u2 l = lb[j];
+            const cb_arms4 rr = rb[j];
+            fill(j, c + j + kPF4);
+            prefix(v, c + j);
+            emit(l, rr, c + j - A);
+        }
+        ov += (unsigned)kPF4 * step_b;
+    }
+#pragma unroll
+    for (int j = 0; j < kPF4 - 1; ++j) {  // leftover columns: their data is already in the ring
+        if (c + j < Wc) {
+            prefix(vb[j], c + j);
+            emit(lb[j], rb[j], c + j - A);
+        }
+    }
+    c = Wc;
+    for (; c < Wc + A; ++c)  // drain
+        emit(left_arms(c - A), cb_load4(rsR, right_off(c - A)), c - A);
+}
+
+__global__ __launch_bounds__(kBlock4) void cbca_v4_kernel(cbca_args a) {
+    __shared__ float ring[2 * kRing4 * kBlock4 * 4];  // [2][slot][disparity of the four][thread]: column prefix sums; packed (N, top, bot)
+    const int t = blockIdx.x * kBlock4 + threadIdx.x;
+    const int total = a.Wc * a.G;
+    const bool live = t < total;
+    const int tt = live ? t : total - 1;
+    const int c = tt / a.G, g = tt - c * a.G, k0 = 4 * g;
+    const int nk = a.D - k0 < 4 ? a.D - k0 : 4;
+    const int tailn = a.D & 3;
+    const int q0 = c + a.d0 + k0;
+    constexpr int mask = kRing4 - 1;
+    const int A = a.A, Hc = a.Hc, Wc = a.Wc;
+    bool inside[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inside[i] = (q0 + i >= 0) & (q0 + i <= Wc - 1);  // the same right columns for every row
+    float* s3 = ring + threadIdx.x;
+    uint32_t* info = reinterpret_cast<uint32_t*>(ring) + kRing4 * kBlock4 * 4 + threadIdx.x;
+    for (int s = 0; s < kRing4 * 4; ++s) {  // row -1: zero sums, zero counts
+        s3[s * kBlock4] = 0.f;
+        info[s * kBlock4] = 0u;
+    }
+    // every thread of the block is on the same image row: the row is the (wave-uniform) descriptor, the thread's offset inside it
+    // never changes
+    const size_t row_bytes = (size_t)a.W * a.D * 4;
+    const unsigned ocol = (unsigned)(((size_t)(c + a.o) * a.D + k0) * 4);
+    auto row_rsrc = [&](int r) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.cv + (size_t)(r + a.o) * row_bytes), 0, cb_span(row_bytes + 256), kCbRsrc3);
+    };
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsL, 0, cb_span((size_t)Hc * Wc * 8), kCbRsrc3);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsRpad, 0, cb_span((size_t)Hc * (Wc + 8) * 8), kCbRsrc3);
+    const unsigned oL = (unsigned)c * 8, oR = (unsigned)(((q0 < -4 ? -4 : (q0 > Wc ? Wc : q0)) + 4) * 8);
+    const unsigned strideL = (unsigned)Wc * 8, strideR = (unsigned)(Wc + 8) * 8;  // bytes per arms row
+    const uint32_t* pn = a.nanbits + (size_t)(c >> 3) * a.G + g;
+    const size_t strideN = (size_t)((Wc + 7) / 8) * a.G;
+    const int nshift = 4 * (c & 7);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t nacc[4] = {0u, 0u, 0u, 0u};
+    auto prefix = [&](const float4& e4, cb_u2 l, const cb_arms4& rr, int r) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e = comp(e4, i);
+            acc[i] = (r == 0) ? e : acc[i] + e;
+            const uint32_t lr = cb_pk_min(l.x, rr.lr[i]), tb = cb_pk_min(l.y, rr.tb[i]);
+            // ring word: running count N(r) of n_h = left + right in bits 0..19, top in bits 20..25, bot in bits 26..31
+            // (63, 63 = this cell is outside the right image, n_h = 0)
+            nacc[i] += inside[i] ? (lr & 0xffffu) + (lr >> 16) : 0u;
+            w[i] = nacc[i] | (inside[i] ? (((tb & 0xffffu) << 20) | ((tb >> 16) << 26)) : ((63u << 20) | (63u << 26)));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s3[((r & mask) * 4 + i) * kBlock4] = acc[i];
+            info[((r & mask) * 4 + i) * kBlock4] = w[i];
+        }
+    };
+    auto emit = [&](uint32_t nanword, int re) {
+        float out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = info[((re & mask) * 4 + i) * kBlock4];
+            const int top = (w >> 20) & 63, bot = w >> 26;
+            const bool cell = top != 63;
+            const int hi_i = cell ? re + bot : re, lo_i = cell ? re - top - 1 : re;
+            const float step = s3[((hi_i & mask) * 4 + i) * kBlock4] - s3[((lo_i & mask) * 4 + i) * kBlock4];
+            const uint32_t n = (info[((hi_i & mask) * 4 + i) * kBlock4] & 0xfffffu) - (info[((lo_i & mask) * 4 + i) * kBlock4] & 0xfffffu) +
+                               (uint32_t)(top + bot);
+            const float step4 = cell ? step : 0.f;
+            const float sum4 = (cell ? (float)n : 0.f) + 1.f;  // small exact integers: any order
+            const float in0 = ((nanword >> (nshift + i)) & 1u) ? c_nan() : 0.f;  // in * 0: NaN stays NaN (cbca.py:145-146,168-171)
+            out[i] = (in0 + step4) / sum4;
+        }
+        cb_storef4(row_rsrc(re), ocol, nk, tailn, live, out);  // over the E_h read A steps ago
+    };
+    auto fetch = [&](int row, float4& e, cb_u2& l, cb_arms4& rr) {
+        e = cb_loadf4(row_rsrc(row), ocol);  // E_h of the row (pass H left it in place of the costs)
+        l = __builtin_amdgcn_raw_buffer_load_b64(rsL, oL + (unsigned)row * strideL, 0, 0);
+        rr = cb_load4(rsR, oR + (unsigned)row * strideR);
+    };
+    int r = 0;
+    for (; r < A; ++r) {  // warm-up
+        float4 e;
+        cb_u2 l;
+        cb_arms4 rr;
+        fetch(r, e, l, rr);
+        prefix(e, l, rr, r);
+    }
+    // steady state: a register ring of kPF4 rows in flight; the NaN word of row re = r - A travels with row r
+    float4 eb[kPF4];
+    cb_u2 lb[kPF4];
+    cb_arms4 rb[kPF4];
+    uint32_t nb[kPF4];
+    auto fill = [&](int j, int row) {
+        fetch(min(row, Hc - 1), eb[j], lb[j], rb[j]);  // clamped: surplus loads re-read the last row
+        nb[j] = pn[(size_t)(min(row, Hc - 1 + A) - A) * strideN];  // row - A >= 0 here
+    };
+#pragma unroll
+    for (int j = 0; j < kPF4; ++j) fill(j, r + j);
+    for (; r + kPF4 <= Hc; r += kPF4) {
+#pragma unroll
+        for (int j = 0; j < kPF4; ++j) {
+            const float4 e = eb[j];
+            const cb_u2 l = lb[j];
+            const cb_arms4 rr = rb[j];
+            const uint32_t nw = nb[j];
+            fill(j, r + j + kPF4);
+            prefix(e, l, rr, r + j);
+            emit(nw, r + j - A);
+        }
+    }
+    {
+        const int r0 = r;
+#pragma unroll
+        for (int j = 0; j < kPF4 - 1; ++j) {  // leftover rows: their data is already in the ring
+            if (r0 + j < Hc) {
+                prefix(eb[j], lb[j], rb[j], r0 + j);
+                emit(nb[j], r0 + j - A);
+                r = r0 + j + 1;
+            }
+        }
+    }
+    for (; r < Hc + A; ++r) emit(pn[(size_t)(r - A) * strideN], r - A);  // drain
+}
+
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance) {
     const int H = cv->H, W = cv->W, o = offset;
     const int Hc = H - 2 * o, Wc = W - 2 * o;
     if (Hc <= 0 || Wc <= 1) return PMX_OK;
-    // small scratch: 2 float images + arms of left and of every shifted right image
-    size_t img_bytes = (size_t)H * W * sizeof(float);
-    size_t arm_bytes = (size_t)Hc * Wc * 4 * sizeof(int16_t);
-    int rc = pmx_need_small(ctx, 2 * img_bytes + arm_bytes * (1 + cv->subpix));
+    cbca_args a;
+    a.A = distance - 1 > 1 ? distance - 1 : 1;
+    // kernel choice.  Default: the phase-split scans when the scanned dimension is long enough, else the generic ones.  The
+    // four-disparities-per-thread kernels work IN PLACE (no second volume: 51.6 GB less at 10000^2 x 129) but measured slower
+    // (2048^2 x 129: 2.15 + 2.97 ms against 1.50 + 1.96: a quarter of the waves, nothing left to hide latency), so they run when
+    // the second volume cannot be had, or on request.  PMX_CBCA_FAST (test hook): 0 generic, 2 phase-split, 4 in-place.
+    const char* ef = getenv("PMX_CBCA_FAST");
+    const int want = ef ? atoi(ef) : 1;
+    const bool long_scans = Wc >= 2 * a.A + 8 && Hc >= 2 * a.A + 8;
+    const bool four_ok = cv->subpix == 1 && 3 * a.A + 3 <= kRing4 && long_scans;
+    bool four = want == 4 && four_ok;
+    if (!four && four_ok && want == 1 && ctx->scratch_bytes < cv->cells() * sizeof(float) + 256) {
+        void* probe = nullptr;  // is there room for the second volume?
+        if (pmx_pool_alloc(ctx, &probe, cv->cells() * sizeof(float) + 256) == hipSuccess) {
+            pmx_pool_free(ctx, ctx->scratch);
+            ctx->scratch = (float*)probe;
+            ctx->scratch_bytes = cv->cells() * sizeof(float) + 256;
+        } else {
+            (void)hipGetLastError();
+            four = true;
+        }
+    }
+    const int G = (cv->D + 3) / 4;
+    // small scratch: 2 float images + arms of left and of every shifted right image (+ padded right arms and NaN bits)
+    const size_t img_bytes = (size_t)H * W * sizeof(float);
+    const size_t arm_bytes = (size_t)Hc * Wc * 4 * sizeof(int16_t);
+    const size_t pad_bytes = four ? (size_t)Hc * (Wc + 8) * 4 * sizeof(int16_t) : 0;
+    const size_t nan_bytes = four ? (size_t)Hc * ((Wc + 7) / 8) * G * sizeof(uint32_t) : 0;
+    int rc = pmx_need_small(ctx, 2 * img_bytes + arm_bytes * (1 + cv->subpix) + pad_bytes + nan_bytes);
     if (rc) return rc;
-    rc = pmx_need_scratch(ctx, cv->cells() * sizeof(float) + 256);
-    if (rc) return rc;
+    if (!four) {
+        rc = pmx_need_scratch(ctx, cv->cells() * sizeof(float) + 256);
+        if (rc) return rc;
+    }
     char* base = (char*)ctx->small;
     float* tmp = (float*)base;
-    cbca_args a;
     a.cv = cv->data;
-    a.eh = ctx->scratch;
+    a.eh = four ? nullptr : ctx->scratch;
     a.armsL = (int16_t*)(base + 2 * img_bytes);
     for (int k = 0; k < PMX_MAX_SUBPIX; ++k) a.armsR[k] = nullptr;
+    int16_t* padded = (int16_t*)(base + 2 * img_bytes + arm_bytes * (1 + cv->subpix));
+    a.armsRpad = padded;
+    a.nanbits = (uint32_t*)((char*)padded + pad_bytes);
+    a.G = G;
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_ARMS);
         rc = build_arms(ctx, 0, o, intensity, distance, tmp, (int16_t*)a.armsL);
         if (rc) return rc;
-        for (int k = 0; k < cv->subpix; ++k) {
-            int16_t* dst = (int16_t*)(base + 2 * img_bytes + arm_bytes * (1 + k));
-            a.armsR[k] = dst;
-            rc = build_arms(ctx, k + 1, o, intensity, distance, tmp, dst);
+        if (four) {
+            PMX_HIP(hipMemsetAsync(padded, 0, pad_bytes, ctx->stream));
+            rc = build_arms(ctx, 1, o, intensity, distance, tmp, padded, 4);
             if (rc) return rc;
+        } else {
+            for (int k = 0; k < cv->subpix; ++k) {
+                int16_t* dst = (int16_t*)(base + 2 * img_bytes + arm_bytes * (1 + k));
+                a.armsR[k] = dst;
+                rc = build_arms(ctx, k + 1, o, intensity, distance, tmp, dst);
+                if (rc) return rc;
+            }
         }
     }
     a.H = H; a.W = W; a.D = cv->D; a.d0 = cv->d0; a.subpix = cv->subpix; a.o = o; a.Hc = Hc; a.Wc = Wc;
-    a.A = distance - 1 > 1 ? distance - 1 : 1;
     int ring = 4;  // 2A+2 live columns + A+1 still-zero slots that stand for the columns before the first (phase-split kernels)
     while (ring < 3 * a.A + 3) ring <<= 1;
     a.ring = ring;
-    // the phase-split kernels need a scan much longer than the arms (PMX_CBCA_FAST=0: test hook for the generic ones)
-    const char* ef = getenv("PMX_CBCA_FAST");
-    const bool fast_ok = !(ef && ef[0] == '0');
+    if (four) {
+        {
+            pmx_stage_scope t(ctx, PMX_STAGE_CBCA_H);
+            const int total = Hc * G;
+            hipLaunchKernelGGL(cbca_h4_kernel, dim3((total + kBlock4 - 1) / kBlock4), dim3(kBlock4), 0, ctx->stream, a);
+        }
+        {
+            pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
+            const int total = Wc * G;
+            hipLaunchKernelGGL(cbca_v4_kernel, dim3((total + kBlock4 - 1) / kBlock4), dim3(kBlock4), 0, ctx->stream, a);
+        }
+        PMX_HIP(hipGetLastError());
+        return PMX_OK;
+    }
+    const bool fast_ok = want != 0;
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_H);
         int total = Hc * cv->D;

@@ -25,6 +25,7 @@
 // S read, the last pass also restores NaN / un-negates.  No MFMA: this is an HBM-bound scan.
 #include <cstdlib>
 
+#include "pmx_buf.h"
 #include "pmx_internal.h"
 
 static constexpr int kWavesPerBlock = 4;
@@ -73,22 +74,11 @@ struct sgm_args {
     int mask;  // multi: directions (bits, definition order) that are wanted; the others' blocks exit at once
 };
 
-template <int KPL>
-struct lane_vals {
-    float v[KPL];
-};
-
-// load KPL consecutive floats starting at p (4-byte aligned only)
-template <int KPL>
-__device__ __forceinline__ lane_vals<KPL> load_vals(const float* p) {
-    lane_vals<KPL> r;
-    __builtin_memcpy(&r, p, sizeof(float) * KPL);
-    return r;
-}
-
-// Walks one line.  TAIL = (D % KPL != 0): the last active lane owns fewer than KPL disparities
-// and must store element-wise; without a tail every active lane does one KPL-wide store.
-template <int KPL, int MODE, bool TAIL>
+// Walks one line.  Every access of the line's pixel is a raw buffer instruction on a descriptor of the pixel's image ROW (the
+// wave is on one row per step, so the descriptor lives in scalar registers): the lane's KPL floats move as 16 / 8 / 4-byte
+// pieces, the last lane of a pixel (fewer than KPL disparities when D is not a multiple of KPL) and the lanes beyond it are
+// handled by the range check of the instruction (pmx_buf.h), reads past the row return 0.
+template <int KPL, int MODE>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args a) {
     if (a.multi) {  // direction order of the definition above
         const int k = blockIdx.y;
@@ -98,33 +88,40 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         if (!(a.mask >> k & 1)) return;
     }
     const int lane = threadIdx.x & 63;
-    const int line = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int line = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool horizontal = (a.dr == 0);
     const int nlines = horizontal ? a.H : a.W;
     if (line >= nlines) return;
     const int nsteps = horizontal ? a.W : a.H;
     const int D = a.D;
     const int d_first = lane * KPL;
-    const bool lane_active = d_first < D;  // lane owns at least one disparity
-    const size_t pix_stride = (size_t)D;
+    const int nv = d_first >= D ? 0 : (D - d_first < KPL ? D - d_first : KPL);  // disparities this lane owns
+    const bool is_tail = nv > 0 && nv < KPL;
+    const int tailn = D % KPL;  // uniform
+    using P = pieces<KPL>;
+    int cov = 0;  // uniform: what the wide pieces cover of the tail lane
+#pragma unroll
+    for (int i = 0; i < P::N; ++i)
+        if (P::start(i) + P::width(i) <= tailn) cov = P::start(i) + P::width(i);
+    const int rem = tailn - cov;
+    const unsigned row_bytes = (unsigned)a.W * (unsigned)D * 4u, pix_bytes = (unsigned)D * 4u;
+    const unsigned lane_load = (unsigned)(nv ? d_first : 0) * 4u;  // lanes without a disparity read the pixel's d = 0
+    const unsigned lane_store = nv ? (unsigned)d_first * 4u : kOob;
+    auto row_rsrc = [&](const float* vol, int r) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (size_t)r * a.W * D), 0, row_bytes, kRsrcWord3);
+    };
 
-    // cursor of the pixel being computed and of the pixel being prefetched
+    // cursor of the pixel being computed and of the pixel being prefetched (wave-uniform)
     int r = horizontal ? line : (a.dr > 0 ? 0 : a.H - 1);
     int c = horizontal ? (a.dc > 0 ? 0 : a.W - 1) : line;
     int pr = r, pc = c;
 
-    lane_vals<KPL> cbuf[kPF];
-    lane_vals<KPL> sbuf[kPF];
-    // Loads are UNCONDITIONAL straight-line code (a load under a branch makes the compiler wait for
-    // it at the join, which would serialise the ring): lanes that own no disparity read the pixel's
-    // d = 0 instead, and read-ahead past the end of the line re-reads its last pixel.
-    const int d_load = lane_active ? d_first : 0;
-    int pleft = nsteps - 1;  // steps the prefetch cursor may still advance
-
-    auto prefetch = [&](lane_vals<KPL>& cslot, lane_vals<KPL>& sslot) {
-        size_t poff = ((size_t)pr * a.W + pc) * pix_stride + d_load;
-        cslot = load_vals<KPL>(a.C + poff);
-        if (MODE & SGM_READS_S) sslot = load_vals<KPL>(a.S + poff);
+    float cbuf[kPF][KPL], sbuf[kPF][KPL];
+    int pleft = nsteps - 1;  // steps the prefetch cursor may still advance (read-ahead past the end re-reads the last pixel)
+    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
+        const unsigned off = (unsigned)pc * pix_bytes + lane_load;
+        buf_load<KPL>(row_rsrc(a.C, pr), off, cslot);
+        if (MODE & SGM_READS_S) buf_load<KPL>(row_rsrc(a.S, pr), off, sslot);
         if (pleft > 0) {
             --pleft;
             pr += a.dr;
@@ -137,21 +134,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
 
     float Lp[KPL];  // path costs of the previous pixel (+inf on padded disparities)
 #pragma unroll
-    for (int k = 0; k < KPL; ++k) Lp[k] = (!TAIL || d_first + k < D) && lane_active ? 0.f : f_inf();
+    for (int k = 0; k < KPL; ++k) Lp[k] = k < nv ? 0.f : f_inf();
     float M = 0.f;  // min_k Lp; (Lp = 0, M = 0) reproduces L = C' on the first pixel of a path
 
-    auto step = [&](lane_vals<KPL>& cslot, lane_vals<KPL>& sslot) {
-        const size_t off = ((size_t)r * a.W + c) * pix_stride + d_first;
+    auto step = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
         // neighbours across the lane boundary
         const float below = from_lane_below(Lp[KPL - 1], f_inf());
         const float above = from_lane_above(Lp[0], f_inf());
         const float mp2 = M + a.P2;
-        float Ln[KPL];
-        lane_vals<KPL> out;
+        float Ln[KPL], out[KPL];
         float lmin = f_inf();
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
-            float cr = cslot.v[k];
+            float cr = cslot[k];
             float cc = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
             float lo = (k > 0) ? Lp[k - 1] : below;
             float hi = (k < KPL - 1) ? Lp[k + 1] : above;
@@ -159,24 +154,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
             float t = fmin2(Lp[k], nb);
             t = fmin2(t, mp2);
             float l = cc + (t - M);
-            bool valid = lane_active && (!TAIL || d_first + k < D);
-            Ln[k] = valid ? l : f_inf();
+            Ln[k] = k < nv ? l : f_inf();
             lmin = fmin2(lmin, Ln[k]);
-            float s = (MODE & SGM_READS_S) ? (sslot.v[k] + l) : l;
+            float s = (MODE & SGM_READS_S) ? (sslot[k] + l) : l;
             if (MODE & SGM_EPILOGUE) {
                 if (a.overcounting) s = s - 7.0f * cc;
                 if (a.is_max) s = -s;
                 if (cr != cr) s = f_nan();
             }
-            out.v[k] = s;
+            out[k] = s;
         }
-        if (!TAIL) {
-            if (lane_active) __builtin_memcpy(a.S + off, &out, sizeof(float) * KPL);
-        } else {
-#pragma unroll
-            for (int k = 0; k < KPL; ++k)
-                if (d_first + k < D) a.S[off + k] = out.v[k];
-        }
+        buf_store<KPL>(row_rsrc(a.S, r), (unsigned)c * pix_bytes + lane_store, nv, is_tail, cov, rem, out);
         // refill this ring slot with pixel i + kPF.  Issued AFTER the slot's last use so the new data
         // lands in the same registers (no copy, hence no wait, at the loop back-edge).
         prefetch(cslot, sslot);
@@ -190,7 +178,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         if (!horizontal && (c >= a.W || c < 0)) {
             c = (c >= a.W) ? 0 : a.W - 1;
 #pragma unroll
-            for (int k = 0; k < KPL; ++k) Lp[k] = (!TAIL || d_first + k < D) && lane_active ? 0.f : f_inf();
+            for (int k = 0; k < KPL; ++k) Lp[k] = k < nv ? 0.f : f_inf();
             M = 0.f;
         }
     };
@@ -218,14 +206,7 @@ static void sgm_launch_direction(pmx_ctx* ctx, const sgm_args& base, int k, int 
     dim3 grid((nlines + kWavesPerBlock - 1) / kWavesPerBlock);
     dim3 block(kWavesPerBlock * 64);
     pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
-    const bool tail = (a.D % KPL) != 0;
-#define PMX_SGM_LAUNCH(MODE)                                                                                       \
-    do {                                                                                                           \
-        if (tail)                                                                                                  \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, MODE, true>), grid, block, 0, ctx->stream, a); \
-        else                                                                                                       \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, MODE, false>), grid, block, 0, ctx->stream, a); \
-    } while (0)
+#define PMX_SGM_LAUNCH(MODE) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, MODE>), grid, block, 0, ctx->stream, a)
     switch (mode) {
         case 0: PMX_SGM_LAUNCH(0); break;
         case SGM_READS_S: PMX_SGM_LAUNCH(SGM_READS_S); break;
@@ -296,10 +277,7 @@ static int sgm_run_parallel(pmx_ctx* ctx, sgm_args a, float* paths, size_t cells
     dim3 block(kWavesPerBlock * 64);
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
-        if ((a.D % KPL) != 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, 0, true>), grid, block, 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, 0, false>), grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_path_kernel<KPL, 0>), grid, block, 0, ctx->stream, a);
     }
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);

@@ -30,12 +30,11 @@
 // waves + 1 hand-off wave per workgroup.  Loads of C and S run PF rows ahead in a register ring.  No MFMA: HBM-bound.
 #include <cstdlib>
 
+#include "pmx_buf.h"
 #include "pmx_internal.h"
 
 namespace {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 // This translation unit is compiled with -fno-honor-nans (v_min_f32 without the canonicalising v_max that IEEE mode otherwise
@@ -50,9 +49,7 @@ __device__ __forceinline__ float dpp(float src) {  // lanes without a source lan
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), CTRL, 0xf, 0xf, true));
 }
 
-constexpr unsigned kRsrcWord3 = 0x00020000;  // raw buffer: out-of-range loads return 0, out-of-range stores are dropped
-constexpr unsigned kOob = 0x80000000u;       // a byte offset beyond every row: lanes that must not touch memory use it
-constexpr int kSc1 = 16;                     // aux bit of the buffer instructions: write-through store / L1-bypassing load
+constexpr int kSc1 = 16;  // aux bit of the buffer instructions: write-through store / L1-bypassing load
 
 struct fam_args {
     const float* C;  // raw cost volume [H][W][D] (NaN = invalid)
@@ -71,79 +68,6 @@ struct fam_args {
 };
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls before a hand-off gives up (seconds; a healthy wait is microseconds)
-
-// A lane's KPL consecutive floats move as 16-byte pieces, then an 8-byte one, then a 4-byte one (4-byte alignment is enough
-// for buffer instructions).  piece i = [piece_start(i), piece_start(i) + piece_width(i)).
-template <int KPL>
-struct pieces {
-    static constexpr int N4 = KPL / 4, N = N4 + ((KPL & 2) ? 1 : 0) + (KPL & 1);
-    static constexpr int start(int i) { return i < N4 ? 4 * i : (i == N4 && (KPL & 2)) ? 4 * N4 : KPL - 1; }
-    static constexpr int width(int i) { return i < N4 ? 4 : (i == N4 && (KPL & 2)) ? 2 : 1; }
-};
-
-template <int KPL>
-__device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, float (&dst)[KPL]) {
-    using P = pieces<KPL>;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int k = P::start(i);
-        if (P::width(i) == 4) {
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 4 * k, 0, 0);
-            dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y);
-            dst[k + 2] = __uint_as_float(t.z); dst[k + 3] = __uint_as_float(t.w);
-        } else if (P::width(i) == 2) {
-            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 4 * k, 0, 0);
-            dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y);
-        } else {
-            dst[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * k, 0, 0));
-        }
-    }
-}
-
-// Stores v[0 .. nv) of every lane: nv = KPL on most lanes, tailn on the pixel's last lane when D is not a multiple of KPL, 0 on
-// lanes without disparities.  No branch on lane-varying data: a lane takes part in a piece when the piece lies inside its
-// nv, otherwise its offset is kOob and the buffer bounds check drops the write.  What the pieces leave of the tail lane (fewer
-// than 4 values, starting at `cov`; cov and rem are the same for every pixel) goes out as single dwords.
-template <int KPL>
-__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned base_off, int nv, bool is_tail, int cov, int rem,
-                                          const float (&v)[KPL]) {
-    using P = pieces<KPL>;
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const int k = P::start(i);
-        const unsigned off = (nv >= k + P::width(i)) ? base_off + 4 * k : kOob;
-        if (P::width(i) == 4) {
-            u32x4 t;
-            t.x = __float_as_uint(v[k]); t.y = __float_as_uint(v[k + 1]); t.z = __float_as_uint(v[k + 2]); t.w = __float_as_uint(v[k + 3]);
-            __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
-        } else if (P::width(i) == 2) {
-            u32x2 t;
-            t.x = __float_as_uint(v[k]); t.y = __float_as_uint(v[k + 1]);
-            __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[k]), rs, off, 0, 0);
-        }
-    }
-    // the tail's leftover (rem < 4 values from `cov`, uniform): one 8-byte and one 4-byte store, masked by their offsets - no
-    // branch around a memory instruction, which would make the compiler's vmcnt bookkeeping wait for the youngest stores
-    float t0 = v[0], t1 = v[0], t2 = v[0];
-#pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const int k = P::start(i);
-        if (cov == k) {
-            t0 = v[k];
-            t1 = v[k + 1 < KPL ? k + 1 : k];
-            t2 = v[k + 2 < KPL ? k + 2 : k];
-        }
-    }
-    const unsigned toff = is_tail ? base_off + 4u * (unsigned)cov : kOob;
-    u32x2 t01;
-    t01.x = __float_as_uint(t0); t01.y = __float_as_uint(t1);
-    __builtin_amdgcn_raw_buffer_store_b64(t01, rs, rem >= 2 ? toff : kOob, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rem == 3 ? t2 : t0), rs, (rem & 1) ? toff + (rem == 3 ? 8u : 0u) : kOob, 0, 0);
-}
 
 // minimum over the GL lanes of a pixel for three independent values at once (the chains interleave, which fills the wait
 // states a DPP operand needs behind the instruction that wrote it); every lane of the pixel receives the results

@@ -1044,11 +1044,12 @@ def test_interval_bounds_reference_vector(eng):
     np.testing.assert_allclose(hi, np.array(c["sup"], np.float32), rtol=1e-6)
 
 
-@pytest.mark.parametrize("fast", ["1", "0"])
+@pytest.mark.parametrize("fast", ["1", "4", "0"])
 @pytest.mark.parametrize("H,W,dmin,dmax,sp,dist", [(70, 150, -12, 5, 1, 5), (45, 90, -4, 3, 2, 9), (40, 61, 0, 9, 1, 2)])
 def test_cbca_phase_split_and_generic_kernels(eng, oracle, monkeypatch, fast, H, W, dmin, dmax, sp, dist):
-    """CBCA on images large enough for the phase-split kernels (warm-up / steady / drain, four steps in flight) and,
-    with PMX_CBCA_FAST=0, through the generic ones: both bit-exact against the reference-pinned oracle (sequential fp32
+    """CBCA on images large enough for the phase-split kernels (warm-up / steady / drain, four steps in flight), with
+    PMX_CBCA_FAST=4 through the in-place four-disparities-per-thread kernels (subpix 1, short arms; else phase-split) and,
+    with PMX_CBCA_FAST=0, through the generic ones: all bit-exact against the reference-pinned oracle (sequential fp32
     prefix sums), with masks, sub-pixel volumes, long arms."""
     monkeypatch.setenv("PMX_CBCA_FAST", fast)
     L, R = pair(H, W, seed=H + dist, integer=True)
