@@ -287,6 +287,10 @@ int pmx_risk(pmx_ctx* ctx, pmx_cv* cv, const double* etas, int nbr_etas, const i
  * regularisation of interval_tools.py is host-side work on the two maps and is not part of this library.) */
 int pmx_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float possibility_threshold, float type_factor, const int64_t* grid_min,
                         const int64_t* grid_max, float* interval_inf, float* interval_sup);
+/* Page-locked host memory for the caller's image / result arrays (the reference works in pageable numpy memory; over PCIe a
+ * pinned buffer copies at the link rate and without first-touch page faults under the DMA).  NULL on failure. */
+void* pmx_host_alloc(size_t bytes);
+void pmx_host_free(void* p);
 /* raw stream handle (hipStream_t) so a caller can enqueue its own work in order */
 void* pmx_stream(pmx_ctx* ctx);
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     "pmx_reset_stage_times": (C.c_int, [vp]),
     "pmx_stage_time": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),
     "pmx_stream": (vp, [vp]),
+    "pmx_host_alloc": (vp, [C.c_size_t]),
+    "pmx_host_free": (None, [vp]),
     "pmx_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
     "pmx_comm_init": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int]),
     "pmx_comm_destroy": (C.c_int, [vp]),

@@ -139,6 +139,21 @@ extern "C" int pmx_debug_sgm_directions(pmx_ctx* ctx, int mask) {
     return PMX_OK;
 }
 
+// page-locked host memory for the caller's result / input arrays: DMA at full PCIe rate, no first-touch page faults under the copy
+extern "C" void* pmx_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        pmx_set_error("pmx_host_alloc: hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void pmx_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" void* pmx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 // ---- placement-aware allocation (opt-in, pmx_set_placement_trials) ---------------------------------------------------

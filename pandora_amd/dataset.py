@@ -83,7 +83,7 @@ class Dataset:
         return self.data_vars[name]
 
     def __setitem__(self, name, value):
-        if isinstance(value, DataArray):
+        if isinstance(value, DataArray) or (hasattr(value, "dims") and hasattr(value, "data")):  # (engine.DeviceMapArray)
             self.data_vars[name] = value
         else:
             dims, data = value

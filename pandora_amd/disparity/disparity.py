@@ -4,6 +4,7 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from ..dataset import DataArray, Dataset
+from ..engine import DeviceMapArray
 from ..matching_cost.matching_cost import ConfigError
 
 
@@ -134,15 +135,17 @@ class WinnerTakesAll(AbstractDisparity):
         vm = cv["validity_mask"].data if "validity_mask" in cv.data_vars else None
         eng.set_validity(vm)
         eng.wta(dcv, is_max, float(self._invalid_disparity))
-        disp, validity = eng.get_disparity()
+        # the maps stay on the GPU until somebody reads them (engine.DeviceMapArray): a refinement step that follows works on them
+        # where they are, a filter or the caller gets them with one download into pinned memory
         coords = {"row": cv.coords["row"], "col": cv.coords["col"]}
-        disp_map = Dataset({"disparity_map": (("row", "col"), disp)}, coords=coords)
+        disp_map = Dataset(coords=coords)
+        disp_map["disparity_map"] = DeviceMapArray(eng, "disp", coords=coords)
         disp_map["disparity_interval"] = extract_disparity_interval_from_cost_volume(cv)
-        cv["disp_indices"] = DataArray(disp.copy(), ("row", "col"))
+        cv["disp_indices"] = DeviceMapArray(eng, "disp", coords=coords)  # (the reference keeps a copy of the WTA result, disparity.py:459)
         disp_map.attrs = dict(cv.attrs)
         if "confidence_measure" in cv.data_vars:
             disp_map.coords["indicator"] = cv.coords["indicator"]
             disp_map["confidence_measure"] = cv["confidence_measure"]
-        disp_map["validity_mask"] = DataArray(validity, ("row", "col"))
+        disp_map["validity_mask"] = DeviceMapArray(eng, "validity", coords=coords)
         disp_map.attrs["_device_cv"] = dcv  # lets the refinement step stay on the device
         return disp_map

@@ -2,6 +2,8 @@
 the resident stereo pair; DeviceCostVolume = a device-resident [H][W][D] float32 volume."""
 import ctypes as C
 
+import weakref
+
 import numpy as np
 
 from . import _lib
@@ -55,6 +57,87 @@ class DeviceCostVolume:
             pass
 
 
+class _PinnedBlock:
+    """A page-locked host buffer that numpy arrays are views of; returns to the pool when its last view dies."""
+    _pool = {}  # bytes -> [address]: process-wide, pinned memory does not belong to a context
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        free = self._pool.get(self.nbytes)
+        self.addr = free.pop() if free else _lib.lib().pmx_host_alloc(self.nbytes)
+        if not self.addr:
+            raise MemoryError(f"pmx_host_alloc({nbytes})")
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.addr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if len(self._pool.setdefault(self.nbytes, [])) < 4:
+                self._pool[self.nbytes].append(self.addr)
+            else:
+                _lib.lib().pmx_host_free(self.addr)
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """np.empty in page-locked memory (recycled through a small pool): the destination of result downloads."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    return np.asarray(_PinnedBlock(max(n, 1)))[:n].view(dtype).reshape(shape)
+
+
+class DeviceMapArray:
+    """A 2-D result of the engine (disparity, validity mask, interpolated coefficient) that has not left the GPU: ``.data``
+    downloads it on first use and keeps the host copy - from then on the host copy is the truth, as for any DataArray (callers
+    edit ``.data`` in place).  A step that consumes the maps right away (refinement after WTA) never pays the round trip."""
+
+    def __init__(self, engine, which, dims=("row", "col"), coords=None):
+        self.engine, self.which = engine, which
+        self.dims, self.coords = tuple(dims), dict(coords or {})
+        self._shape = (engine.H, engine.W)
+        self._host = None
+        self._token = engine.maps_token
+        engine._lazy_maps.add(self)
+
+    def on_device(self):
+        """True while nobody has looked at (or replaced) the values and the engine still holds exactly them."""
+        return self._host is None and self._token is self.engine.maps_token
+
+    def rebind(self):
+        """The engine's current maps are this variable's new value (the step that produced them updated it in place)."""
+        self._host = None
+        self._token = self.engine.maps_token
+        self.engine._lazy_maps.add(self)
+
+    @property
+    def data(self):
+        if self._host is None:
+            if self._token is not self.engine.maps_token:
+                raise RuntimeError("a device-resident map outlived its values (engine bookkeeping error)")
+            self._host = self.engine.fetch_map(self.which)
+        return self._host
+
+    @data.setter
+    def data(self, value):
+        self._host = value
+
+    values = data
+
+    @property
+    def shape(self):
+        return self._shape if self._host is None else self._host.shape
+
+    def sel(self, indexers=None, **kw):
+        from .dataset import DataArray
+
+        return DataArray(self.data, self.dims, self.coords).sel(indexers, **kw)
+
+    def copy(self, deep=True):
+        from .dataset import DataArray
+
+        return DataArray(np.array(self.data, copy=True) if deep else self.data, self.dims, dict(self.coords))
+
+
 class Engine:
     """One MI355X context.  Raises if the HIP library is not built or no GPU is visible."""
 
@@ -71,9 +154,17 @@ class Engine:
         self.H = self.W = 0
         self.subpix = 1
         self.lazy = True  # library default (pmx_set_lazy)
+        # identity of what the device-resident result maps currently hold; DeviceMapArrays of an older token that nobody has
+        # read yet are downloaded before the maps change (new_maps), unless the step declares them superseded
+        self.maps_token = object()
+        self._lazy_maps = weakref.WeakSet()
 
     def close(self):
         if self.ctx:
+            try:
+                self.new_maps()  # results nobody has read yet must survive the context
+            except Exception:
+                pass
             _lib.lib().pmx_destroy(self.ctx)
         self.ctx = None
 
@@ -172,14 +263,34 @@ class Engine:
             if dir_mask != 0xFF:
                 check(_lib.lib().pmx_debug_sgm_directions(self.ctx, 0xFF), "pmx_debug_sgm_directions")
 
+    def new_maps(self, superseded=()):
+        """Call BEFORE an operation that overwrites the device-resident result maps: pending DeviceMapArrays get their values
+        (one download each) unless they are in `superseded` (the operation updates exactly those variables in place)."""
+        for lazy in list(self._lazy_maps):
+            if lazy._host is None and lazy._token is self.maps_token and not any(lazy is s for s in superseded):
+                lazy.data  # noqa: B018  (downloads)
+        self._lazy_maps.clear()
+        self.maps_token = object()
+
+    def fetch_map(self, which):
+        """One of the device-resident result maps into pinned host memory."""
+        out = pinned_empty((self.H, self.W), np.int64 if which == "validity" else np.float32)
+        ptrs = {"disp": (out, None, None), "validity": (None, out, None), "itp": (None, None, out)}[which]
+        check(_lib.lib().pmx_get_disparity(self.ctx, _p(ptrs[0], C.c_float), _p(ptrs[1], C.c_int64), _p(ptrs[2], C.c_float)),
+              "pmx_get_disparity")
+        return out
+
     def set_validity(self, validity=None):
+        self.new_maps()
         v = None if validity is None else np.ascontiguousarray(validity, np.int64)
         check(_lib.lib().pmx_set_validity(self.ctx, _p(v, C.c_int64)), "pmx_set_validity")
 
     def wta(self, cv, is_max=False, invalid_disparity=-9999.0):
+        self.new_maps()
         check(_lib.lib().pmx_wta(self.ctx, cv.handle, int(bool(is_max)), float(invalid_disparity)), "pmx_wta")
 
-    def refine(self, cv, method, is_max=False):
+    def refine(self, cv, method, is_max=False, superseded=()):
+        self.new_maps(superseded)
         m = {"vfit": 0, "quadratic": 1}[method]
         check(_lib.lib().pmx_refine(self.ctx, cv.handle, m, int(bool(is_max))), "pmx_refine")
 
@@ -193,15 +304,16 @@ class Engine:
             for a, dt in ((disp, np.float32), (val, np.int64)) + (((itp, np.float32),) if want_itp else ()):
                 if a.shape != (self.H, self.W) or a.dtype != dt or not a.flags["C_CONTIGUOUS"]:
                     raise ValueError("get_disparity: `out` arrays must be C-contiguous (H, W) float32 / int64 / float32")
-        else:
-            disp = np.empty((self.H, self.W), np.float32)
-            val = np.empty((self.H, self.W), np.int64)
-            itp = np.empty((self.H, self.W), np.float32) if want_itp else None
+        else:  # page-locked, pooled: no first-touch page faults under the DMA
+            disp = pinned_empty((self.H, self.W), np.float32)
+            val = pinned_empty((self.H, self.W), np.int64)
+            itp = pinned_empty((self.H, self.W), np.float32) if want_itp else None
         check(_lib.lib().pmx_get_disparity(self.ctx, _p(disp, C.c_float), _p(val, C.c_int64), _p(itp, C.c_float)),
               "pmx_get_disparity")
         return (disp, val, itp) if want_itp else (disp, val)
 
     def set_disparity(self, disp=None, validity=None):
+        self.new_maps()
         d = None if disp is None else np.ascontiguousarray(disp, np.float32)
         v = None if validity is None else np.ascontiguousarray(validity, np.int64)
         check(_lib.lib().pmx_set_disparity(self.ctx, _p(d, C.c_float), _p(v, C.c_int64)), "pmx_set_disparity")
@@ -211,6 +323,7 @@ class Engine:
               "pmx_wta_minkey")
 
     def wta_from_keys(self, dev_keys_ptr, d0_global, subpix, invalid_disparity):
+        self.new_maps()
         check(_lib.lib().pmx_wta_from_keys(self.ctx, C.c_void_p(dev_keys_ptr), float(d0_global), int(subpix),
                                            float(invalid_disparity)), "pmx_wta_from_keys")
 
@@ -402,16 +515,19 @@ class Engine:
         check(_lib.lib().pmx_shard_minkey(self.ctx, cv.handle, int(bool(is_max)), int(index_offset)), "pmx_shard_minkey")
 
     def shard_from_keys(self, d0_global, subpix, invalid_disparity):
+        self.new_maps()
         check(_lib.lib().pmx_shard_from_keys(self.ctx, float(d0_global), int(subpix), float(invalid_disparity)), "pmx_shard_from_keys")
 
     def shard_nan_pixels(self, cv):
         check(_lib.lib().pmx_shard_nan_pixels(self.ctx, cv.handle), "pmx_shard_nan_pixels")
 
     def shard_refine_pack(self, cv, method, is_max, own_lo, own_hi, last_rank):
+        self.new_maps()
         check(_lib.lib().pmx_shard_refine_pack(self.ctx, cv.handle, {"vfit": 0, "quadratic": 1}[method], int(bool(is_max)), float(own_lo), float(own_hi),
                                                int(bool(last_rank))), "pmx_shard_refine_pack")
 
     def shard_refine_unpack(self):
+        self.new_maps()
         check(_lib.lib().pmx_shard_refine_unpack(self.ctx), "pmx_shard_refine_unpack")
 
     def tile_place(self, full_H, own_lo, own_hi, tile_lo, with_itp):

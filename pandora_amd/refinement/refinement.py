@@ -5,6 +5,7 @@ from abc import ABCMeta
 import numpy as np
 
 from ..dataset import DataArray
+from ..engine import DeviceMapArray
 from ..matching_cost.matching_cost import ConfigError
 
 
@@ -53,14 +54,21 @@ class AbstractRefinement:
         dcv = arr.device_cv
         eng = dcv.engine
         is_max = cv.attrs["type_measure"] == "max"
-        # the host copies may have been edited since WTA (filters): they are the source of truth
-        eng.set_disparity(np.asarray(disp["disparity_map"].data, np.float32), np.asarray(disp["validity_mask"].data, np.int64))
-        eng.refine(dcv, self._refinement_method_name, is_max)
-        d, v, itp = eng.get_disparity(want_itp=True)
-        disp["disparity_map"].data = d
-        disp["validity_mask"].data = v
+        dm, vm = disp["disparity_map"], disp["validity_mask"]
+        coords = {k: disp.coords[k] for k in ("row", "col") if k in disp.coords}
+        if isinstance(dm, DeviceMapArray) and isinstance(vm, DeviceMapArray) and dm.engine is eng and dm.on_device() and vm.on_device():
+            # straight after WTA: the maps never left the GPU and this step updates exactly these two variables in place
+            eng.refine(dcv, self._refinement_method_name, is_max, superseded=(dm, vm))
+            dm.rebind()
+            vm.rebind()
+        else:
+            # the host copies may have been edited since WTA (filters): they are the source of truth
+            eng.set_disparity(np.asarray(dm.data, np.float32), np.asarray(vm.data, np.int64))
+            eng.refine(dcv, self._refinement_method_name, is_max)
+            disp["disparity_map"] = DeviceMapArray(eng, "disp", coords=coords)
+            disp["validity_mask"] = DeviceMapArray(eng, "validity", coords=coords)
         disp.attrs["refinement"] = self._refinement_method_name
-        disp["interpolated_coeff"] = DataArray(itp, ("row", "col"))
+        disp["interpolated_coeff"] = DeviceMapArray(eng, "itp", coords=coords)
 
 
 def _simple_conf(name):

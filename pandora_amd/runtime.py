@@ -2,9 +2,13 @@
 stereo pair is resident so that successive plugin calls (compute_cost_volume, cv_masked,
 cost_volume_aggregation, ...) do not re-upload the images."""
 import os
-import zlib
 
 import numpy as np
+
+try:  # ~15 GB/s: a 4 Mpx float32 image in a millisecond
+    from xxhash import xxh3_64_intdigest as _digest
+except ImportError:  # CRC-32 is ten times slower but always there
+    from zlib import crc32 as _digest
 
 from .engine import Engine
 
@@ -24,11 +28,11 @@ def get_engine(device=None):
 
 
 def _sample(a):
-    """Content fingerprint of the WHOLE buffer (CRC-32, about a millisecond per 4 Mpx image): an array edited in place between
+    """Content fingerprint of the WHOLE buffer (XXH3, about a millisecond per 4 Mpx image): an array edited in place between
     two runs - any pixel of it - is uploaded again.  (A strided sample misses edits: with power-of-two widths a stride
     divides the width and only a comb of columns is ever looked at.)"""
     a = np.ascontiguousarray(a)
-    return zlib.crc32(memoryview(a).cast("B"))
+    return _digest(memoryview(a).cast("B"))
 
 
 def _key(img_left, img_right, subpix, band):
