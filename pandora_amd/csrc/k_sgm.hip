@@ -230,9 +230,234 @@ static int sgm_run(pmx_ctx* ctx, const sgm_args& base, int mask) {
     return PMX_OK;
 }
 
+// ---- the horizontal pair in 12.5 B/cell instead of 20 ---------------------------------------------------------------------
+// (0,+1) then (0,-1) as two line passes cost R C + W S, then R C + R S + W S.  The second read-modify-write of S exists only
+// because a row's (0,+1) costs are long gone when the (0,-1) wave comes back through it - and a row's worth of path costs
+// (W x D floats) fits no on-chip memory.  What fits is a SEGMENT: the forward pass keeps nothing but the state of its path at
+// the end of every kSegCols-th column (checkpoint pass: R C, W 4/kSegCols B/cell); the backward pass walks the row right to
+// left one segment at a time: it reloads the checkpoint before the segment, RE-COMPUTES the forward path costs of the segment
+// into registers from the segment's costs (the same float32 operations on the same inputs: the same bits), then runs the
+// backward recurrence through the segment and stores S = L(0,+1) + L(0,-1) once (R C, W S).  One extra direction-pass of
+// arithmetic buys 7.5 B/cell of HBM traffic; both kernels stay HBM-bound.
+static constexpr int kSegCols = 8;
+
+// one SGM step: new costs from the previous pixel's (Lp, M).  Lanes without the disparity carry +inf.
+template <int KPL>
+__device__ __forceinline__ float sgm_line_step(const float (&Lp)[KPL], float M, const float (&cc)[KPL], int nv, float P1, float P2,
+                                               float (&Ln)[KPL]) {
+    const float below = from_lane_below(Lp[KPL - 1], f_inf());
+    const float above = from_lane_above(Lp[0], f_inf());
+    const float mp2 = M + P2;
+    float lmin = f_inf();
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const float lo = (k > 0) ? Lp[k - 1] : below;
+        const float hi = (k < KPL - 1) ? Lp[k + 1] : above;
+        const float nb = fmin2(lo, hi) + P1;
+        float t = fmin2(Lp[k], nb);
+        t = fmin2(t, mp2);
+        const float l = cc[k] + (t - M);
+        Ln[k] = k < nv ? l : f_inf();
+        lmin = fmin2(lmin, Ln[k]);
+    }
+    return wave_min(lmin);
+}
+
+struct sgm_h_args {
+    const float* C;
+    float* S;
+    float* ckpt;  // [H][nseg][64 * KPL + 64]: the (0,+1) path's costs after the last column of every segment, then its minimum
+    int H, W, D, nseg;
+    float P1, P2, invalid_cost;
+    int is_max, overcounting, epilogue;
+};
+
+// forward pass: wave = row, keeps only the checkpoints
+template <int KPL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_h_checkpoint_kernel(sgm_h_args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= a.H) return;
+    const int D = a.D, W = a.W;
+    const int d_first = lane * KPL;
+    const int nv = d_first >= D ? 0 : (D - d_first < KPL ? D - d_first : KPL);
+    const unsigned pix_bytes = (unsigned)D * 4u, lane_load = (unsigned)(nv ? d_first : 0) * 4u;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.C + (size_t)row * W * D), 0, (unsigned)W * pix_bytes, kRsrcWord3);
+    float* ck = a.ckpt + ((size_t)row * a.nseg) * (64 * KPL + 64) + lane * KPL;
+    float cbuf[kPF][KPL];
+    int pc = 0;
+    auto prefetch = [&](float (&slot)[KPL]) {
+        buf_load<KPL>(rsC, (unsigned)pc * pix_bytes + lane_load, slot);
+        if (pc < W - 1) ++pc;
+    };
+#pragma unroll
+    for (int i = 0; i < kPF; ++i) prefetch(cbuf[i]);
+    float Lp[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) Lp[k] = k < nv ? 0.f : f_inf();
+    float M = 0.f;
+    int c = 0;
+    auto step = [&](float (&slot)[KPL]) {
+        float cc[KPL], Ln[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            const float cr = slot[k];
+            cc[k] = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
+        }
+        M = sgm_line_step<KPL>(Lp, M, cc, nv, a.P1, a.P2, Ln);
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) Lp[k] = Ln[k];
+        if ((c % kSegCols) == kSegCols - 1 && c < W - 1) {  // uniform: the state the next segment starts from
+            float* dst = ck + (size_t)(c / kSegCols) * (64 * KPL + 64);
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) dst[k] = Ln[k];
+            if (lane == 0) dst[64 * KPL - lane * KPL] = M;  // (dst is lane-offset: the minimum sits behind the 64 * KPL costs)
+        }
+        prefetch(slot);
+        ++c;
+    };
+    int i = 0;
+    for (; i + kPF <= W; i += kPF) {
+#pragma unroll
+        for (int j = 0; j < kPF; ++j) step(cbuf[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kPF - 1; ++j)
+        if (i + j < W) step(cbuf[j]);
+}
+
+// backward pass: wave = row, right to left, one segment at a time
+template <int KPL>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_h_backward_kernel(sgm_h_args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= a.H) return;
+    const int D = a.D, W = a.W;
+    const int d_first = lane * KPL;
+    const int nv = d_first >= D ? 0 : (D - d_first < KPL ? D - d_first : KPL);
+    const bool is_tail = nv > 0 && nv < KPL;
+    const int tailn = D % KPL;
+    using P = pieces<KPL>;
+    int cov = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i)
+        if (P::start(i) + P::width(i) <= tailn) cov = P::start(i) + P::width(i);
+    const int rem = tailn - cov;
+    const unsigned pix_bytes = (unsigned)D * 4u, lane_load = (unsigned)(nv ? d_first : 0) * 4u;
+    const unsigned lane_store = nv ? (unsigned)d_first * 4u : kOob;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.C + (size_t)row * W * D), 0, (unsigned)W * pix_bytes, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(a.S + (size_t)row * W * D), 0, (unsigned)W * pix_bytes, kRsrcWord3);
+    const float* ck = a.ckpt + ((size_t)row * a.nseg) * (64 * KPL + 64);
+    // backward path state
+    float Bp[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) Bp[k] = k < nv ? 0.f : f_inf();
+    float MB = 0.f;
+    // costs of the segment being processed and of the next one to the left (in flight)
+    float cur[kSegCols][KPL], nxt[kSegCols][KPL];
+    float fwd[kSegCols][KPL];
+    auto load_segment = [&](int seg, float (&dst)[kSegCols][KPL]) {  // columns outside the row read as 0 and are never used
+#pragma unroll
+        for (int j = 0; j < kSegCols; ++j) {
+            const int c = seg * kSegCols + j;
+            buf_load<KPL>(rsC, (seg >= 0 && c < W) ? (unsigned)c * pix_bytes + lane_load : kOob, dst[j]);
+        }
+    };
+    const int last = a.nseg - 1;
+    load_segment(last, cur);
+    for (int seg = last; seg >= 0; --seg) {
+        load_segment(seg - 1, nxt);
+        // forward state entering the segment
+        float Fp[KPL], MF;
+        if (seg == 0) {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) Fp[k] = k < nv ? 0.f : f_inf();
+            MF = 0.f;
+        } else {
+            const float* src = ck + (size_t)(seg - 1) * (64 * KPL + 64);
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) Fp[k] = src[lane * KPL + k];
+            MF = src[64 * KPL];
+        }
+        const int ncols = (seg == last) ? W - seg * kSegCols : kSegCols;  // uniform
+        float cc[kSegCols][KPL];
+#pragma unroll
+        for (int j = 0; j < kSegCols; ++j) {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                const float cr = cur[j][k];
+                cc[j][k] = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
+            }
+        }
+        // the (0,+1) path through the segment, recomputed
+#pragma unroll
+        for (int j = 0; j < kSegCols; ++j) {  // (columns past the end of the row come last here: what they produce is never used)
+            MF = sgm_line_step<KPL>(Fp, MF, cc[j], nv, a.P1, a.P2, fwd[j]);
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) Fp[k] = fwd[j][k];
+        }
+        // the (0,-1) path, right to left, and the sum
+#pragma unroll
+        for (int j = kSegCols - 1; j >= 0; --j) {
+            // columns past the end of the row (last segment only) come FIRST here: they must leave the path's state alone and
+            // store nothing - a uniform select and an out-of-range offset, no branch around the memory instructions
+            const bool real = j < ncols;
+            float Ln[KPL], out[KPL];
+            const float m = sgm_line_step<KPL>(Bp, MB, cc[j], nv, a.P1, a.P2, Ln);
+            MB = real ? m : MB;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                Bp[k] = real ? Ln[k] : Bp[k];
+                float sv = fwd[j][k] + Ln[k];
+                if (a.epilogue) {
+                    if (a.overcounting) sv = sv - 7.0f * cc[j][k];
+                    if (a.is_max) sv = -sv;
+                    if (cur[j][k] != cur[j][k]) sv = f_nan();
+                }
+                out[k] = sv;
+            }
+            buf_store<KPL>(rsS, real ? (unsigned)(seg * kSegCols + j) * pix_bytes + lane_store : kOob, nv, is_tail, cov, rem, out);
+        }
+#pragma unroll
+        for (int j = 0; j < kSegCols; ++j)
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) cur[j][k] = nxt[j][k];
+    }
+}
+
+template <int KPL>
+static int sgm_run_horizontal_fused(pmx_ctx* ctx, const sgm_args& base, int mask) {
+    sgm_h_args h;
+    h.C = base.C; h.S = base.S;
+    h.H = base.H; h.W = base.W; h.D = base.D;
+    h.nseg = (base.W + kSegCols - 1) / kSegCols;
+    h.P1 = base.P1; h.P2 = base.P2; h.invalid_cost = base.invalid_cost;
+    h.is_max = base.is_max; h.overcounting = base.overcounting;
+    h.epilogue = (mask >> 2) == 0;
+    const size_t bytes = (size_t)h.H * h.nseg * (64 * KPL + 64) * sizeof(float);
+    float* ck = nullptr;
+    PMX_HIP(pmx_pool_alloc(ctx, (void**)&ck, bytes));
+    h.ckpt = ck;
+    dim3 grid((h.H + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * 64);
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_h_checkpoint_kernel<KPL>), grid, block, 0, ctx->stream, h);
+    }
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_h_backward_kernel<KPL>), grid, block, 0, ctx->stream, h);
+    }
+    pmx_pool_free(ctx, ck);  // stream-ordered reuse
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 // the horizontal pair of the family schedule (k_sgmfam.hip runs the six others)
 template <int KPL>
 static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask) {
+    // both horizontal paths: the checkpoint / recompute pair above (PMX_SGM_HFUSED=0: test hook for the two line passes)
+    const char* e = getenv("PMX_SGM_HFUSED");
+    if ((mask & 3) == 3 && KPL <= 6 && !(e && e[0] == '0')) return sgm_run_horizontal_fused<KPL>(ctx, base, mask);
     for (int k = 0; k < 2; ++k)
         if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
     PMX_HIP(hipGetLastError());

@@ -117,3 +117,19 @@ def test_family_schedule_repeated_launches(eng, oracle, monkeypatch):
         cvh = volume(rng, 45, 200, 129)
         exp = oracle.sgm(cvh, 3.0, 11.0, False, 45.0, False)
         np.testing.assert_array_equal(run(eng, cvh, 3.0, 11.0, False, 45.0, False), exp)
+
+
+@pytest.mark.parametrize("H,W,D", [(20, 64, 129), (9, 37, 257), (5, 8, 60), (3, 7, 30), (6, 131, 384)])
+def test_fused_horizontal_pair_equals_the_two_line_passes(eng, oracle, monkeypatch, H, W, D):
+    """The family schedule runs (0,+1) and (0,-1) as a checkpoint pass + a backward pass that re-computes the forward path segment by
+    segment (k_sgm.hip): same bits as the oracle and as the two separate line passes (PMX_SGM_HFUSED=0); widths that are / are not
+    multiples of the 8-column segment, narrower than one segment, max / overcounting epilogue in the backward kernel."""
+    rng = np.random.default_rng(W)
+    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    for is_max, over in ((False, False), (True, True)):
+        cvh = volume(rng, H, W, D, is_max)
+        for mask in (0x03, 0xFF):
+            exp = oracle.sgm(cvh, 1.25, 6.5, is_max, 45.0, over, dir_mask=mask)
+            for fused in ("1", "0"):
+                monkeypatch.setenv("PMX_SGM_HFUSED", fused)
+                np.testing.assert_array_equal(run(eng, cvh, 1.25, 6.5, is_max, 45.0, over, mask), exp)
