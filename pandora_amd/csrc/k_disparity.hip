@@ -215,6 +215,78 @@ int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max) {
     return PMX_OK;
 }
 
+// ---- WTA fused into the last float32 SGM pass (k_sgmfam.hip) ----------------------------------------------------------------
+// The pass left disp and, per pixel, near = (S[k-1], S[k], S[k+1], k) of the winner in the output domain, k = -1 where every cost
+// is NaN.  This kernel applies to_disp's validity rule for those pixels (disparity.py:471-474).
+__global__ __launch_bounds__(kBlock) void wta_fixup_kernel(const float4* __restrict__ near, size_t npix, int64_t* __restrict__ validity) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    if (__float_as_int(near[i].w) == -1) {
+        int64_t m = validity[i];
+        if ((m & MSK_INVALID) == 0) validity[i] = MSK_INVALID;
+    }
+}
+
+int pmx_launch_wta_fixup(pmx_ctx* ctx, const pmx_cv* cv) {
+    size_t npix = (size_t)cv->H * cv->W;
+    pmx_stage_scope t(ctx, PMX_STAGE_WTA);
+    hipLaunchKernelGGL(wta_fixup_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->near, npix,
+                       ctx->validity);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+// refine_kernel on the three values the fused WTA kept instead of the volume (which was never written)
+__global__ __launch_bounds__(kBlock) void near_refine_kernel(const float4* __restrict__ near, size_t npix, double d_min, double d_max,
+                                                             int subpix, int is_max, int method, float* __restrict__ disp,
+                                                             int64_t* __restrict__ validity, float* __restrict__ itp) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    int64_t m = validity[i];
+    if ((m & MSK_INVALID) != 0) { itp[i] = d_nan(); return; }
+    float raw = disp[i];
+    if (!((double)raw >= d_min && (double)raw <= d_max)) { itp[i] = d_nan(); return; }
+    const float4 nb = near[i];
+    float c1 = nb.y;
+    if (c1 != c1) { itp[i] = c1; return; }
+    if ((double)raw == d_min || (double)raw == d_max) { itp[i] = c1; validity[i] = m + MSK_STOPPED; return; }
+    float c0 = nb.x, c2 = nb.z;
+    float ic0, ic2, sd, sc;
+    int64_t flag = 0;
+    if (!validate_costs(c0, c1, c2, is_max != 0, ic0, ic2)) {
+        sd = 0.f; sc = c1; flag = MSK_STOPPED;
+    } else if (method == PMX_REFINE_VFIT) {
+        float a = ic0 > ic2 ? c0 - c1 : c2 - c1;
+        if (fabs((double)a) < 1.0e-15) {
+            sd = 0.f; sc = c1;
+        } else {
+            sd = (c0 - c2) / (2 * a);
+            sc = a * (sd - 1) + c2;
+        }
+    } else {
+        float alpha = (c0 - 2.f * c1 + c2) / 2.f;
+        float beta = (c2 - c0) / 2.f;
+        float x = -beta / (2.f * alpha);
+        float mx = (-1.f < x) ? x : -1.f;
+        sd = (mx < 1.f) ? mx : 1.f;
+        sc = (alpha * sd * sd) + (beta * sd) + c1;
+    }
+    disp[i] = raw + sd / (float)subpix;
+    itp[i] = sc;
+    validity[i] = m + flag;
+}
+
+int pmx_launch_near_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max) {
+    size_t npix = (size_t)cv->H * cv->W;
+    double d_min = (double)cv->d0;
+    double d_max = (double)cv->d0 + (double)(cv->D - 1) / (double)cv->subpix;
+    pmx_stage_scope t(ctx, PMX_STAGE_REFINE);
+    hipLaunchKernelGGL(near_refine_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->near,
+                       npix, d_min, d_max, cv->subpix, is_max, method, ctx->disp, ctx->validity, ctx->itp);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 // ---- packed (cost, index) keys for D-sharded WTA ------------------------------------
 // key = orderable(cost) << 31 | global index, so that min over ranks of the uint64 key is the
 // lexicographic (cost, index) minimum.  For "max" measures the cost is negated first.

@@ -532,10 +532,9 @@ static int sgm_run_parallel(pmx_ctx* ctx, sgm_args a, float* paths, size_t cells
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting) {
     const int mask = ctx->sgm_dir_mask & 0xff;
     PMX_CHECK(mask != 0, PMX_ERR_ARG, "pmx_sgm: empty direction mask");
-    // accumulator volume: the context's scratch; +256 B so the over-read of a lane's tail is in bounds
+    // accumulator volume: the context's scratch (or, for a deferred last pass, the handle's own partial-sum volume)
     size_t bytes = cv->cells() * sizeof(float) + 256;
-    int rc = pmx_need_scratch(ctx, bytes);
-    if (rc) return rc;
+    int rc = PMX_OK;
     if (cv->bytes < bytes) {
         // the input volume needs the same tail padding for the KPL-wide loads of its last pixel
         float* grown = nullptr;
@@ -548,7 +547,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     }
     sgm_args a;
     a.C = cv->data;
-    a.S = ctx->scratch;
+    a.S = nullptr;  // set once the schedule is known
     a.H = cv->H; a.W = cv->W; a.D = cv->D;
     a.dr = 0; a.dc = 0;
     a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
@@ -573,6 +572,13 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     }
     if (sched == PAR && kpl > 8) sched = SEQ;
     if (sched == FAM && !pmx_sgm_family_supported(cv)) sched = SEQ;
+    const char* ep_ = getenv("PMX_SGM_PENDING");
+    const bool defer_ = sched == FAM && ctx->lazy && mask == 0xff && !(ep_ && ep_[0] == '0');
+    if (!defer_) {
+        rc = pmx_need_scratch(ctx, bytes);
+        if (rc) return rc;
+        a.S = ctx->scratch;
+    }
     if (sched == PAR) {
         float* paths = nullptr;
         PMX_HIP(pmx_pool_alloc(ctx, (void**)&paths, 8 * cv->cells() * sizeof(float) + 256));
@@ -581,12 +587,32 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
 #undef PMX_CALL
         pmx_pool_free(ctx, paths);  // stream-ordered reuse: the kernels above are queued on ctx->stream
     } else if (sched == FAM) {
+        // Lazy mode, all eight paths: the horizontal pair and the downward family run now into the handle's own partial-sum
+        // volume; the upward family waits for whoever comes next - pmx_wta runs it in WTA mode (S is never written, the WTA's
+        // read of it never happens: -8 B/cell), anything else runs it in store mode (pmx_sgm_finish_pending).
+        const bool defer = defer_;  // (PMX_SGM_PENDING=0: test hook, always finish at once)
+        if (defer) {
+            if (cv->spart_bytes < bytes) {
+                pmx_pool_free(ctx, cv->spart);
+                cv->spart = nullptr;
+                cv->spart_bytes = 0;
+                PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->spart, bytes));
+                cv->spart_bytes = bytes;
+            }
+            a.S = cv->spart;
+        }
         // horizontal pair with the line kernel, then the downward and the upward family (k_sgmfam.hip)
 #define PMX_CALL(K) sgm_run_horizontal<K>(ctx, a, mask)
         PMX_KPL_SWITCH(kpl, PMX_CALL)
 #undef PMX_CALL
         if (rc) return rc;
-        rc = pmx_launch_sgm_families(ctx, cv, ctx->scratch, P1, P2, is_max, invalid_cost, overcounting, mask);
+        rc = pmx_launch_sgm_families(ctx, cv, a.S, P1, P2, is_max, invalid_cost, overcounting, mask, defer ? 1 : 3, nullptr);
+        if (rc) return rc;
+        if (defer) {
+            cv->pending = {P1, P2, invalid_cost, is_max, overcounting};
+            cv->repr = PMX_REPR_SGM_UP_PENDING;
+            return PMX_OK;  // data = the costs, spart = the partial sums
+        }
     } else {
 #define PMX_CALL(K) sgm_run<K>(ctx, a, mask)
         PMX_KPL_SWITCH(kpl, PMX_CALL)
@@ -600,5 +626,23 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     cv->bytes = ctx->scratch_bytes;
     ctx->scratch = old;
     ctx->scratch_bytes = old_bytes;
+    return PMX_OK;
+}
+
+// The upward family of a PMX_REPR_SGM_UP_PENDING handle: in WTA mode (wta != nullptr: the volume stays pending, the context's
+// disparity map and winner cache are written) or in store mode (the handle becomes a plain float32 volume).
+int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta) {
+    PMX_CHECK(cv->repr == PMX_REPR_SGM_UP_PENDING && cv->data && cv->spart, PMX_ERR_STATE, "pmx_sgm_finish_pending: nothing pending");
+    int rc = pmx_launch_sgm_families(ctx, cv, cv->spart, cv->pending.P1, cv->pending.P2, cv->pending.is_max, cv->pending.invalid_cost,
+                                     cv->pending.overcounting, 0xff, 2, wta);
+    if (rc || wta) return rc;
+    // the sums become the volume; the costs' buffer is kept with the handle for the next pair's partial sums
+    float* costs = cv->data;
+    const size_t costs_bytes = cv->bytes;
+    cv->data = cv->spart;
+    cv->bytes = cv->spart_bytes;
+    cv->spart = costs;
+    cv->spart_bytes = costs_bytes;
+    cv->repr = PMX_REPR_FLOAT;
     return PMX_OK;
 }

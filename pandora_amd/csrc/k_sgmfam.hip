@@ -65,6 +65,13 @@ struct fam_args {
     int NB;          // window borders per row = ceil(W / CW)
     unsigned epoch;
     unsigned* ctl;   // [0] ticket counter (zero at launch), [1] error word
+    // WTA mode (last pass only, template flag): S is not written; the pass reduces over D and leaves, per pixel, the winner's
+    // disparity and (S[k-1], S[k], S[k+1], k) for the refinement step
+    float* disp;
+    float* near;     // float4 [H][W]
+    double d0;
+    int subpix;
+    float invalid_disparity;
 };
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls before a hand-off gives up (seconds; a healthy wait is microseconds)
@@ -109,7 +116,7 @@ __device__ __forceinline__ float path_costs(const float (&Lp)[KPL], float M, boo
     return lmin;
 }
 
-template <int GL, int KPL, int NW, int PF>
+template <int GL, int KPL, int NW, int PF, bool WTA>
 __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     constexpr int NPW = 64 / GL;           // pixels per wave
     constexpr int CW = NW * NPW;           // columns per workgroup window
@@ -405,7 +412,75 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                 acc[k] = (nanmask >> k & 1) ? __uint_as_float(0x7fc00000u) : sv;
             }
         }
-        buf_store<KPL>(row_rsrc(a.S, r), pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
+        if (!WTA) {
+            buf_store<KPL>(row_rsrc(a.S, r), pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
+        } else {
+            // winner-takes-all over the pixel's D values, as wta_kernel (k_disparity.hip) would do it on the stored volume: NaN
+            // counts as the worst value, the FIRST extremum wins (key = orderable value in the "min" domain << 32 | index)
+            unsigned long long key = ~0ull;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                const bool isn = (nanmask >> k & 1) != 0;
+                float v = a.is_max ? __uint_as_float(__float_as_uint(acc[k]) ^ 0x80000000u) : acc[k];  // back to the "min" domain
+                v = isn ? f_inf() : v;
+                if (v == 0.f) v = 0.f;  // -0 and +0 must tie
+                const unsigned u = __float_as_uint(v);
+                const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                const unsigned long long kk = ((unsigned long long)ord << 32) | (unsigned)(d0 + k);
+                if (k < nv) {
+                    key = kk < key ? kk : key;
+                    any = any || !isn;
+                }
+            }
+            unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+            unsigned anyb = any ? 1u : 0u;
+            auto fold = [&](unsigned olo, unsigned ohi, unsigned oany) {
+                const bool less = ohi < khi || (ohi == khi && olo < klo);
+                klo = less ? olo : klo;
+                khi = less ? ohi : khi;
+                anyb |= oany;
+            };
+#define PMX_FOLD_DPP(CTRL)                                                                                              \
+    fold((unsigned)__builtin_amdgcn_mov_dpp((int)klo, CTRL, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)khi, CTRL, 0xf, 0xf, true), \
+         (unsigned)__builtin_amdgcn_mov_dpp((int)anyb, CTRL, 0xf, 0xf, true))
+            PMX_FOLD_DPP(0x121);
+            PMX_FOLD_DPP(0x122);
+            PMX_FOLD_DPP(0x124);
+            PMX_FOLD_DPP(0x128);
+#undef PMX_FOLD_DPP
+            if (GL == 32)
+                fold((unsigned)__builtin_amdgcn_ds_swizzle((int)klo, 0x401f), (unsigned)__builtin_amdgcn_ds_swizzle((int)khi, 0x401f),
+                     (unsigned)__builtin_amdgcn_ds_swizzle((int)anyb, 0x401f));
+            const int kw = (int)klo;            // the winner, the same in every lane of the pixel
+            const int li = kw / KPL, kk = kw - li * KPL;
+            // its neighbours in the output domain (what the stored volume would hold); NaN outside [0, D)
+            const float qnan = __uint_as_float(0x7fc00000u);
+            float prevv = dpp<0x138>(acc[KPL - 1]);  // lane l <- lane l-1
+            float nextv = dpp<0x130>(acc[0]);        // lane l <- lane l+1
+            float c0 = kk == 0 ? prevv : acc[0], c1 = acc[0], c2 = kk == KPL - 1 ? nextv : acc[0];
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                c1 = kk == k ? acc[k] : c1;
+                if (k > 0) c0 = kk == k ? acc[k - 1] : c0;
+                if (k < KPL - 1) c2 = kk == k ? acc[k + 1] : c2;
+            }
+            if (kw == 0) c0 = qnan;
+            if (kw >= D - 1) c2 = qnan;
+            const bool owner = (l == li);
+            const unsigned poff = pix_off(r);  // kOob outside the image
+            const unsigned pidx = poff == kOob ? kOob : poff / pix_bytes;
+            const int rimg = a.flip ? H - 1 - r : r;
+            const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.disp + (size_t)rimg * W), 0, (unsigned)W * 4u, kRsrcWord3);
+            const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(a.near + (size_t)rimg * W * 4), 0, (unsigned)W * 16u, kRsrcWord3);
+            const float dv = anyb ? (float)(a.d0 + (double)(unsigned)kw / (double)a.subpix) : a.invalid_disparity;
+            u32x4 nb;
+            nb.x = __float_as_uint(c0); nb.y = __float_as_uint(c1); nb.z = __float_as_uint(c2);
+            nb.w = anyb ? (unsigned)kw : 0xffffffffu;  // -1: every cost of the pixel is NaN (the fix-up kernel applies the validity rule)
+            const bool st = owner && pidx != kOob;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rsD, st ? pidx * 4u : kOob, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(nb, rsN, st ? pidx * 16u : kOob, 0, 0);
+        }
         // refill this ring slot with row r + PF (issued after the slot's last use: same registers, no copy)
         prefetch(cslot, sslot);
         __syncthreads();
@@ -467,22 +542,24 @@ bool pick_shape(int D, int W, fam_shape* out) {
     return true;
 }
 
-template <int GL, int KPL, int NW>
+template <int GL, int KPL, int NW, bool WTA>
 int launch_family(pmx_ctx* ctx, const fam_args& a, int nwg) {
     constexpr int PF = KPL > 12 ? 2 : 3;
     constexpr int NPW = 64 / GL, CW = NW * NPW, KS = (KPL + 3) & ~3, ES = GL * KS + 4;
     const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4) * sizeof(float);
-    auto kern = sgm_family_kernel<GL, KPL, NW, PF>;
+    auto kern = sgm_family_kernel<GL, KPL, NW, PF, WTA>;
     PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 1) * 64), lds_bytes, ctx->stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
-int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg) {
-#define PMX_FAM(GL, KPL)                                                                  \
-    if (f.gl == GL && f.kpl == KPL)                                                       \
-        return f.nw == 8 ? launch_family<GL, KPL, 8>(ctx, a, nwg) : launch_family<GL, KPL, 4>(ctx, a, nwg);
+int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg, bool wta) {
+#define PMX_FAM(GL, KPL)                                                                                               \
+    if (f.gl == GL && f.kpl == KPL) {                                                                                  \
+        if (wta) return f.nw == 8 ? launch_family<GL, KPL, 8, true>(ctx, a, nwg) : launch_family<GL, KPL, 4, true>(ctx, a, nwg); \
+        return f.nw == 8 ? launch_family<GL, KPL, 8, false>(ctx, a, nwg) : launch_family<GL, KPL, 4, false>(ctx, a, nwg);        \
+    }
     PMX_FAM(16, 3)
     PMX_FAM(16, 5)
     PMX_FAM(16, 7)
@@ -503,7 +580,7 @@ int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg
 bool pmx_sgm_family_supported(const pmx_cv* cv) { return cv->H >= 2 && pick_shape(cv->D, cv->W, nullptr); }
 
 int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
-                            int mask) {
+                            int mask, int fams, const pmx_fam_wta* wta) {
     fam_shape f;
     PMX_CHECK(pick_shape(cv->D, cv->W, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (family schedule): D = %d not supported", cv->D);
     const int npw = 64 / f.gl, CW = f.nw * npw;
@@ -529,7 +606,7 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
     const int nwg = (cv->W + cv->H - 2) / CW + 1;
     for (int fam = 0; fam < 2; ++fam) {
         const int bits = (mask >> (2 + 3 * fam)) & 7;  // definition order: vertical, predecessor c-1, predecessor c+1
-        if (!bits) continue;
+        if (!bits || !(fams >> fam & 1)) continue;
         if (ctx->fam_epoch == 0xffffffffu) {  // epoch space used up: start over on a clean buffer
             PMX_HIP(hipMemsetAsync(ctx->fam_halo, 0, ctx->fam_halo_bytes, ctx->stream));
             ctx->fam_epoch = 0;
@@ -548,10 +625,16 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
         a.NB = NB;
         a.epoch = ++ctx->fam_epoch;
         a.ctl = ctx->fam_ctl;
+        const bool use_wta = wta && fam == 1;
+        a.disp = use_wta ? wta->disp : nullptr;
+        a.near = use_wta ? wta->near : nullptr;
+        a.d0 = use_wta ? wta->d0 : 0.0;
+        a.subpix = use_wta ? wta->subpix : 1;
+        a.invalid_disparity = use_wta ? wta->invalid_disparity : 0.f;
         PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));  // the ticket; the error word is sticky
         {
             pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY);
-            int rc = dispatch_family(ctx, f, a, nwg);
+            int rc = dispatch_family(ctx, f, a, nwg, use_wta);
             if (rc) return rc;
         }
         // the error word travels to pinned host memory behind the launch; pmx_check_async_error reads it after a sync

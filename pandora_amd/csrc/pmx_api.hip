@@ -445,12 +445,14 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
     if (ctx) {
         hipSetDevice(ctx->device);
         pmx_pool_free(ctx, cv->data);
+        pmx_pool_free(ctx, cv->spart);
         pmx_pool_free(ctx, cv->codes);
         pmx_pool_free(ctx, cv->ldir);
         pmx_pool_free(ctx, cv->cost8);
         pmx_pool_free(ctx, cv->range);
     } else {
         hipFree(cv->data);
+        hipFree(cv->spart);
         hipFree(cv->codes);
         hipFree(cv->ldir);
     }
@@ -460,6 +462,7 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
 // Bring a handle back to a plain float32 [H][W][D] volume, whatever exact form it is held in.
 int pmx_cv_materialize(pmx_ctx* ctx, pmx_cv* cv) {
     if (cv->repr == PMX_REPR_FLOAT && cv->data) return PMX_OK;
+    if (cv->repr == PMX_REPR_SGM_UP_PENDING) return pmx_sgm_finish_pending(ctx, cv, nullptr);  // the optimised volume is wanted after all
     if (int rc = pmx_cv_ensure_data(ctx, cv)) return rc;
     switch (cv->repr) {
         case PMX_REPR_FLOAT: return PMX_OK;
@@ -726,7 +729,17 @@ extern "C" int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid
     int rc = check_cv(ctx, cv, "pmx_wta");
     if (rc) return rc;
     ctx->disp_ready = true;
+    ctx->near_exact = false;
     if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_wta(ctx, cv, invalid_disparity);
+    if (cv->repr == PMX_REPR_SGM_UP_PENDING && (is_max != 0) == (cv->pending.is_max != 0)) {
+        // the last SGM pass and the WTA in one kernel: the optimised volume is neither written nor read
+        const pmx_fam_wta w = {ctx->disp, (float*)ctx->near, (double)cv->d0, cv->subpix, invalid_disparity};
+        rc = pmx_sgm_finish_pending(ctx, const_cast<pmx_cv*>(cv), &w);
+        if (rc) return rc;
+        ctx->near_owner = cv;
+        ctx->near_exact = true;
+        return pmx_launch_wta_fixup(ctx, cv);
+    }
     rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
     if (rc) return rc;
     return pmx_launch_wta(ctx, cv, is_max, invalid_disparity);
@@ -739,6 +752,10 @@ extern "C" int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max
               "pmx_refine: unknown refinement method %d", method);
     PMX_CHECK(ctx->disp_ready, PMX_ERR_STATE, "pmx_refine: no disparity map for this pair yet (run pmx_wta or pmx_set_disparity first)");
     if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_refine(ctx, cv, method);
+    if (cv->repr == PMX_REPR_SGM_UP_PENDING && ctx->near_owner == cv && ctx->near_exact) {
+        ctx->near_exact = false;  // the refined map is no longer the WTA's
+        return pmx_launch_near_refine(ctx, cv, method, is_max);
+    }
     rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
     if (rc) return rc;
     return pmx_launch_refine(ctx, cv, method, is_max);
@@ -762,6 +779,7 @@ extern "C" int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t*
     if (disp) {
         PMX_HIP(hipMemcpyAsync(ctx->disp, disp, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         ctx->disp_ready = true;
+        ctx->near_exact = false;  // an edited map: the winner cache of a fused WTA no longer describes it
     }
     if (validity) PMX_HIP(hipMemcpyAsync(ctx->validity, validity, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -782,6 +800,7 @@ extern "C" int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double 
     PMX_CHECK(ctx && ctx->left && dev_keys, PMX_ERR_ARG, "pmx_wta_from_keys: bad argument");
     PMX_HIP(hipSetDevice(ctx->device));
     ctx->disp_ready = true;
+    ctx->near_exact = false;
     return pmx_launch_from_keys(ctx, dev_keys, d0_global, subpix, invalid_disparity);
 }
 

@@ -35,6 +35,8 @@ void pmx_set_error(const char* fmt, ...);
         }                               \
     } while (0)
 
+struct pmx_fam_wta { float* disp; float* near; double d0; int subpix; float invalid_disparity; };
+
 struct pmx_stage_rec {
     std::vector<hipEvent_t> ev;  // pairs (start, stop) not yet folded into total_ms
     double total_ms = 0.0;
@@ -65,6 +67,7 @@ struct pmx_ctx {
     void* near = nullptr;  // float4 [H][W]: (S[k-1], S[k], S[k+1], k) of the last WTA winner (fast path)
     bool disp_ready = false;  // a disparity map is resident for the current pair (pmx_wta / pmx_wta_from_keys / pmx_set_disparity)
     const void* near_owner = nullptr;  // the volume handle that cache was computed from (nullptr = stale)
+    bool near_exact = false;  // the cache matches the resident disparity map pixel for pixel (no host edit since the WTA that wrote it)
     // scratch volume reused across calls (SGM accumulator, CBCA intermediate)
     float* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -110,7 +113,10 @@ void pmx_pool_free(pmx_ctx* ctx, void* p);
 void pmx_pool_release(pmx_ctx* ctx);  // hipFree every cached block
 
 // exact representations a cost-volume handle can be in (see pmx_set_lazy in the public header)
-enum { PMX_REPR_FLOAT = 0, PMX_REPR_ALL_NAN = 1, PMX_REPR_CENSUS_DEFERRED = 2, PMX_REPR_SGM_U8X8 = 3 };
+// PMX_REPR_SGM_UP_PENDING (float32 family schedule, lazy mode): `data` still holds the matching costs, `spart` the sum of the
+// horizontal and downward paths; the upward family has not run.  pmx_wta runs it in WTA mode (S is never written), anything that
+// needs the optimised volume runs it in store mode first (pmx_cv_materialize).
+enum { PMX_REPR_FLOAT = 0, PMX_REPR_ALL_NAN = 1, PMX_REPR_CENSUS_DEFERRED = 2, PMX_REPR_SGM_U8X8 = 3, PMX_REPR_SGM_UP_PENDING = 4 };
 
 struct pmx_cv {
     pmx_ctx* ctx = nullptr;
@@ -139,6 +145,10 @@ struct pmx_cv {
     uint32_t* range = nullptr;
     size_t range_bytes = 0;
     bool has_range = false;
+    // PMX_REPR_SGM_UP_PENDING: the partial sum volume (kept with the handle for the next pair) and what pmx_sgm was asked for
+    float* spart = nullptr;
+    size_t spart_bytes = 0;
+    struct { float P1, P2, invalid_cost; int is_max, overcounting; } pending = {0.f, 0.f, 0.f, 0, 0};
     size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
 };
 
@@ -237,10 +247,15 @@ int pmx_launch_fill_nan(pmx_ctx* ctx, float* p, size_t n);
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
 bool pmx_sgm_family_supported(const pmx_cv* cv);
 // the six non-horizontal paths of `mask` as two fused marching passes adding into S (which already holds the horizontal ones)
+// fams: bit 0 the downward family, bit 1 the upward one.  wta != nullptr: the upward family (which must be the last pass) does not
+// write S but reduces over D (k_sgmfam.hip WTA mode)
 int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
-                            int mask);
+                            int mask, int fams, const pmx_fam_wta* wta);
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
 int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
+int pmx_launch_near_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);  // from the winner's three values (ctx->near)
+int pmx_launch_wta_fixup(pmx_ctx* ctx, const pmx_cv* cv);                          // validity of the pixels a fused WTA found all-NaN
+int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta);      // runs the upward family of a pending volume
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance);
 int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
 int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);

@@ -82,8 +82,17 @@ def check_config(eng, oracle, monkeypatch, H, W, dmin, dmax, kind, shift):
         costs(eng, cv, kind)
         eng.sgm(cv, P1, P2, is_max, inv, False)
         out[sched] = maps(eng, cv, is_max)
+    # lazy mode: the upward family runs fused with the WTA, the optimised volume is never written
+    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    eng.set_lazy(True)
+    costs(eng, cv, kind)
+    eng.sgm(cv, P1, P2, is_max, inv, False)
+    out["fused"] = maps(eng, cv, is_max)
+    eng.set_lazy(False)
     cv.free()
     for a, b in zip(out["fam"], out["seq"]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(out["fam"], out["fused"]):
         np.testing.assert_array_equal(a, b)
     disp, val, itp = out["fam"]
     o = 5 if is_max else 2

@@ -133,3 +133,63 @@ def test_fused_horizontal_pair_equals_the_two_line_passes(eng, oracle, monkeypat
             for fused in ("1", "0"):
                 monkeypatch.setenv("PMX_SGM_HFUSED", fused)
                 np.testing.assert_array_equal(run(eng, cvh, 1.25, 6.5, is_max, 45.0, over, mask), exp)
+
+
+@pytest.mark.parametrize("is_max,over,D", [(False, False, 129), (True, False, 257), (False, True, 61), (True, True, 40)])
+def test_deferred_last_pass_with_fused_wta(oracle, monkeypatch, is_max, over, D):
+    """Lazy mode + family schedule: pmx_sgm leaves the upward family pending; pmx_wta runs it in WTA mode (the optimised volume is
+    never written) and pmx_refine works from the winner's three values; reading the volume instead runs the pass in store mode.
+    Every route gives the oracle's bits: disparity, validity (all-NaN pixels included), interpolated coefficient, volume."""
+    from pandora_amd.engine import Engine
+
+    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    rng = np.random.default_rng(D)
+    H, W, dmin = 21, 150, -7
+    cvh = volume(rng, H, W, D, is_max, nan_frac=0.1)
+    cvh[5, 7] = np.nan      # a pixel without any cost
+    cvh[9, 100:103] = np.nan
+    inv = 45.0
+    exp = oracle.sgm(cvh, 1.5, 7.25, is_max, inv, over)
+    odisp, oval = oracle.wta(exp, dmin, 1, is_max, -9999.0)
+    e = Engine(0)
+    try:
+        e.set_lazy(True)
+        z = np.zeros((H, W), np.float32)
+        e.set_images(z, z, 1)
+        for method in ("vfit", "quadratic"):
+            oitp, ordisp, orval = oracle.refine(exp, odisp.copy(), oval.copy(), dmin, dmin + D - 1, 1, is_max, method)
+            # route 1: sgm -> wta (fused) -> refine (from the winner cache)
+            cv = e.alloc_cv(D, dmin)
+            cv.from_host(cvh)
+            e.sgm(cv, 1.5, 7.25, is_max, inv, over)
+            e.set_validity(None)
+            e.wta(cv, is_max, -9999.0)
+            d, v = e.get_disparity()
+            np.testing.assert_array_equal(d, odisp)
+            np.testing.assert_array_equal(v, oval)
+            e.refine(cv, method, is_max)
+            d, v, t = e.get_disparity(want_itp=True)
+            np.testing.assert_array_equal(d, ordisp)
+            np.testing.assert_array_equal(v, orval)
+            np.testing.assert_array_equal(t, oitp)
+            # ... and the volume is still there for whoever asks (store mode runs now)
+            np.testing.assert_array_equal(cv.to_host(), exp)
+            # route 2: an edited map between WTA and refinement: the cache is not trusted, the volume is materialised
+            cv.from_host(cvh)
+            e.sgm(cv, 1.5, 7.25, is_max, inv, over)
+            e.set_validity(None)
+            e.wta(cv, is_max, -9999.0)
+            d, v = e.get_disparity()
+            e.set_disparity(d, v)
+            e.refine(cv, method, is_max)
+            d, v, t = e.get_disparity(want_itp=True)
+            np.testing.assert_array_equal(d, ordisp)
+            np.testing.assert_array_equal(t, oitp)
+            # route 3: the handle is reused for another volume while a pass is pending
+            cv.from_host(cvh)
+            e.sgm(cv, 1.5, 7.25, is_max, inv, over)
+            cv.from_host(cvh[::-1].copy())
+            np.testing.assert_array_equal(cv.to_host(), cvh[::-1])
+            cv.free()
+    finally:
+        e.close()
