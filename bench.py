@@ -7,8 +7,9 @@ synthetic stereo pair, inputs already resident in HBM.
 One "step" = one pass of that pipeline over ONE pair, at every N.  Workload = the shape BASELINE.json's north_star quotes its
 target on: 4096x4096, d=[0,256] (D=257; configs[3]'s size with the metric's Census+SGM pipeline; it fits one GPU).  N>1 = the same
 pair over N ranks (strong scaling): row tiles with the 40-pixel margin the reference's SGM step asks of ROI runs
-(optimization/optimization.py:43, marge.py:86-101), every rank runs the pipeline on its rows + margin, and ONE RCCL all-gather of
-the owned rows of the three result maps (inside libpandora_amd.so, on the engine's stream) leaves the full maps on every GPU.  One
+(optimization/optimization.py:43, marge.py:86-101), every rank runs the pipeline on its rows + margin, and ONE RCCL exchange per step
+(a group of ncclSend / ncclRecv inside libpandora_amd.so, on the engine's stream: every rank sends the owned rows of its three result
+maps straight to rank 0 over its own xGMI link) leaves the full maps on GPU 0.  One
 process per GPU, launched by `python -m torch.distributed.run` (only its environment variables are used: no PyTorch in this file).
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the 8-path SGM kernel, HIP-event timed on the engine's stream
@@ -200,7 +201,7 @@ def main():
         run_pipeline(eng, cv, win, P1, P2)
         if comm is not None:
             eng.tile_place(H, own_lo, own_hi, tile_lo, True)
-            comm.allgather_rows(H, True)
+            comm.gather_rows(H, True, root=0)
 
     for _ in range(args.warmup):
         step()
@@ -239,8 +240,8 @@ def main():
             parallelism = "1 GPU, no collective"
         else:
             parallelism = (f"one pair over {world} GPUs: row tiles of {H // world} rows + {SGM_MARGIN}-row margin (the reference's ROI "
-                           f"convention for SGM, paths cut at the margin), one RCCL all-gather of the owned rows of disparity / validity / "
-                           f"coefficient maps per step; strong scaling")
+                           f"convention for SGM, paths cut at the margin), one RCCL gather (ncclSend / ncclRecv group) of the owned rows of "
+                           f"disparity / validity / coefficient maps to GPU 0 per step; strong scaling")
         out = {
             "metric": "Mdisparities/s (HxWxD/s) Census5x5+SGM",
             "value": round(value, 1),
@@ -261,8 +262,8 @@ def main():
             "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4),
         }
         if world > 1:
-            out["collective"] = {"kind": "ncclAllGather of owned rows (3 maps, 16 B/pixel)", "ms_per_step": round(stage["collective"][0] / args.steps, 4),
-                                 "bytes_per_step": H * W * 16}
+            out["collective"] = {"kind": "ncclSend / ncclRecv group: owned rows of 3 maps to rank 0 (10 B/pixel, validity as uint16)",
+                                 "ms_per_step": round(stage["collective"][0] / args.steps, 4), "bytes_per_step": H * W * 10}
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
             host_out = eng.get_disparity(want_itp=True)  # (also faults the host pages in once, as a streaming caller would)

@@ -161,7 +161,8 @@ enum { PMX_XBUF_KEYS = 0,          /* uint64 [H][W]   packed (cost, global index
        PMX_XBUF_FULL_VALIDITY = 5, /* int64  [full_H][W] */
        PMX_XBUF_FULL_ITP = 6,      /* float  [full_H][W] */
        PMX_XBUF_SCALARS = 7,       /* double [8] */
-       PMX_XBUF_COUNT = 8 };
+       PMX_XBUF_FULL_VALIDITY16 = 8, /* uint16 [full_H][W]  the validity mask as it travels (and as the reference stores it) */
+       PMX_XBUF_COUNT = 9 };
 enum { PMX_OP_MIN = 0, PMX_OP_SUM = 1, PMX_OP_MAX = 2 };
 int pmx_comm_unique_id(void* id_out, size_t bytes);                                  /* ncclGetUniqueId; bytes >= 128 */
 int pmx_comm_init(pmx_ctx* ctx, const void* id, size_t bytes, int world, int rank);  /* ncclCommInitRank on the context's GPU */
@@ -192,6 +193,9 @@ int pmx_tile_place(pmx_ctx* ctx, int full_H, int own_lo, int own_hi, int tile_lo
 /* the same from host rows (a PandoraMachine run ends with its maps on the host: filters, validation); itp may be NULL */
 int pmx_set_full_rows(pmx_ctx* ctx, int full_H, int own_lo, int own_hi, const float* disp, const int64_t* validity, const float* itp);
 int pmx_comm_allgather_rows(pmx_ctx* ctx, int with_itp);
+/* the same towards ONE rank (whoever downloads or saves the maps): a group of ncclSend / ncclRecv, every peer straight to the root over
+ * its own xGMI link; the validity mask travels as uint16 (10 B/pixel with the coefficient map, 16 for the all-gather) */
+int pmx_comm_gather_rows(pmx_ctx* ctx, int root, int with_itp);
 int pmx_get_full_maps(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp);
 /* TEST TRANSPORT ONLY: host copies of an exchange buffer, so that two ranks sharing the one GPU of a test box (RCCL refuses that)
  * can reduce through the host.  *count = elements, *elem_bytes = bytes per element. */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "pmx_comm_allreduce": (C.c_int, [vp, C.c_int, C.c_int]),
     "pmx_comm_allreduce_scalars": (C.c_int, [vp, c_double_p, C.c_int]),
     "pmx_comm_allgather_rows": (C.c_int, [vp, C.c_int]),
+    "pmx_comm_gather_rows": (C.c_int, [vp, C.c_int, C.c_int]),
     "pmx_shard_minkey": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "pmx_shard_from_keys": (C.c_int, [vp, C.c_double, C.c_int, C.c_float]),
     "pmx_shard_nan_pixels": (C.c_int, [vp, vp]),
@@ -101,7 +102,7 @@ SIGNATURES = {
 }
 
 XBUFS = {"keys": (0, "uint64"), "nanpix": (1, "uint8"), "refine_pack": (2, "float32"), "refine_flags": (3, "int64"),
-         "full_disp": (4, "float32"), "full_validity": (5, "int64"), "full_itp": (6, "float32"), "scalars": (7, "float64")}
+         "full_disp": (4, "float32"), "full_validity": (5, "int64"), "full_itp": (6, "float32"), "scalars": (7, "float64"), "full_validity16": (8, "uint16")}
 
 STAGES = {
     "census_transform": 0, "census_cost": 1, "sad_ssd": 2, "zncc": 3, "mask": 4, "cbca_arms": 5, "cbca_h": 6,

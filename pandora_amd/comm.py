@@ -260,6 +260,15 @@ class Comm:
                 full[rlo:rhi] = np.frombuffer(blob, full.dtype).reshape(rhi - rlo, -1)
             self.engine.xbuf_upload(which, full)
 
+    def gather_rows(self, H, with_itp, root=0):
+        """Every rank placed its owned rows in the engine's full-size maps; afterwards rank `root` holds all rows."""
+        if self.world == 1 and not self.always:
+            return
+        if self.backend == "rccl":
+            self.engine.comm_gather_rows(root, with_itp)
+        else:
+            self.allgather_rows(H, with_itp)  # test transports: everybody gets everything
+
     def close(self):
         if self.backend == "rccl" and self.engine is not None:
             self.engine.comm_destroy()

@@ -30,6 +30,10 @@ struct pmx_comm {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -67,6 +71,10 @@ static int load_rccl(pmx_comm** out) {
         PMX_SYM(AllReduce, "ncclAllReduce")
         PMX_SYM(AllGather, "ncclAllGather")
         PMX_SYM(ReduceScatter, "ncclReduceScatter")
+        PMX_SYM(Send, "ncclSend")
+        PMX_SYM(Recv, "ncclRecv")
+        PMX_SYM(GroupStart, "ncclGroupStart")
+        PMX_SYM(GroupEnd, "ncclGroupEnd")
         PMX_SYM(GetErrorString, "ncclGetErrorString")
 #undef PMX_SYM
         g_loader = c;
@@ -127,14 +135,14 @@ extern "C" int pmx_comm_info(const pmx_ctx* ctx, int* world, int* rank) {
 }
 
 // ---- exchange buffers ------------------------------------------------------------------------------------------------
-static const size_t kElem[PMX_XBUF_COUNT] = {8, 1, 4, 8, 4, 8, 4, 8};
+static const size_t kElem[PMX_XBUF_COUNT] = {8, 1, 4, 8, 4, 8, 4, 8, 2};
 
 static size_t xbuf_count(const pmx_ctx* ctx, int which) {
     const size_t npix = (size_t)ctx->H * ctx->W, nfull = (size_t)ctx->full_H * ctx->W;
     switch (which) {
         case PMX_XBUF_KEYS: case PMX_XBUF_NANPIX: case PMX_XBUF_REFINE_FLAGS: return npix;
         case PMX_XBUF_REFINE_PACK: return 4 * npix;
-        case PMX_XBUF_FULL_DISP: case PMX_XBUF_FULL_VALIDITY: case PMX_XBUF_FULL_ITP: return nfull;
+        case PMX_XBUF_FULL_DISP: case PMX_XBUF_FULL_VALIDITY: case PMX_XBUF_FULL_ITP: case PMX_XBUF_FULL_VALIDITY16: return nfull;
         case PMX_XBUF_SCALARS: return 8;
         default: return 0;
     }
@@ -268,6 +276,70 @@ extern "C" int pmx_comm_allgather_rows(pmx_ctx* ctx, int with_itp) {
             pmx_pool_free(ctx, stage);  // stream-ordered reuse
         }
     }
+    return PMX_OK;
+}
+
+// int64 validity bits <-> the 16 bits they need (the reference stores the mask as uint16, common.py:160-170): what travels
+__global__ __launch_bounds__(256) void narrow_validity_kernel(const int64_t* __restrict__ in, size_t n, uint16_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (uint16_t)in[i];
+}
+__global__ __launch_bounds__(256) void widen_validity_kernel(const uint16_t* __restrict__ in, size_t n, int64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
+}
+
+// Every rank holds its owned rows of the full-size maps; afterwards rank `root` holds all rows (the other ranks' maps are
+// unchanged).  One group of ncclSend / ncclRecv: every peer sends straight to the root over its own xGMI link, which an
+// all-gather's ring would not do.  The validity mask travels as 16 bits per pixel: 10 B/pixel in all (6 without the coefficient).
+extern "C" int pmx_comm_gather_rows(pmx_ctx* ctx, int root, int with_itp) {
+    PMX_CHECK(ctx && ctx->comm, PMX_ERR_STATE, "pmx_comm_gather_rows: no communicator (pmx_comm_init)");
+    PMX_CHECK(ctx->full_H > 0, PMX_ERR_STATE, "pmx_comm_gather_rows: pmx_tile_place first");
+    pmx_comm* c = ctx->comm;
+    PMX_CHECK(root >= 0 && root < c->world, PMX_ERR_ARG, "pmx_comm_gather_rows: root %d of %d ranks", root, c->world);
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int H = ctx->full_H, W = ctx->W;
+    int lo, hi;
+    shard_rows(H, c->world, c->rank, &lo, &hi);
+    int rc = xbuf_need(ctx, PMX_XBUF_FULL_VALIDITY16);
+    if (!rc) rc = xbuf_need(ctx, PMX_XBUF_FULL_VALIDITY);
+    if (!rc) rc = xbuf_need(ctx, PMX_XBUF_FULL_DISP);
+    if (!rc && with_itp) rc = xbuf_need(ctx, PMX_XBUF_FULL_ITP);
+    if (rc) return rc;
+    pmx_stage_scope t(ctx, PMX_STAGE_COLLECTIVE);
+    uint16_t* v16 = (uint16_t*)ctx->xbuf[PMX_XBUF_FULL_VALIDITY16];
+    int64_t* v64 = (int64_t*)ctx->xbuf[PMX_XBUF_FULL_VALIDITY];
+    const size_t own_n = (size_t)(hi - lo) * W;
+    if (c->rank != root)
+        hipLaunchKernelGGL(narrow_validity_kernel, dim3((unsigned)((own_n + 255) / 256)), dim3(256), 0, ctx->stream, v64 + (size_t)lo * W, own_n,
+                           v16 + (size_t)lo * W);
+    struct { void* p; size_t es; } maps[3] = {{ctx->xbuf[PMX_XBUF_FULL_DISP], 4}, {v16, 2}, {with_itp ? ctx->xbuf[PMX_XBUF_FULL_ITP] : nullptr, 4}};
+    PMX_NCCL(c, c->GroupStart());
+    for (auto& m : maps) {
+        if (!m.p) continue;
+        if (c->rank == root) {
+            for (int r = 0; r < c->world; ++r) {
+                if (r == root) continue;
+                int rlo, rhi;
+                shard_rows(H, c->world, r, &rlo, &rhi);
+                PMX_NCCL(c, c->Recv((char*)m.p + (size_t)rlo * W * m.es, (size_t)(rhi - rlo) * W * m.es, ncclInt8, r, c->comm, ctx->stream));
+            }
+        } else {
+            PMX_NCCL(c, c->Send((const char*)m.p + (size_t)lo * W * m.es, own_n * m.es, ncclInt8, root, c->comm, ctx->stream));
+        }
+    }
+    PMX_NCCL(c, c->GroupEnd());
+    if (c->rank == root) {  // the peers' 16-bit rows into the int64 map (the root's own rows are already there)
+        for (int r = 0; r < c->world; ++r) {
+            if (r == root) continue;
+            int rlo, rhi;
+            shard_rows(H, c->world, r, &rlo, &rhi);
+            const size_t n = (size_t)(rhi - rlo) * W;
+            hipLaunchKernelGGL(widen_validity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, v16 + (size_t)rlo * W, n,
+                               v64 + (size_t)rlo * W);
+        }
+    }
+    PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 

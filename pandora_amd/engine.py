@@ -497,6 +497,9 @@ class Engine:
     def comm_allgather_rows(self, with_itp):
         check(_lib.lib().pmx_comm_allgather_rows(self.ctx, int(bool(with_itp))), "pmx_comm_allgather_rows")
 
+    def comm_gather_rows(self, root, with_itp):
+        check(_lib.lib().pmx_comm_gather_rows(self.ctx, int(root), int(bool(with_itp))), "pmx_comm_gather_rows")
+
     def xbuf_download(self, which):
         """TEST TRANSPORT ONLY (two ranks on one GPU): host copy of an exchange buffer."""
         idx, dtype = _lib.XBUFS[which]

@@ -49,4 +49,4 @@ def test_bench_runs_one_pair_over_two_ranks():
     lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
     assert len(lines) == 1 and not outs[1][0].strip(), outs
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"] and d["collective"]["bytes_per_step"] == 300 * 256 * 16
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"] and d["collective"]["bytes_per_step"] == 300 * 256 * 10

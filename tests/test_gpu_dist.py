@@ -78,6 +78,12 @@ def test_row_tile_gather_through_rccl(world1, H):
     np.testing.assert_array_equal(fd, d[:H])
     np.testing.assert_array_equal(fv, v[:H])
     np.testing.assert_array_equal(ft, t[:H])
+    # the same through the gather to one rank (ncclSend / ncclRecv group; with one rank: the validity narrowing / widening only)
+    eng.tile_place(H, 0, H, 0, True)
+    comm.gather_rows(H, True, root=0)
+    fd, fv, ft = eng.get_full_maps(H, want_itp=True)
+    np.testing.assert_array_equal(fd, d[:H])
+    np.testing.assert_array_equal(fv, v[:H])
     # a tile that starts above its owned rows
     eng.tile_place(H + margin - 5, 5, H + margin - 5, 0, False)
     fd, fv = eng.get_full_maps(H + margin - 5)
