@@ -223,8 +223,13 @@ static int sgm_pass_mode(int mask, int k) {
 }
 
 template <int KPL>
+static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask);
+
+template <int KPL>
 static int sgm_run(pmx_ctx* ctx, const sgm_args& base, int mask) {
-    for (int k = 0; k < 8; ++k)
+    int rc = sgm_run_horizontal<KPL>(ctx, base, mask);  // the pair fused when both are wanted
+    if (rc) return rc;
+    for (int k = 2; k < 8; ++k)
         if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
     PMX_HIP(hipGetLastError());
     return PMX_OK;

@@ -19,23 +19,26 @@ constexpr unsigned kOob = 0x80000000u;       // a byte offset beyond every row: 
 // for buffer instructions).  piece i = [piece_start(i), piece_start(i) + piece_width(i)).
 template <int KPL>
 struct pieces {
-    static constexpr int N4 = KPL / 4, N = N4 + ((KPL & 2) ? 1 : 0) + (KPL & 1);
-    static constexpr int start(int i) { return i < N4 ? 4 * i : (i == N4 && (KPL & 2)) ? 4 * N4 : KPL - 1; }
-    static constexpr int width(int i) { return i < N4 ? 4 : (i == N4 && (KPL & 2)) ? 2 : 1; }
+    static constexpr int N4 = KPL / 4, R = KPL % 4, N = N4 + (R ? 1 : 0);
+    static constexpr int start(int i) { return 4 * i; }
+    static constexpr int width(int i) { return i < N4 ? 4 : R; }  // the remainder moves as ONE 12-, 8- or 4-byte piece
 };
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
 template <int KPL>
 __device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, float (&dst)[KPL]) {
     using P = pieces<KPL>;
 #pragma unroll
     for (int i = 0; i < P::N; ++i) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int k = P::start(i);
         if (P::width(i) == 4) {
             const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 4 * k, 0, 0);
             dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y);
             dst[k + 2] = __uint_as_float(t.z); dst[k + 3] = __uint_as_float(t.w);
+        } else if (P::width(i) == 3) {
+            const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + 4 * k, 0, 0);
+            dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y); dst[k + 2] = __uint_as_float(t.z);
         } else if (P::width(i) == 2) {
             const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 4 * k, 0, 0);
             dst[k] = __uint_as_float(t.x); dst[k + 1] = __uint_as_float(t.y);
@@ -61,6 +64,10 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned ba
             u32x4 t;
             t.x = __float_as_uint(v[k]); t.y = __float_as_uint(v[k + 1]); t.z = __float_as_uint(v[k + 2]); t.w = __float_as_uint(v[k + 3]);
             __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
+        } else if (P::width(i) == 3) {
+            u32x3 t;
+            t.x = __float_as_uint(v[k]); t.y = __float_as_uint(v[k + 1]); t.z = __float_as_uint(v[k + 2]);
+            __builtin_amdgcn_raw_buffer_store_b96(t, rs, off, 0, 0);
         } else if (P::width(i) == 2) {
             u32x2 t;
             t.x = __float_as_uint(v[k]); t.y = __float_as_uint(v[k + 1]);
