@@ -120,13 +120,32 @@ class AbstractMatchingCost:
         rng = np.arange(disparity_min, disparity_max, 1 / float(subpix), dtype=np.float64)
         return np.append(rng, [disparity_max])
 
+    @staticmethod
+    def find_nearest_multiple_of_step(value, step):
+        """matching_cost.py:618-632: the nearest multiple of step that is >= value"""
+        return -(-value // step) * step
+
+    @staticmethod
+    def get_coordinates(margin, img_coordinates, step):
+        """matching_cost.py:269-328: the columns to compute for a ROI read with `margin` columns on its left: every step-th column,
+        phased so that the ROI's first column is one of them."""
+        first, last = img_coordinates[0], img_coordinates[-1]
+        if margin % step == 0:
+            start = 0
+        elif margin < step:
+            start = margin
+        else:
+            start = step - (AbstractMatchingCost.find_nearest_multiple_of_step(margin, step) - margin)
+        return np.arange(first + start, last + 1, step)
+
     def grid_estimation(self, img, cfg, disparity_grids):
         """matching_cost.py:330-375: the dataset (coords row / col / disp, the image's attrs, sampling_interval,
         col_to_compute) that will hold the cost volume."""
-        if cfg and "ROI" in cfg:
-            raise ConfigError("ROI tiling is out of scope of pandora_amd (SURVEY 8: margins/ROI are caller-side)")
         c_col = np.asarray(img.coords["col"])
-        index_compute_col = np.arange(c_col[0], c_col[-1] + 1, self._step_col)
+        if cfg and "ROI" in cfg:  # matching_cost.py:353-354: start so that the ROI's first column is computed
+            index_compute_col = self.get_coordinates(cfg["ROI"]["margins"][0], c_col, self._step_col)
+        else:
+            index_compute_col = np.arange(c_col[0], c_col[-1] + 1, self._step_col)
         grids = [np.asarray(g.data if hasattr(g, "data") and not isinstance(g, np.ndarray) else g) for g in disparity_grids]
         disparity_min, disparity_max = self.get_min_max_from_grid(grids[0], grids[1])
         disparity_range = self.get_disparity_range(disparity_min, disparity_max, self._subpix)

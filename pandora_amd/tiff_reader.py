@@ -13,6 +13,58 @@ _TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 8: "h", 9: "i", 11: "
 _SIZES = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 8: 2, 9: 4, 11: 4, 12: 8, 16: 8}
 
 
+GEO_TAGS = (33550, 33922, 34264, 34735, 34736, 34737, 42113)  # pixel scale, tiepoints, 4x4 transformation, GeoKey directory /
+#                                                                  double / ASCII parameters, GDAL no-data
+
+
+def read_tags(path):
+    """Every tag of the first image directory of a classic TIFF as {tag: (type, count, raw little-endian bytes)}; no pixel is
+    decoded, so this also works on files whose layout read_tiff refuses (tiles, LZW ...)."""
+    with open(path, "rb") as f:
+        b = f.read()
+    if b[:2] not in (b"II", b"MM") or struct.unpack(("<" if b[:2] == b"II" else ">") + "H", b[2:4])[0] != 42:
+        return {}
+    bo = "<" if b[:2] == b"II" else ">"
+    off = struct.unpack(bo + "I", b[4:8])[0]
+    n = struct.unpack(bo + "H", b[off:off + 2])[0]
+    tags = {}
+    for i in range(n):
+        tag, typ, cnt, raw = struct.unpack(bo + "HHI4s", b[off + 2 + 12 * i:off + 14 + 12 * i])
+        size = _SIZES.get(typ, 1) * cnt
+        data = raw[:size] if size <= 4 else b[struct.unpack(bo + "I", raw)[0]:struct.unpack(bo + "I", raw)[0] + size]
+        if bo == ">" and typ in _TYPES and typ not in (2, 5) and _SIZES[typ] > 1:  # keep what travels little-endian
+            data = struct.pack("<" + _TYPES[typ] * cnt, *struct.unpack(">" + _TYPES[typ] * cnt, data))
+        tags[tag] = (typ, cnt, bytes(data))
+    return tags
+
+
+def read_georeferencing(path):
+    """-> (crs, transform) of a GeoTIFF, or (None, None).  `crs` is an opaque holder of the file's georeferencing tags (written back
+    unchanged by write_tiff: the passthrough the reference does with rasterio's crs object); `transform` the affine
+    (a, b, c, d, e, f) with x = a col + b row + c, y = d col + e row + f, from the 4x4 transformation or pixel scale + tiepoint."""
+    try:
+        tags = read_tags(path)
+    except (OSError, struct.error):
+        return None, None
+    geo = {t: tags[t] for t in GEO_TAGS if t in tags}
+    if 34735 not in geo:
+        return None, None
+
+    def doubles(t):
+        typ, cnt, raw = tags[t]
+        return struct.unpack("<" + "d" * cnt, raw)
+
+    transform = None
+    if 34264 in tags:
+        m = doubles(34264)
+        transform = (m[0], m[1], m[3], m[4], m[5], m[7])
+    elif 33550 in tags and 33922 in tags:
+        sx, sy = doubles(33550)[:2]
+        i, j, _, x, y, _ = doubles(33922)[:6]
+        transform = (sx, 0.0, x - i * sx, 0.0, -sy, y + j * sy)
+    return {"geotiff_tags": geo}, transform
+
+
 def read_tiff(path):
     """-> (array (row, col) or (band, row, col) in the file's sample type, list of band descriptions or None)"""
     with open(path, "rb") as f:
@@ -70,7 +122,7 @@ def read_tiff(path):
     return (data[0] if spp == 1 else data), names
 
 
-def write_tiff(path, data, band_names=None):
+def write_tiff(path, data, band_names=None, geo=None):
     """Classic little-endian TIFF, uncompressed, one strip per band (planar layout when there are several bands), sample type of
     ``data`` (uint8/16/32, int8/16/32, float32/64); band descriptions go into GDAL's metadata tag so that GDAL / rasterio (and
     read_tiff) give them back.  data: (row, col) or (band, row, col)."""
@@ -97,6 +149,8 @@ def write_tiff(path, data, band_names=None):
         entries.append((338, 3, B - 1, [0] * (B - 1)))
     if meta:
         entries.append((42112, 2, len(meta), meta))
+    for tag, (typ, cnt, raw) in sorted((geo or {}).items()):  # georeferencing tags of the input, byte for byte
+        entries.append((tag, typ, cnt, raw))
     entries.sort(key=lambda e: e[0])
     ifd_off = 8
     ifd_size = 2 + 12 * len(entries) + 4

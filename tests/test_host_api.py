@@ -580,3 +580,93 @@ def test_configuration_limits_of_the_device_kernels_are_refused_at_check_conf():
         cvc.AbstractCostVolumeConfidence(**{"confidence_method": "ambiguity", "eta_max": 0.9, "eta_step": 0.0005})
     with pytest.raises(ConfigError, match="up to 15"):
         flt.AbstractFilter(cfg={"filter_method": "median", "filter_size": 17})
+
+
+# ---- SURVEY 8f N5 remainder: ROI windows and georeferencing passthrough --------------------------------------------------
+_ROI_SHAPE = (8, 11)  # tests/test_pandora_image.py:259-277
+
+
+@pytest.mark.parametrize("roi,expected", [
+    ({"col": {"first": 3, "last": 5}, "row": {"first": 3, "last": 5}, "margins": [2, 2, 2, 2]}, (1, 1, 7, 7)),    # :279-292
+    ({"col": {"first": 0, "last": 2}, "row": {"first": 3, "last": 5}, "margins": [2, 2, 2, 2]}, (0, 1, 5, 7)),    # :294-326 left
+    ({"col": {"first": 10, "last": 12}, "row": {"first": 3, "last": 5}, "margins": [2, 2, 2, 2]}, (8, 1, 3, 7)),  # right
+    ({"col": {"first": 3, "last": 5}, "row": {"first": -1, "last": 5}, "margins": [2, 2, 2, 2]}, (1, 0, 7, 8)),   # up
+    ({"col": {"first": 3, "last": 5}, "row": {"first": 9, "last": 11}, "margins": [2, 2, 2, 2]}, (1, 7, 7, 1)),   # down
+])
+def test_get_window_reference_vectors(roi, expected):
+    from pandora_amd.img_tools import get_window
+
+    assert tuple(get_window(roi, _ROI_SHAPE[1], _ROI_SHAPE[0])) == expected
+
+
+@pytest.mark.parametrize("roi", [
+    {"col": {"first": -10, "last": -12}, "row": {"first": 3, "last": 5}, "margins": [2, 2, 2, 2]},   # tests/test_pandora_image.py:328-357
+    {"col": {"first": 100, "last": 120}, "row": {"first": 3, "last": 5}, "margins": [2, 2, 2, 2]},
+    {"col": {"first": 3, "last": 5}, "row": {"first": -6, "last": -5}, "margins": [2, 2, 2, 2]},
+    {"col": {"first": 3, "last": 5}, "row": {"first": 11, "last": 111}, "margins": [2, 2, 2, 2]},
+])
+def test_get_window_outside_the_image(roi):
+    from pandora_amd.img_tools import get_window
+
+    with pytest.raises(ValueError, match="Roi specified is outside the image"):
+        get_window(roi, _ROI_SHAPE[1], _ROI_SHAPE[0])
+
+
+@pytest.mark.parametrize("step,margin,coords,truth", [  # tests/test_matching_cost/test_matching_cost.py:198-236
+    (2, 4, np.arange(0, 20, 2), np.arange(0, 20, 2)),
+    (3, 2, np.arange(8, 24, 3), np.arange(10, 24, 3)),
+    (2, 3, np.arange(7, 24, 2), np.arange(8, 24, 2)),
+])
+def test_get_coordinates_reference_vectors(step, margin, coords, truth):
+    np.testing.assert_array_equal(matching_cost.AbstractMatchingCost.get_coordinates(margin, coords, step), truth)
+
+
+def test_roi_dataset_and_georeferencing_passthrough(tmp_path):
+    """create_dataset_from_inputs with a ROI (tests/test_pandora_image.py:669-699: the window's pixels, coordinates starting at its
+    offset; mask and disparity-grid files cut the same way), and a GeoTIFF's georeferencing tags travelling from the input image
+    through attrs["crs"] / attrs["transform"] into every file save_results writes (common.py:112-181)."""
+    import struct
+
+    from pandora_amd import common, img_tools
+    from pandora_amd.tiff_reader import read_georeferencing, read_tags, write_tiff
+
+    im = np.array([[np.inf, 1, 2, 5, 1, 3, 6, 4, 9, 7, 8], [5, 1, 2, 7, 1, 4, 7, 8, 5, 8, 0], [1, 2, 0, 3, 0, 4, 0, 6, 7, 4, 9],
+                   [4, 9, 4, 0, 1, 3, 7, 4, 6, 9, 2], [2, 3, 5, 0, 1, 5, 9, 2, 8, 6, 7], [1, 2, 4, 5, 2, 6, 7, 7, 3, 7, 0],
+                   [1, 2, 0, 3, 0, 4, 0, 6, 7, 4, 9], [np.inf, 9, 4, 0, 1, 3, 7, 4, 6, 9, 2]], np.float32)
+    geo = {33550: (12, 3, struct.pack("<3d", 0.5, 0.5, 0.0)), 33922: (12, 6, struct.pack("<6d", 0, 0, 0, 600000.0, 4800000.0, 0)),
+           34735: (3, 16, struct.pack("<16H", 1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32631)),  # projected, EPSG:32631
+           34737: (2, 8, b"WGS 84|\0")}
+    left_path, msk_path, grid_path = (str(tmp_path / n) for n in ("left.tif", "msk.tif", "grid.tif"))
+    write_tiff(left_path, im, geo=geo)
+    msk = np.zeros(im.shape, np.uint8)
+    msk[4, 4] = 7
+    write_tiff(msk_path, msk)
+    write_tiff(grid_path, np.stack([np.full(im.shape, -3.0, np.float32) - np.arange(11, dtype=np.float32), np.full(im.shape, 2.0, np.float32)]))
+    roi = {"col": {"first": 3, "last": 5}, "row": {"first": 3, "last": 5}, "margins": [2, 2, 2, 2]}
+    ds = img_tools.create_dataset_from_inputs({"img": left_path, "nodata": np.inf, "mask": msk_path, "disp": grid_path}, roi=roi)
+    np.testing.assert_array_equal(ds["im"].data, np.where(np.isinf(im), -9999, im)[1:8, 1:8])
+    np.testing.assert_array_equal(ds.coords["row"], np.arange(1, 8))
+    np.testing.assert_array_equal(ds.coords["col"], np.arange(1, 8))
+    assert ds["msk"].data[3, 3] == 2 and ds["msk"].data[6, 0] == 0 and ds["msk"].data.shape == (7, 7)  # msk[4, 4] of the file
+    np.testing.assert_array_equal(ds["disparity"].data[0, 0], -3.0 - np.arange(1, 8))
+    crs, transform = ds.attrs["crs"], ds.attrs["transform"]
+    assert crs is not None and transform == (0.5, 0.0, 600000.0, 0.0, -0.5, 4800000.0)
+    # the ROI reaches grid_estimation through the configuration (matching_cost.py:353-354)
+    mc = matching_cost.AbstractMatchingCost(matching_cost_method="census", window_size=3)
+    grid = mc.grid_estimation(ds, {"ROI": roi}, (ds["disparity"].sel(band_disp="min"), ds["disparity"].sel(band_disp="max")))
+    np.testing.assert_array_equal(grid.attrs["col_to_compute"], np.arange(1, 8))
+    assert grid.attrs["crs"] is crs
+    # ... and out again with the results
+    from pandora_amd.dataset import Dataset
+
+    res = Dataset({"disparity_map": (("row", "col"), np.zeros((7, 7), np.float32)), "validity_mask": (("row", "col"), np.zeros((7, 7), np.int64))},
+                  coords={"row": np.arange(7), "col": np.arange(7)}, attrs={"crs": crs, "transform": transform})
+    common.save_results(res, Dataset(), str(tmp_path / "out"))
+    for name in ("left_disparity.tif", "left_validity_mask.tif"):
+        tags = read_tags(str(tmp_path / "out" / name))
+        assert {t: tags[t] for t in geo} == geo
+        assert read_georeferencing(str(tmp_path / "out" / name))[1] == transform
+    # an image without a GeoKey directory has neither crs nor transform (img_tools.py:400-403)
+    write_tiff(left_path, im)
+    plain = img_tools.create_dataset_from_inputs({"img": left_path, "nodata": np.inf, "disp": [-2, 2]})
+    assert plain.attrs["crs"] is None and plain.attrs["transform"] is None

@@ -510,3 +510,35 @@ def test_resident_pair_is_refreshed_when_arrays_are_replaced_or_edited(oracle):
         disp, _ = pandora_amd.run(machine, left, right, c)
         want, _ = oracle.wta(oracle.census_cost(L, np.roll(R, k, axis=1), 21, -20, 1, 5), -20, 1, False, np.nan)
         np.testing.assert_array_equal(disp["disparity_map"].data, want)
+
+
+@pytest.mark.gpu
+def test_region_of_interest_run_equals_the_full_run_inside_the_window():
+    """A ROI read with margins (img_tools.get_window, create_dataset_from_inputs(roi=...), cfg["ROI"] reaching grid_estimation:
+    the reference's tiling entry for callers like CARS) through a local pipeline: away from the window's border by the window
+    radius the maps are the full-image run's, and the dataset's coordinates place them in the image."""
+    import pandora_amd
+    from pandora_amd.img_tools import create_dataset_from_inputs
+    from pandora_amd.state_machine import PandoraMachine
+
+    pipe = {"matching_cost": {"matching_cost_method": "zncc", "window_size": 5, "subpix": 2},
+            "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"}, "refinement": {"refinement_method": "quadratic"}}
+    roi = {"col": {"first": 150, "last": 300}, "row": {"first": 100, "last": 220}, "margins": [70, 10, 10, 10]}
+
+    def run(r):
+        left = create_dataset_from_inputs({"img": os.path.join(CONES, "left.png"), "nodata": np.nan, "disp": [-60, 0]}, roi=r)
+        right = create_dataset_from_inputs({"img": os.path.join(CONES, "right.png"), "nodata": np.nan, "disp": [0, 60]}, roi=r)
+        m = PandoraMachine()
+        cfg = {"pipeline": m.check_conf({"pipeline": dict(pipe)}, left, right)["pipeline"]}
+        if r is not None:
+            cfg["ROI"] = r
+        out, _ = pandora_amd.run(m, left, right, cfg)
+        return out
+
+    full, part = run(None), run(roi)
+    rows, cols = np.asarray(part.coords["row"]), np.asarray(part.coords["col"])
+    assert rows[0] == 90 and rows[-1] == 230 and cols[0] == 80 and cols[-1] == 310
+    # the window's left margin (70 >= 60 disparities + the window radius) gives the ROI's own pixels their whole search range
+    sel_r, sel_c = slice(100 - 90, 221 - 90), slice(150 - 80, 301 - 80)
+    for key in ("disparity_map", "validity_mask", "interpolated_coeff"):
+        np.testing.assert_array_equal(np.asarray(part[key].data)[sel_r, sel_c], np.asarray(full[key].data)[100:221, 150:301], err_msg=key)
