@@ -49,6 +49,11 @@ int pmx_sync(pmx_ctx* ctx);
  * image hand-off of every compute_cost_volume (e.g. matching_cost/census.py:113-133). */
 int pmx_set_images(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix);
 
+/* Replace the k-th shifted right image (k = 1 .. subpix-1, float32 [H][W-1]) that pmx_set_images built with linear interpolation:
+ * matching_cost's "spline_order" 2..5 resamples with scipy.ndimage.zoom(order=...) on the host (img_tools.py:713-752; 2-D work) and
+ * hands the result over. */
+int pmx_set_shifted_right(pmx_ctx* ctx, int k, const float* shifted);
+
 /* Optional int16 masks (NULL = all valid), convention of img attrs valid_pixels / no_data_mask.
  * Feeds the masks_dilatation predicate of cv_masked (matching_cost/matching_cost.py:484-602) and
  * the CBCA pre-masking (aggregation/cbca.py:217-262). */

@@ -79,25 +79,26 @@ def census_transform(img, win):
     return out
 
 
-def _cv_call(fn, L, R, D, d0, subpix, win, *extra, fill_nan=True):
+def _cv_call(fn, L, R, D, d0, subpix, win, *extra, fill_nan=True, shifted=None):
+    """shifted: the subpix-1 shifted right images to use instead of the linear ones (spline_order > 1)"""
     L = _f32(L)
     H, W = L.shape
-    Rs = pack_shifted(shift_right(R, subpix))
+    Rs = pack_shifted(shift_right(R, subpix) if shifted is None else [R] + list(shifted))
     cv = np.full((H, W, D), np.nan, np.float32) if fill_nan else np.empty((H, W, D), np.float32)
     fn(_p(L), _p(Rs), H, W, D, int(d0), subpix, win, *extra, _p(cv))
     return cv
 
 
-def census_cost(L, R, D, d0, subpix, win):
-    return _cv_call(lib().orc_census_cost, L, R, D, d0, subpix, win)
+def census_cost(L, R, D, d0, subpix, win, shifted=None):
+    return _cv_call(lib().orc_census_cost, L, R, D, d0, subpix, win, shifted=shifted)
 
 
-def sad_ssd(L, R, D, d0, subpix, win, squared):
-    return _cv_call(lib().orc_sad_ssd, L, R, D, d0, subpix, win, int(squared))
+def sad_ssd(L, R, D, d0, subpix, win, squared, shifted=None):
+    return _cv_call(lib().orc_sad_ssd, L, R, D, d0, subpix, win, int(squared), shifted=shifted)
 
 
-def zncc(L, R, D, d0, subpix, win):
-    return _cv_call(lib().orc_zncc, L, R, D, d0, subpix, win)
+def zncc(L, R, D, d0, subpix, win, shifted=None):
+    return _cv_call(lib().orc_zncc, L, R, D, d0, subpix, win, shifted=shifted)
 
 
 def mask_dilatation(msk, win, valid=0, nodata=1):

@@ -340,6 +340,16 @@ extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* righ
     return PMX_OK;
 }
 
+extern "C" int pmx_set_shifted_right(pmx_ctx* ctx, int k, const float* shifted) {
+    PMX_CHECK(ctx && ctx->left && shifted, PMX_ERR_STATE, "pmx_set_shifted_right: call pmx_set_images first");
+    PMX_CHECK(k >= 1 && k < ctx->subpix, PMX_ERR_ARG, "pmx_set_shifted_right: image %d of a pair with subpix %d", k, ctx->subpix);
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipMemcpyAsync(ctx->right[k], shifted, (size_t)ctx->H * (ctx->W - 1) * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->bad_win = 0;
+    return PMX_OK;
+}
+
 extern "C" int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_t* msk_right, int valid_value,
                              int nodata_value) {
     PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_masks: call pmx_set_images first");

@@ -185,6 +185,13 @@ class Engine:
         check(_lib.lib().pmx_set_images(self.ctx, _p(left, C.c_float), _p(right, C.c_float), self.H, self.W, self.subpix),
               "pmx_set_images")
 
+    def set_shifted_right(self, k, img):
+        """the k-th shifted right image resampled on the host (spline_order > 1): float32 (H, W - 1)"""
+        a = np.ascontiguousarray(img, np.float32)
+        if a.shape != (self.H, self.W - 1):
+            raise ValueError(f"shifted right image {a.shape} != {(self.H, self.W - 1)}")
+        check(_lib.lib().pmx_set_shifted_right(self.ctx, int(k), _p(a, C.c_float)), "pmx_set_shifted_right")
+
     def set_masks(self, msk_left=None, msk_right=None, valid=0, nodata=1):
         ml = None if msk_left is None else np.ascontiguousarray(msk_left, np.int16)
         mr = None if msk_right is None else np.ascontiguousarray(msk_right, np.int16)

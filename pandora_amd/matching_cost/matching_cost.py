@@ -77,8 +77,6 @@ class AbstractMatchingCost:
             raise ConfigError("band must be a string or None")
         if not isinstance(cfg["spline_order"], int) or not 1 <= cfg["spline_order"] <= 5:
             raise ConfigError("spline_order must be an int in [1, 5]")
-        if cfg["spline_order"] != 1 and cfg["subpix"] != 1:
-            raise ConfigError("pandora_amd resamples the right image with spline_order 1 only")
         return cfg
 
     def check_band_input_mc(self, img_left, img_right):
@@ -167,7 +165,7 @@ class AbstractMatchingCost:
 
     def _bind_device_volume(self, img_left, img_right, cost_volume):
         self.check_band_input_mc(img_left, img_right)
-        eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band)
+        eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band, spline_order=self._spline_order)
         dcv = eng.alloc_cv(cost_volume.attrs["_D"], cost_volume.attrs["_d0"])
         cost_volume.data_vars["cost_volume"] = DeviceVolumeArray(dcv, {k: cost_volume.coords[k] for k in ("row", "col", "disp")})
         return eng, dcv
@@ -198,7 +196,7 @@ class AbstractMatchingCost:
     def cv_masked(self, img_left, img_right, cost_volume, disp_min, disp_max):
         """In place: NaN for invalid / (dilated) no-data pixels and for disparities outside the
         per-pixel [disp_min, disp_max]; then the validity-mask updates of criteria.py:291-353."""
-        eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band)
+        eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band, spline_order=self._spline_order)
         dcv = cost_volume["cost_volume"].device_cv
         for side in (img_left, img_right):
             if "msk" in side.data_vars and (side.attrs.get("valid_pixels", 0) != img_left.attrs.get("valid_pixels", 0)

@@ -35,14 +35,14 @@ def _sample(a):
     return _digest(memoryview(a).cast("B"))
 
 
-def _key(img_left, img_right, subpix, band):
+def _key(img_left, img_right, subpix, band, spline_order=1):
     def ident(ds):
         im = ds["im"].data
         msk = ds["msk"].data if "msk" in ds.data_vars else None
         return (id(im), im.shape, _sample(im), None if msk is None else (id(msk), _sample(msk)))
 
     return (ident(img_left), ident(img_right), int(subpix), img_left.attrs.get("valid_pixels", 0),
-            img_left.attrs.get("no_data_mask", 1), band)
+            img_left.attrs.get("no_data_mask", 1), band, int(spline_order) if subpix > 1 else 1)
 
 
 def _holders(img_left, img_right):
@@ -60,13 +60,28 @@ def select_band(ds, band):
     return im[list(ds.coords["band_im"]).index(band)]
 
 
-def ensure_pair(img_left, img_right, subpix, device=None, band=None):
+def shifted_right_images(right, subpix, order):
+    """img_tools.py:713-752 shift_right_img for k = 1 .. subpix-1: the reference's own expression (scipy.ndimage.zoom)."""
+    from scipy.ndimage import zoom
+
+    nx = right.shape[1]
+    z = zoom(right, (1, (nx * subpix - (subpix - 1)) / float(nx)), order=order)
+    return [np.ascontiguousarray(z[:, k::subpix], np.float32) for k in range(1, subpix)]
+
+
+def ensure_pair(img_left, img_right, subpix, device=None, band=None, spline_order=1):
     """Make (img_left, img_right) the resident pair of the engine (uploads images and masks once); ``band`` names the
-    band of multiband images that is matched (matching_cost's "band" parameter, kept in cv.attrs["band_correl"])."""
+    band of multiband images that is matched (matching_cost's "band" parameter, kept in cv.attrs["band_correl"]).  The device
+    builds the sub-pixel shifted right images by linear interpolation (= zoom order 1, exactly); a higher ``spline_order`` is
+    resampled with scipy on the host and uploaded."""
     eng = get_engine(device)
-    key = _key(img_left, img_right, subpix, band)
+    key = _key(img_left, img_right, subpix, band, spline_order)
     if _RESIDENT.get(eng.device, (None,))[0] != key:
-        eng.set_images(np.asarray(select_band(img_left, band), np.float32), np.asarray(select_band(img_right, band), np.float32), subpix)
+        right = np.asarray(select_band(img_right, band), np.float32)
+        eng.set_images(np.asarray(select_band(img_left, band), np.float32), right, subpix)
+        if subpix > 1 and int(spline_order) != 1:
+            for k, shifted in enumerate(shifted_right_images(right, subpix, int(spline_order)), start=1):
+                eng.set_shifted_right(k, shifted)
         ml = img_left["msk"].data if "msk" in img_left.data_vars else None
         mr = img_right["msk"].data if "msk" in img_right.data_vars else None
         # the reference keeps one mask convention per image; they are the same in practice

@@ -393,3 +393,52 @@ def test_machine_with_interval_filter_after_cross_checking(oracle):
         # NaN bounds (the census frame) stay NaN, the others are NaN-ignoring 3x3 medians of the pinned bounds
         np.testing.assert_array_equal(conf[:, :, k], oracle.filter_median_disparity(m, np.zeros((H, W), np.int64), 3))
     assert list(left.coords["indicator"])[:2] == ["confidence_from_interval_bounds_inf", "confidence_from_interval_bounds_sup"]
+
+
+@pytest.mark.parametrize("method,order,subpix,with_cbca", [("sad", 3, 2, False), ("census", 2, 4, False), ("zncc", 5, 2, False), ("sad", 3, 2, True)])
+def test_spline_order_resamples_the_right_image_like_the_reference(oracle, method, order, subpix, with_cbca):
+    """matching_cost's "spline_order" (img_tools.py:713-752): the sub-pixel right images are scipy.ndimage.zoom(order=...) of the right
+    image - the reference's own expression, evaluated on the host and handed to the device (pmx_set_shifted_right); the costs are the
+    oracle's on those images.  CBCA's cross supports keep order 1 whatever the matching cost's (cbca.py:248-250 calls shift_right_img
+    with its default), so an aggregation step re-uploads the pair with linear shifts."""
+    from scipy.ndimage import zoom
+
+    H, W, dmin, dmax, win = 40, 66, -5, 3, 3 if method != "census" else 5
+    L, R = pair(H, W, seed=order, integer=False)
+    D = (dmax - dmin) * subpix + 1
+    z = zoom(R, (1, (W * subpix - (subpix - 1)) / float(W)), order=order)
+    shifted = [np.ascontiguousarray(z[:, k::subpix], np.float32) for k in range(1, subpix)]
+    if method == "census":
+        exp = oracle.census_cost(L, R, D, dmin, subpix, win, shifted=shifted)
+    elif method == "sad":
+        exp = oracle.sad_ssd(L, R, D, dmin, subpix, win, False, shifted=shifted)
+    else:
+        exp = oracle.zncc(L, R, D, dmin, subpix, win, shifted=shifted)
+    pipe = {"matching_cost": {"matching_cost_method": method, "window_size": win, "subpix": subpix, "spline_order": order},
+            "disparity": {"disparity_method": "wta", "invalid_disparity": -9999}}
+    if with_cbca:
+        pipe = {"matching_cost": pipe["matching_cost"], "aggregation": {"aggregation_method": "cbca"}, "disparity": pipe["disparity"]}
+        off = win // 2
+
+        def arms(im):
+            m = np.nan_to_num(oracle.median3(im.copy()), nan=np.inf)[off:-off, off:-off]
+            return oracle.cross_support(np.ascontiguousarray(m), 5, 30.0)
+
+        oracle.cbca(exp, dmin, subpix, off, arms(L), [arms(im) for im in oracle.shift_right(R, subpix)])  # linear shifts here
+    # through the plugin API directly: PandoraMachine drops "spline_order" when it checks the configuration, exactly like the
+    # reference (matching_cost.py:153-156: "a pandora2d setting"), so a machine run always resamples with order 1
+    from pandora_amd import aggregation
+
+    left, right = make_image(L, disparity=[dmin, dmax]), make_image(R)
+    mc = matching_cost.AbstractMatchingCost(**pipe["matching_cost"])
+    cv = mc.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min"), left["disparity"].sel(band_disp="max")))
+    cv = mc.compute_cost_volume(left, right, cv)
+    if with_cbca:
+        aggregation.AbstractAggregation(**pipe["aggregation"]).cost_volume_aggregation(left, right, cv)
+    got = cv["cost_volume"].data
+    if method == "zncc":
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5)
+    else:
+        np.testing.assert_array_equal(got, exp)
+    machine, _ = run_machine(L, R, {"pipeline": pipe}, dmin, dmax)  # order 1 through the machine: a different volume
+    assert not np.array_equal(np.nan_to_num(got), np.nan_to_num(machine.left_cv["cost_volume"].data))
