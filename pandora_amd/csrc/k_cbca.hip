@@ -140,6 +140,20 @@ struct cbca_args {
     const int16_t* armsRpad;
     uint32_t* nanbits;
     int G;       // groups of 4 disparities per pixel
+    // whole-row pass H (cbca_h_rows_kernel): arms as 4 bytes per pixel (left | right << 8 | top << 16 | bottom << 24), row-major
+    // [Hc][pitchL] / per phase [Hc][pitchR] with pixel q of the right image at index padR + q and zero pads, so that the arms of
+    // FOUR consecutive steps are one 16-byte load and no index needs clamping
+    const uint32_t* armsL8;
+    const uint32_t* armsR8;      // phase ph at armsR8 + ph * phase_words
+    int pitchL, pitchR, padR;
+    unsigned bytesL8, bytesR8, phase_words;
+    int R;                       // image rows per workgroup
+    // census costs computed in place of a volume read (cbca_h_rows_kernel<., 1>): the handle's codes (one word per pixel), the
+    // per-pixel valid interval of cv_masked (or nullptr: census geometry), the census border
+    const uint32_t* codes;       // the whole allocation (buffer descriptor)
+    unsigned codes_bytes, offCL, offCR;  // word offsets of the left / right code images in it
+    const uint32_t* range;
+    int cb;                      // census window / 2
 };
 
 // combined arm lengths of the support cross at (r, c, k) packed as left | right<<8 | top<<16 | bot<<24;
@@ -394,6 +408,8 @@ __global__ __launch_bounds__(kBlock) void cbca_h_fast_kernel(cbca_args a) {
         emit(cb_load(aL, (size_t)(c - A)), cb_load(aR, right_px(c - A)), c - A);
 }
 
+// SIGN: pass H marked the cells whose input cost was NaN in the sign bit of E_h (costs >= +0 only); the input volume is not read
+template <bool SIGN>
 __global__ __launch_bounds__(kBlock) void cbca_v_fast_kernel(cbca_args a) {
     extern __shared__ float ring[];  // [2][ring][kBlock]: column prefix sums; packed (N, top, bot)
     const int t = blockIdx.x * kBlock + threadIdx.x;
@@ -419,7 +435,12 @@ __global__ __launch_bounds__(kBlock) void cbca_v_fast_kernel(cbca_args a) {
     const size_t strideL = (size_t)Wc, strideR = (size_t)Wr;  // pixels per arms row
     float acc = 0.f;
     uint32_t nacc = 0;
+    uint32_t nh = 0;  // SIGN: bit i = the input cost of row (current - i) was NaN
     auto prefix = [&](float e, cb_arms l, cb_arms rr, int r) {
+        if (SIGN) {
+            nh = (nh << 1) | (__float_as_uint(e) >> 31);
+            e = fabsf(e);
+        }
         acc = (r == 0) ? e : acc + e;
         s3[(r & mask) * kBlock] = acc;
         const uint32_t lr = cb_pk_min(l.lr, rr.lr), tb = cb_pk_min(l.tb, rr.tb);
@@ -438,7 +459,10 @@ __global__ __launch_bounds__(kBlock) void cbca_v_fast_kernel(cbca_args a) {
         const uint32_t n = (info[(hi_i & mask) * kBlock] & 0xfffffu) - (info[(lo_i & mask) * kBlock] & 0xfffffu) + (uint32_t)(top + bot);
         const float step4 = cell ? step : 0.f;
         const float sum4 = (cell ? (float)n : 0.f) + 1.f;  // small exact integers: any order
-        if (live) *pout = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
+        float res;
+        if (SIGN) res = ((nh >> A) & 1u) ? c_nan() : step4 / sum4;
+        else res = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
+        if (live) *pout = res;
         pout += row_stride;
     };
     // every stream advances by one row per step through its own pointer; the loads of the next four rows use the
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void cbca_v_fast_kernel(cbca_args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             qd.e[j] = pe[(size_t)(ahead + j) * row_stride];
-            qd.in[j] = pin[(size_t)(ahead + j) * row_stride];
+            qd.in[j] = SIGN ? 0.f : pin[(size_t)(ahead + j) * row_stride];
             qd.l[j] = cb_load(pl, (size_t)(ahead + j) * strideL);
             qd.rr[j] = cb_load(pr, (size_t)(ahead + j) * strideR);
         }
@@ -493,13 +517,204 @@ __global__ __launch_bounds__(kBlock) void cbca_v_fast_kernel(cbca_args a) {
         pe += row_stride;
         pl += strideL4;
         pr += strideR4;
-        emit(*pin, r - A);
+        emit(SIGN ? 0.f : *pin, r - A);
         pin += row_stride;
     }
     for (; r < Hc + A; ++r) {
-        emit(*pin, r - A);
+        if (SIGN) nh <<= 1;
+        emit(SIGN ? 0.f : *pin, r - A);
         pin += row_stride;
     }
+}
+
+// ---- pass H on whole rows ------------------------------------------------------------------------------------------------
+// What bounds the phase-split pass H is its memory pattern, not its arithmetic (tools/ubench/cbca_pattern.hip, and the kernel
+// with its stores removed runs in 0.66 instead of 1.5 ms at 2048^2 x 129): with D = 129 a wavefront's 64 cells are 256 bytes
+// that straddle three cache lines, written 516 bytes further every step, each line finished by another wavefront much later.
+// Here a workgroup owns R WHOLE image rows (thread = (row, disparity), R*D threads rounded up to whole wavefronts), so the
+// segment sums of four consecutive columns are 4*D*4 contiguous bytes per row: they are collected in LDS and leave as 16 bytes
+// per lane.  Same scan, same order, same results.
+// SRC = 1: the matching costs are the Hamming distances of the handle's census codes (one word per pixel: windows up to 5x5),
+// computed here instead of being read from a float32 volume that then never exists: census + cbca without the 4 B/cell write
+// and the 4 B/cell read of the cost volume.  A cell's cost is a number iff the cost kernel would have written one: inside the
+// pixel's valid interval when cv_masked left one (k_fused.hip: build_range_kernel), else where both census windows fit.
+// SIGN as in the phase-split pass V above.
+#include "pmx_buf.h"
+
+static constexpr int kRowsT = 576;  // most threads per workgroup (R rows x D disparities, whole wavefronts)
+static constexpr int kChunk = 8;    // columns per flush of the output stage
+static constexpr int kStage = 2 * kChunk;
+
+__device__ __forceinline__ uint32_t cb_lr16(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c010c00u); }  // (left, right) as 16-bit halves
+
+__global__ __launch_bounds__(256) void pack_arms_kernel(const int16_t* __restrict__ arms, int Hc, int Wsrc, uint32_t* __restrict__ rows,
+                                                        int pitch, int xoff) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= Wsrc) return;
+    const short4 s = *reinterpret_cast<const short4*>(arms + ((size_t)r * Wsrc + c) * 4);
+    rows[(size_t)r * pitch + xoff + c] = (uint32_t)s.x | ((uint32_t)s.y << 8) | ((uint32_t)s.z << 16) | ((uint32_t)s.w << 24);
+}
+
+// census source: the volume first exists as pass V's output, which covers the image without its border of `o` pixels; the
+// border cells are the NaN the census cost kernel would have left there
+__global__ __launch_bounds__(256) void cbca_border_nan_kernel(float* __restrict__ cv, int H, int W, int D, int o) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    if (r >= o && r < H - o && c >= o && c < W - o) return;
+    float* p = cv + ((size_t)r * W + c) * D;
+    for (int k = 0; k < D; ++k) p[k] = c_nan();
+}
+
+template <bool SIGN, int SRC>
+__global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
+    extern __shared__ float lds[];
+    const int T = blockDim.x, R = a.R, D = a.D, A = a.A, Wc = a.Wc;
+    const int mask = a.ring - 1;
+    float* stage = lds + (size_t)a.ring * T;  // [R][2 * kChunk columns][D]
+    const int tid = threadIdx.x;
+    const int lrow = min(tid / D, R - 1), k = tid - (tid / D) * D;
+    const int r0 = blockIdx.x * R;
+    const bool owner = tid < R * D && r0 + lrow < a.Hc;
+    const int r = min(r0 + lrow, a.Hc - 1);
+    const int kk = k / a.subpix, ph = k - kk * a.subpix, dq = a.d0 + kk;
+    const int Wr = ph == 0 ? Wc : Wc - 1;
+    float* my = lds + tid;
+    for (int s = 0; s < a.ring; ++s) my[s * T] = 0.f;  // S1 of columns < 0 is 0 (aggregation.cpp:113-114)
+    float* st = stage + (size_t)lrow * kStage * D + k;  // + (ce & (kStage - 1)) * D
+    const size_t row_off = ((size_t)(r + a.o) * a.W + a.o) * D + k;
+    const float* pv = a.cv + row_off;  // SRC 0: cost of column c
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsL8, 0, a.bytesL8, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsR8, 0, a.bytesR8, kRsrcWord3);
+    const unsigned offL = (unsigned)r * (unsigned)a.pitchL * 4u;  // + 4 * ce
+    const unsigned offR = ((unsigned)ph * a.phase_words + (unsigned)r * (unsigned)a.pitchR + (unsigned)(a.padR + dq)) * 4u;  // pads: every index is valid
+    // SRC 1: codes and valid intervals of the row, full-image coordinates
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)a.codes, 0, a.codes_bytes, kRsrcWord3);
+    const unsigned pix0 = (unsigned)(r + a.o) * (unsigned)a.W + (unsigned)a.o;          // pixel of column c = 0
+    const unsigned offCL = (a.offCL + pix0) * 4u, offCR = (a.offCR + pix0 + (unsigned)dq) * 4u;  // + 4 * c (guard words around the images)
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.range, 0, (unsigned)a.H * (unsigned)a.W * 4u, kRsrcWord3);
+    constexpr bool has_range = SRC == 2;  // SRC 2: census codes + the valid intervals cv_masked left
+    const bool row_ok = (r + a.o >= a.cb) & (r + a.o < a.H - a.cb);
+    const unsigned wvalid = (unsigned)(a.W - 2 * a.cb);
+    auto census = [&](uint32_t cl, uint32_t cr, uint32_t rg, int c) {
+        bool ok;
+        if (has_range) ok = (k >= (int)(rg & 0xffffu)) & (k < (int)(rg >> 16));
+        else ok = row_ok & ((unsigned)(c + a.o - a.cb) < wvalid) & ((unsigned)(c + a.o + dq - a.cb) < wvalid);
+        return ok ? (float)__popc(cl ^ cr) : c_nan();
+    };
+    float acc = 0.f;
+    uint32_t hist = 0;  // SIGN: bit i = the cost of column (newest - i) was NaN
+    auto prefix = [&](float v, int c) {
+        acc = (v == v) ? acc + v : acc;  // NaN is skipped, the running sum carries on
+        my[__umul24(c & mask, T)] = acc;
+        if (SIGN) hist = (hist << 1) | (v == v ? 0u : 1u);
+    };
+    // segment sum of column ce into the stage; `age` = how many columns newer than ce + A the newest prefix is (SIGN)
+    auto emit = [&](uint32_t l8, uint32_t r8, int ce, int age) {
+        const int q = ce + dq;
+        const bool inside = (q >= 0) & (q <= Wr - 1);
+        const uint32_t lr = cb_pk_min(cb_lr16(l8), cb_lr16(r8));
+        const int left = (int)(lr & 0xffffu), right = (int)(lr >> 16);
+        const float hi_v = my[__umul24((ce + right) & mask, T)];   // (v_mul_u32_u24: full rate, v_mul_lo_u32 is a quarter)
+        const float lo_v = my[__umul24((ce - left - 1) & mask, T)];
+        float e = inside ? hi_v - lo_v : 0.f;
+        if (SIGN) e = __uint_as_float(__float_as_uint(e) | (((hist >> (A + age)) & 1u) << 31));
+        if (owner) st[(ce & (kStage - 1)) * D] = e;
+    };
+    // kChunk finished columns m0 .. of the block's rows leave LDS as 16 bytes per lane; the barrier in front also separates
+    // this chunk's emits from the writes that reuse its half of the stage two chunks later
+    const unsigned rows_left = (unsigned)min(R, a.Hc - r0);
+    const unsigned row_floats = (unsigned)Wc * (unsigned)D;
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.eh + ((size_t)(r0 + a.o) * a.W + a.o) * D), 0, 0x7ffffff0u, kRsrcWord3);
+    const bool aligned = (A & 3) == 0;  // then a chunk is flushed right after the quad that emits its last column
+    auto flush = [&](int m0) {
+        __syncthreads();
+        const unsigned nv = (unsigned)(kChunk / 4) * (unsigned)D;  // 16-byte vectors per row chunk (kChunk columns x D floats)
+        for (unsigned i = tid; i < rows_left * nv; i += T) {
+            const unsigned rr = i / nv, v = i - rr * nv;
+            const u32x4 x = *reinterpret_cast<const u32x4*>(stage + ((size_t)rr * kStage + (m0 & (kStage - 1))) * D + 4 * v);
+            const unsigned f = (unsigned)m0 * (unsigned)D + 4u * v;  // first float of the vector in its (cropped) row
+            const unsigned off = (rr * (unsigned)a.W * (unsigned)D + f) * 4u;
+            if (f + 4 <= row_floats) {
+                __builtin_amdgcn_raw_buffer_store_b128(x, rsE, off, 0, 0);
+            } else {  // the row ends inside this vector (its last chunk, Wc not a multiple of 4)
+                __builtin_amdgcn_raw_buffer_store_b32(x.x, rsE, f < row_floats ? off : kOob, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(x.y, rsE, f + 1 < row_floats ? off + 4 : kOob, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(x.z, rsE, f + 2 < row_floats ? off + 8 : kOob, 0, 0);
+            }
+        }
+        if (!aligned) __syncthreads();  // up to 3 newer columns are pending: the next emits reach into this chunk's half
+    };
+    auto arms1 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, int ce) {
+        return __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4u * (unsigned)ce, 0, 0);
+    };
+    auto cost1 = [&](int c) {  // the cost of one column (warm-up, leftovers)
+        if (SRC == 0) return pv[(size_t)c * D];
+        const uint32_t cl = __builtin_amdgcn_raw_buffer_load_b32(rsC, offCL + 4u * (unsigned)c, 0, 0);
+        const uint32_t cr = __builtin_amdgcn_raw_buffer_load_b32(rsC, offCR + 4u * (unsigned)c, 0, 0);
+        const uint32_t rg = has_range ? __builtin_amdgcn_raw_buffer_load_b32(rsG, (pix0 + (unsigned)c) * 4u, 0, 0) : 0u;
+        return census(cl, cr, rg, c);
+    };
+    int c = 0, flushed = 0;
+    for (; c < A; ++c) prefix(cost1(c), c);  // warm-up: columns whose segment cannot be closed yet
+    // steady state: quads of columns (four prefixes, then four emits: one LDS round trip per quad), two quads in registers, the
+    // loop unrolled over the pair so that no register copies (which would wait for the loads) separate the trips
+    struct quad { float v[4]; u32x4 cl, cr, rg, l, rr; };
+    auto load_quad = [&](quad& g, int c0) {  // columns c0 .. c0+3 (all < Wc) and the arms of c0-A ..
+        if (SRC == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g.v[j] = pv[(size_t)(c0 + j) * D];
+        } else {
+            g.cl = __builtin_amdgcn_raw_buffer_load_b128(rsC, offCL + 4u * (unsigned)c0, 0, 0);
+            g.cr = __builtin_amdgcn_raw_buffer_load_b128(rsC, offCR + 4u * (unsigned)c0, 0, 0);
+            if (has_range) g.rg = __builtin_amdgcn_raw_buffer_load_b128(rsG, (pix0 + (unsigned)c0) * 4u, 0, 0);
+            else g.rg = u32x4{0u, 0u, 0u, 0u};
+        }
+        g.l = __builtin_amdgcn_raw_buffer_load_b128(rsL, offL + 4u * (unsigned)(c0 - A), 0, 0);
+        g.rr = __builtin_amdgcn_raw_buffer_load_b128(rsR, offR + 4u * (unsigned)(c0 - A), 0, 0);
+    };
+    auto run_quad = [&](const quad& g) {
+        if (SRC == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prefix(g.v[j], c + j);
+        } else {
+            prefix(census(g.cl.x, g.cr.x, g.rg.x, c), c);
+            prefix(census(g.cl.y, g.cr.y, g.rg.y, c + 1), c + 1);
+            prefix(census(g.cl.z, g.cr.z, g.rg.z, c + 2), c + 2);
+            prefix(census(g.cl.w, g.cr.w, g.rg.w, c + 3), c + 3);
+        }
+        emit(g.l.x, g.rr.x, c - A, 3);
+        emit(g.l.y, g.rr.y, c + 1 - A, 2);
+        emit(g.l.z, g.rr.z, c + 2 - A, 1);
+        emit(g.l.w, g.rr.w, c + 3 - A, 0);
+        c += 4;
+        while (flushed + kChunk <= c - A) {  // (uniform)
+            flush(flushed);
+            flushed += kChunk;
+        }
+    };
+    if (c + 4 <= Wc) {
+        quad ga, gb;
+        load_quad(ga, c);
+        for (;;) {  // invariant: the quad about to run holds columns c .. c+3, all inside the image
+            if (c + 8 > Wc) { run_quad(ga); break; }
+            load_quad(gb, c + 4);
+            run_quad(ga);
+            if (c + 8 > Wc) { run_quad(gb); break; }
+            load_quad(ga, c + 4);
+            run_quad(gb);
+        }
+    }
+    for (; c < Wc + A; ++c) {  // leftover columns, then the drain (emit only)
+        if (c < Wc) prefix(cost1(c), c);
+        else if (SIGN) hist <<= 1;
+        emit(arms1(rsL, offL, c - A), arms1(rsR, offR, c - A), c - A, 0);
+        if (flushed + kChunk <= c + 1 - A) {
+            flush(flushed);
+            flushed += kChunk;
+        }
+    }
+    if (flushed < Wc) flush(flushed);  // the row's last, partial chunk (the stores past the row's end are dropped)
 }
 
 // ---- four disparities per thread (subpix 1, cbca_distance <= 5) -----------------------------------------------------------
@@ -782,7 +997,18 @@ __global__ __launch_bounds__(kBlock4) void cbca_v4_kernel(cbca_args a) {
     for (; r < Hc + A; ++r) emit(pn[(size_t)(r - A) * strideN], r - A);  // drain
 }
 
-int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance) {
+// can pass H compute the census costs itself (no float volume)?  One code word per pixel, whole-row kernel applicable.
+bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, int distance) {
+    const char* ef = getenv("PMX_CBCA_FAST");
+    const char* eu = getenv("PMX_CBCA_FUSE");
+    if ((ef && atoi(ef) != 1) || (eu && eu[0] == '0')) return false;
+    const int A = distance - 1 > 1 ? distance - 1 : 1;
+    const int Hc = cv->H - 2 * offset, Wc = cv->W - 2 * offset;
+    return cv->repr == PMX_REPR_CENSUS_DEFERRED && cv->subpix == 1 && cv->win * cv->win <= 32 && A <= 28 &&
+           Wc >= 2 * A + 8 && Hc >= 2 * A + 8 && cv->D <= kRowsT && cv->codes_bytes < 0x7fffffffu;
+}
+
+int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance, bool census_src) {
     const int H = cv->H, W = cv->W, o = offset;
     const int Hc = H - 2 * o, Wc = W - 2 * o;
     if (Hc <= 0 || Wc <= 1) return PMX_OK;
@@ -809,12 +1035,24 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         }
     }
     const int G = (cv->D + 3) / 4;
+    // whole-row pass H (the default for long scans): byte arms, row-major with pads
+    const int dq_max = cv->d0 + (cv->D - 1) / cv->subpix;
+    const int padR = (cv->d0 < 0 ? -cv->d0 : 0) + 4;
+    const int pitchL = Wc + 4, pitchR = padR + Wc + (dq_max > 0 ? dq_max : 0) + 8;
+    const size_t bL8 = (size_t)Hc * pitchL * 4, bR8 = (size_t)Hc * pitchR * 4;
+    const bool rows_ok = !four && want == 1 && long_scans && a.A <= 28 && cv->D <= kRowsT && (size_t)cv->subpix * bR8 < 0x7fffffffu &&
+                         bL8 < 0x7fffffffu && (size_t)8 * W * cv->D * 4 < 0x7fffffffu;
+    if (census_src && !rows_ok) {
+        pmx_set_error("pmx_cbca: internal: census source without the whole-row kernel");
+        return PMX_ERR_STATE;
+    }
+    const size_t wide_bytes = rows_ok ? bL8 + (size_t)cv->subpix * bR8 : 0;
     // small scratch: 2 float images + arms of left and of every shifted right image (+ padded right arms and NaN bits)
     const size_t img_bytes = (size_t)H * W * sizeof(float);
     const size_t arm_bytes = (size_t)Hc * Wc * 4 * sizeof(int16_t);
     const size_t pad_bytes = four ? (size_t)Hc * (Wc + 8) * 4 * sizeof(int16_t) : 0;
     const size_t nan_bytes = four ? (size_t)Hc * ((Wc + 7) / 8) * G * sizeof(uint32_t) : 0;
-    int rc = pmx_need_small(ctx, 2 * img_bytes + arm_bytes * (1 + cv->subpix) + pad_bytes + nan_bytes);
+    int rc = pmx_need_small(ctx, 2 * img_bytes + arm_bytes * (1 + cv->subpix) + pad_bytes + nan_bytes + wide_bytes + 64);
     if (rc) return rc;
     if (!four) {
         rc = pmx_need_scratch(ctx, cv->cells() * sizeof(float) + 256);
@@ -830,10 +1068,40 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     a.armsRpad = padded;
     a.nanbits = (uint32_t*)((char*)padded + pad_bytes);
     a.G = G;
+    char* wbase = (char*)(((uintptr_t)((char*)a.nanbits + nan_bytes) + 15) & ~(uintptr_t)15);
+    a.armsL8 = (uint32_t*)wbase;
+    a.armsR8 = (uint32_t*)(wbase + bL8);
+    a.pitchL = pitchL; a.pitchR = pitchR; a.padR = padR;
+    a.bytesL8 = (unsigned)bL8; a.bytesR8 = (unsigned)((size_t)cv->subpix * bR8); a.phase_words = (unsigned)(bR8 / 4);
+    {   // rows per workgroup: R*D threads rounded up to whole wavefronts - the fewer idle lanes the better (D = 129: 2 rows are
+        // 5 wavefronts, the fifth with 2 lanes; 4 rows are 9 with 4), within 576 threads and the LDS of two workgroups per CU
+        const char* er = getenv("PMX_CBCA_ROWS");
+        int best = 1;
+        double best_waste = 1e9;
+        for (int R = 1; R <= 8; ++R) {
+            const int T = ((R * cv->D + 63) / 64) * 64;
+            if (T > kRowsT) break;
+            const double waste = (double)T / (R * cv->D);
+            if (waste < best_waste - 0.02) { best_waste = waste; best = R; }
+        }
+        a.R = er ? atoi(er) : best;
+        if (a.R < 1 || ((a.R * cv->D + 63) / 64) * 64 > kRowsT) a.R = 1;
+    }
+    a.codes = cv->codes; a.codes_bytes = (unsigned)cv->codes_bytes;
+    a.offCL = cv->codeL ? (unsigned)(cv->codeL - cv->codes) : 0u; a.offCR = cv->codeR ? (unsigned)(cv->codeR - cv->codes) : 0u;
+    a.range = (census_src && cv->has_range) ? cv->range : nullptr;
+    a.cb = cv->win / 2;
+    auto pack = [&](const int16_t* src, int Wsrc, const uint32_t* rows, int pitch, int xoff) {
+        hipLaunchKernelGGL(pack_arms_kernel, dim3((Wsrc + 255) / 256, Hc), dim3(256), 0, ctx->stream, src, Hc, Wsrc, (uint32_t*)rows, pitch, xoff);
+    };
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_ARMS);
         rc = build_arms(ctx, 0, o, intensity, distance, tmp, (int16_t*)a.armsL);
         if (rc) return rc;
+        if (rows_ok) {
+            PMX_HIP(hipMemsetAsync(wbase, 0, wide_bytes, ctx->stream));  // the pads are zero arms
+            pack(a.armsL, Wc, a.armsL8, pitchL, 0);
+        }
         if (four) {
             PMX_HIP(hipMemsetAsync(padded, 0, pad_bytes, ctx->stream));
             rc = build_arms(ctx, 1, o, intensity, distance, tmp, padded, 4);
@@ -844,6 +1112,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
                 a.armsR[k] = dst;
                 rc = build_arms(ctx, k + 1, o, intensity, distance, tmp, dst);
                 if (rc) return rc;
+                if (rows_ok) pack(dst, k == 0 ? Wc : Wc - 1, a.armsR8 + (size_t)k * a.phase_words, pitchR, padR);
             }
         }
     }
@@ -866,7 +1135,23 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         return PMX_OK;
     }
     const bool fast_ok = want != 0;
-    {
+    // costs >= +0: the NaN flags of the input travel in the sign bit of E_h (PMX_CBCA_SIGN=0: test hook; the census source has
+    // no input volume to ask)
+    const char* es = getenv("PMX_CBCA_SIGN");
+    const bool sign = rows_ok && (census_src || (cv->nonneg && !(es && es[0] == '0')));
+    if (rows_ok) {
+        pmx_stage_scope t(ctx, PMX_STAGE_CBCA_H);
+        const int T = ((a.R * cv->D + 63) / 64) * 64;
+        const dim3 grid((Hc + a.R - 1) / a.R);
+        const size_t lds = ((size_t)ring * T + (size_t)a.R * kStage * cv->D) * sizeof(float);
+        if (census_src) {
+            if (o > 0) hipLaunchKernelGGL(cbca_border_nan_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, cv->data, H, W, cv->D, o);
+            if (a.range) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 2>), grid, dim3(T), lds, ctx->stream, a);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 1>), grid, dim3(T), lds, ctx->stream, a);
+        }
+        else if (sign) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 0>), grid, dim3(T), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<false, 0>), grid, dim3(T), lds, ctx->stream, a);
+    } else {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_H);
         int total = Hc * cv->D;
         if (fast_ok && Wc >= 2 * a.A + 8)
@@ -879,8 +1164,11 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
         int total = Wc * cv->D;
-        if (fast_ok && Hc >= 2 * a.A + 8)
-            hipLaunchKernelGGL(cbca_v_fast_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+        if (sign)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_fast_kernel<true>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+                               (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
+        else if (fast_ok && Hc >= 2 * a.A + 8)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_fast_kernel<false>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
                                (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
         else
             hipLaunchKernelGGL(cbca_v_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock),

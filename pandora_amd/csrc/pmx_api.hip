@@ -511,6 +511,7 @@ extern "C" int pmx_set_lazy(pmx_ctx* ctx, int enabled) {
 extern "C" int pmx_cv_fill_nan(pmx_ctx* ctx, pmx_cv* cv) {
     PMX_CHECK(ctx && cv, PMX_ERR_ARG, "pmx_cv_fill_nan: null argument");
     cv->repr = PMX_REPR_ALL_NAN;
+    cv->nonneg = true;
     return ctx->lazy ? PMX_OK : pmx_cv_materialize(ctx, cv);
 }
 
@@ -521,6 +522,7 @@ extern "C" int pmx_cv_upload(pmx_ctx* ctx, pmx_cv* cv, const float* host) {
     PMX_HIP(hipMemcpyAsync(cv->data, host, cv->cells() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     cv->repr = PMX_REPR_FLOAT;
+    cv->nonneg = false;  // whatever the caller computed
     return PMX_OK;
 }
 
@@ -582,6 +584,7 @@ extern "C" int pmx_census(pmx_ctx* ctx, pmx_cv* cv, int win) {
     // (a right mask makes cv_masked a per-cell pattern: float volume; grids and a left mask are intervals per pixel and stay lazy)
     const bool defer = ctx->lazy && cv->subpix == 1 && nw <= 6 && cv->D < 320 && abs(cv->d0) + cv->D <= 1024 / nw - 32 && !ctx->msk_right;
     cv->has_range = false;
+    cv->nonneg = true;
     if (!defer) {
         rc = pmx_cv_ensure_data(ctx, cv);
         if (rc) return rc;
@@ -596,6 +599,7 @@ extern "C" int pmx_sad_ssd(pmx_ctx* ctx, pmx_cv* cv, int win, int squared) {
     rc = pmx_cv_ensure_data(ctx, cv);
     if (rc) return rc;
     rc = pmx_launch_sad_ssd(ctx, cv, win, squared);
+    cv->nonneg = true;
     if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
     return rc;
 }
@@ -607,6 +611,7 @@ extern "C" int pmx_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
     rc = pmx_cv_ensure_data(ctx, cv);
     if (rc) return rc;
     rc = pmx_launch_zncc(ctx, cv, win);
+    cv->nonneg = false;
     if (rc == PMX_OK) cv->repr = PMX_REPR_FLOAT;
     return rc;
 }
@@ -634,6 +639,7 @@ extern "C" int pmx_cv_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* weight
     rc = pmx_cv_materialize(ctx, cv);
     if (rc) return rc;
     PMX_HIP(hipMemcpyAsync(ctx->small, weights, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    cv->nonneg = false;  // the weights are the caller's
     rc = pmx_launch_scale_pixels(ctx, cv, (const float*)ctx->small);
     if (rc) return rc;
     PMX_HIP(hipStreamSynchronize(ctx->stream));  // the host weights may be released by the caller
@@ -684,9 +690,14 @@ extern "C" int pmx_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, i
     PMX_CHECK(offset >= 0 && distance >= 1 && intensity > 0.f, PMX_ERR_ARG,
               "pmx_cbca: need offset >= 0, cbca_distance >= 1, cbca_intensity > 0 (cbca.py:59-82)");
     PMX_CHECK(distance <= 32, PMX_ERR_UNSUPPORTED, "pmx_cbca: cbca_distance > 32 not supported");
-    rc = pmx_cv_materialize(ctx, cv);
+    // census costs still implicit (codes only): pass H computes them on the fly and the float volume first exists as the
+    // aggregated one
+    const bool census_src = pmx_cbca_can_fuse_census(ctx, cv, offset, distance);
+    rc = census_src ? pmx_cv_ensure_data(ctx, cv) : pmx_cv_materialize(ctx, cv);
     if (rc) return rc;
-    return pmx_launch_cbca(ctx, cv, offset, intensity, distance);
+    rc = pmx_launch_cbca(ctx, cv, offset, intensity, distance, census_src);
+    if (rc == PMX_OK && census_src) cv->repr = PMX_REPR_FLOAT;
+    return rc;
 }
 
 extern "C" int pmx_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* host_out) {
@@ -715,6 +726,7 @@ extern "C" int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max,
     if (rc) return rc;
     PMX_CHECK(P1 > 0.f && P2 > P1, PMX_ERR_ARG, "pmx_sgm: need 0 < P1 < P2 (plugin_libsgm.rst:170-185), got %g %g", P1, P2);
     PMX_CHECK(cv->D <= 512, PMX_ERR_UNSUPPORTED, "pmx_sgm: D = %d > 512 disparities not supported", cv->D);
+    cv->nonneg = false;  // (true for costs >= 0, but nothing downstream of SGM asks)
     if (ctx->lazy && ctx->sgm_dir_mask == 0xff && pmx_fused_sgm_eligible(ctx, cv, P1, P2, is_max, invalid_cost, overcounting))
         return pmx_launch_sgm_fused(ctx, cv, P1, P2, invalid_cost);  // integer fast path, bit-identical
     rc = pmx_cv_materialize(ctx, cv);

@@ -124,6 +124,7 @@ struct pmx_cv {
     size_t bytes = 0;  // capacity of data
     int H = 0, W = 0, D = 0, d0 = 0, subpix = 1;
     int repr = PMX_REPR_ALL_NAN;
+    bool nonneg = true;  // every cost that is a number is >= +0 (census, SAD, SSD and what CBCA makes of them; all-NaN too)
     // census codes kept with the volume (fast path + deferred cost kernel)
     int win = 0;
     uint32_t* codes = nullptr;  // allocation: [pad | left | pad | right | pad]
@@ -256,7 +257,8 @@ int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
 int pmx_launch_near_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);  // from the winner's three values (ctx->near)
 int pmx_launch_wta_fixup(pmx_ctx* ctx, const pmx_cv* cv);                          // validity of the pixels a fused WTA found all-NaN
 int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta);      // runs the upward family of a pending volume
-int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance);
+int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance, bool census_src);
+bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, int distance);
 int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
 int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
 int pmx_launch_reverse(pmx_ctx* ctx, const pmx_cv* in, int min_disp, pmx_cv* out);

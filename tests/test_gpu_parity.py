@@ -1075,3 +1075,48 @@ def test_cbca_phase_split_and_generic_kernels(eng, oracle, monkeypatch, fast, H,
     crs = [arms(im, mskR, k > 0) for k, im in enumerate(oracle.shift_right(R, sp))]
     oracle.cbca(exp, dmin, sp, off, cl, crs)
     np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("rows", [None, "1", "3"])
+@pytest.mark.parametrize("H,W,dmin,dmax,dist,with_grids,with_left_mask", [
+    (70, 150, -12, 5, 5, False, False), (41, 67, 0, 60, 5, True, False), (45, 91, -30, 3, 3, True, True),
+    (40, 203, -64, 64, 5, False, True), (38, 77, -5, 4, 9, False, False), (33, 52, -3, 3, 2, True, False)])
+def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, H, W, dmin, dmax, dist, with_grids, with_left_mask):
+    """Census + CBCA without a right mask: in lazy mode the census costs are still implicit (codes) when pmx_cbca runs, and pass H
+    computes them on the fly - with the per-pixel valid intervals of cv_masked when grids / a left mask are resident - so the
+    float volume first exists as the aggregated one (its border cells NaN); in eager mode the same whole-row pass H reads the
+    float volume.  Both carry the NaN flags of the input to pass V in the sign bit of E_h.  Widths that are no multiple of the
+    flush chunk, D = 61 / 129 / 16, arms from 1 to 8 columns, 1 to 3 rows per workgroup: bit-exact against the oracle."""
+    if rows:
+        monkeypatch.setenv("PMX_CBCA_ROWS", rows)
+    L, R = pair(H, W, seed=H + W + dist, integer=True)
+    rng = np.random.default_rng(H * dist)
+    win, off = 5, 2
+    mskL = rng.choice([0, 0, 0, 0, 0, 0, 0, 1], (H, W)).astype(np.int16) if with_left_mask else None
+    grids = None
+    if with_grids:
+        gmin = rng.integers(dmin, dmin + 3, (H, W)).astype(np.float64)
+        gmax = rng.integers(dmax - 3, dmax + 1, (H, W)).astype(np.float64)
+        grids = (gmin, gmax)
+    masks = (mskL, None, 0, 1) if with_left_mask else None
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    cv = gpu_cv(eng, "census", L, R, dmin, dmax, 1, win, masks=masks, grids=grids)
+    eng.cbca(cv, off, 30.0, dist)
+    got = cv.to_host()
+    cost_launches = eng.stage_time("census_cost")[1]
+    eng.set_profiling(False)
+    assert cost_launches == (0 if eng.lazy else 1)  # lazy: no census cost kernel ever ran
+    exp = cpu_cv(oracle, "census", L, R, dmin, dmax, 1, win, masks=masks, grids=grids)
+
+    def arms(im, msk):
+        m = im.copy()
+        if msk is not None:
+            m[msk != 0] = np.nan
+        m = np.nan_to_num(oracle.median3(m), nan=np.inf)[off:-off, off:-off]
+        return oracle.cross_support(np.ascontiguousarray(m), dist, 30.0)
+
+    oracle.cbca(exp, dmin, 1, off, arms(L, mskL), [arms(R, None)])
+    np.testing.assert_array_equal(got, exp)
+    eng.set_masks(None, None)
+    eng.set_disparity_grids(None, None)

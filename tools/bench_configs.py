@@ -2,7 +2,7 @@
 """Device time of the five BASELINE.json configurations on ONE MI355X, through the engine (C ABI), inputs resident:
 C1 cones a_local_block_matching.json as written (ZNCC 5x5 subpix 4 + WTA + quadratic) and its SAD variant, C2 cones
 census+CBCA+SGM, C3 2048^2 census+SGM, C4 4096^2 ZNCC 11x11 + SGM (float32 path), C5 10000^2 census+CBCA+SGM (one scale, the
-fine one of the 2-scale run).  Usage: python tools/bench_configs.py [C1 C2 ...]"""
+fine one of the 2-scale run).  Usage: python tools/bench_configs.py [--stages] [C1 C2 ...]"""
 import json
 import os
 import sys
@@ -52,9 +52,22 @@ def run(eng, L, R, dmin, dmax, subpix, cost, cbca, sgm, refine, steps):
         step()
     eng.sync()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    stages = None
+    if STAGES:  # one more step with the library's per-stage HIP events
+        from pandora_amd import _lib
+
+        eng.set_profiling(True)
+        eng.reset_stage_times()
+        step()
+        eng.sync()
+        stages = {k: round(eng.stage_time(k)[0], 3) for k in _lib.STAGES if eng.stage_time(k)[1]}
+        eng.set_profiling(False)
     cv.free()
     cells = L.shape[0] * L.shape[1] * D
-    return {"shape": [L.shape[0], L.shape[1], D], "ms": round(ms, 3), "Gdisp/s": round(cells / ms / 1e6, 2)}
+    out = {"shape": [L.shape[0], L.shape[1], D], "ms": round(ms, 3), "Gdisp/s": round(cells / ms / 1e6, 2)}
+    if stages:
+        out["stages_ms"] = stages
+    return out
 
 
 CONFIGS = {
@@ -66,8 +79,10 @@ CONFIGS = {
     "C5 10000^2 d=[-64,64] census5 + cbca + sgm + wta + vfit (float32, one scale)": lambda e: run(e, *bench.synthetic_pair(10000, 10000, -64, 64), -64, 64, 1, ("census", 5), True, True, "vfit", 1),
 }
 
+STAGES = "--stages" in sys.argv
+
 if __name__ == "__main__":
-    want = sys.argv[1:]
+    want = [a for a in sys.argv[1:] if not a.startswith("--")]
     eng = Engine(0)
     out = {}
     for name, fn in CONFIGS.items():

@@ -41,6 +41,16 @@ if os.environ.get("PMX_BENCH_ONLY") == "cbca":
     timed("cbca (d=5, i=30)", ["cbca_arms", "cbca_h", "cbca_v"], lambda: eng.cbca(cv, 2, 30.0, 5), reps=2)
     print(json.dumps(out, indent=1))
     sys.exit(0)
+if os.environ.get("PMX_BENCH_ONLY") == "census_cbca":  # as the pipeline runs them: the census costs stay implicit until pass H
+    eng.set_lazy(True)
+
+    def both():
+        eng.census(cv, 5)
+        eng.cbca(cv, 2, 30.0, 5)
+
+    timed("census5 + cbca (d=5, i=30), lazy", ["census_transform", "census_cost", "cbca_arms", "cbca_h", "cbca_v"], both, reps=2)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 if os.environ.get("PMX_BENCH_ONLY") == "zncc":
     timed("zncc5", ["zncc"], lambda: eng.zncc(cv, 5), reps=2)
     timed("zncc11", ["zncc"], lambda: eng.zncc(cv, 11), reps=1)

@@ -1,10 +1,18 @@
 #!/bin/bash
-# instruction counters of the CBCA kernels at C3
+# counters of the CBCA scan kernels at C3 (2048^2 x 129): instruction mix, wait / active cycles, texture-addresser busy, HBM bytes.
+# Usage: bash tools/prof_cbca.sh [tag]   (PMX_CBCA_FAST / PMX_CBCA_SIGN select the variant)
+TAG=${1:-cb}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/cb
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
 export PMX_BENCH_ONLY=cbca
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d gpurun_out/cb -o q1 -- python tools/bench_kernels.py > gpurun_out/cb/log1.txt 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/cb -o q2 -- python tools/bench_kernels.py > gpurun_out/cb/log2.txt 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/cb -o q3 -- python tools/bench_kernels.py > gpurun_out/cb/log3.txt 2>&1
-for f in gpurun_out/cb/q1*.db gpurun_out/cb/q2*.db gpurun_out/cb/q3*.db; do python tools/rocpd_pmc.py $f | grep "cbca_[hv]" | rev | cut -d, -f2-4 | rev | paste -d' ' - <(python tools/rocpd_pmc.py $f | grep "cbca_[hv]" | cut -c1-20); done
-rm -f gpurun_out/cb/*.db
+run () { timeout 300 rocprofv3 --pmc "$@" -d $OUT -o q -- python tools/bench_kernels.py > $OUT/log.txt 2>&1; python tools/rocpd_pmc.py $OUT/q*.db | grep "cbca_[hv]" | sed 's/(cbca_args)//; s/void //' | cut -d, -f1,2,4; rm -f $OUT/q*.db; }
+{
+run SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS
+run SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
+run SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_BRANCH SQ_WAIT_INST_LDS
+run GRBM_GUI_ACTIVE TA_TA_BUSY TCP_PENDING_STALL_CYCLES
+run FETCH_SIZE
+run WRITE_SIZE
+} > $OUT/counters.csv 2>&1
+cat $OUT/counters.csv
