@@ -35,6 +35,22 @@ __global__ __launch_bounds__(kBlock) void mask_image_kernel(const float* __restr
     out[(size_t)r * Wd + c] = v;
 }
 
+// nanmedian of the 3x3 neighbourhood, all in registers: NaNs become +inf and sink to the top of a 25-exchange sorting network
+// (a valid +inf sorts among them with the same value, so whichever of them the median index meets reads the same), the median
+// of the n numbers is sorted[n/2] or the mean of the two middle ones.  (An insertion sort over a local array indexes it
+// dynamically, lives in scratch memory and took 3.1 ms per 10000^2 image against 0.3 for this.)
+__device__ __forceinline__ void cb_cswap(float& x, float& y) {
+    const float lo = fminf(x, y), hi = fmaxf(x, y);
+    x = lo;
+    y = hi;
+}
+__device__ __forceinline__ float cb_pick9(const float (&v)[9], int i) {
+    float r = v[0];
+#pragma unroll
+    for (int j = 1; j < 9; ++j) r = (i == j) ? v[j] : r;
+    return r;
+}
+
 __global__ __launch_bounds__(kBlock) void median3_inf_kernel(const float* __restrict__ in, int H, int Wd, float* __restrict__ out) {
     int c = blockIdx.x * kBlock + threadIdx.x;
     int r = blockIdx.y;
@@ -48,16 +64,23 @@ __global__ __launch_bounds__(kBlock) void median3_inf_kernel(const float* __rest
         for (int i = -1; i <= 1; ++i)
 #pragma unroll
             for (int j = -1; j <= 1; ++j) {
-                float x = in[(size_t)(r + i) * Wd + c + j];
-                if (x == x) v[n++] = x;
+                const float x = in[(size_t)(r + i) * Wd + c + j];
+                const bool num = x == x;
+                n += num ? 1 : 0;
+                v[(i + 1) * 3 + j + 1] = num ? x : c_inf();
             }
-        for (int a = 1; a < n; ++a) {
-            float x = v[a];
-            int b = a - 1;
-            while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
-            v[b + 1] = x;
-        }
-        res = (n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.0f;
+        // 9-input sorting network (25 compare-exchanges)
+        cb_cswap(v[0], v[1]); cb_cswap(v[3], v[4]); cb_cswap(v[6], v[7]);
+        cb_cswap(v[1], v[2]); cb_cswap(v[4], v[5]); cb_cswap(v[7], v[8]);
+        cb_cswap(v[0], v[1]); cb_cswap(v[3], v[4]); cb_cswap(v[6], v[7]);
+        cb_cswap(v[0], v[3]); cb_cswap(v[3], v[6]); cb_cswap(v[0], v[3]);
+        cb_cswap(v[1], v[4]); cb_cswap(v[4], v[7]); cb_cswap(v[1], v[4]);
+        cb_cswap(v[2], v[5]); cb_cswap(v[5], v[8]); cb_cswap(v[2], v[5]);
+        cb_cswap(v[1], v[3]); cb_cswap(v[5], v[7]);
+        cb_cswap(v[2], v[6]); cb_cswap(v[4], v[6]); cb_cswap(v[2], v[4]);
+        cb_cswap(v[2], v[3]); cb_cswap(v[5], v[6]);
+        const float hi = cb_pick9(v, n / 2);
+        res = (n & 1) ? hi : (cb_pick9(v, n / 2 - 1) + hi) / 2.0f;
     }
     // np.nan_to_num(nan=inf): NaN -> +inf, +inf -> FLT_MAX, -inf -> -FLT_MAX
     if (res != res) res = c_inf();
@@ -717,6 +740,137 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
     if (flushed < Wc) flush(flushed);  // the row's last, partial chunk (the stores past the row's end are dropped)
 }
 
+// ---- pass V through buffer instructions ---------------------------------------------------------------------------------
+// The phase-split pass V carries five per-lane 64-bit pointers and two buffers of loads: 140 registers, 3 wavefronts per SIMD,
+// which is what hides (or does not hide) the memory latency at sizes that have more wavefronts than that to offer.  Here the
+// volume and the byte arms of the whole-row pass H move through buffer instructions whose descriptor is re-based every row
+// (uniform SALU work) with a lane's cell at a fixed offset inside the row; the ring holds ONE 8-byte entry per row (column
+// prefix sum S3 | packed word); the steps run in quads (four prefixes, then four emits whose ring reads are issued together).
+// Same arithmetic and order as cbca_v_fast_kernel.  SIGN as there.
+__device__ __forceinline__ uint32_t cb_tb16(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c02u); }  // (top, bottom)
+
+template <bool SIGN>
+__global__ __launch_bounds__(kBlock) void cbca_v_buf_kernel(cbca_args a) {
+    extern __shared__ float ring[];  // [ring][kBlock] x (S3, word)
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int total = a.Wc * a.D;
+    const bool live = t < total;
+    const int tt = live ? t : total - 1;
+    const int c = tt / a.D, k = tt - c * a.D;
+    const int kk = k / a.subpix, ph = k - kk * a.subpix, q = c + a.d0 + kk;
+    const int mask = a.ring - 1, A = a.A, Hc = a.Hc, Wc = a.Wc;
+    const int Wr = ph == 0 ? Wc : Wc - 1;
+    const bool inside = (q >= 0) & (q <= Wr - 1);  // the same right column for every row
+    uint2* ent = reinterpret_cast<uint2*>(ring) + threadIdx.x;
+    for (int s = 0; s < a.ring; ++s) ent[s * kBlock] = make_uint2(0u, 0u);  // row -1: zero sums, zero counts
+    const unsigned row_bytes = (unsigned)a.W * (unsigned)a.D * 4u;
+    const unsigned voff = ((unsigned)(c + a.o) * (unsigned)a.D + (unsigned)k) * 4u;
+    const unsigned voff_st = live ? voff : kOob;
+    const size_t row_stride = (size_t)a.W * a.D;
+    // uniform row pointers, advanced as the scan goes
+    const float* e_row = a.eh + (size_t)a.o * row_stride;    // E_h, row r
+    const float* in_row = a.cv + (size_t)a.o * row_stride;   // input cost, row r - A (only its NaN-ness matters; unused when SIGN)
+    float* out_row = a.cv + (size_t)a.o * row_stride;        // output, row r - A
+    const uint32_t* l_row = a.armsL8;                        // arms, row r
+    const uint32_t* r_row = a.armsR8;
+    auto rs_at = [&](const void* row_ptr, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)row_ptr, 0, bytes, kRsrcWord3); };
+    auto ld = [&](const float* row_ptr) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_at(row_ptr, row_bytes), voff, 0, 0)); };
+    const unsigned offL = (unsigned)c * 4u;
+    const unsigned offR = ((unsigned)ph * a.phase_words + (unsigned)(a.padR + q)) * 4u;  // (pads: every q of the lane's cells is readable)
+    const unsigned arms_bytes = 0x7ffffff0u;
+    float acc = 0.f;
+    uint32_t nacc = 0;
+    uint32_t nh = 0;  // SIGN: bit i = the input cost of row (newest - i) was NaN
+    auto prefix = [&](float e, uint32_t l8, uint32_t r8, int r) {
+        if (SIGN) {
+            nh = (nh << 1) | (__float_as_uint(e) >> 31);
+            e = fabsf(e);
+        }
+        acc = (r == 0) ? e : acc + e;
+        const uint32_t lr = cb_pk_min(cb_lr16(l8), cb_lr16(r8)), tb = cb_pk_min(cb_tb16(l8), cb_tb16(r8));
+        // the row's packed word: N(r) in bits 0..19, top in bits 20..25, bot in bits 26..31 (63, 63 = outside the right image)
+        nacc += inside ? (lr & 0xffffu) + (lr >> 16) : 0u;
+        const uint32_t word = nacc | (inside ? (((tb & 0xffffu) << 20) | ((tb >> 16) << 26)) : ((63u << 20) | (63u << 26)));
+        ent[(r & mask) * kBlock] = make_uint2(__float_as_uint(acc), word);
+    };
+    // aggregated cost of row re; `age`: how many rows newer than re + A the newest prefix is (SIGN)
+    auto emit = [&](float in, int re, int age) {
+        const uint32_t w = ent[(re & mask) * kBlock].y;
+        const int top = (w >> 20) & 63, bot = w >> 26;
+        const bool cell = top != 63;
+        const int hi_i = cell ? re + bot : re, lo_i = cell ? re - top - 1 : re;
+        const uint2 hi = ent[(hi_i & mask) * kBlock], lo = ent[(lo_i & mask) * kBlock];
+        const float step = __uint_as_float(hi.x) - __uint_as_float(lo.x);
+        const uint32_t n = (hi.y & 0xfffffu) - (lo.y & 0xfffffu) + (uint32_t)(top + bot);
+        const float step4 = cell ? step : 0.f;
+        const float sum4 = (cell ? (float)n : 0.f) + 1.f;  // small exact integers: any order
+        float res;
+        if (SIGN) res = ((nh >> (A + age)) & 1u) ? c_nan() : step4 / sum4;
+        else res = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rs_at(out_row, row_bytes), voff_st, 0, 0);
+        out_row += row_stride;
+    };
+    struct row_in { float e, in; uint32_t l, rr; };
+    auto load_row = [&](int ahead) {  // row r + ahead of the prefix streams, r + ahead - A of the input
+        row_in x;
+        x.e = ld(e_row + (size_t)ahead * row_stride);
+        x.in = SIGN ? 0.f : ld(in_row + (size_t)ahead * row_stride);
+        x.l = __builtin_amdgcn_raw_buffer_load_b32(rs_at(l_row + (size_t)ahead * a.pitchL, arms_bytes), offL, 0, 0);
+        x.rr = __builtin_amdgcn_raw_buffer_load_b32(rs_at(r_row + (size_t)ahead * a.pitchR, arms_bytes), offR, 0, 0);
+        return x;
+    };
+    auto advance = [&](int n) {
+        e_row += (size_t)n * row_stride;
+        l_row += (size_t)n * a.pitchL;
+        r_row += (size_t)n * a.pitchR;
+    };
+    int r = 0;
+    for (; r < A; ++r) {  // warm-up
+        const row_in x = load_row(0);
+        prefix(x.e, x.l, x.rr, r);
+        advance(1);
+    }
+    // steady state: quads of rows, two quads in registers, the loop unrolled over the pair (no register copies between trips)
+    struct quad { row_in x[4]; };
+    auto load_quad = [&](quad& g, int ahead) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g.x[j] = load_row(ahead + j);
+    };
+    auto run_quad = [&](const quad& g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prefix(g.x[j].e, g.x[j].l, g.x[j].rr, r + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) emit(g.x[j].in, r + j - A, 3 - j);
+        r += 4;
+        advance(4);
+        in_row += (size_t)4 * row_stride;
+    };
+    if (r + 4 <= Hc) {
+        quad ga, gb;
+        load_quad(ga, 0);
+        for (;;) {  // invariant: the quad about to run holds rows r .. r+3, all inside the image
+            if (r + 8 > Hc) { run_quad(ga); break; }
+            load_quad(gb, 4);
+            run_quad(ga);
+            if (r + 8 > Hc) { run_quad(gb); break; }
+            load_quad(ga, 4);
+            run_quad(gb);
+        }
+    }
+    for (; r < Hc; ++r) {  // leftover rows
+        const row_in x = load_row(0);
+        prefix(x.e, x.l, x.rr, r);
+        advance(1);
+        emit(x.in, r - A, 0);
+        in_row += row_stride;
+    }
+    for (; r < Hc + A; ++r) {  // drain
+        if (SIGN) nh <<= 1;
+        emit(SIGN ? 0.f : ld(in_row), r - A, 0);
+        in_row += row_stride;
+    }
+}
+
 // ---- four disparities per thread (subpix 1, cbca_distance <= 5) -----------------------------------------------------------
 // The scans above move 4 bytes per lane per memory instruction and are bound by the texture addresser (~30 cycles per vector
 // memory instruction per CU whatever its width: 4 - 5 of them per 64 cells).  Here a thread owns FOUR consecutive disparities of
@@ -1164,7 +1318,17 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
         int total = Wc * cv->D;
-        if (sign)
+        const char* ev = getenv("PMX_CBCA_VBUF");  // 0: the phase-split kernel with pointers (test hook)
+        // (worth it when there are more wavefronts than the pointer kernel's 3 per SIMD can hold: 2048^2 x 129 has 4 per SIMD and
+        // runs 1.71 against 1.82 ms with pointers, 10000^2 x 129 has 20 and runs 31 against 35 ms with buffers)
+        const bool vbuf = rows_ok && (ev ? ev[0] != '0' : (size_t)total >= (size_t)6144 * 64);
+        if (vbuf && sign)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+                               (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
+        else if (vbuf)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<false>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+                               (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
+        else if (sign)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_fast_kernel<true>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
                                (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
         else if (fast_ok && Hc >= 2 * a.A + 8)
