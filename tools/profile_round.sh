@@ -3,7 +3,8 @@
 #   1. the bench line (bench.py as the driver runs it: 4096x4096x257 headline + the 2048x2048x129 leg);
 #   2. rocprofv3 --kernel-trace --stats of the integer pipeline at both shapes, FETCH_SIZE / WRITE_SIZE (separate passes) and the SQ
 #      instruction mix of the same commands -> *_kernel_stats.csv, *_pmc_hbm.csv, *_pmc_sq.csv, <round>_pmc_traffic.json;
-#   3. the float32 SGM schedules at BASELINE configs[3]'s size (ZNCC-less: census costs as float32): kernel trace + HBM counters;
+#   3. the float32 SGM schedules at BASELINE configs[3]'s size (ZNCC-less: census costs as float32) and census + CBCA at
+#      2048^2 x 129: kernel trace + HBM counters + SQ mix;
 #   4. all five BASELINE configurations on one GPU (tools/bench_configs.py).
 # Outputs land in gpurun_out/<tag>/ (merged back by gpurun); copy the summaries into profiles/.
 TAG=${1:-r02_a}
@@ -29,7 +30,8 @@ prof () {  # prof <name> <command...>: kernel trace + HBM counters + SQ mix of o
 prof northstar python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3
 prof c3 python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3 --height 2048 --width 2048 --dmax 128
 prof float_sgm_c4 python tools/bench_sgm_sched.py C4 --sched fam,seq --reps 2
+prof census_cbca_c3 env PMX_BENCH_ONLY=census_cbca python tools/bench_kernels.py
 python tools/pmc_traffic.py $OUT/northstar_pmc_hbm.csv 4096 4096 257 $OUT/c3_pmc_hbm.csv 2048 2048 129 > $OUT/pmc_traffic.json
-python tools/bench_configs.py > $OUT/baseline_configs.json 2> $OUT/baseline_configs.err
+python tools/bench_configs.py --stages > $OUT/baseline_configs.json 2> $OUT/baseline_configs.err
 python tools/bench_kernels.py > $OUT/general_path_kernels.json 2> $OUT/general.err
 cat $OUT/bench.json; head -12 $OUT/northstar_kernel_stats.csv; cat $OUT/pmc_traffic.json; cat $OUT/baseline_configs.json
