@@ -581,11 +581,17 @@ __global__ __launch_bounds__(256) void pack_arms_kernel(const int16_t* __restric
 // census source: the volume first exists as pass V's output, which covers the image without its border of `o` pixels; the
 // border cells are the NaN the census cost kernel would have left there
 __global__ __launch_bounds__(256) void cbca_border_nan_kernel(float* __restrict__ cv, int H, int W, int D, int o) {
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= W) return;
-    if (r >= o && r < H - o && c >= o && c < W - o) return;
-    float* p = cv + ((size_t)r * W + c) * D;
-    for (int k = 0; k < D; ++k) p[k] = c_nan();
+    // the border as a list of pixels: o full rows on top, o at the bottom, 2o pixels of every row between
+    const int top = o * W, sides = (H - 2 * o) * 2 * o;
+    const size_t cells = (size_t)(2 * top + sides) * D;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / D), k = (int)(i - (size_t)b * D);
+        int r, c;
+        if (b < top) { r = b / W; c = b - r * W; }
+        else if (b < top + sides) { const int j = b - top; r = o + j / (2 * o); const int e = j - (r - o) * 2 * o; c = e < o ? e : W - 2 * o + e; }
+        else { const int j = b - top - sides; r = H - o + j / W; c = j - (r - (H - o)) * W; }
+        cv[((size_t)r * W + c) * D + k] = c_nan();
+    }
 }
 
 template <bool SIGN, int SRC>
@@ -1299,7 +1305,11 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         const dim3 grid((Hc + a.R - 1) / a.R);
         const size_t lds = ((size_t)ring * T + (size_t)a.R * kStage * cv->D) * sizeof(float);
         if (census_src) {
-            if (o > 0) hipLaunchKernelGGL(cbca_border_nan_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, cv->data, H, W, cv->D, o);
+            if (o > 0) {
+                const size_t cells = ((size_t)2 * o * W + (size_t)(H - 2 * o) * 2 * o) * cv->D;
+                const unsigned nb = (unsigned)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
+                hipLaunchKernelGGL(cbca_border_nan_kernel, dim3(nb), dim3(256), 0, ctx->stream, cv->data, H, W, cv->D, o);
+            }
             if (a.range) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 2>), grid, dim3(T), lds, ctx->stream, a);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 1>), grid, dim3(T), lds, ctx->stream, a);
         }
