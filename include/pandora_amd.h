@@ -251,6 +251,15 @@ int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validi
  * elements (results within 1e-6 relative of the reference's float64 numpy arithmetic). */
 int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, double sigma_color,
                                    double sigma_space);
+/* Replaces filter.DisparityDenoiser.filter_disparity (src/pandora/filter/disparity_denoiser.py:223-313) after its get_grad
+ * (:138-149, scipy's gaussian_filter + np.gradient: the caller runs them and passes the two gradient planes): a bilateral
+ * filter of the distance to the local tangent plane over filter_size x filter_size windows of the maps padded with numpy's
+ * "reflect"; weights = euclidian x colour x centred-planar gaussians (:290-295); in place on the pixels that are not invalid
+ * and finite (:297-303).  color = the band of the left image the reference picks (:246-254), float32 [H][W].  Results within
+ * 1e-6 relative of the reference's numpy arithmetic.  Host maps in/out, computed on the device. */
+int pmx_denoise_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, const float* color, const float* grad_row,
+                          const float* grad_col, int H, int W, int filter_size, double sigma_euclidian, double sigma_color,
+                          double sigma_planar);
 /* ---- multiscale ---------------------------------------------------------------------------- */
 /* Replaces img_tools_cpp.interpolate_nodata_sgm (src/pandora/cpp/src/img_tools.cpp:99-155, called by
  * img_tools.fill_nodata_image, src/pandora/img_tools.py:578-613, before the pyramid is built): every pixel whose mask

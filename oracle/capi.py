@@ -225,6 +225,16 @@ def filter_median_disparity(disp, validity, size):
     return d
 
 
+def denoise_disparity(disp, validity, color, grad_row, grad_col, filter_size, sigma_euclidian, sigma_color, sigma_planar):
+    """disparity_denoiser.py:223-313 -> filtered copy of the disparity map (grad_* = np.gradient of the blurred map)."""
+    d = np.ascontiguousarray(disp, np.float32).copy()
+    v = np.ascontiguousarray(validity, np.int64)
+    maps = [np.ascontiguousarray(m, np.float32) for m in (color, grad_row, grad_col)]
+    lib().orc_denoise_disparity(_p(d), _p(v, C.c_int64), _p(maps[0]), _p(maps[1]), _p(maps[2]), d.shape[0], d.shape[1], int(filter_size),
+                                C.c_double(sigma_euclidian), C.c_double(sigma_color), C.c_double(sigma_planar))
+    return d
+
+
 def filter_bilateral_disparity(disp, validity, sigma_color, sigma_space):
     """bilateral.py:100-255 -> filtered copy of the disparity map."""
     d = _f32(disp).copy()

@@ -837,6 +837,66 @@ void orc_filter_bilateral_disparity(float* disp, const int64_t* validity, int H,
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * filter/disparity_denoiser.py:223-313 DisparityDenoiser.filter_disparity after get_grad (:138-149: scipy's gaussian_filter and
+ * np.gradient, which the caller runs - grad_row / grad_col are their two planes).  Per pixel, over the filter_size^2 window of
+ * the maps padded with numpy's "reflect" (:151-166):
+ *   dist(i,j)   = disp(i,j) - (i * grad_row(0,0) + j * grad_col(0,0))                float64            (:204-208)
+ *   planar      = dist - disp(0,0),  centred = dist - mean(dist)                                         (:210-214)
+ *   w(i,j)      = g(|(i,j)|, s_euclid) * g(colour(i,j) - colour(0,0), s_color) * g(centred, s_planar)    (:290-295)
+ *                 with g(v, s) = exp(-(v/s)^2 / 2) (:38-48), the colour one in the image's float32
+ *   out         = disp(0,0) + sum(planar * w / sum(w))                                                   (:228-232)
+ * written where the pixel is not flagged invalid and finite (:297-303).  NaNs propagate as they do in numpy.
+ * ------------------------------------------------------------------------------------------- */
+static int orc_reflect(int i, int n) {
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    int m = i % p;
+    if (m < 0) m += p;
+    return m < n ? m : p - m;
+}
+
+void orc_denoise_disparity(float* disp, const int64_t* validity, const float* color, const float* grad_row, const float* grad_col,
+                           int H, int W, int filter_size, double sigma_euclidian, double sigma_color, double sigma_planar) {
+    const size_t n = (size_t)H * W;
+    const int o = filter_size / 2, ws = filter_size;
+    float* out = (float*)malloc(sizeof(float) * n);
+    double* dist = (double*)malloc(sizeof(double) * (size_t)ws * ws);
+    const float sc = (float)sigma_color;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const size_t at = (size_t)r * W + c;
+            const double g0 = grad_row[at], g1 = grad_col[at];
+            const float dc = disp[at], cc = color[at];
+            double mean = 0.0;
+            for (int i = -o; i <= o; ++i)
+                for (int j = -o; j <= o; ++j) {
+                    const size_t q = (size_t)orc_reflect(r + i, H) * W + orc_reflect(c + j, W);
+                    const double d = (double)disp[q] - ((double)i * g0 + (double)j * g1);
+                    dist[(i + o) * ws + (j + o)] = d;
+                    mean += d;
+                }
+            mean /= (double)(ws * ws);
+            double sw = 0.0, sp = 0.0;
+            for (int i = -o; i <= o; ++i)
+                for (int j = -o; j <= o; ++j) {
+                    const size_t q = (size_t)orc_reflect(r + i, H) * W + orc_reflect(c + j, W);
+                    const double d = dist[(i + o) * ws + (j + o)];
+                    const double e = sqrt((double)(i * i + j * j)) / sigma_euclidian;
+                    const float tc = (color[q] - cc) / sc;
+                    const double pc = (d - mean) / sigma_planar;
+                    const double w = exp(-(e * e) / 2.0) * (double)expf(-(tc * tc) / 2.0f) * exp(-(pc * pc) / 2.0);
+                    sw += w;
+                    sp += (d - (double)dc) * w;
+                }
+            out[at] = (float)((double)dc + sp / sw);
+        }
+    for (size_t i = 0; i < n; ++i)
+        if (!(validity[i] & ORC_MSK_INVALID) && isfinite(disp[i])) disp[i] = out[i];
+    free(out);
+    free(dist);
+}
+
+/* ---------------------------------------------------------------------------------------------
  * multiscale/fixed_zoom_pyramid.py:106-172 FixedZoomPyramid.disparity_range before the zoom: invalid pixels -> NaN
  * (multiscale.py:129-153); interior pixels get nanmin(window) - marge / nanmax(window) + marge in float32; the frame of
  * window/2 pixels and the pixels that are NaN themselves get the global range (int(nanmin(disp_min)), int(nanmax(disp_max))).

@@ -95,6 +95,9 @@ void orc_cross_checking(const float* disp_left, int64_t* validity_left, const fl
 void orc_median_filter(const float* in, int H, int W, int size, float* out);
 void orc_filter_median_disparity(float* disp, const int64_t* validity, int H, int W, int size);
 
+/* filter/disparity_denoiser.py:223-313 (DisparityDenoiser.filter_disparity; the caller supplies np.gradient of the blurred map) */
+void orc_denoise_disparity(float* disp, const int64_t* validity, const float* color, const float* grad_row, const float* grad_col,
+                           int H, int W, int filter_size, double sigma_euclidian, double sigma_color, double sigma_planar);
 /* filter/bilateral.py:100-255 (BilateralFilter.filter_disparity) */
 void orc_filter_bilateral_disparity(float* disp, const int64_t* validity, int H, int W, double sigma_color,
                                     double sigma_space);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pmx_cv_scale_pixels": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     "pmx_interpolate_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, c_int_p, C.c_int]),
     "pmx_median_filter_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int]),
+    "pmx_denoise_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]),
     "pmx_bilateral_filter_disparity": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_double,
                                                  C.c_double]),
     "pmx_interpolate_nodata": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int,

@@ -138,3 +138,65 @@ int pmx_launch_bilateral_disparity(pmx_ctx* ctx, const float* in, const int64_t*
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
+
+
+// filter/disparity_denoiser.py:223-313 DisparityDenoiser.filter_disparity after get_grad (the caller runs scipy's gaussian_filter
+// and np.gradient: 2-D host work, the reference's own expressions).  Thread per pixel, two sweeps over the filter_size^2 window
+// of the maps read through numpy's "reflect" padding (:151-166): the mean distance to the tangent plane first (:204-214), then
+// the weights - euclidian gaussian from a host-built float64 table, colour gaussian in float32 as numpy evaluates it, planar
+// gaussian in float64 (:290-295) - and sum(planar * w) / sum(w) (:228-232, the reference divides every weight first: 1e-16).
+__device__ __forceinline__ int dn_reflect(int i, int n) {
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    int m = i % p;
+    m = m < 0 ? m + p : m;
+    return m < n ? m : p - m;
+}
+
+__global__ __launch_bounds__(kBlock) void denoise_disparity_kernel(const float* __restrict__ in, const int64_t* __restrict__ validity,
+                                                                   const float* __restrict__ color, const float* __restrict__ grad_row,
+                                                                   const float* __restrict__ grad_col, int H, int W, int ws,
+                                                                   const double* __restrict__ ge, float sigma_color_f, double sigma_planar,
+                                                                   float* __restrict__ out) {
+    const int c = blockIdx.x * kBlock + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const int o = ws / 2;
+    const size_t at = (size_t)r * W + c;
+    const float dc = in[at];
+    float res = dc;
+    if ((validity[at] & FMSK_INVALID) == 0 && isfinite(dc)) {
+        const double g0 = grad_row[at], g1 = grad_col[at];
+        const float cc = color[at];
+        double mean = 0.0;
+        for (int i = -o; i <= o; ++i) {
+            const size_t row = (size_t)dn_reflect(r + i, H) * W;
+            for (int j = -o; j <= o; ++j) mean += (double)in[row + dn_reflect(c + j, W)] - ((double)i * g0 + (double)j * g1);
+        }
+        mean /= (double)(ws * ws);
+        double sw = 0.0, sp = 0.0;
+        for (int i = -o; i <= o; ++i) {
+            const size_t row = (size_t)dn_reflect(r + i, H) * W;
+            for (int j = -o; j <= o; ++j) {
+                const size_t q = row + dn_reflect(c + j, W);
+                const double d = (double)in[q] - ((double)i * g0 + (double)j * g1);
+                const float tc = (color[q] - cc) / sigma_color_f;
+                const double pc = (d - mean) / sigma_planar;
+                const double w = ge[(i + o) * ws + (j + o)] * (double)expf(-(tc * tc) / 2.0f) * exp(-(pc * pc) / 2.0);
+                sw += w;
+                sp += (d - (double)dc) * w;
+            }
+        }
+        res = (float)((double)dc + sp / sw);
+    }
+    out[at] = res;
+}
+
+int pmx_launch_denoise_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, const float* color, const float* grad_row,
+                                 const float* grad_col, int H, int W, int ws, const double* ge, double sigma_color, double sigma_planar,
+                                 float* out) {
+    dim3 grid((W + kBlock - 1) / kBlock, H);
+    hipLaunchKernelGGL(denoise_disparity_kernel, grid, dim3(kBlock), 0, ctx->stream, in, validity, color, grad_row, grad_col, H, W, ws, ge,
+                       (float)sigma_color, sigma_planar, out);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}

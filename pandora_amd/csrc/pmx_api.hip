@@ -1017,6 +1017,44 @@ extern "C" int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const i
 }
 
 
+extern "C" int pmx_denoise_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, const float* color, const float* grad_row,
+                                     const float* grad_col, int H, int W, int filter_size, double sigma_euclidian, double sigma_color,
+                                     double sigma_planar) {
+    PMX_CHECK(ctx && disp && validity && color && grad_row && grad_col, PMX_ERR_ARG, "pmx_denoise_disparity: null argument");
+    PMX_CHECK(H > 0 && W > 0, PMX_ERR_ARG, "pmx_denoise_disparity: bad shape %dx%d", H, W);
+    PMX_CHECK(filter_size > 0 && (filter_size & 1), PMX_ERR_ARG,
+              "pmx_denoise_disparity: filter_size must be odd and > 0 (disparity_denoiser.py:80,120), got %d", filter_size);
+    PMX_CHECK(sigma_euclidian > 0 && sigma_color > 0 && sigma_planar > 0, PMX_ERR_ARG,
+              "pmx_denoise_disparity: sigmas must be > 0 (disparity_denoiser.py:121-123)");
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W, ng = (size_t)filter_size * filter_size;
+    std::vector<double> ge(ng);
+    const int o = filter_size / 2;
+    for (int i = -o; i <= o; ++i)
+        for (int j = -o; j <= o; ++j) {
+            const double e = sqrt((double)(i * i + j * j)) / sigma_euclidian;  // disparity_denoiser.py:280-283, :38-48
+            ge[(size_t)(i + o) * filter_size + (j + o)] = exp(-(e * e) / 2.0);
+        }
+    int rc = pmx_need_small(ctx, n * (8 + 5 * 4) + ng * 8);
+    if (rc) return rc;
+    char* base = (char*)ctx->small;
+    int64_t* d_val = (int64_t*)base;
+    double* d_ge = (double*)(base + n * 8);
+    float* d_in = (float*)(base + n * 8 + ng * 8);
+    float *d_col = d_in + n, *d_g0 = d_in + 2 * n, *d_g1 = d_in + 3 * n, *d_out = d_in + 4 * n;
+    PMX_HIP(hipMemcpyAsync(d_val, validity, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_ge, ge.data(), ng * 8, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_in, disp, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_col, color, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_g0, grad_row, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(d_g1, grad_col, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_denoise_disparity(ctx, d_in, d_val, d_col, d_g0, d_g1, H, W, filter_size, d_ge, sigma_color, sigma_planar, d_out);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(disp, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));  // (also keeps `ge` alive until its copy has left)
+    return PMX_OK;
+}
+
 // ---- multiscale -------------------------------------------------------------------------------------
 extern "C" int pmx_interpolate_nodata(pmx_ctx* ctx, const float* img, const int32_t* msk, int H, int W, int invalid_bits,
                                       int filled_value, float* out_img, int32_t* out_msk) {

@@ -226,6 +226,9 @@ int pmx_launch_interpolate_disparity(pmx_ctx* ctx, int pass, const float* disp, 
                                      int64_t* out_valid);
 int pmx_launch_reverse_disp_range(pmx_ctx* ctx, const float* lmin, const float* lmax, int H, int W, int gmin, int gmax, float* rmin,
                                   float* rmax);
+int pmx_launch_denoise_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, const float* color, const float* grad_row,
+                                 const float* grad_col, int H, int W, int ws, const double* ge, double sigma_color, double sigma_planar,
+                                 float* out);
 int pmx_launch_bilateral_disparity(pmx_ctx* ctx, const float* in, const int64_t* validity, int H, int W, int win, const double* gs,
                                    double sigma_color, float* out);
 int pmx_launch_disparity_range(pmx_ctx* ctx, const float* disp, const int64_t* validity, int H, int W, int win, int marge, int gmin,

@@ -387,6 +387,18 @@ class Engine:
                                                      int(filter_size)), "pmx_median_filter_disparity")
         return d
 
+    def denoise_disparity(self, disp, validity, color, grad_row, grad_col, filter_size, sigma_euclidian, sigma_color, sigma_planar):
+        """disparity_denoiser.py:223-313 on the device (grad_* = np.gradient of the blurred map); returns the filtered float32 map."""
+        d = np.array(disp, dtype=np.float32, order="C", copy=True)
+        v = np.ascontiguousarray(validity, np.int64)
+        maps = [np.ascontiguousarray(m, np.float32) for m in (color, grad_row, grad_col)]
+        if d.ndim != 2 or any(m.shape != d.shape for m in maps) or v.shape != d.shape:
+            raise ValueError("denoise_disparity: disparity map, validity mask, colour band and gradients must be 2-D and of one shape")
+        check(_lib.lib().pmx_denoise_disparity(self.ctx, _p(d, C.c_float), _p(v, C.c_int64), _p(maps[0], C.c_float), _p(maps[1], C.c_float),
+                                               _p(maps[2], C.c_float), d.shape[0], d.shape[1], int(filter_size), float(sigma_euclidian),
+                                               float(sigma_color), float(sigma_planar)), "pmx_denoise_disparity")
+        return d
+
     def bilateral_filter_disparity(self, disp, validity, sigma_color, sigma_space):
         """bilateral.py:100-255 on the device; returns the filtered float32 map (input untouched)."""
         d = np.array(disp, np.float32, order="C", copy=True)

@@ -6,9 +6,9 @@ here): three states ``begin -> cost_volume -> disp_map``; triggers are the pipel
 (matching_cost, aggregation, optimization, disparity, refinement) plus the validation step (SURVEY 8f
 N1: cross_checking_accurate / cross_checking_fast, with the left/right duplication of every step the
 reference performs, state_machine.py:311-364, :379-380, :418-419, :436-448, :490-491, :493-519); the
-median / bilateral disparity filters (N2; state_machine.py:449-473) and the multiscale loop (N3;
+median / bilateral / disparity_denoiser filters (N2; state_machine.py:449-473) and the multiscale loop (N3;
 fixed_zoom_pyramid, state_machine.py:521-556, images without masks); the others of the reference
-(semantic_segmentation, the disparity_denoiser filter) are outside this
+(semantic_segmentation) are outside this
 build's scope: an unknown filter raises the reference's KeyError, an unknown step ``MachineError``.
 """
 import logging

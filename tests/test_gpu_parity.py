@@ -812,6 +812,27 @@ def test_bilateral_filter(eng, oracle, H, W, sc, ss):
     np.testing.assert_array_equal(got[inv], disp[inv])
 
 
+@pytest.mark.parametrize("H,W,ws", [(2, 2, 3), (5, 5, 11), (40, 61, 11), (33, 50, 5), (7, 90, 1)])
+def test_disparity_denoiser(eng, oracle, H, W, ws):
+    """disparity_denoiser.py:223-313 on the device against the restatement (pinned by the reference's vectors,
+    tests/test_oracle_golden.py): windows larger than the image (numpy's reflect padding wraps more than once), NaN disparities
+    (every window that sees one turns NaN), invalid pixels untouched, window 1: 1e-6 relative."""
+    from scipy.ndimage import gaussian_filter
+
+    rng = np.random.default_rng(H * W + ws)
+    disp = (rng.integers(-30, 5, (H, W)) + rng.random((H, W))).astype(np.float32)
+    band = rng.integers(0, 4096, (H, W)).astype(np.float32)
+    val = np.where(rng.random((H, W)) < 0.15, rng.choice([1, 2, 64, 256], (H, W)), 0).astype(np.int64)
+    if H > 8:
+        disp[H // 2, W // 3] = np.nan
+    grad = np.gradient(gaussian_filter(disp, sigma=1.5)) if min(H, W) > 1 else [np.zeros_like(disp)] * 2
+    got = eng.denoise_disparity(disp, val, band, grad[0], grad[1], ws, 4.0, 100.0, 12.0)
+    exp = oracle.denoise_disparity(disp, val, band, grad[0], grad[1], ws, 4.0, 100.0, 12.0)
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6, equal_nan=True)
+    inv = (val & 0x3C3) != 0
+    np.testing.assert_array_equal(got[inv], disp[inv])
+
+
 def test_disparity_range_reference_vector_and_random(eng, oracle):
     c = ka.DISPARITY_RANGE
     lo, hi = eng.disparity_range(np.array(c["disp"], np.float32), np.array(c["validity"], np.int64), c["window_size"], c["marge"],

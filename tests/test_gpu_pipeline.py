@@ -264,6 +264,44 @@ def test_machine_filter_then_validation(oracle):
     assert left_disp.attrs["filter"] == "median" and left_disp.attrs["validation"] == "cross_checking_accurate"
 
 
+def test_machine_with_disparity_denoiser(oracle):
+    """filter_method "disparity_denoiser" through the machine (disparity_denoiser.py:223-313): the plugin against the reference's
+    end-to-end vector (tests/golden/disparity_denoiser.json: mono- and multiband image, named band), then census + SGM + WTA + vfit
+    + the filter on a pair, where the filtered map must equal the restatement applied to the unfiltered run's map."""
+    import os
+
+    from scipy.ndimage import gaussian_filter
+
+    from pandora_amd import filter as flt
+    from pandora_amd.dataset import Dataset, make_image
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "disparity_denoiser.json")) as f:
+        e = json.load(f)["end_to_end"]
+    band = np.array(e["band"], np.float32)
+    for left, cfg in ((make_image(band), {}),
+                      (make_image(np.stack([band, band * 3 + 1, band * 2]), band_names=["red", "green", "blue"]), {"band": "red"})):
+        ds = Dataset({"disparity_map": (("row", "col"), np.array(e["disp"], np.float32)),
+                      "validity_mask": (("row", "col"), np.zeros((2, 2), np.uint16))}, coords={"row": np.arange(2), "col": np.arange(2)})
+        flt.AbstractFilter(cfg={"filter_method": "disparity_denoiser", **e["cfg"], **cfg}).filter_disparity(ds, left)
+        np.testing.assert_allclose(ds["disparity_map"].data, np.array(e["expected"]), rtol=2e-7)
+        assert ds.attrs["filter"] == "disparity_denoiser"
+    H, W, dmin, dmax = 48, 80, -9, 3
+    L, R = pair(H, W, seed=17)
+    base = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                         "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                         "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                         "refinement": {"refinement_method": "vfit"}}}
+    _, plain = run_machine(L, R, json.loads(json.dumps(base)), dmin, dmax)
+    cfg = json.loads(json.dumps(base))
+    cfg["pipeline"]["filter"] = {"filter_method": "disparity_denoiser", "filter_size": 7}
+    _, filtered = run_machine(L, R, cfg, dmin, dmax)
+    d0 = np.asarray(plain["disparity_map"].data)
+    grad = np.gradient(gaussian_filter(d0, sigma=1.5))
+    exp = oracle.denoise_disparity(d0, np.asarray(plain["validity_mask"].data), L, grad[0], grad[1], 7, 4.0, 100.0, 12.0)
+    np.testing.assert_allclose(filtered["disparity_map"].data, exp, rtol=1e-6, atol=1e-6, equal_nan=True)
+    assert filtered.attrs["filter"] == "disparity_denoiser" and not np.array_equal(exp, d0, equal_nan=True)
+
+
 def test_machine_confidence_steps(oracle):
     """cost_volume_confidence steps between the cost volume and the disparity (state_machine.py:558-587): std_intensity
     (host) and ambiguity (device) land as indicator layers on the disparity dataset; the ambiguity layer equals

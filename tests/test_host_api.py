@@ -122,10 +122,22 @@ def test_bad_sequencing_is_rejected():
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
                                    "semantic_segmentation": {"segmentation_method": "ARNN"}}})
     assert "semantic_segmentation" in str(err.value)
-    with pytest.raises(MachineError) as err:  # a filter this build does not have: the plugin's KeyError, wrapped as the reference does
+    with pytest.raises(MachineError) as err:  # a filter nobody has: the plugin's KeyError, wrapped as the reference does
         m.check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
-                                   "filter": {"filter_method": "disparity_denoiser"}}})
-    assert "No filter method named disparity_denoiser supported" in str(err.value)
+                                   "filter": {"filter_method": "guided"}}})
+    assert "No filter method named guided supported" in str(err.value)
+    out = PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"}, "disparity": {"disparity_method": "wta"},
+                                                    "filter": {"filter_method": "disparity_denoiser"}}})
+    assert out["pipeline"]["filter"] == {"filter_method": "disparity_denoiser", "filter_size": 11, "sigma_euclidian": 4.0,
+                                         "sigma_color": 100.0, "sigma_planar": 12.0, "sigma_grad": 1.5, "band": None}  # disparity_denoiser.py:56-62
+    from pandora_amd import filter as flt
+    from pandora_amd.matching_cost.matching_cost import ConfigError
+
+    for bad in ({"filter_size": 0}, {"filter_size": 4}, {"sigma_color": 0.0}, {"sigma_planar": 3}, {"sigma_grad": -1.0}, {"band": 2},
+                {"sigma": 1.0}):  # test_disparity_denoiser.py:134-147 + the reference's odd-size assertion
+        with pytest.raises(ConfigError):
+            flt.AbstractFilter(cfg={"filter_method": "disparity_denoiser", **bad})
+    assert flt.AbstractFilter(cfg={"filter_method": "disparity_denoiser", "filter_size": 5, "band": "red"}).cfg["band"] == "red"
     out = PandoraMachine().check_conf({"pipeline": {"matching_cost": {"matching_cost_method": "sad"},
                                                     "disparity": {"disparity_method": "wta"}, "filter": {"filter_method": "bilateral"}}})
     assert out["pipeline"]["filter"]["sigma_color"] == 2.0 and out["pipeline"]["filter"]["sigma_space"] == 6.0  # bilateral.py:47-48

@@ -377,3 +377,68 @@ def test_wta_more_reference_vectors(oracle, case):
         oracle.cv_masked(cv, dmin, sp, win)
     disp, _ = oracle.wta(cv, dmin, sp, case["is_max"], float(case["invalid"]))
     np.testing.assert_array_equal(disp, np.array(case["disp"], np.float32))
+
+
+def _denoiser_vectors():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "disparity_denoiser.json")) as f:
+        return json.load(f)
+
+
+def test_disparity_denoiser_reference_vectors(oracle):
+    """The restatement of DisparityDenoiser.filter_disparity against the literal arrays of the reference's own tests
+    (tests/golden/make_denoiser_vectors.py): the end-to-end 2x2 case of test_with_valid_pixel_multiband_and_monoband (its expected
+    map follows from the test's hand-written distances), get_grad's 3x3 case, and the invalid centre that must keep its value."""
+    from scipy.ndimage import gaussian_filter
+
+    v = _denoiser_vectors()
+    g = v["get_grad"]
+    grad = np.gradient(gaussian_filter(np.array(g["disp"], float), sigma=g["sigma_grad"]))
+    np.testing.assert_allclose(grad[0], np.array(g["grad_row"]), atol=1e-7)
+    np.testing.assert_allclose(grad[1], np.array(g["grad_col"]), atol=1e-7)
+    e = v["end_to_end"]
+    disp, band = np.array(e["disp"], np.float32), np.array(e["band"], np.float32)
+    grad = np.gradient(gaussian_filter(disp, sigma=1.5))
+    got = oracle.denoise_disparity(disp, np.zeros(disp.shape, np.int64), band, grad[0], grad[1], e["cfg"]["filter_size"],
+                                   e["cfg"]["sigma_euclidian"], e["cfg"]["sigma_color"], e["cfg"]["sigma_planar"])
+    np.testing.assert_allclose(got, np.array(e["expected"]), rtol=2e-7)
+    c = v["invalid_center"]
+    disp, band = np.array(c["disp"], np.float32), np.array(c["band_green"], np.float32)
+    val = np.zeros(disp.shape, np.int64)
+    val[tuple(c["invalid_at"])] = 0b01111000011
+    grad = np.gradient(gaussian_filter(disp, sigma=1.5))
+    got = oracle.denoise_disparity(disp, val, band, grad[0], grad[1], 11, 4.0, 100.0, 12.0)
+    assert got[2, 2] == disp[2, 2] and not np.array_equal(got, disp)
+
+
+def test_disparity_denoiser_against_a_numpy_statement(oracle):
+    """... and against the formulas of disparity_denoiser.py:168-232 written with numpy on padded windows (random 9x13 map, a NaN
+    disparity - every window that sees it turns NaN, as in the reference -, an invalid pixel, window 5)."""
+    from scipy.ndimage import gaussian_filter
+
+    rng = np.random.default_rng(12)
+    H, W, ws = 9, 13, 5
+    o = ws // 2
+    disp = (rng.integers(-20, 5, (H, W)) + rng.random((H, W))).astype(np.float32)
+    disp[6, 10] = np.nan
+    band = rng.integers(0, 255, (H, W)).astype(np.float32)
+    val = np.zeros((H, W), np.int64)
+    val[2, 3] = 2
+    grad = np.gradient(gaussian_filter(disp, sigma=1.5))
+    got = oracle.denoise_disparity(disp, val, band, grad[0], grad[1], ws, 4.0, 100.0, 12.0)
+    dp, bp = np.pad(disp, o, "reflect"), np.pad(band, o, "reflect")
+    ii, jj = np.meshgrid(np.arange(-o, o + 1), np.arange(-o, o + 1), indexing="ij")
+    exp = disp.copy()
+    for r in range(H):
+        for c in range(W):
+            if val[r, c] & 0x3C3 or not np.isfinite(disp[r, c]):
+                continue
+            win, clr = dp[r:r + ws, c:c + ws], bp[r:r + ws, c:c + ws]
+            dist = win - (ii * grad[0][r, c] + jj * grad[1][r, c])
+            w = (np.exp(-(np.sqrt(ii ** 2 + jj ** 2) / 4.0) ** 2 / 2) * np.exp(-np.power((clr - clr[o, o]) / 100.0, 2.0) / 2.0)
+                 * np.exp(-((dist - dist.mean()) / 12.0) ** 2 / 2))
+            exp[r, c] = disp[r, c] + np.sum((dist - win[o, o]) * (w / w.sum()))
+    np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True)
+    assert np.isnan(got[5, 9]) and got[2, 3] == disp[2, 3]
