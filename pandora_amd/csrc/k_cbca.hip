@@ -209,9 +209,10 @@ static constexpr int kCbcaPF = 8;  // rows / columns of read-ahead (register rin
 // segment sum E_h(c) needs the running sums up to A columns ahead, so it is emitted A columns late
 // from an LDS ring.  The cost stream and the arms are read kCbcaPF columns ahead into registers:
 // the scan itself is a serial fp32 dependency (the reference's rounding), the loads are not.
-__global__ __launch_bounds__(kBlock) void cbca_h_kernel(cbca_args a) {
-    extern __shared__ float ring[];  // [ring][kBlock]
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+template <int BS>  // threads per workgroup: 256, or 64 when the ring of a long arm would not fit the LDS otherwise
+__global__ __launch_bounds__(BS) void cbca_h_kernel(cbca_args a) {
+    extern __shared__ float ring[];  // [ring][BS]
+    const int t = blockIdx.x * BS + threadIdx.x;
     const int total = a.Hc * a.D;
     const bool live = t < total;
     const int tt = live ? t : total - 1;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void cbca_h_kernel(cbca_args a) {
             }
             if (c < a.Wc) {
                 if (v == v) acc = acc + v;  // NaN is skipped, the running sum carries on
-                my[(c & mask) * kBlock] = acc;
+                my[(c & mask) * BS] = acc;
             }
             const int ce = c - a.A;  // column whose segment sum can now be emitted
             if (ce >= 0 && ce < a.Wc && c < nsteps) {
@@ -253,8 +254,8 @@ __global__ __launch_bounds__(kBlock) void cbca_h_kernel(cbca_args a) {
                 if (arms != 0xffffffffu) {
                     const int left = arms & 0xff, right = (arms >> 8) & 0xff;
                     const int lo = ce - left - 1;
-                    const float hi_v = my[((ce + right) & mask) * kBlock];
-                    const float lo_v = lo < 0 ? 0.f : my[(lo & mask) * kBlock];
+                    const float hi_v = my[((ce + right) & mask) * BS];
+                    const float lo_v = lo < 0 ? 0.f : my[(lo & mask) * BS];
                     e = hi_v - lo_v;
                 }
                 if (live) a.eh[row_off + (size_t)ce * a.D] = e;
@@ -266,9 +267,10 @@ __global__ __launch_bounds__(kBlock) void cbca_h_kernel(cbca_args a) {
 // pass V: steps 3-4 + normalisation (aggregation.cpp:123-221, cbca.py:166-171).  thread = (col, k) marches
 // down the rows; the LDS ring holds the column prefix sums S3 and, packed in one word, n_h | top | bot of
 // every row still needed (so the emit stage never re-reads the arms).
-__global__ __launch_bounds__(kBlock) void cbca_v_kernel(cbca_args a) {
-    extern __shared__ float ring[];  // [2][ring][kBlock]: column prefix sums; packed (n_h, top, bot)
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+template <int BS>
+__global__ __launch_bounds__(BS) void cbca_v_kernel(cbca_args a) {
+    extern __shared__ float ring[];  // [2][ring][BS]: column prefix sums; packed (n_h, top, bot)
+    const int t = blockIdx.x * BS + threadIdx.x;
     const int total = a.Wc * a.D;
     const bool live = t < total;
     const int tt = live ? t : total - 1;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void cbca_v_kernel(cbca_args a) {
     const int kk = k / a.subpix, ph = k - kk * a.subpix, q = c + a.d0 + kk;
     const int mask = a.ring - 1;
     float* s3 = ring + threadIdx.x;
-    uint32_t* info = reinterpret_cast<uint32_t*>(ring) + (size_t)a.ring * kBlock + threadIdx.x;
+    uint32_t* info = reinterpret_cast<uint32_t*>(ring) + (size_t)a.ring * BS + threadIdx.x;
     const size_t col_off = ((size_t)a.o * a.W + (c + a.o)) * a.D + k;
     const size_t row_stride = (size_t)a.W * a.D;
     const int last = a.Hc - 1;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void cbca_v_kernel(cbca_args a) {
             }
             if (r < a.Hc) {
                 acc = (r == 0) ? e : acc + e;
-                s3[(r & mask) * kBlock] = acc;
+                s3[(r & mask) * BS] = acc;
                 // ring word: running count N(r) = sum_{i<=r} n_h(i) in bits 0..19 (n_h = left+right, 0 outside the
                 // right image), top in bits 20..25, bot in bits 26..31 (63,63 = this cell is outside).
                 // The support size of step 4 (aggregation.cpp:199-215) then is two ring reads instead of loops:
@@ -317,20 +319,20 @@ __global__ __launch_bounds__(kBlock) void cbca_v_kernel(cbca_args a) {
                     nacc += (arms & 0xff) + ((arms >> 8) & 0xff);
                     tb = (((arms >> 16) & 0xff) << 20) | ((arms >> 24) << 26);
                 }
-                info[(r & mask) * kBlock] = nacc | tb;
+                info[(r & mask) * BS] = nacc | tb;
             }
             const int re = r - a.A;
             if (re >= 0 && re < a.Hc && r < nsteps) {
-                const uint32_t w = info[(re & mask) * kBlock];
+                const uint32_t w = info[(re & mask) * BS];
                 float step4 = 0.f, sum4 = 0.f;
                 const int top = (w >> 20) & 63, bot = w >> 26;
                 if (top != 63) {
                     const int lo = re - top - 1;
-                    const float hi_v = s3[((re + bot) & mask) * kBlock];
-                    const float lo_v = lo < 0 ? 0.f : s3[(lo & mask) * kBlock];
+                    const float hi_v = s3[((re + bot) & mask) * BS];
+                    const float lo_v = lo < 0 ? 0.f : s3[(lo & mask) * BS];
                     step4 = hi_v - lo_v;
-                    const uint32_t n_hi = info[((re + bot) & mask) * kBlock] & 0xfffffu;
-                    const uint32_t n_lo = lo < 0 ? 0u : (info[(lo & mask) * kBlock] & 0xfffffu);
+                    const uint32_t n_hi = info[((re + bot) & mask) * BS] & 0xfffffu;
+                    const uint32_t n_lo = lo < 0 ? 0u : (info[(lo & mask) * BS] & 0xfffffu);
                     sum4 = (float)(n_hi - n_lo + (uint32_t)(top + bot));  // small exact integers: any order
                 }
                 sum4 += 1.f;
@@ -1157,6 +1159,30 @@ __global__ __launch_bounds__(kBlock4) void cbca_v4_kernel(cbca_args a) {
     for (; r < Hc + A; ++r) emit(pn[(size_t)(r - A) * strideN], r - A);  // drain
 }
 
+static int cbca_ring_slots(int A) {  // 2A+2 live columns + A+1 still-zero slots that stand for the columns before the first
+    int ring = 4;
+    while (ring < 3 * A + 3) ring <<= 1;
+    return ring;
+}
+
+// rows per workgroup of the whole-row pass H: R*D threads rounded up to whole wavefronts - the fewer idle lanes the better
+// (D = 129: 2 rows are 5 wavefronts, the fifth with 2 lanes; 4 rows are 9 with 4) -, within kRowsT threads and 150 KB of LDS
+// (ring + output stage); 0: the kernel does not fit (very long arms with many disparities)
+static int cbca_rows_per_block(int D, int ring) {
+    const char* er = getenv("PMX_CBCA_ROWS");
+    int best = 0;
+    double best_waste = 1e9;
+    for (int R = 1; R <= 8; ++R) {
+        const int T = ((R * D + 63) / 64) * 64;
+        if (T > kRowsT) break;
+        if (((size_t)ring * T + (size_t)R * kStage * D) * sizeof(float) > (size_t)150 * 1024) break;
+        if (er && atoi(er) == R) return R;
+        const double waste = (double)T / (R * D);
+        if (waste < best_waste - 0.02) { best_waste = waste; best = R; }
+    }
+    return best;
+}
+
 // can pass H compute the census costs itself (no float volume)?  One code word per pixel, whole-row kernel applicable.
 bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, int distance) {
     const char* ef = getenv("PMX_CBCA_FAST");
@@ -1164,8 +1190,10 @@ bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, 
     if ((ef && atoi(ef) != 1) || (eu && eu[0] == '0')) return false;
     const int A = distance - 1 > 1 ? distance - 1 : 1;
     const int Hc = cv->H - 2 * offset, Wc = cv->W - 2 * offset;
-    return cv->repr == PMX_REPR_CENSUS_DEFERRED && cv->subpix == 1 && cv->win * cv->win <= 32 && A <= 28 &&
-           Wc >= 2 * A + 8 && Hc >= 2 * A + 8 && cv->D <= kRowsT && cv->codes_bytes < 0x7fffffffu;
+    const int pitchR = (cv->d0 < 0 ? -cv->d0 : 0) + 4 + Wc + (cv->d0 + cv->D - 1 > 0 ? cv->d0 + cv->D - 1 : 0) + 8;
+    return cv->repr == PMX_REPR_CENSUS_DEFERRED && cv->subpix == 1 && cv->win * cv->win <= 32 && cbca_ring_slots(A) <= 64 &&
+           cbca_rows_per_block(cv->D, cbca_ring_slots(A)) > 0 && Wc >= 2 * A + 8 && Hc >= 2 * A + 8 && cv->codes_bytes < 0x7fffffffu &&
+           (size_t)Hc * pitchR * 4 < 0x7fffffffu && (size_t)Hc * (Wc + 4) * 4 < 0x7fffffffu && (size_t)8 * cv->W * cv->D * 4 < 0x7fffffffu;
 }
 
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance, bool census_src) {
@@ -1200,8 +1228,10 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     const int padR = (cv->d0 < 0 ? -cv->d0 : 0) + 4;
     const int pitchL = Wc + 4, pitchR = padR + Wc + (dq_max > 0 ? dq_max : 0) + 8;
     const size_t bL8 = (size_t)Hc * pitchL * 4, bR8 = (size_t)Hc * pitchR * 4;
-    const bool rows_ok = !four && want == 1 && long_scans && a.A <= 28 && cv->D <= kRowsT && (size_t)cv->subpix * bR8 < 0x7fffffffu &&
-                         bL8 < 0x7fffffffu && (size_t)8 * W * cv->D * 4 < 0x7fffffffu;
+    const int ring = cbca_ring_slots(a.A);
+    const int rows = ring <= 64 ? cbca_rows_per_block(cv->D, ring) : 0;
+    const bool rows_ok = !four && want == 1 && long_scans && rows > 0 && (size_t)cv->subpix * bR8 < 0x7fffffffu && bL8 < 0x7fffffffu &&
+                         (size_t)8 * W * cv->D * 4 < 0x7fffffffu;
     if (census_src && !rows_ok) {
         pmx_set_error("pmx_cbca: internal: census source without the whole-row kernel");
         return PMX_ERR_STATE;
@@ -1233,20 +1263,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     a.armsR8 = (uint32_t*)(wbase + bL8);
     a.pitchL = pitchL; a.pitchR = pitchR; a.padR = padR;
     a.bytesL8 = (unsigned)bL8; a.bytesR8 = (unsigned)((size_t)cv->subpix * bR8); a.phase_words = (unsigned)(bR8 / 4);
-    {   // rows per workgroup: R*D threads rounded up to whole wavefronts - the fewer idle lanes the better (D = 129: 2 rows are
-        // 5 wavefronts, the fifth with 2 lanes; 4 rows are 9 with 4), within 576 threads and the LDS of two workgroups per CU
-        const char* er = getenv("PMX_CBCA_ROWS");
-        int best = 1;
-        double best_waste = 1e9;
-        for (int R = 1; R <= 8; ++R) {
-            const int T = ((R * cv->D + 63) / 64) * 64;
-            if (T > kRowsT) break;
-            const double waste = (double)T / (R * cv->D);
-            if (waste < best_waste - 0.02) { best_waste = waste; best = R; }
-        }
-        a.R = er ? atoi(er) : best;
-        if (a.R < 1 || ((a.R * cv->D + 63) / 64) * 64 > kRowsT) a.R = 1;
-    }
+    a.R = rows > 0 ? rows : 1;
     a.codes = cv->codes; a.codes_bytes = (unsigned)cv->codes_bytes;
     a.offCL = cv->codeL ? (unsigned)(cv->codeL - cv->codes) : 0u; a.offCR = cv->codeR ? (unsigned)(cv->codeR - cv->codes) : 0u;
     a.range = (census_src && cv->has_range) ? cv->range : nullptr;
@@ -1277,8 +1294,6 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         }
     }
     a.H = H; a.W = W; a.D = cv->D; a.d0 = cv->d0; a.subpix = cv->subpix; a.o = o; a.Hc = Hc; a.Wc = Wc;
-    int ring = 4;  // 2A+2 live columns + A+1 still-zero slots that stand for the columns before the first (phase-split kernels)
-    while (ring < 3 * a.A + 3) ring <<= 1;
     a.ring = ring;
     if (four) {
         {
@@ -1294,7 +1309,10 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         PMX_HIP(hipGetLastError());
         return PMX_OK;
     }
-    const bool fast_ok = want != 0;
+    // arms of 21 columns and more (cbca_distance > 21) need a ring of 128 slots: 256 KB of LDS for pass V with 256 threads.  Those
+    // run through the generic kernels with 64 threads per workgroup (64 KB).
+    const bool small_blocks = ring > 64;
+    const bool fast_ok = want != 0 && !small_blocks;
     // costs >= +0: the NaN flags of the input travel in the sign bit of E_h (PMX_CBCA_SIGN=0: test hook; the census source has
     // no input volume to ask)
     const char* es = getenv("PMX_CBCA_SIGN");
@@ -1321,9 +1339,11 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         if (fast_ok && Wc >= 2 * a.A + 8)
             hipLaunchKernelGGL(cbca_h_fast_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), (size_t)ring * kBlock * sizeof(float),
                                ctx->stream, a);
+        else if (small_blocks)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_kernel<64>), dim3((total + 63) / 64), dim3(64), (size_t)ring * 64 * sizeof(float), ctx->stream, a);
         else
-            hipLaunchKernelGGL(cbca_h_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), (size_t)ring * kBlock * sizeof(float),
-                               ctx->stream, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_kernel<kBlock>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+                               (size_t)ring * kBlock * sizeof(float), ctx->stream, a);
     }
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
@@ -1344,8 +1364,11 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         else if (fast_ok && Hc >= 2 * a.A + 8)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_fast_kernel<false>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
                                (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
+        else if (small_blocks)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_kernel<64>), dim3((total + 63) / 64), dim3(64), (size_t)2 * ring * 64 * sizeof(float),
+                               ctx->stream, a);
         else
-            hipLaunchKernelGGL(cbca_v_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_kernel<kBlock>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
                                (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
     }
     PMX_HIP(hipGetLastError());

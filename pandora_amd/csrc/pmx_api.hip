@@ -692,7 +692,11 @@ extern "C" int pmx_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, i
     PMX_CHECK(distance <= 32, PMX_ERR_UNSUPPORTED, "pmx_cbca: cbca_distance > 32 not supported");
     // census costs still implicit (codes only): pass H computes them on the fly and the float volume first exists as the
     // aggregated one
-    const bool census_src = pmx_cbca_can_fuse_census(ctx, cv, offset, distance);
+    bool census_src = pmx_cbca_can_fuse_census(ctx, cv, offset, distance);
+    if (census_src && pmx_need_scratch(ctx, cv->cells() * sizeof(float) + 256) != PMX_OK) {
+        (void)hipGetLastError();  // no room for the E_h volume: the in-place kernels of pmx_launch_cbca work on a materialised volume
+        census_src = false;
+    }
     rc = census_src ? pmx_cv_ensure_data(ctx, cv) : pmx_cv_materialize(ctx, cv);
     if (rc) return rc;
     rc = pmx_launch_cbca(ctx, cv, offset, intensity, distance, census_src);
