@@ -611,6 +611,8 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
     const int Wr = ph == 0 ? Wc : Wc - 1;
     float* my = lds + tid;
     for (int s = 0; s < a.ring; ++s) my[s * T] = 0.f;  // S1 of columns < 0 is 0 (aggregation.cpp:113-114)
+    const uint32_t T4 = (uint32_t)T * 4u;  // bytes from one ring slot to the next
+    auto slot = [&](int i) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(my) + __umul24((uint32_t)(i & mask), T4)); };
     float* st = stage + (size_t)lrow * kStage * D + k;  // + (ce & (kStage - 1)) * D
     const size_t row_off = ((size_t)(r + a.o) * a.W + a.o) * D + k;
     const float* pv = a.cv + row_off;  // SRC 0: cost of column c
@@ -636,19 +638,22 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
     uint32_t hist = 0;  // SIGN: bit i = the cost of column (newest - i) was NaN
     auto prefix = [&](float v, int c) {
         acc = (v == v) ? acc + v : acc;  // NaN is skipped, the running sum carries on
-        my[__umul24(c & mask, T)] = acc;
+        slot(c) = acc;
         if (SIGN) hist = (hist << 1) | (v == v ? 0u : 1u);
     };
-    // segment sum of column ce into the stage; `age` = how many columns newer than ce + A the newest prefix is (SIGN)
-    auto emit = [&](uint32_t l8, uint32_t r8, int ce, int age) {
+    // segment sum of column ce; `age` = how many columns newer than ce + A the newest prefix is (SIGN)
+    auto segment = [&](uint32_t l8, uint32_t r8, int ce, int age) {
         const int q = ce + dq;
         const bool inside = (q >= 0) & (q <= Wr - 1);
         const uint32_t lr = cb_pk_min(cb_lr16(l8), cb_lr16(r8));
         const int left = (int)(lr & 0xffffu), right = (int)(lr >> 16);
-        const float hi_v = my[__umul24((ce + right) & mask, T)];   // (v_mul_u32_u24: full rate, v_mul_lo_u32 is a quarter)
-        const float lo_v = my[__umul24((ce - left - 1) & mask, T)];
+        const float hi_v = slot(ce + right);   // (v_mul_u32_u24: full rate, v_mul_lo_u32 is a quarter)
+        const float lo_v = slot(ce - left - 1);
         float e = inside ? hi_v - lo_v : 0.f;
         if (SIGN) e = __uint_as_float(__float_as_uint(e) | (((hist >> (A + age)) & 1u) << 31));
+        return e;
+    };
+    auto put = [&](float e, int ce) {  // ... into the output stage
         if (owner) st[(ce & (kStage - 1)) * D] = e;
     };
     // kChunk finished columns m0 .. of the block's rows leave LDS as 16 bytes per lane; the barrier in front also separates
@@ -714,10 +719,11 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
             prefix(census(g.cl.z, g.cr.z, g.rg.z, c + 2), c + 2);
             prefix(census(g.cl.w, g.cr.w, g.rg.w, c + 3), c + 3);
         }
-        emit(g.l.x, g.rr.x, c - A, 3);
-        emit(g.l.y, g.rr.y, c + 1 - A, 2);
-        emit(g.l.z, g.rr.z, c + 2 - A, 1);
-        emit(g.l.w, g.rr.w, c + 3 - A, 0);
+        // (the four segments first, their ring reads in one batch; then the four stage writes - both live in the one LDS array, so
+        //  the compiler keeps reads and writes in program order)
+        const float e0 = segment(g.l.x, g.rr.x, c - A, 3), e1 = segment(g.l.y, g.rr.y, c + 1 - A, 2);
+        const float e2 = segment(g.l.z, g.rr.z, c + 2 - A, 1), e3 = segment(g.l.w, g.rr.w, c + 3 - A, 0);
+        put(e0, c - A); put(e1, c + 1 - A); put(e2, c + 2 - A); put(e3, c + 3 - A);
         c += 4;
         while (flushed + kChunk <= c - A) {  // (uniform)
             flush(flushed);
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
     for (; c < Wc + A; ++c) {  // leftover columns, then the drain (emit only)
         if (c < Wc) prefix(cost1(c), c);
         else if (SIGN) hist <<= 1;
-        emit(arms1(rsL, offL, c - A), arms1(rsR, offR, c - A), c - A, 0);
+        put(segment(arms1(rsL, offL, c - A), arms1(rsR, offR, c - A), c - A, 0), c - A);
         if (flushed + kChunk <= c + 1 - A) {
             flush(flushed);
             flushed += kChunk;
