@@ -1098,12 +1098,12 @@ def test_cbca_phase_split_and_generic_kernels(eng, oracle, monkeypatch, fast, H,
     np.testing.assert_array_equal(got, exp)
 
 
-@pytest.mark.parametrize("rows", [None, "1", "3"])
+@pytest.mark.parametrize("rows,vbuf", [(None, "0"), ("1", "1"), ("3", "1")])
 @pytest.mark.parametrize("H,W,dmin,dmax,dist,with_grids,with_left_mask", [
     (70, 150, -12, 5, 5, False, False), (41, 67, 0, 60, 5, True, False), (45, 91, -30, 3, 3, True, True),
     (40, 203, -64, 64, 5, False, True), (38, 77, -5, 4, 9, False, False), (33, 52, -3, 3, 2, True, False),
     (60, 120, -64, 64, 12, False, False), (70, 110, -5, 4, 24, False, False), (80, 110, -3, 2, 32, True, False)])
-def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, H, W, dmin, dmax, dist, with_grids, with_left_mask):
+def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, vbuf, H, W, dmin, dmax, dist, with_grids, with_left_mask):
     """Census + CBCA without a right mask: in lazy mode the census costs are still implicit (codes) when pmx_cbca runs, and pass H
     computes them on the fly - with the per-pixel valid intervals of cv_masked when grids / a left mask are resident - so the
     float volume first exists as the aggregated one (its border cells NaN); in eager mode the same whole-row pass H reads the
@@ -1113,6 +1113,7 @@ def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, H, W,
     through the generic kernels with 64-thread workgroups (they used to fail at launch: 256 KB of LDS)."""
     if rows:
         monkeypatch.setenv("PMX_CBCA_ROWS", rows)
+    monkeypatch.setenv("PMX_CBCA_VBUF", vbuf)  # pass V with pointers (what small volumes get) / through buffer instructions (large ones)
     L, R = pair(H, W, seed=H + W + dist, integer=True)
     rng = np.random.default_rng(H * dist)
     win, off = 5, 2
