@@ -131,7 +131,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     constexpr int NGP = NQ * 64;
     constexpr int KH = NQ > 10 ? 2 : 4;   // hand-off look-ahead in rows (register ring of the hand-off wave)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    volatile int* ctl = (volatile int*)(lds + 2 * EBUF);  // [0] window index, [1], [2] abort flag by row parity
+    // [0] window index, [1], [2] abort flag by row parity.  An LDS pointer by TYPE (address space 3): through a generic volatile
+    // pointer these reads were flat loads, and a flat load's wait (vmcnt(0) lgkmcnt(0)) also waits for every global load in
+    // flight - after the barrier of EVERY row the wave stood until the rows it had just prefetched arrived, which made one
+    // memory round trip the duration of a row.
+    typedef __attribute__((address_space(3))) int lds_int;
+    volatile lds_int* ctl = (volatile lds_int*)(lds_int*)(lds + 2 * EBUF);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform values live in scalar registers: buffer
