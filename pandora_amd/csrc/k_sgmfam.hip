@@ -72,6 +72,7 @@ struct fam_args {
     double d0;
     int subpix;
     float invalid_disparity;
+    int dbg;  // ablation hook (PMX_SGM_FAM_DBG): 1 no S store, 2 no C / S loads
 };
 
 constexpr unsigned kSpinLimit = 1u << 21;  // polls before a hand-off gives up (seconds; a healthy wait is microseconds)
@@ -319,7 +320,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     int pr = r_lo;
     float cbuf[PF][KPL], sbuf[PF][KPL];
     auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
-        const unsigned off = pix_off(pr) + lane_off;
+        const unsigned off = (a.dbg & 2) ? kOob : pix_off(pr) + lane_off;
         buf_load<KPL>(row_rsrc(a.C, pr), off, cslot);
         buf_load<KPL>(row_rsrc(a.S, pr), a.has_sin ? off : kOob, sslot);  // first pass of a sum: out of range = zeros, no traffic
         if (pr < r_hi) ++pr;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             }
         }
         if (!WTA) {
-            buf_store<KPL>(row_rsrc(a.S, r), pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
+            buf_store<KPL>(row_rsrc(a.S, r), (a.dbg & 1) ? kOob : pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
         } else {
             // winner-takes-all over the pixel's D values, as wta_kernel (k_disparity.hip) would do it on the stored volume: NaN
             // counts as the worst value, the FIRST extremum wins (key = orderable value in the "min" domain << 32 | index)
@@ -630,6 +631,7 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
         a.NB = NB;
         a.epoch = ++ctx->fam_epoch;
         a.ctl = ctx->fam_ctl;
+        a.dbg = getenv("PMX_SGM_FAM_DBG") ? atoi(getenv("PMX_SGM_FAM_DBG")) : 0;
         const bool use_wta = wta && fam == 1;
         a.disp = use_wta ? wta->disp : nullptr;
         a.near = use_wta ? wta->near : nullptr;
