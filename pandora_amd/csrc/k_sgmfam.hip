@@ -422,42 +422,33 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             buf_store<KPL>(row_rsrc(a.S, r), (a.dbg & 1) ? kOob : pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
         } else {
             // winner-takes-all over the pixel's D values, as wta_kernel (k_disparity.hip) would do it on the stored volume: NaN
-            // counts as the worst value, the FIRST extremum wins (key = orderable value in the "min" domain << 32 | index)
-            unsigned long long key = ~0ull;
-            bool any = false;
+            // counts as the worst value, the FIRST extremum wins.  Two reductions over the pixel's lanes: the minimum value, then the
+            // lowest index that holds it (float equality makes -0 and +0 tie); a third of the instructions of one reduction over
+            // 64-bit (orderable value, index) keys, and this epilogue runs inside the row-synchronous core that bounds the kernel
+            float vv[KPL];
+            float vmin = f_inf();
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
-                const bool isn = (nanmask >> k & 1) != 0;
                 float v = a.is_max ? __uint_as_float(__float_as_uint(acc[k]) ^ 0x80000000u) : acc[k];  // back to the "min" domain
-                v = isn ? f_inf() : v;
-                if (v == 0.f) v = 0.f;  // -0 and +0 must tie
-                const unsigned u = __float_as_uint(v);
-                const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                const unsigned long long kk = ((unsigned long long)ord << 32) | (unsigned)(d0 + k);
-                if (k < nv) {
-                    key = kk < key ? kk : key;
-                    any = any || !isn;
-                }
+                v = ((nanmask >> k & 1) != 0 || k >= nv) ? f_inf() : v;  // NaN costs and padded disparities never win
+                vv[k] = v;
+                vmin = fmin2(vmin, v);
             }
-            unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-            unsigned anyb = any ? 1u : 0u;
-            auto fold = [&](unsigned olo, unsigned ohi, unsigned oany) {
-                const bool less = ohi < khi || (ohi == khi && olo < klo);
-                klo = less ? olo : klo;
-                khi = less ? ohi : khi;
-                anyb |= oany;
-            };
-#define PMX_FOLD_DPP(CTRL)                                                                                              \
-    fold((unsigned)__builtin_amdgcn_mov_dpp((int)klo, CTRL, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)khi, CTRL, 0xf, 0xf, true), \
-         (unsigned)__builtin_amdgcn_mov_dpp((int)anyb, CTRL, 0xf, 0xf, true))
-            PMX_FOLD_DPP(0x121);
-            PMX_FOLD_DPP(0x122);
-            PMX_FOLD_DPP(0x124);
-            PMX_FOLD_DPP(0x128);
-#undef PMX_FOLD_DPP
-            if (GL == 32)
-                fold((unsigned)__builtin_amdgcn_ds_swizzle((int)klo, 0x401f), (unsigned)__builtin_amdgcn_ds_swizzle((int)khi, 0x401f),
-                     (unsigned)__builtin_amdgcn_ds_swizzle((int)anyb, 0x401f));
+            vmin = fmin2(vmin, dpp<0x121>(vmin));
+            vmin = fmin2(vmin, dpp<0x122>(vmin));
+            vmin = fmin2(vmin, dpp<0x124>(vmin));
+            vmin = fmin2(vmin, dpp<0x128>(vmin));
+            if (GL == 32) vmin = fmin2(vmin, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(vmin), 0x401f)));
+            unsigned klo = 0xffffffffu;
+#pragma unroll
+            for (int k = KPL - 1; k >= 0; --k) klo = (vv[k] == vmin) ? (unsigned)(d0 + k) : klo;
+            auto umin_dpp = [&](unsigned o) { klo = o < klo ? o : klo; };
+            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x121, 0xf, 0xf, true));
+            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x122, 0xf, 0xf, true));
+            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x124, 0xf, 0xf, true));
+            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x128, 0xf, 0xf, true));
+            if (GL == 32) umin_dpp((unsigned)__builtin_amdgcn_ds_swizzle((int)klo, 0x401f));
+            const unsigned anyb = vmin != f_inf() ? 1u : 0u;  // some cost of the pixel is a number (sums of finite costs are finite)
             const int kw = (int)klo;            // the winner, the same in every lane of the pixel
             const int li = kw / KPL, kk = kw - li * KPL;
             // its neighbours in the output domain (what the stored volume would hold); NaN outside [0, D)
