@@ -110,9 +110,18 @@ __device__ __forceinline__ float path_costs(const float (&Lp)[KPL], float M, boo
         const float nb = fmin2(lo, hi) + P1;
         float t = fmin2(Lp[k], nb);
         t = fmin2(t, mp2);
-        const float lv = cc[k] + (t - M);
-        Ln[k] = restart ? cc[k] : lv;
+        Ln[k] = cc[k] + (t - M);
         lmin = fmin2(lmin, Ln[k]);
+    }
+    // a path that starts here (first row, image border): L = C'.  Rare, and the selects would cost 9 instructions per path and
+    // step in the row-synchronous core that bounds the kernel: a wave-uniform branch instead
+    if (__builtin_amdgcn_ballot_w64(restart) != 0ull) {
+        lmin = f_inf();
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            Ln[k] = restart ? cc[k] : Ln[k];
+            lmin = fmin2(lmin, Ln[k]);
+        }
     }
     return lmin;
 }
@@ -358,14 +367,19 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         const float MA = Ep[EDIR + j * ES + GL * KS];
         // costs: NaN -> invalid_cost, sign for "max" measures, +inf on padded disparities
         float cc[KPL];
-        unsigned nanmask = 0;
+        // (by bits: this file is compiled with -fno-honor-nans, under which the compiler folds a floating-point class test to
+        //  "never".  Which values were NaN is asked again - from the same registers - only by the last pass's epilogue, instead
+        //  of building a bit mask on every pass)
+        auto was_nan = [&](int k) { return is_nan_bits(cslot[k]); };
+        if (a.is_max) {  // (uniform)
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) {
-            const float cr = cslot[k];
-            const bool isn = is_nan_bits(cr);
-            nanmask |= isn ? (1u << k) : 0u;
-            const float sg = __uint_as_float(__float_as_uint(cr) ^ (a.is_max ? 0x80000000u : 0u));
-            cc[k] = __builtin_fmaxf(isn ? a.invalid_cost : sg, padv[k]);
+            for (int k = 0; k < KPL; ++k) {
+                const float sg = __uint_as_float(__float_as_uint(cslot[k]) ^ 0x80000000u);
+                cc[k] = __builtin_fmaxf(was_nan(k) ? a.invalid_cost : sg, padv[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) cc[k] = __builtin_fmaxf(was_nan(k) ? a.invalid_cost : cslot[k], padv[k]);
         }
         const bool r0 = (r == 0);
         float nV[KPL], nA[KPL], nB[KPL];
@@ -415,7 +429,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                 float sv = acc[k];
                 if (a.overcounting) sv = sv - 7.0f * cc[k];
                 if (a.is_max) sv = __uint_as_float(__float_as_uint(sv) ^ 0x80000000u);
-                acc[k] = (nanmask >> k & 1) ? __uint_as_float(0x7fc00000u) : sv;
+                acc[k] = was_nan(k) ? __uint_as_float(0x7fc00000u) : sv;
             }
         }
         if (!WTA) {
@@ -430,7 +444,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
                 float v = a.is_max ? __uint_as_float(__float_as_uint(acc[k]) ^ 0x80000000u) : acc[k];  // back to the "min" domain
-                v = ((nanmask >> k & 1) != 0 || k >= nv) ? f_inf() : v;  // NaN costs and padded disparities never win
+                v = (was_nan(k) || k >= nv) ? f_inf() : v;  // NaN costs and padded disparities never win
                 vv[k] = v;
                 vmin = fmin2(vmin, v);
             }
