@@ -677,6 +677,7 @@ extern "C" pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, 
         return nullptr;
     }
     out->repr = PMX_REPR_FLOAT;  // the kernel writes every cell
+    out->nonneg = left_cv->nonneg;
     if (pmx_launch_reverse(ctx, left_cv, min_disp, out) != PMX_OK) {
         pmx_cv_free(ctx, out);
         return nullptr;
