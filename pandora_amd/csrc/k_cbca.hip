@@ -129,8 +129,8 @@ static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int d
     float* masked = tmp;
     float* med = tmp + (size_t)H * W;
     dim3 grid((Wd + kBlock - 1) / kBlock, H);
-    hipLaunchKernelGGL(mask_image_kernel, grid, dim3(kBlock), 0, ctx->stream, img, msk, H, Wd, W, shifted, ctx->valid_value, masked);
-    hipLaunchKernelGGL(median3_inf_kernel, grid, dim3(kBlock), 0, ctx->stream, masked, H, Wd, med);
+    if (msk) hipLaunchKernelGGL(mask_image_kernel, grid, dim3(kBlock), 0, ctx->stream, img, msk, H, Wd, W, shifted, ctx->valid_value, masked);
+    hipLaunchKernelGGL(median3_inf_kernel, grid, dim3(kBlock), 0, ctx->stream, msk ? masked : img, H, Wd, med);  // (no mask: nothing to copy)
     int Hc = H - 2 * offset, Wc = Wd - 2 * offset;
     if (Hc <= 0 || Wc <= 0) return PMX_OK;
     dim3 g2((Wc + kBlock - 1) / kBlock, Hc);
