@@ -76,8 +76,9 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned ba
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[k]), rs, off, 0, 0);
         }
     }
-    // the tail's leftover (rem < 4 values from `cov`, uniform): one 8-byte and one 4-byte store, masked by their offsets - no
-    // branch around a memory instruction, which would make the compiler's vmcnt bookkeeping wait for the youngest stores
+    // the tail's leftover (rem < 4 values from `cov`, both uniform): the lanes that are not the tail are masked by their offset -
+    // no LANE-VARYING branch around a memory instruction (that would make the compiler's vmcnt bookkeeping wait for the youngest
+    // stores)
     float t0 = v[0], t1 = v[0], t2 = v[0];
 #pragma unroll
     for (int i = 0; i < P::N; ++i) {
@@ -88,9 +89,18 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned ba
             t2 = v[k + 2 < KPL ? k + 2 : k];
         }
     }
+    // `rem` is the same for every lane and every pixel (D and the lane map): a uniform branch picks the ONE instruction the
+    // leftover needs (12, 8 or 4 bytes) - two always-issued, mostly masked stores cost two texture-addresser slots per step
     const unsigned toff = is_tail ? base_off + 4u * (unsigned)cov : kOob;
-    u32x2 t01;
-    t01.x = __float_as_uint(t0); t01.y = __float_as_uint(t1);
-    __builtin_amdgcn_raw_buffer_store_b64(t01, rs, rem >= 2 ? toff : kOob, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rem == 3 ? t2 : t0), rs, (rem & 1) ? toff + (rem == 3 ? 8u : 0u) : kOob, 0, 0);
+    if (rem == 3) {
+        u32x3 t;
+        t.x = __float_as_uint(t0); t.y = __float_as_uint(t1); t.z = __float_as_uint(t2);
+        __builtin_amdgcn_raw_buffer_store_b96(t, rs, toff, 0, 0);
+    } else if (rem == 2) {
+        u32x2 t01;
+        t01.x = __float_as_uint(t0); t01.y = __float_as_uint(t1);
+        __builtin_amdgcn_raw_buffer_store_b64(t01, rs, toff, 0, 0);
+    } else if (rem == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t0), rs, toff, 0, 0);
+    }
 }
