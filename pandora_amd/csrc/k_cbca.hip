@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
     const unsigned pix0 = (unsigned)(r + a.o) * (unsigned)a.W + (unsigned)a.o;          // pixel of column c = 0
     const unsigned offCL = (a.offCL + pix0) * 4u, offCR = (a.offCR + pix0 + (unsigned)dq) * 4u;  // + 4 * c (guard words around the images)
     const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.range, 0, (unsigned)a.H * (unsigned)a.W * 4u, kRsrcWord3);
-    constexpr bool has_range = SRC == 2;  // SRC 2: census codes + the valid intervals cv_masked left
+    constexpr bool has_range = SRC == 2;  // SRC 2: census codes + the valid intervals cv_masked left (1 and 3: census geometry)
     const bool row_ok = (r + a.o >= a.cb) & (r + a.o < a.H - a.cb);
     const unsigned wvalid = (unsigned)(a.W - 2 * a.cb);
     auto census = [&](uint32_t cl, uint32_t cr, uint32_t rg, int c) {
@@ -634,12 +634,21 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
         else ok = row_ok & ((unsigned)(c + a.o - a.cb) < wvalid) & ((unsigned)(c + a.o + dq - a.cb) < wvalid);
         return ok ? (float)__popc(cl ^ cr) : c_nan();
     };
+    // SRC 3: census geometry alone and a crop equal to the census border (the pipeline's case): a cell's cost is a number iff
+    // its right pixel c + dq lies in the cropped image - the very test of the segment sum below - so no NaN is ever made or
+    // tested and no history of them kept
+    constexpr bool kGeo = SRC == 3;
     float acc = 0.f;
     uint32_t hist = 0;  // SIGN: bit i = the cost of column (newest - i) was NaN
     auto prefix = [&](float v, int c) {
         acc = (v == v) ? acc + v : acc;  // NaN is skipped, the running sum carries on
         slot(c) = acc;
         if (SIGN) hist = (hist << 1) | (v == v ? 0u : 1u);
+    };
+    auto prefix_geo = [&](uint32_t cl, uint32_t cr, int c) {
+        const float v = (float)__popc(cl ^ cr);
+        acc = ((unsigned)(c + dq) < (unsigned)Wc) ? acc + v : acc;
+        slot(c) = acc;
     };
     // segment sum of column ce; `age` = how many columns newer than ce + A the newest prefix is (SIGN)
     auto segment = [&](uint32_t l8, uint32_t r8, int ce, int age) {
@@ -649,6 +658,7 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
         const int left = (int)(lr & 0xffffu), right = (int)(lr >> 16);
         const float hi_v = slot(ce + right);   // (v_mul_u32_u24: full rate, v_mul_lo_u32 is a quarter)
         const float lo_v = slot(ce - left - 1);
+        if (kGeo) return inside ? hi_v - lo_v : -0.f;  // outside: E_h = 0 and "the input was NaN"
         float e = inside ? hi_v - lo_v : 0.f;
         if (SIGN) e = __uint_as_float(__float_as_uint(e) | (((hist >> (A + age)) & 1u) << 31));
         return e;
@@ -691,8 +701,16 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
         const uint32_t rg = has_range ? __builtin_amdgcn_raw_buffer_load_b32(rsG, (pix0 + (unsigned)c) * 4u, 0, 0) : 0u;
         return census(cl, cr, rg, c);
     };
+    auto step1 = [&](int c) {  // the prefix update of one column (warm-up, leftovers)
+        if (kGeo) {
+            prefix_geo(__builtin_amdgcn_raw_buffer_load_b32(rsC, offCL + 4u * (unsigned)c, 0, 0),
+                       __builtin_amdgcn_raw_buffer_load_b32(rsC, offCR + 4u * (unsigned)c, 0, 0), c);
+        } else {
+            prefix(cost1(c), c);
+        }
+    };
     int c = 0, flushed = 0;
-    for (; c < A; ++c) prefix(cost1(c), c);  // warm-up: columns whose segment cannot be closed yet
+    for (; c < A; ++c) step1(c);  // warm-up: columns whose segment cannot be closed yet
     // steady state: quads of columns (four prefixes, then four emits: one LDS round trip per quad), two quads in registers, the
     // loop unrolled over the pair so that no register copies (which would wait for the loads) separate the trips
     struct quad { float v[4]; u32x4 cl, cr, rg, l, rr; };
@@ -713,6 +731,11 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
         if (SRC == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) prefix(g.v[j], c + j);
+        } else if (kGeo) {
+            prefix_geo(g.cl.x, g.cr.x, c);
+            prefix_geo(g.cl.y, g.cr.y, c + 1);
+            prefix_geo(g.cl.z, g.cr.z, c + 2);
+            prefix_geo(g.cl.w, g.cr.w, c + 3);
         } else {
             prefix(census(g.cl.x, g.cr.x, g.rg.x, c), c);
             prefix(census(g.cl.y, g.cr.y, g.rg.y, c + 1), c + 1);
@@ -743,7 +766,7 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
         }
     }
     for (; c < Wc + A; ++c) {  // leftover columns, then the drain (emit only)
-        if (c < Wc) prefix(cost1(c), c);
+        if (c < Wc) step1(c);
         else if (SIGN) hist <<= 1;
         put(segment(arms1(rsL, offL, c - A), arms1(rsR, offR, c - A), c - A, 0), c - A);
         if (flushed + kChunk <= c + 1 - A) {
@@ -1334,7 +1357,9 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
                 const unsigned nb = (unsigned)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
                 hipLaunchKernelGGL(cbca_border_nan_kernel, dim3(nb), dim3(256), 0, ctx->stream, cv->data, H, W, cv->D, o);
             }
+            const char* eg = getenv("PMX_CBCA_GEO");  // 0: the general census source even where the geometry one applies (test hook)
             if (a.range) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 2>), grid, dim3(T), lds, ctx->stream, a);
+            else if (o == a.cb && !(eg && eg[0] == '0')) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 3>), grid, dim3(T), lds, ctx->stream, a);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 1>), grid, dim3(T), lds, ctx->stream, a);
         }
         else if (sign) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 0>), grid, dim3(T), lds, ctx->stream, a);
