@@ -786,10 +786,10 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
 // Same arithmetic and order as cbca_v_fast_kernel.  SIGN as there.
 __device__ __forceinline__ uint32_t cb_tb16(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c02u); }  // (top, bottom)
 
-template <bool SIGN>
-__global__ __launch_bounds__(kBlock) void cbca_v_buf_kernel(cbca_args a) {
-    extern __shared__ float ring[];  // [ring][kBlock] x (S3, word)
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+template <bool SIGN, int BS>  // BS threads per workgroup: its cells are BS * 4 contiguous bytes of every row
+__global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
+    extern __shared__ float ring[];  // [ring][BS] x (S3, word)
+    const int t = blockIdx.x * BS + threadIdx.x;
     const int total = a.Wc * a.D;
     const bool live = t < total;
     const int tt = live ? t : total - 1;
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void cbca_v_buf_kernel(cbca_args a) {
     const int Wr = ph == 0 ? Wc : Wc - 1;
     const bool inside = (q >= 0) & (q <= Wr - 1);  // the same right column for every row
     uint2* ent = reinterpret_cast<uint2*>(ring) + threadIdx.x;
-    for (int s = 0; s < a.ring; ++s) ent[s * kBlock] = make_uint2(0u, 0u);  // row -1: zero sums, zero counts
+    for (int s = 0; s < a.ring; ++s) ent[s * BS] = make_uint2(0u, 0u);  // row -1: zero sums, zero counts
     const unsigned row_bytes = (unsigned)a.W * (unsigned)a.D * 4u;
     const unsigned voff = ((unsigned)(c + a.o) * (unsigned)a.D + (unsigned)k) * 4u;
     const unsigned voff_st = live ? voff : kOob;
@@ -828,15 +828,15 @@ __global__ __launch_bounds__(kBlock) void cbca_v_buf_kernel(cbca_args a) {
         // the row's packed word: N(r) in bits 0..19, top in bits 20..25, bot in bits 26..31 (63, 63 = outside the right image)
         nacc += inside ? (lr & 0xffffu) + (lr >> 16) : 0u;
         const uint32_t word = nacc | (inside ? (((tb & 0xffffu) << 20) | ((tb >> 16) << 26)) : ((63u << 20) | (63u << 26)));
-        ent[(r & mask) * kBlock] = make_uint2(__float_as_uint(acc), word);
+        ent[(r & mask) * BS] = make_uint2(__float_as_uint(acc), word);
     };
     // aggregated cost of row re; `age`: how many rows newer than re + A the newest prefix is (SIGN)
     auto emit = [&](float in, int re, int age) {
-        const uint32_t w = ent[(re & mask) * kBlock].y;
+        const uint32_t w = ent[(re & mask) * BS].y;
         const int top = (w >> 20) & 63, bot = w >> 26;
         const bool cell = top != 63;
         const int hi_i = cell ? re + bot : re, lo_i = cell ? re - top - 1 : re;
-        const uint2 hi = ent[(hi_i & mask) * kBlock], lo = ent[(lo_i & mask) * kBlock];
+        const uint2 hi = ent[(hi_i & mask) * BS], lo = ent[(lo_i & mask) * BS];
         const float step = __uint_as_float(hi.x) - __uint_as_float(lo.x);
         const uint32_t n = (hi.y & 0xfffffu) - (lo.y & 0xfffffu) + (uint32_t)(top + bot);
         const float step4 = cell ? step : 0.f;
@@ -1383,11 +1383,22 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         // (worth it when there are more wavefronts than the pointer kernel's 3 per SIMD can hold: 2048^2 x 129 has 4 per SIMD and
         // runs 1.71 against 1.82 ms with pointers, 10000^2 x 129 has 20 and runs 31 against 35 ms with buffers)
         const bool vbuf = rows_ok && (ev ? ev[0] != '0' : (size_t)total >= (size_t)6144 * 64);
-        if (vbuf && sign)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+        // workgroups of 512 threads read 2 KB contiguous per row: a little kinder to the DRAM pages when the workgroups of a launch
+        // have drifted rows apart (10000^2 x 129: 32.3 against 35.1 ms; at 2048^2 x 129 the coarser grid costs more than it gains)
+        const char* eb = getenv("PMX_CBCA_VBS");
+        int vbs = eb ? atoi(eb) : ((size_t)total >= ((size_t)1 << 20) ? 512 : 256);
+        while (vbs > 256 && (size_t)2 * ring * vbs * sizeof(float) > (size_t)64 * 1024) vbs >>= 1;  // (long arms: the ring decides)
+        if (vbuf && sign && vbs == 512)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true, 512>), dim3((total + 511) / 512), dim3(512),
+                               (size_t)2 * ring * 512 * sizeof(float), ctx->stream, a);
+        else if (vbuf && sign && vbs == 1024)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true, 1024>), dim3((total + 1023) / 1024), dim3(1024),
+                               (size_t)2 * ring * 1024 * sizeof(float), ctx->stream, a);
+        else if (vbuf && sign)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true, kBlock>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
                                (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
         else if (vbuf)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<false>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<false, kBlock>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
                                (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
         else if (sign)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_fast_kernel<true>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),

@@ -1114,6 +1114,8 @@ def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, vbuf,
     if rows:
         monkeypatch.setenv("PMX_CBCA_ROWS", rows)
     monkeypatch.setenv("PMX_CBCA_VBUF", vbuf)  # pass V with pointers (what small volumes get) / through buffer instructions (large ones)
+    if rows == "3":
+        monkeypatch.setenv("PMX_CBCA_VBS", "512")  # ... in the 512-thread workgroups the largest volumes get
     L, R = pair(H, W, seed=H + W + dist, integer=True)
     rng = np.random.default_rng(H * dist)
     win, off = 5, 2
