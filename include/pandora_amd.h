@@ -120,6 +120,12 @@ int pmx_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int d
 /* AbstractOptimization.optimize_cv (optimization/optimization.py:104-123) for method "sgm"; the
  * arithmetic is external to the reference (pandora_plugin_libsgm==1.5.7): see DESIGN.md. */
 int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
+/* The same with P2 given per pixel and path direction: p2maps float32 [8][H][W] (host), directions in the order
+ * (0,+1) (0,-1) (+1,0) (+1,+1) (+1,-1) (-1,0) (-1,+1) (-1,-1) of the step from p-r to p; map k holds, at pixel p, the P2 that
+ * enters p's update on path k.  For the penalty methods that follow the left image's gradient along the path
+ * (p2_method "negativeGradient" / "inverseGradient" of the libSGM plugin, docs/source/userguide/plugins/plugin_libsgm.rst:20-27,
+ * 168-290; the plugin's Python builds the maps).  float32 kernels, one launch per direction.  PARITY UNPINNED like pmx_sgm. */
+int pmx_sgm_p2maps(pmx_ctx* ctx, pmx_cv* cv, float P1, const float* p2maps, int is_max, float invalid_cost, int overcounting);
 
 /* Debug / test hook: restrict the following pmx_sgm calls of this context to a subset of the eight paths.  Bit k of mask =
  * the k-th path of the definition's order (drow, dcol of the step towards the pixel): (0,+1) (0,-1) (+1,0) (+1,+1) (+1,-1)

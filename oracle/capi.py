@@ -152,6 +152,17 @@ def cbca(cv, d0, subpix, offset, crossL, crossRs):
 SGM_DIRECTIONS = ((0, 1), (0, -1), (1, 0), (1, 1), (1, -1), (-1, 0), (-1, 1), (-1, -1))
 
 
+def sgm_p2maps(cv, P1, p2maps, is_max, invalid_cost, overcounting=False):
+    """orc_sgm with P2 given per pixel and direction: p2maps float32 [8][H][W], definition order of the directions."""
+    assert cv.dtype == np.float32 and cv.flags.c_contiguous
+    H, W, D = cv.shape
+    maps = np.ascontiguousarray(p2maps, np.float32)
+    assert maps.shape == (8, H, W)
+    out = np.empty_like(cv)
+    lib().orc_sgm_p2maps(_p(cv), H, W, D, C.c_float(P1), _p(maps), int(is_max), C.c_float(invalid_cost), int(overcounting), _p(out))
+    return out
+
+
 def sgm(cv, P1, P2, is_max=False, invalid_cost=None, overcounting=False, dir_mask=0xFF):
     cv = _f32(cv)
     H, W, D = cv.shape

@@ -497,7 +497,9 @@ static inline void sgm_pixel(const float* Cc, const float* Lq, int D, float P1, 
  * that order, whatever the thread count: horizontal paths run their rows in parallel (a private two-pixel buffer per
  * row), the others run the columns of a row in parallel against the finished previous row (rolling buffers prev / cur,
  * [W][D] each). */
-static void sgm_path(const float* Cp, int H, int W, int D, int dr, int dc, float P1, float P2,
+/* p2map: NULL, or the P2 of every pixel for THIS direction ([H][W]: penalty methods that follow the image gradient along the
+ * path, plugin_libsgm.rst:20-27); the pixel's own value enters its own update */
+static void sgm_path(const float* Cp, int H, int W, int D, int dr, int dc, float P1, float P2, const float* p2map,
                      float* S, float* prev, float* cur) {
     int c0 = dc >= 0 ? 0 : W - 1, c1 = dc >= 0 ? W : -1, cs = dc >= 0 ? 1 : -1;
     if (dr == 0) {
@@ -509,8 +511,8 @@ static void sgm_path(const float* Cp, int H, int W, int D, int dr, int dc, float
                 int which = 0;
                 for (int c = c0; c != c1; c += cs, which ^= 1) {
                     int pc = c - dc;
-                    sgm_pixel(Cp + IDX3(r, c, 0, W, D), (pc < 0 || pc >= W) ? NULL : two + (size_t)(which ^ 1) * D, D, P1, P2,
-                              two + (size_t)which * D, S + IDX3(r, c, 0, W, D));
+                    sgm_pixel(Cp + IDX3(r, c, 0, W, D), (pc < 0 || pc >= W) ? NULL : two + (size_t)(which ^ 1) * D, D, P1,
+                              p2map ? p2map[(size_t)r * W + c] : P2, two + (size_t)which * D, S + IDX3(r, c, 0, W, D));
                 }
             }
             free(two);
@@ -527,14 +529,14 @@ static void sgm_path(const float* Cp, int H, int W, int D, int dr, int dc, float
 #pragma omp parallel for schedule(static)
         for (int c = 0; c < W; ++c) {
             int pc = c - dc;
-            sgm_pixel(Cp + IDX3(r, c, 0, W, D), (pr < 0 || pr >= H || pc < 0 || pc >= W) ? NULL : Lp + (size_t)pc * D, D, P1, P2,
-                      Lc + (size_t)c * D, S + IDX3(r, c, 0, W, D));
+            sgm_pixel(Cp + IDX3(r, c, 0, W, D), (pr < 0 || pr >= H || pc < 0 || pc >= W) ? NULL : Lp + (size_t)pc * D, D, P1,
+                      p2map ? p2map[(size_t)r * W + c] : P2, Lc + (size_t)c * D, S + IDX3(r, c, 0, W, D));
         }
     }
 }
 
-void orc_sgm_dirs(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
-                  int overcounting, int dir_mask, float* out) {
+static void sgm_all(const float* cv, int H, int W, int D, float P1, float P2, const float* p2maps, int is_max, float invalid_cost,
+                    int overcounting, int dir_mask, float* out) {
     size_t n = (size_t)H * W * D;
     float* Cp = (float*)malloc(sizeof(float) * n);
     float* S = (float*)calloc(n, sizeof(float));
@@ -548,7 +550,8 @@ void orc_sgm_dirs(const float* cv, int H, int W, int D, float P1, float P2, int 
     }
     static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {1, 1}, {1, -1}, {-1, 0}, {-1, 1}, {-1, -1}};
     for (int k = 0; k < 8; ++k)
-        if (dir_mask >> k & 1) sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, S, b0, b1);
+        if (dir_mask >> k & 1)
+            sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, p2maps ? p2maps + (size_t)k * H * W : NULL, S, b0, b1);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float s = S[i];
@@ -557,6 +560,17 @@ void orc_sgm_dirs(const float* cv, int H, int W, int D, float P1, float P2, int 
         out[i] = isnan(cv[i]) ? NAN : s;
     }
     free(Cp); free(S); free(b0); free(b1);
+}
+
+void orc_sgm_dirs(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
+                  int overcounting, int dir_mask, float* out) {
+    sgm_all(cv, H, W, D, P1, P2, NULL, is_max, invalid_cost, overcounting, dir_mask, out);
+}
+
+/* P2 per pixel and direction: p2maps [8][H][W] in the definition's direction order */
+void orc_sgm_p2maps(const float* cv, int H, int W, int D, float P1, const float* p2maps, int is_max, float invalid_cost,
+                    int overcounting, float* out) {
+    sgm_all(cv, H, W, D, P1, 0.f, p2maps, is_max, invalid_cost, overcounting, 0xff, out);
 }
 
 void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,

@@ -68,6 +68,8 @@ void orc_cbca(float* cv, int H, int W, int D, int d0, int subpix, int offset, co
 void orc_sgm(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
              int overcounting, float* out);
 /* the same with a subset of the eight paths (bit k = k-th path of the definition's order; 0xff = orc_sgm) */
+void orc_sgm_p2maps(const float* cv, int H, int W, int D, float P1, const float* p2maps, int is_max, float invalid_cost,
+                    int overcounting, float* out);
 void orc_sgm_dirs(const float* cv, int H, int W, int D, float P1, float P2, int is_max, float invalid_cost,
                   int overcounting, int dir_mask, float* out);
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pmx_cbca": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int]),
     "pmx_cross_support": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, c_i16_p]),
     "pmx_sgm": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int]),
+    "pmx_sgm_p2maps": (C.c_int, [vp, vp, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int]),
     "pmx_debug_sgm_directions": (C.c_int, [vp, C.c_int]),
     "pmx_set_validity": (C.c_int, [vp, c_i64_p]),
     "pmx_wta": (C.c_int, [vp, vp, C.c_int, C.c_float]),

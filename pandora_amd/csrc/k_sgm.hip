@@ -72,6 +72,9 @@ struct sgm_args {
     int multi;
     size_t vol;
     int mask;  // multi: directions (bits, definition order) that are wanted; the others' blocks exit at once
+    // penalty methods that follow the image (plugin_libsgm.rst:20-27): P2 of every pixel for the direction of this launch
+    // ([H][W] float32; multi: [8][H][W]); nullptr = the constant a.P2
+    const float* p2map;
 };
 
 // Walks one line.  Every access of the line's pixel is a raw buffer instruction on a descriptor of the pixel's image ROW (the
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         a.dr = (k < 2) ? 0 : (k < 5 ? 1 : -1);
         a.dc = (k == 0) ? 1 : (k == 1) ? -1 : (k == 2 || k == 5) ? 0 : ((k == 3 || k == 6) ? 1 : -1);
         a.S += (size_t)k * a.vol;
+        if (a.p2map) a.p2map += (size_t)k * a.H * a.W;
         if (!(a.mask >> k & 1)) return;
     }
     const int lane = threadIdx.x & 63;
@@ -117,11 +121,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
     int pr = r, pc = c;
 
     float cbuf[kPF][KPL], sbuf[kPF][KPL];
+    float p2buf[kPF];  // the pixel's P2 when it varies (rides in the same ring as its costs)
+    const bool var_p2 = a.p2map != nullptr;  // (uniform)
     int pleft = nsteps - 1;  // steps the prefetch cursor may still advance (read-ahead past the end re-reads the last pixel)
-    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
+    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL], float& p2slot) {
         const unsigned off = (unsigned)pc * pix_bytes + lane_load;
         buf_load<KPL>(row_rsrc(a.C, pr), off, cslot);
         if (MODE & SGM_READS_S) buf_load<KPL>(row_rsrc(a.S, pr), off, sslot);
+        if (var_p2) p2slot = a.p2map[(size_t)pr * a.W + pc];
         if (pleft > 0) {
             --pleft;
             pr += a.dr;
@@ -130,18 +137,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         }
     };
 #pragma unroll
-    for (int i = 0; i < kPF; ++i) prefetch(cbuf[i], sbuf[i]);
+    for (int i = 0; i < kPF; ++i) prefetch(cbuf[i], sbuf[i], p2buf[i]);
 
     float Lp[KPL];  // path costs of the previous pixel (+inf on padded disparities)
 #pragma unroll
     for (int k = 0; k < KPL; ++k) Lp[k] = k < nv ? 0.f : f_inf();
     float M = 0.f;  // min_k Lp; (Lp = 0, M = 0) reproduces L = C' on the first pixel of a path
 
-    auto step = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
+    auto step = [&](float (&cslot)[KPL], float (&sslot)[KPL], float& p2slot) {
         // neighbours across the lane boundary
         const float below = from_lane_below(Lp[KPL - 1], f_inf());
         const float above = from_lane_above(Lp[0], f_inf());
-        const float mp2 = M + a.P2;
+        const float mp2 = M + (var_p2 ? p2slot : a.P2);
         float Ln[KPL], out[KPL];
         float lmin = f_inf();
 #pragma unroll
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         buf_store<KPL>(row_rsrc(a.S, r), (unsigned)c * pix_bytes + lane_store, nv, is_tail, cov, rem, out);
         // refill this ring slot with pixel i + kPF.  Issued AFTER the slot's last use so the new data
         // lands in the same registers (no copy, hence no wait, at the loop back-edge).
-        prefetch(cslot, sslot);
+        prefetch(cslot, sslot, p2slot);
         M = wave_min(lmin);
 #pragma unroll
         for (int k = 0; k < KPL; ++k) Lp[k] = Ln[k];
@@ -186,11 +193,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
     int i = 0;
     for (; i + kPF <= nsteps; i += kPF) {
 #pragma unroll
-        for (int j = 0; j < kPF; ++j) step(cbuf[j], sbuf[j]);
+        for (int j = 0; j < kPF; ++j) step(cbuf[j], sbuf[j], p2buf[j]);
     }
 #pragma unroll
     for (int j = 0; j < kPF - 1; ++j)
-        if (i + j < nsteps) step(cbuf[j], sbuf[j]);
+        if (i + j < nsteps) step(cbuf[j], sbuf[j], p2buf[j]);
 }
 
 // (drow, dcol) of the step from p-r to p, in the definition's order
@@ -202,6 +209,7 @@ static void sgm_launch_direction(pmx_ctx* ctx, const sgm_args& base, int k, int 
     sgm_args a = base;
     a.dr = kSgmDirs[k][0];
     a.dc = kSgmDirs[k][1];
+    if (a.p2map) a.p2map += (size_t)k * a.H * a.W;
     int nlines = a.dr == 0 ? a.H : a.W;
     dim3 grid((nlines + kWavesPerBlock - 1) / kWavesPerBlock);
     dim3 block(kWavesPerBlock * 64);
@@ -462,7 +470,7 @@ template <int KPL>
 static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask) {
     // both horizontal paths: the checkpoint / recompute pair above (PMX_SGM_HFUSED=0: test hook for the two line passes)
     const char* e = getenv("PMX_SGM_HFUSED");
-    if ((mask & 3) == 3 && KPL <= 6 && !(e && e[0] == '0')) return sgm_run_horizontal_fused<KPL>(ctx, base, mask);
+    if ((mask & 3) == 3 && KPL <= 6 && !base.p2map && !(e && e[0] == '0')) return sgm_run_horizontal_fused<KPL>(ctx, base, mask);
     for (int k = 0; k < 2; ++k)
         if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
     PMX_HIP(hipGetLastError());
@@ -558,6 +566,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
     a.is_max = is_max; a.overcounting = overcounting;
     a.multi = 0; a.vol = 0; a.mask = mask;
+    a.p2map = ctx->sgm_p2maps;  // set by pmx_sgm_p2maps for the duration of its call
     const int kpl = (cv->D + 63) / 64;
     // Schedule.  Small volumes cannot fill the GPU one direction at a time (a wave per scanline: 375 - 450 waves on cones, each a
     // chain of dependent steps): "par" runs the eight directions side by side into eight path volumes and adds them in the
@@ -577,6 +586,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     }
     if (sched == PAR && kpl > 8) sched = SEQ;
     if (sched == FAM && !pmx_sgm_family_supported(cv)) sched = SEQ;
+    if (a.p2map && sched == FAM) sched = SEQ;  // the marching kernels take the constant penalty only
     const char* ep_ = getenv("PMX_SGM_PENDING");
     const bool defer_ = sched == FAM && ctx->lazy && mask == 0xff && !(ep_ && ep_[0] == '0');
     if (!defer_) {

@@ -739,6 +739,32 @@ extern "C" int pmx_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max,
     return pmx_launch_sgm(ctx, cv, P1, P2, is_max, invalid_cost, overcounting);
 }
 
+extern "C" int pmx_sgm_p2maps(pmx_ctx* ctx, pmx_cv* cv, float P1, const float* p2maps, int is_max, float invalid_cost, int overcounting) {
+    int rc = check_cv(ctx, cv, "pmx_sgm_p2maps");
+    if (rc) return rc;
+    PMX_CHECK(p2maps, PMX_ERR_ARG, "pmx_sgm_p2maps: null penalty maps");
+    PMX_CHECK(P1 > 0.f, PMX_ERR_ARG, "pmx_sgm_p2maps: need P1 > 0, got %g", P1);
+    PMX_CHECK(cv->D <= 512, PMX_ERR_UNSUPPORTED, "pmx_sgm_p2maps: D = %d > 512 disparities not supported", cv->D);
+    PMX_CHECK(ctx->sgm_dir_mask == 0xff, PMX_ERR_STATE, "pmx_sgm_p2maps: the direction mask of pmx_debug_sgm_directions is set");
+    cv->nonneg = false;
+    rc = pmx_cv_materialize(ctx, cv);  // float32 kernels only: the integer fast path has the constant penalty in its arithmetic
+    if (rc) return rc;
+    const size_t n = (size_t)8 * cv->H * cv->W;
+    float* dev = nullptr;
+    PMX_HIP(pmx_pool_alloc(ctx, (void**)&dev, n * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(dev, p2maps, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the caller may release the maps
+    if (e != hipSuccess) {
+        pmx_pool_free(ctx, dev);
+        PMX_HIP(e);
+    }
+    ctx->sgm_p2maps = dev;
+    rc = pmx_launch_sgm(ctx, cv, P1, 0.f, is_max, invalid_cost, overcounting);
+    ctx->sgm_p2maps = nullptr;
+    pmx_pool_free(ctx, dev);  // stream-ordered reuse: the kernels above are queued on ctx->stream
+    return rc;
+}
+
 extern "C" int pmx_set_validity(pmx_ctx* ctx, const int64_t* validity) {
     PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_validity: call pmx_set_images first");
     PMX_HIP(hipSetDevice(ctx->device));

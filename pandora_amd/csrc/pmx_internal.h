@@ -94,6 +94,7 @@ struct pmx_ctx {
     unsigned* fam_ctl = nullptr;
     unsigned* fam_err_host = nullptr;  // pinned copy of the error word, filled behind every family launch
     int sgm_dir_mask = 0xff;           // pmx_debug_sgm_directions
+    const float* sgm_p2maps = nullptr; // pmx_sgm_p2maps, for the duration of its call: P2 per pixel and direction (device)
     // one pair over several GPUs (pmx_comm.hip): RCCL communicator and the device buffers the collectives work on
     struct pmx_comm* comm = nullptr;
     void* xbuf[PMX_XBUF_COUNT] = {};

@@ -270,6 +270,14 @@ class Engine:
             if dir_mask != 0xFF:
                 check(_lib.lib().pmx_debug_sgm_directions(self.ctx, 0xFF), "pmx_debug_sgm_directions")
 
+    def sgm_p2maps(self, cv, P1, p2maps, is_max=False, invalid_cost=0.0, overcounting=False):
+        """pmx_sgm_p2maps: P2 per pixel and path direction, float32 [8][H][W] in the definition's order of the directions."""
+        maps = np.ascontiguousarray(p2maps, np.float32)
+        if maps.shape != (8, self.H, self.W):
+            raise ValueError(f"sgm_p2maps: the penalty maps must be [8][{self.H}][{self.W}], got {maps.shape}")
+        check(_lib.lib().pmx_sgm_p2maps(self.ctx, cv.handle, float(P1), _p(maps, C.c_float), int(bool(is_max)), float(invalid_cost),
+                                        int(bool(overcounting))), "pmx_sgm_p2maps")
+
     def new_maps(self, superseded=()):
         """Call BEFORE an operation that overwrites the device-resident result maps: pending DeviceMapArrays get their values
         (one download each) unless they are in `superseded` (the operation updates exactly those variables in place)."""

@@ -3,9 +3,15 @@
 In the reference this step is the EXTERNAL plugin pandora_plugin_libsgm==1.5.7 (pyproject.toml:59-61)
 wrapping CNES libSGM; only its configuration surface is documented in the reference tree
 (docs/source/userguide/plugins/plugin_libsgm.rst:88-209).  This class keeps that surface
-(overcounting, min_cost_paths, penalty{penalty_method, P1, P2, p2_method}) for the constant-penalty
+(overcounting, min_cost_paths, penalty{penalty_method, P1, P2, p2_method, alpha, beta, gamma}) for the
 "sgm_penalty" method and runs this build's own SGM definition (oracle/oracle.c orc_sgm) as
 HIP kernels.  Numerical parity with libSGM is UNPINNED (no reference test pins it).
+
+p2_method (plugin_libsgm.rst:20-27, 168-290): "constant"; "negativeGradient": P2 = -alpha * |I(p) - I(p-r)| + gamma;
+"inverseGradient": P2 = alpha / (|I(p) - I(p-r)| + beta) + gamma, with I the left image and p-r the pixel before p on the
+path.  This build's reading of what the documentation leaves open: the configured P2 is the floor of the adaptive value
+(P2 > P1 keeps the recurrence's order of penalties), the gradient of a path's first pixel is 0 (its update ignores P2).
+The maps are 2-D host work (numpy), the recurrence runs on the device (pmx_sgm_p2maps).
 """
 import numpy as np
 
@@ -24,6 +30,8 @@ class Sgm(AbstractOptimization):
         self.cfg = self.check_conf(**cfg)
         pen = self.cfg["penalty"]
         self._p1, self._p2 = float(pen["P1"]), float(pen["P2"])
+        self._p2_method = pen["p2_method"]
+        self._alpha, self._beta, self._gamma = float(pen.get("alpha", 1.0)), float(pen.get("beta", 1)), float(pen.get("gamma", 1))
         self._overcounting = bool(self.cfg["overcounting"])
         self._use_confidence = self.cfg.get("use_confidence") or None
 
@@ -35,11 +43,23 @@ class Sgm(AbstractOptimization):
         pen.setdefault("p2_method", "constant")
         pen.setdefault("P1", self._P1)
         pen.setdefault("P2", self._P2)
+        if pen["p2_method"] in ("negativeGradient", "inverseGradient"):  # defaults of plugin_libsgm.rst:215-290
+            pen.setdefault("alpha", 1.0)
+            pen.setdefault("gamma", 1)
+            if pen["p2_method"] == "inverseGradient":
+                pen.setdefault("beta", 1)
         cfg["penalty"] = pen
         if cfg.get("optimization_method") != "sgm":
             raise ConfigError("optimization_method must be sgm")
-        if pen["penalty_method"] != "sgm_penalty" or pen["p2_method"] != "constant":
-            raise ConfigError("pandora_amd implements the constant-penalty sgm_penalty method only")
+        if pen["penalty_method"] != "sgm_penalty":
+            raise ConfigError("pandora_amd implements the sgm_penalty method only (mc_cnn_fast_penalty belongs to the MC-CNN plugin)")
+        if pen["p2_method"] not in ("constant", "negativeGradient", "inverseGradient"):
+            raise ConfigError("p2_method must be constant, negativeGradient or inverseGradient (plugin_libsgm.rst:163-166)")
+        for key in ("alpha", "beta", "gamma"):
+            if key in pen and (not isinstance(pen[key], (int, float)) or isinstance(pen[key], bool)):
+                raise ConfigError(f"penalty {key} must be a number")
+        if pen.get("beta", 1) <= 0:
+            raise ConfigError("penalty beta must be > 0 (it keeps alpha / (gradient + beta) finite)")
         if not isinstance(pen["P1"], (int, float)) or not isinstance(pen["P2"], (int, float)) or pen["P1"] <= 0 or pen["P2"] <= pen["P1"]:
             raise ConfigError("penalties must satisfy 0 < P1 < P2 (plugin_libsgm.rst:170-185)")
         if cfg["min_cost_paths"]:
@@ -72,7 +92,43 @@ class Sgm(AbstractOptimization):
             if "confidence_measure" in cv.data_vars and name in list(cv.coords.get("indicator", [])):
                 layer = list(cv.coords["indicator"]).index(name)
                 dcv.engine.scale_pixels(dcv, np.asarray(cv["confidence_measure"].data)[:, :, layer])
-        dcv.engine.sgm(dcv, self._p1, self._p2, is_max, invalid_cost, self._overcounting)
+        p2_top = self._p2
+        if self._p2_method == "constant":
+            dcv.engine.sgm(dcv, self._p1, self._p2, is_max, invalid_cost, self._overcounting)
+        else:
+            maps = self.p2_maps(self._band_of(img_left, cv))
+            p2_top = float(maps.max())
+            dcv.engine.sgm_p2maps(dcv, self._p1, maps, is_max, invalid_cost, self._overcounting)
         cv.attrs["optimization"] = "sgm"
-        cv.attrs["cmax"] = 8.0 * (cmax + self._p2)  # upper bound of the 8-path sum
+        cv.attrs["cmax"] = 8.0 * (cmax + p2_top)  # upper bound of the 8-path sum
         return cv
+
+    # (drow, dcol) of the step from p-r to p, in the definition's order (oracle.c orc_sgm_dirs)
+    DIRECTIONS = ((0, 1), (0, -1), (1, 0), (1, 1), (1, -1), (-1, 0), (-1, 1), (-1, -1))
+
+    @staticmethod
+    def _band_of(img_left, cv):
+        """the band the matching cost was computed on (band_correl), else the image / its first band"""
+        im = np.asarray(img_left["im"].data)
+        if im.ndim == 2:
+            return im
+        band = cv.attrs.get("band_correl")
+        names = [str(b) for b in np.asarray(img_left.coords["band_im"])]
+        return im[names.index(band)] if band in names else im[0]
+
+    def p2_maps(self, image):
+        """float32 [8][H][W]: the P2 that enters pixel p's update on each path, from the left image's gradient along the path"""
+        img = np.asarray(image, np.float32)
+        H, W = img.shape
+        maps = np.empty((8, H, W), np.float32)
+        for k, (dr, dc) in enumerate(self.DIRECTIONS):
+            grad = np.zeros((H, W), np.float32)  # |I(p) - I(p - r)|, 0 where p - r is outside the image
+            r0, r1 = max(dr, 0), H + min(dr, 0)
+            c0, c1 = max(dc, 0), W + min(dc, 0)
+            grad[r0:r1, c0:c1] = np.abs(img[r0:r1, c0:c1] - img[r0 - dr:r1 - dr, c0 - dc:c1 - dc])
+            if self._p2_method == "negativeGradient":
+                adaptive = np.float32(-self._alpha) * grad + np.float32(self._gamma)
+            else:
+                adaptive = np.float32(self._alpha) / (grad + np.float32(self._beta)) + np.float32(self._gamma)
+            maps[k] = np.maximum(adaptive, np.float32(self._p2))
+        return maps

@@ -1,6 +1,8 @@
 """GPU parity: every HIP kernel, called through the C ABI (ctypes -> libpandora_amd.so), against the
 CPU oracle on the same seeded inputs.  Bit-exact for census / NaN patterns / WTA indices / integer
 costs; float costs within the tolerance written in each test."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1147,3 +1149,31 @@ def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, vbuf,
     np.testing.assert_array_equal(got, exp)
     eng.set_masks(None, None)
     eng.set_disparity_grids(None, None)
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,method,win", [(23, 41, -9, 3, "census", 5), (30, 70, -4, 60, "sad", 3), (9, 300, -20, 0, "zncc", 5),
+                                                       (64, 33, -2, 2, "census", 7)])
+def test_sgm_with_penalty_maps(eng, oracle, H, W, dmin, dmax, method, win):
+    """pmx_sgm_p2maps (P2 per pixel and path direction: the libSGM plugin's gradient-driven penalty methods) against the
+    restatement, bit for bit, on random maps, in both modes (lazy census codes are materialised: float32 kernels only), "min" and
+    "max" measures, D up to 65, the side-by-side and the one-after-the-other schedules; constant maps reproduce pmx_sgm."""
+    L, R = pair(H, W, seed=H * W, integer=method != "zncc")
+    rng = np.random.default_rng(H + W)
+    is_max = method == "zncc"
+    maps = rng.uniform(6.0, 90.0, (8, H, W)).astype(np.float32)
+    ocv = cpu_cv(oracle, method, L, R, dmin, dmax, 1, win)
+    invalid_cost = float(win * win + 1) if method == "census" else float(np.nanmax(np.abs(ocv)) + 1)
+    exp = oracle.sgm_p2maps(ocv, 4.5, maps, is_max, invalid_cost, False)
+    for sched in ("par", "seq"):
+        os.environ["PMX_SGM_SCHED"] = sched
+        try:
+            cv = gpu_cv(eng, method, L, R, dmin, dmax, 1, win)
+            eng.sgm_p2maps(cv, 4.5, maps, is_max, invalid_cost, False)
+            np.testing.assert_array_equal(cv.to_host(), exp)
+            cv.free()
+        finally:
+            del os.environ["PMX_SGM_SCHED"]
+    cv = gpu_cv(eng, method, L, R, dmin, dmax, 1, win)
+    eng.sgm_p2maps(cv, 4.5, np.full((8, H, W), 31.0, np.float32), is_max, invalid_cost, True)
+    np.testing.assert_array_equal(cv.to_host(), oracle.sgm(ocv, 4.5, 31.0, is_max, invalid_cost, True))
+    cv.free()

@@ -264,6 +264,35 @@ def test_machine_filter_then_validation(oracle):
     assert left_disp.attrs["filter"] == "median" and left_disp.attrs["validation"] == "cross_checking_accurate"
 
 
+def test_machine_with_gradient_penalties(oracle):
+    """optimization.penalty.p2_method "negativeGradient" / "inverseGradient" through the machine (plugin_libsgm.rst:20-27,
+    168-290): the plugin builds P2 per pixel and path from the left image's gradient (its own reading of the documentation:
+    module docstring of optimization/sgm.py), the device runs the recurrence; the maps after WTA + vfit equal the oracle
+    pipeline run with the same maps.  UNPINNED against libSGM, like the constant method."""
+    from pandora_amd.optimization.sgm import Sgm
+
+    H, W, dmin, dmax = 40, 64, -8, 2
+    L, R = pair(H, W, seed=33)
+    for pen in ({"p2_method": "negativeGradient", "P1": 4, "P2": 12, "alpha": 0.5, "gamma": 60},
+                {"p2_method": "inverseGradient", "P1": 4, "P2": 12, "alpha": 90.0, "beta": 2, "gamma": 5}):
+        cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                            "optimization": {"optimization_method": "sgm", "penalty": dict(pen)},
+                            "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                            "refinement": {"refinement_method": "vfit"}}}
+        _, got = run_machine(L, R, json.loads(json.dumps(cfg)), dmin, dmax)
+        plugin = Sgm(**cfg["pipeline"]["optimization"])
+        maps = plugin.p2_maps(L)
+        assert maps.shape == (8, H, W) and maps.min() >= 12.0 and maps.max() > 12.0
+        np.testing.assert_array_equal(maps[0][:, 0], np.float32(max(12.0, pen["gamma"] + (0 if "beta" not in pen else pen["alpha"] / pen["beta"]))))
+        ocv = oracle.census_cost(L, R, dmax - dmin + 1, dmin, 1, 5)
+        exp_cv = oracle.sgm_p2maps(ocv, 4.0, maps, False, 26.0, False)
+        val0 = expected_validity(L, R, cfg, dmin, dmax, None, None, np.min(np.isnan(ocv), axis=2))
+        odisp, oval = oracle.wta(exp_cv, dmin, 1, False, np.nan, val0)
+        _, odisp, oval = oracle.refine(exp_cv, odisp, oval, dmin, dmax, 1, False, "vfit")
+        np.testing.assert_array_equal(got["disparity_map"].data, odisp)
+        np.testing.assert_array_equal(got["validity_mask"].data, oval)
+
+
 def test_machine_with_disparity_denoiser(oracle):
     """filter_method "disparity_denoiser" through the machine (disparity_denoiser.py:223-313): the plugin against the reference's
     end-to-end vector (tests/golden/disparity_denoiser.json: mono- and multiband image, named band), then census + SGM + WTA + vfit

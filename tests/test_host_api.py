@@ -682,3 +682,29 @@ def test_roi_dataset_and_georeferencing_passthrough(tmp_path):
     write_tiff(left_path, im)
     plain = img_tools.create_dataset_from_inputs({"img": left_path, "nodata": np.inf, "disp": [-2, 2]})
     assert plain.attrs["crs"] is None and plain.attrs["transform"] is None
+
+
+def test_sgm_penalty_configuration_like_the_plugin():
+    """plugin_libsgm.rst:136-290: penalty_method sgm_penalty with p2_method constant / negativeGradient / inverseGradient and
+    their documented defaults (P1 8, P2 32, alpha 1.0, beta 1, gamma 1); mc_cnn_fast_penalty belongs to another plugin."""
+    from pandora_amd.matching_cost.matching_cost import ConfigError
+    from pandora_amd.optimization.sgm import Sgm
+
+    assert Sgm(optimization_method="sgm").cfg["penalty"] == {"penalty_method": "sgm_penalty", "p2_method": "constant", "P1": 8, "P2": 32}
+    pen = Sgm(optimization_method="sgm", penalty={"p2_method": "negativeGradient"}).cfg["penalty"]
+    assert (pen["alpha"], pen["gamma"], "beta" in pen) == (1.0, 1, False)
+    pen = Sgm(optimization_method="sgm", penalty={"p2_method": "inverseGradient", "alpha": 3.0}).cfg["penalty"]
+    assert (pen["alpha"], pen["beta"], pen["gamma"]) == (3.0, 1, 1)
+    for bad in ({"p2_method": "cubic"}, {"penalty_method": "mc_cnn_fast_penalty"}, {"p2_method": "inverseGradient", "beta": 0},
+                {"p2_method": "negativeGradient", "alpha": "1"}, {"P1": 8, "P2": 8}):
+        with pytest.raises(ConfigError):
+            Sgm(optimization_method="sgm", penalty=bad)
+    # the maps: the configured P2 is the floor, a path's first pixel has no gradient
+    s = Sgm(optimization_method="sgm", penalty={"p2_method": "negativeGradient", "P1": 4, "P2": 20, "alpha": 0.5, "gamma": 60})
+    img = (np.arange(20, dtype=np.float32).reshape(4, 5) * 3)
+    maps = s.p2_maps(img)
+    np.testing.assert_array_equal(maps[0][:, 0], np.float32(60.0))          # (0,+1): column 0 starts the path
+    np.testing.assert_array_equal(maps[0][:, 1:], np.float32(60.0 - 0.5 * 3))  # |I(p) - I(p - (0,1))| = 3
+    np.testing.assert_array_equal(maps[2][1:], np.float32(60.0 - 0.5 * 15))    # (+1,0): 15 between rows
+    s = Sgm(optimization_method="sgm", penalty={"p2_method": "inverseGradient", "P1": 4, "P2": 20, "alpha": 8.0, "beta": 1, "gamma": 2})
+    np.testing.assert_array_equal(s.p2_maps(img)[1][:, :-1], np.float32(20.0))  # 8 / (3 + 1) + 2 = 4 < P2: the floor

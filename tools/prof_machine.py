@@ -36,4 +36,4 @@ pr = cProfile.Profile()
 pr.enable()
 once()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
