@@ -34,19 +34,22 @@ def test_bench_prints_one_contract_line():
     assert d["cpu_baseline_reference_compiled"]["kind"] == "reference-compiled"  # the reference's own census C++, same strip
 
 
-def test_bench_runs_one_pair_over_two_ranks():
-    """--gpus 2 = ONE pair over two ranks (row tiles + 40-row margin, all-gather of the owned rows), launched with the launcher's
-    environment variables; both ranks share the box's one GPU, so the gather goes through the tcp test transport."""
+@pytest.mark.parametrize("world,port", [(2, 29547), (8, 29561)])
+def test_bench_runs_one_pair_over_the_ranks(world, port):
+    """--gpus N = ONE pair over N ranks (row tiles + 40-row margin, gather of the owned rows on rank 0), launched with the launcher's
+    environment variables; the ranks share the box's one GPU, so the exchange goes through the tcp test transport.  Eight ranks over
+    300 rows: tiles of 37 / 38 owned rows whose margins reach over several neighbours."""
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    PANDORA_COMM_BACKEND="tcp", PANDORA_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
                                        "--height", "300", "--width", "256", "--dmax", "40", "--placement-trials", "1"],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
-    outs = [p.communicate(timeout=600) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "".join(o[1][-1500:] for o in outs)
     lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
-    assert len(lines) == 1 and not outs[1][0].strip(), outs
+    assert len(lines) == 1 and not any(o[0].strip() for o in outs[1:]), outs
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"] and d["collective"]["bytes_per_step"] == 300 * 256 * 10
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"]
+    assert d["collective"]["bytes_per_step"] == 300 * 256 * 10
