@@ -9,7 +9,18 @@
 // pass H: thread = (row, d), marches along columns; pass V: thread = (column, d), marches down
 // rows.  H*D and W*D independent scans, disparity innermost -> coalesced.  The prefix values a
 // segment sum needs (at most cbca_distance-1 ahead / behind) live in a per-thread LDS ring.
-// HBM: pass H reads cv, writes E_h; pass V reads E_h + cv (NaN test), writes cv.
+//
+// Kernels (pmx_launch_cbca picks; DESIGN.md section 3 has the measurements behind each choice):
+//   pass H  cbca_h_rows_kernel   a workgroup owns whole image rows and stores E_h through an LDS stage (16 bytes per lane);
+//                                SRC 1-3: the census Hamming costs are computed in the kernel, the cost volume never exists
+//           cbca_h_fast_kernel   phase-split scan, 4 bytes per lane (short scans, PMX_CBCA_FAST=2)
+//           cbca_h_kernel        generic (images a few arms wide; 64-thread workgroups for arms of 21 columns and more)
+//           cbca_h4_kernel       four disparities per thread, in place (no second volume available)
+//   pass V  cbca_v_fast_kernel   phase-split scan with per-lane pointers (volumes up to ~6000 wavefronts)
+//           cbca_v_buf_kernel    the same through buffer instructions, 62 registers, 256 / 512 threads (large volumes)
+//           cbca_v_kernel, cbca_v4_kernel   as for pass H
+// HBM: pass H reads the costs (or the census codes) and writes E_h; pass V reads E_h and writes the volume; which input costs
+// were NaN travels in the sign bit of E_h when the costs are known to be >= 0 (else pass V reads the input volume again).
 #include <cstdlib>
 
 #include "pmx_internal.h"
