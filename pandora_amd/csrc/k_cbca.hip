@@ -1239,7 +1239,7 @@ bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, 
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance, bool census_src) {
     const int H = cv->H, W = cv->W, o = offset;
     const int Hc = H - 2 * o, Wc = W - 2 * o;
-    if (Hc <= 0 || Wc <= 1) return PMX_OK;
+    if (Hc <= 0 || Wc <= 0) return PMX_OK;  // (one cropped column is a volume like any other: its columns still aggregate)
     cbca_args a;
     a.A = distance - 1 > 1 ? distance - 1 : 1;
     // kernel choice.  Default: the phase-split scans when the scanned dimension is long enough, else the generic ones.  The

@@ -815,7 +815,9 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
 
 int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
     const int H = cv->H, W = cv->W, o = win / 2;
-    if (H - 2 * o <= 0 || W - 1 - 2 * o <= 0) return pmx_launch_fill_nan(ctx, cv->data, cv->cells());
+    // (an image exactly one window wide still has ONE column of valid cells at the integer disparities: only its half-pixel
+    //  phases, whose shifted right images are one column narrower, have none - their statistics rasters are empty)
+    if (H - 2 * o <= 0 || W - 2 * o <= 0) return pmx_launch_fill_nan(ctx, cv->data, cv->cells());
     size_t per = (size_t)(H - 2 * o) * (W - 2 * o) * sizeof(double);
     int rc = pmx_need_small(ctx, per * 3 * (1 + cv->subpix));
     if (rc) return rc;
@@ -838,6 +840,7 @@ int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
         st.rmean[k] = (double*)(base + per * (3 + 3 * k));
         st.rsd[k] = (double*)(base + per * (4 + 3 * k));
         risd[k] = (double*)(base + per * (5 + 3 * k));
+        if (wk - 2 * o <= 0) continue;  // nothing of this phase is valid
         dim3 grid((wk - 2 * o + kBlock - 1) / kBlock, H - 2 * o);
         hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, win,
                            (double*)st.rmean[k], (double*)st.rsd[k], risd[k]);

@@ -1177,3 +1177,47 @@ def test_sgm_with_penalty_maps(eng, oracle, H, W, dmin, dmax, method, win):
     eng.sgm_p2maps(cv, 4.5, np.full((8, H, W), 31.0, np.float32), is_max, invalid_cost, True)
     np.testing.assert_array_equal(cv.to_host(), oracle.sgm(ocv, 4.5, 31.0, is_max, invalid_cost, True))
     cv.free()
+
+
+@pytest.mark.parametrize("method", ["zncc", "sad", "census"])
+@pytest.mark.parametrize("sp", [1, 2, 4])
+def test_image_exactly_one_window_wide(eng, oracle, method, sp):
+    """W == window_size: one column of valid cells at the integer disparities, none at the sub-pixel phases (their shifted
+    right images are one column narrower).  pmx_zncc used to answer all-NaN here (found by tools/fuzz_more.py, seed 1397)."""
+    win, H, W, dmin, dmax = 7, 22, 7, -5, 6
+    L, R = pair(H, W, seed=11 + sp, integer=False)
+    D = (dmax - dmin) * sp + 1
+    cv = gpu_cv(eng, method, L, R, dmin, dmax, sp, win, masked=False)
+    got = cv.to_host()
+    exp = cpu_cv(oracle, method, L, R, dmin, dmax, sp, win)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    assert np.isfinite(exp).sum() == (H - win + 1)  # one column, disparity 0 only
+    if method == "zncc":
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5, equal_nan=True)
+    else:
+        np.testing.assert_array_equal(got, exp)
+    assert got.shape == (H, W, D)
+    cv.free()
+
+
+@pytest.mark.parametrize("sp", [1, 2])
+def test_cbca_on_one_cropped_column(eng, oracle, sp):
+    """Image exactly one window wide: the volume CBCA sees has ONE column, whose rows still aggregate along the vertical arms
+    (pmx_cbca used to return such a volume untouched; tools/fuzz_more.py, seeds 3995 and 4456)."""
+    win, H, W, dmin, dmax, dist = 9, 18, 9, -3, 4, 3
+    off = win // 2
+    L, R = pair(H, W, seed=5 + sp, integer=True)
+    cv = gpu_cv(eng, "sad", L, R, dmin, dmax, sp, win, masked=False)
+    before = cv.to_host()
+    eng.cbca(cv, off, 30.0, dist)
+    got = cv.to_host()
+    exp = cpu_cv(oracle, "sad", L, R, dmin, dmax, sp, win)
+
+    def arms(im):
+        m = np.nan_to_num(oracle.median3(im), nan=np.inf)[off:-off, off:-off]
+        return oracle.cross_support(np.ascontiguousarray(m), dist, 30.0)
+
+    oracle.cbca(exp, dmin, sp, off, arms(L), [arms(im) for im in oracle.shift_right(R, sp)])
+    np.testing.assert_array_equal(got, exp)
+    assert not np.array_equal(got, before, equal_nan=True)
+    cv.free()
