@@ -254,7 +254,8 @@ int pmx_reverse_disp_range(pmx_ctx* ctx, const float* left_min, const float* lef
 int pmx_median_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, int filter_size);
 /* Replaces filter.BilateralFilter.filter_disparity (src/pandora/filter/bilateral.py:100-255): same in-place protocol as
  * the median filter; window = min(H, W, int(3*sigma_space + 1)), float64 weighted means over the non-NaN window
- * elements (results within 1e-6 relative of the reference's float64 numpy arithmetic). */
+ * elements (results within 1e-6 relative - 2e-6 absolute where the weighted mean cancels to about zero - of the reference's
+ * float64 numpy arithmetic: the colour gaussian is a float32 exp on both sides, an ulp apart). */
 int pmx_bilateral_filter_disparity(pmx_ctx* ctx, float* disp, const int64_t* validity, int H, int W, double sigma_color,
                                    double sigma_space);
 /* Replaces filter.DisparityDenoiser.filter_disparity (src/pandora/filter/disparity_denoiser.py:223-313) after its get_grad

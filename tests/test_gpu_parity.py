@@ -809,7 +809,8 @@ def test_bilateral_filter(eng, oracle, H, W, sc, ss):
     disp[H // 2, W // 3] = np.nan
     got = eng.bilateral_filter_disparity(disp, val, sc, ss)
     exp = oracle.filter_bilateral_disparity(disp, val, sc, ss)
-    np.testing.assert_allclose(got, exp, rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=2e-6, equal_nan=True)  # (atol: weighted means that cancel to ~0; the
+    # device's expf and libm's differ by an ulp of a weight, against disparities of tens - tools/fuzz_filters.py)
     inv = (val & 0x3C3) != 0
     np.testing.assert_array_equal(got[inv], disp[inv])
 
