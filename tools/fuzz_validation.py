@@ -1,0 +1,85 @@
+"""Random left + right pipelines with cross-checking through PandoraMachine (accurate: both sides computed; fast: the right side
+is the re-indexed left volume) against the oracle composition of tests/test_gpu_pipeline.py.  FUZZ_FROM / FUZZ_TO."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+import numpy as np  # noqa: E402
+
+import tests.test_gpu_pipeline as tp  # noqa: E402
+from oracle import capi as orc  # noqa: E402
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    method = str(rng.choice(["census", "census", "sad"]))
+    win = int(rng.choice([3, 5, 7] if method == "census" else [3, 5]))
+    H, W = int(rng.integers(2 * win + 4, 50)), int(rng.integers(2 * win + 10, 100))
+    dmin = int(rng.integers(-20, -2))
+    dmax = dmin + int(rng.integers(3, 20))
+    p = {"matching_cost": {"matching_cost_method": method, "window_size": win}}
+    if rng.random() < 0.3:
+        p["aggregation"] = {"aggregation_method": "cbca", "cbca_distance": int(rng.integers(2, 6))}
+    if rng.random() < 0.7:
+        P1 = int(rng.integers(1, 10))
+        p["optimization"] = {"optimization_method": "sgm", "penalty": {"P1": P1, "P2": P1 + int(rng.integers(1, 40))}}
+    p["disparity"] = {"disparity_method": "wta", "invalid_disparity": "NaN"}
+    p["refinement"] = {"refinement_method": str(rng.choice(["vfit", "quadratic"]))}
+    mode = str(rng.choice(["cross_checking_accurate", "cross_checking_fast"]))
+    p["validation"] = {"validation_method": mode, "cross_checking_threshold": float(rng.choice([0.5, 1.0, 2.0]))}
+    L, R = tp.pair(H, W, seed=seed, integer=bool(rng.random() < 0.7))
+    if rng.random() < 0.7:
+        r0, c0 = int(rng.integers(0, H - 6)), int(rng.integers(0, W - 8))
+        R[r0:r0 + 6, c0:c0 + 8] = 255 - R[r0:r0 + 6, c0:c0 + 8]
+    return {"pipeline": p}, L, R, dmin, dmax
+
+
+def one(seed):
+    cfg, L, R, dmin, dmax = draw(seed)
+    p = cfg["pipeline"]
+    mode, refine = p["validation"]["validation_method"], p["refinement"]["refinement_method"]
+    off = p["matching_cost"]["window_size"] // 2
+    machine, left = tp.run_machine(L, R, cfg, dmin, dmax)
+    right = machine.right_disparity
+    no_val = {"pipeline": {k: v for k, v in p.items() if k != "validation"}}
+    mc_only = {"pipeline": {"matching_cost": p["matching_cost"], "disparity": {"disparity_method": "wta"}}}
+    cv0, _, _, _ = tp.oracle_pipeline(orc, L, R, mc_only, dmin, dmax)
+    val0 = tp.expected_validity(L, R, cfg, dmin, dmax, None, None, np.min(np.isnan(cv0), axis=2))
+    lcv, ldisp, lval, _ = tp.oracle_pipeline(orc, L, R, no_val, dmin, dmax, validity0=val0)
+    if mode == "cross_checking_accurate":
+        rcv0, _, _, _ = tp.oracle_pipeline(orc, R, L, mc_only, -dmax, -dmin)
+        rval0 = tp.expected_validity(R, L, cfg, -dmax, -dmin, None, None, np.min(np.isnan(rcv0), axis=2))
+        _, rdisp, rval, _ = tp.oracle_pipeline(orc, R, L, no_val, -dmax, -dmin, validity0=rval0)
+    else:
+        rcv = orc.reverse_cost_volume(lcv, -dmax)
+        rval0 = tp._geometry_validity(R, L, cfg, -dmax, -dmin)["validity_mask"].data
+        rdisp, rval = orc.wta(rcv, -dmax, 1, False, np.nan, rval0)
+        _, rdisp, rval = orc.refine(rcv, rdisp, rval, -dmax, -dmin, 1, False, refine)
+    thr = p["validation"]["cross_checking_threshold"]
+    lval2, lconf = orc.cross_checking(ldisp, lval, rdisp, dmin, dmax, thr)
+    rval2, rconf = orc.cross_checking(rdisp, rval, ldisp, -dmax, -dmin, thr)
+    for v in (lval2, rval2):
+        if off:
+            v[:off, :] = v[-off:, :] = 1
+            v[off:-off, :off] = v[off:-off, -off:] = 1
+    np.testing.assert_array_equal(left["disparity_map"].data, ldisp, err_msg="left disparity")
+    np.testing.assert_array_equal(left["validity_mask"].data, lval2, err_msg="left validity")
+    np.testing.assert_array_equal(left["confidence_measure"].data[:, :, -1], lconf, err_msg="left confidence")
+    if mode == "cross_checking_accurate":
+        np.testing.assert_array_equal(right["disparity_map"].data, rdisp, err_msg="right disparity")
+        np.testing.assert_array_equal(right["validity_mask"].data, rval2, err_msg="right validity")
+        np.testing.assert_array_equal(right["confidence_measure"].data[:, :, -1], rconf, err_msg="right confidence")
+
+
+fails = 0
+for seed in range(int(os.environ.get("FUZZ_FROM", "0")), int(os.environ.get("FUZZ_TO", "300"))):
+    try:
+        one(seed)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        cfg = draw(seed)[0]
+        print("FAIL", seed, json.dumps(cfg), draw(seed)[1].shape, draw(seed)[3:], type(e).__name__, str(e)[:300].replace("\n", " "))
+        if fails > 8:
+            break
+print("done, failures:", fails)
