@@ -52,7 +52,7 @@ for name, cfg in (("local", LOCAL), ("sgm", SGM)):
             bad = (np.abs(np.nan_to_num(tl["disparity_map"], nan=1e4) + gt) > 1) & (gt != 0)
             assert bad.sum() / gt.size <= 0.20 and tr is not None and tr["disparity_map"].shape == L.shape
             print("SGM_TILED_SAME_FRACTION", same.mean())
-            assert same.mean() > 0.97
+            assert same.mean() > (0.97 if comm.world == 2 else 0.90)  # (every seam costs a few pixels)
 comm.barrier()
 comm.close()
 if rank == 0:
@@ -60,21 +60,23 @@ if rank == 0:
 '''
 
 
-def two_ranks(script, port):
-    """Both ranks on the box's one GPU, launched as plain processes with the launcher's environment variables."""
+def ranks(script, port, world=2):
+    """All ranks on the box's one GPU, launched as plain processes with the launcher's environment variables."""
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+    for rank in range(world):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
     outs = [p.communicate(timeout=900) for p in procs]
     return outs[0][0], "".join(o[0][-2000:] + o[1][-4000:] for o in outs)
 
 
-def test_row_tiled_pair_over_two_ranks(tmp_path):
+@pytest.mark.parametrize("world,port", [(2, 29541), (5, 29571)])
+def test_row_tiled_pair_over_the_ranks(tmp_path, world, port):
+    """(five ranks over cones' 375 rows: 75 owned rows each, the 40-row margins of a tile reach into both neighbours)"""
     script = tmp_path / "tiled.py"
     script.write_text(SCRIPT % {"root": ROOT})
-    out, log = two_ranks(script, 29541)
+    out, log = ranks(script, port, world)
     assert "TILED_OK" in out, log
 
 
@@ -118,10 +120,12 @@ if rank == 0:
 '''
 
 
-def test_d_sharded_pair_over_two_ranks(tmp_path):
+@pytest.mark.parametrize("world,port", [(2, 29543), (5, 29575)])
+def test_d_sharded_pair_over_the_ranks(tmp_path, world, port):
     """pandora_amd.dist.run_d_sharded (costs sharded over D, one all_reduce(MIN) of packed keys, owner-rank refinement) with two
-    ranks == the unsharded machine run, bit for bit: ZNCC sub-pixel + vfit, SAD + CBCA + quadratic with masks, census."""
+    and with five ranks (41 disparities: shards of 8 and 9) == the unsharded machine run, bit for bit: ZNCC sub-pixel + vfit,
+    SAD + CBCA + quadratic with masks, census."""
     script = tmp_path / "dshard.py"
     script.write_text(DSHARD % {"root": ROOT})
-    out, log = two_ranks(script, 29543)
+    out, log = ranks(script, port, world)
     assert "DSHARD_OK" in out, log
