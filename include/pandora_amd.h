@@ -105,6 +105,12 @@ int pmx_cv_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* weights);
 /* Pixels whose cost is NaN for every disparity (np.min(np.isnan(cv), axis=2)), uint8 [H][W] on the
  * host: input of criteria.mask_invalid_variable_disparity_range (criteria.py:291-322). */
 int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out);
+/* The same flags kept ON THE DEVICE with the volume: a snapshot of "NaN for every disparity" per pixel as the volume is when
+ * this is called (the machine calls it where the reference calls criteria.mask_invalid_variable_disparity_range, right after
+ * cv_masked: matching_cost/matching_cost.py:866-872); pmx_cv_get_missing copies the snapshot to the host, uint8 [H][W];
+ * pmx_compose_validity consumes it where it is. */
+int pmx_cv_mark_missing(pmx_ctx* ctx, pmx_cv* cv);
+int pmx_cv_get_missing(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out);
 /* matching_cost_cpp.reverse_cost_volume (matching_cost/cpp/src/matching_cost.cpp:26-56) */
 pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, int min_disp);
 
@@ -137,8 +143,22 @@ int pmx_debug_sgm_directions(pmx_ctx* ctx, int mask);
 /* Upload the int64 validity mask computed by criteria.validity_mask (criteria.py:66-158);
  * NULL = zeros. */
 int pmx_set_validity(pmx_ctx* ctx, const int64_t* validity);
+/* The validity mask a cost volume carries into the disparity step, put together on the device instead of on the host
+ * (criteria.validity_mask, criteria.py:66-158, then mask_invalid_variable_disparity_range :291-322 and mask_border :325-353):
+ * validity(r, c) = base, then |= PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING where `missing_of`'s snapshot
+ * (pmx_cv_mark_missing; NULL: skip) is set, then the frame of `border` pixels (0: none) = PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER.
+ * base: int64 host, base_rows == 1: one line of W flags for every row (the disparity-range criteria depend on the column only),
+ * base_rows == H: a full map (input masks took part).  Replaces pmx_set_validity for that volume's pmx_wta. */
+int pmx_compose_validity(pmx_ctx* ctx, const int64_t* base, int base_rows, const pmx_cv* missing_of, int border);
 /* WinnerTakesAll.to_disp (disparity/disparity.py:399-516). Results stay on the device. */
 int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
+/* Device-side copies of a result map (which: 0 disparity float32, 1 validity int64, 2 interpolated coefficient float32) as it is
+ * now: the reference deep-copies 2-D results on the host where a later step overwrites them (cv["disp_indices"] =
+ * disp_map["disparity_map"].copy(deep=True), disparity/disparity.py:459); here the copy stays in HBM (queued behind the kernels
+ * that produce the map, nothing waits) and crosses PCIe only if it is read.  NULL on failure. */
+void* pmx_map_snapshot(pmx_ctx* ctx, int which);
+int pmx_map_snapshot_read(pmx_ctx* ctx, const void* snapshot, void* host_out);
+void pmx_map_snapshot_free(pmx_ctx* ctx, void* snapshot);
 /* refinement_cpp.loop_refinement + vfit/quadratic (refinement/cpp/src/refinement.cpp:28-99,
  * vfit.cpp:28-56, quadratic.cpp:28-50) on the device-resident WTA result. */
 int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
@@ -312,6 +332,12 @@ int pmx_risk(pmx_ctx* ctx, pmx_cv* cv, const double* etas, int nbr_etas, const i
  * regularisation of interval_tools.py is host-side work on the two maps and is not part of this library.) */
 int pmx_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float possibility_threshold, float type_factor, const int64_t* grid_min,
                         const int64_t* grid_max, float* interval_inf, float* interval_sup);
+/* Host helpers of the plugin layer (no GPU involved): the O(H*W) passes over the caller's arrays that the reference leaves to
+ * numpy, on a few host threads.  pmx_host_minmax_i64: extrema of an integer disparity grid (np.nanmin / np.nanmax of
+ * matching_cost.py:604-616 on an integer grid).  pmx_host_fingerprint: 64-bit content fingerprint of a buffer - "is this image the
+ * resident one?" (the reference has no residency; any changed word changes the value; not cryptographic). */
+int pmx_host_minmax_i64(const int64_t* a, size_t n, int64_t* out_min, int64_t* out_max);
+uint64_t pmx_host_fingerprint(const void* data, size_t bytes);
 /* Page-locked host memory for the caller's image / result arrays (the reference works in pageable numpy memory; over PCIe a
  * pinned buffer copies at the link rate and without first-touch page faults under the DMA).  NULL on failure. */
 void* pmx_host_alloc(size_t bytes);

@@ -42,6 +42,11 @@ SIGNATURES = {
     "pmx_zncc": (C.c_int, [vp, vp, C.c_int]),
     "pmx_cv_masked": (C.c_int, [vp, vp, C.c_int]),
     "pmx_nan_pixels": (C.c_int, [vp, vp, C.POINTER(C.c_uint8)]),
+    "pmx_host_minmax_i64": (C.c_int, [c_i64_p, C.c_size_t, c_i64_p, c_i64_p]),
+    "pmx_host_fingerprint": (C.c_uint64, [vp, C.c_size_t]),
+    "pmx_cv_mark_missing": (C.c_int, [vp, vp]),
+    "pmx_cv_get_missing": (C.c_int, [vp, vp, C.POINTER(C.c_uint8)]),
+    "pmx_compose_validity": (C.c_int, [vp, c_i64_p, C.c_int, vp, C.c_int]),
     "pmx_reverse_cost_volume": (vp, [vp, vp, C.c_int]),
     "pmx_cbca": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int]),
     "pmx_cross_support": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, c_i16_p]),
@@ -49,6 +54,9 @@ SIGNATURES = {
     "pmx_sgm_p2maps": (C.c_int, [vp, vp, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_int]),
     "pmx_debug_sgm_directions": (C.c_int, [vp, C.c_int]),
     "pmx_set_validity": (C.c_int, [vp, c_i64_p]),
+    "pmx_map_snapshot": (vp, [vp, C.c_int]),
+    "pmx_map_snapshot_read": (C.c_int, [vp, vp, vp]),
+    "pmx_map_snapshot_free": (None, [vp, vp]),
     "pmx_wta": (C.c_int, [vp, vp, C.c_int, C.c_float]),
     "pmx_refine": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "pmx_get_disparity": (C.c_int, [vp, c_float_p, c_i64_p, c_float_p]),

@@ -10,6 +10,88 @@ from . import constants as cst
 from .dataset import DataArray
 
 
+class LazyValidity:
+    """``cv["validity_mask"]`` (criteria.py:66-158) for as long as nobody looks at it.  The machine only ever hands this mask to
+    the disparity step, after mask_invalid_variable_disparity_range and mask_border have updated it; building it (a 4 Mpx int64
+    map is 32 MB), fetching the all-NaN pixels from the GPU to OR them in and uploading the result is host work the device does in
+    one small kernel (pmx_compose_validity).  So the mask is kept as its recipe - the base (one line of flags for every row when no
+    input mask takes part, else the full map) plus the deferred updates - and ``.data`` carries the recipe out on the host, with
+    the same functions as before, the first time anybody reads it; from then on it is a plain array."""
+    dims = ("row", "col")
+
+    def __init__(self, base, shape, coords=None):
+        self._base = base
+        self._shape = tuple(shape)
+        self.coords = dict(coords or {})
+        self._ops = []  # ("missing", device volume) | ("border", offset), in the order they were asked for
+        self._host = None
+
+    @property
+    def pending(self):
+        return self._host is None
+
+    def defer(self, op, arg):
+        self._ops.append((op, arg))
+
+    def recipe(self, engine):
+        """(base, volume whose missing-range snapshot is ORed in | None, border) when the deferred updates are the machine's
+        sequence - at most one of each, in that order, on this engine -, else None (the caller reads ``.data``)."""
+        if self._host is not None:
+            return None
+        ops, dcv, border = list(self._ops), None, 0
+        if ops and ops[0][0] == "missing":
+            dcv = ops.pop(0)[1]
+        if ops and ops[0][0] == "border":
+            border = ops.pop(0)[1]
+        if ops or (dcv is not None and dcv.engine is not engine):
+            return None
+        return self._base, dcv, border
+
+    @property
+    def data(self):
+        if self._host is None:
+            if self._base.shape == self._shape:
+                vm = self._base
+            else:
+                vm = np.empty(self._shape, np.int64)
+                vm[:] = self._base
+            ops, self._ops, self._base, self._host = self._ops, [], None, vm
+            for op, arg in ops:
+                if op == "missing":
+                    _or_missing(vm, arg.engine.get_missing(arg))
+                else:
+                    _frame(vm, arg)
+        return self._host
+
+    @data.setter
+    def data(self, value):
+        self._host, self._base, self._ops = value, None, []
+
+    values = data
+
+    @property
+    def shape(self):
+        return self._shape if self._host is None else self._host.shape
+
+    def sel(self, indexers=None, **kw):
+        return DataArray(self.data, self.dims, self.coords).sel(indexers, **kw)
+
+    def copy(self, deep=True):
+        return DataArray(np.array(self.data, copy=True) if deep else self.data, self.dims, dict(self.coords))
+
+
+def _or_missing(vm, missing):
+    # "+= where the bit is not set yet" (criteria.py:317-322) is an OR
+    np.bitwise_or(vm, cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING, out=vm, where=np.asarray(missing, bool))
+
+
+def _frame(vm, offset):
+    vm[:offset, :] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
+    vm[-offset:, :] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
+    vm[offset:-offset, :offset] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
+    vm[offset:-offset, -offset:] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
+
+
 def _dilate(mask, window_size):
     """scipy.ndimage.binary_dilation(mask, ones((w, w))) (criteria.py:37-62) without scipy."""
     o = window_size // 2
@@ -49,6 +131,10 @@ def validity_mask(img_left, img_right, cv):
         sel = np.where(((col + d_min) < (col[0] + offset)) | (col + d_max > (col[-1]) - offset))
     line[sel[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_INCOMPLETE_DISPARITY_RANGE
     line[bit_1[0]] += cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING
+    coords = {k: cv.coords[k] for k in ("row", "col")}
+    if "msk" not in img_left.data_vars and "msk" not in img_right.data_vars:
+        cv["validity_mask"] = LazyValidity(line, (H, W), coords)  # every row is this line
+        return cv
     vm = np.empty((H, W), np.int64)
     vm[:] = line
     cv["validity_mask"] = DataArray(vm, ("row", "col"))
@@ -58,6 +144,7 @@ def validity_mask(img_left, img_right, cv):
         allocate_right_mask(cv, img_right, bit_1)
         if "disparity" in img_left.data_vars:
             mask_partially_missing_variable_ranges(cv, img_left, img_right)
+    cv["validity_mask"] = LazyValidity(cv["validity_mask"].data, (H, W), coords)  # (the later updates can still be deferred)
     return cv
 
 
@@ -132,25 +219,26 @@ def mask_partially_missing_variable_ranges(cv, img_left, img_right):
 def mask_invalid_variable_disparity_range(cv, missing_disparity_range=None):
     """criteria.py:291-322.  ``missing_disparity_range``: bool (row, col), True where the cost is NaN
     for every disparity; computed on the GPU when the volume is device resident."""
+    arr, lazy = cv.data_vars.get("cost_volume"), cv["validity_mask"]
+    if missing_disparity_range is None and isinstance(lazy, LazyValidity) and lazy.pending and hasattr(arr, "device_cv"):
+        arr.device_cv.engine.mark_missing(arr.device_cv)  # the snapshot is taken now, it joins the mask when the mask is needed
+        lazy.defer("missing", arr.device_cv)
+        return
     if missing_disparity_range is None:
-        arr = cv["cost_volume"]
         if hasattr(arr, "device_cv"):
             missing_disparity_range = arr.device_cv.engine.nan_pixels(arr.device_cv)
         else:
             missing_disparity_range = np.min(np.isnan(arr.data), axis=2)
-    vm = cv["validity_mask"].data
-    # "+= where the bit is not set yet" (criteria.py:317-322) is an OR
-    np.bitwise_or(vm, cst.PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING, out=vm,
-                  where=np.asarray(missing_disparity_range, bool))
+    _or_missing(cv["validity_mask"].data, missing_disparity_range)
 
 
 def mask_border(dataset):
     """criteria.py:325-353"""
     offset = dataset.attrs["offset_row_col"]
-    vm = dataset["validity_mask"].data
+    lazy = dataset["validity_mask"]
     if offset > 0:
-        vm[:offset, :] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
-        vm[-offset:, :] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
-        vm[offset:-offset, :offset] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
-        vm[offset:-offset, -offset:] = cst.PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER
+        if isinstance(lazy, LazyValidity) and lazy.pending:
+            lazy.defer("border", int(offset))
+        else:
+            _frame(lazy.data, offset)
     return dataset["validity_mask"]

@@ -386,6 +386,30 @@ int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out) {
     return PMX_OK;
 }
 
+// ---- the cost volume's validity mask put together on the device (criteria.py:66-158 line + :291-322 + :325-353) -----------
+// validity(r, c) = base (one line for every row, or a full map), | RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING where the volume was
+// NaN for every disparity when pmx_cv_mark_missing looked, then the frame of `border` pixels = LEFT_NODATA_OR_BORDER.
+__global__ __launch_bounds__(kBlock) void compose_validity_kernel(const int64_t* base, int base_rows,  // (base may BE validity)
+                                                                  const uint8_t* __restrict__ missing, int H, int W, int border,
+                                                                  int64_t* validity) {
+    const size_t npix = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+    int64_t v = base_rows == 1 ? base[c] : base[i];
+    if (missing && missing[i]) v |= 2;  // PANDORA_MSK_PIXEL_RIGHT_NODATA_OR_DISPARITY_RANGE_MISSING
+    if (border > 0 && (r < border || r >= H - border || c < border || c >= W - border)) v = 1;  // ..._LEFT_NODATA_OR_BORDER
+    validity[i] = v;
+}
+
+int pmx_launch_compose_validity(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border) {
+    const size_t npix = (size_t)ctx->H * ctx->W;
+    hipLaunchKernelGGL(compose_validity_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, dev_base,
+                       base_rows, dev_missing, ctx->H, ctx->W, border, ctx->validity);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 // ---- reverse_cost_volume (matching_cost.cpp:26-56): out(i, j, d) = in(i, j + d + min_disp, D-1-d) ---------------------
 // An output tile of TC columns x D disparities reads a parallelogram of the input: from input column q it needs the
 // run of (at most TC) consecutive disparities D-1-d, d = q - min_disp - c, c in the tile - contiguous in memory.  The runs go

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include <cstdio>
+#include <thread>
 #include <vector>
 #include <cstdlib>
 
@@ -101,6 +102,9 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     hipFree(ctx->fam_halo);
     hipFree(ctx->fam_ctl);
     if (ctx->fam_err_host) hipHostFree(ctx->fam_err_host);
+    if (ctx->line_host) hipHostFree(ctx->line_host);
+    if (ctx->line_dev) hipFree(ctx->line_dev);
+    if (ctx->line_ev) hipEventDestroy(ctx->line_ev);
     pmx_pool_release(ctx);
     if (getenv("PMX_DEBUG_PTRS")) {
         size_t live = 0;
@@ -152,6 +156,73 @@ extern "C" void* pmx_host_alloc(size_t bytes) {
 
 extern "C" void pmx_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+// ---- host helpers of the plugin layer: the O(H*W) passes over the caller's arrays that the reference does in numpy, spread
+// over a few host threads (a 4 Mpx int64 grid is 32 MB: one core reads it in a millisecond or two, eight in a fraction) ---------
+namespace {
+template <typename F>
+void host_chunks(size_t n, size_t min_chunk, F&& body) {  // body(chunk index, begin, end); chunk count <= 8
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? (hw < 8 ? hw : 8) : 1;
+    if (n / (min_chunk ? min_chunk : 1) < nt) nt = n / (min_chunk ? min_chunk : 1);
+    if (nt <= 1) {
+        body(0, (size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back([&, t] { body(t, t * per < n ? t * per : n, (t + 1) * per < n ? (t + 1) * per : n); });
+    body(0, (size_t)0, per < n ? per : n);
+    for (auto& x : th) x.join();
+}
+constexpr uint64_t kMix = 0x9E3779B97F4A7C15ull;
+}  // namespace
+
+extern "C" int pmx_host_minmax_i64(const int64_t* a, size_t n, int64_t* out_min, int64_t* out_max) {
+    PMX_CHECK(a && n && out_min && out_max, PMX_ERR_ARG, "pmx_host_minmax_i64: empty input or null output");
+    int64_t mn[8], mx[8];
+    for (int i = 0; i < 8; ++i) { mn[i] = INT64_MAX; mx[i] = INT64_MIN; }
+    host_chunks(n, 1u << 17, [&](size_t t, size_t b, size_t e) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (size_t i = b; i < e; ++i) {
+            lo = a[i] < lo ? a[i] : lo;
+            hi = a[i] > hi ? a[i] : hi;
+        }
+        mn[t] = lo;
+        mx[t] = hi;
+    });
+    int64_t lo = mn[0], hi = mx[0];
+    for (int i = 1; i < 8; ++i) { lo = mn[i] < lo ? mn[i] : lo; hi = mx[i] > hi ? mx[i] : hi; }
+    *out_min = lo;
+    *out_max = hi;
+    return PMX_OK;
+}
+
+// Content fingerprint of a buffer (is the array the caller hands over the one that is resident?): eight interleaved lanes of
+// h = (h ^ word) * odd - every step is a bijection of the lane, so changing any one word changes the result for certain, several
+// words with probability 1 - 2^-64.  Not a cryptographic hash.
+extern "C" uint64_t pmx_host_fingerprint(const void* data, size_t bytes) {
+    if (!data || !bytes) return kMix;
+    const uint8_t* p = (const uint8_t*)data;
+    uint64_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t blocks = bytes / 64;
+    host_chunks(blocks, 1u << 14, [&](size_t t, size_t b, size_t e) {
+        uint64_t h[8];
+        for (int l = 0; l < 8; ++l) h[l] = kMix * (uint64_t)(l + 1);
+        for (size_t i = b; i < e; ++i) {
+            uint64_t w[8];
+            memcpy(w, p + i * 64, 64);
+            for (int l = 0; l < 8; ++l) h[l] = (h[l] ^ w[l]) * kMix;
+        }
+        uint64_t acc = 0;
+        for (int l = 0; l < 8; ++l) acc = (acc ^ h[l]) * kMix + (h[l] >> 29);
+        part[t] = acc;
+    });
+    uint64_t acc = bytes;
+    for (int t = 0; t < 8; ++t) acc = (acc ^ part[t]) * kMix + (acc >> 31);
+    for (size_t i = blocks * 64; i < bytes; ++i) acc = (acc ^ p[i]) * kMix;
+    return acc ^ (acc >> 32);
 }
 
 extern "C" void* pmx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -460,6 +531,7 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
         pmx_pool_free(ctx, cv->ldir);
         pmx_pool_free(ctx, cv->cost8);
         pmx_pool_free(ctx, cv->range);
+        pmx_pool_free(ctx, cv->missing);
     } else {
         hipFree(cv->data);
         hipFree(cv->spart);
@@ -646,6 +718,14 @@ extern "C" int pmx_cv_scale_pixels(pmx_ctx* ctx, pmx_cv* cv, const float* weight
     return PMX_OK;
 }
 
+static int launch_missing(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out) {
+    if (cv->repr == PMX_REPR_CENSUS_DEFERRED || cv->repr == PMX_REPR_SGM_U8X8)
+        return pmx_launch_census_nan_pixels(ctx, cv, dev_out);  // NaN pattern = census geometry (x cv_masked's snapshot)
+    int rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
+    if (rc) return rc;
+    return pmx_launch_nan_pixels(ctx, cv, dev_out);
+}
+
 extern "C" int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out) {
     int rc = check_cv(ctx, cv, "pmx_nan_pixels");
     if (rc) return rc;
@@ -653,18 +733,78 @@ extern "C" int pmx_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out)
     size_t n = (size_t)cv->H * cv->W;
     rc = pmx_need_small(ctx, n);
     if (rc) return rc;
-    pmx_cv* mcv = const_cast<pmx_cv*>(cv);
-    if (cv->repr == PMX_REPR_CENSUS_DEFERRED || cv->repr == PMX_REPR_SGM_U8X8) {
-        rc = pmx_launch_census_nan_pixels(ctx, cv, (uint8_t*)ctx->small);  // NaN pattern = census geometry (x cv_masked's snapshot)
-    } else {
-        rc = pmx_cv_materialize(ctx, mcv);
-        if (rc) return rc;
-        rc = pmx_launch_nan_pixels(ctx, cv, (uint8_t*)ctx->small);
-    }
+    rc = launch_missing(ctx, cv, (uint8_t*)ctx->small);
     if (rc) return rc;
     PMX_HIP(hipMemcpyAsync(host_out, ctx->small, n, hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
+}
+
+extern "C" int pmx_cv_mark_missing(pmx_ctx* ctx, pmx_cv* cv) {
+    int rc = check_cv(ctx, cv, "pmx_cv_mark_missing");
+    if (rc) return rc;
+    const size_t n = (size_t)cv->H * cv->W;
+    if (cv->missing_bytes < n) {
+        pmx_pool_free(ctx, cv->missing);
+        cv->missing = nullptr;
+        cv->missing_bytes = 0;
+        cv->has_missing = false;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->missing, n));
+        cv->missing_bytes = n;
+    }
+    rc = launch_missing(ctx, cv, cv->missing);
+    if (rc) return rc;
+    cv->has_missing = true;
+    return PMX_OK;
+}
+
+extern "C" int pmx_cv_get_missing(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out) {
+    int rc = check_cv(ctx, cv, "pmx_cv_get_missing");
+    if (rc) return rc;
+    PMX_CHECK(host_out, PMX_ERR_ARG, "pmx_cv_get_missing: null output");
+    PMX_CHECK(cv->has_missing, PMX_ERR_STATE, "pmx_cv_get_missing: pmx_cv_mark_missing has not been called on this volume");
+    PMX_HIP(hipMemcpyAsync(host_out, cv->missing, (size_t)cv->H * cv->W, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return pmx_check_async_error(ctx, "pmx_cv_get_missing");
+}
+
+extern "C" int pmx_compose_validity(pmx_ctx* ctx, const int64_t* base, int base_rows, const pmx_cv* missing_of, int border) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_compose_validity: call pmx_set_images first");
+    PMX_CHECK(base && (base_rows == 1 || base_rows == ctx->H), PMX_ERR_ARG,
+              "pmx_compose_validity: the base is one line of W flags (base_rows 1) or a full H x W map (base_rows H)");
+    PMX_CHECK(border >= 0, PMX_ERR_ARG, "pmx_compose_validity: negative border");
+    if (missing_of) {
+        int rc = check_cv(ctx, missing_of, "pmx_compose_validity");
+        if (rc) return rc;
+        PMX_CHECK(missing_of->has_missing, PMX_ERR_STATE, "pmx_compose_validity: pmx_cv_mark_missing has not been called on the volume");
+    }
+    PMX_HIP(hipSetDevice(ctx->device));
+    const uint8_t* miss = missing_of ? missing_of->missing : nullptr;
+    if (base_rows == 1) {
+        // the line goes through a pinned buffer: the copy is queued, nothing waits for the kernels in front of it
+        const size_t n = (size_t)ctx->W;
+        if (ctx->line_cap < n) {
+            if (ctx->line_ev) PMX_HIP(hipEventSynchronize(ctx->line_ev));
+            if (ctx->line_host) PMX_HIP(hipHostFree(ctx->line_host));
+            if (ctx->line_dev) PMX_HIP(hipFree(ctx->line_dev));
+            ctx->line_host = ctx->line_dev = nullptr;
+            ctx->line_cap = 0;
+            PMX_HIP(hipHostMalloc((void**)&ctx->line_host, n * sizeof(int64_t), hipHostMallocDefault));
+            PMX_HIP(hipMalloc((void**)&ctx->line_dev, n * sizeof(int64_t)));
+            ctx->line_cap = n;
+        }
+        if (!ctx->line_ev) PMX_HIP(hipEventCreateWithFlags(&ctx->line_ev, hipEventDisableTiming));
+        else PMX_HIP(hipEventSynchronize(ctx->line_ev));  // the previous line has left the buffer (normally long ago)
+        memcpy(ctx->line_host, base, n * sizeof(int64_t));
+        PMX_HIP(hipMemcpyAsync(ctx->line_dev, ctx->line_host, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipEventRecord(ctx->line_ev, ctx->stream));
+        return pmx_launch_compose_validity(ctx, ctx->line_dev, 1, miss, border);
+    }
+    // a full map (input masks took part): uploaded into the validity buffer itself, then finished in place
+    const size_t bytes = (size_t)ctx->H * ctx->W * sizeof(int64_t);
+    PMX_HIP(hipMemcpyAsync(ctx->validity, base, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));  // the caller's buffer is pageable: it may change as soon as we return
+    return pmx_launch_compose_validity(ctx, ctx->validity, ctx->H, miss, border);
 }
 
 extern "C" pmx_cv* pmx_reverse_cost_volume(pmx_ctx* ctx, const pmx_cv* left_cv, int min_disp) {
@@ -823,6 +963,53 @@ extern "C" int pmx_get_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, f
     if (itp) PMX_HIP(hipMemcpyAsync(itp, ctx->itp, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return pmx_check_async_error(ctx, "pmx_get_disparity");
+}
+
+// ---- snapshots of the result maps: a device-side copy that outlives the next step's overwrite and is only brought to the
+// host if somebody reads it (the reference's deep copies of 2-D results, e.g. cv["disp_indices"], disparity.py:459) ------------
+struct pmx_snap {
+    void* dev = nullptr;
+    size_t bytes = 0;
+};
+
+extern "C" void* pmx_map_snapshot(pmx_ctx* ctx, int which) {
+    if (!ctx || !ctx->left || which < 0 || which > 2) {
+        pmx_set_error("pmx_map_snapshot: nothing resident, or unknown map %d (0 disparity, 1 validity, 2 interpolated coefficient)", which);
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    const size_t n = (size_t)ctx->H * ctx->W;
+    const void* src = which == 0 ? (const void*)ctx->disp : which == 1 ? (const void*)ctx->validity : (const void*)ctx->itp;
+    pmx_snap* s = new pmx_snap;
+    s->bytes = n * (which == 1 ? sizeof(int64_t) : sizeof(float));
+    if (pmx_pool_alloc(ctx, &s->dev, s->bytes) != hipSuccess ||
+        hipMemcpyAsync(s->dev, src, s->bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        pmx_set_error("pmx_map_snapshot: no device memory for %zu bytes", s->bytes);
+        pmx_pool_free(ctx, s->dev);
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+extern "C" int pmx_map_snapshot_read(pmx_ctx* ctx, const void* snapshot, void* host_out) {
+    PMX_CHECK(ctx && snapshot && host_out, PMX_ERR_ARG, "pmx_map_snapshot_read: null argument");
+    const pmx_snap* s = (const pmx_snap*)snapshot;
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipMemcpyAsync(host_out, s->dev, s->bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return pmx_check_async_error(ctx, "pmx_map_snapshot_read");
+}
+
+extern "C" void pmx_map_snapshot_free(pmx_ctx* ctx, void* snapshot) {
+    if (!snapshot) return;
+    pmx_snap* s = (pmx_snap*)snapshot;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        pmx_pool_free(ctx, s->dev);
+    }
+    delete s;
 }
 
 extern "C" int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t* validity) {

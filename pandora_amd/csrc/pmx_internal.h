@@ -74,6 +74,11 @@ struct pmx_ctx {
     // generic small scratch (census codes, arms, medians)
     void* small = nullptr;
     size_t small_bytes = 0;
+    // pinned staging of pmx_compose_validity's line (the copy is asynchronous; line_ev says when the buffer is free again)
+    int64_t* line_host = nullptr;
+    int64_t* line_dev = nullptr;
+    size_t line_cap = 0;
+    hipEvent_t line_ev = nullptr;
     bool profiling = false;
     bool lazy = true;
     void* probe_sink = nullptr;   // 64 bytes the placement probe may write to
@@ -147,6 +152,10 @@ struct pmx_cv {
     uint32_t* range = nullptr;
     size_t range_bytes = 0;
     bool has_range = false;
+    // pmx_cv_mark_missing: snapshot of "the cost is NaN for every disparity" per pixel, uint8 [H][W], taken when it was called
+    uint8_t* missing = nullptr;
+    size_t missing_bytes = 0;
+    bool has_missing = false;
     // PMX_REPR_SGM_UP_PENDING: the partial sum volume (kept with the handle for the next pair) and what pmx_sgm was asked for
     float* spart = nullptr;
     size_t spart_bytes = 0;
@@ -265,6 +274,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
 bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, int distance);
 int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
 int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
+int pmx_launch_compose_validity(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border);
 int pmx_launch_reverse(pmx_ctx* ctx, const pmx_cv* in, int min_disp, pmx_cv* out);
 int pmx_launch_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int index_offset, uint64_t* keys);
 int pmx_launch_from_keys(pmx_ctx* ctx, const uint64_t* keys, double d0, int subpix, float invalid_disparity);

@@ -83,7 +83,9 @@ class Dataset:
         return self.data_vars[name]
 
     def __setitem__(self, name, value):
-        if isinstance(value, DataArray) or (hasattr(value, "dims") and hasattr(value, "data")):  # (engine.DeviceMapArray)
+        # (engine.DeviceMapArray, criteria.LazyValidity: asked of the TYPE - hasattr on the instance would run the ``data``
+        #  property, i.e. download the map)
+        if isinstance(value, DataArray) or (hasattr(type(value), "data") and hasattr(value, "dims")):
             self.data_vars[name] = value
         else:
             dims, data = value

@@ -4,6 +4,7 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from ..dataset import DataArray, Dataset
+from ..criteria import LazyValidity
 from ..engine import DeviceMapArray
 from ..matching_cost.matching_cost import ConfigError
 
@@ -132,8 +133,12 @@ class WinnerTakesAll(AbstractDisparity):
         dcv = arr.device_cv
         eng = dcv.engine
         is_max = cv.attrs["type_measure"] == "max"
-        vm = cv["validity_mask"].data if "validity_mask" in cv.data_vars else None
-        eng.set_validity(vm)
+        vm = cv["validity_mask"] if "validity_mask" in cv.data_vars else None
+        recipe = vm.recipe(eng) if isinstance(vm, LazyValidity) else None
+        if recipe is not None:  # nobody has looked at the volume's mask: the device puts it together where the WTA needs it
+            eng.compose_validity(*recipe)
+        else:
+            eng.set_validity(None if vm is None else vm.data)
         eng.wta(dcv, is_max, float(self._invalid_disparity))
         # the maps stay on the GPU until somebody reads them (engine.DeviceMapArray): a refinement step that follows works on them
         # where they are, a filter or the caller gets them with one download into pinned memory

@@ -96,30 +96,57 @@ class DeviceMapArray:
         self.dims, self.coords = tuple(dims), dict(coords or {})
         self._shape = (engine.H, engine.W)
         self._host = None
+        self._snap = None  # device-side copy taken when the engine's maps moved on before anybody read this one
         self._token = engine.maps_token
         engine._lazy_maps.add(self)
 
     def on_device(self):
         """True while nobody has looked at (or replaced) the values and the engine still holds exactly them."""
-        return self._host is None and self._token is self.engine.maps_token
+        return self._host is None and self._snap is None and self._token is self.engine.maps_token
+
+    def detach(self):
+        """The engine's maps are about to change: keep these values in a device-side copy of their own (nothing waits, nothing
+        crosses PCIe unless somebody reads them)."""
+        if self._host is None and self._snap is None:
+            self._snap = self.engine.snapshot(self.which)
+            self.engine._snapshots.add(self)
+
+    def __del__(self):
+        try:
+            if self._snap is not None:
+                self.engine.free_snapshot(self._snap)
+                self._snap = None
+        except Exception:  # interpreter shutdown, engine already closed
+            pass
 
     def rebind(self):
         """The engine's current maps are this variable's new value (the step that produced them updated it in place)."""
         self._host = None
+        self._drop_snapshot()
         self._token = self.engine.maps_token
         self.engine._lazy_maps.add(self)
+
+    def _drop_snapshot(self):
+        if self._snap is not None:
+            self.engine.free_snapshot(self._snap)
+            self._snap = None
 
     @property
     def data(self):
         if self._host is None:
-            if self._token is not self.engine.maps_token:
+            if self._snap is not None:
+                self._host = self.engine.read_snapshot(self._snap, self.which, self._shape)
+                self._drop_snapshot()
+            elif self._token is not self.engine.maps_token:
                 raise RuntimeError("a device-resident map outlived its values (engine bookkeeping error)")
-            self._host = self.engine.fetch_map(self.which)
+            else:
+                self._host = self.engine.fetch_map(self.which)
         return self._host
 
     @data.setter
     def data(self, value):
         self._host = value
+        self._drop_snapshot()
 
     values = data
 
@@ -158,11 +185,14 @@ class Engine:
         # read yet are downloaded before the maps change (new_maps), unless the step declares them superseded
         self.maps_token = object()
         self._lazy_maps = weakref.WeakSet()
+        self._snapshots = weakref.WeakSet()  # DeviceMapArrays living in a device-side copy of their own
 
     def close(self):
         if self.ctx:
-            try:
-                self.new_maps()  # results nobody has read yet must survive the context
+            try:  # results nobody has read yet must survive the context
+                for lazy in list(self._lazy_maps) + list(self._snapshots):
+                    if lazy._host is None and (lazy._snap is not None or lazy._token is self.maps_token):
+                        lazy.data  # noqa: B018  (downloads)
             except Exception:
                 pass
             _lib.lib().pmx_destroy(self.ctx)
@@ -180,6 +210,7 @@ class Engine:
         right = np.ascontiguousarray(right, np.float32)
         if left.ndim != 2 or left.shape != right.shape:
             raise ValueError("left/right must be 2-D arrays of the same shape")
+        self.new_maps()  # result maps of the previous pair that nobody has read yet keep their values
         self.H, self.W = left.shape
         self.subpix = int(subpix)
         check(_lib.lib().pmx_set_images(self.ctx, _p(left, C.c_float), _p(right, C.c_float), self.H, self.W, self.subpix),
@@ -243,6 +274,26 @@ class Engine:
         check(_lib.lib().pmx_nan_pixels(self.ctx, cv.handle, _p(out, C.c_uint8)), "pmx_nan_pixels")
         return out.astype(bool)
 
+    def mark_missing(self, cv):
+        """Snapshot, kept on the device with the volume, of the pixels whose cost is NaN for every disparity NOW (pmx_cv_mark_missing)."""
+        check(_lib.lib().pmx_cv_mark_missing(self.ctx, cv.handle), "pmx_cv_mark_missing")
+
+    def get_missing(self, cv):
+        out = np.empty((self.H, self.W), np.uint8)
+        check(_lib.lib().pmx_cv_get_missing(self.ctx, cv.handle, _p(out, C.c_uint8)), "pmx_cv_get_missing")
+        return out.astype(bool)
+
+    def compose_validity(self, base, missing_of=None, border=0):
+        """The validity mask the next WTA starts from, put together on the device (pmx_compose_validity): ``base`` int64 (W,) - one
+        line for every row - or (H, W); ``missing_of``: volume whose mark_missing snapshot sets the missing-range bit; ``border``:
+        width of the frame that becomes PANDORA_MSK_PIXEL_LEFT_NODATA_OR_BORDER."""
+        self.new_maps()
+        b = np.ascontiguousarray(base, np.int64)
+        if b.shape not in ((self.W,), (self.H, self.W)):
+            raise ValueError(f"compose_validity: base {b.shape} is neither ({self.W},) nor ({self.H}, {self.W})")
+        check(_lib.lib().pmx_compose_validity(self.ctx, _p(b, C.c_int64), 1 if b.ndim == 1 else self.H,
+                                              None if missing_of is None else missing_of.handle, int(border)), "pmx_compose_validity")
+
     def reverse_cost_volume(self, cv, min_disp):
         h = _lib.lib().pmx_reverse_cost_volume(self.ctx, cv.handle, int(min_disp))
         if not h:
@@ -279,13 +330,29 @@ class Engine:
                                         int(bool(overcounting))), "pmx_sgm_p2maps")
 
     def new_maps(self, superseded=()):
-        """Call BEFORE an operation that overwrites the device-resident result maps: pending DeviceMapArrays get their values
-        (one download each) unless they are in `superseded` (the operation updates exactly those variables in place)."""
+        """Call BEFORE an operation that overwrites the device-resident result maps: pending DeviceMapArrays move into a
+        device-side copy of their own (DeviceMapArray.detach) unless they are in `superseded` (the operation updates exactly those
+        variables in place)."""
         for lazy in list(self._lazy_maps):
             if lazy._host is None and lazy._token is self.maps_token and not any(lazy is s for s in superseded):
-                lazy.data  # noqa: B018  (downloads)
+                lazy.detach()
         self._lazy_maps.clear()
         self.maps_token = object()
+
+    def snapshot(self, which):
+        h = _lib.lib().pmx_map_snapshot(self.ctx, {"disp": 0, "validity": 1, "itp": 2}[which])
+        if not h:
+            raise PmxError("pmx_map_snapshot failed: " + _lib.lib().pmx_last_error().decode())
+        return h
+
+    def read_snapshot(self, snap, which, shape):
+        out = pinned_empty(shape, np.int64 if which == "validity" else np.float32)
+        check(_lib.lib().pmx_map_snapshot_read(self.ctx, snap, out.ctypes.data), "pmx_map_snapshot_read")
+        return out
+
+    def free_snapshot(self, snap):
+        if self.ctx:
+            _lib.lib().pmx_map_snapshot_free(self.ctx, snap)
 
     def fetch_map(self, which):
         """One of the device-resident result maps into pinned host memory."""

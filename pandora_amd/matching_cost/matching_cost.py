@@ -18,6 +18,21 @@ class ConfigError(ValueError):
     """Raised where the reference's json_checker schema would reject a configuration."""
 
 
+def grid_extrema(grid):
+    """(min, max) of an integer disparity grid; int64 C-contiguous grids (what create_dataset_from_inputs makes of a [min, max]
+    list) in one pass on a few host threads (pmx_host_minmax_i64), anything else with numpy."""
+    if grid.dtype == np.int64 and grid.flags["C_CONTIGUOUS"] and grid.size:
+        import ctypes as C
+
+        from .. import _lib
+
+        lo, hi = C.c_int64(), C.c_int64()
+        rc = _lib.lib().pmx_host_minmax_i64(grid.ctypes.data_as(_lib.c_i64_p), grid.size, C.byref(lo), C.byref(hi))
+        if rc == 0:
+            return lo.value, hi.value
+    return int(grid.min()), int(grid.max())
+
+
 class AbstractMatchingCost:
     __metaclass__ = ABCMeta
 
@@ -109,6 +124,8 @@ class AbstractMatchingCost:
     # -- geometry (matching_cost.py:330-427, 604-616) ------------------------------------------
     @staticmethod
     def get_min_max_from_grid(disp_min, disp_max):
+        if disp_min.dtype == np.int64 and disp_max.dtype == np.int64 and disp_min.size and disp_max.size:
+            return grid_extrema(disp_min)[0], grid_extrema(disp_max)[1]  # (integers hold no NaN)
         return int(np.nanmin(disp_min)), int(np.nanmax(disp_max))
 
     @staticmethod
@@ -167,6 +184,7 @@ class AbstractMatchingCost:
         self.check_band_input_mc(img_left, img_right)
         eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band, spline_order=self._spline_order)
         dcv = eng.alloc_cv(cost_volume.attrs["_D"], cost_volume.attrs["_d0"])
+        cost_volume.attrs["_pair_token"] = runtime.resident_token(eng)
         cost_volume.data_vars["cost_volume"] = DeviceVolumeArray(dcv, {k: cost_volume.coords[k] for k in ("row", "col", "disp")})
         return eng, dcv
 
@@ -196,7 +214,7 @@ class AbstractMatchingCost:
     def cv_masked(self, img_left, img_right, cost_volume, disp_min, disp_max):
         """In place: NaN for invalid / (dilated) no-data pixels and for disparities outside the
         per-pixel [disp_min, disp_max]; then the validity-mask updates of criteria.py:291-353."""
-        eng = runtime.ensure_pair(img_left, img_right, self._subpix, band=self._band, spline_order=self._spline_order)
+        eng = runtime.pair_engine(cost_volume, img_left, img_right, self._subpix, band=self._band, spline_order=self._spline_order)
         dcv = cost_volume["cost_volume"].device_cv
         for side in (img_left, img_right):
             if "msk" in side.data_vars and (side.attrs.get("valid_pixels", 0) != img_left.attrs.get("valid_pixels", 0)
@@ -210,7 +228,7 @@ class AbstractMatchingCost:
         # constant grids that cover the whole volume need no per-pixel range test on the device; integer grids (the usual
         # case) cannot hold NaN, so plain min / max do
         if disp_min.dtype.kind in "iu" and disp_max.dtype.kind in "iu":
-            lo0, lo1, hi0, hi1 = disp_min.min(), disp_min.max(), disp_max.min(), disp_max.max()
+            (lo0, lo1), (hi0, hi1) = grid_extrema(disp_min), grid_extrema(disp_max)
             uniform = lo0 == lo1 and hi0 == hi1 and lo0 <= coords[0] and hi0 >= coords[-1]
         else:
             uniform = (np.nanmin(disp_min) == np.nanmax(disp_min) and np.nanmin(disp_max) == np.nanmax(disp_max)

@@ -5,11 +5,7 @@ import os
 
 import numpy as np
 
-try:  # ~15 GB/s: a 4 Mpx float32 image in a millisecond
-    from xxhash import xxh3_64_intdigest as _digest
-except ImportError:  # CRC-32 is ten times slower but always there
-    from zlib import crc32 as _digest
-
+from . import _lib
 from .engine import Engine
 
 _ENGINES = {}
@@ -28,11 +24,11 @@ def get_engine(device=None):
 
 
 def _sample(a):
-    """Content fingerprint of the WHOLE buffer (XXH3, about a millisecond per 4 Mpx image): an array edited in place between
-    two runs - any pixel of it - is uploaded again.  (A strided sample misses edits: with power-of-two widths a stride
-    divides the width and only a comb of columns is ever looked at.)"""
+    """Content fingerprint of the WHOLE buffer (pmx_host_fingerprint: a few host threads, well under a millisecond per 4 Mpx
+    image): an array edited in place between two runs - any pixel of it - is uploaded again.  (A strided sample misses edits:
+    with power-of-two widths a stride divides the width and only a comb of columns is ever looked at.)"""
     a = np.ascontiguousarray(a)
-    return _digest(memoryview(a).cast("B"))
+    return int(_lib.lib().pmx_host_fingerprint(a.ctypes.data, a.nbytes))
 
 
 def _key(img_left, img_right, subpix, band, spline_order=1):
@@ -89,6 +85,33 @@ def ensure_pair(img_left, img_right, subpix, device=None, band=None, spline_orde
         eng.set_disparity_grids(None, None)
         _RESIDENT[eng.device] = (key, _holders(img_left, img_right))
     return eng
+
+
+def pair_engine(cost_volume, img_left, img_right, subpix, band=None, spline_order=1):
+    """The engine for a step that works on a volume ALREADY computed from this pair and reads, besides the volume, the input MASKS
+    only (cv_masked): when the pair the volume was computed from is still the resident one - same image arrays, masks unchanged -
+    the images are not fingerprinted again.  Anything else goes through ensure_pair."""
+    var = cost_volume.data_vars.get("cost_volume")
+    token = cost_volume.attrs.get("_pair_token")
+    dcv = getattr(var, "device_cv", None)
+    if dcv is not None and token is not None:
+        res = _RESIDENT.get(dcv.engine.device)
+        if res is not None and res[0] is token:
+            same = True
+            for ds, ident in ((img_left, token[0]), (img_right, token[1])):
+                msk = ds["msk"].data if "msk" in ds.data_vars else None
+                same &= id(ds["im"].data) == ident[0] and ((msk is None) == (ident[3] is None))
+                if same and msk is not None:
+                    same &= (id(msk), _sample(msk)) == ident[3]
+            if same and (int(subpix), img_left.attrs.get("valid_pixels", 0), img_left.attrs.get("no_data_mask", 1), band) == (
+                    token[2], token[3], token[4], token[5]):
+                return dcv.engine
+    return ensure_pair(img_left, img_right, subpix, band=band, spline_order=spline_order)
+
+
+def resident_token(eng):
+    """What identifies the pair resident on ``eng`` right now (kept with a volume computed from it: pair_engine)."""
+    return _RESIDENT.get(eng.device, (None,))[0]
 
 
 def invalidate(device=None):

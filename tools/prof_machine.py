@@ -37,3 +37,4 @@ pr.enable()
 once()
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+pstats.Stats(pr).sort_stats("cumtime").print_stats(45)
