@@ -48,6 +48,10 @@ int pmx_sync(pmx_ctx* ctx);
  * (img_tools.py:713-752 shift_right_img, linear interpolation in double).  Replaces the numpy
  * image hand-off of every compute_cost_volume (e.g. matching_cost/census.py:113-133). */
 int pmx_set_images(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix);
+/* pmx_set_images that also returns pmx_host_fingerprint of the two images, taken in the pass that copies them to the
+ * staging buffer (a caller that keeps track of which pair is resident reads every image once instead of twice). */
+int pmx_set_images_fingerprinted(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix,
+                                 uint64_t* fp_left, uint64_t* fp_right);
 
 /* Replace the k-th shifted right image (k = 1 .. subpix-1, float32 [H][W-1]) that pmx_set_images built with linear interpolation:
  * matching_cost's "spline_order" 2..5 resamples with scipy.ndimage.zoom(order=...) on the host (img_tools.py:713-752; 2-D work) and

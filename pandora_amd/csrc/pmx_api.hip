@@ -103,6 +103,7 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     hipFree(ctx->fam_ctl);
     if (ctx->fam_err_host) hipHostFree(ctx->fam_err_host);
     if (ctx->line_host) hipHostFree(ctx->line_host);
+    if (ctx->stage_host) hipHostFree(ctx->stage_host);
     if (ctx->line_dev) hipFree(ctx->line_dev);
     if (ctx->line_ev) hipEventDestroy(ctx->line_ev);
     pmx_pool_release(ctx);
@@ -161,10 +162,14 @@ extern "C" void pmx_host_free(void* p) {
 // ---- host helpers of the plugin layer: the O(H*W) passes over the caller's arrays that the reference does in numpy, spread
 // over a few host threads (a 4 Mpx int64 grid is 32 MB: one core reads it in a millisecond or two, eight in a fraction) ---------
 namespace {
+constexpr int kHostThreads = 8;  // (a 32 MB scan stops gaining at 8 on the MI355X hosts; every thread costs ~20 us to start)
 template <typename F>
-void host_chunks(size_t n, size_t min_chunk, F&& body) {  // body(chunk index, begin, end); chunk count <= 8
+void host_chunks(size_t n, size_t min_chunk, F&& body) {  // body(chunk index, begin, end); chunk count <= kHostThreads
     unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = hw ? (hw < 8 ? hw : 8) : 1;
+    static const int cap = getenv("PMX_HOST_THREADS") ? atoi(getenv("PMX_HOST_THREADS")) : kHostThreads;
+    size_t nt = hw ? (hw < (unsigned)cap ? hw : cap) : 1;
+    if (nt > (size_t)kHostThreads) nt = kHostThreads;
+    if (nt < 1) nt = 1;
     if (n / (min_chunk ? min_chunk : 1) < nt) nt = n / (min_chunk ? min_chunk : 1);
     if (nt <= 1) {
         body(0, (size_t)0, n);
@@ -181,8 +186,8 @@ constexpr uint64_t kMix = 0x9E3779B97F4A7C15ull;
 
 extern "C" int pmx_host_minmax_i64(const int64_t* a, size_t n, int64_t* out_min, int64_t* out_max) {
     PMX_CHECK(a && n && out_min && out_max, PMX_ERR_ARG, "pmx_host_minmax_i64: empty input or null output");
-    int64_t mn[8], mx[8];
-    for (int i = 0; i < 8; ++i) { mn[i] = INT64_MAX; mx[i] = INT64_MIN; }
+    int64_t mn[kHostThreads], mx[kHostThreads];
+    for (int i = 0; i < kHostThreads; ++i) { mn[i] = INT64_MAX; mx[i] = INT64_MIN; }
     host_chunks(n, 1u << 17, [&](size_t t, size_t b, size_t e) {
         int64_t lo = INT64_MAX, hi = INT64_MIN;
         for (size_t i = b; i < e; ++i) {
@@ -193,7 +198,7 @@ extern "C" int pmx_host_minmax_i64(const int64_t* a, size_t n, int64_t* out_min,
         mx[t] = hi;
     });
     int64_t lo = mn[0], hi = mx[0];
-    for (int i = 1; i < 8; ++i) { lo = mn[i] < lo ? mn[i] : lo; hi = mx[i] > hi ? mx[i] : hi; }
+    for (int i = 1; i < kHostThreads; ++i) { lo = mn[i] < lo ? mn[i] : lo; hi = mx[i] > hi ? mx[i] : hi; }
     *out_min = lo;
     *out_max = hi;
     return PMX_OK;
@@ -202,10 +207,11 @@ extern "C" int pmx_host_minmax_i64(const int64_t* a, size_t n, int64_t* out_min,
 // Content fingerprint of a buffer (is the array the caller hands over the one that is resident?): eight interleaved lanes of
 // h = (h ^ word) * odd - every step is a bijection of the lane, so changing any one word changes the result for certain, several
 // words with probability 1 - 2^-64.  Not a cryptographic hash.
-extern "C" uint64_t pmx_host_fingerprint(const void* data, size_t bytes) {
+static uint64_t fingerprint_copy(void* dst, const void* data, size_t bytes) {  // dst: optional copy made in the same pass
     if (!data || !bytes) return kMix;
     const uint8_t* p = (const uint8_t*)data;
-    uint64_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint8_t* q = (uint8_t*)dst;
+    uint64_t part[kHostThreads] = {};
     const size_t blocks = bytes / 64;
     host_chunks(blocks, 1u << 14, [&](size_t t, size_t b, size_t e) {
         uint64_t h[8];
@@ -213,6 +219,7 @@ extern "C" uint64_t pmx_host_fingerprint(const void* data, size_t bytes) {
         for (size_t i = b; i < e; ++i) {
             uint64_t w[8];
             memcpy(w, p + i * 64, 64);
+            if (q) memcpy(q + i * 64, w, 64);
             for (int l = 0; l < 8; ++l) h[l] = (h[l] ^ w[l]) * kMix;
         }
         uint64_t acc = 0;
@@ -220,10 +227,17 @@ extern "C" uint64_t pmx_host_fingerprint(const void* data, size_t bytes) {
         part[t] = acc;
     });
     uint64_t acc = bytes;
-    for (int t = 0; t < 8; ++t) acc = (acc ^ part[t]) * kMix + (acc >> 31);
-    for (size_t i = blocks * 64; i < bytes; ++i) acc = (acc ^ p[i]) * kMix;
+    // (the value depends on how the buffer was cut into chunks, i.e. on the thread count - constant within a process, and
+    //  fingerprints are only ever compared within one)
+    for (int t = 0; t < kHostThreads; ++t) acc = (acc ^ part[t]) * kMix + (acc >> 31);
+    for (size_t i = blocks * 64; i < bytes; ++i) {
+        if (q) q[i] = p[i];
+        acc = (acc ^ p[i]) * kMix;
+    }
     return acc ^ (acc >> 32);
 }
+
+extern "C" uint64_t pmx_host_fingerprint(const void* data, size_t bytes) { return fingerprint_copy(nullptr, data, bytes); }
 
 extern "C" void* pmx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -375,6 +389,11 @@ int pmx_need_small(pmx_ctx* ctx, size_t bytes) {
 }
 
 extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix) {
+    return pmx_set_images_fingerprinted(ctx, left, right, H, W, subpix, nullptr, nullptr);
+}
+
+extern "C" int pmx_set_images_fingerprinted(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix,
+                                            uint64_t* fp_left, uint64_t* fp_right) {
     PMX_CHECK(ctx && left && right, PMX_ERR_ARG, "pmx_set_images: null argument");
     PMX_CHECK(H > 0 && W > 1, PMX_ERR_ARG, "pmx_set_images: bad shape %dx%d", H, W);
     PMX_CHECK(subpix == 1 || subpix == 2 || subpix == 4, PMX_ERR_ARG,
@@ -399,15 +418,50 @@ extern "C" int pmx_set_images(pmx_ctx* ctx, const float* left, const float* righ
     }
     ctx->near_owner = nullptr;
     ctx->disp_ready = false;
-    PMX_HIP(hipMemcpyAsync(ctx->left, left, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    PMX_HIP(hipMemcpyAsync(ctx->right[0], right, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // The caller's arrays are pageable.  Pairs up to kStageMax bytes go through a pinned staging buffer: a few host threads copy
+    // them in (faster than the runtime's own single-threaded staging), the DMA is queued and the call returns - the transfer
+    // overlaps whatever the host does next (the machine: sizing the cost volume from the disparity grids).
+    constexpr size_t kStageMax = 256u << 20;
+    const size_t img_bytes = n * sizeof(float);
+    const bool staged = 2 * img_bytes <= kStageMax;
+    if (staged) {
+        if (ctx->stage_cap < 2 * img_bytes) {
+            if (ctx->stage_host) PMX_HIP(hipHostFree(ctx->stage_host));
+            ctx->stage_host = nullptr;
+            ctx->stage_cap = 0;
+            PMX_HIP(hipHostMalloc((void**)&ctx->stage_host, 2 * img_bytes, hipHostMallocDefault));
+            ctx->stage_cap = 2 * img_bytes;
+        }
+        // (the stream was drained above: the previous pair's transfer has left the buffer)
+        if (fp_left || fp_right) {  // the fingerprints of pmx_host_fingerprint, taken while the images are copied
+            const uint64_t fl = fingerprint_copy(ctx->stage_host, left, img_bytes);
+            const uint64_t fr = fingerprint_copy(ctx->stage_host + img_bytes, right, img_bytes);
+            if (fp_left) *fp_left = fl;
+            if (fp_right) *fp_right = fr;
+        } else {
+            host_chunks(2 * img_bytes, 1u << 20, [&](size_t, size_t b, size_t e) {
+                if (b < img_bytes) memcpy(ctx->stage_host + b, (const char*)left + b, (e < img_bytes ? e : img_bytes) - b);
+                if (e > img_bytes) {
+                    const size_t b2 = b > img_bytes ? b : img_bytes;
+                    memcpy(ctx->stage_host + b2, (const char*)right + (b2 - img_bytes), e - b2);
+                }
+            });
+        }
+        PMX_HIP(hipMemcpyAsync(ctx->left, ctx->stage_host, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(ctx->right[0], ctx->stage_host + img_bytes, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        if (fp_left) *fp_left = fingerprint_copy(nullptr, left, img_bytes);
+        if (fp_right) *fp_right = fingerprint_copy(nullptr, right, img_bytes);
+        PMX_HIP(hipMemcpyAsync(ctx->left, left, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(ctx->right[0], right, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     for (int k = 1; k < subpix; ++k) {
         int rc = pmx_launch_shift_right(ctx, ctx->right[0], H, W, subpix, k, ctx->right[k]);
         if (rc) return rc;
     }
     PMX_HIP(hipMemsetAsync(ctx->near, 0xff, n * 16, ctx->stream));
     PMX_HIP(hipMemsetAsync(ctx->validity, 0, n * sizeof(int64_t), ctx->stream));
-    PMX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
+    if (!staged) PMX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
     return PMX_OK;
 }
 
@@ -425,6 +479,12 @@ extern "C" int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_
                              int nodata_value) {
     PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_set_masks: call pmx_set_images first");
     PMX_HIP(hipSetDevice(ctx->device));
+    if (!msk_left && !msk_right && !ctx->msk_left && !ctx->msk_right) {  // no masks before, none now: nothing to wait for
+        ctx->bad_win = 0;
+        ctx->valid_value = valid_value;
+        ctx->nodata_value = nodata_value;
+        return PMX_OK;
+    }
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     size_t n = (size_t)ctx->H * ctx->W;
     hipFree(ctx->msk_left); ctx->msk_left = nullptr;
@@ -468,6 +528,7 @@ extern "C" int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, con
     PMX_CHECK((disp_min == nullptr) == (disp_max == nullptr), PMX_ERR_ARG,
               "pmx_set_disparity_grids: give both grids or neither");
     PMX_HIP(hipSetDevice(ctx->device));
+    if (!disp_min && !ctx->grid_min && !ctx->grid_max) return PMX_OK;  // no grids before, none now: nothing to wait for
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     hipFree(ctx->grid_min); ctx->grid_min = nullptr;
     hipFree(ctx->grid_max); ctx->grid_max = nullptr;

@@ -74,6 +74,9 @@ struct pmx_ctx {
     // generic small scratch (census codes, arms, medians)
     void* small = nullptr;
     size_t small_bytes = 0;
+    // pinned staging of pmx_set_images (both images of a pair)
+    char* stage_host = nullptr;
+    size_t stage_cap = 0;
     // pinned staging of pmx_compose_validity's line (the copy is asynchronous; line_ev says when the buffer is free again)
     int64_t* line_host = nullptr;
     int64_t* line_dev = nullptr;

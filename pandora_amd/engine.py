@@ -206,6 +206,8 @@ class Engine:
 
     # -- residency ---------------------------------------------------------------------------
     def set_images(self, left, right, subpix=1):
+        """Upload the pair; returns the content fingerprints (pmx_host_fingerprint) of the two float32 arrays, taken in the same
+        pass over them."""
         left = np.ascontiguousarray(left, np.float32)
         right = np.ascontiguousarray(right, np.float32)
         if left.ndim != 2 or left.shape != right.shape:
@@ -213,8 +215,10 @@ class Engine:
         self.new_maps()  # result maps of the previous pair that nobody has read yet keep their values
         self.H, self.W = left.shape
         self.subpix = int(subpix)
-        check(_lib.lib().pmx_set_images(self.ctx, _p(left, C.c_float), _p(right, C.c_float), self.H, self.W, self.subpix),
-              "pmx_set_images")
+        fl, fr = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().pmx_set_images_fingerprinted(self.ctx, _p(left, C.c_float), _p(right, C.c_float), self.H, self.W, self.subpix,
+                                                      C.byref(fl), C.byref(fr)), "pmx_set_images")
+        return fl.value, fr.value  # pmx_host_fingerprint of the two arrays as uploaded
 
     def set_shifted_right(self, k, img):
         """the k-th shifted right image resampled on the host (spline_order > 1): float32 (H, W - 1)"""

@@ -31,14 +31,24 @@ def _sample(a):
     return int(_lib.lib().pmx_host_fingerprint(a.ctypes.data, a.nbytes))
 
 
-def _key(img_left, img_right, subpix, band, spline_order=1):
-    def ident(ds):
+def _key(img_left, img_right, subpix, band, spline_order=1, fingerprints=None):
+    """What identifies a resident pair: the arrays (id, shape, content fingerprint) of images and masks plus the parameters the
+    device-side copies depend on.  ``fingerprints``: (left, right) image fingerprints already known (Engine.set_images)."""
+    def ident(ds, fp):
         im = ds["im"].data
         msk = ds["msk"].data if "msk" in ds.data_vars else None
-        return (id(im), im.shape, _sample(im), None if msk is None else (id(msk), _sample(msk)))
+        return (id(im), im.shape, _sample(im) if fp is None else fp, None if msk is None else (id(msk), _sample(msk)))
 
-    return (ident(img_left), ident(img_right), int(subpix), img_left.attrs.get("valid_pixels", 0),
+    fl, fr = fingerprints or (None, None)
+    return (ident(img_left, fl), ident(img_right, fr), int(subpix), img_left.attrs.get("valid_pixels", 0),
             img_left.attrs.get("no_data_mask", 1), band, int(spline_order) if subpix > 1 else 1)
+
+
+def _fingerprint_is_of_the_image(ds, band):
+    """True when what goes to the device is the dataset's array itself (2-D float32 C-contiguous): then the fingerprint
+    Engine.set_images takes of the uploaded array is the fingerprint _sample would take of ds["im"].data."""
+    im = ds["im"].data
+    return isinstance(im, np.ndarray) and im.ndim == 2 and im.dtype == np.float32 and im.flags["C_CONTIGUOUS"]
 
 
 def _holders(img_left, img_right):
@@ -71,10 +81,17 @@ def ensure_pair(img_left, img_right, subpix, device=None, band=None, spline_orde
     builds the sub-pixel shifted right images by linear interpolation (= zoom order 1, exactly); a higher ``spline_order`` is
     resampled with scipy on the host and uploaded."""
     eng = get_engine(device)
-    key = _key(img_left, img_right, subpix, band, spline_order)
-    if _RESIDENT.get(eng.device, (None,))[0] != key:
+    res = _RESIDENT.get(eng.device)
+    # other arrays than the resident pair's: an upload for certain - the images are fingerprinted in the pass that stages them
+    fresh = (res is None or (res[0][0][0], res[0][1][0]) != (id(img_left["im"].data), id(img_right["im"].data))) and \
+        _fingerprint_is_of_the_image(img_left, band) and _fingerprint_is_of_the_image(img_right, band)
+    key = None if fresh else _key(img_left, img_right, subpix, band, spline_order)
+    if fresh or res is None or res[0] != key:
+        _RESIDENT.pop(eng.device, None)  # (an upload that fails half-way leaves nothing that could be taken for resident)
         right = np.asarray(select_band(img_right, band), np.float32)
-        eng.set_images(np.asarray(select_band(img_left, band), np.float32), right, subpix)
+        fps = eng.set_images(np.asarray(select_band(img_left, band), np.float32), right, subpix)
+        if fresh:
+            key = _key(img_left, img_right, subpix, band, spline_order, fingerprints=fps)
         if subpix > 1 and int(spline_order) != 1:
             for k, shifted in enumerate(shifted_right_images(right, subpix, int(spline_order)), start=1):
                 eng.set_shifted_right(k, shifted)

@@ -168,6 +168,10 @@ class PandoraMachine:
     # -- run callbacks (state_machine.py:292-490) ----------------------------------------------
     def matching_cost_prepare(self, cfg, input_step):
         self.matching_cost_ = matching_cost.AbstractMatchingCost(**cfg["pipeline"][input_step])
+        self.matching_cost_.prefetch(self.left_img, self.right_img)  # the images travel while the grids are scanned
+        # matching_cost_prepare and matching_cost_run are the two callbacks of ONE trigger: no user code runs between them, the
+        # disparity grids cannot change, one scan of each serves both the sizing of the volume and cv_masked
+        self.matching_cost_._grid_memo = {}
         if self.scale_factor != 1:  # (a 4 M-pixel grid times one is 8 ms of host time for nothing)
             self.disp_min = self.disp_min * self.scale_factor
             self.disp_max = self.disp_max * self.scale_factor
@@ -186,11 +190,14 @@ class PandoraMachine:
 
     def matching_cost_run(self, _, __):
         logging.info("Matching cost computation...")
-        self.left_cv = self.matching_cost_.compute_cost_volume(self.left_img, self.right_img, self.left_cv)
-        self.matching_cost_.cv_masked(self.left_img, self.right_img, self.left_cv, self.disp_min, self.disp_max)
-        if self.right_disp_map == "cross_checking_accurate":
-            self.right_cv = self.matching_cost_.compute_cost_volume(self.right_img, self.left_img, self.right_cv)
-            self.matching_cost_.cv_masked(self.right_img, self.left_img, self.right_cv, self.right_disp_min, self.right_disp_max)
+        try:
+            self.left_cv = self.matching_cost_.compute_cost_volume(self.left_img, self.right_img, self.left_cv)
+            self.matching_cost_.cv_masked(self.left_img, self.right_img, self.left_cv, self.disp_min, self.disp_max)
+            if self.right_disp_map == "cross_checking_accurate":
+                self.right_cv = self.matching_cost_.compute_cost_volume(self.right_img, self.left_img, self.right_cv)
+                self.matching_cost_.cv_masked(self.right_img, self.left_img, self.right_cv, self.right_disp_min, self.right_disp_max)
+        finally:
+            self.matching_cost_._grid_memo = None
 
     def aggregation_run(self, cfg, input_step):
         logging.info("Aggregation computation...")

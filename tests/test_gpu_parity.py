@@ -1222,3 +1222,76 @@ def test_cbca_on_one_cropped_column(eng, oracle, sp):
     np.testing.assert_array_equal(got, exp)
     assert not np.array_equal(got, before, equal_nan=True)
     cv.free()
+
+
+def test_validity_put_together_on_the_device(eng):
+    """pmx_cv_mark_missing / pmx_compose_validity against the host functions they replace (criteria.py:291-353): the snapshot of
+    the all-NaN pixels is the volume's state WHEN IT WAS TAKEN, a line base is broadcast over the rows, a full base is taken as
+    it is, the frame overrides everything."""
+    from pandora_amd import criteria
+
+    rng = np.random.default_rng(77)
+    H, W, D = 37, 53, 9
+    L, R = pair(H, W, 5)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(D, -4)
+    vol = rng.random((H, W, D)).astype(np.float32)
+    gone = rng.random((H, W)) < 0.2
+    vol[gone] = np.nan
+    vol[rng.random((H, W, D)) < 0.3] = np.nan
+    cv.from_host(vol)
+    missing = np.isnan(vol).all(axis=2)
+    eng.mark_missing(cv)
+    np.testing.assert_array_equal(eng.nan_pixels(cv), missing)
+    vol2 = vol.copy()
+    vol2[:5] = np.nan
+    cv.from_host(vol2)  # the volume moves on, the snapshot does not
+    np.testing.assert_array_equal(eng.get_missing(cv), missing)
+    assert eng.nan_pixels(cv)[:5].all()
+    for border in (0, 1, 3, 19, 40):
+        for full in (False, True):
+            base = rng.integers(0, 1 << 12, (H, W) if full else (W,)).astype(np.int64)
+            for use_missing in (False, True):
+                eng.compose_validity(base, cv if use_missing else None, border)
+                want = np.empty((H, W), np.int64)
+                want[:] = base
+                if use_missing:
+                    criteria._or_missing(want, missing)
+                if border:
+                    criteria._frame(want, border)
+                got = eng.get_disparity()[1]
+                np.testing.assert_array_equal(got, want, err_msg=f"border {border} full {full} missing {use_missing}")
+    with pytest.raises(Exception, match="mark_missing"):
+        eng.compose_validity(np.zeros(W, np.int64), eng.alloc_cv(D, 0), 0)
+    with pytest.raises(ValueError):
+        eng.compose_validity(np.zeros(W + 1, np.int64), None, 0)
+
+
+def test_result_maps_survive_on_the_device_until_read(eng):
+    """engine.DeviceMapArray: maps nobody has read move into a device-side snapshot (pmx_map_snapshot) when the next WTA, the next
+    refinement or the next PAIR overwrites the engine's maps; reading them later gives the values of their own time."""
+    from pandora_amd.engine import DeviceMapArray
+
+    L, R = pair(40, 64, 9)
+    want = {}
+    lazies = {}
+    for tag, (a, b, shape) in {"first": (L, R, (40, 64)), "second": (R[:30, :50].copy(), L[:30, :50].copy(), (30, 50))}.items():
+        eng.set_images(a, b, 1)
+        cv = eng.alloc_cv(7, -3)
+        eng.census(cv, 5)
+        eng.set_validity(None)
+        eng.wta(cv, False, -9999.0)
+        lazies[tag] = (DeviceMapArray(eng, "disp"), DeviceMapArray(eng, "validity"))
+        assert lazies[tag][0].on_device() and lazies[tag][0].shape == shape
+        eng.refine(cv, "vfit", False)  # overwrites disp / validity: the two lazies above are not superseded -> snapshots
+        assert not lazies[tag][0].on_device() and lazies[tag][0]._snap is not None and lazies[tag][0]._host is None
+        lazies[tag + " refined"] = (DeviceMapArray(eng, "disp"), DeviceMapArray(eng, "itp"))
+        eng.set_validity(None)  # (the refinement left its flags in the engine's mask)
+        eng.wta(cv, False, -9999.0)
+        want[tag] = [x.copy() for x in eng.get_disparity()[:2]]
+        eng.refine(cv, "vfit", False)
+        want[tag + " refined"] = [eng.get_disparity(want_itp=True)[i].copy() for i in (0, 2)]
+    for tag, (x, y) in lazies.items():  # read long after: both pairs are gone from the engine's maps
+        np.testing.assert_array_equal(x.data, want[tag][0], err_msg=tag)
+        np.testing.assert_array_equal(y.data, want[tag][1], err_msg=tag)
+        assert x._snap is None and x.data is x.data

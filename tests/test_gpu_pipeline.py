@@ -509,3 +509,34 @@ def test_spline_order_resamples_the_right_image_like_the_reference(oracle, metho
         np.testing.assert_array_equal(got, exp)
     machine, _ = run_machine(L, R, {"pipeline": pipe}, dmin, dmax)  # order 1 through the machine: a different volume
     assert not np.array_equal(np.nan_to_num(got), np.nan_to_num(machine.left_cv["cost_volume"].data))
+
+
+def test_machine_keeps_its_maps_on_the_device_until_they_are_read():
+    """A PandoraMachine run of census + SGM + WTA + vfit never brings a full-size map to the host by itself: the volume's validity
+    mask stays a recipe (criteria.LazyValidity) that the device carries out (pmx_compose_validity), the result maps are
+    engine.DeviceMapArrays still on the GPU when run() returns; reading them - and the volume's mask, afterwards - gives what the
+    eager host path gives (the oracle composition checks of this file cover the values)."""
+    import pandora_amd
+    from pandora_amd import criteria
+    from pandora_amd.engine import DeviceMapArray
+    from pandora_amd.state_machine import PandoraMachine
+
+    L, R = pair(60, 90, 3)
+    left, right = make_image(L, disparity=[-9, 2]), make_image(R)
+    machine = PandoraMachine()
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                        "optimization": {"optimization_method": "sgm", "penalty": {"P1": 8, "P2": 32}},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                        "refinement": {"refinement_method": "vfit"}}}
+    cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+    out, _ = pandora_amd.run(machine, left, right, cfg)
+    lazy = machine.left_cv["validity_mask"]
+    assert isinstance(lazy, criteria.LazyValidity) and lazy.pending
+    for k in ("disparity_map", "validity_mask", "interpolated_coeff"):
+        assert isinstance(out[k], DeviceMapArray) and out[k].on_device(), k
+    vm = np.array(out["validity_mask"].data)
+    # the volume's own mask, materialised on the host now (snapshot of the all-NaN pixels taken at cv_masked time), is the
+    # result's mask minus what WTA / refinement added
+    np.testing.assert_array_equal(lazy.data & 0b111, vm & 0b111)
+    assert (lazy.data[:2] == 1).all() and (lazy.data[:, -2:] == 1).all() and not lazy.pending
+    assert np.isfinite(out["disparity_map"].data[10:-10, 20:-10]).all()

@@ -708,3 +708,59 @@ def test_sgm_penalty_configuration_like_the_plugin():
     np.testing.assert_array_equal(maps[2][1:], np.float32(60.0 - 0.5 * 15))    # (+1,0): 15 between rows
     s = Sgm(optimization_method="sgm", penalty={"p2_method": "inverseGradient", "P1": 4, "P2": 20, "alpha": 8.0, "beta": 1, "gamma": 2})
     np.testing.assert_array_equal(s.p2_maps(img)[1][:, :-1], np.float32(20.0))  # 8 / (3 + 1) + 2 = 4 < P2: the floor
+
+
+def test_host_helpers_of_the_library():
+    """pmx_host_minmax_i64 / pmx_host_fingerprint (threaded host passes, no GPU): extrema equal numpy's on sizes that do not
+    divide into the chunks; the fingerprint is stable, sees any single byte - tail bytes included - and an empty buffer."""
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 131071, 131072, 1 << 20, (1 << 21) + 13):
+        a = rng.integers(-2**40, 2**40, n).astype(np.int64)
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        assert L.pmx_host_minmax_i64(a.ctypes.data_as(_lib.c_i64_p), n, ctypes.byref(lo), ctypes.byref(hi)) == 0
+        assert (lo.value, hi.value) == (a.min(), a.max())
+    lo = ctypes.c_int64()
+    assert L.pmx_host_minmax_i64(None, 0, ctypes.byref(lo), ctypes.byref(lo)) != 0  # refused, not a crash
+    from pandora_amd.matching_cost.matching_cost import grid_extrema
+    g = rng.integers(-60, 5, (300, 401))
+    assert grid_extrema(g) == (g.min(), g.max()) and grid_extrema(g[:, ::2]) == (g[:, ::2].min(), g[:, ::2].max())
+    assert grid_extrema(g.astype(np.int32)) == (g.min(), g.max())
+    memo = {}
+    assert grid_extrema(g, memo) == grid_extrema(g, memo) == (g.min(), g.max()) and len(memo) == 1
+    for nbytes in (0, 1, 63, 64, 65, (1 << 20) + 5, (1 << 24) + 77):
+        b = rng.integers(0, 256, nbytes).astype(np.uint8)
+        h = L.pmx_host_fingerprint(b.ctypes.data, nbytes)
+        assert h == L.pmx_host_fingerprint(b.ctypes.data, nbytes)
+        for pos in {0, nbytes // 2, nbytes - 1} if nbytes else ():
+            b[pos] ^= 0x10
+            assert L.pmx_host_fingerprint(b.ctypes.data, nbytes) != h, (nbytes, pos)
+            b[pos] ^= 0x10
+
+
+def test_validity_mask_is_a_recipe_until_somebody_reads_it():
+    """criteria.validity_mask without input masks gives a LazyValidity (one line of flags for every row); reading ``.data``
+    carries the recipe out on the host - same values as the eager construction - and later in-place updates then work on the
+    array like before; with masks the base is the full map."""
+    left, right = make_image(np.zeros((6, 9), np.float32), disparity=[-3, 1]), make_image(np.zeros((6, 9), np.float32))
+    mc = matching_cost.AbstractMatchingCost(matching_cost_method="census", window_size=3)
+    cv = criteria.validity_mask(left, right, mc.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min").data,
+                                                                              left["disparity"].sel(band_disp="max").data)))
+    lazy = cv["validity_mask"]
+    assert isinstance(lazy, criteria.LazyValidity) and lazy.pending and lazy.shape == (6, 9) and cv.sizes["row"] == 6
+    line = np.array(lazy._base)
+    criteria.mask_border(cv)  # deferred
+    assert lazy.pending and lazy.recipe(None) is not None and lazy.recipe(None)[1:] == (None, 1)
+    want = np.tile(line, (6, 1))
+    want[0], want[-1], want[:, 0], want[:, -1] = 1, 1, 1, 1
+    np.testing.assert_array_equal(lazy.data, want)
+    assert not lazy.pending and lazy.recipe(None) is None and lazy.data.dtype == np.int64
+    criteria.mask_invalid_variable_disparity_range(cv, np.eye(6, 9, dtype=bool))  # now on the array
+    assert (cv["validity_mask"].data[2, 2] & 2) and cv["validity_mask"].data is lazy.data
+    msk = np.zeros((6, 9), np.int16)
+    msk[2, 4] = 1
+    cvm = criteria.validity_mask(make_image(np.zeros((6, 9), np.float32), disparity=[-3, 1], msk=msk), right,
+                                 mc.allocate_cost_volume(left, (left["disparity"].sel(band_disp="min").data,
+                                                                left["disparity"].sel(band_disp="max").data)))
+    assert isinstance(cvm["validity_mask"], criteria.LazyValidity) and cvm["validity_mask"]._base.shape == (6, 9)
+    assert cvm["validity_mask"].data[2, 4] & 1

@@ -30,32 +30,56 @@ CFGS = {
                                     "filter.this_time_after_validation": {"filter_method": "median", "filter_size": 3}},
 }
 out = {"shape": [H, W, dmax - dmin + 1]}
+MAPS = ("disparity_map", "validity_mask", "interpolated_coeff")
+
+
+def read_maps(machine):
+    """the caller reads its maps: device-resident maps come down now"""
+    for side in (machine.left_disparity, machine.right_disparity):
+        if side is not None and len(side.sizes):
+            for k in MAPS:
+                if k in side.data_vars:
+                    side[k].data
+
+
+alive = []  # (freeing the previous pair's 100 MB of arrays is the caller's business, not the run's)
 for name, pipe in CFGS.items():
     best = None
-    for rep in range(3):
+    for rep in range(4):
         left, right = make_image(L, disparity=[dmin, dmax]), make_image(R, disparity=[-dmax, -dmin])
+        alive.append((left, right))
         machine = PandoraMachine()
         cfg = {"pipeline": json.loads(json.dumps(pipe))}
         cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
         runtime.get_engine().sync()
+        # (a) the run as a caller sees it: run the steps, read the maps - nothing waits for the GPU in between
         t0 = time.perf_counter()
-        steps = {}
         machine.run_prepare(cfg, left, right)
         for step in list(cfg["pipeline"]):
-            t = time.perf_counter()
             machine.run(step, cfg)
-            runtime.get_engine().sync()
-            steps[step] = round((time.perf_counter() - t) * 1e3, 2)
         machine.run_exit()
-        t = time.perf_counter()
-        for side in (machine.left_disparity, machine.right_disparity):  # the caller reads its maps: lazy device maps come down now
-            if side is not None and len(side.sizes):
-                for k in ("disparity_map", "validity_mask", "interpolated_coeff"):
-                    if k in side.data_vars:
-                        side[k].data
-        steps["(reading the result maps)"] = round((time.perf_counter() - t) * 1e3, 2)
-        total = (time.perf_counter() - t0) * 1e3
+        t1 = time.perf_counter()
+        read_maps(machine)
+        total, host = (time.perf_counter() - t0) * 1e3, (t1 - t0) * 1e3
         if best is None or total < best[0]:
-            best = (total, steps)
-    out[name] = {"total_ms": round(best[0], 2), "steps_ms": best[1]}
+            best = [total, host]
+    # (b) where the time goes: the same run with a device synchronisation after every step (this serialises host and GPU, the
+    #     steps add up to more than (a))
+    left, right = make_image(L, disparity=[dmin, dmax]), make_image(R, disparity=[-dmax, -dmin])
+    machine = PandoraMachine()
+    cfg = {"pipeline": json.loads(json.dumps(pipe))}
+    cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+    runtime.get_engine().sync()
+    steps = {}
+    machine.run_prepare(cfg, left, right)
+    for step in list(cfg["pipeline"]):
+        t = time.perf_counter()
+        machine.run(step, cfg)
+        runtime.get_engine().sync()
+        steps[step] = round((time.perf_counter() - t) * 1e3, 2)
+    machine.run_exit()
+    t = time.perf_counter()
+    read_maps(machine)
+    steps["(reading the result maps)"] = round((time.perf_counter() - t) * 1e3, 2)
+    out[name] = {"total_ms": round(best[0], 2), "host_ms_before_reading_the_maps": round(best[1], 2), "steps_ms_synchronised": steps}
 print(json.dumps(out, indent=1))
