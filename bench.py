@@ -141,6 +141,22 @@ def pmc_traffic(H, W, D):
     return None
 
 
+def pcie_inclusive_ms(eng, cv, L, R, win, P1, P2, reps=3):
+    """Host images in (pmx_set_images: staged through pinned memory, transfer queued), the pipeline, the three 2-D result maps
+    out into pinned host arrays (pmx_get_disparity): one step as a caller streaming pairs pays it; best of `reps`."""
+    host_out = eng.get_disparity(want_itp=True)  # (also faults the host pages in once, as a streaming caller would)
+    best = None
+    for _ in range(reps):
+        eng.sync()
+        t1 = time.perf_counter()
+        eng.set_images(L, R, 1)
+        run_pipeline(eng, cv, win, P1, P2)
+        eng.get_disparity(want_itp=True, out=host_out)
+        dt = (time.perf_counter() - t1) * 1e3
+        best = dt if best is None or dt < best else best
+    return best
+
+
 def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed):
     """One pair on one GPU through the whole protocol; returns (ms per step, stage times, (L, R))."""
     L, R = synthetic_pair(H, W, dmin, dmax, seed=seed)
@@ -158,6 +174,7 @@ def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed):
     ms = (time.perf_counter() - t0) / steps * 1e3
     stage = {name: eng.stage_time(name) for name in STAGES}
     eng.set_profiling(False)
+    stage["(pcie inclusive)"] = (pcie_inclusive_ms(eng, cv, L, R, 5, 8.0, 32.0), 1)
     cv.free()
     return ms, stage, (L, R)
 
@@ -266,19 +283,14 @@ def main():
                                  "ms_per_step": round(stage["collective"][0] / args.steps, 4), "bytes_per_step": H * W * 10}
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
-            host_out = eng.get_disparity(want_itp=True)  # (also faults the host pages in once, as a streaming caller would)
-            eng.sync()
-            t1 = time.perf_counter()
-            eng.set_images(L, R, 1)
-            run_pipeline(eng, cv, win, P1, P2)
-            eng.get_disparity(want_itp=True, out=host_out)
-            pcie_s = time.perf_counter() - t1
+            pcie_s = pcie_inclusive_ms(eng, cv, L, R, win, P1, P2) * 1e-3
             out["pcie_inclusive"] = {"ms_per_step": round(pcie_s * 1e3, 3), "value": round(cells / pcie_s / 1e6, 1), "unit": "Mdisp/s",
                                      "note": "pmx_set_images (2 float32 images up) + pipeline + pmx_get_disparity (disp, validity "
                                              "int64, itp down); informational only"}
             cv.free()
             if not args.no_c3 and (H, W, D) != (2048, 2048, 129):
                 ms3, st3, _ = measure_shape(eng, 2048, 2048, 0, 128, args.steps, args.warmup, 20260928)
+                pcie3 = st3.pop("(pcie inclusive)")[0]
                 c3 = 2048 * 2048 * 129
                 r3 = roofline_block(st3, args.steps, c3)
                 if st3["sgm_fused"][1] > 0:
@@ -287,7 +299,8 @@ def main():
                                                "pipeline and protocol", "steps": args.steps, "ms_per_step": round(ms3, 3),
                                    "value": round(c3 / ms3 / 1e3, 1), "unit": "Mdisp/s", "roofline": r3,
                                    "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in st3.items()},
-                                   "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                   "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "pcie_inclusive_ms": round(pcie3, 3)}
             if args.cpu_rows > 0:  # the CPU legs belong to the N=1 line only
                 rows = min(args.cpu_rows, H)
                 base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)

@@ -433,22 +433,13 @@ extern "C" int pmx_set_images_fingerprinted(pmx_ctx* ctx, const float* left, con
             ctx->stage_cap = 2 * img_bytes;
         }
         // (the stream was drained above: the previous pair's transfer has left the buffer)
-        if (fp_left || fp_right) {  // the fingerprints of pmx_host_fingerprint, taken while the images are copied
-            const uint64_t fl = fingerprint_copy(ctx->stage_host, left, img_bytes);
-            const uint64_t fr = fingerprint_copy(ctx->stage_host + img_bytes, right, img_bytes);
-            if (fp_left) *fp_left = fl;
-            if (fp_right) *fp_right = fr;
-        } else {
-            host_chunks(2 * img_bytes, 1u << 20, [&](size_t, size_t b, size_t e) {
-                if (b < img_bytes) memcpy(ctx->stage_host + b, (const char*)left + b, (e < img_bytes ? e : img_bytes) - b);
-                if (e > img_bytes) {
-                    const size_t b2 = b > img_bytes ? b : img_bytes;
-                    memcpy(ctx->stage_host + b2, (const char*)right + (b2 - img_bytes), e - b2);
-                }
-            });
-        }
+        // left image staged -> its transfer is queued and runs while the right image is staged
+        const uint64_t fl = fingerprint_copy(ctx->stage_host, left, img_bytes);  // (pmx_host_fingerprint, taken in the copying pass)
         PMX_HIP(hipMemcpyAsync(ctx->left, ctx->stage_host, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+        const uint64_t fr = fingerprint_copy(ctx->stage_host + img_bytes, right, img_bytes);
         PMX_HIP(hipMemcpyAsync(ctx->right[0], ctx->stage_host + img_bytes, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (fp_left) *fp_left = fl;
+        if (fp_right) *fp_right = fr;
     } else {
         if (fp_left) *fp_left = fingerprint_copy(nullptr, left, img_bytes);
         if (fp_right) *fp_right = fingerprint_copy(nullptr, right, img_bytes);
