@@ -28,7 +28,9 @@ def oracle_pipeline(oracle, L, R, cfg, dmin, dmax, mskL=None, mskR=None, validit
     elif method in ("sad", "ssd"):
         cv, is_max = oracle.sad_ssd(L, R, D, dmin, sp, win, method == "ssd"), False
         a, b = abs(L.max() - R.min()), abs(R.max() - L.min())
-        cmax = int(max(a, b) * win * win) if method == "sad" else int(max(a ** 2, b ** 2) * win * win)
+        # (sad_ssd.py:132-137's own expression: in float32 x * (w ** 2) and x * w * w round differently, and after CBCA's
+        #  scaling cmax + 1 - SGM's cost of an invalid cell - then differs by a float32 step of 16: fuzz seed 21870)
+        cmax = int(max(a, b) * (win ** 2)) if method == "sad" else int(max(a ** 2, b ** 2) * (win ** 2))
     else:
         cv, is_max, cmax = oracle.zncc(L, R, D, dmin, sp, win), True, 1
     if mskL is not None or mskR is not None:
