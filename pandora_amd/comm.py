@@ -57,33 +57,64 @@ class Rendezvous:
         self.peers = []  # rank 0: sockets of ranks 1..world-1 (index = rank - 1); others: [socket to rank 0]
         if world == 1:
             return
+        # the port may be taken by somebody else's service: rank 0 listens at the first free one of a short list of candidates,
+        # the others try the candidates in turn and only stay where the greeting is answered by this run's rank 0
+        ports = [port + k * 97 for k in range(8)]
+        greeting = b"PMX-RDV1" + struct.pack("<I", world)
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+            srv = None
+            for cand in ports:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, cand))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise OSError(f"rendezvous: none of the ports {ports} at {addr} is free")
             srv.listen(world)
             srv.settimeout(timeout)
             by_rank = {}
             while len(by_rank) < world - 1:
                 conn, _ = srv.accept()
+                conn.settimeout(timeout)
+                try:
+                    hello = _recv_exact(conn, len(greeting) + 4)
+                except (OSError, ConnectionError):
+                    conn.close()
+                    continue
+                if hello[:len(greeting)] != greeting:  # not one of ours
+                    conn.close()
+                    continue
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                conn.sendall(greeting)
+                (r,) = struct.unpack("<I", hello[len(greeting):])
                 by_rank[r] = conn
             srv.close()
             self.peers = [by_rank[r] for r in range(1, world)]
         else:
             deadline = time.time() + timeout
-            while True:
-                try:
-                    s = socket.create_connection((addr, port), timeout=5.0)
-                    break
-                except OSError:
+            s = None
+            while s is None:
+                for cand in ports:
+                    try:
+                        c = socket.create_connection((addr, cand), timeout=5.0)
+                        c.settimeout(5.0)
+                        c.sendall(greeting + struct.pack("<I", rank))
+                        if _recv_exact(c, len(greeting)) == greeting:
+                            s = c
+                            break
+                        c.close()
+                    except (OSError, ConnectionError):
+                        pass
+                if s is None:
                     if time.time() > deadline:
-                        raise
+                        raise TimeoutError(f"rendezvous: rank 0 did not answer at {addr}, ports {ports}")
                     time.sleep(0.05)
             s.settimeout(timeout)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            s.sendall(struct.pack("<I", rank))
             self.peers = [s]
 
     def broadcast(self, payload=None):

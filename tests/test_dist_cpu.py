@@ -149,3 +149,56 @@ def test_tcp_rendezvous_world3(oracle):
     assert uid == bytes(range(128)) and tmax == 3.0 and rows == [b"\x00" * 2, b"\x01" * 3, b"\x02" * 4]
     edisp, _ = oracle.wta(cv, -20, 1, False, -9999.0)
     np.testing.assert_array_equal(disp, edisp)
+
+
+def _rdv_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from pandora_amd.comm import Rendezvous
+
+    rdv = Rendezvous(rank, world, "127.0.0.1", port, timeout=60.0)
+    got = rdv.broadcast(b"the id" if rank == 0 else None)
+    rdv.barrier()
+    q.put((rank, got))
+    rdv.close()
+
+
+def test_rendezvous_steps_past_a_port_somebody_else_holds():
+    """The port one above the launcher's may belong to another service: rank 0 listens at the next free candidate, the other
+    ranks recognise this run's rank 0 by its greeting (a foreign listener that accepts and stays silent - or talks - is skipped)."""
+    import multiprocessing as mp
+    import threading
+
+    foreign = socket.socket()
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    foreign.bind(("127.0.0.1", 0))
+    port = foreign.getsockname()[1]
+    foreign.listen(8)
+    stop = threading.Event()
+
+    def babble():  # accepts, says something that is not the greeting, hangs up
+        foreign.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+                c.sendall(b"HTTP/1.1 400 Bad Request\r\n\r\n")
+                c.close()
+            except OSError:
+                pass
+
+    t = threading.Thread(target=babble, daemon=True)
+    t.start()
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rdv_worker, args=(r, 3, port, q)) for r in range(3)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=120) for _ in range(3))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert got == [(0, b"the id"), (1, b"the id"), (2, b"the id")]
+    finally:
+        stop.set()
+        t.join()
+        foreign.close()
