@@ -161,8 +161,24 @@ int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity)
  * disp_map["disparity_map"].copy(deep=True), disparity/disparity.py:459); here the copy stays in HBM (queued behind the kernels
  * that produce the map, nothing waits) and crosses PCIe only if it is read.  NULL on failure. */
 void* pmx_map_snapshot(pmx_ctx* ctx, int which);
+/* An uninitialised snapshot of the same kind: the output of a step that works on snapshots. */
+void* pmx_map_snapshot_alloc(pmx_ctx* ctx, int which);
 int pmx_map_snapshot_read(pmx_ctx* ctx, const void* snapshot, void* host_out);
 void pmx_map_snapshot_free(pmx_ctx* ctx, void* snapshot);
+/* Steps on snapshots - maps that stay in HBM from the WTA to the last filter (the reference hands numpy arrays from step to step;
+ * the host-pointer forms of these steps, further down, are the same kernels between an upload and a download):
+ *   pmx_maps_restore         the engine's disparity / validity maps become what two snapshots hold, e.g. the LEFT maps again after
+ *                            the right side's WTA (state_machine.py:449-490 runs left and right through every step in turn);
+ *   pmx_median_filter_maps   MedianFilter.filter_disparity (filter/median.py:94-131), out != in;
+ *   pmx_cross_checking_maps  CrossChecking.disparity_checking (validation/validation.py:226-371): the left validity snapshot is
+ *                            updated in place, the left-right distance goes to a float32 snapshot;
+ *   pmx_validity_frame_map   criteria.mask_border (criteria.py:325-353) on a validity snapshot. */
+int pmx_maps_restore(pmx_ctx* ctx, const void* disp_snapshot, const void* validity_snapshot);
+int pmx_median_filter_maps(pmx_ctx* ctx, const void* disp_snapshot, const void* validity_snapshot, int filter_size,
+                           void* out_disp_snapshot);
+int pmx_cross_checking_maps(pmx_ctx* ctx, const void* disp_left, void* validity_left, const void* disp_right, int dmin, int dmax,
+                            double threshold, void* conf_out);
+int pmx_validity_frame_map(pmx_ctx* ctx, void* validity_snapshot, int border);
 /* refinement_cpp.loop_refinement + vfit/quadratic (refinement/cpp/src/refinement.cpp:28-99,
  * vfit.cpp:28-56, quadratic.cpp:28-50) on the device-resident WTA result. */
 int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);

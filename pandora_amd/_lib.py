@@ -57,6 +57,11 @@ SIGNATURES = {
     "pmx_debug_sgm_directions": (C.c_int, [vp, C.c_int]),
     "pmx_set_validity": (C.c_int, [vp, c_i64_p]),
     "pmx_map_snapshot": (vp, [vp, C.c_int]),
+    "pmx_map_snapshot_alloc": (vp, [vp, C.c_int]),
+    "pmx_maps_restore": (C.c_int, [vp, vp, vp]),
+    "pmx_median_filter_maps": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "pmx_cross_checking_maps": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, vp]),
+    "pmx_validity_frame_map": (C.c_int, [vp, vp, C.c_int]),
     "pmx_map_snapshot_read": (C.c_int, [vp, vp, vp]),
     "pmx_map_snapshot_free": (None, [vp, vp]),
     "pmx_wta": (C.c_int, [vp, vp, C.c_int, C.c_float]),

@@ -402,12 +402,17 @@ __global__ __launch_bounds__(kBlock) void compose_validity_kernel(const int64_t*
     validity[i] = v;
 }
 
-int pmx_launch_compose_validity(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border) {
+int pmx_launch_compose_validity_into(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border,
+                                     int64_t* dev_out) {
     const size_t npix = (size_t)ctx->H * ctx->W;
     hipLaunchKernelGGL(compose_validity_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, dev_base,
-                       base_rows, dev_missing, ctx->H, ctx->W, border, ctx->validity);
+                       base_rows, dev_missing, ctx->H, ctx->W, border, dev_out);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
+}
+
+int pmx_launch_compose_validity(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border) {
+    return pmx_launch_compose_validity_into(ctx, dev_base, base_rows, dev_missing, border, ctx->validity);
 }
 
 // ---- reverse_cost_volume (matching_cost.cpp:26-56): out(i, j, d) = in(i, j + d + min_disp, D-1-d) ---------------------

@@ -105,7 +105,8 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     if (ctx->line_host) hipHostFree(ctx->line_host);
     if (ctx->stage_host) hipHostFree(ctx->stage_host);
     if (ctx->line_dev) hipFree(ctx->line_dev);
-    if (ctx->line_ev) hipEventDestroy(ctx->line_ev);
+    for (hipEvent_t e : ctx->line_ev)
+        if (e) hipEventDestroy(e);
     pmx_pool_release(ctx);
     if (getenv("PMX_DEBUG_PTRS")) {
         size_t live = 0;
@@ -835,22 +836,28 @@ extern "C" int pmx_compose_validity(pmx_ctx* ctx, const int64_t* base, int base_
     if (base_rows == 1) {
         // the line goes through a pinned buffer: the copy is queued, nothing waits for the kernels in front of it
         const size_t n = (size_t)ctx->W;
+        constexpr int kSlots = pmx_ctx::kLineSlots;
         if (ctx->line_cap < n) {
-            if (ctx->line_ev) PMX_HIP(hipEventSynchronize(ctx->line_ev));
+            PMX_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->line_host) PMX_HIP(hipHostFree(ctx->line_host));
             if (ctx->line_dev) PMX_HIP(hipFree(ctx->line_dev));
             ctx->line_host = ctx->line_dev = nullptr;
             ctx->line_cap = 0;
-            PMX_HIP(hipHostMalloc((void**)&ctx->line_host, n * sizeof(int64_t), hipHostMallocDefault));
-            PMX_HIP(hipMalloc((void**)&ctx->line_dev, n * sizeof(int64_t)));
+            PMX_HIP(hipHostMalloc((void**)&ctx->line_host, kSlots * n * sizeof(int64_t), hipHostMallocDefault));
+            PMX_HIP(hipMalloc((void**)&ctx->line_dev, kSlots * n * sizeof(int64_t)));
             ctx->line_cap = n;
         }
-        if (!ctx->line_ev) PMX_HIP(hipEventCreateWithFlags(&ctx->line_ev, hipEventDisableTiming));
-        else PMX_HIP(hipEventSynchronize(ctx->line_ev));  // the previous line has left the buffer (normally long ago)
-        memcpy(ctx->line_host, base, n * sizeof(int64_t));
-        PMX_HIP(hipMemcpyAsync(ctx->line_dev, ctx->line_host, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-        PMX_HIP(hipEventRecord(ctx->line_ev, ctx->stream));
-        return pmx_launch_compose_validity(ctx, ctx->line_dev, 1, miss, border);
+        const int slot = ctx->line_next;
+        ctx->line_next = (slot + 1) % kSlots;
+        if (!ctx->line_ev[slot]) PMX_HIP(hipEventCreateWithFlags(&ctx->line_ev[slot], hipEventDisableTiming));
+        else PMX_HIP(hipEventSynchronize(ctx->line_ev[slot]));  // this slot's previous line was used kSlots calls ago
+        int64_t* hl = ctx->line_host + (size_t)slot * ctx->line_cap;
+        int64_t* dl = ctx->line_dev + (size_t)slot * ctx->line_cap;
+        memcpy(hl, base, n * sizeof(int64_t));
+        PMX_HIP(hipMemcpyAsync(dl, hl, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        int rc = pmx_launch_compose_validity(ctx, dl, 1, miss, border);
+        PMX_HIP(hipEventRecord(ctx->line_ev[slot], ctx->stream));  // (behind the kernel that reads the device line)
+        return rc;
     }
     // a full map (input masks took part): uploaded into the validity buffer itself, then finished in place
     const size_t bytes = (size_t)ctx->H * ctx->W * sizeof(int64_t);
@@ -1043,6 +1050,82 @@ extern "C" void* pmx_map_snapshot(pmx_ctx* ctx, int which) {
         return nullptr;
     }
     return s;
+}
+
+extern "C" void* pmx_map_snapshot_alloc(pmx_ctx* ctx, int which) {  // uninitialised: the output of a step that works on snapshots
+    if (!ctx || !ctx->left || which < 0 || which > 2) {
+        pmx_set_error("pmx_map_snapshot_alloc: nothing resident, or unknown map %d", which);
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    pmx_snap* s = new pmx_snap;
+    s->bytes = (size_t)ctx->H * ctx->W * (which == 1 ? sizeof(int64_t) : sizeof(float));
+    if (pmx_pool_alloc(ctx, &s->dev, s->bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        pmx_set_error("pmx_map_snapshot_alloc: no device memory for %zu bytes", s->bytes);
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+static int check_snap(pmx_ctx* ctx, const void* snapshot, size_t elem, const char* who, const char* what) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "%s: nothing resident", who);
+    PMX_CHECK(snapshot, PMX_ERR_ARG, "%s: null %s", who, what);
+    PMX_CHECK(((const pmx_snap*)snapshot)->bytes == (size_t)ctx->H * ctx->W * elem, PMX_ERR_ARG,
+              "%s: %s is not a %zu-byte-per-pixel map of the resident %dx%d pair", who, what, elem, ctx->H, ctx->W);
+    return PMX_OK;
+}
+#define PMX_SNAP(p) (((const pmx_snap*)(p))->dev)
+
+// The engine's disparity / validity maps become what two snapshots hold (device-to-device): the step that follows (pmx_refine,
+// pmx_get_disparity ...) works on them as if the WTA had just produced them.
+extern "C" int pmx_maps_restore(pmx_ctx* ctx, const void* disp_snapshot, const void* validity_snapshot) {
+    if (int rc = check_snap(ctx, disp_snapshot, sizeof(float), "pmx_maps_restore", "disparity snapshot")) return rc;
+    if (int rc = check_snap(ctx, validity_snapshot, sizeof(int64_t), "pmx_maps_restore", "validity snapshot")) return rc;
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->H * ctx->W;
+    PMX_HIP(hipMemcpyAsync(ctx->disp, PMX_SNAP(disp_snapshot), n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(ctx->validity, PMX_SNAP(validity_snapshot), n * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->disp_ready = true;
+    ctx->near_exact = false;  // the winner cache of a fused WTA describes the LAST WTA's map, not this one
+    return PMX_OK;
+}
+
+// median.py:94-131 / validation.py:226-371 / criteria.py:325-353 on snapshots: nothing crosses PCIe, nothing waits
+extern "C" int pmx_median_filter_maps(pmx_ctx* ctx, const void* disp_snapshot, const void* validity_snapshot, int filter_size,
+                                      void* out_disp_snapshot) {
+    if (int rc = check_snap(ctx, disp_snapshot, sizeof(float), "pmx_median_filter_maps", "disparity snapshot")) return rc;
+    if (int rc = check_snap(ctx, validity_snapshot, sizeof(int64_t), "pmx_median_filter_maps", "validity snapshot")) return rc;
+    if (int rc = check_snap(ctx, out_disp_snapshot, sizeof(float), "pmx_median_filter_maps", "output snapshot")) return rc;
+    PMX_CHECK(out_disp_snapshot != disp_snapshot, PMX_ERR_ARG, "pmx_median_filter_maps: the filter does not work in place");
+    PMX_CHECK(filter_size >= 1 && (filter_size & 1) && filter_size <= 15, PMX_ERR_ARG,
+              "pmx_median_filter_maps: filter_size must be odd, >= 1 (median.py:86) and <= 15, got %d", filter_size);
+    PMX_CHECK(filter_size <= ctx->H && filter_size <= ctx->W, PMX_ERR_ARG, "pmx_median_filter_maps: filter_size %d exceeds the %dx%d map",
+              filter_size, ctx->H, ctx->W);
+    PMX_HIP(hipSetDevice(ctx->device));
+    return pmx_launch_median_disparity(ctx, (const float*)PMX_SNAP(disp_snapshot), (const int64_t*)PMX_SNAP(validity_snapshot), ctx->H,
+                                       ctx->W, filter_size, (float*)PMX_SNAP(out_disp_snapshot));
+}
+
+extern "C" int pmx_cross_checking_maps(pmx_ctx* ctx, const void* disp_left, void* validity_left, const void* disp_right, int dmin,
+                                       int dmax, double threshold, void* conf_out) {
+    if (int rc = check_snap(ctx, disp_left, sizeof(float), "pmx_cross_checking_maps", "left disparity snapshot")) return rc;
+    if (int rc = check_snap(ctx, validity_left, sizeof(int64_t), "pmx_cross_checking_maps", "left validity snapshot")) return rc;
+    if (int rc = check_snap(ctx, disp_right, sizeof(float), "pmx_cross_checking_maps", "right disparity snapshot")) return rc;
+    if (int rc = check_snap(ctx, conf_out, sizeof(float), "pmx_cross_checking_maps", "confidence snapshot")) return rc;
+    PMX_CHECK(dmin <= dmax, PMX_ERR_ARG, "pmx_cross_checking_maps: bad interval [%d,%d]", dmin, dmax);
+    PMX_HIP(hipSetDevice(ctx->device));
+    return pmx_launch_cross_checking(ctx, (const float*)PMX_SNAP(disp_left), (int64_t*)PMX_SNAP(validity_left),
+                                     (const float*)PMX_SNAP(disp_right), ctx->H, ctx->W, dmin, dmax, threshold, (float*)PMX_SNAP(conf_out));
+}
+
+extern "C" int pmx_validity_frame_map(pmx_ctx* ctx, void* validity_snapshot, int border) {
+    if (int rc = check_snap(ctx, validity_snapshot, sizeof(int64_t), "pmx_validity_frame_map", "validity snapshot")) return rc;
+    PMX_CHECK(border >= 0, PMX_ERR_ARG, "pmx_validity_frame_map: negative border");
+    PMX_HIP(hipSetDevice(ctx->device));
+    return pmx_launch_compose_validity_into(ctx, (const int64_t*)PMX_SNAP(validity_snapshot), ctx->H, nullptr, border,
+                                            (int64_t*)PMX_SNAP(validity_snapshot));
 }
 
 extern "C" int pmx_map_snapshot_read(pmx_ctx* ctx, const void* snapshot, void* host_out) {

@@ -78,10 +78,13 @@ struct pmx_ctx {
     char* stage_host = nullptr;
     size_t stage_cap = 0;
     // pinned staging of pmx_compose_validity's line (the copy is asynchronous; line_ev says when the buffer is free again)
+    // (a ring of kLineSlots lines: a slot is only waited for when the ring comes round to it while its copy is still queued)
+    static constexpr int kLineSlots = 8;
     int64_t* line_host = nullptr;
     int64_t* line_dev = nullptr;
-    size_t line_cap = 0;
-    hipEvent_t line_ev = nullptr;
+    size_t line_cap = 0;  // elements per slot
+    hipEvent_t line_ev[kLineSlots] = {};
+    int line_next = 0;
     bool profiling = false;
     bool lazy = true;
     void* probe_sink = nullptr;   // 64 bytes the placement probe may write to
@@ -278,6 +281,8 @@ bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, 
 int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
 int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
 int pmx_launch_compose_validity(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border);
+int pmx_launch_compose_validity_into(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border,
+                                     int64_t* dev_out);
 int pmx_launch_reverse(pmx_ctx* ctx, const pmx_cv* in, int min_disp, pmx_cv* out);
 int pmx_launch_minkey(pmx_ctx* ctx, const pmx_cv* cv, int is_max, int index_offset, uint64_t* keys);
 int pmx_launch_from_keys(pmx_ctx* ctx, const uint64_t* keys, double d0, int subpix, float invalid_disparity);

@@ -60,19 +60,26 @@ class DeviceCostVolume:
 class _PinnedBlock:
     """A page-locked host buffer that numpy arrays are views of; returns to the pool when its last view dies."""
     _pool = {}  # bytes -> [address]: process-wide, pinned memory does not belong to a context
+    _pool_bytes = [0]
+    POOL_MAX = 2 << 30  # hipHostMalloc / hipHostFree of a 16 MB block cost 2 - 3 ms each: blocks are recycled, up to this many bytes
 
     def __init__(self, nbytes):
         self.nbytes = int(nbytes)
         free = self._pool.get(self.nbytes)
-        self.addr = free.pop() if free else _lib.lib().pmx_host_alloc(self.nbytes)
+        if free:
+            self.addr = free.pop()
+            self._pool_bytes[0] -= self.nbytes
+        else:
+            self.addr = _lib.lib().pmx_host_alloc(self.nbytes)
         if not self.addr:
             raise MemoryError(f"pmx_host_alloc({nbytes})")
         self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.addr, False), "version": 3}
 
     def __del__(self):
         try:
-            if len(self._pool.setdefault(self.nbytes, [])) < 4:
-                self._pool[self.nbytes].append(self.addr)
+            if self._pool_bytes[0] + self.nbytes <= self.POOL_MAX:
+                self._pool.setdefault(self.nbytes, []).append(self.addr)
+                self._pool_bytes[0] += self.nbytes
             else:
                 _lib.lib().pmx_host_free(self.addr)
         except Exception:  # interpreter shutdown
@@ -103,6 +110,28 @@ class DeviceMapArray:
     def on_device(self):
         """True while nobody has looked at (or replaced) the values and the engine still holds exactly them."""
         return self._host is None and self._snap is None and self._token is self.engine.maps_token
+
+    @classmethod
+    def from_snapshot(cls, engine, which, snap, coords=None, dims=("row", "col")):
+        """A map that lives in a device-side snapshot of its own from the start (the output of a step on snapshots)."""
+        self = cls.__new__(cls)
+        self.engine, self.which = engine, which
+        self.dims, self.coords = tuple(dims), dict(coords or {})
+        self._shape = (engine.H, engine.W)
+        self._host, self._snap, self._token = None, snap, None
+        engine._snapshots.add(self)
+        return self
+
+    def device_snapshot(self):
+        """The snapshot handle that holds these values on the device - taking it out of the engine's current maps if that is
+        where they still are - or None when the host copy is the truth (somebody read or assigned ``.data``)."""
+        if self._host is not None:
+            return None
+        if self._snap is None:
+            if self._token is not self.engine.maps_token:
+                raise RuntimeError("a device-resident map outlived its values (engine bookkeeping error)")
+            self.detach()
+        return self._snap
 
     def detach(self):
         """The engine's maps are about to change: keep these values in a device-side copy of their own (nothing waits, nothing
@@ -348,6 +377,41 @@ class Engine:
         if not h:
             raise PmxError("pmx_map_snapshot failed: " + _lib.lib().pmx_last_error().decode())
         return h
+
+    def alloc_snapshot(self, which):
+        """An uninitialised snapshot (float32 for "disp" / "itp" / "conf", int64 for "validity")."""
+        h = _lib.lib().pmx_map_snapshot_alloc(self.ctx, 1 if which == "validity" else 0)
+        if not h:
+            raise PmxError("pmx_map_snapshot_alloc failed: " + _lib.lib().pmx_last_error().decode())
+        return h
+
+    def maps_restore(self, disp_snap, validity_snap):
+        """The engine's disparity / validity maps become what the two snapshots hold (pmx_maps_restore)."""
+        self.new_maps()
+        check(_lib.lib().pmx_maps_restore(self.ctx, disp_snap, validity_snap), "pmx_maps_restore")
+
+    def median_filter_maps(self, disp_snap, validity_snap, filter_size):
+        out = self.alloc_snapshot("disp")
+        try:
+            check(_lib.lib().pmx_median_filter_maps(self.ctx, disp_snap, validity_snap, int(filter_size), out), "pmx_median_filter_maps")
+        except Exception:
+            self.free_snapshot(out)
+            raise
+        return out
+
+    def cross_checking_maps(self, disp_left, validity_left, disp_right, dmin, dmax, threshold, border=0):
+        """validation.py:226-371 on snapshots: ``validity_left`` is updated in place (then framed, criteria.mask_border, when
+        ``border`` > 0); returns the snapshot of the left-right distance."""
+        conf = self.alloc_snapshot("conf")
+        try:
+            check(_lib.lib().pmx_cross_checking_maps(self.ctx, disp_left, validity_left, disp_right, int(dmin), int(dmax),
+                                                     float(threshold), conf), "pmx_cross_checking_maps")
+            if border > 0:
+                check(_lib.lib().pmx_validity_frame_map(self.ctx, validity_left, int(border)), "pmx_validity_frame_map")
+        except Exception:
+            self.free_snapshot(conf)
+            raise
+        return conf
 
     def read_snapshot(self, snap, which, shape):
         out = pinned_empty(shape, np.int64 if which == "validity" else np.float32)

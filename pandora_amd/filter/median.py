@@ -2,6 +2,7 @@
 import numpy as np
 
 from .. import runtime
+from ..engine import DeviceMapArray
 from ..matching_cost.matching_cost import ConfigError
 from . import filter as _filter
 
@@ -44,6 +45,12 @@ class MedianFilter(_filter.AbstractFilter):
     def filter_disparity(self, disp, img_left=None, img_right=None, cv=None):
         """median.py:94-131: median over the valid pixels, invalid neighbours ignored, in place."""
         eng = runtime.get_engine()
-        disp["disparity_map"].data = eng.median_filter_disparity(np.asarray(disp["disparity_map"].data),
-                                                                 np.asarray(disp["validity_mask"].data), self._filter_size)
+        dm, vm = disp["disparity_map"], disp["validity_mask"]
+        snaps = [m.device_snapshot() if isinstance(m, DeviceMapArray) and m.engine is eng and m.shape == (eng.H, eng.W) else None
+                 for m in (dm, vm)]
+        if snaps[0] is not None and snaps[1] is not None:  # the maps never left the GPU: neither does the filtered one
+            out = eng.median_filter_maps(snaps[0], snaps[1], self._filter_size)
+            disp["disparity_map"] = DeviceMapArray.from_snapshot(eng, "disp", out, coords=dm.coords, dims=dm.dims)
+        else:
+            dm.data = eng.median_filter_disparity(np.asarray(dm.data), np.asarray(vm.data), self._filter_size)
         disp.attrs["filter"] = "median"

@@ -62,8 +62,14 @@ class AbstractRefinement:
             dm.rebind()
             vm.rebind()
         else:
-            # the host copies may have been edited since WTA (filters): they are the source of truth
-            eng.set_disparity(np.asarray(dm.data, np.float32), np.asarray(vm.data, np.int64))
+            snaps = [m.device_snapshot() if isinstance(m, DeviceMapArray) and m.engine is eng else None for m in (dm, vm)]
+            if snaps[0] is not None and snaps[1] is not None:
+                # the maps left the engine's buffers for snapshots of their own (the other side's WTA came in between): they go
+                # back device to device
+                eng.maps_restore(snaps[0], snaps[1])
+            else:
+                # the host copies may have been edited since WTA (filters): they are the source of truth
+                eng.set_disparity(np.asarray(dm.data, np.float32), np.asarray(vm.data, np.int64))
             eng.refine(dcv, self._refinement_method_name, is_max)
             disp["disparity_map"] = DeviceMapArray(eng, "disp", coords=coords)
             disp["validity_mask"] = DeviceMapArray(eng, "validity", coords=coords)

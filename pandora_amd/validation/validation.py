@@ -10,6 +10,7 @@ import numpy as np
 from .. import runtime
 from ..criteria import mask_border
 from ..dataset import DataArray
+from ..engine import DeviceMapArray
 from ..matching_cost.matching_cost import ConfigError
 
 
@@ -28,7 +29,7 @@ def allocate_confidence_map(name_confidence_measure, confidence_map, disp, cv):
             data[:, :, -1] = layer
             indicator = np.append(np.copy(ds.coords["indicator"]), name_confidence_measure)
         else:
-            data = layer[:, :, np.newaxis].astype(np.float32)
+            data = layer[:, :, np.newaxis]  # (a view: the layer's array is the indicator's storage, no 16 MB copy at 4 Mpx)
             indicator = np.array([name_confidence_measure])
         ds.coords["indicator"] = indicator
         coords = {k: ds.coords[k] for k in ("row", "col") if k in ds.coords}  # (the machine's pre-disparity dataset has none)
@@ -113,6 +114,21 @@ class CrossCheckingAccurate(AbstractValidation):
         interval = np.asarray(dataset_left["disparity_interval"].data)
         dmin, dmax = int(interval[0]), int(interval[1])  # np.arange(disparity_min, disparity_max + 1), disparity.py:334-347
         eng = runtime.get_engine()
+        maps = (dataset_left["disparity_map"], dataset_left["validity_mask"], dataset_right["disparity_map"])
+        snaps = [m.device_snapshot() if isinstance(m, DeviceMapArray) and m.engine is eng and m.shape == (eng.H, eng.W) else None
+                 for m in maps]
+        if all(s is not None for s in snaps):
+            # both sides' maps are still in HBM: checked there, the left mask updated (and framed, criteria.mask_border) in its own
+            # snapshot; only the left-right distance comes down, into the confidence_measure array the reference stacks it on
+            border = int(dataset_left.attrs.get("offset_row_col", 0))
+            conf_snap = eng.cross_checking_maps(snaps[0], snaps[1], snaps[2], dmin, dmax, float(self._threshold), border)
+            try:
+                conf = eng.read_snapshot(conf_snap, "conf", maps[0].shape)
+            finally:
+                eng.free_snapshot(conf_snap)
+            dataset_left.attrs["validation"] = self._method
+            dataset_left, _ = allocate_confidence_map("left_right_consistency", conf, dataset_left, cv)
+            return dataset_left
         validity, conf = eng.cross_checking(dataset_left["disparity_map"].data, dataset_left["validity_mask"].data,
                                             dataset_right["disparity_map"].data, dmin, dmax, float(self._threshold))
         dataset_left["validity_mask"].data = validity.astype(np.asarray(dataset_left["validity_mask"].data).dtype, copy=False)

@@ -1295,3 +1295,44 @@ def test_result_maps_survive_on_the_device_until_read(eng):
         np.testing.assert_array_equal(x.data, want[tag][0], err_msg=tag)
         np.testing.assert_array_equal(y.data, want[tag][1], err_msg=tag)
         assert x._snap is None and x.data is x.data
+
+
+def test_steps_on_snapshots_equal_the_host_pointer_forms(eng):
+    """pmx_median_filter_maps / pmx_cross_checking_maps / pmx_validity_frame_map / pmx_maps_restore work on device-side snapshots
+    and give what the host-pointer entry points (checked against the oracle elsewhere in this file) give on the same maps."""
+    from pandora_amd.engine import DeviceMapArray
+
+    rng = np.random.default_rng(31)
+    H, W = 45, 70
+    L, R = pair(H, W, 12)
+    eng.set_images(L, R, 1)
+    dl = rng.integers(-12, 3, (H, W)).astype(np.float32) + rng.random((H, W)).astype(np.float32)
+    dr = -dl + rng.integers(-2, 3, (H, W)).astype(np.float32)
+    dl[rng.random((H, W)) < 0.05] = np.nan
+    val = (rng.random((H, W)) < 0.15).astype(np.int64) * 2 + (rng.random((H, W)) < 0.1).astype(np.int64) * 4
+    # host maps -> engine maps -> snapshots
+    eng.set_disparity(dl, val)
+    left = (DeviceMapArray(eng, "disp"), DeviceMapArray(eng, "validity"))
+    snap_l, snap_v = left[0].device_snapshot(), left[1].device_snapshot()
+    eng.set_disparity(dr, np.zeros((H, W), np.int64))
+    snap_r = DeviceMapArray(eng, "disp")
+    for size in (3, 5):
+        out = eng.median_filter_maps(snap_l, snap_v, size)
+        got = DeviceMapArray.from_snapshot(eng, "disp", out).data
+        np.testing.assert_array_equal(got, eng.median_filter_disparity(dl.copy(), val, size))
+    with pytest.raises(Exception, match="in place|snapshot"):
+        from pandora_amd import _lib
+        from pandora_amd.engine import check
+        check(_lib.lib().pmx_median_filter_maps(eng.ctx, snap_l, snap_v, 3, snap_l), "pmx_median_filter_maps")
+    want_val, want_conf = eng.cross_checking(dl, val, dr, -12, 3, 1.0)
+    conf = eng.cross_checking_maps(snap_l, snap_v, snap_r.device_snapshot(), -12, 3, 1.0, border=2)
+    from pandora_amd import criteria
+    criteria._frame(want_val, 2)
+    np.testing.assert_array_equal(left[1].data, want_val)  # updated in place in the left mask's own snapshot
+    np.testing.assert_array_equal(DeviceMapArray.from_snapshot(eng, "conf", conf).data, want_conf)
+    # restore: the engine's maps are the snapshots' values again
+    a, b = DeviceMapArray(eng, "disp"), DeviceMapArray(eng, "validity")  # (current maps: the right side's)
+    eng.maps_restore(snap_l, a.device_snapshot() and b.device_snapshot())
+    np.testing.assert_array_equal(eng.get_disparity()[0], dl)
+    np.testing.assert_array_equal(eng.get_disparity()[1], np.zeros((H, W), np.int64))
+    np.testing.assert_array_equal(a.data, dr)

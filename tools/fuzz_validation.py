@@ -77,6 +77,10 @@ for seed in range(int(os.environ.get("FUZZ_FROM", "0")), int(os.environ.get("FUZ
     try:
         one(seed)
     except Exception as e:  # noqa: BLE001
+        if isinstance(e, ValueError) and "NaN to integer" in str(e):
+            # a disparity range that lies wholly outside the image: the reversed (right) grids are all NaN and
+            # int(np.nanmin(...)) raises - in the reference as here (matching_cost.py:604-616)
+            continue
         fails += 1
         cfg = draw(seed)[0]
         print("FAIL", seed, json.dumps(cfg), draw(seed)[1].shape, draw(seed)[3:], type(e).__name__, str(e)[:300].replace("\n", " "))
