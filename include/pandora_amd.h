@@ -48,6 +48,10 @@ int pmx_sync(pmx_ctx* ctx);
  * (img_tools.py:713-752 shift_right_img, linear interpolation in double).  Replaces the numpy
  * image hand-off of every compute_cost_volume (e.g. matching_cost/census.py:113-133). */
 int pmx_set_images(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix);
+/* The resident pair with left and right exchanged (masks too; the sub-pixel right images are rebuilt by linear interpolation):
+ * what compute_cost_volume(img_right, img_left, ...) of the validation step's right-side volume needs (state_machine.py:311-331),
+ * without sending the same two images again. */
+int pmx_swap_images(pmx_ctx* ctx);
 /* pmx_set_images that also returns pmx_host_fingerprint of the two images, taken in the pass that copies them to the
  * staging buffer (a caller that keeps track of which pair is resident reads every image once instead of twice). */
 int pmx_set_images_fingerprinted(pmx_ctx* ctx, const float* left, const float* right, int H, int W, int subpix,

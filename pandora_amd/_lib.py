@@ -28,6 +28,7 @@ SIGNATURES = {
     "pmx_set_images": (C.c_int, [vp, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int]),
     "pmx_set_images_fingerprinted": (C.c_int, [vp, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64),
                                                C.POINTER(C.c_uint64)]),
+    "pmx_swap_images": (C.c_int, [vp]),
     "pmx_set_masks": (C.c_int, [vp, c_i16_p, c_i16_p, C.c_int, C.c_int]),
     "pmx_set_shifted_right": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float)]),
     "pmx_set_disparity_grids": (C.c_int, [vp, c_double_p, c_double_p]),

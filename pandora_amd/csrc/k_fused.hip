@@ -649,7 +649,7 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
             int rc8 = pmx_launch_sgm8(ctx, cv, kpl, (uint32_t)P1, (uint32_t)P2, (uint32_t)invalid_cost);
             if (rc8) return rc8;
             cv->repr = PMX_REPR_SGM_U8X8;
-            if (ctx->near_owner == cv) ctx->near_owner = nullptr;
+            pmx_near_forget(ctx, cv);
             return PMX_OK;
         }
     }
@@ -693,7 +693,7 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
     PMX_CHECK(launched, PMX_ERR_STATE, "pmx_sgm (fused): no kernel for lane map %dx%d", gl, kpl);
     PMX_HIP(hipGetLastError());
     cv->repr = PMX_REPR_SGM_U8X8;
-    if (ctx->near_owner == cv) ctx->near_owner = nullptr;  // the volume changed under the cache
+    pmx_near_forget(ctx, cv);  // the volume changed under the cache
     return PMX_OK;
 }
 

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <thread>
+#include <utility>
 #include <vector>
 #include <cstdlib>
 
@@ -86,6 +87,8 @@ static void free_images(pmx_ctx* ctx) {
     hipFree(ctx->itp); ctx->itp = nullptr;
     hipFree(ctx->validity); ctx->validity = nullptr;
     hipFree(ctx->near); ctx->near = nullptr;
+    hipFree(ctx->near2); ctx->near2 = nullptr;
+    ctx->near2_owner = nullptr;
     ctx->bad_win = 0;
 }
 
@@ -418,6 +421,7 @@ extern "C" int pmx_set_images_fingerprinted(pmx_ctx* ctx, const float* left, con
         PMX_HIP(hipMalloc(&ctx->near, n * 16));
     }
     ctx->near_owner = nullptr;
+    ctx->near2_owner = nullptr;
     ctx->disp_ready = false;
     // The caller's arrays are pageable.  Pairs up to kStageMax bytes go through a pinned staging buffer: a few host threads copy
     // them in (faster than the runtime's own single-threaded staging), the DMA is queued and the call returns - the transfer
@@ -454,6 +458,32 @@ extern "C" int pmx_set_images_fingerprinted(pmx_ctx* ctx, const float* left, con
     PMX_HIP(hipMemsetAsync(ctx->near, 0xff, n * 16, ctx->stream));
     PMX_HIP(hipMemsetAsync(ctx->validity, 0, n * sizeof(int64_t), ctx->stream));
     if (!staged) PMX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
+    return PMX_OK;
+}
+
+// The right-side volume of a cross-checked run is computed from the SAME two images in the other order
+// (state_machine.py:311-331, matching_cost_run): both are in HBM already, the pair is swapped where it is.
+extern "C" int pmx_swap_images(pmx_ctx* ctx) {
+    PMX_CHECK(ctx && ctx->left, PMX_ERR_STATE, "pmx_swap_images: call pmx_set_images first");
+    PMX_HIP(hipSetDevice(ctx->device));
+    std::swap(ctx->left, ctx->right[0]);
+    std::swap(ctx->msk_left, ctx->msk_right);
+    std::swap(ctx->bad_left, ctx->bad_right);
+    for (int k = 1; k < ctx->subpix; ++k) {  // the sub-pixel images of the NEW right image (img_tools.py:713-752, order 1)
+        int rc = pmx_launch_shift_right(ctx, ctx->right[0], ctx->H, ctx->W, ctx->subpix, k, ctx->right[k]);
+        if (rc) return rc;
+    }
+    if (ctx->grid_min || ctx->grid_max) {  // per-pixel ranges belong to the side they were set for
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->grid_min); ctx->grid_min = nullptr;
+        hipFree(ctx->grid_max); ctx->grid_max = nullptr;
+    }
+    const size_t n = (size_t)ctx->H * ctx->W;
+    ctx->near_owner = nullptr;
+    ctx->near2_owner = nullptr;
+    ctx->disp_ready = false;
+    PMX_HIP(hipMemsetAsync(ctx->near, 0xff, n * 16, ctx->stream));
+    PMX_HIP(hipMemsetAsync(ctx->validity, 0, n * sizeof(int64_t), ctx->stream));
     return PMX_OK;
 }
 
@@ -575,7 +605,7 @@ int pmx_cv_ensure_data(pmx_ctx* ctx, pmx_cv* cv) {
 
 extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
     if (!cv) return;
-    if (ctx && ctx->near_owner == cv) ctx->near_owner = nullptr;
+    if (ctx) pmx_near_forget(ctx, cv);
     if (ctx) {
         hipSetDevice(ctx->device);
         pmx_pool_free(ctx, cv->data);
@@ -977,13 +1007,55 @@ extern "C" int pmx_set_validity(pmx_ctx* ctx, const int64_t* validity) {
     return PMX_OK;
 }
 
+// ---- the winner cache (ctx->near: what the WTA left of its winner, so that the refinement does not gather it again) belongs to
+// ONE volume.  A cross-checked run takes the left and the right volume through WTA and refinement in turn: with one cache the
+// left refinement would find the right side's winners in it and gather again (0.9 ms at 2048^2 x 129), so there are two, and the
+// one that belongs to the volume at hand is made the active one.
+int pmx_near_select(pmx_ctx* ctx, const pmx_cv* cv, bool for_write) {
+    if (ctx->near_owner == cv) return PMX_OK;
+    auto swap_slots = [&] {
+        std::swap(ctx->near, ctx->near2);
+        std::swap(ctx->near_owner, ctx->near2_owner);
+        std::swap(ctx->near_exact, ctx->near2_exact);
+    };
+    if (ctx->near2 && ctx->near2_owner == cv) {
+        swap_slots();
+        return PMX_OK;
+    }
+    if (!for_write || ctx->near_owner == nullptr) return PMX_OK;  // reading: no cache of this volume; writing: the active one is free
+    // the active cache belongs to another volume: write into the other one (taking it from whoever had it)
+    if (!ctx->near2) {
+        const size_t bytes = (size_t)ctx->H * ctx->W * 16;
+        if (hipMalloc(&ctx->near2, bytes) != hipSuccess) {  // no room for a second cache: overwrite the only one, as before
+            (void)hipGetLastError();
+            ctx->near2 = nullptr;
+            return PMX_OK;
+        }
+        PMX_HIP(hipMemsetAsync(ctx->near2, 0xff, bytes, ctx->stream));
+    }
+    ctx->near2_owner = nullptr;
+    ctx->near2_exact = false;
+    swap_slots();
+    return PMX_OK;
+}
+
+void pmx_near_forget(pmx_ctx* ctx, const pmx_cv* cv) {
+    if (ctx->near_owner == cv) ctx->near_owner = nullptr;
+    if (ctx->near2_owner == cv) ctx->near2_owner = nullptr;
+}
+
 extern "C" int pmx_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity) {
     int rc = check_cv(ctx, cv, "pmx_wta");
     if (rc) return rc;
     ctx->disp_ready = true;
-    ctx->near_exact = false;
+    ctx->near_exact = ctx->near2_exact = false;
+    const bool up_pending = cv->repr == PMX_REPR_SGM_UP_PENDING && (is_max != 0) == (cv->pending.is_max != 0);
+    if ((cv->repr == PMX_REPR_SGM_U8X8 && !is_max) || up_pending) {  // the two routes that leave a winner cache
+        rc = pmx_near_select(ctx, cv, true);
+        if (rc) return rc;
+    }
     if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_wta(ctx, cv, invalid_disparity);
-    if (cv->repr == PMX_REPR_SGM_UP_PENDING && (is_max != 0) == (cv->pending.is_max != 0)) {
+    if (up_pending) {
         // the last SGM pass and the WTA in one kernel: the optimised volume is neither written nor read
         const pmx_fam_wta w = {ctx->disp, (float*)ctx->near, (double)cv->d0, cv->subpix, invalid_disparity};
         rc = pmx_sgm_finish_pending(ctx, const_cast<pmx_cv*>(cv), &w);
@@ -1003,6 +1075,8 @@ extern "C" int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max
     PMX_CHECK(method == PMX_REFINE_VFIT || method == PMX_REFINE_QUADRATIC, PMX_ERR_ARG,
               "pmx_refine: unknown refinement method %d", method);
     PMX_CHECK(ctx->disp_ready, PMX_ERR_STATE, "pmx_refine: no disparity map for this pair yet (run pmx_wta or pmx_set_disparity first)");
+    rc = pmx_near_select(ctx, cv, false);
+    if (rc) return rc;
     if (cv->repr == PMX_REPR_SGM_U8X8 && !is_max) return pmx_launch_sum8_refine(ctx, cv, method);
     if (cv->repr == PMX_REPR_SGM_UP_PENDING && ctx->near_owner == cv && ctx->near_exact) {
         ctx->near_exact = false;  // the refined map is no longer the WTA's
@@ -1088,7 +1162,7 @@ extern "C" int pmx_maps_restore(pmx_ctx* ctx, const void* disp_snapshot, const v
     PMX_HIP(hipMemcpyAsync(ctx->disp, PMX_SNAP(disp_snapshot), n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     PMX_HIP(hipMemcpyAsync(ctx->validity, PMX_SNAP(validity_snapshot), n * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
     ctx->disp_ready = true;
-    ctx->near_exact = false;  // the winner cache of a fused WTA describes the LAST WTA's map, not this one
+    ctx->near_exact = ctx->near2_exact = false;  // a winner cache describes its WTA's map; whether this is that map nobody knows
     return PMX_OK;
 }
 
@@ -1154,7 +1228,7 @@ extern "C" int pmx_set_disparity(pmx_ctx* ctx, const float* disp, const int64_t*
     if (disp) {
         PMX_HIP(hipMemcpyAsync(ctx->disp, disp, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         ctx->disp_ready = true;
-        ctx->near_exact = false;  // an edited map: the winner cache of a fused WTA no longer describes it
+        ctx->near_exact = ctx->near2_exact = false;  // an edited map: the winner cache of a fused WTA no longer describes it
     }
     if (validity) PMX_HIP(hipMemcpyAsync(ctx->validity, validity, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));

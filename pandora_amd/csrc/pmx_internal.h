@@ -68,6 +68,11 @@ struct pmx_ctx {
     bool disp_ready = false;  // a disparity map is resident for the current pair (pmx_wta / pmx_wta_from_keys / pmx_set_disparity)
     const void* near_owner = nullptr;  // the volume handle that cache was computed from (nullptr = stale)
     bool near_exact = false;  // the cache matches the resident disparity map pixel for pixel (no host edit since the WTA that wrote it)
+    // a second winner cache (allocated when a second volume of the pair runs its WTA while the first still owns the other: the
+    // left and right sides of a cross-checked run); pmx_near_select makes the one that belongs to a volume the active one
+    void* near2 = nullptr;
+    const void* near2_owner = nullptr;
+    bool near2_exact = false;
     // scratch volume reused across calls (SGM accumulator, CBCA intermediate)
     float* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -273,6 +278,8 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
                             int mask, int fams, const pmx_fam_wta* wta);
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
 int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
+int pmx_near_select(pmx_ctx* ctx, const pmx_cv* cv, bool for_write);  // the winner cache of `cv` becomes ctx->near (see pmx_api.hip)
+void pmx_near_forget(pmx_ctx* ctx, const pmx_cv* cv);                 // the volume changed: no cache describes it any more
 int pmx_launch_near_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);  // from the winner's three values (ctx->near)
 int pmx_launch_wta_fixup(pmx_ctx* ctx, const pmx_cv* cv);                          // validity of the pixels a fused WTA found all-NaN
 int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta);      // runs the upward family of a pending volume

@@ -249,6 +249,11 @@ class Engine:
                                                       C.byref(fl), C.byref(fr)), "pmx_set_images")
         return fl.value, fr.value  # pmx_host_fingerprint of the two arrays as uploaded
 
+    def swap_images(self):
+        """Left and right of the resident pair exchanged on the device (pmx_swap_images)."""
+        self.new_maps()
+        check(_lib.lib().pmx_swap_images(self.ctx), "pmx_swap_images")
+
     def set_shifted_right(self, k, img):
         """the k-th shifted right image resampled on the host (spline_order > 1): float32 (H, W - 1)"""
         a = np.ascontiguousarray(img, np.float32)

@@ -85,7 +85,19 @@ def ensure_pair(img_left, img_right, subpix, device=None, band=None, spline_orde
     # other arrays than the resident pair's: an upload for certain - the images are fingerprinted in the pass that stages them
     fresh = (res is None or (res[0][0][0], res[0][1][0]) != (id(img_left["im"].data), id(img_right["im"].data))) and \
         _fingerprint_is_of_the_image(img_left, band) and _fingerprint_is_of_the_image(img_right, band)
-    key = None if fresh else _key(img_left, img_right, subpix, band, spline_order)
+    swapped = (fresh and res is not None and (res[0][1][0], res[0][0][0]) == (id(img_left["im"].data), id(img_right["im"].data))
+               and (int(subpix) == 1 or int(spline_order) == 1))
+    if swapped:
+        # the resident pair's arrays in the other order (the right-side volume of a cross-checked run): if nothing else changed
+        # - contents, masks, parameters - the device exchanges the two where they are
+        key = _key(img_left, img_right, subpix, band, spline_order)
+        if key == (res[0][1], res[0][0]) + res[0][2:]:
+            eng.swap_images()
+            _RESIDENT[eng.device] = (key, _holders(img_left, img_right))
+            return eng
+        fresh = False
+    else:
+        key = None if fresh else _key(img_left, img_right, subpix, band, spline_order)
     if fresh or res is None or res[0] != key:
         _RESIDENT.pop(eng.device, None)  # (an upload that fails half-way leaves nothing that could be taken for resident)
         right = np.asarray(select_band(img_right, band), np.float32)

@@ -1336,3 +1336,35 @@ def test_steps_on_snapshots_equal_the_host_pointer_forms(eng):
     np.testing.assert_array_equal(eng.get_disparity()[0], dl)
     np.testing.assert_array_equal(eng.get_disparity()[1], np.zeros((H, W), np.int64))
     np.testing.assert_array_equal(a.data, dr)
+
+
+@pytest.mark.parametrize("subpix", [1, 2, 4])
+def test_swapped_pair_equals_the_pair_uploaded_the_other_way_round(eng, subpix):
+    """pmx_swap_images (the right-side volume of a cross-checked run: same two images, other order) against pmx_set_images(right,
+    left): images, masks and the rebuilt sub-pixel right images give the same volumes, masked the same way."""
+    rng = np.random.default_rng(3)
+    H, W = 33, 61
+    L, R = pair(H, W, 21, integer=False)
+    mL = (rng.random((H, W)) < 0.02).astype(np.int16) * rng.integers(1, 3, (H, W)).astype(np.int16)
+    mR = (rng.random((H, W)) < 0.03).astype(np.int16) * rng.integers(1, 3, (H, W)).astype(np.int16)
+    D = 9 * subpix + 1
+    vols = []
+    for way in ("swap", "upload"):
+        if way == "swap":
+            eng.set_images(L, R, subpix)
+            eng.set_masks(mL, mR, 0, 1)
+            eng.swap_images()
+        else:
+            eng.set_images(R, L, subpix)
+            eng.set_masks(mR, mL, 0, 1)
+        got = []
+        for method in ("census", "zncc", "sad"):
+            cv = eng.alloc_cv(D, -4)
+            {"census": lambda: eng.census(cv, 5), "zncc": lambda: eng.zncc(cv, 3), "sad": lambda: eng.sad_ssd(cv, 3, False)}[method]()
+            eng.cv_masked(cv, 5 if method == "census" else 3)
+            got.append(cv.to_host())
+            cv.free()
+        vols.append(got)
+    for a, b in zip(*vols):
+        np.testing.assert_array_equal(a, b)
+    assert all(np.isfinite(v).any() and np.isnan(v).any() for v in vols[0])
