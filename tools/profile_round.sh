@@ -31,7 +31,10 @@ prof northstar python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3
 prof c3 python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3 --height 2048 --width 2048 --dmax 128
 prof float_sgm_c4 python tools/bench_sgm_sched.py C4 --sched fam,seq --reps 2
 prof census_cbca_c3 env PMX_BENCH_ONLY=census_cbca python tools/bench_kernels.py
+prof c4 python tools/bench_configs.py --stages C4
+prof c5 python tools/bench_configs.py --stages C5
 python tools/pmc_traffic.py $OUT/northstar_pmc_hbm.csv 4096 4096 257 $OUT/c3_pmc_hbm.csv 2048 2048 129 > $OUT/pmc_traffic.json
 python tools/bench_configs.py --stages > $OUT/baseline_configs.json 2> $OUT/baseline_configs.err
 python tools/bench_kernels.py > $OUT/general_path_kernels.json 2> $OUT/general.err
+python tools/bench_machine.py > $OUT/machine_level.json 2> $OUT/machine.err
 cat $OUT/bench.json; head -12 $OUT/northstar_kernel_stats.csv; cat $OUT/pmc_traffic.json; cat $OUT/baseline_configs.json
