@@ -162,6 +162,7 @@ int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity
 
 // ---- the two scan passes -------------------------------------------------------------------------
 struct cbca_args {
+    int dbg;          // ablation hook (PMX_CBCA_DBG), pass V through buffers: 1 no right-arm loads, 2 no left-arm loads, 4 no E_h loads, 8 no stores
     float* cv;        // [H][W][D] in/out
     float* eh;        // [H][W][D] horizontal segment sums (scratch)
     const int16_t* armsL;                   // [Hc][Wc][4]
@@ -855,16 +856,17 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
         float res;
         if (SIGN) res = ((nh >> (A + age)) & 1u) ? c_nan() : step4 / sum4;
         else res = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rs_at(out_row, row_bytes), voff_st, 0, 0);
+        if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rs_at(out_row, row_bytes), voff_st, 0, 0);
+        else if (res == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rs_at(out_row, row_bytes), voff_st, 0, 0);
         out_row += row_stride;
     };
     struct row_in { float e, in; uint32_t l, rr; };
     auto load_row = [&](int ahead) {  // row r + ahead of the prefix streams, r + ahead - A of the input
         row_in x;
-        x.e = ld(e_row + (size_t)ahead * row_stride);
+        x.e = (a.dbg & 4) ? 1.f : ld(e_row + (size_t)ahead * row_stride);
         x.in = SIGN ? 0.f : ld(in_row + (size_t)ahead * row_stride);
-        x.l = __builtin_amdgcn_raw_buffer_load_b32(rs_at(l_row + (size_t)ahead * a.pitchL, arms_bytes), offL, 0, 0);
-        x.rr = __builtin_amdgcn_raw_buffer_load_b32(rs_at(r_row + (size_t)ahead * a.pitchR, arms_bytes), offR, 0, 0);
+        x.l = (a.dbg & 2) ? 0x01010101u : __builtin_amdgcn_raw_buffer_load_b32(rs_at(l_row + (size_t)ahead * a.pitchL, arms_bytes), offL, 0, 0);
+        x.rr = (a.dbg & 1) ? 0x01010101u : __builtin_amdgcn_raw_buffer_load_b32(rs_at(r_row + (size_t)ahead * a.pitchR, arms_bytes), offR, 0, 0);
         return x;
     };
     auto advance = [&](int n) {
@@ -1240,7 +1242,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     const int H = cv->H, W = cv->W, o = offset;
     const int Hc = H - 2 * o, Wc = W - 2 * o;
     if (Hc <= 0 || Wc <= 0) return PMX_OK;  // (one cropped column is a volume like any other: its columns still aggregate)
-    cbca_args a;
+    cbca_args a{};
     a.A = distance - 1 > 1 ? distance - 1 : 1;
     // kernel choice.  Default: the phase-split scans when the scanned dimension is long enough, else the generic ones.  The
     // four-disparities-per-thread kernels work IN PLACE (no second volume: 51.6 GB less at 10000^2 x 129) but measured slower
@@ -1396,6 +1398,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         const bool vbuf = rows_ok && (ev ? ev[0] != '0' : (size_t)total >= (size_t)6144 * 64);
         // workgroups of 512 threads read 2 KB contiguous per row: a little kinder to the DRAM pages when the workgroups of a launch
         // have drifted rows apart (10000^2 x 129: 32.3 against 35.1 ms; at 2048^2 x 129 the coarser grid costs more than it gains)
+        a.dbg = getenv("PMX_CBCA_DBG") ? atoi(getenv("PMX_CBCA_DBG")) : 0;
         const char* eb = getenv("PMX_CBCA_VBS");
         int vbs = eb ? atoi(eb) : ((size_t)total >= ((size_t)1 << 20) ? 512 : 256);
         while (vbs > 256 && (size_t)2 * ring * vbs * sizeof(float) > (size_t)64 * 1024) vbs >>= 1;  // (long arms: the ring decides)
