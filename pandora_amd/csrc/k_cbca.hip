@@ -798,7 +798,7 @@ __global__ __launch_bounds__(kRowsT) void cbca_h_rows_kernel(cbca_args a) {
 // Same arithmetic and order as cbca_v_fast_kernel.  SIGN as there.
 __device__ __forceinline__ uint32_t cb_tb16(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c02u); }  // (top, bottom)
 
-template <bool SIGN, int BS>  // BS threads per workgroup: its cells are BS * 4 contiguous bytes of every row
+template <bool SIGN, int BS, bool ROWDESC>  // BS threads per workgroup: its cells are BS * 4 contiguous bytes of every row
 __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
     extern __shared__ float ring[];  // [ring][BS] x (S3, word)
     const int t = blockIdx.x * BS + threadIdx.x;
@@ -822,11 +822,18 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
     float* out_row = a.cv + (size_t)a.o * row_stride;        // output, row r - A
     const uint32_t* l_row = a.armsL8;                        // arms, row r
     const uint32_t* r_row = a.armsR8;
+    // Descriptors are re-based once per QUAD of rows (a volume is larger than a descriptor's 4 GB of offsets); inside the quad the
+    // row is chosen by the instruction's SCALAR offset (it IS part of the range check on gfx950: the descriptors span the quad's
+    // four rows; a lane's own offset stays inside one row, a dead lane's out-of-range offset still drops its access).  (Re-basing every row was 6 scalar instructions per memory instruction -
+    // the pass is issue-bound with as many scalar as vector instructions)  PMX_CBCA_DBG empties descriptors.
+    const unsigned quad_bytes = 4u * row_bytes;
+    const unsigned e_bytes = (a.dbg & 4) ? 0u : quad_bytes, st_bytes = (a.dbg & 8) ? 0u : quad_bytes;
     auto rs_at = [&](const void* row_ptr, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)row_ptr, 0, bytes, kRsrcWord3); };
     auto ld = [&](const float* row_ptr) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_at(row_ptr, row_bytes), voff, 0, 0)); };
     const unsigned offL = (unsigned)c * 4u;
     const unsigned offR = ((unsigned)ph * a.phase_words + (unsigned)(a.padR + q)) * 4u;  // (pads: every q of the lane's cells is readable)
-    const unsigned arms_bytes = 0x7ffffff0u;
+    const unsigned armsL_bytes = (a.dbg & 2) ? 0u : 0x7ffffff0u, armsR_bytes = (a.dbg & 1) ? 0u : 0x7ffffff0u;
+    const unsigned pitchL_bytes = (unsigned)a.pitchL * 4u, pitchR_bytes = (unsigned)a.pitchR * 4u;
     float acc = 0.f;
     uint32_t nacc = 0;
     uint32_t nh = 0;  // SIGN: bit i = the input cost of row (newest - i) was NaN
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
         ent[(r & mask) * BS] = make_uint2(__float_as_uint(acc), word);
     };
     // aggregated cost of row re; `age`: how many rows newer than re + A the newest prefix is (SIGN)
-    auto emit = [&](float in, int re, int age) {
+    auto emit = [&](float in, int re, int age, __amdgpu_buffer_rsrc_t rsO, unsigned srow) {
         const uint32_t w = ent[(re & mask) * BS].y;
         const int top = (w >> 20) & 63, bot = w >> 26;
         const bool cell = top != 63;
@@ -856,17 +863,20 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
         float res;
         if (SIGN) res = ((nh >> (A + age)) & 1u) ? c_nan() : step4 / sum4;
         else res = (in * 0.f + step4) / sum4;  // NaN stays NaN (cbca.py:145-146,168-171)
-        if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rs_at(out_row, row_bytes), voff_st, 0, 0);
-        else if (res == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rs_at(out_row, row_bytes), voff_st, 0, 0);
-        out_row += row_stride;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rsO, voff_st, srow, 0);
     };
     struct row_in { float e, in; uint32_t l, rr; };
-    auto load_row = [&](int ahead) {  // row r + ahead of the prefix streams, r + ahead - A of the input
+    struct row_rs { __amdgpu_buffer_rsrc_t e, in, l, r; };
+    auto rs_rows = [&](int ahead) {  // descriptors of row r + ahead of the prefix streams, r + ahead - A of the input
+        return row_rs{rs_at(e_row + (size_t)ahead * row_stride, e_bytes), rs_at(in_row + (size_t)ahead * row_stride, quad_bytes),
+                      rs_at(l_row + (size_t)ahead * a.pitchL, armsL_bytes), rs_at(r_row + (size_t)ahead * a.pitchR, armsR_bytes)};
+    };
+    auto load_row = [&](const row_rs& rs, int j) {  // row j below the descriptors' row
         row_in x;
-        x.e = (a.dbg & 4) ? 1.f : ld(e_row + (size_t)ahead * row_stride);
-        x.in = SIGN ? 0.f : ld(in_row + (size_t)ahead * row_stride);
-        x.l = (a.dbg & 2) ? 0x01010101u : __builtin_amdgcn_raw_buffer_load_b32(rs_at(l_row + (size_t)ahead * a.pitchL, arms_bytes), offL, 0, 0);
-        x.rr = (a.dbg & 1) ? 0x01010101u : __builtin_amdgcn_raw_buffer_load_b32(rs_at(r_row + (size_t)ahead * a.pitchR, arms_bytes), offR, 0, 0);
+        x.e = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs.e, voff, (unsigned)j * row_bytes, 0));
+        x.in = SIGN ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs.in, voff, (unsigned)j * row_bytes, 0));
+        x.l = __builtin_amdgcn_raw_buffer_load_b32(rs.l, offL, (unsigned)j * pitchL_bytes, 0);
+        x.rr = __builtin_amdgcn_raw_buffer_load_b32(rs.r, offR, (unsigned)j * pitchR_bytes, 0);
         return x;
     };
     auto advance = [&](int n) {
@@ -876,24 +886,39 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
     };
     int r = 0;
     for (; r < A; ++r) {  // warm-up
-        const row_in x = load_row(0);
+        const row_in x = load_row(rs_rows(0), 0);
         prefix(x.e, x.l, x.rr, r);
         advance(1);
     }
     // steady state: quads of rows, two quads in registers, the loop unrolled over the pair (no register copies between trips)
     struct quad { row_in x[4]; };
+    // ROWDESC: descriptors re-based every row after all.  Six more scalar instructions per memory instruction, and still the
+    // faster form when a row of the volume is more than 5 MB (10000^2 x 129: 33.8 against 35.6 ms for the quad form on one box,
+    // 31.9 against 32.6 on another; 6000^2 x 129: 12.3 against 11.5, 4096^2 x 257: 13.2 against 12.4, 4096^2 x 129: 6.70 against
+    // 6.05 and 6.48 against 6.47, 2048^2 x 129: 2.17 against 1.82) - the launcher picks by the row size.
     auto load_quad = [&](quad& g, int ahead) {
+        if (ROWDESC) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g.x[j] = load_row(ahead + j);
+            for (int j = 0; j < 4; ++j) g.x[j] = load_row(rs_rows(ahead + j), 0);
+        } else {
+            const row_rs rs = rs_rows(ahead);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g.x[j] = load_row(rs, j);
+        }
     };
     auto run_quad = [&](const quad& g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) prefix(g.x[j].e, g.x[j].l, g.x[j].rr, r + j);
+        const __amdgpu_buffer_rsrc_t rsO = rs_at(out_row, st_bytes);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) emit(g.x[j].in, r + j - A, 3 - j);
+        for (int j = 0; j < 4; ++j) {
+            if (ROWDESC) emit(g.x[j].in, r + j - A, 3 - j, rs_at(out_row + (size_t)j * row_stride, st_bytes), 0u);
+            else emit(g.x[j].in, r + j - A, 3 - j, rsO, (unsigned)j * row_bytes);
+        }
         r += 4;
         advance(4);
         in_row += (size_t)4 * row_stride;
+        out_row += (size_t)4 * row_stride;
     };
     if (r + 4 <= Hc) {
         quad ga, gb;
@@ -908,16 +933,18 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
         }
     }
     for (; r < Hc; ++r) {  // leftover rows
-        const row_in x = load_row(0);
+        const row_in x = load_row(rs_rows(0), 0);
         prefix(x.e, x.l, x.rr, r);
         advance(1);
-        emit(x.in, r - A, 0);
+        emit(x.in, r - A, 0, rs_at(out_row, st_bytes), 0u);
         in_row += row_stride;
+        out_row += row_stride;
     }
     for (; r < Hc + A; ++r) {  // drain
         if (SIGN) nh <<= 1;
-        emit(SIGN ? 0.f : ld(in_row), r - A, 0);
+        emit(SIGN ? 0.f : ld(in_row), r - A, 0, rs_at(out_row, st_bytes), 0u);
         in_row += row_stride;
+        out_row += row_stride;
     }
 }
 
@@ -1402,18 +1429,23 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         const char* eb = getenv("PMX_CBCA_VBS");
         int vbs = eb ? atoi(eb) : ((size_t)total >= ((size_t)1 << 20) ? 512 : 256);
         while (vbs > 256 && (size_t)2 * ring * vbs * sizeof(float) > (size_t)64 * 1024) vbs >>= 1;  // (long arms: the ring decides)
-        if (vbuf && sign && vbs == 512)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true, 512>), dim3((total + 511) / 512), dim3(512),
-                               (size_t)2 * ring * 512 * sizeof(float), ctx->stream, a);
-        else if (vbuf && sign && vbs == 1024)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true, 1024>), dim3((total + 1023) / 1024), dim3(1024),
-                               (size_t)2 * ring * 1024 * sizeof(float), ctx->stream, a);
-        else if (vbuf && sign)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<true, kBlock>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
-                               (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
-        else if (vbuf)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<false, kBlock>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
-                               (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
+        // (descriptors per row or per quad of rows: see the kernel - the per-row form wins once a row of the volume is several MB)
+        const char* er = getenv("PMX_CBCA_ROWDESC");
+        const bool rowdesc = er ? er[0] != '0' : (size_t)cv->W * cv->D * sizeof(float) > ((size_t)5 << 20);
+#define PMX_VBUF(SIGNV, BSV)                                                                                                        \
+    do {                                                                                                                            \
+        if (rowdesc)                                                                                                                \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<SIGNV, BSV, true>), dim3((total + BSV - 1) / BSV), dim3(BSV),      \
+                               (size_t)2 * ring * BSV * sizeof(float), ctx->stream, a);                                             \
+        else                                                                                                                        \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_buf_kernel<SIGNV, BSV, false>), dim3((total + BSV - 1) / BSV), dim3(BSV),     \
+                               (size_t)2 * ring * BSV * sizeof(float), ctx->stream, a);                                             \
+    } while (0)
+        if (vbuf && sign && vbs == 512) PMX_VBUF(true, 512);
+        else if (vbuf && sign && vbs == 1024) PMX_VBUF(true, 1024);
+        else if (vbuf && sign) PMX_VBUF(true, kBlock);
+        else if (vbuf) PMX_VBUF(false, kBlock);
+#undef PMX_VBUF
         else if (sign)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_v_fast_kernel<true>), dim3((total + kBlock - 1) / kBlock), dim3(kBlock),
                                (size_t)2 * ring * kBlock * sizeof(float), ctx->stream, a);
