@@ -109,7 +109,8 @@ class Dataset:
         return ds
 
 
-def make_image(data, disparity=None, msk=None, valid_pixels=0, no_data_mask=1, disparity_grids=None, band_names=None):
+def make_image(data, disparity=None, msk=None, valid_pixels=0, no_data_mask=1, disparity_grids=None, band_names=None, segm=None,
+               edges=None, classif=None):
     """Image dataset as produced by img_tools.create_dataset_from_inputs (img_tools.py:345-437):
     ``im`` float32 (row, col) - or (band_im, row, col) with ``band_names`` as the band_im coordinate -, optional ``msk``
     int16, ``disparity`` (band_disp=[min,max], row, col)."""
@@ -128,6 +129,14 @@ def make_image(data, disparity=None, msk=None, valid_pixels=0, no_data_mask=1, d
     ds.attrs.update({"valid_pixels": valid_pixels, "no_data_mask": no_data_mask, "crs": None, "transform": None, "no_data_img": None})
     if msk is not None:
         ds["msk"] = (("row", "col"), np.asarray(msk, np.int16))
+    if segm is not None:  # img_tools.py:190-231: layers the SGM step's geometric_prior reads
+        ds["segm"] = (("row", "col"), np.asarray(segm, np.int16))
+    if edges is not None:
+        ds["edges"] = (("row", "col"), np.asarray(edges, np.int16))
+    if classif is not None:  # (bands, names): img_tools.py:165-187
+        bands, names = classif
+        ds.coords["band_classif"] = np.asarray(list(names), dtype=object)
+        ds["classif"] = DataArray(np.asarray(bands, np.int16), ("band_classif", "row", "col"))
     ds.attrs["disparity_source"] = None
     if disparity is not None:
         dmin, dmax = disparity

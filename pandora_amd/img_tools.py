@@ -3,7 +3,7 @@ add_no_data / add_mask, :345-437 create_dataset_from_inputs).  Host-side I/O: th
 not in this image; Pillow reads the single-band PNG / TIFF files, tiff_reader.py the multi-sample TIFFs (multiband images,
 two-band disparity grids); a GeoTIFF's georeferencing tags ride along in attrs["crs"] / attrs["transform"] and are written back
 by common.save_results.  ROI windows (get_window) are cut out of the decoded raster.  Classification / segmentation / edge layers
-are outside this build and refused loudly."""
+(img_tools.py:165-231) ride along as int16 variables: the SGM step's geometric_prior reads them."""
 from collections import namedtuple
 
 import numpy as np
@@ -119,9 +119,6 @@ def create_dataset_from_inputs(input_config, roi=None):
     and the row / col coordinates start at its offset (img_tools.py:377-398)."""
     params = {"mask": None, "classif": None, "segm": None, "edges": None}
     params.update(input_config)
-    for layer in ("classif", "segm", "edges"):
-        if params[layer] is not None:
-            raise NotImplementedError(f"the '{layer}' layer is out of scope of pandora_amd")
     data, names = _read_raster(params["img"])
     data = data.astype(np.float32)
     window = get_window(roi, data.shape[-1], data.shape[-2]) if roi else None
@@ -149,4 +146,26 @@ def create_dataset_from_inputs(input_config, roi=None):
     else:
         no_data_pixels = np.where(data == no_data)
     add_no_data(dataset, no_data, no_data_pixels)
+    add_layers(dataset, params, window)
     return add_mask(dataset, params["mask"], no_data_pixels, nx_, ny_, window)
+
+
+def add_layers(dataset, params, window=None):
+    """img_tools.py:165-231 add_classif / add_segm / add_edges: "classif" int16 (band_classif, row, col) with the band names of
+    the file as the band_classif coordinate, "segm" and "edges" int16 (row, col) from the first band."""
+    ny_, nx_ = np.asarray(dataset["im"].data).shape[-2:]
+    if params.get("classif") is not None:
+        data, names = _read_raster(params["classif"])
+        data = _cut(data if data.ndim == 3 else data[np.newaxis], window).astype(np.int16)
+        if data.shape[-2:] != (ny_, nx_):
+            raise ValueError("the classification must have the image's dimensions (plugin_libsgm.rst:58)")
+        dataset.coords["band_classif"] = np.asarray(names if names else [None] * data.shape[0], dtype=object)
+        dataset["classif"] = DataArray(data, ("band_classif", "row", "col"))
+    for layer in ("segm", "edges"):
+        if params.get(layer) is not None:
+            data, _ = _read_raster(params[layer])
+            data = _cut(data if data.ndim == 2 else data[0], window).astype(np.int16)
+            if data.shape != (ny_, nx_):
+                raise ValueError(f"the {layer} layer must have the image's dimensions (plugin_libsgm.rst:58)")
+            dataset[layer] = DataArray(data, ("row", "col"))
+    return dataset

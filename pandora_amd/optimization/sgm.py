@@ -12,6 +12,14 @@ p2_method (plugin_libsgm.rst:20-27, 168-290): "constant"; "negativeGradient": P2
 path.  This build's reading of what the documentation leaves open: the configured P2 is the floor of the adaptive value
 (P2 > P1 keeps the recurrence's order of penalties), the gradient of a path's first pixel is 0 (its update ignores P2).
 The maps are 2-D host work (numpy), the recurrence runs on the device (pmx_sgm_p2maps).
+
+geometric_prior (3SGM's piecewise optimisation, plugin_libsgm.rst:49-78): "For each segment, optimization will only be applied
+inside this segment"; "when using edges, the optimization paths will stop at the first edge found".  Read as: a path that would
+step from p-r to p across a segment border starts again at p (L_r(p, d) = C(p, d), as at the image border) - for "segm" when the
+two pixels carry different values, for "classif" when they differ in the selected classes, for "edges" when either of them is an
+edge pixel (value > 0).  No kernel of its own: a restart IS the update with P2 = 0 (min(L(p-r, d), ..., M + 0) = M, so
+L = C + (M - M)), bit for bit, so the cut (pixel, direction) pairs become zeros of the penalty maps.  "internal" (the default) cuts
+nothing, as in the plugin.  UNPINNED like everything SGM.
 """
 import numpy as np
 
@@ -34,6 +42,8 @@ class Sgm(AbstractOptimization):
         self._alpha, self._beta, self._gamma = float(pen.get("alpha", 1.0)), float(pen.get("beta", 1)), float(pen.get("gamma", 1))
         self._overcounting = bool(self.cfg["overcounting"])
         self._use_confidence = self.cfg.get("use_confidence") or None
+        prior = self.cfg.get("geometric_prior") or {"source": "internal"}
+        self._prior_source, self._prior_classes = prior["source"], list(prior.get("classes", []))
 
     def check_conf(self, **cfg):
         cfg.setdefault("overcounting", self._OVERCOUNTING)
@@ -64,8 +74,15 @@ class Sgm(AbstractOptimization):
             raise ConfigError("penalties must satisfy 0 < P1 < P2 (plugin_libsgm.rst:170-185)")
         if cfg["min_cost_paths"]:
             raise ConfigError("min_cost_paths is not implemented")
-        if cfg.get("geometric_prior") not in (None, False, {"source": "internal"}):
-            raise ConfigError("geometric_prior (piecewise optimisation) is out of scope of pandora_amd")
+        prior = cfg.get("geometric_prior")
+        if prior not in (None, False):  # plugin_libsgm.rst:122-137
+            if not isinstance(prior, dict) or prior.get("source") not in ("internal", "classif", "segm", "edges"):
+                raise ConfigError("geometric_prior is {'source': 'internal' | 'classif' | 'segm' | 'edges'[, 'classes': [...]]}")
+            if prior["source"] == "classif":
+                if not isinstance(prior.get("classes"), (list, tuple)) or not prior["classes"]:
+                    raise ConfigError("geometric_prior with source 'classif' needs the list of 'classes' to use")
+            elif set(prior) - {"source"}:
+                raise ConfigError("geometric_prior: 'classes' goes with source 'classif' only")
         use = cfg.get("use_confidence")
         if use not in (None, False) and not (isinstance(use, str) and use.split(".")[0] == "cost_volume_confidence"):
             raise ConfigError("use_confidence names the cost_volume_confidence step whose ambiguity is applied, "
@@ -93,11 +110,17 @@ class Sgm(AbstractOptimization):
                 layer = list(cv.coords["indicator"]).index(name)
                 dcv.engine.scale_pixels(dcv, np.asarray(cv["confidence_measure"].data)[:, :, layer])
         p2_top = self._p2
-        if self._p2_method == "constant":
+        cuts = self.path_cuts(img_left) if self._prior_source != "internal" else None
+        if self._p2_method == "constant" and cuts is None:
             dcv.engine.sgm(dcv, self._p1, self._p2, is_max, invalid_cost, self._overcounting)
         else:
-            maps = self.p2_maps(self._band_of(img_left, cv))
+            if self._p2_method == "constant":
+                maps = np.full((8,) + cuts.shape[1:], np.float32(self._p2), np.float32)
+            else:
+                maps = self.p2_maps(self._band_of(img_left, cv))
             p2_top = float(maps.max())
+            if cuts is not None:
+                maps[cuts] = 0.0  # the path starts again here: the update with P2 = 0 is L = C (module docstring)
             dcv.engine.sgm_p2maps(dcv, self._p1, maps, is_max, invalid_cost, self._overcounting)
         cv.attrs["optimization"] = "sgm"
         cv.attrs["cmax"] = 8.0 * (cmax + p2_top)  # upper bound of the 8-path sum
@@ -115,6 +138,35 @@ class Sgm(AbstractOptimization):
         band = cv.attrs.get("band_correl")
         names = [str(b) for b in np.asarray(img_left.coords["band_im"])]
         return im[names.index(band)] if band in names else im[0]
+
+    def path_cuts(self, img):
+        """bool [8][H][W]: True where the path of direction k that arrives at pixel p crosses a border of the geometric prior
+        between p - r and p (it then starts again at p).  Needs the layer the configuration names in the image dataset
+        (img_tools.py:165-231: "segm" / "edges" int16 (row, col), "classif" int16 (band_classif, row, col))."""
+        src = self._prior_source
+        if src not in img.data_vars:
+            raise AttributeError(f"geometric_prior source '{src}' is not in the image dataset (no {src} layer was given)")
+        layer = np.asarray(img[src].data)
+        if src == "classif":
+            names = [str(b) for b in np.asarray(img.coords["band_classif"])]
+            missing = [c for c in self._prior_classes if str(c) not in names]
+            if missing:
+                raise AttributeError(f"geometric_prior classes {missing} are not bands of the classification {names}")
+            label = np.zeros(layer.shape[1:], np.int64)  # which of the selected classes a pixel belongs to, as one number
+            for i, c in enumerate(self._prior_classes):
+                label |= (layer[names.index(str(c))] != 0).astype(np.int64) << i
+        elif src == "edges":
+            label = layer > 0
+        else:
+            label = layer
+        H, W = label.shape
+        cuts = np.zeros((8, H, W), bool)
+        for k, (dr, dc) in enumerate(self.DIRECTIONS):
+            r0, r1 = max(dr, 0), H + min(dr, 0)
+            c0, c1 = max(dc, 0), W + min(dc, 0)
+            here, before = label[r0:r1, c0:c1], label[r0 - dr:r1 - dr, c0 - dc:c1 - dc]
+            cuts[k, r0:r1, c0:c1] = (here | before) if src == "edges" else (here != before)
+        return cuts
 
     def p2_maps(self, image):
         """float32 [8][H][W]: the P2 that enters pixel p's update on each path, from the left image's gradient along the path"""

@@ -542,3 +542,70 @@ def test_machine_keeps_its_maps_on_the_device_until_they_are_read():
     np.testing.assert_array_equal(lazy.data & 0b111, vm & 0b111)
     assert (lazy.data[:2] == 1).all() and (lazy.data[:, -2:] == 1).all() and not lazy.pending
     assert np.isfinite(out["disparity_map"].data[10:-10, 20:-10]).all()
+
+
+def test_geometric_prior_optimises_every_segment_on_its_own():
+    """plugin_libsgm.rst:49-78 (3SGM's piecewise optimisation): "for each segment, optimization will only be applied inside this
+    segment".  (1) The machine with a segmentation, the reference's classification file or an edge map == the restatement with
+    the same penalty maps (the cut (pixel, direction) pairs are zeros of the P2 maps), bit for bit; (2) what the sentence says:
+    with the image cut in two by a vertical segment border, each half comes out exactly as if it had been optimised alone."""
+    from PIL import Image
+
+    from oracle import capi as orc
+    from pandora_amd import optimization, runtime
+
+    cones = os.path.join(os.path.dirname(__file__), "golden", "cones")
+    L = np.array(Image.open(os.path.join(cones, "left.png"))).astype(np.float32)[100:180, 60:200]
+    R = np.array(Image.open(os.path.join(cones, "right.png"))).astype(np.float32)[100:180, 60:200]
+    from pandora_amd.tiff_reader import read_tiff
+    classif = read_tiff(os.path.join(cones, "left_classif.tif"))[0][:, 100:180, 60:200].astype(np.int16)
+    H, W = L.shape
+    segm = np.zeros((H, W), np.int16)
+    segm[:, 77:] = 4
+    segm[20:40, 30:60] = 9
+    edges = np.zeros((H, W), np.int16)
+    edges[50, :] = 1
+    edges[:, 100] = 3
+    layers = {"segm": dict(segm=segm), "edges": dict(edges=edges), "classif": dict(classif=(classif, ["cornfields", "olive tree", "forest"]))}
+    for source, kw in layers.items():
+        for p2_method in ("constant", "inverseGradient"):
+            prior = {"source": source}
+            if source == "classif":
+                prior["classes"] = ["olive tree", "forest"]
+            pen = {"P1": 8, "P2": 32, "p2_method": p2_method}
+            cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5},
+                                "optimization": {"optimization_method": "sgm", "penalty": pen, "geometric_prior": prior},
+                                "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"}}}
+            left, right = make_image(L, disparity=[-30, 0], **kw), make_image(R)
+            machine = PandoraMachine()
+            cfg["pipeline"] = machine.check_conf(cfg, left, right)["pipeline"]
+            pandora_amd.run(machine, left, right, cfg)
+            got = machine.left_cv["cost_volume"].data
+            plugin = optimization.AbstractOptimization(None, **cfg["pipeline"]["optimization"])
+            maps = (np.full((8, H, W), 32, np.float32) if p2_method == "constant" else plugin.p2_maps(L))
+            cuts = plugin.path_cuts(left)
+            assert cuts.any() and not cuts.all()
+            maps[cuts] = 0
+            cost = orc.census_cost(L, R, 31, -30, 1, 5)
+            want = orc.sgm_p2maps(cost, 8.0, maps, False, 26.0)
+            np.testing.assert_array_equal(got, want, err_msg=f"{source} {p2_method}")
+    # (2) a vertical border at column 77: every half as if optimised alone
+    eng = runtime.get_engine()
+    cost = orc.census_cost(L, R, 31, -30, 1, 5)
+    cuts = optimization.AbstractOptimization(None, optimization_method="sgm", geometric_prior={"source": "segm"}).path_cuts(
+        make_image(L, segm=(np.arange(W) >= 77).astype(np.int16)[None, :].repeat(H, 0)))
+    maps = np.full((8, H, W), 32, np.float32)
+    maps[cuts] = 0
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(31, -30)
+    cv.from_host(cost)
+    eng.sgm_p2maps(cv, 8.0, maps, False, 26.0)
+    whole = cv.to_host()
+    cv.free()
+    for lo, hi in ((0, 77), (77, W)):
+        eng.set_images(np.ascontiguousarray(L[:, lo:hi]), np.ascontiguousarray(R[:, lo:hi]), 1)
+        half = eng.alloc_cv(31, -30)
+        half.from_host(np.ascontiguousarray(cost[:, lo:hi]))
+        eng.sgm(half, 8.0, 32.0, False, 26.0)
+        np.testing.assert_array_equal(whole[:, lo:hi], half.to_host(), err_msg=f"columns {lo}:{hi}")
+        half.free()

@@ -395,7 +395,7 @@ def test_create_dataset_from_inputs_reference_vectors():
     # no mask and no no-data pixel: no msk at all (img_tools.py:283-285); inf as no-data (test_pandora_image.py:631-668)
     ds = img_tools.create_dataset_from_inputs({"img": os.path.join(gold, "left_img.tif"), "nodata": 12345, "disp": [0, 2]})
     assert "msk" not in ds.data_vars
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):
         img_tools.create_dataset_from_inputs({"img": os.path.join(gold, "left_img.tif"), "nodata": 0, "classif": "x.tif"})
     with pytest.raises(AttributeError):
         check_datasets(img_tools.create_dataset_from_inputs({"img": os.path.join(gold, "left_img.tif"), "nodata": 0}), ds)
@@ -477,7 +477,7 @@ def test_sgm_use_confidence_configuration():  # plugin_libsgm.rst:38-47, :88-209
     with pytest.raises(ConfigError):
         optimization.AbstractOptimization(None, optimization_method="sgm", use_confidence="ambiguity")
     with pytest.raises(ConfigError):
-        optimization.AbstractOptimization(None, optimization_method="sgm", geometric_prior={"source": "segm"})
+        optimization.AbstractOptimization(None, optimization_method="sgm", geometric_prior={"source": "superpixels"})
 
 
 def test_tiff_reader_and_multiband_inputs(tmp_path):
@@ -764,3 +764,71 @@ def test_validity_mask_is_a_recipe_until_somebody_reads_it():
                                                                 left["disparity"].sel(band_disp="max").data)))
     assert isinstance(cvm["validity_mask"], criteria.LazyValidity) and cvm["validity_mask"]._base.shape == (6, 9)
     assert cvm["validity_mask"].data[2, 4] & 1
+
+
+def test_classification_segmentation_and_edge_layers_in_the_dataset(tmp_path):
+    """img_tools.py:165-231 add_classif / add_segm / add_edges: the reference's own classification file (tests/pandora/
+    left_classif.tif, test_pandora_image.py:466-484: bands "cornfields", "olive tree", "forest") next to the cones image, int16,
+    also through a ROI window; segm / edges from single-band files."""
+    from PIL import Image
+
+    from pandora_amd import img_tools
+
+    cones = os.path.join(ROOT, "tests", "golden", "cones")
+    cfg = {"img": os.path.join(cones, "left.png"), "nodata": -9999, "classif": os.path.join(cones, "left_classif.tif"), "disp": [-60, 0]}
+    ds = img_tools.create_dataset_from_inputs(cfg)
+    assert list(ds.coords["band_classif"]) == ["cornfields", "olive tree", "forest"]
+    assert ds["classif"].data.shape == (3, 375, 450) and ds["classif"].data.dtype == np.int16 and ds["classif"].dims == ("band_classif", "row", "col")
+    assert [int(b.sum()) for b in ds["classif"].data] == [5643, 14973, 3468]
+    roi = {"col": {"first": 10, "last": 100}, "row": {"first": 10, "last": 100}, "margins": [2, 3, 4, 5]}
+    win = img_tools.create_dataset_from_inputs(cfg, roi)
+    np.testing.assert_array_equal(win["classif"].data, ds["classif"].data[:, 7:106, 8:105])
+    segm = np.zeros((375, 450), np.int16)
+    segm[:, 200:] = 7
+    edges = np.zeros((375, 450), np.float32)
+    edges[100, :] = 0.5  # (a float edge map: "higher than zero" - but the reference reads it as int16, img_tools.py:228)
+    Image.fromarray(segm).save(tmp_path / "segm.tif")
+    Image.fromarray(edges).save(tmp_path / "edges.tif")
+    ds2 = img_tools.create_dataset_from_inputs({"img": cfg["img"], "nodata": -9999, "segm": str(tmp_path / "segm.tif"),
+                                                "edges": str(tmp_path / "edges.tif"), "disp": [-60, 0]})
+    np.testing.assert_array_equal(ds2["segm"].data, segm)
+    assert ds2["edges"].data.dtype == np.int16 and ds2["edges"].data.sum() == 0
+    with pytest.raises(ValueError, match="dimensions"):
+        Image.fromarray(segm[:10]).save(tmp_path / "small.tif")
+        img_tools.create_dataset_from_inputs({"img": cfg["img"], "nodata": -9999, "segm": str(tmp_path / "small.tif"), "disp": [-60, 0]})
+
+
+def test_geometric_prior_configuration_and_cuts():
+    """plugin_libsgm.rst:49-78, :122-137: the geometric_prior option of the SGM step and the (pixel, direction) pairs at which a
+    path starts again - hand-made layers, every direction of the definition's order."""
+    sgm = lambda **kw: optimization.AbstractOptimization(None, optimization_method="sgm", **kw)
+    assert sgm().cfg.get("geometric_prior") is None and sgm(geometric_prior={"source": "internal"})._prior_source == "internal"
+    for bad in ({"source": "superpixels"}, {"source": "classif"}, {"source": "classif", "classes": []}, {"source": "segm", "classes": ["a"]}, "segm"):
+        with pytest.raises(ConfigError):
+            sgm(geometric_prior=bad)
+    segm = np.array([[1, 1, 2, 2],
+                     [1, 1, 2, 2],
+                     [3, 3, 3, 2]], np.int16)
+    img = make_image(np.zeros((3, 4), np.float32), segm=segm)
+    cuts = sgm(geometric_prior={"source": "segm"}).path_cuts(img)
+    assert cuts.shape == (8, 3, 4) and cuts.dtype == bool
+    np.testing.assert_array_equal(cuts[0], [[0, 0, 1, 0], [0, 0, 1, 0], [0, 0, 0, 1]])  # (0,+1): coming from the left neighbour
+    np.testing.assert_array_equal(cuts[1], [[0, 1, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]])  # (0,-1): from the right neighbour
+    np.testing.assert_array_equal(cuts[2], [[0, 0, 0, 0], [0, 0, 0, 0], [1, 1, 1, 0]])  # (+1,0): from above
+    np.testing.assert_array_equal(cuts[5], [[0, 0, 0, 0], [1, 1, 1, 0], [0, 0, 0, 0]])  # (-1,0): from below
+    np.testing.assert_array_equal(cuts[3], [[0, 0, 0, 0], [0, 0, 1, 0], [0, 1, 1, 0]])  # (+1,+1): from the upper left
+    np.testing.assert_array_equal(cuts[7], [[0, 1, 0, 0], [1, 1, 0, 0], [0, 0, 0, 0]])  # (-1,-1): from the lower right
+    edges = np.zeros((3, 4), np.int16)
+    edges[1, 1] = 5
+    ecuts = sgm(geometric_prior={"source": "edges"}).path_cuts(make_image(np.zeros((3, 4), np.float32), edges=edges))
+    np.testing.assert_array_equal(ecuts[0], [[0, 0, 0, 0], [0, 1, 1, 0], [0, 0, 0, 0]])  # the edge pixel and the pixel behind it
+    np.testing.assert_array_equal(ecuts[2], [[0, 0, 0, 0], [0, 1, 0, 0], [0, 1, 0, 0]])
+    bands = np.stack([segm == 1, segm == 2, segm == 3]).astype(np.int16)
+    img_c = make_image(np.zeros((3, 4), np.float32), classif=(bands, ["a", "b", "c"]))
+    np.testing.assert_array_equal(sgm(geometric_prior={"source": "classif", "classes": ["a", "b", "c"]}).path_cuts(img_c), cuts)
+    only_b = sgm(geometric_prior={"source": "classif", "classes": ["b"]}).path_cuts(img_c)  # a and c are one background now
+    np.testing.assert_array_equal(only_b[2], [[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 1, 0]])
+    with pytest.raises(AttributeError):
+        sgm(geometric_prior={"source": "classif", "classes": ["d"]}).path_cuts(img_c)
+    with pytest.raises(AttributeError):
+        sgm(geometric_prior={"source": "segm"}).path_cuts(img_c)
