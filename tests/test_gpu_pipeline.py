@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def oracle_pipeline(oracle, L, R, cfg, dmin, dmax, mskL=None, mskR=None, validity0=None):
+def oracle_pipeline(oracle, L, R, cfg, dmin, dmax, mskL=None, mskR=None, validity0=None, layers=None):
     p = cfg["pipeline"]
     mc = p["matching_cost"]
     win, sp = mc.get("window_size", 5), mc.get("subpix", 1)
@@ -57,7 +57,17 @@ def oracle_pipeline(oracle, L, R, cfg, dmin, dmax, mskL=None, mskR=None, validit
         cmax = cmax * (2 * dist - 1) ** 2
     if "optimization" in p:
         pen = p["optimization"].get("penalty", {})
-        cv = oracle.sgm(cv, pen.get("P1", 8), pen.get("P2", 32), is_max, float(cmax) + 1.0, p["optimization"].get("overcounting", False))
+        prior = p["optimization"].get("geometric_prior") or {"source": "internal"}
+        if pen.get("p2_method", "constant") == "constant" and prior["source"] == "internal":
+            cv = oracle.sgm(cv, pen.get("P1", 8), pen.get("P2", 32), is_max, float(cmax) + 1.0, p["optimization"].get("overcounting", False))
+        else:  # penalty maps: the plugin's host-side 2-D work (hand-checked in test_host_api.py), the recurrence restated
+            from pandora_amd import optimization as popt
+
+            plug = popt.AbstractOptimization(None, **json.loads(json.dumps(p["optimization"])))
+            maps = (np.full((8,) + L.shape, np.float32(plug._p2), np.float32) if plug._p2_method == "constant" else plug.p2_maps(L))
+            if prior["source"] != "internal":
+                maps[plug.path_cuts(make_image(L, **(layers or {})))] = 0
+            cv = oracle.sgm_p2maps(cv, pen.get("P1", 8), maps, is_max, float(cmax) + 1.0, p["optimization"].get("overcounting", False))
     inv = p["disparity"].get("invalid_disparity", -9999)
     inv = np.nan if inv == "NaN" else inv
     disp, val = oracle.wta(cv, dmin, sp, is_max, inv, validity0)
@@ -67,8 +77,8 @@ def oracle_pipeline(oracle, L, R, cfg, dmin, dmax, mskL=None, mskR=None, validit
     return cv, disp, val, itp
 
 
-def run_machine(L, R, cfg, dmin, dmax, mskL=None, mskR=None):
-    left = make_image(L, disparity=[dmin, dmax], msk=mskL)
+def run_machine(L, R, cfg, dmin, dmax, mskL=None, mskR=None, layers=None):
+    left = make_image(L, disparity=[dmin, dmax], msk=mskL, **(layers or {}))
     right = make_image(R, msk=mskR)
     machine = PandoraMachine()
     cfg = json.loads(json.dumps(cfg))

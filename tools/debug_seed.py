@@ -10,7 +10,7 @@ src = open("tools/fuzz_machine.py").read().split("fails = 0")[0]
 ns = {}
 exec(compile(src, "fm", "exec"), ns)
 seed = int(sys.argv[1])
-cfg, L, R, dmin, dmax, mskL, mskR = ns["draw"](seed)
+cfg, L, R, dmin, dmax, mskL, mskR, layers = ns["draw"](seed)
 print(json.dumps(cfg), L.shape, dmin, dmax, mskL is not None, mskR is not None, "integer" if (L == np.round(L)).all() else "float")
 steps = list(cfg["pipeline"])
 for n in range(1, len(steps) + 1):
@@ -20,11 +20,11 @@ for n in range(1, len(steps) + 1):
     for lazy in (True, False):
         from pandora_amd import runtime
         runtime.get_engine().set_lazy(lazy)
-        machine, got = tp.run_machine(L, R, json.loads(json.dumps(sub)), dmin, dmax, mskL, mskR)
+        machine, got = tp.run_machine(L, R, json.loads(json.dumps(sub)), dmin, dmax, mskL, mskR, layers)
         mc_only = {"pipeline": {"matching_cost": cfg["pipeline"]["matching_cost"], "disparity": {"disparity_method": "wta"}}}
         cv0, _, _, _ = tp.oracle_pipeline(orc, L, R, mc_only, dmin, dmax, mskL, mskR)
         val0 = tp.expected_validity(L, R, sub, dmin, dmax, mskL, mskR, np.min(np.isnan(cv0), axis=2))
-        ecv, edisp, eval_, eitp = tp.oracle_pipeline(orc, L, R, sub, dmin, dmax, mskL, mskR, val0)
+        ecv, edisp, eval_, eitp = tp.oracle_pipeline(orc, L, R, sub, dmin, dmax, mskL, mskR, val0, layers)
         g = machine.left_cv["cost_volume"].data
         bad = ~((g == ecv) | (np.isnan(g) & np.isnan(ecv)))
         print(steps[:n][-1], "lazy" if lazy else "eager", "cv mismatches", int(bad.sum()), "disp mismatches",

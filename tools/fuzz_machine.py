@@ -35,22 +35,44 @@ def draw(seed):
         cfg["pipeline"]["refinement"] = {"refinement_method": str(rng.choice(["vfit", "quadratic"]))}
     integer = bool(rng.random() < 0.6)
     L, R = tp.pair(H, W, seed=seed, integer=integer)
+    layers = None
+    if "optimization" in cfg["pipeline"] and rng.random() < 0.35:  # penalty methods that follow the image, geometric priors
+        pen = cfg["pipeline"]["optimization"]["penalty"]
+        how = rng.random()
+        if how < 0.6:
+            pen["p2_method"] = str(rng.choice(["negativeGradient", "inverseGradient"]))
+            pen["alpha"], pen["gamma"] = float(rng.choice([0.5, 1.0, 3.0])), float(rng.choice([1, 20, 60]))
+            if pen["p2_method"] == "inverseGradient":
+                pen["beta"] = float(rng.choice([0.5, 1, 4]))
+        if how > 0.4:
+            source = str(rng.choice(["segm", "edges", "classif"]))
+            prior = {"source": source}
+            if source == "segm":
+                lab = rng.integers(0, 3, (H // 7 + 1, W // 9 + 1))
+                layers = {"segm": np.kron(lab, np.ones((7, 9), int))[:H, :W]}
+            elif source == "edges":
+                layers = {"edges": (rng.random((H, W)) < 0.06).astype(np.int16) * rng.integers(1, 4, (H, W)).astype(np.int16)}
+            else:
+                bands = (rng.random((3, H, W)) < 0.3).astype(np.int16)
+                layers = {"classif": (bands, ["a", "b", "c"])}
+                prior["classes"] = [str(x) for x in rng.choice(["a", "b", "c"], int(rng.integers(1, 4)), replace=False)]
+            cfg["pipeline"]["optimization"]["geometric_prior"] = prior
     mskL = mskR = None
     if rng.random() < 0.5:
         mskL = rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 2], (H, W)).astype(np.int16)
         if rng.random() < 0.6:
             mskR = rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 2], (H, W)).astype(np.int16)
-    return cfg, L, R, dmin, dmax, mskL, mskR
+    return cfg, L, R, dmin, dmax, mskL, mskR, layers
 
 
 def one(seed):
-    cfg, L, R, dmin, dmax, mskL, mskR = draw(seed)
+    cfg, L, R, dmin, dmax, mskL, mskR, layers = draw(seed)
     sp = cfg["pipeline"]["matching_cost"]["subpix"]
-    machine, got = tp.run_machine(L, R, cfg, dmin, dmax, mskL, mskR)
+    machine, got = tp.run_machine(L, R, cfg, dmin, dmax, mskL, mskR, layers)
     mc_only = {"pipeline": {"matching_cost": cfg["pipeline"]["matching_cost"], "disparity": {"disparity_method": "wta"}}}
     cv0, _, _, _ = tp.oracle_pipeline(orc, L, R, mc_only, dmin, dmax, mskL, mskR)
     val0 = tp.expected_validity(L, R, cfg, dmin, dmax, mskL, mskR, np.min(np.isnan(cv0), axis=2))
-    ecv, edisp, eval_, eitp = tp.oracle_pipeline(orc, L, R, cfg, dmin, dmax, mskL, mskR, val0)
+    ecv, edisp, eval_, eitp = tp.oracle_pipeline(orc, L, R, cfg, dmin, dmax, mskL, mskR, val0, layers)
     np.testing.assert_array_equal(machine.left_cv["cost_volume"].data, ecv)
     np.testing.assert_array_equal(got["disparity_map"].data, edisp)
     np.testing.assert_array_equal(got["validity_mask"].data, eval_)
@@ -64,7 +86,7 @@ for seed in range(int(os.environ.get("FUZZ_FROM", "0")), int(os.environ.get("FUZ
         one(seed)
     except Exception as e:  # noqa: BLE001
         fails += 1
-        cfg, L, R, dmin, dmax, mskL, mskR = draw(seed)
+        cfg, L, R, dmin, dmax, mskL, mskR, _ = draw(seed)
         print("FAIL", seed, json.dumps(cfg), L.shape, dmin, dmax, mskL is not None, mskR is not None, type(e).__name__, str(e)[:300].replace("\n", " "))
         if fails > 10:
             break
