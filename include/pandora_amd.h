@@ -362,6 +362,10 @@ int pmx_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float possibility_threshold, f
  * resident one?" (the reference has no residency; any changed word changes the value; not cryptographic). */
 int pmx_host_minmax_i64(const int64_t* a, size_t n, int64_t* out_min, int64_t* out_max);
 uint64_t pmx_host_fingerprint(const void* data, size_t bytes);
+/* Order statistics of a float32 array: out[i] = the ranks[i]-th smallest value (0-based; NaNs sort last, as in numpy) - what
+ * np.percentile's partition provides to the percentile normalisation of the ambiguity measure
+ * (cost_volume_confidence/ambiguity.py:168-184), by radix selection on the device instead of a host-side partition. */
+int pmx_order_statistics(pmx_ctx* ctx, const float* values, size_t n, const size_t* ranks, int n_ranks, float* out);
 /* Page-locked host memory for the caller's image / result arrays (the reference works in pageable numpy memory; over PCIe a
  * pinned buffer copies at the link rate and without first-touch page faults under the DMA).  NULL on failure. */
 void* pmx_host_alloc(size_t bytes);

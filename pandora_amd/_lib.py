@@ -45,6 +45,7 @@ SIGNATURES = {
     "pmx_zncc": (C.c_int, [vp, vp, C.c_int]),
     "pmx_cv_masked": (C.c_int, [vp, vp, C.c_int]),
     "pmx_nan_pixels": (C.c_int, [vp, vp, C.POINTER(C.c_uint8)]),
+    "pmx_order_statistics": (C.c_int, [vp, c_float_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, c_float_p]),
     "pmx_host_minmax_i64": (C.c_int, [c_i64_p, C.c_size_t, c_i64_p, c_i64_p]),
     "pmx_host_fingerprint": (C.c_uint64, [vp, C.c_size_t]),
     "pmx_cv_mark_missing": (C.c_int, [vp, vp]),

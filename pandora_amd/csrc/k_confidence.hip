@@ -1,5 +1,7 @@
 // k_confidence.hip - SURVEY 8f N4: the ambiguity integral of cost_volume_confidence (a reduction over D on the resident
 // float32 volume).  gfx950.
+#include <cstring>
+
 #include "pmx_internal.h"
 
 static constexpr int kBlock = 256;
@@ -396,5 +398,58 @@ int pmx_launch_interval_bounds(pmx_ctx* ctx, pmx_cv* cv, float threshold, float 
     const size_t want = (npix + 15) / 16;
     hipLaunchKernelGGL(interval_bounds_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream, a);
     PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+
+// ---- order statistics of a float32 map (np.percentile's partition, ambiguity.py:168-184) ---------------------------------------
+// The k-th smallest of n values by radix selection on order-preserving 32-bit keys: three histogram passes (11 + 11 + 10 bits),
+// each over the values whose higher bits match what the earlier passes chose.  Exact (it returns an element of the input), no
+// sort.  NaNs sort last, as in numpy; their count comes back with the first pass.
+__device__ __forceinline__ uint32_t os_key(float v) {
+    const uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN of either sign: last
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void os_hist_kernel(const float* __restrict__ v, size_t n, uint32_t prefix, int prefix_bits, int shift,
+                                                      int bits, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[2048];
+    const int nb = 1 << bits;
+    for (int i = threadIdx.x; i < nb; i += 256) h[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t k = os_key(v[i]);
+        if (prefix_bits == 0 || (k >> (32 - prefix_bits)) == prefix) atomicAdd(&h[(k >> shift) & (uint32_t)(nb - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+int pmx_launch_order_statistic(pmx_ctx* ctx, const float* dev_values, size_t n, size_t rank, uint32_t* dev_hist, uint32_t* host_hist,
+                               float* out) {
+    const int widths[3] = {11, 11, 10};
+    uint32_t prefix = 0;
+    int prefix_bits = 0;
+    size_t k = rank;  // rank among the values that share the prefix
+    for (int pass = 0; pass < 3; ++pass) {
+        const int bits = widths[pass], shift = 32 - prefix_bits - bits;
+        PMX_HIP(hipMemsetAsync(dev_hist, 0, 2048 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(os_hist_kernel, dim3(1024), dim3(256), 0, ctx->stream, dev_values, n, prefix, prefix_bits, shift, bits, dev_hist);
+        PMX_HIP(hipMemcpyAsync(host_hist, dev_hist, ((size_t)1 << bits) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        uint32_t b = 0;
+        for (; b < (1u << bits); ++b) {
+            if (k < host_hist[b]) break;
+            k -= host_hist[b];
+        }
+        PMX_CHECK(b < (1u << bits), PMX_ERR_STATE, "pmx_order_statistics: rank beyond the values (internal)");
+        prefix = (prefix << bits) | b;
+        prefix_bits += bits;
+    }
+    uint32_t u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;  // the key back to the float's bits
+    if (prefix == 0xffffffffu) u = 0x7fc00000u;  // (NaN)
+    memcpy(out, &u, sizeof(float));
     return PMX_OK;
 }

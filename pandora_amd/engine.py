@@ -583,6 +583,15 @@ class Engine:
         return lo, hi
 
     # -- cost-volume confidence -------------------------------------------------------
+    def order_statistics(self, values, ranks):
+        """float32 array of the ranks-th smallest values of ``values`` (0-based, NaNs last): pmx_order_statistics."""
+        v = np.ascontiguousarray(values, np.float32).ravel()
+        r = np.ascontiguousarray(ranks, np.uint64)
+        out = np.empty(len(r), np.float32)
+        check(_lib.lib().pmx_order_statistics(self.ctx, _p(v, C.c_float), v.size, r.ctypes.data_as(C.POINTER(C.c_size_t)), len(r),
+                                              _p(out, C.c_float)), "pmx_order_statistics")
+        return out
+
     def ambiguity(self, cv, etas, grid_min, grid_max, negate=False):
         """ambiguity.cpp:28-142 on the resident volume -> float32 [H][W] integral of the ambiguity (not normalised)."""
         e = np.ascontiguousarray(etas, np.float32)

@@ -1368,3 +1368,30 @@ def test_swapped_pair_equals_the_pair_uploaded_the_other_way_round(eng, subpix):
     for a, b in zip(*vols):
         np.testing.assert_array_equal(a, b)
     assert all(np.isfinite(v).any() and np.isnan(v).any() for v in vols[0])
+
+
+def test_percentiles_from_device_order_statistics(eng):
+    """pmx_order_statistics (radix selection) == np.partition's elements, and ambiguity.percentiles == np.percentile bit for bit:
+    random maps, heavy ties, negative values, infinities, a map with NaNs (numpy's answer is NaN), percentiles at both ends."""
+    from pandora_amd.cost_volume_confidence.ambiguity import percentiles
+
+    rng = np.random.default_rng(17)
+    n = 300 * 401
+    maps = {"normal": rng.normal(0, 50, n).astype(np.float32),
+            "ties": rng.integers(0, 70, n).astype(np.float32),
+            "ambiguity-like": (rng.integers(0, 71, n) + rng.integers(0, 2, n) * 0.5).astype(np.float32),
+            "with infinities": np.where(rng.random(n) < 0.01, np.inf, rng.normal(0, 1, n)).astype(np.float32) * np.where(rng.random(n) < 0.5, -1, 1).astype(np.float32),
+            "tiny and huge": (rng.normal(0, 1, n) * 10.0 ** rng.integers(-30, 30, n)).astype(np.float32)}
+    for name, a in maps.items():
+        ranks = sorted({0, 1, n // 3, n // 2, n - 2, n - 1, int(0.01 * (n - 1)), int(0.99 * (n - 1))})
+        want = np.sort(a)[ranks]
+        np.testing.assert_array_equal(eng.order_statistics(a, ranks), want, err_msg=name)
+        for qs in ((1.0, 99.0), (0.0, 100.0), (37.123, 50.0), (2.5, 97.5)):
+            got = percentiles(a.reshape(300, 401), qs)
+            for g, q in zip(got, qs):
+                w = np.percentile(a, q)
+                assert g.dtype == w.dtype and (g == w or (np.isnan(g) and np.isnan(w))), (name, q, g, w)
+    b = maps["normal"].copy()
+    b[[5, 777]] = [np.nan, -np.nan]
+    assert np.isnan(eng.order_statistics(b, [n - 1, n - 2])).all() and not np.isnan(eng.order_statistics(b, [n - 3])).any()
+    assert all(np.isnan(p) for p in percentiles(b, (1.0, 99.0)))
