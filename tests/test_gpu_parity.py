@@ -1387,9 +1387,10 @@ def test_percentiles_from_device_order_statistics(eng):
         want = np.sort(a)[ranks]
         np.testing.assert_array_equal(eng.order_statistics(a, ranks), want, err_msg=name)
         for qs in ((1.0, 99.0), (0.0, 100.0), (37.123, 50.0), (2.5, 97.5)):
-            got = percentiles(a.reshape(300, 401), qs)
-            for g, q in zip(got, qs):
-                w = np.percentile(a, q)
+            with np.errstate(invalid="ignore"):  # (inf - inf inside numpy's interpolation between two infinities)
+                got = percentiles(a.reshape(300, 401), qs)
+                want_q = [np.percentile(a, q) for q in qs]
+            for g, q, w in zip(got, qs, want_q):
                 assert g.dtype == w.dtype and (g == w or (np.isnan(g) and np.isnan(w))), (name, q, g, w)
     b = maps["normal"].copy()
     b[[5, 777]] = [np.nan, -np.nan]
