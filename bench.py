@@ -258,7 +258,8 @@ def main():
         else:
             parallelism = (f"one pair over {world} GPUs: row tiles of {H // world} rows + {SGM_MARGIN}-row margin (the reference's ROI "
                            f"convention for SGM, paths cut at the margin), one RCCL gather (ncclSend / ncclRecv group) of the owned rows of "
-                           f"disparity / validity / coefficient maps to GPU 0 per step; strong scaling")
+                           f"disparity / validity / coefficient maps to GPU 0 per step, on a stream of its own (it runs under the next step's kernels; "
+                           f"the last step's is inside the timed region); strong scaling")
         out = {
             "metric": "Mdisparities/s (HxWxD/s) Census5x5+SGM",
             "value": round(value, 1),

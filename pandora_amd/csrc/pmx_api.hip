@@ -138,6 +138,7 @@ int pmx_check_async_error(pmx_ctx* ctx, const char* where) {
 extern "C" int pmx_sync(pmx_ctx* ctx) {
     PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_sync: null context");
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) PMX_HIP(hipStreamSynchronize(ctx->comm_stream));
     return pmx_check_async_error(ctx, "pmx_sync");
 }
 

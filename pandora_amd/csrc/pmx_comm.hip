@@ -121,6 +121,15 @@ extern "C" int pmx_comm_destroy(pmx_ctx* ctx) {
     PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_comm_destroy: null context");
     if (!ctx->comm) return PMX_OK;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) {
+        (void)hipStreamSynchronize(ctx->comm_stream);
+        (void)hipStreamDestroy(ctx->comm_stream);
+        ctx->comm_stream = nullptr;
+    }
+    if (ctx->placed_ev) (void)hipEventDestroy(ctx->placed_ev);
+    if (ctx->gathered_ev) (void)hipEventDestroy(ctx->gathered_ev);
+    ctx->placed_ev = ctx->gathered_ev = nullptr;
+    ctx->gather_pending = false;
     if (ctx->comm->comm) ctx->comm->CommDestroy(ctx->comm->comm);
     delete ctx->comm;
     ctx->comm = nullptr;
@@ -187,6 +196,7 @@ extern "C" int pmx_xbuf_download(pmx_ctx* ctx, int which, void* host) {
     PMX_HIP(hipSetDevice(ctx->device));
     int rc = xbuf_need(ctx, which);
     if (rc) return rc;
+    if ((rc = pmx_comm_join(ctx))) return rc;
     PMX_HIP(hipMemcpyAsync(host, ctx->xbuf[which], xbuf_count(ctx, which) * kElem[which], hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
@@ -197,8 +207,17 @@ extern "C" int pmx_xbuf_upload(pmx_ctx* ctx, int which, const void* host) {
     PMX_HIP(hipSetDevice(ctx->device));
     int rc = xbuf_need(ctx, which);
     if (rc) return rc;
+    if ((rc = pmx_comm_join(ctx))) return rc;
     PMX_HIP(hipMemcpyAsync(ctx->xbuf[which], host, xbuf_count(ctx, which) * kElem[which], hipMemcpyHostToDevice, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+// A gather queued on the communication stream (pmx_comm_gather_rows) reads and writes the full-size maps and uses the
+// communicator: whatever touches either on the context's own stream waits for it first (an event wait on the device, the host
+// goes on).
+int pmx_comm_join(pmx_ctx* ctx) {
+    if (ctx->gather_pending) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->gathered_ev, 0));
     return PMX_OK;
 }
 
@@ -219,6 +238,7 @@ extern "C" int pmx_comm_allreduce(pmx_ctx* ctx, int which, int op) {
     }
     PMX_CHECK(op == PMX_OP_MIN || op == PMX_OP_SUM || op == PMX_OP_MAX, PMX_ERR_ARG, "pmx_comm_allreduce: unknown operation %d", op);
     const ncclRedOp_t ro = op == PMX_OP_MIN ? ncclMin : op == PMX_OP_SUM ? ncclSum : ncclMax;
+    if ((rc = pmx_comm_join(ctx))) return rc;
     pmx_stage_scope t(ctx, PMX_STAGE_COLLECTIVE);
     PMX_NCCL(ctx->comm, ctx->comm->AllReduce(ctx->xbuf[which], ctx->xbuf[which], xbuf_count(ctx, which), dt, ro, ctx->comm->comm, ctx->stream));
     return PMX_OK;
@@ -248,6 +268,7 @@ extern "C" int pmx_comm_allgather_rows(pmx_ctx* ctx, int with_itp) {
     PMX_CHECK(ctx && ctx->comm, PMX_ERR_STATE, "pmx_comm_allgather_rows: no communicator (pmx_comm_init)");
     PMX_CHECK(ctx->full_H > 0, PMX_ERR_STATE, "pmx_comm_allgather_rows: pmx_tile_place first");
     PMX_HIP(hipSetDevice(ctx->device));
+    if (int jr = pmx_comm_join(ctx)) return jr;
     pmx_comm* c = ctx->comm;
     const int which[3] = {PMX_XBUF_FULL_DISP, PMX_XBUF_FULL_VALIDITY, PMX_XBUF_FULL_ITP};
     const int H = ctx->full_H, W = ctx->W;
@@ -306,40 +327,65 @@ extern "C" int pmx_comm_gather_rows(pmx_ctx* ctx, int root, int with_itp) {
     if (!rc) rc = xbuf_need(ctx, PMX_XBUF_FULL_DISP);
     if (!rc && with_itp) rc = xbuf_need(ctx, PMX_XBUF_FULL_ITP);
     if (rc) return rc;
-    pmx_stage_scope t(ctx, PMX_STAGE_COLLECTIVE);
-    uint16_t* v16 = (uint16_t*)ctx->xbuf[PMX_XBUF_FULL_VALIDITY16];
-    int64_t* v64 = (int64_t*)ctx->xbuf[PMX_XBUF_FULL_VALIDITY];
-    const size_t own_n = (size_t)(hi - lo) * W;
-    if (c->rank != root)
-        hipLaunchKernelGGL(narrow_validity_kernel, dim3((unsigned)((own_n + 255) / 256)), dim3(256), 0, ctx->stream, v64 + (size_t)lo * W, own_n,
-                           v16 + (size_t)lo * W);
-    struct { void* p; size_t es; } maps[3] = {{ctx->xbuf[PMX_XBUF_FULL_DISP], 4}, {v16, 2}, {with_itp ? ctx->xbuf[PMX_XBUF_FULL_ITP] : nullptr, 4}};
-    PMX_NCCL(c, c->GroupStart());
-    for (auto& m : maps) {
-        if (!m.p) continue;
-        if (c->rank == root) {
+    // On a stream of its own, ordered by events: it starts when this rank's rows are in the full-size maps (whatever is queued on
+    // the context's stream so far) and whoever touches those maps or the communicator next waits for it (pmx_comm_join) - the
+    // kernels of the NEXT pair do neither and run under the transfer.  PMX_COMM_OVERLAP=0: on the context's stream, as a plain
+    // sequence.
+    const char* eo = getenv("PMX_COMM_OVERLAP");
+    const bool overlap = !(eo && eo[0] == '0');
+    hipStream_t st = ctx->stream;
+    if (overlap) {
+        if (!ctx->comm_stream) {
+            PMX_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+            PMX_HIP(hipEventCreateWithFlags(&ctx->placed_ev, hipEventDisableTiming));
+            PMX_HIP(hipEventCreateWithFlags(&ctx->gathered_ev, hipEventDisableTiming));
+        }
+        st = ctx->comm_stream;
+        PMX_HIP(hipEventRecord(ctx->placed_ev, ctx->stream));
+        PMX_HIP(hipStreamWaitEvent(st, ctx->placed_ev, 0));  // (gathers follow one another on this stream anyway)
+    } else if ((rc = pmx_comm_join(ctx))) {
+        return rc;
+    }
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_COLLECTIVE, st);
+        uint16_t* v16 = (uint16_t*)ctx->xbuf[PMX_XBUF_FULL_VALIDITY16];
+        int64_t* v64 = (int64_t*)ctx->xbuf[PMX_XBUF_FULL_VALIDITY];
+        const size_t own_n = (size_t)(hi - lo) * W;
+        if (c->rank != root)
+            hipLaunchKernelGGL(narrow_validity_kernel, dim3((unsigned)((own_n + 255) / 256)), dim3(256), 0, st, v64 + (size_t)lo * W, own_n,
+                               v16 + (size_t)lo * W);
+        struct { void* p; size_t es; } maps[3] = {{ctx->xbuf[PMX_XBUF_FULL_DISP], 4}, {v16, 2}, {with_itp ? ctx->xbuf[PMX_XBUF_FULL_ITP] : nullptr, 4}};
+        PMX_NCCL(c, c->GroupStart());
+        for (auto& m : maps) {
+            if (!m.p) continue;
+            if (c->rank == root) {
+                for (int r = 0; r < c->world; ++r) {
+                    if (r == root) continue;
+                    int rlo, rhi;
+                    shard_rows(H, c->world, r, &rlo, &rhi);
+                    PMX_NCCL(c, c->Recv((char*)m.p + (size_t)rlo * W * m.es, (size_t)(rhi - rlo) * W * m.es, ncclInt8, r, c->comm, st));
+                }
+            } else {
+                PMX_NCCL(c, c->Send((const char*)m.p + (size_t)lo * W * m.es, own_n * m.es, ncclInt8, root, c->comm, st));
+            }
+        }
+        PMX_NCCL(c, c->GroupEnd());
+        if (c->rank == root) {  // the peers' 16-bit rows into the int64 map (the root's own rows are already there)
             for (int r = 0; r < c->world; ++r) {
                 if (r == root) continue;
                 int rlo, rhi;
                 shard_rows(H, c->world, r, &rlo, &rhi);
-                PMX_NCCL(c, c->Recv((char*)m.p + (size_t)rlo * W * m.es, (size_t)(rhi - rlo) * W * m.es, ncclInt8, r, c->comm, ctx->stream));
+                const size_t n = (size_t)(rhi - rlo) * W;
+                hipLaunchKernelGGL(widen_validity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v16 + (size_t)rlo * W, n,
+                                   v64 + (size_t)rlo * W);
             }
-        } else {
-            PMX_NCCL(c, c->Send((const char*)m.p + (size_t)lo * W * m.es, own_n * m.es, ncclInt8, root, c->comm, ctx->stream));
         }
+        PMX_HIP(hipGetLastError());
     }
-    PMX_NCCL(c, c->GroupEnd());
-    if (c->rank == root) {  // the peers' 16-bit rows into the int64 map (the root's own rows are already there)
-        for (int r = 0; r < c->world; ++r) {
-            if (r == root) continue;
-            int rlo, rhi;
-            shard_rows(H, c->world, r, &rlo, &rhi);
-            const size_t n = (size_t)(rhi - rlo) * W;
-            hipLaunchKernelGGL(widen_validity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, v16 + (size_t)rlo * W, n,
-                               v64 + (size_t)rlo * W);
-        }
+    if (overlap) {
+        PMX_HIP(hipEventRecord(ctx->gathered_ev, st));
+        ctx->gather_pending = true;
     }
-    PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
@@ -351,6 +397,7 @@ extern "C" int pmx_tile_place(pmx_ctx* ctx, int full_H, int own_lo, int own_hi, 
     PMX_CHECK(full_H > 0 && 0 <= tile_lo && tile_lo <= own_lo && own_lo < own_hi && own_hi <= full_H && own_hi - tile_lo <= ctx->H, PMX_ERR_ARG,
               "pmx_tile_place: rows [%d, %d) of %d do not lie inside the tile [%d, %d)", own_lo, own_hi, full_H, tile_lo, tile_lo + ctx->H);
     PMX_HIP(hipSetDevice(ctx->device));
+    if (int jr = pmx_comm_join(ctx)) return jr;  // (a gather still reading / writing the full-size maps)
     ctx->full_H = full_H;
     const void* src[3] = {ctx->disp, ctx->validity, ctx->itp};
     const int which[3] = {PMX_XBUF_FULL_DISP, PMX_XBUF_FULL_VALIDITY, PMX_XBUF_FULL_ITP};
@@ -371,6 +418,7 @@ extern "C" int pmx_set_full_rows(pmx_ctx* ctx, int full_H, int own_lo, int own_h
     PMX_CHECK(full_H > 0 && 0 <= own_lo && own_lo < own_hi && own_hi <= full_H, PMX_ERR_ARG, "pmx_set_full_rows: rows [%d, %d) of %d", own_lo,
               own_hi, full_H);
     PMX_HIP(hipSetDevice(ctx->device));
+    if (int jr = pmx_comm_join(ctx)) return jr;
     ctx->full_H = full_H;
     const void* src[3] = {disp, validity, itp};
     const int which[3] = {PMX_XBUF_FULL_DISP, PMX_XBUF_FULL_VALIDITY, PMX_XBUF_FULL_ITP};
@@ -389,6 +437,7 @@ extern "C" int pmx_set_full_rows(pmx_ctx* ctx, int full_H, int own_lo, int own_h
 extern "C" int pmx_get_full_maps(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp) {
     PMX_CHECK(ctx && ctx->full_H > 0, PMX_ERR_STATE, "pmx_get_full_maps: pmx_tile_place first");
     PMX_HIP(hipSetDevice(ctx->device));
+    if (int jr = pmx_comm_join(ctx)) return jr;
     void* dst[3] = {disp, validity, itp};
     const int which[3] = {PMX_XBUF_FULL_DISP, PMX_XBUF_FULL_VALIDITY, PMX_XBUF_FULL_ITP};
     for (int m = 0; m < 3; ++m)

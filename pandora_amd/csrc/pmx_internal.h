@@ -79,6 +79,10 @@ struct pmx_ctx {
     // generic small scratch (census codes, arms, medians)
     void* small = nullptr;
     size_t small_bytes = 0;
+    // the gather of a row-tiled run on a stream of its own (pmx_comm_gather_rows): the next pair's kernels run under it
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t placed_ev = nullptr, gathered_ev = nullptr;
+    bool gather_pending = false;  // gathered_ev has been recorded and somebody may still have to wait for it
     // pinned staging of pmx_set_images (both images of a pair)
     char* stage_host = nullptr;
     size_t stage_cap = 0;
@@ -178,18 +182,19 @@ struct pmx_cv {
 struct pmx_stage_scope {
     pmx_ctx* ctx;
     int stage;
+    hipStream_t st;  // the stream the bracketed work is queued on (the context's own unless said otherwise)
     hipEvent_t a = nullptr, b = nullptr;
-    pmx_stage_scope(pmx_ctx* c, int s) : ctx(c), stage(s) {
+    pmx_stage_scope(pmx_ctx* c, int s, hipStream_t on = nullptr) : ctx(c), stage(s), st(on ? on : c->stream) {
         // a failed event only loses a timing sample: pmx_stage_time skips null events
         if (ctx->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
-            if (hipEventRecord(a, ctx->stream) != hipSuccess) drop();
+            if (hipEventRecord(a, st) != hipSuccess) drop();
         } else {
             drop();
         }
     }
     ~pmx_stage_scope() {
         if (a && b) {
-            if (hipEventRecord(b, ctx->stream) == hipSuccess) {
+            if (hipEventRecord(b, st) == hipSuccess) {
                 ctx->stages[stage].ev.push_back(a);
                 ctx->stages[stage].ev.push_back(b);
             } else {
@@ -286,6 +291,7 @@ int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta);   
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance, bool census_src);
 bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, int distance);
 int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
+int pmx_comm_join(pmx_ctx* ctx);  // the context's stream waits for a gather still running on the communication stream
 int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);
 int pmx_launch_order_statistic(pmx_ctx* ctx, const float* dev_values, size_t n, size_t rank, uint32_t* dev_hist, uint32_t* host_hist, float* out);
 int pmx_launch_compose_validity(pmx_ctx* ctx, const int64_t* dev_base, int base_rows, const uint8_t* dev_missing, int border);

@@ -95,3 +95,28 @@ def test_host_scalars_through_rccl(world1):
     _, comm = world1
     out = comm.engine.comm_allreduce_scalars(np.arange(8, dtype=np.float64), "max")
     np.testing.assert_array_equal(out, np.arange(8.0))
+
+
+def test_gathers_on_their_own_stream_keep_their_order(world1):
+    """pmx_comm_gather_rows queues its work on the communication stream, between two events: a loop of steps as bench.py runs them
+    (new maps, pmx_tile_place, gather - nothing synchronised in between) ends with the LAST step's maps in the full-size buffers,
+    and a collective on the context's own stream afterwards still works (it joins the communication stream first)."""
+    eng, comm = world1
+    rng = np.random.default_rng(3)
+    H, W = 48, 40
+    img = rng.random((H, W)).astype(np.float32)
+    eng.set_images(img, img, 1)
+    last = None
+    for step in range(6):
+        d = rng.random((H, W)).astype(np.float32) + step
+        v = rng.integers(0, 4096, (H, W)).astype(np.int64)
+        eng.set_disparity(d, v)
+        eng.tile_place(H, 0, H, 0, False)
+        comm.gather_rows(H, False, root=0)
+        last = (d, v)
+    out = comm.engine.comm_allreduce_scalars(np.arange(8, dtype=np.float64), "sum")
+    np.testing.assert_array_equal(out, np.arange(8.0))
+    fd, fv = eng.get_full_maps(H)
+    np.testing.assert_array_equal(fd, last[0])
+    np.testing.assert_array_equal(fv, last[1])
+    eng.sync()
