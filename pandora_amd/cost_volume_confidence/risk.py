@@ -17,8 +17,15 @@ def _device_volume_and_grids(cv, img_left):
     gmin = np.asarray(img_left["disparity"].sel(band_disp="min").data)[:ny_, :nx_]
     gmax = np.asarray(img_left["disparity"].sel(band_disp="max").data)[:ny_, :nx_]
     disp = np.asarray(cv.coords["disp"])
-    if gmin.flat[0] == disp[0] and gmax.flat[0] == disp[-1] and (gmin == disp[0]).all() and (gmax == disp[-1]).all():
-        return dcv, None, None
+    if gmin.flat[0] == disp[0] and gmax.flat[0] == disp[-1]:
+        if gmin.dtype.kind in "iu" and gmax.dtype.kind in "iu":  # (one threaded pass per grid: matching_cost.grid_extrema)
+            from ..matching_cost.matching_cost import grid_extrema
+
+            constant = grid_extrema(gmin) == (disp[0], disp[0]) and grid_extrema(gmax) == (disp[-1], disp[-1])
+        else:
+            constant = (gmin == disp[0]).all() and (gmax == disp[-1]).all()
+        if constant:
+            return dcv, None, None
     return dcv, gmin.astype(np.int64), gmax.astype(np.int64)
 
 

@@ -596,7 +596,7 @@ class Engine:
         """ambiguity.cpp:28-142 on the resident volume -> float32 [H][W] integral of the ambiguity (not normalised)."""
         e = np.ascontiguousarray(etas, np.float32)
         gmin, gmax = self._grids("ambiguity", grid_min, grid_max)
-        out = np.empty((self.H, self.W), np.float32)
+        out = pinned_empty((self.H, self.W), np.float32)  # (page-locked, recycled: no first-touch page faults under the copy)
         check(_lib.lib().pmx_ambiguity(self.ctx, cv.handle, _p(e, C.c_float), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64),
                                        int(bool(negate)), _p(out, C.c_float)), "pmx_ambiguity")
         return out
@@ -616,7 +616,7 @@ class Engine:
         """risk.cpp:28-197 as risk.py:144-166 drives it, on the resident volume -> (risk_max, risk_min, disp_sup, disp_inf)."""
         e = np.ascontiguousarray(etas, np.float64)
         gmin, gmax = self._grids("risk", grid_min, grid_max)
-        outs = [np.empty((self.H, self.W), np.float32) for _ in range(4)]
+        outs = [pinned_empty((self.H, self.W), np.float32) for _ in range(4)]
         check(_lib.lib().pmx_risk(self.ctx, cv.handle, _p(e, C.c_double), len(e), _p(gmin, C.c_int64), _p(gmax, C.c_int64),
                                   int(bool(negate)), *[_p(o, C.c_float) for o in outs]), "pmx_risk")
         return tuple(outs)
@@ -624,7 +624,7 @@ class Engine:
     def interval_bounds(self, cv, possibility_threshold, type_factor, grid_min, grid_max):
         """interval_bounds.cpp:28-161 on the resident volume -> (interval_inf, interval_sup) float32 [H][W]."""
         gmin, gmax = self._grids("interval_bounds", grid_min, grid_max)
-        lo, hi = np.empty((self.H, self.W), np.float32), np.empty((self.H, self.W), np.float32)
+        lo, hi = pinned_empty((self.H, self.W), np.float32), pinned_empty((self.H, self.W), np.float32)
         check(_lib.lib().pmx_interval_bounds(self.ctx, cv.handle, float(possibility_threshold), float(type_factor), _p(gmin, C.c_int64),
                                              _p(gmax, C.c_int64), _p(lo, C.c_float), _p(hi, C.c_float)), "pmx_interval_bounds")
         return lo, hi
