@@ -282,6 +282,21 @@ def main():
         if world > 1:
             out["collective"] = {"kind": "ncclSend / ncclRecv group: owned rows of 3 maps to rank 0 (10 B/pixel, validity as uint16)",
                                  "ms_per_step": round(stage["collective"][0] / args.steps, 4), "bytes_per_step": H * W * 10}
+            # what arrived (outside the timed region): the gathered maps of the last step against ONE GPU doing the whole pair.
+            # Tiles cut the SGM paths at their 40-row margin, like the reference's ROI tiling: a fraction of a percent of the pixels
+            # near the seams may differ, everything else must be identical - anything else means the exchange is broken.
+            gd, gv, gi = eng.get_full_maps(H, want_itp=True)
+            one = Engine(local_rank)
+            one.set_images(L, R, 1)
+            cv1 = one.alloc_cv(D, dmin)
+            run_pipeline(one, cv1, win, P1, P2)
+            od, ov, oi = one.get_disparity(want_itp=True)
+            cv1.free()
+            one.close()
+            out["gathered_maps_vs_one_gpu"] = {
+                "disparity_identical": round(float(np.mean((gd == od) | (np.isnan(gd) & np.isnan(od)))), 6),
+                "validity_identical": round(float(np.mean(gv == ov)), 6),
+                "coefficient_identical": round(float(np.mean((gi == oi) | (np.isnan(gi) & np.isnan(oi)))), 6)}
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
             pcie_s = pcie_inclusive_ms(eng, cv, L, R, win, P1, P2) * 1e-3

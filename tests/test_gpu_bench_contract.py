@@ -53,3 +53,7 @@ def test_bench_runs_one_pair_over_the_ranks(world, port):
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"]
     assert d["collective"]["bytes_per_step"] == 300 * 256 * 10
+    # what arrived on rank 0 is the pair's result: identical to one GPU doing the whole pair except near the tile seams (SGM paths
+    # are cut at the 40-row margin, as in the reference's ROI tiling; with 8 ranks over 300 rows there is a seam every 37 rows)
+    g = d["gathered_maps_vs_one_gpu"]
+    assert g["disparity_identical"] > (0.97 if world == 2 else 0.85) and g["validity_identical"] > 0.97, g
