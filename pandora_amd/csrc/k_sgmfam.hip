@@ -532,21 +532,38 @@ bool pick_shape(int D, int W, fam_shape* out) {
         f.gl = 16;
         for (int k : k16)
             if (16 * k >= D) { f.kpl = k; break; }
-        f.nw = W >= 32 * 224 ? 8 : 4;
     } else if (D <= 512) {
         f.gl = 32;
         for (int k : k32)
             if (32 * k >= D) { f.kpl = k; break; }
-        f.nw = W >= 16 * 224 ? 8 : 4;
     }
     if (!f.kpl) return false;
+    {
+        // compute waves per workgroup: the smallest of 4 / 8 / 10 that gives every window of a row a CU of its own (a launch with
+        // more windows than CUs runs them in two generations: 10000 columns in 32-column windows = 313 windows on 256 CUs took
+        // 41.0 ms per family, in 40-column windows = 250 windows 37.2)
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const int npw = 64 / f.gl;
+        const int es = f.gl * ((f.kpl + 3) & ~3) + 4;  // floats per column slot of the exchange buffers (launch_family)
+        auto fits = [&](int nw) { return (size_t)(2 * 2 * (nw * npw + 2) * es + 4) * sizeof(float) <= (size_t)160 * 1024; };
+        f.nw = fits(10) ? 10 : 8;
+        for (int nw : {4, 8, 10})
+            if (fits(nw) && (W + nw * npw - 1) / (nw * npw) <= cus) { f.nw = nw; break; }
+    }
     if (const char* e = getenv("PMX_SGM_FAM_SHAPE")) {  // test hook: "gl,kpl,nw" forces an instantiated lane map that fits D
         int gl = 0, kpl = 0, nw = 0;
-        if (sscanf(e, "%d,%d,%d", &gl, &kpl, &nw) == 3 && gl * kpl >= D && (nw == 4 || nw == 8)) {
+        if (sscanf(e, "%d,%d,%d", &gl, &kpl, &nw) == 3 && gl * kpl >= D && (nw == 4 || nw == 8 || nw == 10)) {
             bool known = false;
             if (gl == 16) for (int k : k16) known |= k == kpl;
             if (gl == 32) for (int k : k32) known |= k == kpl;
-            if (known) f = fam_shape{gl, kpl, nw};
+            const size_t lds = (size_t)(2 * 2 * (nw * (64 / (gl ? gl : 64)) + 2) * (gl * ((kpl + 3) & ~3) + 4) + 4) * sizeof(float);
+            if (known && lds <= (size_t)160 * 1024) f = fam_shape{gl, kpl, nw};  // (a map whose exchange buffers do not fit is ignored)
         }
     }
     if (out) *out = f;
@@ -568,6 +585,7 @@ int launch_family(pmx_ctx* ctx, const fam_args& a, int nwg) {
 int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg, bool wta) {
 #define PMX_FAM(GL, KPL)                                                                                               \
     if (f.gl == GL && f.kpl == KPL) {                                                                                  \
+        if (f.nw == 10) return wta ? launch_family<GL, KPL, 10, true>(ctx, a, nwg) : launch_family<GL, KPL, 10, false>(ctx, a, nwg); \
         if (wta) return f.nw == 8 ? launch_family<GL, KPL, 8, true>(ctx, a, nwg) : launch_family<GL, KPL, 4, true>(ctx, a, nwg); \
         return f.nw == 8 ? launch_family<GL, KPL, 8, false>(ctx, a, nwg) : launch_family<GL, KPL, 4, false>(ctx, a, nwg);        \
     }

@@ -47,7 +47,12 @@ SHAPES = [
     (33, 100, 61, "16,5,8"),    # cones' D
     (70, 41, 100, "16,7,4"),    # taller than wide: most windows start below the first row
     (25, 130, 129, "16,9,4"),   # C3 / C5 D: the last lane owns 3 disparities
-    (25, 130, 129, "16,9,8"),   # C5's map
+    (25, 130, 129, "16,9,8"),
+    (25, 130, 129, "16,9,10"),  # C5's map: 40-column windows (250 of them over 10000 columns: one per CU)
+    (31, 95, 61, "16,5,10"),
+    (37, 50, 257, "32,9,10"),
+    (12, 45, 300, "32,12,10"),
+    (9, 33, 512, "32,16,10"),   # (the launcher only picks it when the exchange buffers fit: they do not, 181 KB; the hook must not crash)
     (25, 130, 129, None),       # C3's map: 32 x 5
     (30, 64, 144, "16,9,4"),    # no tail
     (28, 60, 90, "32,3,8"),
