@@ -10,12 +10,21 @@ pair over N ranks (strong scaling): row tiles with the 40-pixel margin the refer
 (optimization/optimization.py:43, marge.py:86-101), every rank runs the pipeline on its rows + margin, and ONE RCCL exchange per step
 (a group of ncclSend / ncclRecv inside libpandora_amd.so, on the engine's stream: every rank sends the owned rows of its three result
 maps straight to rank 0 over its own xGMI link) leaves the full maps on GPU 0.  One
-process per GPU, launched by `python -m torch.distributed.run` (only its environment variables are used: no PyTorch in this file).
+process per GPU, launched by `python -m torch.distributed.run` (only its environment variables are used: no PyTorch in this file) -
+or by bench.py itself: `python bench.py --gpus N` without a launcher's WORLD_SIZE spawns its N ranks (LOCAL_RANK = device, a free
+MASTER_PORT), and refuses to run when the box has fewer than N devices or when --gpus disagrees with WORLD_SIZE: a run that was
+meant to span N GPUs cannot print a 1-GPU line.  The line carries RCCL's own rank count (ncclCommCount) as `rccl_ranks`.
+At N>1 a second leg, `d_sharded_exact`, times north_star's exact multi-GPU form on BASELINE configs[3]'s steps that shard over D
+(ZNCC 11x11 + WTA + vfit at 4096x4096x257: disparity slices per rank, ONE ncclAllReduce(min, uint64) of the packed per-pixel keys,
+one ncclAllReduce(sum) of the owner-refined maps) and reports the maps' identity with one GPU doing the whole volume.
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the 8-path SGM kernel, HIP-event timed on the engine's stream
 inside the timed region), `cpu_baseline` (the C oracle, kind "port", 1 thread, on a bounded row strip of the same pair),
 `cpu_baseline_all_cores` (same strip, OpenMP), `cpu_baseline_reference_compiled` (the reference's OWN census C++, oracle/_ref,
-census stage only) and, at N=1, `c3_shape` (BASELINE configs[2], 2048x2048x129, the round-1 headline, same protocol).
+census stage only) and, at N=1, `c3_shape` (BASELINE configs[2], 2048x2048x129, the round-1 headline, same protocol),
+`c4_as_stated` (configs[3] as BASELINE words it: ZNCC 11x11 + SGM + WTA + vfit, 4096x4096x257, float32 kernels) and `c5_as_stated`
+(configs[4]'s fine scale on one GPU: census + CBCA + SGM + WTA + vfit, 10000x10000x129, float32 kernels), each with its own roofline
+block (its dominant kernel family), and `default_allocation` (the headline step with plain hipMalloc placement, --placement-trials 1).
 """
 import argparse
 import json
@@ -179,6 +188,88 @@ def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed):
     return ms, stage, (L, R)
 
 
+def d_sharded_leg(eng, comm, L, R, dmin, dmax, win, steps, check_device):
+    """north_star's exact multi-GPU form on the steps of BASELINE configs[3] that shard over D: every rank builds the
+    ZNCC costs of its disparity slice (+1 disparity of halo for the refinement), ONE ncclAllReduce(min, uint64) of a packed
+    (orderable cost, global index) key per pixel is the winner-takes-all over the whole range (np.argmax's first extremum), the
+    rank owning a pixel's winner refines it and one ncclAllReduce(sum) of value-or-zero maps merges.  Every rank takes part;
+    rank 0 returns the block, with the maps' identity against ONE GPU running the whole volume (outside the timed region)."""
+    from pandora_amd import dist as pdist
+    from pandora_amd.engine import Engine
+
+    rank, world = comm.rank, comm.world
+    H, W = L.shape
+    eng.set_images(L, R, 1)
+    (olo, ohi), (wlo, whi) = pdist.disparity_shard(dmin, dmax, 1, world, rank, halo=1)
+    cv = eng.alloc_cv(whi - wlo + 1, wlo)
+
+    def step():
+        eng.zncc(cv, win)
+        eng.set_validity(None)
+        pdist.sharded_wta(eng, comm, cv, True, wlo - dmin, dmin, 1, -9999.0)
+        eng.shard_refine_pack(cv, "vfit", True, olo, ohi, rank == world - 1)
+        comm.allreduce_xbuf("refine_pack", "sum")
+        comm.allreduce_xbuf("refine_flags", "sum")
+        eng.shard_refine_unpack()
+
+    step()
+    eng.sync()
+    comm.barrier()
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    eng.sync()
+    dt = float(comm.host_allreduce(np.array([time.perf_counter() - t0]), "max")[0]) / steps
+    coll_ms = eng.stage_time("collective")[0] / steps
+    eng.set_profiling(False)
+    comm.barrier()
+    out = None
+    if rank == 0:
+        gd, gv, gi = eng.get_disparity(want_itp=True)
+        one = Engine(check_device)
+        one.set_images(L, R, 1)
+        cv1 = one.alloc_cv(dmax - dmin + 1, dmin)
+        one.zncc(cv1, win)
+        one.set_validity(None)
+        one.wta(cv1, True, -9999.0)
+        one.refine(cv1, "vfit", True)
+        od, ov, oi = one.get_disparity(want_itp=True)
+        cv1.free()
+        one.close()
+        same = [float(np.mean((a == b) | (np.isnan(a) & np.isnan(b)))) for a, b in ((gd, od), (gi, oi))] + [float(np.mean(gv == ov))]
+        cells = H * W * (dmax - dmin + 1)
+        out = {"workload": f"{H}x{W} pair, d=[{dmin},{dmax}], ZNCC {win}x{win} + WTA + vfit (BASELINE configs[3] without its SGM step, which "
+                           f"does not shard over D); costs sharded over D across {world} ranks",
+               "collectives": "ncclAllReduce(min, uint64) of 8 B/pixel packed keys + ncclAllReduce(sum) of the owner-refined maps (20 B/pixel)",
+               "ms_per_step": round(dt * 1e3, 3), "value": round(cells / dt / 1e6, 1), "unit": "Mdisp/s", "steps": steps,
+               "collective_ms_per_step": round(coll_ms, 4),
+               "maps_identical_to_one_gpu": round(min(same), 6)}
+    cv.free()
+    comm.barrier()
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N ranks of this very command, one per device (LOCAL_RANK = device), a free
+    rendezvous port at 127.0.0.1; rank 0's stdout (the JSON line) is passed through, a failing rank fails the run."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    return next((c for c in codes if c), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,19 +283,45 @@ def main():
     ap.add_argument("--placement-trials", type=int, default=6,
                     help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials; 1 = plain hipMalloc)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 2048x2048x129 leg (BASELINE configs[2])")
+    ap.add_argument("--no-configs", action="store_true", help="skip the c4_as_stated / c5_as_stated / default_allocation legs (N=1)")
+    ap.add_argument("--no-dshard", action="store_true", help="skip the exact D-sharded leg (N>1)")
+    ap.add_argument("--test-comm", default=None, metavar="MODULE:CLASS",
+                    help="TEST HOOK: a pandora_amd.comm.Comm subclass from tests/ (e.g. tests.transports:TcpComm) that carries the "
+                         "exchange steps through the host, so that several ranks can share the one GPU of a test box")
+    ap.add_argument("--test-device", type=int, default=None, help="TEST HOOK: every rank uses this device (with --test-comm)")
     args = ap.parse_args()
 
+    from pandora_amd import _lib
     from pandora_amd.comm import Comm, env_world
     from pandora_amd.dist import row_tile
     from pandora_amd.engine import Engine
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    ndev = _lib.lib().pmx_device_count()
+    if args.test_device is None and ndev < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, this box shows {ndev}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # no launcher: bench.py starts its own ranks and relays rank 0's line
     rank, world, local_rank, _, _ = env_world()
-    # test hooks only (two ranks on a 1-GPU box): PANDORA_COMM_BACKEND=tcp, PANDORA_BENCH_DEVICE=<index>
-    local_rank = int(os.environ.get("PANDORA_BENCH_DEVICE", local_rank))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: refusing to print a line for the wrong N")
+    if args.test_device is not None:
+        local_rank = args.test_device
     H, W, dmin, dmax, win, P1, P2 = args.height, args.width, args.dmin, args.dmax, 5, 8.0, 32.0
     D = dmax - dmin + 1
     eng = Engine(local_rank)
-    comm = Comm(eng) if world > 1 else None
+    comm = None
+    if world > 1:
+        if args.test_comm:
+            import importlib
+
+            mod, cls = args.test_comm.split(":")
+            comm = getattr(importlib.import_module(mod), cls)(eng)
+        else:
+            comm = Comm(eng)
+        if comm.nranks != world:
+            sys.exit(f"bench.py: the communicator reports {comm.nranks} ranks, WORLD_SIZE is {world}")
     if args.placement_trials > 1:
         eng.set_placement_trials(args.placement_trials)  # well-placed volumes, chosen once before the warm-up
 
@@ -245,6 +362,10 @@ def main():
     cells = H * W * D
     stage = {name: eng.stage_time(name) for name in STAGES}
     eng.set_profiling(False)
+    gathered = eng.get_full_maps(H, want_itp=True) if comm is not None and rank == 0 else None  # the last step's maps, before anything else runs
+    dshard = None
+    if comm is not None and not args.no_dshard and D >= 2 * world:
+        dshard = d_sharded_leg(eng, comm, L, R, dmin, dmax, 11, max(2, args.steps // 2), local_rank)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -265,6 +386,7 @@ def main():
             "value": round(value, 1),
             "unit": "Mdisp/s",
             "n_gpus": world,
+            "rccl_ranks": comm.nranks if comm is not None else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -285,7 +407,7 @@ def main():
             # what arrived (outside the timed region): the gathered maps of the last step against ONE GPU doing the whole pair.
             # Tiles cut the SGM paths at their 40-row margin, like the reference's ROI tiling: a fraction of a percent of the pixels
             # near the seams may differ, everything else must be identical - anything else means the exchange is broken.
-            gd, gv, gi = eng.get_full_maps(H, want_itp=True)
+            gd, gv, gi = gathered
             one = Engine(local_rank)
             one.set_images(L, R, 1)
             cv1 = one.alloc_cv(D, dmin)
@@ -297,6 +419,8 @@ def main():
                 "disparity_identical": round(float(np.mean((gd == od) | (np.isnan(gd) & np.isnan(od)))), 6),
                 "validity_identical": round(float(np.mean(gv == ov)), 6),
                 "coefficient_identical": round(float(np.mean((gi == oi) | (np.isnan(gi) & np.isnan(oi)))), 6)}
+            if dshard is not None:
+                out["d_sharded_exact"] = dshard
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
             pcie_s = pcie_inclusive_ms(eng, cv, L, R, win, P1, P2) * 1e-3

@@ -223,6 +223,9 @@ int pmx_comm_unique_id(void* id_out, size_t bytes);                             
 int pmx_comm_init(pmx_ctx* ctx, const void* id, size_t bytes, int world, int rank);  /* ncclCommInitRank on the context's GPU */
 int pmx_comm_destroy(pmx_ctx* ctx);
 int pmx_comm_info(const pmx_ctx* ctx, int* world, int* rank);                        /* (1, 0) without a communicator */
+/* what RCCL itself reports for the communicator (ncclCommCount; 1 without one): bench.py prints it beside WORLD_SIZE so that a run
+ * that was meant to span N GPUs and did not cannot pass for one that did */
+int pmx_comm_count(const pmx_ctx* ctx, int* nranks);
 /* In-place ncclAllReduce of an exchange buffer over all ranks (keys: MIN = np.argmin over the full volume, ties to the lowest
  * index; NaN flags: MIN = NaN in every shard; refinement packs: SUM with exactly one non-zero contributor per pixel = exact). */
 int pmx_comm_allreduce(pmx_ctx* ctx, int which, int op);

@@ -105,6 +105,7 @@ SIGNATURES = {
     "pmx_comm_init": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int]),
     "pmx_comm_destroy": (C.c_int, [vp]),
     "pmx_comm_info": (C.c_int, [vp, c_int_p, c_int_p]),
+    "pmx_comm_count": (C.c_int, [vp, c_int_p]),
     "pmx_comm_allreduce": (C.c_int, [vp, C.c_int, C.c_int]),
     "pmx_comm_allreduce_scalars": (C.c_int, [vp, c_double_p, C.c_int]),
     "pmx_comm_allgather_rows": (C.c_int, [vp, C.c_int]),

@@ -3,14 +3,10 @@
 The data path is RCCL over xGMI INSIDE libpandora_amd.so (csrc/pmx_comm.hip: ncclAllReduce / ncclAllGather on device buffers the
 context owns).  This module only bootstraps it - rank 0 draws the 128-byte RCCL id (pmx_comm_unique_id) and hands it to the other
 ranks over a TCP socket at MASTER_ADDR (the launcher's rendezvous address; any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK /
-MASTER_ADDR / MASTER_PORT works, `python -m torch.distributed.run` included) - and offers the same exchange steps over two TEST
-transports for boxes where RCCL cannot run the ranks (two ranks on one GPU, or no GPU at all):
-
-  "rccl"  the product: collectives on the device exchange buffers, on the engine's stream
-  "tcp"   test transport: the exchange buffer visits the host (pmx_xbuf_download / _upload) and is reduced through rank 0's socket
-  "gloo"  test transport: the same through an initialised torch.distributed gloo group (CPU tests)
-
-No PyTorch is imported unless the gloo transport is asked for."""
+MASTER_ADDR / MASTER_PORT works, `python -m torch.distributed.run` included).  RCCL is the ONLY transport of this module: there
+is no environment switch and no host fallback.  The host-side stand-ins that let the exchange STEPS be exercised where RCCL cannot
+run the ranks (two ranks on one GPU, or no GPU at all) are test infrastructure and live in tests/transports.py (subclasses of
+Comm that a test constructs explicitly).  No PyTorch anywhere in this file."""
 import os
 import socket
 import struct
@@ -191,51 +187,37 @@ class _StdoutToStderr:
 
 
 class Comm:
-    """The ranks of one run.  `engine` may be None for host-only use (CPU tests of the merge arithmetic)."""
+    """The ranks of one run: RCCL collectives on the engine's device exchange buffers, on the engine's stream."""
 
-    def __init__(self, engine=None, backend=None, rank=None, world=None, addr=None, port=None, always=False):
+    def __init__(self, engine, rank=None, world=None, addr=None, port=None, always=False):
         erank, eworld, _, eaddr, eport = env_world()
         self.rank = erank if rank is None else rank
         self.world = eworld if world is None else world
         self.engine = engine
         self.always = always  # run the collectives even with one rank (tests of the RCCL path on a one-GPU box)
-        self.backend = backend or os.environ.get("PANDORA_COMM_BACKEND", "rccl")
-        if self.backend not in ("rccl", "tcp", "gloo"):
-            raise ValueError(f"unknown transport {self.backend!r}")
-        self._torch_dist = None
         self.rdv = None
-        if self.backend == "gloo":
-            import torch.distributed as dist  # test transport only
+        self._bootstrap(eaddr if addr is None else addr, eport if port is None else port)
 
-            if not dist.is_initialized():
-                raise RuntimeError("the gloo test transport needs an initialised torch.distributed group")
-            self._torch_dist = dist
-            self.rank, self.world = dist.get_rank(), dist.get_world_size()
-            return
+    def _bootstrap(self, addr, port):
+        if self.engine is None:
+            raise ValueError("the RCCL transport works on an engine's device buffers")
         # the launcher's port belongs to the launcher (torch.distributed.run keeps its store there): rendezvous one above
-        port = int(os.environ.get("PANDORA_COMM_PORT", (eport if port is None else port) + 1))
-        self.rdv = Rendezvous(self.rank, self.world, eaddr if addr is None else addr, port)
-        if self.backend == "rccl":
-            if engine is None:
-                raise ValueError("the RCCL transport works on an engine's device buffers")
-            with _StdoutToStderr():
-                uid = self.rdv.broadcast(engine.comm_unique_id() if self.rank == 0 else None)
-                engine.comm_init(uid, self.world, self.rank)
+        port = int(os.environ.get("PANDORA_COMM_PORT", port + 1))
+        self.rdv = Rendezvous(self.rank, self.world, addr, port)
+        with _StdoutToStderr():
+            uid = self.rdv.broadcast(self.engine.comm_unique_id() if self.rank == 0 else None)
+            self.engine.comm_init(uid, self.world, self.rank)
+
+    @property
+    def nranks(self):
+        """what RCCL itself says (ncclCommCount): bench.py prints it next to WORLD_SIZE"""
+        return self.engine.comm_count()
 
     # ---- host values ---------------------------------------------------------------------------------------------
     def host_allreduce(self, arr, op):
-        """small host arrays (timings, test vectors).  RCCL: eight doubles at a time through the device."""
+        """small host arrays (timings, test vectors): eight doubles at a time through the device."""
         if self.world == 1:
             return np.asarray(arr)
-        if self.backend == "gloo":
-            import torch
-
-            t = torch.from_numpy(np.ascontiguousarray(arr).copy())
-            red = {"min": self._torch_dist.ReduceOp.MIN, "sum": self._torch_dist.ReduceOp.SUM, "max": self._torch_dist.ReduceOp.MAX}[op]
-            self._torch_dist.all_reduce(t, op=red)
-            return t.numpy()
-        if self.backend == "tcp":
-            return self.rdv.allreduce(np.asarray(arr), op)
         a = np.asarray(arr, np.float64).ravel()
         out = np.empty_like(a)
         for i in range(0, a.size, 8):
@@ -248,60 +230,30 @@ class Comm:
     def barrier(self):
         if self.world == 1:
             return
-        if self.engine is not None:
-            self.engine.sync()
-        if self.backend == "gloo":
-            self._torch_dist.barrier()
-        elif self.backend == "tcp":
-            self.rdv.barrier()
-        else:
-            self.host_allreduce(np.zeros(1), "sum")  # a collective on the stream + the download that waits for it
+        self.engine.sync()
+        self.host_allreduce(np.zeros(1), "sum")  # a collective on the stream + the download that waits for it
 
     # ---- device exchange buffers -------------------------------------------------------------------------------------
     def allreduce_xbuf(self, which, op):
         """In-place reduction of one of the engine's exchange buffers over the ranks."""
         if self.world == 1 and not self.always:
             return
-        if self.backend == "rccl":
-            self.engine.comm_allreduce(which, op)
-            return
-        host = self.engine.xbuf_download(which)  # test transports: through the host
-        self.engine.xbuf_upload(which, self.host_allreduce(host, op).astype(host.dtype, copy=False))
+        self.engine.comm_allreduce(which, op)
 
     def allgather_rows(self, H, with_itp):
         """Every rank placed its owned rows in the engine's full-size maps; afterwards every rank holds all rows."""
         if self.world == 1 and not self.always:
             return
-        if self.backend == "rccl":
-            self.engine.comm_allgather_rows(with_itp)
-            return
-        from .dist import shard_range
-
-        lo, hi = shard_range(H, self.world, self.rank)
-        for which in ("full_disp", "full_validity") + (("full_itp",) if with_itp else ()):
-            full = self.engine.xbuf_download(which).reshape(H, -1)
-            raw = np.ascontiguousarray(full[lo:hi]).tobytes()
-            if self.backend == "gloo":
-                parts = [None] * self.world
-                self._torch_dist.all_gather_object(parts, raw)
-            else:
-                parts = self.rdv.allgather(raw)
-            for r, blob in enumerate(parts):
-                rlo, rhi = shard_range(H, self.world, r)
-                full[rlo:rhi] = np.frombuffer(blob, full.dtype).reshape(rhi - rlo, -1)
-            self.engine.xbuf_upload(which, full)
+        self.engine.comm_allgather_rows(with_itp)
 
     def gather_rows(self, H, with_itp, root=0):
         """Every rank placed its owned rows in the engine's full-size maps; afterwards rank `root` holds all rows."""
         if self.world == 1 and not self.always:
             return
-        if self.backend == "rccl":
-            self.engine.comm_gather_rows(root, with_itp)
-        else:
-            self.allgather_rows(H, with_itp)  # test transports: everybody gets everything
+        self.engine.comm_gather_rows(root, with_itp)
 
     def close(self):
-        if self.backend == "rccl" and self.engine is not None:
+        if self.engine is not None and self.rdv is not None:
             self.engine.comm_destroy()
         if self.rdv is not None:
             self.rdv.close()

@@ -44,6 +44,30 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)));
 }
+// Small integers compare as positive f16 values exactly as they compare as integers (the bit patterns of positive halves are
+// monotone), so the MINIMA of the recurrence may run on the f16 pipe: gfx950's v_pk_minimum3_f16 takes three operands (the
+// integer pipe has no packed min3).  Additions stay integer: a 32-bit add of two packed pairs is the packed add as long as no half
+// overflows, and v_add3_u32 folds "- M + C" into one instruction (the 32-bit two's complement of (M | M << 16) subtracts M from
+// both halves exactly when every half of the result is >= 0).  tools/ubench/pk_probe.hip checks the arithmetic exhaustively.
+// Padded disparities carry kPad16 (not a NaN pattern, room above it for P2 and a byte of cost).
+static constexpr uint32_t kPad16 = 0x7000u;
+static constexpr uint32_t kPadPk = 0x70007000u;
+__device__ __forceinline__ uint32_t hmin(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t hmin3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t c) {  // (the compiler would split a + b + (0 - M) into an add and a sub)
+    uint32_t d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp8(uint32_t oldv, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)oldv, (int)src, CTRL, 0xf, 0xf, false);
@@ -130,9 +154,10 @@ struct sgm8_args {
     uint32_t P1, P2;
 };
 
-template <int KPL, int CBITS>
+template <int KPL, int CBITS, bool HF>
 __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_args a) {
     constexpr int Q = KPL / 4;
+    constexpr uint32_t kI16 = HF ? kPad16 : kInf16, kIPk = HF ? kPadPk : kInfPk;
     constexpr int PER = CBITS == 8 ? 4 : 6;     // costs per dword of the cost volume
     constexpr int NDW = (KPL + PER - 1) / PER;  // cost dwords per lane
     static_assert(KPL % 4 == 0, "whole dwords per lane");
@@ -193,8 +218,8 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int d = d_first + 4 * q;
-        padA[q] = ((d < D) ? 0u : kInf16) | (((d + 2 < D) ? 0u : kInf16) << 16);
-        padB[q] = ((d + 1 < D) ? 0u : kInf16) | (((d + 3 < D) ? 0u : kInf16) << 16);
+        padA[q] = ((d < D) ? 0u : kI16) | (((d + 2 < D) ? 0u : kI16) << 16);
+        padB[q] = ((d + 1 < D) ? 0u : kI16) | (((d + 3 < D) ? 0u : kI16) << 16);
     }
     uint32_t A[Q], B[Q];
 #pragma unroll
@@ -203,9 +228,10 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
     const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
 
     auto step = [&](slot_t& s) {
-        const uint32_t belowB = dpp8<0x111>(kInfPk, B[Q - 1]);  // row_shr:1 - previous lane's (.., L[d_first-1])
-        const uint32_t aboveA = dpp8<0x101>(kInfPk, A[0]);      // row_shl:1 - next lane's (L[d_first+KPL], ..)
-        const uint32_t mp2 = pk_add(M, P2pk);
+        const uint32_t belowB = dpp8<0x111>(kIPk, B[Q - 1]);  // row_shr:1 - previous lane's (.., L[d_first-1])
+        const uint32_t aboveA = dpp8<0x101>(kIPk, A[0]);      // row_shl:1 - next lane's (L[d_first+KPL], ..)
+        const uint32_t mp2 = HF ? M + P2pk : pk_add(M, P2pk);
+        const uint32_t negM = 0u - M;
         uint32_t nA[Q], nB[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -221,10 +247,17 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
             // neighbours: A = (d, d+2) has lo = (d-1, d+1), hi = (d+1, d+3) = B;  B has lo = A, hi = (d+2, d+4)
             const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
             const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
-            const uint32_t tA = pk_min(pk_min(A[q], pk_add(pk_min(loA, B[q]), P1pk)), mp2);
-            const uint32_t tB = pk_min(pk_min(B[q], pk_add(pk_min(A[q], hiB), P1pk)), mp2);
-            nA[q] = pk_add(ccA, pk_sub(tA, M));
-            nB[q] = pk_add(ccB, pk_sub(tB, M));
+            if (HF) {
+                const uint32_t tA = hmin3(A[q], hmin(loA, B[q]) + P1pk, mp2);
+                const uint32_t tB = hmin3(B[q], hmin(A[q], hiB) + P1pk, mp2);
+                nA[q] = add3(tA, ccA, negM);
+                nB[q] = add3(tB, ccB, negM);
+            } else {
+                const uint32_t tA = pk_min(pk_min(A[q], pk_add(pk_min(loA, B[q]), P1pk)), mp2);
+                const uint32_t tB = pk_min(pk_min(B[q], pk_add(pk_min(A[q], hiB), P1pk)), mp2);
+                nA[q] = pk_add(ccA, pk_sub(tA, M));
+                nB[q] = pk_add(ccB, pk_sub(tB, M));
+            }
         }
         if (lane_active) {
             uint32_t packed[Q];
@@ -232,9 +265,16 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
             for (int q = 0; q < Q; ++q) packed[q] = nA[q] | (nB[q] << 8);  // bytes d, d+1, d+2, d+3 (pads spill upwards only)
             __builtin_memcpy(pO, packed, 4 * Q);
         }
-        uint32_t m = pk_min(nA[0], nB[0]);
+        uint32_t m;
+        if (HF) {
+            m = hmin(nA[0], nB[0]);
 #pragma unroll
-        for (int q = 1; q < Q; ++q) m = pk_min(m, pk_min(nA[q], nB[q]));
+            for (int q = 1; q < Q; ++q) m = hmin3(m, nA[q], nB[q]);
+        } else {
+            m = pk_min(nA[0], nB[0]);
+#pragma unroll
+            for (int q = 1; q < Q; ++q) m = pk_min(m, pk_min(nA[q], nB[q]));
+        }
         uint32_t m1 = m & 0xffffu, m2 = m >> 16;
         uint32_t lmin = m1 < m2 ? m1 : m2;
         prefetch(s);
@@ -258,12 +298,15 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
             c += fix;
             pO += (ptrdiff_t)fix * a.Dp;
             const bool wrapped = hi || lo;
+            if (__builtin_amdgcn_ballot_w64(wrapped) != 0ull) {  // once per line and image width: a wave-uniform branch, not 2Q + 1 selects per step
+                asm volatile("; path restart" ::);                // (keeps the compiler from flattening the branch into those selects)
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                A[q] = wrapped ? padA[q] : A[q];
-                B[q] = wrapped ? padB[q] : B[q];
+                for (int q = 0; q < Q; ++q) {
+                    A[q] = wrapped ? padA[q] : A[q];
+                    B[q] = wrapped ? padB[q] : B[q];
+                }
+                M = wrapped ? 0u : M;
             }
-            M = wrapped ? 0u : M;
         }
     };
 
@@ -355,9 +398,13 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     const dim3 grid((nwaves + kWaves8 - 1) / kWaves8), block(kWaves8 * 64);
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
+        // PMX_SGM8_HF=0: the minima on the integer pipe (v_pk_min_u16 chains), the round-2 form - an A/B hook
+        static const bool hf = !(getenv("PMX_SGM8_HF") && getenv("PMX_SGM8_HF")[0] == '0');
 #define PMX_SGM8(KPLV)                                                                                                   \
-    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 5>), grid, block, 0, ctx->stream, a);        \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 8>), grid, block, 0, ctx->stream, a)
+    if (five && hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 5, true>), grid, block, 0, ctx->stream, a); \
+    else if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 5, false>), grid, block, 0, ctx->stream, a); \
+    else if (hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 8, true>), grid, block, 0, ctx->stream, a);    \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 8, false>), grid, block, 0, ctx->stream, a)
         switch (kpl) {
             case 4: PMX_SGM8(4); break;
             case 8: PMX_SGM8(8); break;

@@ -27,6 +27,7 @@ struct pmx_comm {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -68,6 +69,7 @@ static int load_rccl(pmx_comm** out) {
         PMX_SYM(GetUniqueId, "ncclGetUniqueId")
         PMX_SYM(CommInitRank, "ncclCommInitRank")
         PMX_SYM(CommDestroy, "ncclCommDestroy")
+        PMX_SYM(CommCount, "ncclCommCount")
         PMX_SYM(AllReduce, "ncclAllReduce")
         PMX_SYM(AllGather, "ncclAllGather")
         PMX_SYM(ReduceScatter, "ncclReduceScatter")
@@ -140,6 +142,13 @@ extern "C" int pmx_comm_info(const pmx_ctx* ctx, int* world, int* rank) {
     PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_comm_info: null context");
     if (world) *world = ctx->comm ? ctx->comm->world : 1;
     if (rank) *rank = ctx->comm ? ctx->comm->rank : 0;
+    return PMX_OK;
+}
+
+extern "C" int pmx_comm_count(const pmx_ctx* ctx, int* nranks) {
+    PMX_CHECK(ctx && nranks, PMX_ERR_ARG, "pmx_comm_count: null argument");
+    *nranks = 1;
+    if (ctx->comm && ctx->comm->comm) PMX_NCCL(ctx->comm, ctx->comm->CommCount(ctx->comm->comm, nranks));
     return PMX_OK;
 }
 
@@ -286,6 +295,10 @@ extern "C" int pmx_comm_allgather_rows(pmx_ctx* ctx, int with_itp) {
             const size_t slot = (size_t)(H / c->world + 1) * row;
             char* stage = nullptr;
             PMX_HIP(pmx_pool_alloc(ctx, (void**)&stage, slot * (c->world + 1)));
+            struct stage_guard {  // the staging block goes back to the pool on every way out (stream-ordered reuse)
+                pmx_ctx* ctx; char* p;
+                ~stage_guard() { pmx_pool_free(ctx, p); }
+            } guard{ctx, stage};
             PMX_HIP(hipMemcpyAsync(stage + slot * c->world, full + (size_t)lo * row, (size_t)(hi - lo) * row, hipMemcpyDeviceToDevice, ctx->stream));
             PMX_NCCL(c, c->AllGather(stage + slot * c->world, stage, slot, ncclInt8, c->comm, ctx->stream));
             for (int r = 0; r < c->world; ++r) {
@@ -294,7 +307,6 @@ extern "C" int pmx_comm_allgather_rows(pmx_ctx* ctx, int with_itp) {
                 if (r != c->rank)
                     PMX_HIP(hipMemcpyAsync(full + (size_t)rlo * row, stage + slot * r, (size_t)(rhi - rlo) * row, hipMemcpyDeviceToDevice, ctx->stream));
             }
-            pmx_pool_free(ctx, stage);  // stream-ordered reuse
         }
     }
     return PMX_OK;

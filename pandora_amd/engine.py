@@ -654,6 +654,11 @@ class Engine:
     def comm_init(self, uid, world, rank):
         check(_lib.lib().pmx_comm_init(self.ctx, C.c_char_p(bytes(uid)), len(uid), int(world), int(rank)), "pmx_comm_init")
 
+    def comm_count(self):
+        n = C.c_int(0)
+        check(_lib.lib().pmx_comm_count(self.ctx, C.byref(n)), "pmx_comm_count")
+        return n.value
+
     def comm_destroy(self):
         check(_lib.lib().pmx_comm_destroy(self.ctx), "pmx_comm_destroy")
 

@@ -1,5 +1,5 @@
 """world_size-2 tests (CPU) of the multi-GPU exchange logic.  The product exchanges are RCCL collectives inside the library; here
-the same merge arithmetic runs through pandora_amd.comm.Comm's two test transports: "gloo" (torch.distributed on CPU) and "tcp"
+the same merge arithmetic runs through the two host stand-ins of tests/transports.py: GlooComm (torch.distributed on CPU) and TcpComm
 (the launcher-independent socket rendezvous that also hands out the RCCL id).  D-sharded WTA: two processes each reduce their
 disparity slice to packed keys (numpy restatement of the kernel's packing, test-only), one all-reduce(MIN) merges them, and the
 decode equals np.argmin over the full volume (first minimum on ties, NaN = +inf, all-NaN -> invalid)."""
@@ -32,11 +32,11 @@ def _worker(rank, world, port, is_max, q):
     import torch.distributed as dist
 
     from pandora_amd import dist as pdist
-    from pandora_amd.comm import Comm
+    from tests.transports import GlooComm
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = Comm(backend="gloo")
+    comm = GlooComm()
     rng = np.random.default_rng(0)  # same volume on both ranks
     H, W, dmin, dmax = 9, 13, -7, 5
     D = dmax - dmin + 1
@@ -110,9 +110,9 @@ def test_row_tiles_cover_the_image_with_margins():
 def _tcp_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     from pandora_amd import dist as pdist
-    from pandora_amd.comm import Comm
+    from tests.transports import TcpComm
 
-    comm = Comm(backend="tcp", rank=rank, world=world, addr="127.0.0.1", port=port)
+    comm = TcpComm(None, rank=rank, world=world, addr="127.0.0.1", port=port)
     uid = comm.rdv.broadcast(bytes(range(128)) if rank == 0 else None)  # how the RCCL id travels
     rng = np.random.default_rng(5)
     H, W, dmin, dmax = 11, 17, -20, 12

@@ -157,12 +157,12 @@ import numpy as np
 sys.path.insert(0, %(root)r)
 import pandora_amd
 from pandora_amd import dist as pdist, runtime
-from pandora_amd.comm import Comm
+from tests.transports import TcpComm
 from pandora_amd.dataset import make_image
 from pandora_amd.state_machine import PandoraMachine
 sys.path.insert(0, os.path.join(%(root)r, "tests"))
 from test_gpu_baseline_configs import periodic_pair
-comm = Comm(runtime.get_engine(), backend="tcp")
+comm = TcpComm(runtime.get_engine())
 H, W, shift = 2400, 3000, 7
 L, R = periodic_pair(H, W, shift, 5)
 rng = np.random.default_rng(3)

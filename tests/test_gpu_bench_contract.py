@@ -37,23 +37,41 @@ def test_bench_prints_one_contract_line():
 @pytest.mark.parametrize("world,port", [(2, 29547), (8, 29561)])
 def test_bench_runs_one_pair_over_the_ranks(world, port):
     """--gpus N = ONE pair over N ranks (row tiles + 40-row margin, gather of the owned rows on rank 0), launched with the launcher's
-    environment variables; the ranks share the box's one GPU, so the exchange goes through the tcp test transport.  Eight ranks over
+    environment variables; the ranks share the box's one GPU, so the exchange goes through the TcpComm stand-in of tests/transports.py
+    (bench.py's explicit --test-comm hook; the product Comm is RCCL only).  Eight ranks over
     300 rows: tiles of 37 / 38 owned rows whose margins reach over several neighbours."""
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PANDORA_COMM_BACKEND="tcp", PANDORA_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-                                       "--height", "300", "--width", "256", "--dmax", "40", "--placement-trials", "1"],
+                                       "--height", "300", "--width", "256", "--dmax", "40", "--placement-trials", "1",
+                                       "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), "".join(o[1][-1500:] for o in outs)
     lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
     assert len(lines) == 1 and not any(o[0].strip() for o in outs[1:]), outs
     d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"]
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"]
+    # the exact multi-GPU form rides along: costs sharded over D, one all-reduce(min) of packed keys - identical to one GPU
+    assert d["d_sharded_exact"]["maps_identical_to_one_gpu"] == 1.0, d["d_sharded_exact"]
     assert d["collective"]["bytes_per_step"] == 300 * 256 * 10
     # what arrived on rank 0 is the pair's result: identical to one GPU doing the whole pair except near the tile seams (SGM paths
     # are cut at the 40-row margin, as in the reference's ROI tiling; with 8 ranks over 300 rows there is a seam every 37 rows)
     g = d["gathered_maps_vs_one_gpu"]
     assert g["disparity_identical"] > (0.97 if world == 2 else 0.85) and g["validity_identical"] > 0.97, g
+
+
+def test_bench_refuses_to_mislabel_a_run():
+    """`--gpus 2` on a box with one device must fail loudly (no 1-GPU line labelled as 2), and so must a --gpus that disagrees with
+    the launcher's WORLD_SIZE."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    from pandora_amd import _lib
+    if _lib.lib().pmx_device_count() < 2:
+        assert out.returncode != 0 and "needs 2 devices" in out.stderr and not out.stdout.strip(), (out.stdout, out.stderr[-500:])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr and not out.stdout.strip()

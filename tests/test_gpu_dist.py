@@ -13,7 +13,7 @@ def world1():
     from pandora_amd.engine import Engine
 
     eng = Engine(0)
-    comm = Comm(eng, backend="rccl", rank=0, world=1, always=True)
+    comm = Comm(eng, rank=0, world=1, always=True)
     yield eng, comm
     comm.close()
     eng.close()

@@ -1,5 +1,5 @@
 """GPU: pandora_amd.dist.run_row_tiled / run_d_sharded with TWO ranks, both on the box's one GPU (RCCL refuses two ranks on one
-device, so the exchange buffers travel through pandora_amd.comm's "tcp" test transport; no PyTorch involved) against the untiled
+device, so the exchange buffers travel through tests/transports.py's TcpComm stand-in; no PyTorch involved) against the untiled
 run: a local pipeline must be identical everywhere; a census+SGM pipeline is cut at the 40-row margin like the reference's
 own ROI tiling, so it may differ on a few pixels but must stay within the cones gate."""
 import os
@@ -19,10 +19,10 @@ sys.path.insert(0, %(root)r)
 from PIL import Image
 import pandora_amd
 from pandora_amd import dist as pdist, runtime
-from pandora_amd.comm import Comm
+from tests.transports import TcpComm
 from pandora_amd.dataset import make_image
 from pandora_amd.state_machine import PandoraMachine
-comm = Comm(runtime.get_engine(), backend="tcp")
+comm = TcpComm(runtime.get_engine())
 rank = comm.rank
 cones = os.path.join(%(root)r, "tests", "golden", "cones")
 L = np.array(Image.open(os.path.join(cones, "left.png"))).astype(np.float32)
@@ -87,10 +87,10 @@ sys.path.insert(0, %(root)r)
 from PIL import Image
 import pandora_amd
 from pandora_amd import dist as pdist, runtime
-from pandora_amd.comm import Comm
+from tests.transports import TcpComm
 from pandora_amd.dataset import make_image
 from pandora_amd.state_machine import PandoraMachine
-comm = Comm(runtime.get_engine(), backend="tcp")
+comm = TcpComm(runtime.get_engine())
 rank = comm.rank
 cones = os.path.join(%(root)r, "tests", "golden", "cones")
 L = np.array(Image.open(os.path.join(cones, "left.png"))).astype(np.float32)[40:200, 30:330]

@@ -4,7 +4,7 @@ steps that shard exactly: ZNCC 11x11 + WTA + vfit; the SGM step of that configur
 runs SGM pipelines over row tiles).  Every exchange is a RCCL collective inside libpandora_amd.so on device buffers:
 ncclAllReduce(min, uint64) of the packed keys, ncclAllReduce(sum) of the owner-refined maps.
 Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_multi.py
-(only the launcher's environment variables are used; PANDORA_COMM_BACKEND=tcp PANDORA_BENCH_DEVICE=0 runs several ranks on one GPU).
+(only the launcher's environment variables are used).  bench.py --gpus N runs the same steps as its `d_sharded_exact` leg.
 Rank 0 prints one JSON line: wall time per pair (max over ranks), Mdisp/s of the whole pair, ms spent in the collectives."""
 import argparse
 import json
@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     args = ap.parse_args()
     rank, world, local_rank, _, _ = env_world()
-    eng = Engine(int(os.environ.get("PANDORA_BENCH_DEVICE", local_rank)))
+    eng = Engine(local_rank)
     comm = Comm(eng, always=True)
     H, W, dmin, dmax = args.height, args.width, args.dmin, args.dmax
     L, R = bench.synthetic_pair(H, W, dmin, dmax)
