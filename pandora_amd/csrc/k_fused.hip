@@ -298,6 +298,7 @@ struct sum8_args {
     size_t dstride;         // bytes between the direction volumes
     int H, W, D, Dp, d0, o;
     int gl, kpl, nact;    // lane map the volumes were written with (nact = ceil(D / kpl) lanes own a disparity)
+    int nvol;             // volumes that add up to S: eight paths, or three direction families (k_sgmfam8.hip)
 };
 
 // is cell (r, c, k) a NaN of the census volume?  Geometry alone, or the snapshot cv_masked took (grids, left mask)
@@ -321,7 +322,7 @@ __device__ __forceinline__ bool cell_is_nan(const sum8_args& a, int r, int c, in
 // minimum, and the winner's lane also writes (S[k-1], S[k], S[k+1], k) for the refinement step.
 // As in the path kernel, GL*KPL > D makes the last slot of a group a pad, so the row shifts that fetch the
 // neighbour lane's edge value never leak a value of the next pixel into a valid result.
-template <int GL, int KPL>
+template <int GL, int KPL, int NV>
 __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix, double d0, float invalid_disparity,
                                                        float* __restrict__ disp, int64_t* __restrict__ validity,
                                                        float4* __restrict__ near) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
         const uint8_t* base = a.ldir + pix * a.Dp + (lane_active ? sub * M4 : 0);  // idle lanes re-read lane 0
         const uint8_t* tbase = a.ldir + pix * a.Dp + a.nact * M4 + (lane_active ? sub : 0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < NV; ++k) {
             uint32_t x[NB];
             __builtin_memcpy(x, base + k * vol, 4 * NB);
             if (T) s[KPL - 1] += tbase[k * vol];
@@ -419,8 +420,7 @@ __device__ __forceinline__ float sum8_cell(const sum8_args& a, size_t pix, int r
     const size_t vol = a.dstride;
     uint32_t s = 0;
     const int pos = fused_pos(k, a.nact, a.kpl);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += a.ldir[j * vol + pix * a.Dp + pos];
+    for (int j = 0; j < a.nvol; ++j) s += a.ldir[j * vol + pix * a.Dp + pos];
     return (float)s;
 }
 
@@ -548,6 +548,7 @@ static sum8_args make_sum8(const pmx_cv* cv) {
     s.dstride = cv->dstride;
     s.H = cv->H; s.W = cv->W; s.D = cv->D; s.Dp = cv->Dp; s.d0 = cv->d0; s.o = cv->win / 2;
     s.gl = cv->gl; s.kpl = cv->kpl; s.nact = cv->kpl ? (cv->D + cv->kpl - 1) / cv->kpl : 0;  // (no map before the SGM step)
+    s.nvol = cv->nvol;
     return s;
 }
 
@@ -665,7 +666,7 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
         PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->ldir, need + 64));
         cv->ldir_bytes = need;
     }
-    cv->Dp = Dp; cv->gl = gl; cv->kpl = kpl; cv->dstride = dstride;
+    cv->Dp = Dp; cv->gl = gl; cv->kpl = kpl; cv->dstride = dstride; cv->nvol = 8;
     const int nw = (cv->win * cv->win + 31) / 32;
     fused_args a;
     a.codeL = cv->codeL;
@@ -706,13 +707,21 @@ int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity)
     {
         pmx_stage_scope t(ctx, PMX_STAGE_WTA);
 #define PMX_WTA_CASE(GLV, KPLV)                                                                                         \
-    if (!launched && cv->gl == GLV && cv->kpl == KPLV) {                                                                \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sum8_wta_kernel<GLV, KPLV>), dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), \
+    if (!launched && cv->nvol == 8 && cv->gl == GLV && cv->kpl == KPLV) {                                              \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sum8_wta_kernel<GLV, KPLV, 8>), dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), \
                            npix, (double)cv->d0, invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near);     \
         launched = true;                                                                                                \
     }
         PMX_FUSED_MAPS(PMX_WTA_CASE)
 #undef PMX_WTA_CASE
+#define PMX_WTA3_CASE(KPLV)                                                                                             \
+    if (!launched && cv->nvol == 3 && cv->gl == 16 && cv->kpl == KPLV) {                                               \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sum8_wta_kernel<16, KPLV, 3>), dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), \
+                           npix, (double)cv->d0, invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near);     \
+        launched = true;                                                                                                \
+    }
+        PMX_WTA3_CASE(4) PMX_WTA3_CASE(8) PMX_WTA3_CASE(12) PMX_WTA3_CASE(16) PMX_WTA3_CASE(20)
+#undef PMX_WTA3_CASE
     }
     PMX_CHECK(launched, PMX_ERR_STATE, "pmx_wta (fused): no kernel for lane map %dx%d", cv->gl, cv->kpl);
     PMX_HIP(hipGetLastError());

@@ -24,6 +24,7 @@
 // register of the recurrence (three such pairs per dword).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "pmx_internal.h"
 
@@ -320,6 +321,122 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
         if (i + j < nsteps) step(ring[j]);
 }
 
+// ---- the horizontal pair, summed -----------------------------------------------------------------------------------------
+// Family form of the integer path (k_sgmfam8.hip): three byte volumes instead of eight.  The two horizontal paths of a row cannot
+// meet in registers (a row's forward costs are W x D values), so the backward pass ADDS into the volume the forward pass wrote:
+// a wavefront owns 4 rows, walks them left to right storing L_(0,+1), then right to left adding L_(0,-1) to what it reads back
+// through a second read-ahead ring (R cost + W, then R cost + R + W = 4.4 B/cell for two paths; the sums are <= 2 (invalid_cost
+// + P2) and bytes add as plain 32-bit adds).  Same recurrence, registers and cost formats as sgm_u8_packed_kernel<.., true>.
+template <int KPL, int CBITS>
+__global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args a) {
+    constexpr int Q = KPL / 4;
+    constexpr int PER = CBITS == 8 ? 4 : 6;
+    constexpr int NDW = (KPL + PER - 1) / PER;
+    static_assert(KPL % 4 == 0, "whole dwords per lane");
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const int gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves8 + (threadIdx.x >> 6));
+    const int H = a.H, W = a.W, D = a.D;
+    if (gwave * kLines8 >= H) return;
+    const int line = min(gwave * kLines8 + grp, H - 1);  // surplus groups of the last wave repeat the last row (same bytes)
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < D;
+    uint32_t padA[Q], padB[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int d = d_first + 4 * q;
+        padA[q] = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
+        padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
+    }
+    const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
+    struct slot_t { uint32_t x[NDW]; };
+    struct sum_t { uint32_t x[Q]; };
+
+    auto pass = [&](auto acc_tag) {
+        constexpr bool ACC = decltype(acc_tag)::value;
+        const int dc = ACC ? -1 : 1;
+        const int c0 = ACC ? W - 1 : 0;
+        const uint8_t* pC = a.cost + ((size_t)line * W + c0) * a.Dc + (lane_active ? sub * NDW * 4 : 0);
+        uint8_t* pO = a.ldir + ((size_t)line * W + c0) * a.Dp + d_first;
+        const uint8_t* pI = pO - (lane_active ? 0 : d_first);  // lanes without a disparity re-read lane 0 (nothing is stored)
+        int pleft = W - 1;
+        slot_t ring[kRing8];
+        sum_t prev[kRing8];
+        auto prefetch = [&](slot_t& sl, sum_t& pv) {
+            __builtin_memcpy(sl.x, pC, 4 * NDW);
+            if (ACC) __builtin_memcpy(pv.x, pI, 4 * Q);
+            if (pleft > 0) {  // wave-uniform; past the end the last pixel is re-read
+                --pleft;
+                pC += (ptrdiff_t)dc * a.Dc;
+                pI += (ptrdiff_t)dc * a.Dp;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < kRing8; ++i) prefetch(ring[i], prev[i]);
+        uint32_t A[Q], B[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
+        uint32_t M = 0u;
+        auto step = [&](slot_t& sl, sum_t& pv) {
+            const uint32_t belowB = dpp8<0x111>(kPadPk, B[Q - 1]);
+            const uint32_t aboveA = dpp8<0x101>(kPadPk, A[0]);
+            const uint32_t mp2 = M + P2pk, negM = 0u - M;
+            uint32_t nA[Q], nB[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                uint32_t ccA, ccB;
+                if (CBITS == 8) {
+                    ccA = (sl.x[q] & 0x00ff00ffu) | padA[q];
+                    ccB = ((sl.x[q] >> 8) & 0x00ff00ffu) | padB[q];
+                } else {
+                    constexpr uint32_t m5 = 0x001f001fu;
+                    ccA = ((sl.x[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
+                    ccB = ((sl.x[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
+                }
+                const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
+                const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
+                const uint32_t tA = hmin3(A[q], hmin(loA, B[q]) + P1pk, mp2);
+                const uint32_t tB = hmin3(B[q], hmin(A[q], hiB) + P1pk, mp2);
+                nA[q] = add3(tA, ccA, negM);
+                nB[q] = add3(tB, ccB, negM);
+            }
+            if (lane_active) {
+                uint32_t packed[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) packed[q] = (nA[q] | (nB[q] << 8)) + (ACC ? pv.x[q] : 0u);  // bytes d .. d+3 (pads spill upwards only)
+                __builtin_memcpy(pO, packed, 4 * Q);
+            }
+            uint32_t m = hmin(nA[0], nB[0]);
+#pragma unroll
+            for (int q = 1; q < Q; ++q) m = hmin3(m, nA[q], nB[q]);
+            uint32_t m1 = m & 0xffffu, m2 = m >> 16;
+            uint32_t lmin = m1 < m2 ? m1 : m2;
+            prefetch(sl, pv);
+            {
+                uint32_t t;
+                t = dpp8<0x128>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+                t = dpp8<0x124>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+                t = dpp8<0x122>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+                t = dpp8<0x121>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            }
+            M = lmin | (lmin << 16);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { A[q] = nA[q]; B[q] = nB[q]; }
+            pO += (ptrdiff_t)dc * a.Dp;
+        };
+        int i = 0;
+        for (; i + kRing8 <= W; i += kRing8) {
+#pragma unroll
+            for (int jj = 0; jj < kRing8; ++jj) step(ring[jj], prev[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < kRing8 - 1; ++jj)
+            if (i + jj < W) step(ring[jj], prev[jj]);
+    };
+    pass(std::false_type{});
+    pass(std::true_type{});
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 // Spacing of the eight path volumes: H*W*Dp rounded to 256 bytes.  PMX_DIR_SKEW=<bytes> (multiples of 4) adds a skew between
 // them - an experiment hook: skews of 4 KB ... 1 MB showed no benefit at C3 (tools/skew_probe.sh; the 7 % differences seen
@@ -351,13 +468,23 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->cost8, cvol + 64));
         cv->cost8_bytes = cvol;
     }
-    if (cv->ldir_bytes < 8 * vol) {
+    // Direction families (k_sgmfam8.hip) when a family's sum fits a byte: three volumes (horizontal pair, downward family, upward
+    // family) instead of eight.  PMX_SGM8_FAM=0 keeps the eight path volumes, =1 takes the families whatever the size (test hooks;
+    // by default images from 1536 columns on: below that the marching kernels have too few columns to fill the chip).
+    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && W >= 1536 && H >= 64;
+    if (const char* ef = getenv("PMX_SGM8_FAM")) {
+        if (ef[0] == '0') fam = false;
+        if (ef[0] == '1') fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u;
+    }
+    const int nvol = fam ? 3 : 8;
+    if (cv->ldir_bytes < (size_t)nvol * vol) {
         pmx_pool_free(ctx, cv->ldir);
         cv->ldir = nullptr;
         cv->ldir_bytes = 0;
-        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->ldir, 8 * vol + 64));
-        cv->ldir_bytes = 8 * vol;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->ldir, (size_t)nvol * vol + 64));
+        cv->ldir_bytes = (size_t)nvol * vol;
     }
+    cv->nvol = nvol;
     cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl; cv->dstride = vol;
     if (getenv("PMX_DEBUG_PTRS")) fprintf(stderr, "PMX_PTRS cost8=%p ldir=%p codes=%p vol=%zu cvol=%zu\n", (void*)cv->cost8, (void*)cv->ldir, (void*)cv->codes, vol, cvol);
     {
@@ -394,6 +521,26 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     sgm8_args a;
     a.cost = cv->cost8; a.ldir = cv->ldir; a.dstride = cv->dstride;
     a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.Dc = Dc; a.P1 = P1; a.P2 = P2;
+    if (fam) {
+        {   // volume 0: the horizontal pair
+            pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
+            const dim3 hgrid(((H + kLines8 - 1) / kLines8 + kWaves8 - 1) / kWaves8), hblock(kWaves8 * 64);
+#define PMX_HP(KPLV)                                                                                                       \
+    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 5>), hgrid, hblock, 0, ctx->stream, a);         \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 8>), hgrid, hblock, 0, ctx->stream, a)
+            switch (kpl) {
+                case 4: PMX_HP(4); break;
+                case 8: PMX_HP(8); break;
+                case 12: PMX_HP(12); break;
+                case 16: PMX_HP(16); break;
+                default: PMX_HP(20); break;
+            }
+#undef PMX_HP
+        }
+        PMX_HIP(hipGetLastError());
+        // volumes 1, 2: the downward and the upward family, one launch
+        return pmx_launch_sgm_fam8(ctx, cv, kpl, five, Dc, cv->ldir + vol, vol, P1, P2, 3);
+    }
     const int nwaves = 2 * ((H + kLines8 - 1) / kLines8) + 6 * ((W + kLines8 - 1) / kLines8);
     const dim3 grid((nwaves + kWaves8 - 1) / kWaves8), block(kWaves8 * 64);
     {

@@ -606,6 +606,31 @@ int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg
 
 }  // namespace
 
+// The strip-to-strip hand-off buffer of the marching kernels (this file and k_sgmfam8.hip): at least `halo_bytes`, zeroed when
+// (re)allocated so that a stale tag can never equal a future epoch (epochs count launches from 1), plus the ticket / error words.
+int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes) {
+    if (ctx->fam_halo_bytes < halo_bytes) {
+        if (ctx->fam_halo) PMX_HIP(hipFree(ctx->fam_halo));
+        ctx->fam_halo = nullptr;
+        ctx->fam_halo_bytes = 0;
+        PMX_HIP(hipMalloc((void**)&ctx->fam_halo, halo_bytes));
+        ctx->fam_halo_bytes = halo_bytes;
+        PMX_HIP(hipMemsetAsync(ctx->fam_halo, 0, halo_bytes, ctx->stream));
+        ctx->fam_epoch = 0;
+    }
+    if (!ctx->fam_ctl) {
+        PMX_HIP(hipMalloc((void**)&ctx->fam_ctl, 2 * sizeof(unsigned)));
+        PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, 2 * sizeof(unsigned), ctx->stream));
+        PMX_HIP(hipHostMalloc((void**)&ctx->fam_err_host, sizeof(unsigned), hipHostMallocDefault));
+        *ctx->fam_err_host = 0;
+    }
+    if (ctx->fam_epoch >= 0xfffffff0u) {  // epoch space used up: start over on a clean buffer
+        PMX_HIP(hipMemsetAsync(ctx->fam_halo, 0, ctx->fam_halo_bytes, ctx->stream));
+        ctx->fam_epoch = 0;
+    }
+    return PMX_OK;
+}
+
 bool pmx_sgm_family_supported(const pmx_cv* cv) { return cv->H >= 2 && pick_shape(cv->D, cv->W, nullptr); }
 
 int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
@@ -616,30 +641,12 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
     const int NB = (cv->W + CW - 1) / CW;
     const int NG = 3 * f.gl * ((f.kpl + 1) / 2) + 2, NGP = (NG + 63) / 64 * 64;  // 16-byte blocks per (row, border)
     const size_t halo_bytes = (size_t)cv->H * NB * NGP * 16;
-    if (ctx->fam_halo_bytes < halo_bytes) {
-        if (ctx->fam_halo) PMX_HIP(hipFree(ctx->fam_halo));
-        ctx->fam_halo = nullptr;
-        ctx->fam_halo_bytes = 0;
-        PMX_HIP(hipMalloc((void**)&ctx->fam_halo, halo_bytes));
-        ctx->fam_halo_bytes = halo_bytes;
-        // stale tags must never equal a future epoch: zero once, count epochs from 1
-        PMX_HIP(hipMemsetAsync(ctx->fam_halo, 0, halo_bytes, ctx->stream));
-        ctx->fam_epoch = 0;
-    }
-    if (!ctx->fam_ctl) {
-        PMX_HIP(hipMalloc((void**)&ctx->fam_ctl, 2 * sizeof(unsigned)));
-        PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, 2 * sizeof(unsigned), ctx->stream));
-        PMX_HIP(hipHostMalloc((void**)&ctx->fam_err_host, sizeof(unsigned), hipHostMallocDefault));
-        *ctx->fam_err_host = 0;
-    }
+    if (int rcp = pmx_fam_prepare(ctx, halo_bytes)) return rcp;
     const int nwg = (cv->W + cv->H - 2) / CW + 1;
     for (int fam = 0; fam < 2; ++fam) {
         const int bits = (mask >> (2 + 3 * fam)) & 7;  // definition order: vertical, predecessor c-1, predecessor c+1
         if (!bits || !(fams >> fam & 1)) continue;
-        if (ctx->fam_epoch == 0xffffffffu) {  // epoch space used up: start over on a clean buffer
-            PMX_HIP(hipMemsetAsync(ctx->fam_halo, 0, ctx->fam_halo_bytes, ctx->stream));
-            ctx->fam_epoch = 0;
-        }
+        if (int rcp = pmx_fam_prepare(ctx, halo_bytes)) return rcp;  // (epoch space used up: starts over on a clean buffer)
         fam_args a;
         a.C = cv->data;
         a.S = S;

@@ -1,0 +1,538 @@
+// k_sgmfam8.hip - the integer fast path's SGM as DIRECTION FAMILIES on packed 16-bit arithmetic.  gfx950.
+//
+// The one-launch-per-eight-paths kernel of k_sgm8.hip writes eight byte volumes and the WTA reads them back: 16 of the step's
+// ~22 B/cell are path volumes, and both kernels run at the speed of that traffic (profiles/r02_e_northstar_pmc_hbm.csv;
+// taking 12 % of the path kernel's instructions out moved nothing, profiles/r03_a_*).  The three paths that advance one image
+// row per step - (+1,0) (+1,+1) (+1,-1), or their mirror images - can be summed IN REGISTERS when one kernel marches down the
+// rows computing all three at each pixel: one byte per cell and family leaves the chip instead of three (every L_r <=
+// invalid_cost + P2, so a family's sum fits a byte whenever 3 * (invalid_cost + P2) <= 255: census 5x5 with P2 = 32 gives 174).
+// The horizontal pair is summed in k_sgm8.hip (the backward pass adds into the forward pass's volume).  Volumes: 8 -> 3.
+//
+// Decomposition: the float32 family kernel's (k_sgmfam.hip), restated for two disparities per 32-bit register.  Rows are
+// sequential, columns are the parallel axis; a workgroup owns a window of CW columns that SLIDES LEFT by one column per row,
+//     column(r, j) = base - r + j,   j = 0 .. CW-1,   base = s * CW,
+// so that the (+1,-1) path stays in its lane group (registers), the vertical path comes from local column j-1 and the (+1,+1)
+// path from j-2: every cross-window dependency points to the LEFT neighbour, workgroups form a one-directional pipeline, and the
+// hand-off latency is paid once as pipeline lag.  Window indices come from an atomic ticket (a window's left neighbour has
+// always started before it: no co-residency assumption); both families run in ONE launch (ticket & 1 = family), so that a CU
+// holds waves of both and the chip sees 2 x W columns of parallel work.  Inside a workgroup the two shifting paths go through
+// LDS as they are (packed u16 pairs, double-buffered by row parity, one barrier per row); the left neighbour's last two columns
+// arrive through global memory as BYTES (every L_r < 256) in 16-byte blocks {value, tag, value, tag}, tag = launch epoch, each
+// 8-byte half written by one sc1 store and self-validating (cdna_hip_programming.md Guideline 16, form R2), read by a dedicated
+// wave with bounded polling.  Same lane map as the path kernel and the cost kernel: 16 lanes per pixel, KPL = 4 Q consecutive
+// disparities per lane as A[q] = (L[4q], L[4q+2]), B[q] = (L[4q+1], L[4q+3]); 4 pixels per wave.
+//
+// Arithmetic: minima on the f16 pipe (positive halves order like integers; v_pk_minimum3_f16), additions as plain 32-bit adds of
+// packed pairs (no half overflows), "- M + C" in one v_add3_u32 - see k_sgm8.hip.  Semantics = oracle.c orc_sgm on integers:
+// L = C + min(Lp[d], min(Lp[d-1], Lp[d+1]) + P1, M + P2) - M, paths start from (Lp, M) = (0, 0) at the image border.
+#include <cstdlib>
+
+#include "pmx_buf.h"
+#include "pmx_internal.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+constexpr int kSc1 = 16;                    // aux bit of the buffer instructions: write-through store / L1-bypassing load
+constexpr uint32_t kPad16 = 0x7000u;        // what a padded disparity (d >= D) carries: beyond every real value, not an f16 NaN
+constexpr uint32_t kPadPk = 0x70007000u;
+constexpr unsigned kSpinLimit = 1u << 21;   // polls before a hand-off gives up
+
+__device__ __forceinline__ uint32_t hmin(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t hmin3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppo(uint32_t oldv, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)oldv, (int)src, CTRL, 0xf, 0xf, false);
+}
+
+struct fam8_args {
+    const uint8_t* cost;  // [H][W][Dc]: a pixel's costs lane by lane (k_sgm8.hip census_cost_u8_kernel)
+    uint8_t* out;         // family f's sums at out + f * dstride, [H][W][Dp] bytes in lane-map order
+    size_t dstride;
+    int H, W, D, Dp, Dc;
+    uint32_t P1, P2;
+    u32x4* halo;          // hand-off blocks [family][H][NB][NGP]
+    size_t halo_fam;      // blocks per family
+    int NB;               // window borders per row = ceil(W / CW)
+    unsigned epoch;
+    unsigned* ctl;        // [0] ticket counter (zero at launch), [1] error word
+    int fam0, nfam;       // families of this launch: fam0, fam0 + 1, ... (0 = downward, 1 = upward)
+};
+
+template <int N>
+__device__ __forceinline__ void load_dwords(__amdgpu_buffer_rsrc_t rs, unsigned off, uint32_t (&x)[N]) {
+    static_assert(N >= 1 && N <= 5, "cost dwords per lane");
+    if constexpr (N == 1) {
+        x[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+    } else if constexpr (N == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+        x[0] = t.x; x[1] = t.y;
+    } else if constexpr (N == 3) {
+        const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z;
+    } else {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+        if constexpr (N == 5) x[4] = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 16, 0, 0);
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, unsigned off, const uint32_t (&x)[N]) {
+    static_assert(N >= 1 && N <= 5, "bytes per lane / 4");
+    if constexpr (N == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(x[0], rs, off, 0, 0);
+    } else if constexpr (N == 2) {
+        u32x2 t; t.x = x[0]; t.y = x[1];
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, 0, 0);
+    } else if constexpr (N == 3) {
+        u32x3 t; t.x = x[0]; t.y = x[1]; t.z = x[2];
+        __builtin_amdgcn_raw_buffer_store_b96(t, rs, off, 0, 0);
+    } else {
+        u32x4 t; t.x = x[0]; t.y = x[1]; t.z = x[2]; t.w = x[3];
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
+        if constexpr (N == 5) __builtin_amdgcn_raw_buffer_store_b32(x[4], rs, off == kOob ? kOob : off + 16, 0, 0);
+    }
+}
+
+// One path, one pixel per 16-lane row: new path costs (nA, nB) from the predecessor's (A, B, M); returns the packed minimum of the
+// lane's new costs (both halves still to be reduced).
+template <int Q>
+__device__ __forceinline__ uint32_t path_update(const uint32_t (&A)[Q], const uint32_t (&B)[Q], uint32_t M, const uint32_t (&ccA)[Q],
+                                                const uint32_t (&ccB)[Q], uint32_t P1pk, uint32_t P2pk, uint32_t (&nA)[Q], uint32_t (&nB)[Q]) {
+    const uint32_t belowB = dppo<0x111>(kPadPk, B[Q - 1]);  // row_shr:1 - the previous lane's (.., L[d_first - 1]); +inf in lane 0
+    const uint32_t aboveA = dppo<0x101>(kPadPk, A[0]);      // row_shl:1 - the next lane's (L[d_first + KPL], ..); +inf in lane 15
+    const uint32_t mp2 = M + P2pk;
+    const uint32_t negM = 0u - M;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        // neighbours: A = (d, d+2) has lo = (d-1, d+1), hi = (d+1, d+3) = B;  B has lo = A, hi = (d+2, d+4)
+        const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
+        const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
+        const uint32_t tA = hmin3(A[q], hmin(loA, B[q]) + P1pk, mp2);
+        const uint32_t tB = hmin3(B[q], hmin(A[q], hiB) + P1pk, mp2);
+        nA[q] = add3(tA, ccA[q], negM);
+        nB[q] = add3(tB, ccB[q], negM);
+    }
+    uint32_t m = hmin(nA[0], nB[0]);
+#pragma unroll
+    for (int q = 1; q < Q; ++q) m = hmin3(m, nA[q], nB[q]);
+    return m;
+}
+
+// minima of three paths over the 16 lanes of each pixel, every lane receives them as (m | m << 16)
+__device__ __forceinline__ void group_min3(uint32_t& a, uint32_t& b, uint32_t& c) {
+    auto halves = [](uint32_t m) { const uint32_t lo = m & 0xffffu, hi = m >> 16; return lo < hi ? lo : hi; };
+    a = halves(a); b = halves(b); c = halves(c);
+    auto mn = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+    a = mn(a, dppo<0x128>(0xffffffffu, a)); b = mn(b, dppo<0x128>(0xffffffffu, b)); c = mn(c, dppo<0x128>(0xffffffffu, c));
+    a = mn(a, dppo<0x124>(0xffffffffu, a)); b = mn(b, dppo<0x124>(0xffffffffu, b)); c = mn(c, dppo<0x124>(0xffffffffu, c));
+    a = mn(a, dppo<0x122>(0xffffffffu, a)); b = mn(b, dppo<0x122>(0xffffffffu, b)); c = mn(c, dppo<0x122>(0xffffffffu, c));
+    a = mn(a, dppo<0x121>(0xffffffffu, a)); b = mn(b, dppo<0x121>(0xffffffffu, b)); c = mn(c, dppo<0x121>(0xffffffffu, c));
+    a |= a << 16; b |= b << 16; c |= c << 16;
+}
+
+template <int KPL, int CBITS, int NW, int PF>
+__global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
+    constexpr int Q = KPL / 4;                  // (A, B) register pairs per lane and path
+    constexpr int NR = 2 * Q;                   // registers per lane and path
+    constexpr int PER = CBITS == 8 ? 4 : 6;     // costs per dword of the cost volume
+    constexpr int NDW = (KPL + PER - 1) / PER;  // cost dwords per lane
+    constexpr int CW = NW * 4;                  // columns per window
+    constexpr int KS = (NR + 3) & ~3;           // LDS dwords per lane slice: A0 B0 A1 B1 ... (16-byte aligned)
+    constexpr int ES = 16 * KS + 4;             // LDS dwords per (path, column): 16 slices + the minimum
+    constexpr int EDIR = (CW + 2) * ES;         // one path: column slots -2 .. CW-1
+    constexpr int EBUF = 2 * EDIR;              // one row parity: vertical path, diagonal path
+    constexpr int NVB = 8 * Q;                  // hand-off blocks per vector: 16 Q dwords of packed bytes, two per block
+    constexpr int NG = 3 * NVB + 2;             // blocks per (row, border): V[CW-1], A[CW-1], A[CW-2], then their three minima
+    constexpr int NQ = (NG + 63) / 64;
+    constexpr int NGP = NQ * 64;
+    static_assert(KPL % 4 == 0 && KPL >= 4 && KPL <= 20, "whole dwords per lane");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds8[];
+    typedef __attribute__((address_space(3))) int lds_int;
+    volatile lds_int* ctl = (volatile lds_int*)(lds_int*)(lds8 + 2 * EBUF);  // [0] ticket, [1], [2] abort flag by row parity
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) {
+        ctl[0] = (int)atomicAdd(a.ctl, 1u);
+        ctl[1] = 0;
+        ctl[2] = 0;
+    }
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(ctl[0]);
+    const int fam = a.fam0 + ticket % a.nfam;  // 0: rows top -> bottom, paths (+1,0) (+1,+1) (+1,-1);  1: bottom -> top, mirrored
+    const int s = ticket / a.nfam;
+    const int H = a.H, W = a.W, D = a.D;
+    const int base = s * CW;
+    const int r_lo = base - W + 1 > 0 ? base - W + 1 : 0;
+    const int r_hi = base + CW - 1 < H - 1 ? base + CW - 1 : H - 1;
+    if (r_lo > r_hi) return;
+    gu32* errw = (gu32*)(a.ctl + 1);
+    u32x4* const halo = a.halo + (size_t)(fam - a.fam0) * a.halo_fam;
+    constexpr unsigned kBlockBytes = (unsigned)NGP * 16u;
+
+    if (wave == NW) {
+        // ---- hand-off wave: brings the left neighbour's columns CW-2, CW-1 of row t into column slots -2, -1 -------------------
+        int off0[NQ], off1[NQ];       // LDS dword offsets (within a row parity) of the block's two values
+        uint32_t pA0[NQ], pB0[NQ], pA1[NQ], pB1[NQ];  // pad masks of the two packed dwords (kind 2)
+        int kind[NQ];                 // 0 padding block, 2 two packed dwords, 3 minima (V, A of slot -1), 4 minimum (A of slot -2)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = q * 64 + lane;
+            kind[q] = 0; off0[q] = off1[q] = 0; pA0[q] = pB0[q] = pA1[q] = pB1[q] = 0;
+            if (idx < 3 * NVB) {
+                const int vec = idx / NVB, rem = idx - vec * NVB;
+                // vec 0: vertical path of column CW-1 -> slot -1;  1: diagonal of CW-1 -> slot -1;  2: diagonal of CW-2 -> slot -2
+                const int slot = (vec == 0 ? 0 : EDIR) + (vec == 2 ? 0 : ES);
+                auto place = [&](int m, int& off, uint32_t& pa, uint32_t& pb) {
+                    const int l = m / Q, qq = m - l * Q, d = l * KPL + 4 * qq;
+                    off = slot + l * KS + 2 * qq;
+                    pa = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
+                    pb = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
+                };
+                place(2 * rem, off0[q], pA0[q], pB0[q]);
+                place(2 * rem + 1, off1[q], pA1[q], pB1[q]);
+                kind[q] = 2;
+            } else if (idx == 3 * NVB) {
+                kind[q] = 3; off0[q] = ES + 16 * KS; off1[q] = EDIR + ES + 16 * KS;
+            } else if (idx == 3 * NVB + 1) {
+                kind[q] = 4; off0[q] = EDIR + 16 * KS; off1[q] = off0[q];
+            }
+        }
+        // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
+        const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
+        const int tB = (r_hi < base ? r_hi : base) - 1;
+        auto in_rsrc = [&](int t) {
+            const bool need = t >= tA && t <= tB;
+            const int cb = base - (t + 1);  // image column of the neighbour's last pixel on row t (0 <= cb < W when needed)
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0,
+                                                     need ? kBlockBytes : 0u, kRsrcWord3);
+        };
+        u32x4 x[NQ];
+        auto issue = [&](int t) {
+            const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
+        };
+        auto consume = [&](int t) -> bool {
+            if (t < tA || t > tB) return true;
+            const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) ok &= kind[q] == 0 || (x[q].y == a.epoch && x[q].w == a.epoch);
+                if (__all(ok)) break;
+                if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+                if (spins > kSpinLimit) {
+                    if (lane == 0) __hip_atomic_store(errw, 0x80000000u + (unsigned)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
+            }
+            uint32_t* Eb = lds8 + (t & 1) * EBUF;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (kind[q] == 2) {
+                    u32x2 v0, v1;  // bytes d, d+1, d+2, d+3 -> A = (d, d+2), B = (d+1, d+3), pads restored
+                    v0.x = (x[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((x[q].x >> 8) & 0x00ff00ffu) | pB0[q];
+                    v1.x = (x[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((x[q].z >> 8) & 0x00ff00ffu) | pB1[q];
+                    *(u32x2*)(Eb + off0[q]) = v0;
+                    *(u32x2*)(Eb + off1[q]) = v1;
+                } else if (kind[q] == 3) {
+                    Eb[off0[q]] = x[q].x;
+                    Eb[off1[q]] = x[q].z;
+                } else if (kind[q] == 4) {
+                    Eb[off0[q]] = x[q].x;
+                }
+            }
+            return true;
+        };
+        // Publishes row t of this window for window s+1: the compute waves left the path costs of local columns CW-2, CW-1 in LDS
+        // (column slots CW, CW+1 of row parity t & 1), complete once barrier t is passed and untouched until barrier t+1.  Window
+        // s+1 computes row t+1 at image column cb = base+CW-1-t: it exists and needs the row iff cb < W and t < H-1.
+        auto publish = [&](int t) {
+            const int cb = base + CW - 1 - t;
+            const bool need = t >= r_lo && cb < W && t < H - 1;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
+            const uint32_t* Eb = lds8 + (t & 1) * EBUF + CW * ES;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                u32x4 b;
+                b.y = a.epoch;
+                b.w = a.epoch;
+                if (kind[q] == 2) {
+                    const u32x2 v0 = *(const u32x2*)(Eb + off0[q]);
+                    const u32x2 v1 = *(const u32x2*)(Eb + off1[q]);
+                    b.x = v0.x | (v0.y << 8);  // (pads spill upwards only: into bytes that are pads themselves)
+                    b.z = v1.x | (v1.y << 8);
+                } else {
+                    b.x = Eb[off0[q]];
+                    b.z = Eb[off1[q]];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(b, rs, kind[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
+            }
+        };
+        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi.  Row t of the neighbour is asked for as
+        // early as it can exist (one look-ahead load per barrier), and polled for when it is due.
+        issue(r_lo - 1);
+        for (int t = r_lo - 1; t <= r_hi; ++t) {
+            publish(t - 1);
+            if (!consume(t)) ctl[1 + (t & 1)] = 1;
+            issue(t + 1);
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(ctl[1 + (t & 1)])) return;
+        }
+        publish(r_hi);
+        return;
+    }
+
+    // ---- compute waves ---------------------------------------------------------------------------------------------------
+    const int g = lane >> 4, sub = lane & 15;
+    const int j = wave * 4 + g;
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < D;
+    const unsigned cost_lane = lane_active ? (unsigned)sub * NDW * 4u : kOob;  // lanes without a disparity read zeros
+    const unsigned out_lane = (unsigned)sub * KPL;
+    const unsigned cost_row_bytes = (unsigned)W * (unsigned)a.Dc, out_row_bytes = (unsigned)W * (unsigned)a.Dp;
+    uint8_t* const outv = a.out + (size_t)fam * a.dstride;
+
+    uint32_t padA[Q], padB[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int d = d_first + 4 * q;
+        padA[q] = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
+        padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
+    }
+    const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
+
+    auto rimg_of = [&](int r) { return fam ? H - 1 - r : r; };
+    auto col_of = [&](int r) { return base - r + j; };
+
+    // loads of the costs run PF rows ahead in a register ring
+    int pr = r_lo;
+    struct slot_t { uint32_t x[NDW]; };
+    slot_t ring[PF];
+    auto prefetch = [&](slot_t& sl) {
+        const int c = col_of(pr);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(a.cost + (size_t)rimg_of(pr) * cost_row_bytes), 0, cost_row_bytes, kRsrcWord3);
+        load_dwords<NDW>(rs, (c >= 0 && c < W && lane_active) ? (unsigned)c * (unsigned)a.Dc + cost_lane : kOob, sl.x);
+        if (pr < r_hi) ++pr;
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) prefetch(ring[i]);
+
+    uint32_t LBa[Q], LBb[Q];  // the path that stays in its lane group (predecessor column c+1)
+    uint32_t MB = 0u;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { LBa[q] = padA[q]; LBb[q] = padB[q]; }
+
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(ctl[1 + ((r_lo - 1) & 1)])) return;
+
+    auto step = [&](int r, slot_t& sl) {
+        const int c = col_of(r);
+        const uint32_t* Ep = lds8 + ((r - 1) & 1) * EBUF;
+        uint32_t* En = lds8 + (r & 1) * EBUF;
+        // predecessors: vertical path (r-1, c) = local column j-1, diagonal (r-1, c-1) = local column j-2 (LDS, previous row
+        // parity), diagonal (r-1, c+1) = this lane group (registers)
+        uint32_t LVa[Q], LVb[Q], LAa[Q], LAb[Q];
+        {
+            const uint32_t* srcV = Ep + (j + 1) * ES + sub * KS;
+            const uint32_t* srcA = Ep + EDIR + j * ES + sub * KS;
+#pragma unroll
+            for (int i = 0; i < KS / 4; ++i) {
+                if (4 * i + 2 < NR) {
+                    const u32x4 t = *(const u32x4*)(srcV + 4 * i);
+                    const u32x4 u = *(const u32x4*)(srcA + 4 * i);
+                    LVa[2 * i] = t.x; LVb[2 * i] = t.y; LVa[2 * i + 1] = t.z; LVb[2 * i + 1] = t.w;
+                    LAa[2 * i] = u.x; LAb[2 * i] = u.y; LAa[2 * i + 1] = u.z; LAb[2 * i + 1] = u.w;
+                } else if (4 * i < NR) {
+                    const u32x2 t = *(const u32x2*)(srcV + 4 * i);
+                    const u32x2 u = *(const u32x2*)(srcA + 4 * i);
+                    LVa[2 * i] = t.x; LVb[2 * i] = t.y;
+                    LAa[2 * i] = u.x; LAb[2 * i] = u.y;
+                }
+            }
+        }
+        uint32_t MV = Ep[(j + 1) * ES + 16 * KS];
+        uint32_t MA = Ep[EDIR + j * ES + 16 * KS];
+        // costs of the pixel: (d, d+2) and (d+1, d+3) pairs, padded disparities carry kPad16
+        uint32_t ccA[Q], ccB[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (CBITS == 8) {
+                ccA[q] = (sl.x[q] & 0x00ff00ffu) | padA[q];
+                ccB[q] = ((sl.x[q] >> 8) & 0x00ff00ffu) | padB[q];
+            } else {  // pair jj of the lane: bits 5 * (jj % 3) of both halves of dword jj / 3 (census_cost_u8_kernel)
+                constexpr uint32_t m5 = 0x001f001fu;
+                ccA[q] = ((sl.x[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
+                ccB[q] = ((sl.x[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
+            }
+        }
+        // paths that start at this pixel (first row, image border): (Lp, M) = (0, 0).  Rare: a wave-uniform branch
+        const bool r0 = (r == 0);
+        const bool rsA = r0 || c == 0, rsB = r0 || c == W - 1;
+        if (__builtin_amdgcn_ballot_w64(rsA || rsB) != 0ull) {
+            asm volatile("; path starts" ::);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                LVa[q] = r0 ? padA[q] : LVa[q]; LVb[q] = r0 ? padB[q] : LVb[q];
+                LAa[q] = rsA ? padA[q] : LAa[q]; LAb[q] = rsA ? padB[q] : LAb[q];
+                LBa[q] = rsB ? padA[q] : LBa[q]; LBb[q] = rsB ? padB[q] : LBb[q];
+            }
+            MV = r0 ? 0u : MV; MA = rsA ? 0u : MA; MB = rsB ? 0u : MB;
+        }
+        uint32_t nVa[Q], nVb[Q], nAa[Q], nAb[Q], nBa[Q], nBb[Q];
+        uint32_t mV = path_update<Q>(LVa, LVb, MV, ccA, ccB, P1pk, P2pk, nVa, nVb);
+        uint32_t mA = path_update<Q>(LAa, LAb, MA, ccA, ccB, P1pk, P2pk, nAa, nAb);
+        uint32_t mB = path_update<Q>(LBa, LBb, MB, ccA, ccB, P1pk, P2pk, nBa, nBb);
+        group_min3(mV, mA, mB);
+        MB = mB;
+        // next row's predecessors
+        {
+            uint32_t* dstV = En + (j + 2) * ES + sub * KS;
+            uint32_t* dstA = En + EDIR + (j + 2) * ES + sub * KS;
+#pragma unroll
+            for (int i = 0; i < KS / 4; ++i) {
+                if (4 * i + 2 < NR) {
+                    u32x4 t, u;
+                    t.x = nVa[2 * i]; t.y = nVb[2 * i]; t.z = nVa[2 * i + 1]; t.w = nVb[2 * i + 1];
+                    u.x = nAa[2 * i]; u.y = nAb[2 * i]; u.z = nAa[2 * i + 1]; u.w = nAb[2 * i + 1];
+                    *(u32x4*)(dstV + 4 * i) = t;
+                    *(u32x4*)(dstA + 4 * i) = u;
+                } else if (4 * i < NR) {
+                    u32x2 t, u;
+                    t.x = nVa[2 * i]; t.y = nVb[2 * i];
+                    u.x = nAa[2 * i]; u.y = nAb[2 * i];
+                    *(u32x2*)(dstV + 4 * i) = t;
+                    *(u32x2*)(dstA + 4 * i) = u;
+                }
+            }
+            if (sub == 0) {
+                En[(j + 2) * ES + 16 * KS] = mV;
+                En[EDIR + (j + 2) * ES + 16 * KS] = mA;
+            }
+        }
+        // the family's sum leaves as bytes d, d+1, d+2, d+3 per dword (pads spill upwards only, into bytes that are pads)
+        uint32_t packed[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t sa = add3(nVa[q], nAa[q], nBa[q]), sb = add3(nVb[q], nAb[q], nBb[q]);
+            packed[q] = sa | (sb << 8);
+            LBa[q] = nBa[q];
+            LBb[q] = nBb[q];
+        }
+        {
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(outv + (size_t)rimg_of(r) * out_row_bytes), 0, out_row_bytes, kRsrcWord3);
+            store_dwords<Q>(rs, (c >= 0 && c < W && lane_active) ? (unsigned)c * (unsigned)a.Dp + out_lane : kOob, packed);
+        }
+        prefetch(sl);
+        __syncthreads();
+    };
+
+    int r = r_lo;
+    bool dead = false;
+    for (; r + PF <= r_hi + 1 && !dead; r += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (!dead) {
+                step(r + u, ring[u]);
+                dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
+            }
+        }
+    }
+    if (dead) return;
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) {
+        if (r + u <= r_hi && !dead) {
+            step(r + u, ring[u]);
+            dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
+        }
+    }
+}
+
+template <int KPL, int CBITS, int NW>
+int launch_fam8(pmx_ctx* ctx, const fam8_args& a, int nwg) {
+    constexpr int PF = 3;
+    constexpr int Q = KPL / 4, NR = 2 * Q, KS = (NR + 3) & ~3, ES = 16 * KS + 4, CW = NW * 4;
+    const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4) * sizeof(uint32_t);
+    auto kern = sgm_fam8_kernel<KPL, CBITS, NW, PF>;
+    PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 1) * 64), lds_bytes, ctx->stream, a);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
+}  // namespace
+
+// compute wavefronts per window for an image width: the smallest of 4 / 8 that keeps the chain of windows short (every window
+// border costs one hand-off per row and one step of pipeline lag)
+int pmx_fam8_waves(int W) {
+    if (const char* e = getenv("PMX_SGM8_FAM_NW")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8) return v;
+    }
+    return W >= 2048 ? 8 : 4;
+}
+
+bool pmx_fam8_supported(int kpl, int H) { return (kpl % 4) == 0 && kpl >= 4 && kpl <= 20 && H >= 2; }
+
+// Both vertical families (fams: bit 0 downward, bit 1 upward) into out + f * dstride
+int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, uint8_t* out, size_t dstride, uint32_t P1, uint32_t P2,
+                        int fams) {
+    const int nw = pmx_fam8_waves(cv->W), CW = nw * 4;
+    const int Q = kpl / 4;
+    const int NB = (cv->W + CW - 1) / CW;
+    const int NG = 3 * 8 * Q + 2, NGP = (NG + 63) / 64 * 64;
+    const int fam0 = (fams & 1) ? 0 : 1, nfam = (fams == 3) ? 2 : 1;
+    const size_t halo_fam = (size_t)cv->H * NB * NGP;
+    int rc = pmx_fam_prepare(ctx, halo_fam * nfam * 16);
+    if (rc) return rc;
+    fam8_args a;
+    a.cost = cv->cost8; a.out = out; a.dstride = dstride;
+    a.H = cv->H; a.W = cv->W; a.D = cv->D; a.Dp = cv->Dp; a.Dc = Dc;
+    a.P1 = P1; a.P2 = P2;
+    a.halo = (u32x4*)ctx->fam_halo; a.halo_fam = halo_fam; a.NB = NB;
+    a.epoch = ++ctx->fam_epoch;
+    a.ctl = ctx->fam_ctl;
+    a.fam0 = fam0; a.nfam = nfam;
+    const int nwin = (cv->W + cv->H - 2) / CW + 1;
+    PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));  // the ticket; the error word is sticky
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY);
+#define PMX_FAM8(KPLV, CB)                                                                              \
+    (nw == 8 ? launch_fam8<KPLV, CB, 8>(ctx, a, nwin * nfam) : launch_fam8<KPLV, CB, 4>(ctx, a, nwin * nfam))
+#define PMX_FAM8_KPL(KPLV) rc = five ? PMX_FAM8(KPLV, 5) : PMX_FAM8(KPLV, 8)
+        switch (kpl) {
+            case 4: PMX_FAM8_KPL(4); break;
+            case 8: PMX_FAM8_KPL(8); break;
+            case 12: PMX_FAM8_KPL(12); break;
+            case 16: PMX_FAM8_KPL(16); break;
+            default: PMX_FAM8_KPL(20); break;
+        }
+#undef PMX_FAM8_KPL
+#undef PMX_FAM8
+        if (rc) return rc;
+    }
+    PMX_HIP(hipMemcpyAsync(ctx->fam_err_host, ctx->fam_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    return PMX_OK;
+}

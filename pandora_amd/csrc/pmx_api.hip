@@ -1276,7 +1276,8 @@ extern "C" int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double 
 extern "C" int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp, int* gl,
                                     int* kpl) {
     PMX_CHECK(ctx && cv, PMX_ERR_ARG, "pmx_debug_path_costs: null argument");
-    PMX_CHECK(cv->repr == PMX_REPR_SGM_U8X8 && cv->ldir, PMX_ERR_STATE, "pmx_debug_path_costs: volume is not in the fused SGM representation");
+    PMX_CHECK(cv->repr == PMX_REPR_SGM_U8X8 && cv->ldir && cv->nvol == 8, PMX_ERR_STATE,
+              "pmx_debug_path_costs: volume is not in the fused SGM representation with eight path volumes");
     if (Dp) *Dp = cv->Dp;
     if (gl) *gl = cv->gl;
     if (kpl) *kpl = cv->kpl;

@@ -158,6 +158,7 @@ struct pmx_cv {
     int Dp = 0;
     size_t dstride = 0;  // bytes from one direction's volume to the next (H*W*Dp + a skew, see pmx_dir_stride)
     int gl = 0, kpl = 0;  // lane map of the fused kernels: gl lanes per scanline/pixel, kpl disparities per lane
+    int nvol = 8;         // byte volumes behind PMX_REPR_SGM_U8X8: eight paths, or three direction families (k_sgmfam8.hip)
     // uint8 matching costs [H][W][Dp] in the same lane-map order (packed-arithmetic SGM path, k_sgm8.hip)
     uint8_t* cost8 = nullptr;
     size_t cost8_bytes = 0;
@@ -281,6 +282,12 @@ bool pmx_sgm_family_supported(const pmx_cv* cv);
 // write S but reduces over D (k_sgmfam.hip WTA mode)
 int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
                             int mask, int fams, const pmx_fam_wta* wta);
+int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes);  // hand-off buffer + ticket / error words of the marching kernels
+// integer path as direction families (k_sgmfam8.hip): the vertical families' byte sums into out + f * dstride
+int pmx_fam8_waves(int W);
+bool pmx_fam8_supported(int kpl, int H);
+int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, uint8_t* out, size_t dstride, uint32_t P1, uint32_t P2,
+                        int fams);
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
 int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
 int pmx_near_select(pmx_ctx* ctx, const pmx_cv* cv, bool for_write);  // the winner cache of `cv` becomes ctx->near (see pmx_api.hip)

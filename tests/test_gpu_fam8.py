@@ -1,0 +1,138 @@
+"""GPU parity of the integer path's direction-family form (k_sgmfam8.hip + sgm_u8_hpair_kernel): three byte volumes (horizontal
+pair, downward family, upward family) instead of eight path volumes.  Forced onto small pairs with PMX_SGM8_FAM=1 (by default it
+takes images from 1536 columns on) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
+refinement.  Shapes exercise every lane map (KPL 4 ... 20), both window widths (16 / 32 columns), images narrower than a window,
+images a window does not divide, and windows that enter and leave the image during the march."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pandora_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture
+def forced_families(monkeypatch):
+    monkeypatch.setenv("PMX_SGM8_FAM", "1")
+    yield monkeypatch
+
+
+def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
+    D = dmax - dmin + 1
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(D, dmin)
+    eng.census(cv, win)
+    eng.sgm(cv, P1, P2, False, float(win * win + 1), False)
+    eng.set_validity(None)
+    eng.wta(cv, False, -9999.0)
+    eng.refine(cv, "vfit", False)
+    disp, val, itp = eng.get_disparity(want_itp=True)
+    with pytest.raises(Exception):
+        eng.debug_path_costs(cv, raw=True)  # (there are no eight path volumes: the family form ran)
+    vol = cv.to_host()
+    cv.free()
+    ref = oracle.sgm(oracle.census_cost(L, R, D, dmin, 1, win), P1, P2, False, float(win * win + 1), False)
+    rdisp, rval = oracle.wta(ref, dmin, 1, False, -9999.0)
+    ritp, rdisp2, rval2 = oracle.refine(ref, rdisp, rval, dmin, dmax, 1, False, "vfit")
+    np.testing.assert_array_equal(vol, ref)
+    np.testing.assert_array_equal(disp, rdisp2)
+    np.testing.assert_array_equal(val, rval2)
+    np.testing.assert_array_equal(itp, ritp)
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,win,P1,P2", [
+    (24, 37, -6, 3, 5, 8, 32),        # KPL 4, two windows of 16 columns + the ones that slide in
+    (33, 70, -60, 0, 5, 8, 32),       # KPL 4 (61 disparities)
+    (40, 100, 0, 64, 5, 8, 32),       # KPL 8
+    (21, 90, 0, 128, 3, 4, 20),       # KPL 12, census 3x3
+    (50, 45, -100, 100, 5, 8, 32),    # KPL 16 (201 disparities), more rows than columns
+    (30, 130, 0, 256, 5, 8, 32),      # KPL 20 (257 disparities): the headline's lane map
+    (9, 11, -2, 2, 3, 8, 32),         # narrower than one window
+    (2, 64, 0, 10, 5, 8, 32),         # two rows
+    (70, 16, -5, 5, 5, 1, 2),         # exactly one window wide, tall
+    (45, 67, -20, 20, 7, 8, 30),      # census 7x7: byte costs (invalid cost 50: 3 * 80 = 240 fits a byte)
+])
+@pytest.mark.parametrize("nw", ["4", "8"])
+def test_family_form_equals_the_oracle(eng, oracle, forced_families, H, W, dmin, dmax, win, P1, P2, nw):
+    forced_families.setenv("PMX_SGM8_FAM_NW", nw)
+    L, R = pair(H, W, seed=3 * H + W)
+    run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2)
+
+
+def test_family_form_is_not_taken_when_a_sum_would_not_fit_a_byte(eng, oracle, forced_families):
+    """census 9x9: invalid cost 82, 3 * (82 + 32) > 255 -> the eight path volumes stay"""
+    L, R = pair(30, 50, seed=4)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(9, -4)
+    eng.census(cv, 9)
+    eng.sgm(cv, 8, 32, False, 82.0, False)
+    raw, _, _ = eng.debug_path_costs(cv, raw=True)
+    assert raw.shape[0] == 8
+    ref = oracle.sgm(oracle.census_cost(L, R, 9, -4, 1, 9), 8, 32, False, 82.0, False)
+    np.testing.assert_array_equal(cv.to_host(), ref)
+    cv.free()
+
+
+def test_family_form_with_disparity_grids(eng, oracle, forced_families):
+    """cv_masked on the integer path (per-pixel ranges): invalid cells carry invalid_cost in the byte costs, as on the 8-path route"""
+    H, W, dmin, dmax, win = 40, 90, -12, 12, 5
+    L, R = pair(H, W, seed=77)
+    rng = np.random.default_rng(2)
+    gmin = rng.integers(dmin, -2, (H, W)).astype(np.float64)
+    gmax = rng.integers(2, dmax + 1, (H, W)).astype(np.float64)
+    D = dmax - dmin + 1
+    eng.set_images(L, R, 1)
+    eng.set_disparity_grids(gmin, gmax)
+    cv = eng.alloc_cv(D, dmin)
+    eng.census(cv, win)
+    eng.cv_masked(cv, win)
+    eng.sgm(cv, 8, 32, False, float(win * win + 1), False)
+    vol = cv.to_host()
+    cv.free()
+    eng.set_disparity_grids(None, None)
+    cpu = oracle.census_cost(L, R, D, dmin, 1, win)
+    oracle.cv_masked(cpu, dmin, 1, win, dmin=gmin, dmax=gmax)
+    np.testing.assert_array_equal(vol, oracle.sgm(cpu, 8, 32, False, float(win * win + 1), False))
+
+
+def test_family_form_mid_size_against_the_eight_volumes(eng):
+    """A pair large enough for dozens of windows in flight (and the default route from 1536 columns on): the family form and the
+    eight-volume form give the same maps bit for bit."""
+    from bench import synthetic_pair
+
+    H, W, dmin, dmax = 300, 1600, 0, 128
+    L, R = synthetic_pair(H, W, dmin, dmax, seed=5)
+    maps = {}
+    for mode in ("0", "auto"):
+        if mode == "auto":
+            os.environ.pop("PMX_SGM8_FAM", None)
+        else:
+            os.environ["PMX_SGM8_FAM"] = mode
+        try:
+            eng.set_images(L, R, 1)
+            cv = eng.alloc_cv(dmax - dmin + 1, dmin)
+            eng.census(cv, 5)
+            eng.sgm(cv, 8, 32, False, 26.0, False)
+            eng.set_validity(None)
+            eng.wta(cv, False, -9999.0)
+            eng.refine(cv, "vfit", False)
+            maps[mode] = eng.get_disparity(want_itp=True)
+            if mode == "auto":
+                with pytest.raises(Exception):
+                    eng.debug_path_costs(cv, raw=True)
+            cv.free()
+        finally:
+            os.environ.pop("PMX_SGM8_FAM", None)
+    for a, b in zip(maps["0"], maps["auto"]):
+        np.testing.assert_array_equal(a, b)
