@@ -327,6 +327,10 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
 // a wavefront owns 4 rows, walks them left to right storing L_(0,+1), then right to left adding L_(0,-1) to what it reads back
 // through a second read-ahead ring (R cost + W, then R cost + R + W = 4.4 B/cell for two paths; the sums are <= 2 (invalid_cost
 // + P2) and bytes add as plain 32-bit adds).  Same recurrence, registers and cost formats as sgm_u8_packed_kernel<.., true>.
+// The kernel moves 20 GB at 4096 x 4096 x 257 in 4.6 ms = 4.4 TB/s: HBM-bound even with one wavefront per SIMD.  Tried and
+// taken out again: a two-sided walk (wavefronts from both ends of the rows meeting at one barrier, the first arrival stores and the
+// second adds: twice the wavefronts, half the length) ran alone at the same 4.6 ms and, beside the marching kernel, slowed that
+// one from 10.1 to 12.1 ms (profiles/r03_b_*).
 template <int KPL, int CBITS>
 __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args a) {
     constexpr int Q = KPL / 4;
@@ -522,12 +526,28 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     a.cost = cv->cost8; a.ldir = cv->ldir; a.dstride = cv->dstride;
     a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.Dc = Dc; a.P1 = P1; a.P2 = P2;
     if (fam) {
+        // The horizontal pair has one wavefront per four rows (1024 at 4096 rows: one per SIMD, latency-bound on its own) and is
+        // independent of the vertical families: it runs on the context's second stream, beside the marching kernel
+        // (PMX_SGM8_OVERLAP=0 keeps everything in line: A/B hook).
+        const char* eo = getenv("PMX_SGM8_OVERLAP");
+        const bool overlap = !(eo && eo[0] == '0');
+        hipStream_t hs = ctx->stream;
+        if (overlap) {
+            if (!ctx->aux_stream) {
+                PMX_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+                PMX_HIP(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+                PMX_HIP(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+            }
+            PMX_HIP(hipEventRecord(ctx->aux_fork, ctx->stream));  // behind the cost kernel
+            PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+            hs = ctx->aux_stream;
+        }
         {   // volume 0: the horizontal pair
-            pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
+            pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED, hs);
             const dim3 hgrid(((H + kLines8 - 1) / kLines8 + kWaves8 - 1) / kWaves8), hblock(kWaves8 * 64);
 #define PMX_HP(KPLV)                                                                                                       \
-    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 5>), hgrid, hblock, 0, ctx->stream, a);         \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 8>), hgrid, hblock, 0, ctx->stream, a)
+    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 5>), hgrid, hblock, 0, hs, a);                  \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 8>), hgrid, hblock, 0, hs, a)
             switch (kpl) {
                 case 4: PMX_HP(4); break;
                 case 8: PMX_HP(8); break;
@@ -538,8 +558,11 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
 #undef PMX_HP
         }
         PMX_HIP(hipGetLastError());
+        if (overlap) PMX_HIP(hipEventRecord(ctx->aux_join, ctx->aux_stream));
         // volumes 1, 2: the downward and the upward family, one launch
-        return pmx_launch_sgm_fam8(ctx, cv, kpl, five, Dc, cv->ldir + vol, vol, P1, P2, 3);
+        const int rcf = pmx_launch_sgm_fam8(ctx, cv, kpl, five, Dc, cv->ldir + vol, vol, P1, P2, 3);
+        if (overlap) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));  // whoever reads the volumes next waits for both
+        return rcf;
     }
     const int nwaves = 2 * ((H + kLines8 - 1) / kLines8) + 6 * ((W + kLines8 - 1) / kLines8);
     const dim3 grid((nwaves + kWaves8 - 1) / kWaves8), block(kWaves8 * 64);

@@ -71,6 +71,7 @@ struct fam8_args {
     unsigned epoch;
     unsigned* ctl;        // [0] ticket counter (zero at launch), [1] error word
     int fam0, nfam;       // families of this launch: fam0, fam0 + 1, ... (0 = downward, 1 = upward)
+    int prio;             // wave priority of this launch's wavefronts (beside the horizontal-pair kernel on the second stream)
 };
 
 template <int N>
@@ -167,6 +168,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the marching pipeline is one long dependency chain (every row waits for the row before, every window for its neighbour):
+    // its wavefronts go first, whatever shares the SIMD with them (the horizontal pair on the second stream) fills the gaps
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) {
         ctl[0] = (int)atomicAdd(a.ctl, 1u);
         ctl[1] = 0;
@@ -515,6 +521,7 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.epoch = ++ctx->fam_epoch;
     a.ctl = ctx->fam_ctl;
     a.fam0 = fam0; a.nfam = nfam;
+    a.prio = getenv("PMX_SGM8_FAM_PRIO") ? atoi(getenv("PMX_SGM8_FAM_PRIO")) : 3;  // (0: 14.6 ms per 4096^2 x 257 step, 3: 13.9)
     const int nwin = (cv->W + cv->H - 2) / CW + 1;
     PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));  // the ticket; the error word is sticky
     {

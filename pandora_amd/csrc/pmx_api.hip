@@ -102,6 +102,12 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     hipFree(ctx->probe_sink);
     pmx_comm_destroy(ctx);
     pmx_comm_release(ctx);
+    if (ctx->aux_stream) {
+        hipStreamSynchronize(ctx->aux_stream);
+        hipStreamDestroy(ctx->aux_stream);
+    }
+    if (ctx->aux_fork) hipEventDestroy(ctx->aux_fork);
+    if (ctx->aux_join) hipEventDestroy(ctx->aux_join);
     hipFree(ctx->fam_halo);
     hipFree(ctx->fam_ctl);
     if (ctx->fam_err_host) hipHostFree(ctx->fam_err_host);

@@ -83,6 +83,10 @@ struct pmx_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t placed_ev = nullptr, gathered_ev = nullptr;
     bool gather_pending = false;  // gathered_ev has been recorded and somebody may still have to wait for it
+    // a second stream for kernels that are independent of each other inside ONE entry point (the horizontal pair of the integer SGM
+    // runs beside the marching kernel of the vertical families, k_sgm8.hip): forked from and joined back into `stream` by events
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     // pinned staging of pmx_set_images (both images of a pair)
     char* stage_host = nullptr;
     size_t stage_cap = 0;
