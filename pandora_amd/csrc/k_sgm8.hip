@@ -473,9 +473,11 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         cv->cost8_bytes = cvol;
     }
     // Direction families (k_sgmfam8.hip) when a family's sum fits a byte: three volumes (horizontal pair, downward family, upward
-    // family) instead of eight.  PMX_SGM8_FAM=0 keeps the eight path volumes, =1 takes the families whatever the size (test hooks;
-    // by default images from 1536 columns on: below that the marching kernels have too few columns to fill the chip).
-    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && W >= 1536 && H >= 64;
+    // family) instead of eight.  PMX_SGM8_FAM=0 keeps the eight path volumes, =1 takes the families whatever the size (test hooks).
+    // By default for large images only: the marching kernels want >= 3072 columns (one 32-column window per CU and family; at
+    // 2048 x 2048 x 129 the step takes 3.7 ms against 2.9), the horizontal pair >= 1536 rows (one wavefront per four rows; a
+    // 592-row tile of 4096 columns takes 4.8 ms against 4.2, a 4096 x 1024 image 7.8 against 3.7) - profiles/r03_b_shapes.txt.
+    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && W >= 3072 && H >= 1536;
     if (const char* ef = getenv("PMX_SGM8_FAM")) {
         if (ef[0] == '0') fam = false;
         if (ef[0] == '1') fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u;

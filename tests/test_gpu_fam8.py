@@ -1,6 +1,6 @@
 """GPU parity of the integer path's direction-family form (k_sgmfam8.hip + sgm_u8_hpair_kernel): three byte volumes (horizontal
 pair, downward family, upward family) instead of eight path volumes.  Forced onto small pairs with PMX_SGM8_FAM=1 (by default it
-takes images from 1536 columns on) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
+takes images from 3072 columns and 1536 rows on) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
 refinement.  Shapes exercise every lane map (KPL 4 ... 20), both window widths (16 / 32 columns), images narrower than a window,
 images a window does not divide, and windows that enter and leave the image during the march."""
 import os
@@ -107,11 +107,11 @@ def test_family_form_with_disparity_grids(eng, oracle, forced_families):
 
 
 def test_family_form_mid_size_against_the_eight_volumes(eng):
-    """A pair large enough for dozens of windows in flight (and the default route from 1536 columns on): the family form and the
-    eight-volume form give the same maps bit for bit."""
+    """A pair large enough for a hundred windows in flight and for the default route (>= 3072 columns, >= 1536 rows): the family
+    form and the eight-volume form give the same maps bit for bit."""
     from bench import synthetic_pair
 
-    H, W, dmin, dmax = 300, 1600, 0, 128
+    H, W, dmin, dmax = 1540, 3100, 0, 64
     L, R = synthetic_pair(H, W, dmin, dmax, seed=5)
     maps = {}
     for mode in ("0", "auto"):
