@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SGM_ALGO_BYTES_PER_CELL = 20.0  # two-sweep minimum for 8 paths
 PIPELINE_ALGO_BYTES_PER_CELL = 28.0  # census 4 + sgm 20 + wta 4
 SGM_MARGIN = 40  # rows of context an SGM tile carries on each side (reference: UniformMargins(40))
-STAGES = ("census_transform", "census_cost", "sgm_path", "sgm_family", "sgm_fused", "wta", "refine", "collective")
+STAGES = ("census_transform", "census_cost", "sgm_path", "sgm_family", "sgm_fused", "sgm_span", "wta", "refine", "collective")
 
 
 def synthetic_pair(H, W, dmin, dmax, seed=20260928):
@@ -113,41 +113,66 @@ def cpu_reference_compiled(L, R, dmin, dmax, win, rows):
                       f"{L.shape[0]}x{L.shape[1]} pair, D={D}, {dt:.1f} s"}
 
 
+def sgm_source_hash():
+    """sha256 (16 hex digits) of the sources of the integer path's SGM kernels: a committed traffic figure (rocprofv3 --pmc cannot
+    run inside bench.py) is only quoted while the kernels it was counted on are the ones that were built."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("k_sgm8.hip", "k_sgmfam8.hip", "k_fused.hip"):
+        with open(os.path.join(ROOT, "pandora_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def roofline_block(stage, steps, cells):
-    """The dominant kernel of the step: all 8 SGM paths in ONE launch on the integer path (20 B/cell algorithmic), else the
-    float32 schedule's path launches together (20 B/cell over the launches of one step)."""
-    if stage["sgm_fused"][1] > 0:
+    """The dominant kernel of the step.  Integer path, family form: sgm_fam8_kernel (the six vertical / diagonal paths as two
+    direction families in ONE launch) runs beside sgm_u8_hpair_kernel (the horizontal pair) on the context's two streams; the
+    launch duration of the marching kernel IS the span of the SGM step (fork -> join on the context's stream, HIP events), and all
+    8 paths are priced at SURVEY 8(d)'s 20 B/cell.  Integer path, eight volumes: all 8 paths in one launch.  Otherwise the float32
+    schedule's path launches of one step together."""
+    if stage.get("sgm_span", (0, 0))[1] > 0:
+        name = ("sgm_fam8_kernel (two direction families = 6 paths, packed u16 marching kernel, one launch) beside sgm_u8_hpair_kernel "
+                "(horizontal pair) on a second stream: the SGM step, fork -> join")
+        ms, n = stage["sgm_span"]
+        avg = ms / max(n, 1)
+    elif stage["sgm_fused"][1] > 0:
         name = "sgm_u8_packed_kernel (all 8 SGM paths in one launch, packed u16 arithmetic on 5-bit / byte costs)"
         ms, n = stage["sgm_fused"]
-        algo = SGM_ALGO_BYTES_PER_CELL * cells
         avg = ms / max(n, 1)
     else:
-        name = "float32 SGM schedule (sgm_path_kernel + sgm_family_kernel launches of one step)"
+        name = "float32 SGM schedule (sgm_h_* / sgm_path_kernel + sgm_family_kernel launches of one step)"
         ms = stage["sgm_path"][0] + stage["sgm_family"][0]
         n = stage["sgm_path"][1] + stage["sgm_family"][1]
-        algo = SGM_ALGO_BYTES_PER_CELL * cells
         avg = ms / max(steps, 1)
+    algo = SGM_ALGO_BYTES_PER_CELL * cells
     achieved = algo / (avg * 1e-3) / 1e9 if n else 0.0
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg, 4), "launches": n,
             "algorithmic_bytes_per_launch": algo}
 
 
-def pmc_traffic(H, W, D):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (they cannot run inside bench.py);
-    None when no pass exists for this shape."""
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if name.endswith("_pmc_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    pmc = json.load(f)
-                for w in pmc if isinstance(pmc, list) else [pmc]:
-                    wl = w["workload"]
-                    if (wl["H"], wl["W"], wl["D"]) == (H, W, D):
-                        return w["hbm_bytes_per_launch"]
-            except (OSError, KeyError, ValueError, TypeError):
-                continue
-    return None
+def add_traffic(roof, H, W, D):
+    """`traffic` = counted HBM bytes of the SGM kernels per step, (2 FETCH_SIZE + WRITE_SIZE) * 1024 from the committed rocprofv3 --pmc
+    passes of this very command (profiles/*_pmc_traffic.json, tools/pmc_traffic.py) - only while the kernel sources are the ones
+    the passes ran on; `frac_counted` prices the same launch time with those bytes instead of the algorithmic ones."""
+    prof = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(prof), reverse=True):
+        if not name.endswith("_pmc_traffic.json"):
+            continue
+        try:
+            with open(os.path.join(prof, name)) as f:
+                pmc = json.load(f)
+            for w in pmc if isinstance(pmc, list) else [pmc]:
+                wl = w["workload"]
+                if (wl["H"], wl["W"], wl["D"]) == (H, W, D) and w.get("kernel_source_sha16") == sgm_source_hash():
+                    roof["traffic"] = w["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = f"profiles/{name} (commit {w.get('commit')})"
+                    if roof["avg_launch_ms"] > 0:
+                        roof["frac_counted"] = round(w["hbm_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    return
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
 
 
 def pcie_inclusive_ms(eng, cv, L, R, win, P1, P2, reps=3):
@@ -166,7 +191,7 @@ def pcie_inclusive_ms(eng, cv, L, R, win, P1, P2, reps=3):
     return best
 
 
-def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed):
+def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed, pcie=True):
     """One pair on one GPU through the whole protocol; returns (ms per step, stage times, (L, R))."""
     L, R = synthetic_pair(H, W, dmin, dmax, seed=seed)
     eng.set_images(L, R, 1)
@@ -183,9 +208,57 @@ def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed):
     ms = (time.perf_counter() - t0) / steps * 1e3
     stage = {name: eng.stage_time(name) for name in STAGES}
     eng.set_profiling(False)
-    stage["(pcie inclusive)"] = (pcie_inclusive_ms(eng, cv, L, R, 5, 8.0, 32.0), 1)
+    if pcie:
+        stage["(pcie inclusive)"] = (pcie_inclusive_ms(eng, cv, L, R, 5, 8.0, 32.0), 1)
     cv.free()
     return ms, stage, (L, R)
+
+
+def config_leg(eng, L, R, dmin, dmax, cost, cbca, steps, label):
+    """One BASELINE configuration AS STATED on one GPU through the general float32 kernels (the cost volume is float32 between the
+    steps): cost = ("zncc", 11) or ("census", 5), optional CBCA (intensity 30, distance 5), SGM 8-path (P1 = 8, P2 = 32), WTA, vfit.
+    Same protocol as the headline: inputs resident, one warm-up, `steps` timed steps between stream syncs; per-stage HIP events of
+    the same steps.  Its roofline block prices the float32 SGM launches of a step at SURVEY 8(d)'s 20 B/cell."""
+    from pandora_amd import _lib
+
+    H, W = L.shape
+    D = dmax - dmin + 1
+    is_max = cost[0] == "zncc"
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(D, dmin)
+
+    def step():
+        if cost[0] == "census":
+            eng.census(cv, cost[1])
+        else:
+            eng.zncc(cv, cost[1])
+        if cbca:
+            eng.cbca(cv, cost[1] // 2, 30.0, 5)
+        eng.sgm(cv, 8.0, 32.0, is_max, float(cost[1] ** 2 + 1) if cost[0] == "census" else 2.0, False)
+        eng.set_validity(None)
+        eng.wta(cv, is_max, -9999.0)
+        eng.refine(cv, "vfit", is_max)
+
+    step()
+    eng.sync()
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    eng.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    stage = {k: eng.stage_time(k) for k in _lib.STAGES}
+    eng.set_profiling(False)
+    cv.free()
+    cells = H * W * D
+    roof = roofline_block({k: stage[k] for k in STAGES}, steps, cells)
+    per_cell = 36.0 if cbca else 28.0
+    return {"workload": label, "steps": steps, "ms_per_step": round(ms, 3), "value": round(cells / ms / 1e3, 1), "unit": "Mdisp/s",
+            "dtype": "f32", "roofline": roof,
+            "stage_ms_per_step": {k: round(v[0] / steps, 4) for k, v in stage.items() if v[1]},
+            "pipeline_hbm_frac": round(per_cell * cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "pipeline_algorithmic_bytes_per_cell": per_cell}
 
 
 def d_sharded_leg(eng, comm, L, R, dmin, dmax, win, steps, check_device):
@@ -373,7 +446,7 @@ def main():
         tile_cells = (tile_hi - tile_lo) * W * D  # what this rank's kernels worked on
         roof = roofline_block(stage, args.steps, tile_cells)
         if stage["sgm_fused"][1] > 0 and world == 1:
-            roof["traffic"] = pmc_traffic(H, W, D)
+            add_traffic(roof, H, W, D)
         if world == 1:
             parallelism = "1 GPU, no collective"
         else:
@@ -434,13 +507,32 @@ def main():
                 c3 = 2048 * 2048 * 129
                 r3 = roofline_block(st3, args.steps, c3)
                 if st3["sgm_fused"][1] > 0:
-                    r3["traffic"] = pmc_traffic(2048, 2048, 129)
+                    add_traffic(r3, 2048, 2048, 129)
                 out["c3_shape"] = {"workload": "2048x2048 synthetic pair, d=[0,128] (D=129): BASELINE configs[2], the round-1 headline; same "
                                                "pipeline and protocol", "steps": args.steps, "ms_per_step": round(ms3, 3),
                                    "value": round(c3 / ms3 / 1e3, 1), "unit": "Mdisp/s", "roofline": r3,
                                    "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in st3.items()},
                                    "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "pcie_inclusive_ms": round(pcie3, 3)}
+            if not args.no_configs and (H, W, D) == (4096, 4096, 257):
+                # the headline step again with plain hipMalloc placement (what a plugin user gets without pmx_set_placement_trials)
+                if args.placement_trials > 1:
+                    plain = Engine(local_rank)
+                    msd, std, _ = measure_shape(plain, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
+                    out["default_allocation"] = {"placement_trials": 1, "ms_per_step": round(msd, 3), "value": round(cells / msd / 1e3, 1),
+                                                 "unit": "Mdisp/s", "note": "same workload and protocol on a fresh context with plain hipMalloc"}
+                    plain.close()
+                # BASELINE configs[3] and configs[4] as stated, float32 between the steps, one GPU
+                eng.set_placement_trials(1)  # (six candidates of a 51.6 GB volume would not fit the device)
+                out["c4_as_stated"] = config_leg(eng, L, R, dmin, dmax, ("zncc", 11), False, 3,
+                                                 "BASELINE configs[3] as stated: 4096x4096 synthetic pair, d=[0,256] (D=257), ZNCC 11x11 + SGM 8-path "
+                                                 "+ WTA + vfit, float32 cost volume between the steps; one GPU")
+                L5, R5 = synthetic_pair(10000, 10000, -64, 64)
+                out["c5_as_stated"] = config_leg(eng, L5, R5, -64, 64, ("census", 5), True, 2,
+                                                 "BASELINE configs[4], fine scale, as stated: 10000x10000 synthetic pair, d=[-64,64] (D=129), "
+                                                 "Census 5x5 + CBCA + SGM 8-path + WTA + vfit, float32 cost volume between the steps; the whole "
+                                                 "strip on one GPU")
+                del L5, R5
             if args.cpu_rows > 0:  # the CPU legs belong to the N=1 line only
                 rows = min(args.cpu_rows, H)
                 base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)

@@ -33,7 +33,9 @@ enum {
     PMX_STAGE_CENSUS_TRANSFORM = 0, PMX_STAGE_CENSUS_COST = 1, PMX_STAGE_SAD_SSD = 2, PMX_STAGE_ZNCC = 3,
     PMX_STAGE_MASK = 4, PMX_STAGE_CBCA_ARMS = 5, PMX_STAGE_CBCA_H = 6, PMX_STAGE_CBCA_V = 7,
     PMX_STAGE_SGM_PATH = 8, PMX_STAGE_SGM_FINAL = 9, PMX_STAGE_WTA = 10, PMX_STAGE_REFINE = 11,
-    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_SGM_FUSED = 14, PMX_STAGE_SGM_FAMILY = 15, PMX_STAGE_COLLECTIVE = 16, PMX_STAGE_COUNT = 24
+    PMX_STAGE_REVERSE = 12, PMX_STAGE_MINKEY = 13, PMX_STAGE_SGM_FUSED = 14, PMX_STAGE_SGM_FAMILY = 15, PMX_STAGE_COLLECTIVE = 16,
+    PMX_STAGE_SGM_SPAN = 17, /* the whole SGM step when its kernels run side by side on two streams (fork -> join on the context's stream) */
+    PMX_STAGE_COUNT = 24
 };
 
 const char* pmx_last_error(void);

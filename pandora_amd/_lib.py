@@ -128,7 +128,7 @@ XBUFS = {"keys": (0, "uint64"), "nanpix": (1, "uint8"), "refine_pack": (2, "floa
 
 STAGES = {
     "census_transform": 0, "census_cost": 1, "sad_ssd": 2, "zncc": 3, "mask": 4, "cbca_arms": 5, "cbca_h": 6,
-    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13, "sgm_fused": 14, "sgm_family": 15, "collective": 16,
+    "cbca_v": 7, "sgm_path": 8, "sgm_final": 9, "wta": 10, "refine": 11, "reverse": 12, "minkey": 13, "sgm_fused": 14, "sgm_family": 15, "collective": 16, "sgm_span": 17,
 }
 
 

@@ -533,6 +533,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         // (PMX_SGM8_OVERLAP=0 keeps everything in line: A/B hook).
         const char* eo = getenv("PMX_SGM8_OVERLAP");
         const bool overlap = !(eo && eo[0] == '0');
+        pmx_stage_scope span(ctx, PMX_STAGE_SGM_SPAN);  // fork ... join on the context's stream: the SGM step as the pipeline sees it
         hipStream_t hs = ctx->stream;
         if (overlap) {
             if (!ctx->aux_stream) {
