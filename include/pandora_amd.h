@@ -132,6 +132,17 @@ int pmx_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance
 /* the arms alone (int16 [H-2o][W-2o][4]) for tests: side 0 = left, 1.. = right shifted image k-1 */
 int pmx_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* host_out);
 
+/* The reference's INNER native functions at their own granularity: what the pybind11 face pandora_amd.inner_cpp
+ * (csrc/inner_face.cpp) binds, signature for signature, so that aggregation/cbca.py can swap its import and keep its python loop.
+ * aggregation_cpp.cross_support(image, len_arms, intensity) (aggregation/cpp/src/aggregation.cpp:224-321): arms of a given image
+ * (already filtered, invalid pixels +inf), int16 [H][W][4] = left, right, top, bottom. */
+int pmx_cross_support_image(pmx_ctx* ctx, const float* image, int H, int W, int len_arms, float intensity, int16_t* host_out);
+/* aggregation_cpp.cbca(input, cross_left, cross_right, range_col, range_col_right) (aggregation.cpp:323-356 = steps 1-4, :28-221)
+ * on ONE disparity slice: input float32 [H][W], arms int16 [H][W][4] and [H][Wr][4], nvalid column pairs (left column, right
+ * column); out_e = fully aggregated cost, out_n = number of support pixels WITHOUT the anchor (cbca.py:166 adds it), float32 [H][W]. */
+int pmx_cbca_slice(pmx_ctx* ctx, const float* input, const int16_t* cross_left, const int16_t* cross_right, int H, int W, int Wr,
+                   const int64_t* range_col, const int64_t* range_col_right, int nvalid, float* out_e, float* out_n);
+
 /* ---- optimization --------------------------------------------------------------------------- */
 /* AbstractOptimization.optimize_cv (optimization/optimization.py:104-123) for method "sgm"; the
  * arithmetic is external to the reference (pandora_plugin_libsgm==1.5.7): see DESIGN.md. */

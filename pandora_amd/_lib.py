@@ -101,6 +101,8 @@ SIGNATURES = {
     "pmx_stream": (vp, [vp]),
     "pmx_host_alloc": (vp, [C.c_size_t]),
     "pmx_host_free": (None, [vp]),
+    "pmx_cross_support_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "pmx_cbca_slice": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]),
     "pmx_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
     "pmx_comm_init": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int]),
     "pmx_comm_destroy": (C.c_int, [vp]),

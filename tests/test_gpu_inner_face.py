@@ -1,0 +1,117 @@
+"""GPU: pandora_amd.inner_cpp - the pybind11 face with the reference's own native-function signatures (matching_cost_cpp /
+aggregation_cpp / refinement_cpp) - against the reference's COMPILED modules (oracle/_ref, built from /root/reference by
+oracle/Makefile) on the same numpy arguments, call for call, bit for bit.  Where oracle/_ref cannot be built (a box without the
+reference sources) the C restatement (oracle/liboracle.so, itself diffed against those modules) stands in."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def face():
+    from pandora_amd import inner_cpp
+
+    return inner_cpp
+
+
+def _ref(name):
+    from oracle import ref
+
+    return ref.load(name)
+
+
+@pytest.mark.parametrize("win,subpix,dmin,D", [(5, 1, -7, 12), (3, 2, -3, 11), (7, 4, 0, 17), (11, 1, -20, 9)])
+def test_compute_matching_costs_like_the_reference_module(face, oracle, win, subpix, dmin, D):
+    H, W = 23, 41
+    L, R = pair(H, W, seed=win + subpix)
+    rights = oracle.shift_right(R, subpix)  # what img_tools.shift_right_img hands to census.py:113-133
+    disps = (dmin + np.arange(D) / subpix).astype(np.float32)
+    cv = np.full((H, W, D), np.nan, np.float32)
+    got = face.compute_matching_costs(L, [np.ascontiguousarray(r) for r in rights], cv, disps, win, win)
+    assert got is cv  # written into and returned (census.cpp:106,179)
+    mc = _ref("matching_cost_cpp")
+    if mc is not None:
+        exp = mc.compute_matching_costs(L, [np.ascontiguousarray(r) for r in rights], np.full((H, W, D), np.nan, np.float32), disps, win, win)
+    else:
+        exp = oracle.census_cost(L, R, D, dmin, subpix, win)
+    np.testing.assert_array_equal(got, exp)
+    # forcecast semantics: a float64, strided left image and an integer disparity vector are silently converted
+    got2 = face.compute_matching_costs(np.asfortranarray(L.astype(np.float64)), [np.ascontiguousarray(r) for r in rights],
+                                       np.full((H, W, D), np.nan, np.float32), disps.astype(np.float64), win, win)
+    np.testing.assert_array_equal(got2, exp)
+    # cells the kernel cannot compute keep what the caller passed
+    seven = face.compute_matching_costs(L, [np.ascontiguousarray(r) for r in rights], np.full((H, W, D), 7.0, np.float32), disps, win, win)
+    np.testing.assert_array_equal(seven, np.where(np.isnan(exp), np.float32(7.0), exp))
+
+
+def test_cross_support_and_cbca_like_the_reference_module(face, oracle):
+    H, W, dmin, D = 31, 47, -6, 9
+    L, R = pair(H, W, seed=5, integer=False)
+    L[3, 4] = np.inf
+    R[10:12, 20:23] = np.inf
+    agg = _ref("aggregation_cpp")
+    armsL, armsR = face.cross_support(L, 5, 30.0), face.cross_support(R, 5, 30.0)
+    assert armsL.dtype == np.int16 and armsL.shape == (H, W, 4)
+    if agg is not None:
+        np.testing.assert_array_equal(armsL, agg.cross_support(L, 5, 30.0))
+        np.testing.assert_array_equal(armsR, agg.cross_support(R, 5, 30.0))
+    else:
+        np.testing.assert_array_equal(armsL, oracle.cross_support(L, 5, 30.0))
+    cv = np.random.default_rng(1).random((H, W, D)).astype(np.float32) * 40
+    cv[np.random.default_rng(2).random(cv.shape) < 0.1] = np.nan
+    range_col = np.arange(W)
+    for k in range(D):  # the loop of cbca.py:152-171
+        right = range_col + (dmin + k)
+        valid = np.where((right >= 0) & (right < W))
+        e, n = face.cbca(cv[:, :, k], armsL, armsR, range_col[valid], right[valid].astype(int))
+        assert e.dtype == np.float32 and n.dtype == np.float32 and e.shape == (H, W)
+        if agg is not None:
+            ee, en = agg.cbca(cv[:, :, k], armsL, armsR, range_col[valid], right[valid].astype(int))
+            np.testing.assert_array_equal(e, ee)
+            np.testing.assert_array_equal(n, en)
+    # the whole python recipe of cbca.py:127-177 around the face equals the fused device aggregation's restatement
+    exp = cv.copy()
+    oracle.cbca(exp, dmin, 1, 0, armsL, [armsR])
+    out = np.empty_like(cv)
+    for k in range(D):
+        right = range_col + (dmin + k)
+        valid = np.where((right >= 0) & (right < W))
+        e, n = face.cbca(cv[:, :, k], armsL, armsR, range_col[valid], right[valid].astype(int))
+        out[:, :, k] = (cv[:, :, k] * 0 + e) / (n + 1)
+    np.testing.assert_array_equal(out, exp)
+
+
+@pytest.mark.parametrize("method", ["vfit", "quadratic"])
+@pytest.mark.parametrize("measure,subpix", [("min", 1), ("max", 2)])
+def test_loop_refinement_like_the_reference_module(face, oracle, method, measure, subpix):
+    H, W, dmin, dmax = 19, 27, -4, 3
+    D = (dmax - dmin) * subpix + 1
+    rng = np.random.default_rng(8)
+    cv = rng.integers(0, 9, (H, W, D)).astype(np.float32)
+    cv[rng.random(cv.shape) < 0.1] = np.nan
+    disp, mask = oracle.wta(cv, dmin, subpix, measure == "max", -9999.0)
+    mask = mask.astype(np.int64)
+    fn = getattr(face, f"{method}_refinement_method")
+
+    def callback(cost, d, meas):  # the shape of vfit.py:43-45's staticmethod
+        return fn(cost, d, meas, 8)
+
+    itp, d2, m2 = face.loop_refinement(cv, disp.copy(), mask.copy(), float(dmin), float(dmax), subpix, measure, callback, 963, 8)
+    rf = _ref("refinement_cpp")
+    if rf is not None:
+        rfn = getattr(rf, f"{method}_refinement_method")
+        eitp, ed, em = rf.loop_refinement(cv, disp.copy(), mask.copy(), float(dmin), float(dmax), subpix, measure,
+                                          lambda cost, d, meas: rfn(cost, d, meas, 8), 963, 8)
+        for probe in ([3, 1, 2], [1, 1, 1], [np.nan, 1, 2], [2, 5, 3]):
+            c = np.array(probe, np.float32)
+            assert fn(c, 0.0, measure, 8) == pytest.approx(rfn(c, 0.0, measure, 8), nan_ok=True, abs=0)
+    else:
+        eitp, ed, em = oracle.refine(cv, disp.copy(), mask.copy(), dmin, dmax, subpix, measure == "max", method)
+    np.testing.assert_array_equal(itp, eitp)
+    np.testing.assert_array_equal(d2, ed)
+    np.testing.assert_array_equal(m2, em)
+    with pytest.raises(Exception):
+        face.loop_refinement(cv, disp, mask, float(dmin), float(dmax), subpix, measure, lambda c, d, m: (0.0, 0.0, 0), 963, 8)

@@ -619,3 +619,69 @@ def test_geometric_prior_optimises_every_segment_on_its_own():
         eng.sgm(half, 8.0, 32.0, False, 26.0)
         np.testing.assert_array_equal(whole[:, lo:hi], half.to_host(), err_msg=f"columns {lo}:{hi}")
         half.free()
+
+
+# ---- BASELINE.json configurations as they are worded, on the cones pair, whole volumes against the oracle ------------------------
+def _cones():
+    from PIL import Image
+
+    d = os.path.join(ROOT, "tests", "golden", "cones")
+    return (np.array(Image.open(os.path.join(d, "left.png"))).astype(np.float32),
+            np.array(Image.open(os.path.join(d, "right.png"))).astype(np.float32),
+            np.array(Image.open(os.path.join(d, "disp_left.tif"))).astype(np.float32))
+
+
+@pytest.mark.parametrize("lazy", [True, False], ids=["lazy", "eager"])
+def test_config2_as_stated_on_cones(oracle, lazy):
+    """BASELINE configs[1]: cones, Census 5x5 + CBCA (intensity 30., distance 5: the defaults, cbca.py:46-47) + SGM (P1 = 8, P2 = 32,
+    a_semi_global_matching.json:18-28) + WTA + vfit, d = [-60, 0]: the full 375 x 450 x 61 volume after the optimisation and the
+    three maps equal the oracle's pipeline bit for bit, with the lazy representations and without."""
+    from pandora_amd import runtime
+
+    L, R, gt = _cones()
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "census", "window_size": 5, "subpix": 1},
+                        "aggregation": {"aggregation_method": "cbca", "cbca_intensity": 30.0, "cbca_distance": 5},
+                        "optimization": {"optimization_method": "sgm", "overcounting": False,
+                                         "penalty": {"penalty_method": "sgm_penalty", "P1": 8, "P2": 32, "p2_method": "constant"}},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                        "refinement": {"refinement_method": "vfit"}}}
+    dmin, dmax = -60, 0
+    runtime.get_engine().set_lazy(lazy)
+    try:
+        machine, left_disp = run_machine(L, R, cfg, dmin, dmax)
+        got_cv = machine.left_cv["cost_volume"].data
+    finally:
+        runtime.get_engine().set_lazy(True)
+    mc_only = {"pipeline": {"matching_cost": cfg["pipeline"]["matching_cost"], "disparity": {"disparity_method": "wta"}}}
+    cv0, _, _, _ = oracle_pipeline(oracle, L, R, mc_only, dmin, dmax)
+    val0 = expected_validity(L, R, cfg, dmin, dmax, None, None, np.min(np.isnan(cv0), axis=2))
+    ecv, edisp, eval_, eitp = oracle_pipeline(oracle, L, R, cfg, dmin, dmax, validity0=val0)
+    assert got_cv.shape == (375, 450, 61)
+    np.testing.assert_array_equal(got_cv, ecv)
+    np.testing.assert_array_equal(left_disp["disparity_map"].data, edisp)
+    np.testing.assert_array_equal(left_disp["validity_mask"].data, eval_)
+    np.testing.assert_array_equal(left_disp["interpolated_coeff"].data, eitp)
+    bad = (np.abs(np.nan_to_num(edisp, nan=1e4) + gt) > 1) & (gt != 0)
+    assert bad.sum() / gt.size <= 0.20  # the reference's gate (tests/functional_tests/test_basic.py:120-156)
+
+
+def test_config1_as_baseline_words_it(oracle):
+    """BASELINE configs[0] as its string describes it: cones, SAD 5x5, d = [-64, 0], WTA (+ vfit) - beside the
+    as-written a_local_block_matching.json run of test_quality_cones.py.  Whole volume and maps against the oracle, bit for bit
+    (float32 summation order included)."""
+    L, R, gt = _cones()
+    cfg = {"pipeline": {"matching_cost": {"matching_cost_method": "sad", "window_size": 5, "subpix": 1},
+                        "disparity": {"disparity_method": "wta", "invalid_disparity": "NaN"},
+                        "refinement": {"refinement_method": "vfit"}}}
+    dmin, dmax = -64, 0
+    machine, left_disp = run_machine(L, R, cfg, dmin, dmax)
+    got_cv = machine.left_cv["cost_volume"].data
+    cv0, _, _, _ = oracle_pipeline(oracle, L, R, {"pipeline": {"matching_cost": cfg["pipeline"]["matching_cost"],
+                                                              "disparity": {"disparity_method": "wta"}}}, dmin, dmax)
+    val0 = expected_validity(L, R, cfg, dmin, dmax, None, None, np.min(np.isnan(cv0), axis=2))
+    ecv, edisp, eval_, eitp = oracle_pipeline(oracle, L, R, cfg, dmin, dmax, validity0=val0)
+    assert got_cv.shape == (375, 450, 65)
+    np.testing.assert_array_equal(got_cv, ecv)
+    np.testing.assert_array_equal(left_disp["disparity_map"].data, edisp)
+    np.testing.assert_array_equal(left_disp["validity_mask"].data, eval_)
+    np.testing.assert_array_equal(left_disp["interpolated_coeff"].data, eitp)
