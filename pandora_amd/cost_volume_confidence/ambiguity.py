@@ -20,9 +20,14 @@ def percentiles(values, qs):
     n = a.size
     if a.dtype != np.float32 or n < (1 << 16):
         return [np.percentile(a, q) for q in qs]
-    # numpy's "linear" method: virtual index (n - 1) * q / 100 - in the ARRAY's dtype (np.percentile divides q by a.dtype.type(100):
-    # for a float32 map the index itself is a float32, a 4 Mpx map's gamma is good to 1/4 only; mirrored, not improved)
-    virtual = [(n - 1) * np.true_divide(q, a.dtype.type(100)) for q in qs]
+    # numpy's "linear" method: virtual index (n - 1) * q / 100.  Under numpy 2 (NEP 50: python scalars are weak) np.percentile
+    # divides q by a.dtype.type(100) and the index of a float32 map is itself a float32 (a 4 Mpx map's gamma is good to 1/4
+    # only); under numpy 1's value-based casting it is a float64.  Mirrored - whatever the installed numpy does, so that small
+    # maps (np.percentile itself) and large ones agree and the reference's normalisation bounds come out on its numpy too.
+    if int(np.__version__.split(".")[0]) >= 2:
+        virtual = [(n - 1) * np.true_divide(q, a.dtype.type(100)) for q in qs]
+    else:
+        virtual = [(n - 1) * (np.float64(q) / 100.0) for q in qs]
     lows = [int(np.floor(v)) for v in virtual]
     ranks = sorted({r for lo in lows for r in (lo, min(lo + 1, n - 1))} | {n - 1})
     stats = dict(zip(ranks, runtime.get_engine().order_statistics(a, ranks)))

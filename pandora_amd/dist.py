@@ -70,7 +70,7 @@ def stitch_tiles(parts):
 
 
 def tile_dataset(ds, rlo, rhi):
-    """Rows [rlo, rhi) of an image dataset (im, msk, disparity grids), attrs shared."""
+    """Rows [rlo, rhi) of an image dataset (im, msk, disparity grids, segm / edges / classif layers), attrs shared."""
     from .dataset import DataArray, Dataset
 
     im = np.asarray(ds["im"].data)
@@ -82,6 +82,12 @@ def tile_dataset(ds, rlo, rhi):
     if "disparity" in ds.data_vars:
         out["disparity"] = DataArray(np.ascontiguousarray(np.asarray(ds["disparity"].data)[:, rows]), ("band_disp", "row", "col"),
                                      {"band_disp": ["min", "max"]})
+    for name in ("segm", "edges"):  # the layers an SGM geometric_prior may name (img_tools.add_layers): 2-D, sliced like the image
+        if name in ds.data_vars:
+            out[name] = (("row", "col"), np.ascontiguousarray(np.asarray(ds[name].data)[rows]))
+    if "classif" in ds.data_vars:   # (band_classif, row, col)
+        out["classif"] = DataArray(np.ascontiguousarray(np.asarray(ds["classif"].data)[:, rows]), ds["classif"].dims,
+                                   {k: v for k, v in getattr(ds["classif"], "coords", {}).items()})
     return out
 
 

@@ -72,11 +72,14 @@ class _PinnedBlock:
         else:
             self.addr = _lib.lib().pmx_host_alloc(self.nbytes)
         if not self.addr:
+            self.addr = None  # (nothing for __del__ to put into the pool)
             raise MemoryError(f"pmx_host_alloc({nbytes})")
         self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.addr, False), "version": 3}
 
     def __del__(self):
         try:
+            if not getattr(self, "addr", None):
+                return  # the allocation failed: there is no block
             if self._pool_bytes[0] + self.nbytes <= self.POOL_MAX:
                 self._pool.setdefault(self.nbytes, []).append(self.addr)
                 self._pool_bytes[0] += self.nbytes
@@ -90,7 +93,10 @@ def pinned_empty(shape, dtype):
     """np.empty in page-locked memory (recycled through a small pool): the destination of result downloads."""
     dtype = np.dtype(dtype)
     n = int(np.prod(shape)) * dtype.itemsize
-    return np.asarray(_PinnedBlock(max(n, 1)))[:n].view(dtype).reshape(shape)
+    try:
+        return np.asarray(_PinnedBlock(max(n, 1)))[:n].view(dtype).reshape(shape)
+    except MemoryError:  # no page-locked memory left: a pageable destination is slower, not wrong
+        return np.empty(shape, dtype)
 
 
 class DeviceMapArray:

@@ -4,7 +4,13 @@
 PARITY UNPINNED for the pyramid itself: the reference calls skimage.transform.pyramid_gaussian(sigma=1.2, order=1,
 mode="reflect"), and scikit-image is not installed here.  `_pyramid_reduce` restates what that function does with the
 scipy.ndimage calls scikit-image itself makes (gaussian_filter in 'reflect' mode, then resize = ndimage.zoom with
-grid_mode=True and the 'mirror' boundary that skimage maps 'reflect' to, anti-aliasing off)."""
+grid_mode=True and the 'mirror' boundary that skimage maps 'reflect' to, anti-aliasing off).
+
+What the documented definition of pyramid_gaussian fixes for ANY faithful implementation is tested in
+tests/test_pyramid_properties.py: layer shapes ceil(n / downscale), layers stop when they no longer shrink, constants are kept,
+a linear ramp is sampled at the pixel-centre grid x_j = (j + 0.5) * downscale - 0.5, linearity, mirror symmetry, the 1.2-pixel
+gaussian, and on even sizes the 2 x 2 block mean of the smoothed image.  A vector from scikit-image itself would pin the rest
+(border handling of the resize); until then the row stays "parity unpinned" in DESIGN.md."""
 import math
 
 import numpy as np

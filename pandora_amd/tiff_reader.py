@@ -13,8 +13,11 @@ _TYPES = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 8: "h", 9: "i", 11: "
 _SIZES = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 6: 1, 8: 2, 9: 4, 11: 4, 12: 8, 16: 8}
 
 
-GEO_TAGS = (33550, 33922, 34264, 34735, 34736, 34737, 42113)  # pixel scale, tiepoints, 4x4 transformation, GeoKey directory /
-#                                                                  double / ASCII parameters, GDAL no-data
+GEO_TAGS = (33550, 33922, 34264, 34735, 34736, 34737)  # pixel scale, tiepoints, 4x4 transformation, GeoKey directory / double /
+#                                                           ASCII parameters.  NOT 42113 (GDAL_NODATA): the reference hands
+#                                                           rasterio crs and transform only (common.py:66-95); an input's no-data
+#                                                           value copied into the outputs would make GDAL readers drop every valid
+#                                                           validity-mask pixel (0) and every zero disparity
 
 
 def read_tags(path):

@@ -202,3 +202,28 @@ def test_rendezvous_steps_past_a_port_somebody_else_holds():
         stop.set()
         t.join()
         foreign.close()
+
+
+def test_row_tiles_keep_the_layers_a_geometric_prior_names():
+    """dist.tile_dataset slices segm / edges like the image and classif along its rows, band names kept: an SGM geometric_prior
+    (plugin_libsgm.rst:49-78) on a row-tiled run finds its source layer in every tile."""
+    from pandora_amd import dist as pd
+    from pandora_amd.dataset import DataArray, make_image
+
+    H, W = 23, 11
+    rng = np.random.default_rng(1)
+    ds = make_image(rng.random((H, W)).astype(np.float32), disparity=[-3, 3], msk=rng.integers(0, 2, (H, W)).astype(np.int16))
+    ds["segm"] = (("row", "col"), rng.integers(0, 4, (H, W)).astype(np.int16))
+    ds["edges"] = (("row", "col"), rng.integers(0, 2, (H, W)).astype(np.int16))
+    ds.coords["band_classif"] = np.array(["water", "forest"], dtype=object)
+    ds["classif"] = DataArray(rng.integers(0, 2, (2, H, W)).astype(np.int16), ("band_classif", "row", "col"))
+    for world in (2, 3):
+        for rank in range(world):
+            (lo, hi), (rlo, rhi) = pd.row_tile(H, world, rank, margin=4)
+            t = pd.tile_dataset(ds, rlo, rhi)
+            for name in ("im", "msk", "segm", "edges"):
+                np.testing.assert_array_equal(np.asarray(t[name].data), np.asarray(ds[name].data)[rlo:rhi])
+            np.testing.assert_array_equal(np.asarray(t["classif"].data), np.asarray(ds["classif"].data)[:, rlo:rhi])
+            np.testing.assert_array_equal(np.asarray(t["disparity"].data), np.asarray(ds["disparity"].data)[:, rlo:rhi])
+            assert list(t.coords["band_classif"]) == ["water", "forest"] and t["classif"].dims == ("band_classif", "row", "col")
+            assert t.sizes["row"] == rhi - rlo
