@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "pmx_buf.h"
 #include "pmx_internal.h"
 
 static constexpr int kWaves8 = 4;       // wavefronts per workgroup
@@ -327,10 +328,9 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
 // a wavefront owns 4 rows, walks them left to right storing L_(0,+1), then right to left adding L_(0,-1) to what it reads back
 // through a second read-ahead ring (R cost + W, then R cost + R + W = 4.4 B/cell for two paths; the sums are <= 2 (invalid_cost
 // + P2) and bytes add as plain 32-bit adds).  Same recurrence, registers and cost formats as sgm_u8_packed_kernel<.., true>.
-// The kernel moves 20 GB at 4096 x 4096 x 257 in 4.6 ms = 4.4 TB/s: HBM-bound even with one wavefront per SIMD.  Tried and
-// taken out again: a two-sided walk (wavefronts from both ends of the rows meeting at one barrier, the first arrival stores and the
-// second adds: twice the wavefronts, half the length) ran alone at the same 4.6 ms and, beside the marching kernel, slowed that
-// one from 10.1 to 12.1 ms (profiles/r03_b_*).
+// The kernel moves 20 GB at 4096 x 4096 x 257 in 4.6 ms = 4.4 TB/s: HBM-bound even with one wavefront per SIMD.  The two-sided
+// walk below (twice the wavefronts, half the steps) ran alone at the same 4.6 ms there and, beside the marching kernel, slowed
+// that one from 10.1 to 12.1 ms; it is the form for SHORT images, where this kernel's few wavefronts are latency-bound.
 template <int KPL, int CBITS>
 __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args a) {
     constexpr int Q = KPL / 4;
@@ -441,6 +441,175 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args
     pass(std::true_type{});
 }
 
+// The horizontal pair for SHORT images (row tiles of a multi-GPU run): with one wavefront per four rows a 592-row tile has 148
+// wavefronts for 1024 SIMDs and every one of them walks 2 x W latency-bound steps (4.1 ms at W = 4096 whatever the height).  Here
+// the walk is TWO-SIDED: a workgroup's wavefronts 0, 1 walk four rows each from the left, wavefronts 2, 3 the same rows from the
+// right; each stores on the first half of its walk (nobody has been there), all four meet at one barrier, and each adds on the
+// second half to what the partner stored (read through a second look-ahead ring with L1-bypassing loads: the bytes came from
+// another wavefront).  Twice the wavefronts, half the steps.  At full height it is no faster than the one-sided kernel (both are
+// then HBM-bound) and takes more from the marching kernel beside it, so the launcher picks by height.
+template <int KPL, int CBITS>
+__global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair2_kernel(sgm8_args a) {
+    constexpr int Q = KPL / 4;
+    constexpr int PER = CBITS == 8 ? 4 : 6;
+    constexpr int NDW = (KPL + PER - 1) / PER;
+    static_assert(KPL % 4 == 0 && kWaves8 == 4, "whole dwords per lane; two row groups per workgroup");
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rgroup = blockIdx.x * 2 + (wv & 1);  // four rows
+    const bool backward = wv >= 2;
+    const int H = a.H, W = a.W, D = a.D;
+    if (rgroup * kLines8 >= H) return;  // (both wavefronts of the row group leave together)
+    const int line = min(rgroup * kLines8 + grp, H - 1);  // surplus groups of the last wave repeat the last row (same bytes)
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < D;
+    uint32_t padA[Q], padB[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int d = d_first + 4 * q;
+        padA[q] = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
+        padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
+    }
+    const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
+    struct slot_t { uint32_t x[NDW]; };
+    struct sum_t { uint32_t x[Q]; };
+
+    const int dc = backward ? -1 : 1;
+    const int c0 = backward ? W - 1 : 0;
+    const int nfirst = backward ? W - W / 2 : W / 2;  // columns [0, W/2) belong to the forward walk's first half
+    const uint8_t* pC = a.cost + ((size_t)line * W + c0) * a.Dc + (lane_active ? sub * NDW * 4 : 0);
+    uint8_t* pO = a.ldir + ((size_t)line * W + c0) * a.Dp + d_first;
+    int pleft = W - 1;
+    slot_t ring[kRing8];
+    sum_t prev[kRing8];
+    auto fetch_cost = [&](slot_t& sl) {
+        __builtin_memcpy(sl.x, pC, 4 * NDW);
+        if (pleft > 0) {  // wave-uniform; past the end the last pixel is re-read
+            --pleft;
+            pC += (ptrdiff_t)dc * a.Dc;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < kRing8; ++i) fetch_cost(ring[i]);
+    uint32_t A[Q], B[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
+    uint32_t M = 0u;
+
+    // the partner's bytes: this lane's Q dwords of pixel (line, ci), through the L1-bypassing path
+    const __amdgpu_buffer_rsrc_t rsum = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ldir + (size_t)(rgroup * kLines8) * W * a.Dp), 0,
+                                                                            (unsigned)(min(kLines8, H - rgroup * kLines8) * W * a.Dp), kRsrcWord3);
+    int ci = c0 + dc * nfirst;  // column the sum ring reads next
+    int ileft = W - nfirst;
+    auto fetch_sum = [&](sum_t& pv) {
+        const unsigned off = (unsigned)((line - rgroup * kLines8) * W + ci) * (unsigned)a.Dp + (lane_active ? (unsigned)d_first : 0u);
+        if constexpr (Q == 1) {
+            pv.x[0] = __builtin_amdgcn_raw_buffer_load_b32(rsum, off, 0, 16);
+        } else if constexpr (Q == 2) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsum, off, 0, 16);
+            pv.x[0] = t.x; pv.x[1] = t.y;
+        } else if constexpr (Q == 3) {
+            const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rsum, off, 0, 16);
+            pv.x[0] = t.x; pv.x[1] = t.y; pv.x[2] = t.z;
+        } else {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsum, off, 0, 16);
+            pv.x[0] = t.x; pv.x[1] = t.y; pv.x[2] = t.z; pv.x[3] = t.w;
+            if constexpr (Q == 5) pv.x[4] = __builtin_amdgcn_raw_buffer_load_b32(rsum, off + 16, 0, 16);
+        }
+        if (ileft > 1) {  // wave-uniform
+            --ileft;
+            ci += dc;
+        }
+    };
+
+    auto step = [&](slot_t& sl, sum_t& pv, auto acc_tag) {
+        constexpr bool ACC = decltype(acc_tag)::value;
+        const uint32_t belowB = dpp8<0x111>(kPadPk, B[Q - 1]);
+        const uint32_t aboveA = dpp8<0x101>(kPadPk, A[0]);
+        const uint32_t mp2 = M + P2pk, negM = 0u - M;
+        uint32_t nA[Q], nB[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            uint32_t ccA, ccB;
+            if (CBITS == 8) {
+                ccA = (sl.x[q] & 0x00ff00ffu) | padA[q];
+                ccB = ((sl.x[q] >> 8) & 0x00ff00ffu) | padB[q];
+            } else {
+                constexpr uint32_t m5 = 0x001f001fu;
+                ccA = ((sl.x[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
+                ccB = ((sl.x[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
+            }
+            const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
+            const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
+            const uint32_t tA = hmin3(A[q], hmin(loA, B[q]) + P1pk, mp2);
+            const uint32_t tB = hmin3(B[q], hmin(A[q], hiB) + P1pk, mp2);
+            nA[q] = add3(tA, ccA, negM);
+            nB[q] = add3(tB, ccB, negM);
+        }
+        if (lane_active) {
+            uint32_t packed[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) packed[q] = (nA[q] | (nB[q] << 8)) + (ACC ? pv.x[q] : 0u);  // bytes d .. d+3 (pads spill upwards only)
+            __builtin_memcpy(pO, packed, 4 * Q);
+        }
+        uint32_t m = hmin(nA[0], nB[0]);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) m = hmin3(m, nA[q], nB[q]);
+        uint32_t m1 = m & 0xffffu, m2 = m >> 16;
+        uint32_t lmin = m1 < m2 ? m1 : m2;
+        fetch_cost(sl);
+        if (ACC) fetch_sum(pv);
+        {
+            uint32_t t;
+            t = dpp8<0x128>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            t = dpp8<0x124>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            t = dpp8<0x122>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            t = dpp8<0x121>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+        }
+        M = lmin | (lmin << 16);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] = nA[q]; B[q] = nB[q]; }
+        pO += (ptrdiff_t)dc * a.Dp;
+    };
+    // first half of the walk: nobody has been here, store.  (The cost ring's slot of step i is i % kRing8 throughout.)
+    int i = 0;
+    for (; i + kRing8 <= nfirst; i += kRing8) {
+#pragma unroll
+        for (int jj = 0; jj < kRing8; ++jj) step(ring[jj], prev[jj], std::false_type{});
+    }
+    const int rem = nfirst - i;  // < kRing8, wave-uniform
+#pragma unroll
+    for (int jj = 0; jj < kRing8 - 1; ++jj)
+        if (jj < rem) step(ring[jj], prev[jj], std::false_type{});
+    // everybody's first half is in memory before anybody's second half reads it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // second half: the partner walking the other way has stored its costs here, add.  Step k of this half uses cost slot
+    // (rem + k) % kRing8 (the cost ring runs on) and sum slot k % kRing8: compile-time indices per value of rem.
+    const int nsecond = W - nfirst;
+#pragma unroll
+    for (int jj = 0; jj < kRing8; ++jj) fetch_sum(prev[jj]);
+    auto second = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
+        int k = 0;
+        for (; k + kRing8 <= nsecond; k += kRing8) {
+#pragma unroll
+            for (int jj = 0; jj < kRing8; ++jj) step(ring[(R + jj) % kRing8], prev[jj], std::true_type{});
+        }
+#pragma unroll
+        for (int jj = 0; jj < kRing8 - 1; ++jj)
+            if (k + jj < nsecond) step(ring[(R + jj) % kRing8], prev[jj], std::true_type{});
+    };
+    static_assert(kRing8 == 4, "dispatch below");
+    switch (rem) {
+        case 0: second(std::integral_constant<int, 0>{}); break;
+        case 1: second(std::integral_constant<int, 1>{}); break;
+        case 2: second(std::integral_constant<int, 2>{}); break;
+        default: second(std::integral_constant<int, 3>{}); break;
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 // Spacing of the eight path volumes: H*W*Dp rounded to 256 bytes.  PMX_DIR_SKEW=<bytes> (multiples of 4) adds a skew between
 // them - an experiment hook: skews of 4 KB ... 1 MB showed no benefit at C3 (tools/skew_probe.sh; the 7 % differences seen
@@ -474,10 +643,11 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     }
     // Direction families (k_sgmfam8.hip) when a family's sum fits a byte: three volumes (horizontal pair, downward family, upward
     // family) instead of eight.  PMX_SGM8_FAM=0 keeps the eight path volumes, =1 takes the families whatever the size (test hooks).
-    // By default for large images only: the marching kernels want >= 3072 columns (one 32-column window per CU and family; at
-    // 2048 x 2048 x 129 the step takes 3.7 ms against 2.9), the horizontal pair >= 1536 rows (one wavefront per four rows; a
-    // 592-row tile of 4096 columns takes 4.8 ms against 4.2, a 4096 x 1024 image 7.8 against 3.7) - profiles/r03_b_shapes.txt.
-    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && W >= 3072 && H >= 1536;
+    // By default for wide images: the marching kernels want one 32-column window per CU and family (2560 columns x 2128 rows:
+    // 6.8 ms against 7.6; 2048 x 2048 x 129: 3.7 against 2.9), and a few hundred rows to amortise the pipeline of windows
+    // (4096 columns: 336 rows 2.7 ms against 2.8, 592 rows 3.7 against 4.1, 1104 rows 5.5 against 6.6, 2128 rows 8.9 against 12.5, 3072 rows
+    // 12.3 against 16.7) - profiles/r03_b_shapes.txt, r03_e_shapes.txt.
+    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && W >= 2560 && H >= 480;
     if (const char* ef = getenv("PMX_SGM8_FAM")) {
         if (ef[0] == '0') fam = false;
         if (ef[0] == '1') fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u;
@@ -547,9 +717,15 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         }
         {   // volume 0: the horizontal pair
             pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED, hs);
-            const dim3 hgrid(((H + kLines8 - 1) / kLines8 + kWaves8 - 1) / kWaves8), hblock(kWaves8 * 64);
+            // one wavefront per four rows, or the two-sided walk for short images (PMX_SGM8_HPAIR=1 / 2 forces one: A/B hook)
+            const char* ehp = getenv("PMX_SGM8_HPAIR");
+            const bool two_sided = ehp ? ehp[0] == '2' : H < 2560;  // (2128 rows: 8.9 against 9.7 ms; 3072 rows: 13.0 against 12.3)
+            const int ngroups = (H + kLines8 - 1) / kLines8;
+            const dim3 hgrid(two_sided ? (ngroups + 1) / 2 : (ngroups + kWaves8 - 1) / kWaves8), hblock(kWaves8 * 64);
 #define PMX_HP(KPLV)                                                                                                       \
-    if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 5>), hgrid, hblock, 0, hs, a);                  \
+    if (two_sided && five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair2_kernel<KPLV, 5>), hgrid, hblock, 0, hs, a);    \
+    else if (two_sided) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair2_kernel<KPLV, 8>), hgrid, hblock, 0, hs, a);       \
+    else if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 5>), hgrid, hblock, 0, hs, a);             \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 8>), hgrid, hblock, 0, hs, a)
             switch (kpl) {
                 case 4: PMX_HP(4); break;

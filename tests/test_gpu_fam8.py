@@ -1,6 +1,6 @@
 """GPU parity of the integer path's direction-family form (k_sgmfam8.hip + sgm_u8_hpair_kernel): three byte volumes (horizontal
 pair, downward family, upward family) instead of eight path volumes.  Forced onto small pairs with PMX_SGM8_FAM=1 (by default it
-takes images from 3072 columns and 1536 rows on) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
+takes images from 2560 columns and 480 rows on) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
 refinement.  Shapes exercise every lane map (KPL 4 ... 20), both window widths (16 / 32 columns), images narrower than a window,
 images a window does not divide, and windows that enter and leave the image during the march."""
 import os
@@ -63,9 +63,10 @@ def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
     (70, 16, -5, 5, 5, 1, 2),         # exactly one window wide, tall
     (45, 67, -20, 20, 7, 8, 30),      # census 7x7: byte costs (invalid cost 50: 3 * 80 = 240 fits a byte)
 ])
-@pytest.mark.parametrize("nw", ["4", "8"])
-def test_family_form_equals_the_oracle(eng, oracle, forced_families, H, W, dmin, dmax, win, P1, P2, nw):
+@pytest.mark.parametrize("nw,hpair", [("4", "2"), ("8", "1"), ("8", "2")])
+def test_family_form_equals_the_oracle(eng, oracle, forced_families, H, W, dmin, dmax, win, P1, P2, nw, hpair):
     forced_families.setenv("PMX_SGM8_FAM_NW", nw)
+    forced_families.setenv("PMX_SGM8_HPAIR", hpair)  # the horizontal pair's one-sided (tall images) / two-sided (short images) walk
     L, R = pair(H, W, seed=3 * H + W)
     run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2)
 
@@ -107,11 +108,16 @@ def test_family_form_with_disparity_grids(eng, oracle, forced_families):
 
 
 def test_family_form_mid_size_against_the_eight_volumes(eng):
-    """A pair large enough for a hundred windows in flight and for the default route (>= 3072 columns, >= 1536 rows): the family
-    form and the eight-volume form give the same maps bit for bit."""
+    """Pairs large enough for a hundred windows in flight and for the default route (>= 2560 columns, >= 480 rows) - a short one
+    (the two-sided horizontal walk) and a tall one (the one-sided walk): the family form and the eight-volume form give the same
+    maps bit for bit."""
     from bench import synthetic_pair
 
-    H, W, dmin, dmax = 1540, 3100, 0, 64
+    for H, W, dmin, dmax in ((500, 2600, 0, 64), (2600, 2600, -30, 10)):
+        _family_against_eight_volumes(eng, synthetic_pair, H, W, dmin, dmax)
+
+
+def _family_against_eight_volumes(eng, synthetic_pair, H, W, dmin, dmax):
     L, R = synthetic_pair(H, W, dmin, dmax, seed=5)
     maps = {}
     for mode in ("0", "auto"):

@@ -39,6 +39,7 @@ def main():
             if P2 <= P1:
                 continue
         os.environ["PMX_SGM8_FAM_NW"] = str(rng.choice([4, 8]))
+        os.environ["PMX_SGM8_HPAIR"] = str(rng.choice([1, 2]))  # the horizontal pair's one-sided / two-sided walk
         base = rng.integers(0, 256, (H, W + 8)).astype(np.float32)
         base = np.floor((base + np.roll(base, 1, 1) + np.roll(base, 1, 0)) / 3.0)
         L = base[:, 4:4 + W].copy()
