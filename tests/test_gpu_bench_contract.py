@@ -34,18 +34,19 @@ def test_bench_prints_one_contract_line():
     assert d["cpu_baseline_reference_compiled"]["kind"] == "reference-compiled"  # the reference's own census C++, same strip
 
 
-@pytest.mark.parametrize("world,port", [(2, 29547), (8, 29561)])
-def test_bench_runs_one_pair_over_the_ranks(world, port):
+@pytest.mark.parametrize("world,port,height,width", [(2, 29547, 300, 256), (8, 29561, 300, 256), (2, 29583, 1000, 2600)])
+def test_bench_runs_one_pair_over_the_ranks(world, port, height, width):
     """--gpus N = ONE pair over N ranks (row tiles + 40-row margin, gather of the owned rows on rank 0), launched with the launcher's
     environment variables; the ranks share the box's one GPU, so the exchange goes through the TcpComm stand-in of tests/transports.py
     (bench.py's explicit --test-comm hook; the product Comm is RCCL only).  Eight ranks over
-    300 rows: tiles of 37 / 38 owned rows whose margins reach over several neighbours."""
+    300 rows: tiles of 37 / 38 owned rows whose margins reach over several neighbours.  1000 x 2600 over two ranks: tiles of 540 rows,
+    wide enough for the integer path's direction-family form (marching kernel + two-sided horizontal walk) inside every tile."""
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-                                       "--height", "300", "--width", "256", "--dmax", "40", "--placement-trials", "1",
+                                       "--height", str(height), "--width", str(width), "--dmax", "40", "--placement-trials", "1",
                                        "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -56,11 +57,15 @@ def test_bench_runs_one_pair_over_the_ranks(world, port):
     assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"]
     # the exact multi-GPU form rides along: costs sharded over D, one all-reduce(min) of packed keys - identical to one GPU
     assert d["d_sharded_exact"]["maps_identical_to_one_gpu"] == 1.0, d["d_sharded_exact"]
-    assert d["collective"]["bytes_per_step"] == 300 * 256 * 10
+    assert d["collective"]["bytes_per_step"] == height * width * 10
+    if width >= 2560:
+        assert d["stage_ms_per_step"]["sgm_span"] > 0  # the family form ran in the tiles
     # what arrived on rank 0 is the pair's result: identical to one GPU doing the whole pair except near the tile seams (SGM paths
     # are cut at the 40-row margin, as in the reference's ROI tiling; with 8 ranks over 300 rows there is a seam every 37 rows)
     g = d["gathered_maps_vs_one_gpu"]
     assert g["disparity_identical"] > (0.97 if world == 2 else 0.85) and g["validity_identical"] > 0.97, g
+    if height >= 1000:
+        assert g["disparity_identical"] > 0.99, g
 
 
 def test_bench_refuses_to_mislabel_a_run():
