@@ -328,19 +328,29 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
     }
     const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
 
-    auto rimg_of = [&](int r) { return fam ? H - 1 - r : r; };
-    auto col_of = [&](int r) { return base - r + j; };
+    // Row pointers and lane offsets advance with the march (one row, one column to the left per step) instead of being rebuilt:
+    // the scalar unit's multiplications for a 64-bit row address were a fifth of this kernel's instructions.
+    const ptrdiff_t cost_step = fam ? -(ptrdiff_t)cost_row_bytes : (ptrdiff_t)cost_row_bytes;
+    const ptrdiff_t out_step = fam ? -(ptrdiff_t)out_row_bytes : (ptrdiff_t)out_row_bytes;
+    const int rimg_lo = fam ? H - 1 - r_lo : r_lo;
+    const uint8_t* cost_row = a.cost + (size_t)rimg_lo * cost_row_bytes;   // row `pr` of the prefetch
+    uint8_t* out_row = outv + (size_t)rimg_lo * out_row_bytes;             // row `r` of the step
+    int pc = base - r_lo + j;                                              // column of the prefetched row
+    unsigned pcoff = (unsigned)pc * (unsigned)a.Dc + cost_lane;            // (wraps for negative columns: masked below)
 
     // loads of the costs run PF rows ahead in a register ring
     int pr = r_lo;
     struct slot_t { uint32_t x[NDW]; };
     slot_t ring[PF];
     auto prefetch = [&](slot_t& sl) {
-        const int c = col_of(pr);
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(a.cost + (size_t)rimg_of(pr) * cost_row_bytes), 0, cost_row_bytes, kRsrcWord3);
-        load_dwords<NDW>(rs, (c >= 0 && c < W && lane_active) ? (unsigned)c * (unsigned)a.Dc + cost_lane : kOob, sl.x);
-        if (pr < r_hi) ++pr;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cost_row, 0, cost_row_bytes, kRsrcWord3);
+        load_dwords<NDW>(rs, ((unsigned)pc < (unsigned)W && lane_active) ? pcoff : kOob, sl.x);
+        if (pr < r_hi) {  // (uniform; past the last row the last one is read again)
+            ++pr;
+            cost_row += cost_step;
+            --pc;
+            pcoff -= (unsigned)a.Dc;
+        }
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) prefetch(ring[i]);
@@ -353,8 +363,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(ctl[1 + ((r_lo - 1) & 1)])) return;
 
+    int c = base - r_lo + j;                                       // column of the step's row
+    unsigned ooff = (unsigned)c * (unsigned)a.Dp + out_lane;
     auto step = [&](int r, slot_t& sl) {
-        const int c = col_of(r);
         const uint32_t* Ep = lds8 + ((r - 1) & 1) * EBUF;
         uint32_t* En = lds8 + (r & 1) * EBUF;
         // predecessors: vertical path (r-1, c) = local column j-1, diagonal (r-1, c-1) = local column j-2 (LDS, previous row
@@ -447,10 +458,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
             LBb[q] = nBb[q];
         }
         {
-            const __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(outv + (size_t)rimg_of(r) * out_row_bytes), 0, out_row_bytes, kRsrcWord3);
-            store_dwords<Q>(rs, (c >= 0 && c < W && lane_active) ? (unsigned)c * (unsigned)a.Dp + out_lane : kOob, packed);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out_row, 0, out_row_bytes, kRsrcWord3);
+            store_dwords<Q>(rs, ((unsigned)c < (unsigned)W && lane_active) ? ooff : kOob, packed);
         }
+        out_row += out_step;
+        --c;
+        ooff -= (unsigned)a.Dp;
         prefetch(sl);
         __syncthreads();
     };
