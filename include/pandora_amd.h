@@ -286,6 +286,11 @@ int pmx_stage_time(pmx_ctx* ctx, int stage, double* total_ms, int* launches);
  * (k < (kpl & ~3)) ? s*(kpl & ~3) + k : nact*(kpl & ~3) + s   with s = d / kpl, k = d % kpl, nact = ceil(D / kpl).
  * Returns PMX_ERR_STATE when the handle is not in that representation. */
 int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp, int* gl, int* kpl);
+/* Debug / test hook of the census + CBCA marching kernel (k_cbca.hip: cbca_census_march_kernel), whose cells end in the division of
+ * two small integers: runs the kernel's division (hardware reciprocal + one Newton step) against the IEEE division for EVERY
+ * numerator 0 .. 65535 and denominator 1 .. 1024 on the device; *mismatches receives how many quotients differ in any bit (0 is
+ * the contract; aggregation.cpp:108-121 divides in float32). */
+int pmx_debug_small_division(pmx_ctx* ctx, unsigned* mismatches);
 /* ---- validation --------------------------------------------------------------------------
  * Replaces validation.CrossCheckingAccurate.disparity_checking (src/pandora/validation/validation.py:226-371; the
  * class is registered for both "cross_checking_accurate" and "cross_checking_fast").  Host maps in/out, computed

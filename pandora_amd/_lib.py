@@ -94,6 +94,7 @@ SIGNATURES = {
     "pmx_interval_bounds": (C.c_int, [vp, vp, C.c_float, C.c_float, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_float),
                                       C.POINTER(C.c_float)]),
     "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
+    "pmx_debug_small_division": (C.c_int, [vp, C.POINTER(C.c_uint)]),
     "pmx_set_placement_trials": (C.c_int, [vp, C.c_int]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmx_reset_stage_times": (C.c_int, [vp]),

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(BS) void cbca_v_kernel(cbca_args a) {
 // cut into warm-up (prefix only), steady state (prefix + emit, no tests, incrementing pointers, four steps of loads in
 // flight) and drain (emit only); arms are combined with two packed 16-bit minima.  Same arithmetic, same order.
 typedef short cb_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short cb_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t cb_pk_min(uint32_t x, uint32_t y) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(cb_s2, x), __builtin_bit_cast(cb_s2, y)));
 }
@@ -948,6 +949,296 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
     }
 }
 
+// ---- census costs + both scans in ONE marching kernel: exact integer sums ----------------------------------------------------
+// With census costs every quantity of the aggregation is a small integer: a cost is at most 32 (one code word), a horizontal
+// segment sum at most 9 x 32, the column prefix of those stays below 2^24 for any image of fewer than 58 000 rows - every float32
+// operation of aggregation.cpp:28-121 is exact whatever its order, and the only rounding of a cell is its final division.  So the
+// horizontal sums need not come from a row-long prefix, and the scratch volume E_h (written by pass H, read by pass V: 8 of the
+// 12 bytes per cell the two passes move) need not exist.  A workgroup owns NC columns (NC * D threads, thread = (column,
+// disparity), cells contiguous in the volume's rows as in pass V) and marches down the rows in quads:
+//   a) the codes and byte arms of the quad's rows arrive in LDS (one or two dwords per thread and quad, loaded two quads ahead):
+//      NC + 8 left codes, NC + 8 + D - 1 right codes, NC + NC + D - 1 arms per row;
+//   b) every thread computes the cost of its own cell and of its share of the 8 halo columns (4 on either side: the longest arm)
+//      and leaves it as a BYTE in a row of 16 per disparity; one barrier;
+//   c) a cell's horizontal segment sum is four v_dot4_u32_u8 of its disparity's 16 bytes with a 0/1 byte mask looked up by
+//      (first, last) column; the column prefix S3 and the count N are 16-bit fields of ONE ring word (differences of prefixes are
+//      below 2^16, so the fields may wrap: v_pk_sub_u16 takes both differences at once).  The vertical step: with arms of at
+//      most 4 rows the row that leaves at step j of a quad is the row prefixed at step j of the quad before - its (top, bottom)
+//      wait in four registers, the ring holds 12 rows, and the final division of two small integers is the hardware reciprocal
+//      plus one Newton step (small_int_div: every pair checked against the IEEE division).
+// HBM traffic of the aggregation: the 4-byte store per cell and the two small images.  Legal for a census source with one code
+// word per pixel, subpix 1, arms of at most 4 (cbca_distance <= 5), D <= 1024 (pmx_launch_cbca decides).
+struct cbca_march {
+    int NC, T;                  // useful columns and threads of a workgroup
+    int nsh;                    // halo cells per thread (1 or 2)
+    unsigned cost_off, code_off, arms_off, tab_off;  // LDS byte offsets (the ring starts at 0)
+    unsigned cost_buf, code_buf, arms_buf;           // bytes of one of the two buffers of each
+    int wprc, wpra;             // staged words per row: codes (NC + 8 left, NC + 8 + D - 1 right), arms (NC left, NC + D - 1 right)
+    unsigned arms_bytes;        // one descriptor over armsL8 .. the end of armsR8
+    unsigned armsR_word;        // where armsR8 starts in it (words)
+};
+static constexpr int kMarchSlots = 2;   // staged words per thread and quad, of each kind
+static constexpr int kMarchRing = 12;
+static constexpr int kMarchTab = 144 * 16;  // byte masks by (first column 0 .. 11, last column 4 .. 15)
+
+#define PMX_AS3 __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t lds_r32(uint32_t addr) { return *(const uint32_t PMX_AS3*)(uintptr_t)addr; }
+__device__ __forceinline__ u32x4 lds_r128(uint32_t addr) { return *(const u32x4 PMX_AS3*)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_w32(uint32_t addr, uint32_t v) { *(uint32_t PMX_AS3*)(uintptr_t)addr = v; }
+__device__ __forceinline__ void lds_w8(uint32_t addr, uint32_t v) { *(uint8_t PMX_AS3*)(uintptr_t)addr = (uint8_t)v; }
+__device__ __forceinline__ void lds_w128(uint32_t addr, u32x4 v) { *(u32x4 PMX_AS3*)(uintptr_t)addr = v; }
+
+// a / b for integers 0 <= a < 65536, 1 <= b <= 1024 as float32, correctly rounded: one Newton step on the hardware reciprocal's
+// quotient.  pmx_debug_small_division compares every pair with the IEEE division (tests/test_gpu_parity.py).
+__device__ __forceinline__ float small_int_div(float af, float bf) {
+    const float y = __builtin_amdgcn_rcpf(bf);
+    const float q0 = af * y;
+    const float r = __builtin_fmaf(-bf, q0, af);
+    return __builtin_fmaf(r, y, q0);
+}
+
+__global__ __launch_bounds__(256) void small_division_check_kernel(unsigned* __restrict__ bad) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;  // a = i & 0xffff, b = (i >> 16) + 1
+    const float af = (float)(i & 0xffffu), bf = (float)((i >> 16) + 1u);
+    float ieee = af / bf;
+    asm volatile("" : "+v"(ieee));
+    if (__float_as_uint(small_int_div(af, bf)) != __float_as_uint(ieee)) atomicAdd(bad, 1u);
+}
+
+int pmx_launch_small_division_check(pmx_ctx* ctx, unsigned* host_count) {
+    unsigned* dev = nullptr;
+    PMX_HIP(hipMalloc((void**)&dev, sizeof(unsigned)));
+    PMX_HIP(hipMemsetAsync(dev, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(small_division_check_kernel, dim3((1024u << 16) / 256u), dim3(256), 0, ctx->stream, dev);
+    hipError_t e = hipMemcpyAsync(host_count, dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    PMX_HIP(e);
+    return PMX_OK;
+}
+
+// LDS of a workgroup (bytes): ring [12][NC * D] words | cost bytes [2][4 rows][D][16] | masks [144][16] | codes [2][wprc][4 rows]
+// words | arms [2][2][wpra][4 rows] words: (left, right) and (top, bottom) as 16-bit pairs, expanded once by the staging thread.
+// Codes and arms have the four rows of a quad as their FASTEST index: a thread's four rows of one pixel are one 16-byte read, and
+// consecutive disparities read consecutive 16 bytes (no bank conflict; rows of 16 bytes 64 apart would collide eight ways).
+template <int SRC>  // 3: census geometry with the crop equal to the census border; 1: census geometry, any crop
+__global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a, cbca_march m) {
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // (LDS addresses below are absolute: the dynamic block starts at 0)
+    const int D = a.D, NC = m.NC, T = m.T, Wc = a.Wc, Hc = a.Hc, W = a.W, o = a.o;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * NC;
+    // No lane-varying branch anywhere in the march.  A lane without a cell of its own (the last wavefront's tail) doubles the
+    // workgroup's last cell - same reads, same values written to the same LDS bytes, its stores out of range; a lane without a
+    // halo cell doubles the last halo cell.
+    const int ci = min(tid, NC * D - 1);  // this thread's cell
+    const int cloc = ci / D, k = ci - cloc * D;
+    const int c = c0 + cloc, q = c + a.d0 + k;
+    const bool live = (tid < NC * D) & (c < Wc);
+    const bool inside = (q >= 0) & (q < Wc);
+    const uint32_t RS4 = (uint32_t)(NC * D) * 4u, own = (uint32_t)ci * 4u;  // ring: bytes per slot, this cell's word in a slot
+    // column tests of a cost (its row test is uniform): geometry of the census windows
+    const unsigned wvalid = (unsigned)(W - 2 * a.cb);
+    auto col_ok = [&](int cc, int kk) -> bool {  // cropped column cc, disparity index kk
+        if (SRC == 3) return (unsigned)(cc + a.d0 + kk) < (unsigned)Wc;
+        return (bool)(((unsigned)(cc + o - a.cb) < wvalid) & ((unsigned)(cc + o + a.d0 + kk - a.cb) < wvalid));
+    };
+    auto row_mask = [&](int r) -> uint32_t { return (SRC == 3 || ((r + o >= a.cb) & (r + o < a.H - a.cb))) ? 0xffffffffu : 0u; };
+    const bool own_ok = col_ok(c, k);
+    // ---- one-time LDS set-up: the byte masks, the empty ring
+    for (int e = tid; e < 144; e += T) {
+        const int lo = e / 12, hi = e - lo * 12 + 4;
+        u32x4 w;
+        for (int i = 0; i < 4; ++i) {
+            uint32_t x = 0;
+            for (int b = 0; b < 4; ++b) x |= (4 * i + b >= lo && 4 * i + b <= hi) ? (1u << (8 * b)) : 0u;
+            w[i] = x;
+        }
+        lds_w128(m.tab_off + (uint32_t)e * 16u, w);
+    }
+#pragma unroll
+    for (int s = 0; s < kMarchRing; ++s) lds_w32((uint32_t)s * RS4 + own, 0u);  // row -1: zero sum, zero count
+    // ---- staging: which words of a quad's rows this thread brings in (the same for every quad).  Word idx of a kind is
+    // (row j, position w) = (idx / words per row, idx mod words per row)
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)a.codes, 0, a.codes_bytes, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsL8, 0, m.arms_bytes, kRsrcWord3);
+    const int CWL = NC + 8;
+    const uint32_t tb_off = (uint32_t)m.wpra * 16u;  // the (top, bottom) half of an arms buffer
+    unsigned gc[kMarchSlots], lc[kMarchSlots], ga[kMarchSlots], la[kMarchSlots], adv_a[kMarchSlots];
+#pragma unroll
+    for (int s = 0; s < kMarchSlots; ++s) {
+        {
+            const int idx = min(tid + s * T, 4 * m.wprc - 1);  // (a thread beyond the last word doubles it)
+            const int j = idx / m.wprc, w = idx - j * m.wprc;
+            const unsigned row0 = (unsigned)(j + o) * (unsigned)W + (unsigned)(o + c0 - 4);
+            const unsigned word = w < CWL ? a.offCL + row0 + (unsigned)w : a.offCR + row0 + (unsigned)(a.d0 + (w - CWL));
+            gc[s] = word * 4u;
+            lc[s] = m.code_off + (uint32_t)(w * 4 + j) * 4u;
+        }
+        {
+            const int idx = min(tid + s * T, 4 * m.wpra - 1);
+            const int j = idx / m.wpra, w = idx - j * m.wpra;
+            const bool left = w < NC;
+            const unsigned word = left ? (unsigned)j * (unsigned)a.pitchL + (unsigned)(c0 + w)
+                                       : m.armsR_word + (unsigned)j * (unsigned)a.pitchR + (unsigned)(a.padR + c0 + a.d0 + (w - NC));
+            ga[s] = word * 4u;
+            la[s] = m.arms_off + (uint32_t)(w * 4 + j) * 4u;
+            adv_a[s] = (left ? (unsigned)a.pitchL : (unsigned)a.pitchR) * 16u;
+        }
+    }
+    const unsigned adv_c = (unsigned)W * 16u;  // four rows of code words
+    uint32_t sc[kMarchSlots], sa[kMarchSlots];
+    auto issue = [&]() {  // the next quad's words into registers, offsets advanced
+#pragma unroll
+        for (int s = 0; s < kMarchSlots; ++s) {
+            sc[s] = __builtin_amdgcn_raw_buffer_load_b32(rsC, gc[s], 0, 0);
+            gc[s] += adv_c;
+            sa[s] = __builtin_amdgcn_raw_buffer_load_b32(rsA, ga[s], 0, 0);
+            ga[s] += adv_a[s];
+        }
+    };
+    auto land = [&](uint32_t cbuf, uint32_t abuf) {  // the registers into the buffers at these byte offsets
+#pragma unroll
+        for (int s = 0; s < kMarchSlots; ++s) {
+            lds_w32(lc[s] + cbuf, sc[s]);
+            const uint32_t at = la[s] + abuf;
+            lds_w32(at, cb_lr16(sa[s]));
+            lds_w32(at + tb_off, cb_tb16(sa[s]));
+        }
+    };
+    // ---- per-thread addresses (the buffer of a quad and its rows are added as a scalar / as immediate offsets)
+    const uint32_t xc = 4u + (uint32_t)cloc;
+    const uint32_t code_l = m.code_off + xc * 16u;
+    const uint32_t code_r = own_ok ? m.code_off + ((uint32_t)CWL + xc + (uint32_t)k) * 16u : code_l;  // (no cost: a code against itself)
+    const uint32_t arms_l = m.arms_off + (uint32_t)cloc * 16u, arms_r = m.arms_off + (uint32_t)(NC + cloc + k) * 16u;  // (+ tb_off)
+    const uint32_t cost_row = m.cost_off + (uint32_t)k * 16u;  // the 16 bytes of this disparity (+ row * rowb)
+    const uint32_t rowb = (uint32_t)D * 16u;
+    const uint32_t own_dst = cost_row + xc;
+    const uint32_t tab_own = m.tab_off + (xc * 13u - 4u) * 16u;  // + (right - 12 * left) * 16
+    // halo cells: 8 columns x D disparities shared out over the workgroup (a second one only where a wavefront has any)
+    uint32_t h_l[2], h_r[2], h_dst[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int h = min(tid + s * T, 8 * D - 1);
+        const int hx = h / D, hk = h - hx * D;
+        const int x = hx < 4 ? hx : NC + hx;  // columns 0 .. 3 and NC + 4 .. NC + 7 of the row of 16
+        h_l[s] = m.code_off + (uint32_t)x * 16u;
+        h_r[s] = col_ok(c0 - 4 + x, hk) ? m.code_off + (uint32_t)(CWL + x + hk) * 16u : h_l[s];
+        h_dst[s] = m.cost_off + (uint32_t)hk * 16u + (uint32_t)x;
+    }
+    const bool wave_h1 = m.nsh > 1 && __builtin_amdgcn_ballot_w64(tid + T < 8 * D) != 0;  // (uniform: a scalar branch)
+    // ---- the march
+    const unsigned row_bytes = (unsigned)W * (unsigned)D * 4u;
+    const unsigned voff_st = live ? ((unsigned)(c + o) * (unsigned)D + (unsigned)k) * 4u : kOob;
+    const size_t row_stride = (size_t)W * D;
+    float* out_row = a.cv + (ptrdiff_t)(o - 4) * (ptrdiff_t)row_stride;  // output row of the quad's first leaving row (4n - 4)
+    uint32_t acc = 0, nacc = 0;
+    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;  // (top | bottom << 16) of the four rows that leave next
+    issue();
+    land(0u, 0u);
+    issue();
+    __syncthreads();
+    const int NQ = (Hc + 4 + 3) / 4;  // rows 0 .. Hc + 3: the last four only leave
+    int s0 = 0;                       // ring slot of the quad's first row: 4 * (n mod 3)
+    for (int n = 0; n < NQ; ++n) {
+        const int par = n & 1, r = 4 * n;
+        const uint32_t cb_ = (uint32_t)par * m.code_buf, ab_ = (uint32_t)par * m.arms_buf, kb_ = (uint32_t)par * m.cost_buf;
+        // a) the next quad's words land, the one after is requested; this quad's costs (bytes) and arms
+        land(m.code_buf - cb_, m.arms_buf - ab_);
+        issue();
+        {
+            const u32x4 cl = lds_r128(code_l + cb_), cr = lds_r128(code_r + cb_);
+            const u32x4 hl = lds_r128(h_l[0] + cb_), hr = lds_r128(h_r[0] + cb_);
+            uint32_t od = own_dst + kb_, hd = h_dst[0] + kb_;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t rm = row_mask(r + j);
+                lds_w8(od, (uint32_t)__popc(cl[j] ^ cr[j]) & rm);
+                lds_w8(hd, (uint32_t)__popc(hl[j] ^ hr[j]) & rm);
+                od += rowb;
+                hd += rowb;
+            }
+        }
+        if (wave_h1) {
+            const u32x4 hl = lds_r128(h_l[1] + cb_), hr = lds_r128(h_r[1] + cb_);
+            uint32_t hd = h_dst[1] + kb_;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lds_w8(hd, (uint32_t)__popc(hl[j] ^ hr[j]) & row_mask(r + j));
+                hd += rowb;
+            }
+        }
+        uint32_t lr[4], tb[4];
+        {
+            // the four rows' (left, right) and (top, bottom) pairs of the two pixels
+            const u32x4 ll = lds_r128(arms_l + ab_), lt = lds_r128(arms_l + ab_ + tb_off);
+            const u32x4 rl = lds_r128(arms_r + ab_), rt = lds_r128(arms_r + ab_ + tb_off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lr[j] = r + j < Hc ? cb_pk_min(ll[j], rl[j]) : 0u;  // a row past the image has no arms (what was staged for it is not arms)
+                tb[j] = cb_pk_min(lt[j], rt[j]);
+            }
+        }
+        __syncthreads();
+        // c) segment sums, prefixes, and the four rows that leave.  A row past the image (the last quads) runs like any other
+        // on zero codes and no arms: what it leaves in the ring is never read (a ring of 12: row r + 3 takes the slot of row
+        // r - 9, which the first leaving row may still need - hence its reads come first).
+        uint32_t ent[4];
+        const uint32_t crow = cost_row + kb_;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 w[2], mk[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = 2 * h + i;
+                w[i] = lds_r128(crow + (uint32_t)j * rowb);
+                const int32_t sel = (int32_t)(lr[j] >> 16) - 12 * (int32_t)(lr[j] & 0xffffu);
+                mk[i] = lds_r128(tab_own + (uint32_t)(sel * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = 2 * h + i;
+                uint32_t e = __builtin_amdgcn_udot4(w[i].x, mk[i].x, 0u, false);
+                e = __builtin_amdgcn_udot4(w[i].y, mk[i].y, e, false);
+                e = __builtin_amdgcn_udot4(w[i].z, mk[i].z, e, false);
+                e = __builtin_amdgcn_udot4(w[i].w, mk[i].w, e, false);
+                acc += e;
+                nacc = __builtin_amdgcn_sad_u16(lr[j], 0u, nacc) + 1u;
+                ent[j] = __builtin_amdgcn_perm(nacc, acc, 0x05040100u);  // (S3 & 0xffff) | N << 16
+            }
+        }
+        struct pair_hl { uint32_t hi, lo; };
+        const int e0 = s0 >= 4 ? s0 - 4 : 8;  // slot of row r - 4
+        auto fetch = [&](uint32_t tbv, int j) {
+            uint32_t u = (uint32_t)(e0 + j) + (tbv >> 16), v = (uint32_t)(e0 + j + kMarchRing - 1) - (tbv & 0xffffu);
+            u = min(u, u - (uint32_t)kMarchRing);
+            v = min(v, v - (uint32_t)kMarchRing);
+            return pair_hl{lds_r32(__umul24(u, RS4) + own), lds_r32(__umul24(v, RS4) + own)};
+        };
+        const uint32_t ring_w = (uint32_t)s0 * RS4 + own;
+        lds_w32(ring_w, ent[0]);
+        lds_w32(ring_w + RS4, ent[1]);
+        lds_w32(ring_w + 2u * RS4, ent[2]);
+        const pair_hl p0 = fetch(t0, 0);
+        lds_w32(ring_w + 3u * RS4, ent[3]);
+        const pair_hl p1 = fetch(t1, 1), p2 = fetch(t2, 2), p3 = fetch(t3, 3);
+        auto emit = [&](const pair_hl& p, int j) {
+            const uint32_t d = __builtin_bit_cast(uint32_t, __builtin_bit_cast(cb_us2, p.hi) - __builtin_bit_cast(cb_us2, p.lo));
+            const float quot = small_int_div((float)(d & 0xffffu), (float)(d >> 16));
+            float res;
+            if (SRC == 3) res = inside ? quot : c_nan();
+            else res = (own_ok && row_mask(r - 4 + j)) ? (inside ? quot : 0.f) : c_nan();
+            const bool row_in = (r - 4 + j >= 0) & (r - 4 + j < Hc);  // (uniform: a row that does not exist gets an empty descriptor)
+            const __amdgpu_buffer_rsrc_t rsO =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(out_row + (size_t)j * row_stride), 0, row_in ? row_bytes : 0u, kRsrcWord3);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res), rsO, voff_st, 0, 0);
+        };
+        emit(p0, 0); emit(p1, 1); emit(p2, 2); emit(p3, 3);
+        t0 = tb[0]; t1 = tb[1]; t2 = tb[2]; t3 = tb[3];
+        s0 = s0 == 8 ? 0 : s0 + 4;
+        out_row += (size_t)4 * row_stride;
+    }
+}
+
 // ---- four disparities per thread (subpix 1, cbca_distance <= 5) -----------------------------------------------------------
 // The scans above move 4 bytes per lane per memory instruction and are bound by the texture addresser (~30 cycles per vector
 // memory instruction per CU whatever its width: 4 - 5 of them per 64 cells).  Here a thread owns FOUR consecutive disparities of
@@ -1260,7 +1551,8 @@ bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, 
     const int A = distance - 1 > 1 ? distance - 1 : 1;
     const int Hc = cv->H - 2 * offset, Wc = cv->W - 2 * offset;
     const int pitchR = (cv->d0 < 0 ? -cv->d0 : 0) + 4 + Wc + (cv->d0 + cv->D - 1 > 0 ? cv->d0 + cv->D - 1 : 0) + 8;
-    return cv->repr == PMX_REPR_CENSUS_DEFERRED && cv->subpix == 1 && cv->win * cv->win <= 32 && cbca_ring_slots(A) <= 64 &&
+    // (a crop wider than the census border leaves cells with real costs outside the aggregated area: they need the volume)
+    return cv->repr == PMX_REPR_CENSUS_DEFERRED && cv->subpix == 1 && cv->win * cv->win <= 32 && offset <= cv->win / 2 && cbca_ring_slots(A) <= 64 &&
            cbca_rows_per_block(cv->D, cbca_ring_slots(A)) > 0 && Wc >= 2 * A + 8 && Hc >= 2 * A + 8 && cv->codes_bytes < 0x7fffffffu &&
            (size_t)Hc * pitchR * 4 < 0x7fffffffu && (size_t)Hc * (Wc + 4) * 4 < 0x7fffffffu && (size_t)8 * cv->W * cv->D * 4 < 0x7fffffffu;
 }
@@ -1305,6 +1597,48 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         pmx_set_error("pmx_cbca: internal: census source without the whole-row kernel");
         return PMX_ERR_STATE;
     }
+    // census source, short arms: costs and both scans in one marching kernel, no E_h volume (PMX_CBCA_MARCH=0/1: test hook)
+    cbca_march m{};
+    size_t march_lds = 0;
+    bool march = false;
+    {
+        const char* em = getenv("PMX_CBCA_MARCH");
+        const bool shape_ok = census_src && rows_ok && !(cv->has_range) && a.A <= 4 && cv->subpix == 1 && cv->D <= 256 &&
+                              (size_t)Hc * 9 * 32 < ((size_t)1 << 24) && bL8 + bR8 < 0xfffffff0u;
+        // columns per workgroup: as many (up to 8: a disparity's costs of a row are 16 bytes with the 8 halo columns) as leave
+        // room for two workgroups per CU, else as fit one
+        auto layout = [&](int NC) {
+            m.NC = NC;
+            m.T = ((NC * cv->D + 63) / 64) * 64;
+            m.wprc = 2 * (NC + 8) + cv->D - 1;
+            m.wpra = 2 * NC + cv->D - 1;
+            m.nsh = (8 * cv->D + m.T - 1) / m.T;
+            m.cost_buf = (unsigned)cv->D * 64u;
+            m.code_buf = (unsigned)m.wprc * 16u;
+            m.arms_buf = (unsigned)m.wpra * 32u;
+            m.cost_off = (unsigned)kMarchRing * (unsigned)(NC * cv->D) * 4u;
+            m.cost_off = (m.cost_off + 15u) & ~15u;
+            m.tab_off = m.cost_off + 2u * m.cost_buf;
+            m.code_off = m.tab_off + (unsigned)kMarchTab;
+            m.arms_off = m.code_off + 2u * m.code_buf;
+            march_lds = (size_t)m.arms_off + 2u * m.arms_buf;
+            return m.T <= 1024 && m.nsh <= 2 && 4 * m.wprc <= kMarchSlots * m.T && 4 * m.wpra <= kMarchSlots * m.T;
+        };
+        int pick = 0;
+        if (shape_ok) {
+            for (int NC = 8; NC >= 4 && !pick; --NC)
+                if (layout(NC) && march_lds <= (size_t)80 * 1024) pick = NC;
+            for (int NC = 8; NC >= 4 && !pick; --NC)
+                if (layout(NC) && march_lds <= (size_t)160 * 1024) pick = NC;
+        }
+        if (pick) {
+            layout(pick);
+            const bool big = (Wc + m.NC - 1) / m.NC >= 192 && Hc >= 512;
+            m.arms_bytes = (unsigned)(bL8 + bR8);
+            m.armsR_word = (unsigned)(bL8 / 4);
+            march = em ? em[0] != '0' : big;
+        }
+    }
     const size_t wide_bytes = rows_ok ? bL8 + (size_t)cv->subpix * bR8 : 0;
     // small scratch: 2 float images + arms of left and of every shifted right image (+ padded right arms and NaN bits)
     const size_t img_bytes = (size_t)H * W * sizeof(float);
@@ -1313,7 +1647,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     const size_t nan_bytes = four ? (size_t)Hc * ((Wc + 7) / 8) * G * sizeof(uint32_t) : 0;
     int rc = pmx_need_small(ctx, 2 * img_bytes + arm_bytes * (1 + cv->subpix) + pad_bytes + nan_bytes + wide_bytes + 64);
     if (rc) return rc;
-    if (!four) {
+    if (!four && !march) {
         rc = pmx_need_scratch(ctx, cv->cells() * sizeof(float) + 256);
         if (rc) return rc;
     }
@@ -1386,6 +1720,20 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     // no input volume to ask)
     const char* es = getenv("PMX_CBCA_SIGN");
     const bool sign = rows_ok && (census_src || (cv->nonneg && !(es && es[0] == '0')));
+    if (march) {
+        pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
+        if (o > 0) {
+            const size_t cells = ((size_t)2 * o * W + (size_t)(H - 2 * o) * 2 * o) * cv->D;
+            const unsigned nb = (unsigned)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
+            hipLaunchKernelGGL(cbca_border_nan_kernel, dim3(nb), dim3(256), 0, ctx->stream, cv->data, H, W, cv->D, o);
+        }
+        const dim3 grid((Wc + m.NC - 1) / m.NC);
+        void (*kern)(cbca_args, cbca_march) = o == a.cb ? cbca_census_march_kernel<3> : cbca_census_march_kernel<1>;
+        PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)march_lds));
+        hipLaunchKernelGGL(kern, grid, dim3(m.T), march_lds, ctx->stream, a, m);
+        PMX_HIP(hipGetLastError());
+        return PMX_OK;
+    }
     if (rows_ok) {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_H);
         const int T = ((a.R * cv->D + 63) / 64) * 64;

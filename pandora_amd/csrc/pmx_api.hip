@@ -1279,6 +1279,12 @@ extern "C" int pmx_wta_from_keys(pmx_ctx* ctx, const uint64_t* dev_keys, double 
     return pmx_launch_from_keys(ctx, dev_keys, d0_global, subpix, invalid_disparity);
 }
 
+extern "C" int pmx_debug_small_division(pmx_ctx* ctx, unsigned* mismatches) {
+    PMX_CHECK(ctx && mismatches, PMX_ERR_ARG, "pmx_debug_small_division: null argument");
+    PMX_HIP(hipSetDevice(ctx->device));
+    return pmx_launch_small_division_check(ctx, mismatches);
+}
+
 extern "C" int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size_t host_bytes, int* Dp, int* gl,
                                     int* kpl) {
     PMX_CHECK(ctx && cv, PMX_ERR_ARG, "pmx_debug_path_costs: null argument");

@@ -301,6 +301,7 @@ int pmx_launch_wta_fixup(pmx_ctx* ctx, const pmx_cv* cv);                       
 int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta);      // runs the upward family of a pending volume
 int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int distance, bool census_src);
 bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, int distance);
+int pmx_launch_small_division_check(pmx_ctx* ctx, unsigned* host_count);
 int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity, int distance, int16_t* dev_out);
 int pmx_comm_join(pmx_ctx* ctx);  // the context's stream waits for a gather still running on the communication stream
 int pmx_launch_nan_pixels(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* dev_out);

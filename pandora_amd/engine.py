@@ -635,6 +635,12 @@ class Engine:
                                              _p(gmax, C.c_int64), _p(lo, C.c_float), _p(hi, C.c_float)), "pmx_interval_bounds")
         return lo, hi
 
+    def debug_small_division(self):
+        """how many of the 65536 x 1024 small-integer quotients of the census + CBCA marching kernel differ from the IEEE division"""
+        bad = C.c_uint(0)
+        check(_lib.lib().pmx_debug_small_division(self.ctx, C.byref(bad)), "pmx_debug_small_division")
+        return bad.value
+
     def debug_path_costs(self, cv, raw=False):
         """uint8 [8][H][W][D] per-direction SGM path costs of a volume in the fused representation
         (raw=True: the device byte order [8][H][W][Dp] and the (gl, kpl) lane map)."""

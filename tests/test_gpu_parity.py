@@ -1152,6 +1152,68 @@ def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, vbuf,
     eng.set_disparity_grids(None, None)
 
 
+def test_small_integer_division_of_the_marching_kernel(eng):
+    """every quotient a / b, a < 65536, 1 <= b <= 1024, of the kernel's reciprocal + Newton step equals the IEEE division bit for bit"""
+    assert eng.debug_small_division() == 0
+
+
+def test_cbca_crop_wider_than_the_census_border(eng, oracle):
+    """offset 3 with a 5x5 census: the ring of cells between the census border and the crop keeps its costs, so the volume has to
+    exist before the aggregation (pmx_cbca_can_fuse_census says no; the census-source kernels used to write NaN there)."""
+    H, W, dmin, dmax, dist, win, off = 47, 83, -20, 6, 5, 5, 3
+    L, R = pair(H, W, seed=H + W + dist, integer=True)
+    cv = gpu_cv(eng, "census", L, R, dmin, dmax, 1, win)
+    eng.cbca(cv, off, 30.0, dist)
+    got = cv.to_host()
+    exp = cpu_cv(oracle, "census", L, R, dmin, dmax, 1, win)
+
+    def arms(im):
+        m = np.nan_to_num(oracle.median3(im.copy()), nan=np.inf)[off:-off, off:-off]
+        return oracle.cross_support(np.ascontiguousarray(m), dist, 30.0)
+
+    oracle.cbca(exp, dmin, 1, off, arms(L), [arms(R)])
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,dist,win,off", [
+    (70, 150, -12, 5, 5, 5, 2),      # D = 18: 8 columns per workgroup, two staging words per thread
+    (41, 67, 0, 60, 5, 5, 2),        # D = 61
+    (45, 203, -64, 64, 5, 5, 2),     # D = 129: 7 columns per workgroup (the BASELINE configurations' D), two halo cells per thread
+    (33, 52, -6, 6, 2, 5, 2),        # arms of one pixel, D = 13 (fewer than 11 disparities keep passes H and V)
+    (38, 77, -5, 4, 3, 3, 1),        # census 3x3
+    (52, 90, -100, 99, 4, 5, 2),     # D = 200: 5 columns per workgroup
+    (40, 300, 0, 255, 5, 5, 2),      # D = 256: 4 columns per workgroup
+    (47, 83, -20, 6, 5, 5, 1),       # crop narrower than the census border: the general geometry test
+    (36, 61, -7, 7, 5, 5, 0),        # no crop at all
+    (20, 20, -8, 7, 5, 5, 2),        # 16 x 16 cropped pixels: the smallest image the long-scan kernels take
+])
+def test_cbca_census_march(eng, oracle, monkeypatch, H, W, dmin, dmax, dist, win, off):
+    """cbca_census_march_kernel (census costs, horizontal and vertical scans in one marching kernel on exact integer sums, no E_h
+    volume) forced onto small pairs: bit-exact against the oracle, which follows the reference's float32 scans - all integers
+    below 2^24.  Passes H and V must not have run."""
+    if not eng.lazy:
+        pytest.skip("census codes are only kept in lazy mode")
+    monkeypatch.setenv("PMX_CBCA_MARCH", "1")
+    L, R = pair(H, W, seed=H + W + dist, integer=True)
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    cv = gpu_cv(eng, "census", L, R, dmin, dmax, 1, win)
+    eng.cbca(cv, off, 30.0, dist)
+    got = cv.to_host()
+    launches = {k: eng.stage_time(k)[1] for k in ("census_cost", "cbca_h", "cbca_v")}
+    eng.set_profiling(False)
+    assert launches == {"census_cost": 0, "cbca_h": 0, "cbca_v": 1}
+    exp = cpu_cv(oracle, "census", L, R, dmin, dmax, 1, win)
+
+    def arms(im):
+        m = np.nan_to_num(oracle.median3(im.copy()), nan=np.inf)
+        m = m[off:m.shape[0] - off, off:m.shape[1] - off]
+        return oracle.cross_support(np.ascontiguousarray(m), dist, 30.0)
+
+    oracle.cbca(exp, dmin, 1, off, arms(L), [arms(R)])
+    np.testing.assert_array_equal(got, exp)
+
+
 @pytest.mark.parametrize("H,W,dmin,dmax,method,win", [(23, 41, -9, 3, "census", 5), (30, 70, -4, 60, "sad", 3), (9, 300, -20, 0, "zncc", 5),
                                                        (64, 33, -2, 2, "census", 7)])
 def test_sgm_with_penalty_maps(eng, oracle, H, W, dmin, dmax, method, win):
