@@ -1116,6 +1116,7 @@ def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, vbuf,
     through the generic kernels with 64-thread workgroups (they used to fail at launch: 256 KB of LDS)."""
     if rows:
         monkeypatch.setenv("PMX_CBCA_ROWS", rows)
+    monkeypatch.setenv("PMX_CBCA_MARCH", "0")  # (plain census geometry with short arms would take the one-kernel route: test_cbca_census_march)
     monkeypatch.setenv("PMX_CBCA_VBUF", vbuf)  # pass V with pointers (what small volumes get) / through buffer instructions (large ones)
     if rows == "3":
         monkeypatch.setenv("PMX_CBCA_VBS", "512")  # ... in the 512-thread workgroups the largest volumes get
@@ -1189,11 +1190,10 @@ def test_cbca_crop_wider_than_the_census_border(eng, oracle):
 ])
 def test_cbca_census_march(eng, oracle, monkeypatch, H, W, dmin, dmax, dist, win, off):
     """cbca_census_march_kernel (census costs, horizontal and vertical scans in one marching kernel on exact integer sums, no E_h
-    volume) forced onto small pairs: bit-exact against the oracle, which follows the reference's float32 scans - all integers
+    volume; the default whenever it is legal): bit-exact against the oracle, which follows the reference's float32 scans - all integers
     below 2^24.  Passes H and V must not have run."""
     if not eng.lazy:
         pytest.skip("census codes are only kept in lazy mode")
-    monkeypatch.setenv("PMX_CBCA_MARCH", "1")
     L, R = pair(H, W, seed=H + W + dist, integer=True)
     eng.set_profiling(True)
     eng.reset_stage_times()

@@ -1,6 +1,7 @@
 """Mid-size random pipelines (images up to 200 x 500, D up to 140) with the kernel-choice hooks drawn at random, so that the paths
 the small-image fuzz never reaches are compared with the oracle too: the whole-row CBCA pass H with 1..4 rows per workgroup, pass V
-through pointers / buffers / 512-thread workgroups, census costs inside pass H with and without valid intervals, the float32 SGM
+through pointers / buffers / 512-thread workgroups, census costs inside pass H with and without valid intervals, census + CBCA as one
+marching kernel, the float32 SGM
 schedules (one after the other, side by side, marching families), the integer path with odd lane maps.  FUZZ_FROM / FUZZ_TO."""
 import os
 import sys
@@ -14,7 +15,7 @@ from tests.cbca_helpers import oracle_cross_supports  # noqa: E402
 
 HOOKS = {"PMX_CBCA_VBUF": ["0", "1"], "PMX_CBCA_VBS": ["256", "512"], "PMX_CBCA_ROWS": [None, "1", "2", "3"],
          "PMX_CBCA_GEO": [None, "0"], "PMX_SGM_SCHED": [None, "seq", "par", "fam"], "PMX_SGM_PENDING": [None, "0"],
-         "PMX_SGM_HFUSED": [None, "0"], "PMX_COST5": [None, "0"]}
+         "PMX_SGM_HFUSED": [None, "0"], "PMX_COST5": [None, "0"], "PMX_CBCA_MARCH": [None, None, "0"]}
 
 
 def one(seed):
