@@ -971,6 +971,7 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
 struct cbca_march {
     int NC, T;                  // useful columns and threads of a workgroup
     int nsh;                    // halo cells per thread (1 or 2)
+    unsigned ring_stride;       // bytes of a ring slot
     unsigned cost_off, code_off, arms_off, tab_off;  // LDS byte offsets (the ring starts at 0)
     unsigned cost_buf, code_buf, arms_buf;           // bytes of one of the two buffers of each
     int wprc, wpra;             // staged words per row: codes (NC + 8 left, NC + 8 + D - 1 right), arms (NC left, NC + D - 1 right)
@@ -1023,7 +1024,7 @@ int pmx_launch_small_division_check(pmx_ctx* ctx, unsigned* host_count) {
 // consecutive disparities read consecutive 16 bytes (no bank conflict; rows of 16 bytes 64 apart would collide eight ways).
 // (8 wavefronts per SIMD: 64 registers, so that two workgroups of 15 wavefronts share a CU and fill each other's barriers -
 // 24.7 against 26.8 ms at 10000^2 x 129 for the 71 registers the compiler would take)
-template <int SRC>  // 3: census geometry with the crop equal to the census border; 1: census geometry, any crop
+template <int SRC>  // 3: census geometry with the crop equal to the census border; 1: census geometry, any crop; 2: the valid intervals cv_masked left
 __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a, cbca_march m) {
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // (LDS addresses below are absolute: the dynamic block starts at 0)
     const int D = a.D, NC = m.NC, T = m.T, Wc = a.Wc, Hc = a.Hc, W = a.W, o = a.o;
@@ -1037,14 +1038,17 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
     const int c = c0 + cloc, q = c + a.d0 + k;
     const bool live = (tid < NC * D) & (c < Wc);
     const bool inside = (q >= 0) & (q < Wc);
-    const uint32_t RS4 = (uint32_t)(NC * D) * 4u, own = (uint32_t)ci * 4u;  // ring: bytes per slot, this cell's word in a slot
+    // ring: bytes per slot (a multiple of the 32 banks: which bank a cell's word lies in does not depend on the slot, so lanes that
+    // read different slots do not collide), this cell's word in a slot
+    const uint32_t RS4 = m.ring_stride, own = (uint32_t)ci * 4u;
     // column tests of a cost (its row test is uniform): geometry of the census windows
     const unsigned wvalid = (unsigned)(W - 2 * a.cb);
     auto col_ok = [&](int cc, int kk) -> bool {  // cropped column cc, disparity index kk
         if (SRC == 3) return (unsigned)(cc + a.d0 + kk) < (unsigned)Wc;
+        if (SRC == 2) return true;  // (the valid interval of the pixel decides, row by row)
         return (bool)(((unsigned)(cc + o - a.cb) < wvalid) & ((unsigned)(cc + o + a.d0 + kk - a.cb) < wvalid));
     };
-    auto row_mask = [&](int r) -> uint32_t { return (SRC == 3 || ((r + o >= a.cb) & (r + o < a.H - a.cb))) ? 0xffffffffu : 0u; };
+    auto row_mask = [&](int r) -> uint32_t { return (SRC != 1 || ((r + o >= a.cb) & (r + o < a.H - a.cb))) ? 0xffffffffu : 0u; };
     const bool own_ok = col_ok(c, k);
     // ---- one-time LDS set-up: the byte masks, the empty ring
     for (int e = tid; e < 144; e += T) {
@@ -1060,25 +1064,30 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
 #pragma unroll
     for (int s = 0; s < kMarchRing; ++s) lds_w32((uint32_t)s * RS4 + own, 0u);  // row -1: zero sum, zero count
     // ---- staging: which words of a quad's rows this thread brings in (the same for every quad).  Word idx of a kind is
-    // (row j, position w) = (idx / words per row, idx mod words per row)
+    // (position w, row j) = (idx / 4, idx mod 4)
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)a.codes, 0, a.codes_bytes, kRsrcWord3);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsL8, 0, m.arms_bytes, kRsrcWord3);
     const int CWL = NC + 8;
     const uint32_t tb_off = (uint32_t)m.wpra * 16u;  // the (top, bottom) half of an arms buffer
     unsigned gc[kMarchSlots], lc[kMarchSlots], ga[kMarchSlots], la[kMarchSlots], adv_a[kMarchSlots];
+    bool is_rng[kMarchSlots];
+    constexpr bool kRange = SRC == 2;
+    const int CWR = CWL + D - 1;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.range, 0, kRange ? (unsigned)a.H * (unsigned)W * 4u : 0u, kRsrcWord3);
 #pragma unroll
     for (int s = 0; s < kMarchSlots; ++s) {
         {
             const int idx = min(tid + s * T, 4 * m.wprc - 1);  // (a thread beyond the last word doubles it)
-            const int j = idx / m.wprc, w = idx - j * m.wprc;
+            const int w = idx >> 2, j = idx & 3;  // consecutive lanes, consecutive LDS words (a word's LDS index IS idx)
             const unsigned row0 = (unsigned)(j + o) * (unsigned)W + (unsigned)(o + c0 - 4);
             const unsigned word = w < CWL ? a.offCL + row0 + (unsigned)w : a.offCR + row0 + (unsigned)(a.d0 + (w - CWL));
-            gc[s] = word * 4u;
+            is_rng[s] = kRange && w >= CWL + CWR;  // SRC 2: the pixels' valid intervals ride behind the codes (another buffer)
+            gc[s] = is_rng[s] ? (row0 + (unsigned)(w - CWL - CWR)) * 4u : word * 4u;
             lc[s] = m.code_off + (uint32_t)(w * 4 + j) * 4u;
         }
         {
             const int idx = min(tid + s * T, 4 * m.wpra - 1);
-            const int j = idx / m.wpra, w = idx - j * m.wpra;
+            const int w = idx >> 2, j = idx & 3;
             const bool left = w < NC;
             const unsigned word = left ? (unsigned)j * (unsigned)a.pitchL + (unsigned)(c0 + w)
                                        : m.armsR_word + (unsigned)j * (unsigned)a.pitchR + (unsigned)(a.padR + c0 + a.d0 + (w - NC));
@@ -1092,7 +1101,8 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
     auto issue = [&]() {  // the next quad's words into registers, offsets advanced
 #pragma unroll
         for (int s = 0; s < kMarchSlots; ++s) {
-            sc[s] = __builtin_amdgcn_raw_buffer_load_b32(rsC, gc[s], 0, 0);
+            sc[s] = __builtin_amdgcn_raw_buffer_load_b32(rsC, (kRange && is_rng[s]) ? kOob : gc[s], 0, 0);
+            if (kRange) sc[s] |= __builtin_amdgcn_raw_buffer_load_b32(rsG, is_rng[s] ? gc[s] : kOob, 0, 0);  // (the load out of range returns 0)
             gc[s] += adv_c;
             sa[s] = __builtin_amdgcn_raw_buffer_load_b32(rsA, ga[s], 0, 0);
             ga[s] += adv_a[s];
@@ -1115,9 +1125,10 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
     const uint32_t cost_row = m.cost_off + (uint32_t)k * 16u;  // the 16 bytes of this disparity (+ row * rowb)
     const uint32_t rowb = (uint32_t)D * 16u;
     const uint32_t own_dst = cost_row + xc;
+    const uint32_t rng_own = m.code_off + ((uint32_t)(CWL + CWR) + xc) * 16u;  // SRC 2: the valid intervals of this column's four rows
     const uint32_t tab_own = m.tab_off + (xc * 13u - 4u) * 16u;  // + (right - 12 * left) * 16
     // halo cells: 8 columns x D disparities shared out over the workgroup (a second one only where a wavefront has any)
-    uint32_t h_l[2], h_r[2], h_dst[2];
+    uint32_t h_l[2], h_r[2], h_dst[2], h_g[2], h_k[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int h = min(tid + s * T, 8 * D - 1);
@@ -1126,6 +1137,8 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
         h_l[s] = m.code_off + (uint32_t)x * 16u;
         h_r[s] = col_ok(c0 - 4 + x, hk) ? m.code_off + (uint32_t)(CWL + x + hk) * 16u : h_l[s];
         h_dst[s] = m.cost_off + (uint32_t)hk * 16u + (uint32_t)x;
+        h_g[s] = m.code_off + (uint32_t)(CWL + CWR + x) * 16u;
+        h_k[s] = (uint32_t)hk;
     }
     const bool wave_h1 = m.nsh > 1 && __builtin_amdgcn_ballot_w64(tid + T < 8 * D) != 0;  // (uniform: a scalar branch)
     // ---- the march
@@ -1135,6 +1148,7 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
     float* out_row = a.cv + (ptrdiff_t)(o - 4) * (ptrdiff_t)row_stride;  // output row of the quad's first leaving row (4n - 4)
     uint32_t acc = 0, nacc = 0;
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;  // (top | bottom << 16) of the four rows that leave next
+    bool ok_old[4] = {false, false, false, false}, ok_new[4] = {false, false, false, false};  // SRC 2: was the cell's own cost a number?
     issue();
     land(0u, 0u);
     issue();
@@ -1150,22 +1164,37 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
         {
             const u32x4 cl = lds_r128(code_l + cb_), cr = lds_r128(code_r + cb_);
             const u32x4 hl = lds_r128(h_l[0] + cb_), hr = lds_r128(h_r[0] + cb_);
+            u32x4 og{}, hg{};
+            if (kRange) {
+                og = lds_r128(rng_own + cb_);
+                hg = lds_r128(h_g[0] + cb_);
+            }
             uint32_t od = own_dst + kb_, hd = h_dst[0] + kb_;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t rm = row_mask(r + j);
-                lds_w8(od, (uint32_t)__popc(cl[j] ^ cr[j]) & rm);
-                lds_w8(hd, (uint32_t)__popc(hl[j] ^ hr[j]) & rm);
+                uint32_t oc = (uint32_t)__popc(cl[j] ^ cr[j]) & rm, hc = (uint32_t)__popc(hl[j] ^ hr[j]) & rm;
+                if (kRange) {  // lo <= k < hi of the pixel's interval (lo | hi << 16)
+                    ok_new[j] = (uint32_t)k - (og[j] & 0xffffu) < (og[j] >> 16) - (og[j] & 0xffffu);
+                    oc = ok_new[j] ? oc : 0u;
+                    hc = (h_k[0] - (hg[j] & 0xffffu) < (hg[j] >> 16) - (hg[j] & 0xffffu)) ? hc : 0u;
+                }
+                lds_w8(od, oc);
+                lds_w8(hd, hc);
                 od += rowb;
                 hd += rowb;
             }
         }
         if (wave_h1) {
             const u32x4 hl = lds_r128(h_l[1] + cb_), hr = lds_r128(h_r[1] + cb_);
+            u32x4 hg{};
+            if (kRange) hg = lds_r128(h_g[1] + cb_);
             uint32_t hd = h_dst[1] + kb_;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                lds_w8(hd, (uint32_t)__popc(hl[j] ^ hr[j]) & row_mask(r + j));
+                uint32_t hc = (uint32_t)__popc(hl[j] ^ hr[j]) & row_mask(r + j);
+                if (kRange) hc = (h_k[1] - (hg[j] & 0xffffu) < (hg[j] >> 16) - (hg[j] & 0xffffu)) ? hc : 0u;
+                lds_w8(hd, hc);
                 hd += rowb;
             }
         }
@@ -1228,6 +1257,7 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
             const float quot = small_int_div((float)(d & 0xffffu), (float)(d >> 16));
             float res;
             if (SRC == 3) res = inside ? quot : c_nan();
+            else if (SRC == 2) res = ok_old[j] ? (inside ? quot : 0.f) : c_nan();
             else res = (own_ok && row_mask(r - 4 + j)) ? (inside ? quot : 0.f) : c_nan();
             const bool row_in = (r - 4 + j >= 0) & (r - 4 + j < Hc);  // (uniform: a row that does not exist gets an empty descriptor)
             const __amdgpu_buffer_rsrc_t rsO =
@@ -1236,6 +1266,10 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
         };
         emit(p0, 0); emit(p1, 1); emit(p2, 2); emit(p3, 3);
         t0 = tb[0]; t1 = tb[1]; t2 = tb[2]; t3 = tb[3];
+        if (kRange) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ok_old[j] = ok_new[j];
+        }
         s0 = s0 == 8 ? 0 : s0 + 4;
         out_row += (size_t)4 * row_stride;
     }
@@ -1605,21 +1639,21 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     bool march = false;
     {
         const char* em = getenv("PMX_CBCA_MARCH");
-        const bool shape_ok = census_src && rows_ok && !(cv->has_range) && a.A <= 4 && cv->subpix == 1 && cv->D <= 256 &&
+        const bool shape_ok = census_src && rows_ok && a.A <= 4 && cv->subpix == 1 && cv->D <= 256 &&
                               (size_t)Hc * 9 * 32 < ((size_t)1 << 24) && bL8 + bR8 < 0xfffffff0u;
         // columns per workgroup: as many (up to 8: a disparity's costs of a row are 16 bytes with the 8 halo columns) as leave
         // room for two workgroups per CU, else as fit one
         auto layout = [&](int NC) {
             m.NC = NC;
             m.T = ((NC * cv->D + 63) / 64) * 64;
-            m.wprc = 2 * (NC + 8) + cv->D - 1;
+            m.wprc = 2 * (NC + 8) + cv->D - 1 + (cv->has_range ? NC + 8 : 0);  // (+ the valid intervals of the left columns)
             m.wpra = 2 * NC + cv->D - 1;
             m.nsh = (8 * cv->D + m.T - 1) / m.T;
             m.cost_buf = (unsigned)cv->D * 64u;
             m.code_buf = (unsigned)m.wprc * 16u;
             m.arms_buf = (unsigned)m.wpra * 32u;
-            m.cost_off = (unsigned)kMarchRing * (unsigned)(NC * cv->D) * 4u;
-            m.cost_off = (m.cost_off + 15u) & ~15u;
+            m.ring_stride = ((unsigned)(NC * cv->D) * 4u + 127u) & ~127u;
+            m.cost_off = (unsigned)kMarchRing * m.ring_stride;
             m.tab_off = m.cost_off + 2u * m.cost_buf;
             m.code_off = m.tab_off + (unsigned)kMarchTab;
             m.arms_off = m.code_off + 2u * m.code_buf;
@@ -1729,7 +1763,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
             hipLaunchKernelGGL(cbca_border_nan_kernel, dim3(nb), dim3(256), 0, ctx->stream, cv->data, H, W, cv->D, o);
         }
         const dim3 grid((Wc + m.NC - 1) / m.NC);
-        void (*kern)(cbca_args, cbca_march) = o == a.cb ? cbca_census_march_kernel<3> : cbca_census_march_kernel<1>;
+        void (*kern)(cbca_args, cbca_march) = a.range ? cbca_census_march_kernel<2> : o == a.cb ? cbca_census_march_kernel<3> : cbca_census_march_kernel<1>;
         PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)march_lds));
         hipLaunchKernelGGL(kern, grid, dim3(m.T), march_lds, ctx->stream, a, m);
         PMX_HIP(hipGetLastError());

@@ -1176,41 +1176,55 @@ def test_cbca_crop_wider_than_the_census_border(eng, oracle):
     np.testing.assert_array_equal(got, exp)
 
 
-@pytest.mark.parametrize("H,W,dmin,dmax,dist,win,off", [
-    (70, 150, -12, 5, 5, 5, 2),      # D = 18: 8 columns per workgroup, two staging words per thread
-    (41, 67, 0, 60, 5, 5, 2),        # D = 61
-    (45, 203, -64, 64, 5, 5, 2),     # D = 129: 7 columns per workgroup (the BASELINE configurations' D), two halo cells per thread
-    (33, 52, -6, 6, 2, 5, 2),        # arms of one pixel, D = 13 (fewer than 11 disparities keep passes H and V)
-    (38, 77, -5, 4, 3, 3, 1),        # census 3x3
-    (52, 90, -100, 99, 4, 5, 2),     # D = 200: 5 columns per workgroup
-    (40, 300, 0, 255, 5, 5, 2),      # D = 256: 4 columns per workgroup
-    (47, 83, -20, 6, 5, 5, 1),       # crop narrower than the census border: the general geometry test
-    (36, 61, -7, 7, 5, 5, 0),        # no crop at all
-    (20, 20, -8, 7, 5, 5, 2),        # 16 x 16 cropped pixels: the smallest image the long-scan kernels take
+@pytest.mark.parametrize("H,W,dmin,dmax,dist,win,off,with_grids,with_left_mask", [
+    (70, 150, -12, 5, 5, 5, 2, False, False),      # D = 18: 8 columns per workgroup, two staging words per thread
+    (41, 67, 0, 60, 5, 5, 2, False, False),        # D = 61
+    (45, 203, -64, 64, 5, 5, 2, False, False),     # D = 129: 7 columns per workgroup (the BASELINE configurations' D), two halo cells per thread
+    (33, 52, -6, 6, 2, 5, 2, False, False),        # arms of one pixel, D = 13 (fewer than 11 disparities keep passes H and V)
+    (38, 77, -5, 4, 3, 3, 1, False, False),        # census 3x3
+    (52, 90, -100, 99, 4, 5, 2, False, False),     # D = 200: 5 columns per workgroup
+    (40, 300, 0, 255, 5, 5, 2, False, False),      # D = 256: 4 columns per workgroup
+    (47, 83, -20, 6, 5, 5, 1, False, False),       # crop narrower than the census border: the general geometry test
+    (36, 61, -7, 7, 5, 5, 0, False, False),        # no crop at all
+    (20, 20, -8, 7, 5, 5, 2, False, False),        # 16 x 16 cropped pixels: the smallest image the long-scan kernels take
+    (41, 67, 0, 60, 5, 5, 2, True, False),         # per-pixel disparity ranges: the valid intervals cv_masked left decide what is a cost
+    (45, 203, -64, 64, 5, 5, 2, True, True),       # ... and a left mask, D = 129
+    (38, 77, -5, 4, 3, 3, 1, False, True),
 ])
-def test_cbca_census_march(eng, oracle, monkeypatch, H, W, dmin, dmax, dist, win, off):
+def test_cbca_census_march(eng, oracle, H, W, dmin, dmax, dist, win, off, with_grids, with_left_mask):
     """cbca_census_march_kernel (census costs, horizontal and vertical scans in one marching kernel on exact integer sums, no E_h
     volume; the default whenever it is legal): bit-exact against the oracle, which follows the reference's float32 scans - all integers
     below 2^24.  Passes H and V must not have run."""
     if not eng.lazy:
         pytest.skip("census codes are only kept in lazy mode")
     L, R = pair(H, W, seed=H + W + dist, integer=True)
+    rng = np.random.default_rng(H * dist)
+    mskL = rng.choice([0, 0, 0, 0, 0, 0, 0, 1], (H, W)).astype(np.int16) if with_left_mask else None
+    grids = None
+    if with_grids:
+        grids = (rng.integers(dmin, dmin + 3, (H, W)).astype(np.float64), rng.integers(dmax - 3, dmax + 1, (H, W)).astype(np.float64))
+    masks = (mskL, None, 0, 1) if with_left_mask else None
     eng.set_profiling(True)
     eng.reset_stage_times()
-    cv = gpu_cv(eng, "census", L, R, dmin, dmax, 1, win)
+    cv = gpu_cv(eng, "census", L, R, dmin, dmax, 1, win, masks=masks, grids=grids)
     eng.cbca(cv, off, 30.0, dist)
     got = cv.to_host()
     launches = {k: eng.stage_time(k)[1] for k in ("census_cost", "cbca_h", "cbca_v")}
     eng.set_profiling(False)
+    eng.set_masks(None, None)
+    eng.set_disparity_grids(None, None)
     assert launches == {"census_cost": 0, "cbca_h": 0, "cbca_v": 1}
-    exp = cpu_cv(oracle, "census", L, R, dmin, dmax, 1, win)
+    exp = cpu_cv(oracle, "census", L, R, dmin, dmax, 1, win, masks=masks, grids=grids)
 
-    def arms(im):
-        m = np.nan_to_num(oracle.median3(im.copy()), nan=np.inf)
+    def arms(im, msk):
+        m = im.copy()
+        if msk is not None:
+            m[msk != 0] = np.nan
+        m = np.nan_to_num(oracle.median3(m), nan=np.inf)
         m = m[off:m.shape[0] - off, off:m.shape[1] - off]
         return oracle.cross_support(np.ascontiguousarray(m), dist, 30.0)
 
-    oracle.cbca(exp, dmin, 1, off, arms(L), [arms(R)])
+    oracle.cbca(exp, dmin, 1, off, arms(L, mskL), [arms(R, None)])
     np.testing.assert_array_equal(got, exp)
 
 
