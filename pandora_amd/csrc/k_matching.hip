@@ -638,7 +638,14 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, uint32
 template <int WIN_T, int SUBPIX>  // window known at compile time (0: any)
 __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_params q) {
     constexpr int ND = kZnccND;
-    __shared__ double colbuf[kZnccWaves][ND][64];
+    // The window's COLUMNS: 8 x 7 (or 8 x 8) lanes of the wavefront each take one disparity and 8 adjacent output columns, read
+    // the 8 + WIN - 1 column sums they span (16 bytes at a time), SLIDE the window sum along them in registers (WIN - 1 additions
+    // for the first, two for each of the other seven) and leave the 8 sums where the output lanes pick them up: 18 doubles read
+    // and 24 additions for 8 windows of 11 instead of 88 and 80.  (kColStride: room for the last segment's reads, rows of 16-byte
+    // multiples, disparities in different banks.)
+    constexpr bool kJob = WIN_T >= 3 && WIN_T <= 13;
+    constexpr int kColStride = kJob ? 70 : 64;
+    __shared__ __attribute__((aligned(16))) double colbuf[kZnccWaves][ND][kColStride];
     __shared__ double rstat[kZnccWaves][2][64 + ND];  // [wave][mean|isd][column]
     __shared__ __attribute__((aligned(16))) float ostage[2][64][kZnccOutStride];
 
@@ -763,9 +770,52 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int kShift = kJob ? 2 - ((WIN_T / 2) & 1) : 0;  // where a window sum waits: column + kShift (16-byte aligned runs of 8)
+        if (kJob) {
+            constexpr int OJ = WIN_T / 2, NOUT = 64 - 2 * OJ, NSEG = (NOUT + 7) / 8, NRD = 8 + WIN_T - 1, NRD2 = (NRD + 1) / 2;
+            if (lane < NSEG * 8) {
+                typedef double zd2 __attribute__((ext_vector_type(2)));
+                const int je = lane & 7, js = lane >> 3;
+                double* row = &colbuf[wv][je][js * 8];
+                double v[2 * NRD2];
+#pragma unroll
+                for (int i = 0; i < NRD2; ++i) {
+                    const zd2 t = *reinterpret_cast<const zd2*>(row + 2 * i);
+                    v[2 * i] = t.x;
+                    v[2 * i + 1] = t.y;
+                }
+                // the segment's first window as a tree, the other seven slide to the right (so that the columns past the tile's 64,
+                // which nobody wrote, only ever reach windows that are not output)
+                double w8[8];
+                double t[WIN_T > 0 ? WIN_T : 1];
+#pragma unroll
+                for (int i = 0; i < WIN_T; ++i) t[i] = v[i];
+#pragma unroll
+                for (int n = WIN_T; n > 1; n = (n + 1) / 2)
+#pragma unroll
+                    for (int i = 0; i < n / 2; ++i) t[i] = t[i] + t[n - 1 - i];
+                w8[0] = t[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) w8[i] = (w8[i - 1] - v[i - 1]) + v[i + WIN_T - 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    zd2 pr;
+                    pr.x = w8[2 * i];
+                    pr.y = w8[2 * i + 1];
+                    *reinterpret_cast<zd2*>(row + OJ + kShift + 2 * i) = pr;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         if (out_lane) {
             float out[ND];
             double box[ND];
+            if (kJob) {
+#pragma unroll
+                for (int e = 0; e < ND; ++e) box[e] = colbuf[wv][e][lane + kShift];
+            } else {
             // SUBPIX 1: volatile, typed as LDS = plain ds_read_b64 (2 LDS cycles each).  Left alone, the compiler pairs neighbouring
             // columns into ds_read2_b64, which the LDS serves at half the rate (8 cycles for the two: MI355X_MICROARCH.md, LDS
             // table) - and the window columns are most of what this kernel asks of the LDS (11 x 11 at 4096^2 x 257: 13.0 -> 11.0 ms;
@@ -784,6 +834,7 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
                 for (int j = 1; j < win; ++j)
 #pragma unroll
                     for (int e = 0; e < ND; ++e) box[e] += cb[e * 64 + j];
+            }
             }
 #pragma unroll
             for (int e = 0; e < ND; ++e) {
