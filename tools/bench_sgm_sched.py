@@ -16,7 +16,9 @@ from pandora_amd.engine import Engine  # noqa: E402
 SIZES = {"C2": (375, 450, -60, 0), "C3": (2048, 2048, 0, 128), "C4": (4096, 4096, 0, 256), "C5": (10000, 10000, -64, 64),
          "W8k": (2048, 8192, 0, 128),
          # the marching kernels' time against the number of rows: slope = time per row, intercept = pipeline fill
-         "C4h1k": (1024, 4096, 0, 256), "C4h2k": (2048, 4096, 0, 256), "C4h3k": (3072, 4096, 0, 256)}
+         "C4h1k": (1024, 4096, 0, 256), "C4h2k": (2048, 4096, 0, 256), "C4h3k": (3072, 4096, 0, 256),
+         # the same lane map (3 disparities per lane) with 43 and with 64 active lanes: issue-bound or memory-bound?
+         "K3a": (4096, 4096, 0, 128), "K3b": (4096, 4096, 0, 191)}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("names", nargs="*", default=["C3", "C4"])
