@@ -34,6 +34,14 @@ static constexpr int kPF = 8;  // pixels of read-ahead per wave (register ring)
 __device__ __forceinline__ float f_inf() { return __int_as_float(0x7f800000); }
 __device__ __forceinline__ float f_nan() { return __int_as_float(0x7fc00000); }
 __device__ __forceinline__ float fmin2(float a, float b) { return a < b ? a : b; }
+// This file is compiled with -fno-honor-nans (Makefile): no NaN ever reaches a floating-point instruction of the recurrences - an
+// invalid cost is replaced by `invalid_cost` before it is used, lanes without a disparity carry +inf - so the minima are single
+// v_min_f32 / v_min3_f32 (with NaNs honoured every `a < b ? a : b` is a compare and a select, and the line kernels are bound by
+// their vector instructions: 86 per step of the checkpoint pass).  What IS a NaN is recognised by its bits.
+__device__ __forceinline__ bool is_nan_bits(float v) { return (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u; }
+// NaN where `c`.  Under -fno-honor-nans a select that may yield a NaN CONSTANT is fair game for the optimiser (it was folded away,
+// bit casts or not), so the NaN's bits come in as a kernel argument (`nan_bits` = 0x7fc00000, set by the launchers).
+__device__ __forceinline__ float nan_where(bool c, float v, uint32_t nan_bits) { return __uint_as_float(c ? nan_bits : __float_as_uint(v)); }
 
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov(float oldv, float src) {
@@ -46,14 +54,25 @@ __device__ __forceinline__ float from_lane_below(float v, float fill) { return d
 // lane l receives the value of lane l+1 (lane 63 keeps `fill`)
 __device__ __forceinline__ float from_lane_above(float v, float fill) { return dpp_mov<0x130>(fill, v); }  // wave_shl:1
 
-// minimum over the 64 lanes, returned wave-uniform
+// minimum over the 64 lanes, returned wave-uniform.  Six in-place v_min_f32_dpp (a lane whose source lane does not exist keeps its
+// value): written as assembly because the compiler's form of `min(v, dpp(v))` is a copy, a v_mov_dpp and a v_min per stage, and
+// the line kernels are bound by their vector instructions.  (s_nop 1: the two wait states a DPP source needs after a VALU write -
+// the hazard recogniser does not look into inline assembly.)
 __device__ __forceinline__ float wave_min(float v) {
-    v = fmin2(v, dpp_mov<0x111>(v, v));             // row_shr:1
-    v = fmin2(v, dpp_mov<0x112>(v, v));             // row_shr:2
-    v = fmin2(v, dpp_mov<0x114>(v, v));             // row_shr:4
-    v = fmin2(v, dpp_mov<0x118>(v, v));             // row_shr:8  -> lane 15 of every row holds the row min
-    v = fmin2(v, dpp_mov<0x142, 0xa>(v, v));        // row_bcast:15 into rows 1,3
-    v = fmin2(v, dpp_mov<0x143, 0xc>(v, v));        // row_bcast:31 into rows 2,3 -> lane 63 holds the min
+    asm("s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"  // lane 15 of every row holds the row's minimum
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // into rows 1, 3
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // into rows 2, 3: lane 63 holds the minimum
+        "s_nop 1"
+        : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -75,6 +94,7 @@ struct sgm_args {
     // penalty methods that follow the image (plugin_libsgm.rst:20-27): P2 of every pixel for the direction of this launch
     // ([H][W] float32; multi: [8][H][W]); nullptr = the constant a.P2
     const float* p2map;
+    uint32_t nan_bits;  // 0x7fc00000 (see nan_where)
 };
 
 // Walks one line.  Every access of the line's pixel is a raw buffer instruction on a descriptor of the pixel's image ROW (the
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
             float cr = cslot[k];
-            float cc = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
+            float cc = is_nan_bits(cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
             float lo = (k > 0) ? Lp[k - 1] : below;
             float hi = (k < KPL - 1) ? Lp[k + 1] : above;
             float nb = fmin2(lo, hi) + a.P1;
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
             if (MODE & SGM_EPILOGUE) {
                 if (a.overcounting) s = s - 7.0f * cc;
                 if (a.is_max) s = -s;
-                if (cr != cr) s = f_nan();
+                s = nan_where(is_nan_bits(cr), s, a.nan_bits);
             }
             out[k] = s;
         }
@@ -283,6 +303,7 @@ struct sgm_h_args {
     int H, W, D, nseg;
     float P1, P2, invalid_cost;
     int is_max, overcounting, epilogue;
+    uint32_t nan_bits;  // 0x7fc00000 (see nan_where)
 };
 
 // forward pass: wave = row, keeps only the checkpoints
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_h_checkpoint_kernel(s
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
             const float cr = slot[k];
-            cc[k] = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
+            cc[k] = is_nan_bits(cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
         }
         M = sgm_line_step<KPL>(Lp, M, cc, nv, a.P1, a.P2, Ln);
 #pragma unroll
@@ -399,7 +420,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_h_backward_kernel(sgm
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
                 const float cr = cur[j][k];
-                cc[j][k] = (cr != cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
+                cc[j][k] = is_nan_bits(cr) ? a.invalid_cost : (a.is_max ? -cr : cr);
             }
         }
         // the (0,+1) path through the segment, recomputed
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_h_backward_kernel(sgm
                 if (a.epilogue) {
                     if (a.overcounting) sv = sv - 7.0f * cc[j][k];
                     if (a.is_max) sv = -sv;
-                    if (cur[j][k] != cur[j][k]) sv = f_nan();
+                    sv = nan_where(is_nan_bits(cur[j][k]), sv, a.nan_bits);
                 }
                 out[k] = sv;
             }
@@ -446,6 +467,7 @@ static int sgm_run_horizontal_fused(pmx_ctx* ctx, const sgm_args& base, int mask
     h.nseg = (base.W + kSegCols - 1) / kSegCols;
     h.P1 = base.P1; h.P2 = base.P2; h.invalid_cost = base.invalid_cost;
     h.is_max = base.is_max; h.overcounting = base.overcounting;
+    h.nan_bits = base.nan_bits;
     h.epilogue = (mask >> 2) == 0;
     const size_t bytes = (size_t)h.H * h.nseg * (64 * KPL + 64) * sizeof(float);
     float* ck = nullptr;
@@ -481,7 +503,7 @@ static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask) {
 // compute), then the epilogue of the last pass: overcounting, sign, NaN where the input was NaN.
 __global__ __launch_bounds__(256) void sgm_sum_paths_kernel(const float* __restrict__ C, const float* __restrict__ L, size_t n,
                                                             float invalid_cost, int is_max, int overcounting, int mask,
-                                                            float* __restrict__ out) {
+                                                            uint32_t nan_bits, float* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t step = (size_t)gridDim.x * 256;
     for (; i < n; i += step) {
@@ -495,10 +517,10 @@ __global__ __launch_bounds__(256) void sgm_sum_paths_kernel(const float* __restr
                 any = true;
             }
         const float cr = C[i];
-        const float cc = (cr != cr) ? invalid_cost : (is_max ? -cr : cr);
+        const float cc = is_nan_bits(cr) ? invalid_cost : (is_max ? -cr : cr);
         if (overcounting) s = s - 7.0f * cc;
         if (is_max) s = -s;
-        if (cr != cr) s = f_nan();
+        s = nan_where(is_nan_bits(cr), s, nan_bits);
         out[i] = s;
     }
 }
@@ -521,7 +543,7 @@ static int sgm_run_parallel(pmx_ctx* ctx, sgm_args a, float* paths, size_t cells
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_PATH);
         const size_t want = (cells + 255) / 256;
         hipLaunchKernelGGL(sgm_sum_paths_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, ctx->stream, a.C, paths,
-                           cells, a.invalid_cost, a.is_max, a.overcounting, mask, ctx->scratch);
+                           cells, a.invalid_cost, a.is_max, a.overcounting, mask, a.nan_bits, ctx->scratch);
     }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
@@ -567,6 +589,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     a.is_max = is_max; a.overcounting = overcounting;
     a.multi = 0; a.vol = 0; a.mask = mask;
     a.p2map = ctx->sgm_p2maps;  // set by pmx_sgm_p2maps for the duration of its call
+    a.nan_bits = 0x7fc00000u;
     const int kpl = (cv->D + 63) / 64;
     // Schedule.  Small volumes cannot fill the GPU one direction at a time (a wave per scanline: 375 - 450 waves on cones, each a
     // chain of dependent steps): "par" runs the eight directions side by side into eight path volumes and adds them in the

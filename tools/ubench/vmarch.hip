@@ -118,6 +118,45 @@ __global__ __launch_bounds__(BS) void march(args a) {
     (void)prog;
 }
 
+// The horizontal passes' pattern: one wavefront per image ROW streams its row (5.16 MB) in pieces of `CH` KB, `AH` pieces ahead -
+// thousands of sequential streams, every one in its own pages.  mode as above.
+template <int CH, int AH>
+__global__ __launch_bounds__(256) void rowstream(args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.H) return;
+    const float4* in = reinterpret_cast<const float4*>(a.in + (size_t)row * a.row);
+    float4* out = reinterpret_cast<float4*>(a.out + (size_t)row * a.row);
+    constexpr int V = CH * 1024 / 16 / 64;  // float4 per lane and piece
+    const size_t npiece = a.row * 4 / (CH * 1024);
+    float4 buf[AH][V];
+    float acc = 0.f;
+    auto ld = [&](size_t p, float4 (&dst)[V]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) dst[v] = (a.mode != 2 && p < npiece) ? in[p * (CH * 64) + v * 64 + lane] : float4{0, 0, 0, 0};
+    };
+#pragma unroll
+    for (int i = 0; i < AH; ++i) ld(i, buf[i]);
+    for (size_t p = 0; p < npiece; p += AH) {
+#pragma unroll
+        for (int i = 0; i < AH; ++i) {
+            float4 cur[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) cur[v] = buf[i][v];
+            ld(p + AH + i, buf[i]);
+            if (p + i < npiece) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    acc += cur[v].x;
+                    cur[v].x = acc;
+                    if (a.mode != 1) out[(p + i) * (CH * 64) + v * 64 + lane] = cur[v];
+                }
+            }
+        }
+    }
+    if (a.mode == 1 && acc == 12345.678f) a.out[row] = acc;
+}
+
 int main(int argc, char** argv) {
     const int H = argc > 1 ? atoi(argv[1]) : 10000, W = argc > 2 ? atoi(argv[2]) : 10000, D = argc > 3 ? atoi(argv[3]) : 129;
     const size_t row = (size_t)W * D, n = (size_t)H * row;
@@ -176,5 +215,15 @@ int main(int argc, char** argv) {
     RUN(512, 1, 1, 4, 0, 1, 64);
     RUN(256, 4, 1, 4, 0, 1, 8);
     RUN(256, 1, 4, 4, 0, 1, 8);
+#define RUNROW(CH, AH, mode)                                                                                                         \
+    timeit("one wavefront per row, pieces of " #CH " KB, " #AH " ahead", mode, 0, 0, [&](const args& a) {                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rowstream<CH, AH>), dim3((unsigned)((H + 3) / 4)), dim3(256), 0, 0, a);                   \
+    })
+    RUNROW(1, 8, 1);
+    RUNROW(4, 2, 1);
+    RUNROW(4, 4, 1);
+    RUNROW(1, 8, 0);
+    RUNROW(4, 2, 0);
+    RUNROW(4, 4, 0);
     return 0;
 }
