@@ -16,7 +16,8 @@ MASTER_PORT), and refuses to run when the box has fewer than N devices or when -
 meant to span N GPUs cannot print a 1-GPU line.  The line carries RCCL's own rank count (ncclCommCount) as `rccl_ranks`.
 At N>1 a second leg, `d_sharded_exact`, times north_star's exact multi-GPU form on BASELINE configs[3]'s steps that shard over D
 (ZNCC 11x11 + WTA + vfit at 4096x4096x257: disparity slices per rank, ONE ncclAllReduce(min, uint64) of the packed per-pixel keys,
-one ncclAllReduce(sum) of the owner-refined maps) and reports the maps' identity with one GPU doing the whole volume.
+one ncclAllReduce(sum) of the owner-refined maps) and reports the maps' identity with one GPU doing the whole volume; a third,
+`pair_per_rank`, is the weak-scaling figure beside the strong-scaling `value`: one whole pair per rank and step, no exchange.
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the 8-path SGM kernel, HIP-event timed on the engine's stream
 inside the timed region), `cpu_baseline` (the C oracle, kind "port", 1 thread, on a bounded row strip of the same pair),
@@ -324,6 +325,33 @@ def d_sharded_leg(eng, comm, L, R, dmin, dmax, win, steps, check_device):
     return out
 
 
+def pair_per_rank_leg(comm, device, H, W, dmin, dmax, win, P1, P2, steps, rank, world):
+    """N > 1, weak scaling beside the strong-scaling headline: every rank runs the WHOLE pipeline on a pair of its own (the way the
+    reference is deployed on many tiles or many pairs: no exchange at all), same barrier / max-over-ranks protocol; the aggregate is
+    world x cells / time.  Outside the headline's timed region."""
+    from pandora_amd.engine import Engine
+
+    one = Engine(device)
+    L, R = synthetic_pair(H, W, dmin, dmax, seed=20260928 + rank)
+    one.set_images(L, R, 1)
+    cv = one.alloc_cv(dmax - dmin + 1, dmin)
+    run_pipeline(one, cv, win, P1, P2)
+    one.sync()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_pipeline(one, cv, win, P1, P2)
+    one.sync()
+    elapsed = float(comm.host_allreduce(np.array([time.perf_counter() - t0]), "max")[0])
+    comm.barrier()
+    cv.free()
+    one.close()
+    cells = H * W * (dmax - dmin + 1)
+    return {"workload": f"one {H}x{W}x{dmax - dmin + 1} pair PER RANK and step (Census5x5 + SGM + WTA + vfit), no exchange",
+            "scaling": "weak", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "value": round(world * cells / (elapsed / steps) / 1e6, 1), "unit": "Mdisp/s"}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: N ranks of this very command, one per device (LOCAL_RANK = device), a free
     rendezvous port at 127.0.0.1; rank 0's stdout (the JSON line) is passed through, a failing rank fails the run."""
@@ -358,6 +386,7 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the 2048x2048x129 leg (BASELINE configs[2])")
     ap.add_argument("--no-configs", action="store_true", help="skip the c4_as_stated / c5_as_stated / default_allocation legs (N=1)")
     ap.add_argument("--no-dshard", action="store_true", help="skip the exact D-sharded leg (N>1)")
+    ap.add_argument("--no-weak", action="store_true", help="skip the pair-per-rank (weak scaling) leg (N>1)")
     ap.add_argument("--test-comm", default=None, metavar="MODULE:CLASS",
                     help="TEST HOOK: a pandora_amd.comm.Comm subclass from tests/ (e.g. tests.transports:TcpComm) that carries the "
                          "exchange steps through the host, so that several ranks can share the one GPU of a test box")
@@ -439,6 +468,9 @@ def main():
     dshard = None
     if comm is not None and not args.no_dshard and D >= 2 * world:
         dshard = d_sharded_leg(eng, comm, L, R, dmin, dmax, 11, max(2, args.steps // 2), local_rank)
+    weak = None
+    if comm is not None and not args.no_weak:
+        weak = pair_per_rank_leg(comm, local_rank, H, W, dmin, dmax, win, P1, P2, max(2, args.steps // 2), rank, world)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -494,6 +526,8 @@ def main():
                 "coefficient_identical": round(float(np.mean((gi == oi) | (np.isnan(gi) & np.isnan(oi)))), 6)}
             if dshard is not None:
                 out["d_sharded_exact"] = dshard
+            if weak is not None:
+                out["pair_per_rank"] = weak
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
             pcie_s = pcie_inclusive_ms(eng, cv, L, R, win, P1, P2) * 1e-3

@@ -58,6 +58,8 @@ def test_bench_runs_one_pair_over_the_ranks(world, port, height, width):
     # the exact multi-GPU form rides along: costs sharded over D, one all-reduce(min) of packed keys - identical to one GPU
     assert d["d_sharded_exact"]["maps_identical_to_one_gpu"] == 1.0, d["d_sharded_exact"]
     assert d["collective"]["bytes_per_step"] == height * width * 10
+    # ... and the weak-scaling figure: one whole pair per rank and step, no exchange
+    assert d["pair_per_rank"]["scaling"] == "weak" and d["pair_per_rank"]["value"] > 0
     if width >= 2560:
         assert d["stage_ms_per_step"]["sgm_span"] > 0  # the family form ran in the tiles
     # what arrived on rank 0 is the pair's result: identical to one GPU doing the whole pair except near the tile seams (SGM paths
