@@ -328,7 +328,12 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
                                                        float4* __restrict__ near) {
     constexpr int PPW = 64 / GL;   // pixels per wavefront
     constexpr int M4 = KPL & ~3, NB = M4 / 4, T = KPL & 3;
-    constexpr int SROW = GL * KPL + 4;  // sums of one pixel in LDS (wave-private; +4: slot -1 and slot GL*KPL exist)
+    // sums of one pixel in LDS (wave-private), slots d = -1 .. GL*KPL.  A lane's KPL sums start KST = KPL | 1 words after its
+    // neighbour's and a pixel's row SROW = 16 (mod 32) words after the previous pixel's: with the natural strides (20 words per lane,
+    // 324 per pixel) the 64 lanes of a store hit each bank up to eight times (73 % of this kernel's LDS cycles were conflicts);
+    // now twice, the least 64 lanes on 32 banks can do
+    constexpr int KST = KPL | 1;
+    constexpr int SROW = ((GL * KST + 2 + 15) / 32) * 32 + 16;
     static_assert(T <= 1, "KPL must be 0 or 1 mod 4");
     __shared__ uint32_t sbuf[4][PPW][SROW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
         }
         // the sums go to LDS (wave-private row of the pixel) so that the winner's neighbours can be fetched by index
 #pragma unroll
-        for (int e = 0; e < KPL; ++e) srow[d_first + e] = s[e];
+        for (int e = 0; e < KPL; ++e) srow[sub * KST + e] = s[e];
         // ---- validity of the lane's cells (geometry only on this path): slot e is a number iff elo <= e < ehi
         const bool pix_ok = (r >= a.o) & (r < a.H - a.o) & (c >= a.o) & (c < a.W - a.o);
         const int us = c + a.d0 + d_first - a.o;  // right column of slot 0, relative to the first valid one
@@ -405,7 +410,8 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
                 const int q0 = c + a.d0 + kb - a.o;  // right column of the winner, relative
                 const bool v0 = a.range ? (kb - 1 >= rlo) : ((kb - 1 >= 0) & (q0 - 1 >= 0));
                 const bool v2 = a.range ? (kb + 1 < rhi) : ((kb + 1 < a.D) & (q0 + 1 < wvalid));
-                const uint32_t c0 = srow[kb - 1], c2 = srow[kb + 1];
+                const int k0 = kb - 1, k2 = kb + 1;  // slot of disparity d: (d / KPL) * KST + d % KPL (d = -1: the word before the row)
+                const uint32_t c0 = k0 < 0 ? 0u : srow[(k0 / KPL) * KST + k0 % KPL], c2 = srow[(k2 / KPL) * KST + k2 % KPL];
                 near[pix] = make_float4(v0 ? (float)c0 : g_nan(), (float)(key >> 16), v2 ? (float)c2 : g_nan(), __int_as_float(kb));
                 disp[pix] = (float)(d0 + (double)kb);
             }
