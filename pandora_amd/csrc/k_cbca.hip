@@ -989,6 +989,17 @@ __device__ __forceinline__ void lds_w32(uint32_t addr, uint32_t v) { *(uint32_t 
 __device__ __forceinline__ void lds_w8(uint32_t addr, uint32_t v) { *(uint8_t PMX_AS3*)(uintptr_t)addr = (uint8_t)v; }
 __device__ __forceinline__ void lds_w128(uint32_t addr, u32x4 v) { *(u32x4 PMX_AS3*)(uintptr_t)addr = v; }
 
+// a.lo * b.lo + a.hi * b.hi + c on 16-bit halves in ONE instruction (v_dot2_u32_u16 / v_dot2_i32_i16): a packed pair of arms
+// times two strides is an LDS address
+typedef unsigned short pmx_us2 __attribute__((ext_vector_type(2)));
+typedef short pmx_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(pmx_us2, a), __builtin_bit_cast(pmx_us2, b), c, false);
+}
+__device__ __forceinline__ int32_t sdot2(uint32_t a, uint32_t b, int32_t c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(pmx_s2, a), __builtin_bit_cast(pmx_s2, b), c, false);
+}
+
 // a / b for integers 0 <= a < 65536, 1 <= b <= 1024 as float32, correctly rounded: one Newton step on the hardware reciprocal's
 // quotient.  pmx_debug_small_division compares every pair with the IEEE division (tests/test_gpu_parity.py).
 __device__ __forceinline__ float small_int_div(float af, float bf) {
@@ -1127,6 +1138,7 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
     const uint32_t own_dst = cost_row + xc;
     const uint32_t rng_own = m.code_off + ((uint32_t)(CWL + CWR) + xc) * 16u;  // SRC 2: the valid intervals of this column's four rows
     const uint32_t tab_own = m.tab_off + (xc * 13u - 4u) * 16u;  // + (right - 12 * left) * 16
+    const uint32_t kTabStrides = ((0u - 192u) & 0xffffu) | (16u << 16);  // (left, right) . (-192, 16)
     // halo cells: 8 columns x D disparities shared out over the workgroup (a second one only where a wavefront has any)
     uint32_t h_l[2], h_r[2], h_dst[2], h_g[2], h_k[2];
 #pragma unroll
@@ -1222,8 +1234,7 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
             for (int i = 0; i < 2; ++i) {
                 const int j = 2 * h + i;
                 w[i] = lds_r128(crow + (uint32_t)j * rowb);
-                const int32_t sel = (int32_t)(lr[j] >> 16) - 12 * (int32_t)(lr[j] & 0xffffu);
-                mk[i] = lds_r128(tab_own + (uint32_t)(sel * 16));
+                mk[i] = lds_r128((uint32_t)sdot2(lr[j], kTabStrides, (int32_t)tab_own));  // tab_own + (right - 12 * left) * 16
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1239,11 +1250,15 @@ __global__ __launch_bounds__(1024, 8) void cbca_census_march_kernel(cbca_args a,
         }
         struct pair_hl { uint32_t hi, lo; };
         const int e0 = s0 >= 4 ? s0 - 4 : 8;  // slot of row r - 4
+        const uint32_t ring_bytes = (uint32_t)kMarchRing * RS4, neg_rs4 = (0u - RS4) & 0xffffu;  // (RS4 < 32768: a ring slot of at most 8 K cells)
         auto fetch = [&](uint32_t tbv, int j) {
-            uint32_t u = (uint32_t)(e0 + j) + (tbv >> 16), v = (uint32_t)(e0 + j + kMarchRing - 1) - (tbv & 0xffffu);
-            u = min(u, u - (uint32_t)kMarchRing);
-            v = min(v, v - (uint32_t)kMarchRing);
-            return pair_hl{lds_r32(__umul24(u, RS4) + own), lds_r32(__umul24(v, RS4) + own)};
+            // byte addresses: own + ((e0 + j + bot) mod 12) * RS4 and own + ((e0 + j - 1 - top) mod 12) * RS4 - one dot product of the
+            // packed (top, bottom) with (0, RS4) / (-RS4, 0) each, then the wrap (x - 12 RS4 is huge when x did not reach it)
+            const uint32_t b0 = (uint32_t)(e0 + j) * RS4 + own;
+            uint32_t u = udot2(tbv, RS4 << 16, b0), v = (uint32_t)sdot2(tbv, neg_rs4, (int32_t)(b0 + (uint32_t)(kMarchRing - 1) * RS4));
+            u = min(u, u - ring_bytes);
+            v = min(v, v - ring_bytes);
+            return pair_hl{lds_r32(u), lds_r32(v)};
         };
         const uint32_t ring_w = (uint32_t)s0 * RS4 + own;
         lds_w32(ring_w, ent[0]);
