@@ -11,6 +11,10 @@
 // segment sum needs (at most cbca_distance-1 ahead / behind) live in a per-thread LDS ring.
 //
 // Kernels (pmx_launch_cbca picks; DESIGN.md section 3 has the measurements behind each choice):
+//   census source, arms of at most 4 (cbca_distance <= 5), 11 <= D <= 256:
+//           cbca_census_march_kernel   costs, horizontal sums, vertical scan and the division in ONE marching launch on exact integer
+//                                sums (every census sum is an integer below 2^24: float32 order does not matter); no E_h volume
+//   everything else (float costs, longer arms), two passes over the volume:
 //   pass H  cbca_h_rows_kernel   a workgroup owns whole image rows and stores E_h through an LDS stage (16 bytes per lane);
 //                                SRC 1-3: the census Hamming costs are computed in the kernel, the cost volume never exists
 //           cbca_h_fast_kernel   phase-split scan, 4 bytes per lane (short scans, PMX_CBCA_FAST=2)
