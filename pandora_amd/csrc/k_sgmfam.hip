@@ -44,6 +44,19 @@ __device__ __forceinline__ float f_inf() { return __int_as_float(0x7f800000); }
 __device__ __forceinline__ bool is_nan_bits(float v) { return (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u; }
 __device__ __forceinline__ float fmin2(float a, float b) { return __builtin_fminf(a, b); }
 
+// minimum of a value with the same lane of the pixel's OTHER row of 16 lanes (32 lanes per pixel): gfx950's v_permlane16_swap
+// exchanges the odd rows of one register with the even rows of another - given the value twice it leaves (row 0, row 0, row 2,
+// row 2) and (row 1, row 1, row 3, row 3), whose minimum is the pair's in both rows.  One vector instruction where ds_swizzle was a
+// round trip through the LDS pipe inside the row-synchronous chain.
+__device__ __forceinline__ float min_other_row(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __builtin_fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ unsigned umin_other_row(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return r[0] < r[1] ? r[0] : r[1];
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp(float src) {  // lanes without a source lane read 0
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), CTRL, 0xf, 0xf, true));
@@ -85,10 +98,10 @@ __device__ __forceinline__ void group_min3(float& a, float& b, float& c) {
     a = fmin2(a, dpp<0x122>(a)); b = fmin2(b, dpp<0x122>(b)); c = fmin2(c, dpp<0x122>(c));  // row_ror:2
     a = fmin2(a, dpp<0x124>(a)); b = fmin2(b, dpp<0x124>(b)); c = fmin2(c, dpp<0x124>(c));  // row_ror:4
     a = fmin2(a, dpp<0x128>(a)); b = fmin2(b, dpp<0x128>(b)); c = fmin2(c, dpp<0x128>(c));  // row_ror:8: the 16-lane row is done
-    if (GL == 32) {  // the pixel's other row: lane ^ 16 (ds_swizzle bit mode, no LDS storage involved)
-        a = fmin2(a, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a), 0x401f)));
-        b = fmin2(b, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(b), 0x401f)));
-        c = fmin2(c, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(c), 0x401f)));
+    if (GL == 32) {  // the pixel's other row: lane ^ 16
+        a = min_other_row(a);
+        b = min_other_row(b);
+        c = min_other_row(c);
     }
 }
 
@@ -452,7 +465,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             vmin = fmin2(vmin, dpp<0x122>(vmin));
             vmin = fmin2(vmin, dpp<0x124>(vmin));
             vmin = fmin2(vmin, dpp<0x128>(vmin));
-            if (GL == 32) vmin = fmin2(vmin, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(vmin), 0x401f)));
+            if (GL == 32) vmin = min_other_row(vmin);
             unsigned klo = 0xffffffffu;
 #pragma unroll
             for (int k = KPL - 1; k >= 0; --k) klo = (vv[k] == vmin) ? (unsigned)(d0 + k) : klo;
@@ -461,7 +474,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x122, 0xf, 0xf, true));
             umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x124, 0xf, 0xf, true));
             umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x128, 0xf, 0xf, true));
-            if (GL == 32) umin_dpp((unsigned)__builtin_amdgcn_ds_swizzle((int)klo, 0x401f));
+            if (GL == 32) klo = umin_other_row(klo);
             const unsigned anyb = vmin != f_inf() ? 1u : 0u;  // some cost of the pixel is a number (sums of finite costs are finite)
             const int kw = (int)klo;            // the winner, the same in every lane of the pixel
             const int li = kw / KPL, kk = kw - li * KPL;
