@@ -649,7 +649,14 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
     __shared__ double rstat[kZnccWaves][2][64 + ND];  // [wave][mean|isd][column]
     __shared__ __attribute__((aligned(16))) float ostage[2][64][kZnccOutStride];
 
-    const uint32_t logical = blockIdx.x;
+    // Workgroup -> (tile, strip, disparity block), XCD-aware: the disparity blocks of one (tile, strip) write the SAME cache lines of
+    // the volume (a block's 128 bytes per pixel start at 4-byte alignment: every line of a pixel is shared by two blocks), and the
+    // hardware deals workgroups to the eight XCDs round robin.  Workgroups 8 apart sit on one XCD: the ndblock blocks of a group take
+    // indices x, x + 8, x + 16 .. so that the two halves of a line meet in ONE L2 instead of leaving two of them as partial lines.
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+    const uint32_t group = (seq / (uint32_t)q.ndblock) * 8u + xcd;  // (tile, strip) pair
+    if (group >= (uint32_t)(q.ntile * q.nstrip)) return;            // (the grid is rounded up to whole rounds of eight groups)
+    const uint32_t logical = group * (uint32_t)q.ndblock + seq % (uint32_t)q.ndblock;
     const int dblock = logical % q.ndblock;
     const int tile = (logical / q.ndblock) % q.ntile;
     const int strip = logical / (q.ndblock * q.ntile);
@@ -923,7 +930,7 @@ int pmx_launch_zncc(pmx_ctx* ctx, pmx_cv* cv, int win) {
         q.nstrip = (H + q.strip_rows - 1) / q.strip_rows;
         q.img_bytes = (uint32_t)((size_t)H * W * 4);
         q.stat_bytes = (uint32_t)per;
-        const uint32_t grid = (uint32_t)q.ntile * q.ndblock * q.nstrip;
+        const uint32_t grid = (((uint32_t)q.ntile * q.nstrip + 7u) / 8u) * 8u * (uint32_t)q.ndblock;
         const dim3 block(64 * kZnccWaves);
 #define PMX_ZNCC_LAUNCH(WN)                                                                                                  \
     if (cv->subpix == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(zncc_march_kernel<WN, 1>), dim3(grid), block, 0, ctx->stream, q);     \
