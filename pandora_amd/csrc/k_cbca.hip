@@ -1023,12 +1023,15 @@ __global__ __launch_bounds__(256) void small_division_check_kernel(unsigned* __r
 
 int pmx_launch_small_division_check(pmx_ctx* ctx, unsigned* host_count) {
     unsigned* dev = nullptr;
-    PMX_HIP(hipMalloc((void**)&dev, sizeof(unsigned)));
-    PMX_HIP(hipMemsetAsync(dev, 0, sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(small_division_check_kernel, dim3((1024u << 16) / 256u), dim3(256), 0, ctx->stream, dev);
-    hipError_t e = hipMemcpyAsync(host_count, dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+    PMX_HIP(pmx_pool_alloc(ctx, (void**)&dev, sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(unsigned), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(small_division_check_kernel, dim3((1024u << 16) / 256u), dim3(256), 0, ctx->stream, dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host_count, dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dev);
+    pmx_pool_free(ctx, dev);  // (on every path)
     PMX_HIP(e);
     return PMX_OK;
 }
