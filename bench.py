@@ -23,7 +23,7 @@ Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the 8-path 
 inside the timed region), `cpu_baseline` (the C oracle, kind "port", 1 thread, on a bounded row strip of the same pair),
 `cpu_baseline_all_cores` (same strip, OpenMP), `cpu_baseline_reference_compiled` (the reference's OWN census C++, oracle/_ref,
 census stage only) and, at N=1, `c3_shape` (BASELINE configs[2], 2048x2048x129, the round-1 headline, same protocol),
-`c4_as_stated` (configs[3] as BASELINE words it: ZNCC 11x11 + SGM + WTA + vfit, 4096x4096x257, float32 kernels) and `c5_as_stated`
+`c2_cones` (configs[1]: census + CBCA + SGM on the reference's cones pair), `c4_as_stated` (configs[3] as BASELINE words it: ZNCC 11x11 + SGM + WTA + vfit, 4096x4096x257, float32 kernels) and `c5_as_stated`
 (configs[4]'s fine scale on one GPU: census + CBCA + SGM + WTA + vfit, 10000x10000x129, float32 kernels), each with its own roofline
 block (its dominant kernel family), and `default_allocation` (the headline step with plain hipMalloc placement, --placement-trials 1).
 """
@@ -561,6 +561,17 @@ def main():
                 out["c4_as_stated"] = config_leg(eng, L, R, dmin, dmax, ("zncc", 11), False, 3,
                                                  "BASELINE configs[3] as stated: 4096x4096 synthetic pair, d=[0,256] (D=257), ZNCC 11x11 + SGM 8-path "
                                                  "+ WTA + vfit, float32 cost volume between the steps; one GPU")
+                # BASELINE configs[1] on the reference's own cones pair (tests/golden/cones: data, not code): census + CBCA + SGM + WTA +
+                # vfit, d = [-60, 0] as data_samples/json_conf_files/a_semi_global_matching.json has it for this pair
+                cones_dir = os.path.join(ROOT, "tests", "golden", "cones")
+                if os.path.exists(os.path.join(cones_dir, "left.png")):
+                    from PIL import Image
+
+                    Lc = np.array(Image.open(os.path.join(cones_dir, "left.png"))).astype(np.float32)
+                    Rc = np.array(Image.open(os.path.join(cones_dir, "right.png"))).astype(np.float32)
+                    out["c2_cones"] = config_leg(eng, Lc, Rc, -60, 0, ("census", 5), True, 20,
+                                                 "BASELINE configs[1]: the cones pair (375x450), d=[-60,0] (D=61), Census 5x5 + CBCA + SGM 8-path "
+                                                 "+ WTA + vfit; one GPU (a launch-latency-sized problem: 10.3 M cells)")
                 L5, R5 = synthetic_pair(10000, 10000, -64, 64)
                 out["c5_as_stated"] = config_leg(eng, L5, R5, -64, 64, ("census", 5), True, 2,
                                                  "BASELINE configs[4], fine scale, as stated: 10000x10000 synthetic pair, d=[-64,64] (D=129), "
