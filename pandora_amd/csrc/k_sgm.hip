@@ -131,14 +131,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
     const unsigned row_bytes = (unsigned)a.W * (unsigned)D * 4u, pix_bytes = (unsigned)D * 4u;
     const unsigned lane_load = (unsigned)(nv ? d_first : 0) * 4u;  // lanes without a disparity read the pixel's d = 0
     const unsigned lane_store = nv ? (unsigned)d_first * 4u : kOob;
-    auto row_rsrc = [&](const float* vol, int r) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(vol + (size_t)r * a.W * D), 0, row_bytes, kRsrcWord3);
-    };
+    // (row pointers advance with the cursors: a descriptor from `vol + r * W * D` at every step was twenty scalar instructions per
+    //  memory instruction, and on small volumes - a few wavefronts per SIMD, every one a chain of dependent steps - the kernel is
+    //  bound by its instruction count: cones, eight directions side by side, 0.29 ms of the 0.52 of BASELINE configs[1])
+    auto rsrc_of = [&](const float* row) { return __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, row_bytes, kRsrcWord3); };
+    const ptrdiff_t row_step = (ptrdiff_t)a.dr * (ptrdiff_t)a.W * (ptrdiff_t)D;  // floats from a line's pixel to its next one's row
 
     // cursor of the pixel being computed and of the pixel being prefetched (wave-uniform)
     int r = horizontal ? line : (a.dr > 0 ? 0 : a.H - 1);
     int c = horizontal ? (a.dc > 0 ? 0 : a.W - 1) : line;
     int pr = r, pc = c;
+    const float* c_pre = a.C + (size_t)r * a.W * D;  // rows of the prefetch cursor ...
+    const float* s_pre = a.S + (size_t)r * a.W * D;
+    float* s_row = a.S + (size_t)r * a.W * D;        // ... and of the pixel being computed
 
     float cbuf[kPF][KPL], sbuf[kPF][KPL];
     float p2buf[kPF];  // the pixel's P2 when it varies (rides in the same ring as its costs)
@@ -146,13 +151,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
     int pleft = nsteps - 1;  // steps the prefetch cursor may still advance (read-ahead past the end re-reads the last pixel)
     auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL], float& p2slot) {
         const unsigned off = (unsigned)pc * pix_bytes + lane_load;
-        buf_load<KPL>(row_rsrc(a.C, pr), off, cslot);
-        if (MODE & SGM_READS_S) buf_load<KPL>(row_rsrc(a.S, pr), off, sslot);
+        buf_load<KPL>(rsrc_of(c_pre), off, cslot);
+        if (MODE & SGM_READS_S) buf_load<KPL>(rsrc_of(s_pre), off, sslot);
         if (var_p2) p2slot = a.p2map[(size_t)pr * a.W + pc];
         if (pleft > 0) {
             --pleft;
             pr += a.dr;
             pc += a.dc;
+            c_pre += row_step;
+            s_pre += row_step;
             if (!horizontal) { if (pc >= a.W) pc = 0; else if (pc < 0) pc = a.W - 1; }
         }
     };
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
             }
             out[k] = s;
         }
-        buf_store<KPL>(row_rsrc(a.S, r), (unsigned)c * pix_bytes + lane_store, nv, is_tail, cov, rem, out);
+        buf_store<KPL>(rsrc_of(s_row), (unsigned)c * pix_bytes + lane_store, nv, is_tail, cov, rem, out);
         // refill this ring slot with pixel i + kPF.  Issued AFTER the slot's last use so the new data
         // lands in the same registers (no copy, hence no wait, at the loop back-edge).
         prefetch(cslot, sslot, p2slot);
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         // restarts there (border initialisation)
         r += a.dr;
         c += a.dc;
+        s_row += row_step;
         if (!horizontal && (c >= a.W || c < 0)) {
             c = (c >= a.W) ? 0 : a.W - 1;
 #pragma unroll
