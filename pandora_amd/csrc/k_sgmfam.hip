@@ -180,6 +180,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 
     if (wave == NW) {
         // ---- hand-off wave: brings the left neighbour's columns CW-2, CW-1 of row t into column slots -2, -1 ----
+        // (every row's barrier waits for this wavefront: it goes first on its SIMD - A/B on one box at 4096^2 x 257: 14.2-14.4 ms per
+        //  family against 15.0-15.2; 10000^2 x 129: no difference)
+        __builtin_amdgcn_s_setprio(3);
         int ldsoff[NQ];
         int nreal[NQ];  // how many of the block's two values exist (0: padding block)
 #pragma unroll
