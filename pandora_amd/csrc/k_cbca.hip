@@ -134,8 +134,72 @@ __global__ __launch_bounds__(kBlock) void cross_support_kernel(const float* __re
     *reinterpret_cast<short4*>(cross + ((size_t)row * pitch + col + xoff) * 4) = v;
 }
 
+// The same arms without a data-dependent loop, for arms shorter than LM (the default cbca_distance is 5): the 4 x (len - 1)
+// neighbours are loaded at once (clamped addresses, one memory latency instead of one per step), every comparison leaves a bit,
+// and an arm is the number of consecutive set bits from the pixel outwards.  PACKED: the arms leave as one word per pixel
+// (left | right << 8 | top << 16 | bottom << 24) in the padded rows the whole-row and marching kernels read, else as short4.
+template <int LM, bool PACKED>
+__global__ __launch_bounds__(kBlock) void cross_support_flat_kernel(const float* __restrict__ img, int Wd, int o, int Hc, int Wc,
+                                                                    int len_arms, float intensity, void* __restrict__ out, int pitch,
+                                                                    int xoff) {
+    // (PACKED: the grid spans the padded row, the pads are zero arms)
+    const int col = blockIdx.x * kBlock + threadIdx.x - (PACKED ? xoff : 0);
+    const int row = blockIdx.y;
+    if (PACKED) {
+        if (col + xoff >= pitch) return;
+        if (col < 0 || col >= Wc) {
+            reinterpret_cast<uint32_t*>(out)[(size_t)row * pitch + col + xoff] = 0u;
+            return;
+        }
+    } else if (col >= Wc) return;
+    const float* base = img + (size_t)o * Wd + o;
+    const float* prow = base + (size_t)row * Wd;
+    const float cur = prow[col];
+    unsigned ml = 0, mr = 0, mu = 0, md = 0;
+    bool nl = false, nr = false, nu = false, nd = false;  // the neighbour exists and is finite: an arm of at least 1
+#pragma unroll
+    for (int k = 1; k < LM; ++k) {
+        const float vl = prow[max(col - k, 0)];
+        const float vr = prow[min(col + k, Wc - 1)];
+        const float vu = base[(size_t)max(row - k, 0) * Wd + col];
+        const float vd = base[(size_t)min(row + k, Hc - 1) * Wd + col];
+        const bool use = k < len_arms;
+        const bool il = col - k >= 0, ir = col + k < Wc, iu = row - k >= 0, id = row + k < Hc;
+        ml |= (use && il && !(fabsf(cur - vl) >= intensity)) ? 1u << (k - 1) : 0u;
+        mr |= (use && ir && !(fabsf(cur - vr) >= intensity)) ? 1u << (k - 1) : 0u;
+        mu |= (use && iu && !(fabsf(cur - vu) >= intensity)) ? 1u << (k - 1) : 0u;
+        md |= (use && id && !(fabsf(cur - vd) >= intensity)) ? 1u << (k - 1) : 0u;
+        if (k == 1) {
+            nl = il && isfinite(vl);
+            nr = ir && isfinite(vr);
+            nu = iu && isfinite(vu);
+            nd = id && isfinite(vd);
+        }
+    }
+    int l = 0, rt = 0, up = 0, dn = 0;
+    if (isfinite(cur)) {
+        l = max(__builtin_ctz(~ml), (int)nl);
+        rt = max(__builtin_ctz(~mr), (int)nr);
+        up = max(__builtin_ctz(~mu), (int)nu);
+        dn = max(__builtin_ctz(~md), (int)nd);
+    }
+    if (PACKED)
+        reinterpret_cast<uint32_t*>(out)[(size_t)row * pitch + col + xoff] = (uint32_t)l | ((uint32_t)rt << 8) | ((uint32_t)up << 16) | ((uint32_t)dn << 24);
+    else
+        *reinterpret_cast<short4*>(reinterpret_cast<int16_t*>(out) + ((size_t)row * pitch + col + xoff) * 4) = make_short4((short)l, (short)rt, (short)up, (short)dn);
+}
+
+__global__ void pack_arms_kernel(const int16_t* __restrict__ arms, int Hc, int Wsrc, uint32_t* __restrict__ rows, int pitch, int xoff);
+
+static bool arms_flat(int distance) {
+    const char* ef = getenv("PMX_CBCA_ARMS_FLAT");  // =0: the loop form (A/B and test hook)
+    return !(ef && ef[0] == '0') && distance >= 1 && distance <= 18;
+}
+
 // builds the arms of image `side` (0 = left, k+1 = k-th shifted right) into dev_out; tmp = 2 images
-static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int distance, float* tmp, int16_t* dev_out, int pad = 0) {
+// (packed != nullptr: also one word per pixel into rows of `ppitch` words, pixel 0 at word `pxoff`; !want16: only those)
+static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int distance, float* tmp, int16_t* dev_out, int pad = 0,
+                      uint32_t* packed = nullptr, int ppitch = 0, int pxoff = 0, bool want16 = true) {
     const int H = ctx->H, W = ctx->W;
     const float* img = side == 0 ? ctx->left : ctx->right[side - 1];
     const int16_t* msk = side == 0 ? ctx->msk_left : ctx->msk_right;
@@ -149,8 +213,25 @@ static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int d
     int Hc = H - 2 * offset, Wc = Wd - 2 * offset;
     if (Hc <= 0 || Wc <= 0) return PMX_OK;
     dim3 g2((Wc + kBlock - 1) / kBlock, Hc);
-    hipLaunchKernelGGL(cross_support_kernel, g2, dim3(kBlock), 0, ctx->stream, med, Wd, offset, Hc, Wc, distance, intensity, dev_out,
-                       Wc + 2 * pad, pad);
+    const bool flat = arms_flat(distance);
+#define PMX_FLAT(LMV)                                                                                                                  \
+    do {                                                                                                                               \
+        if (packed && !want16)                                                                                                         \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_support_flat_kernel<LMV, true>), dim3((ppitch + kBlock - 1) / kBlock, Hc), dim3(kBlock), 0, ctx->stream, med, Wd, offset, Hc, \
+                               Wc, distance, intensity, (void*)packed, ppitch, pxoff);                                                 \
+        else                                                                                                                           \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(cross_support_flat_kernel<LMV, false>), g2, dim3(kBlock), 0, ctx->stream, med, Wd, offset, Hc, \
+                               Wc, distance, intensity, (void*)dev_out, Wc + 2 * pad, pad);                                            \
+    } while (0)
+    if (flat && distance <= 6) PMX_FLAT(6);
+    else if (flat && distance <= 10) PMX_FLAT(10);
+    else if (flat) PMX_FLAT(18);
+    else
+        hipLaunchKernelGGL(cross_support_kernel, g2, dim3(kBlock), 0, ctx->stream, med, Wd, offset, Hc, Wc, distance, intensity, dev_out,
+                           Wc + 2 * pad, pad);
+    if (packed && (want16 || !flat))
+        hipLaunchKernelGGL(pack_arms_kernel, dim3((Wc + 255) / 256, Hc), dim3(256), 0, ctx->stream, dev_out, Hc, Wc, packed, ppitch, pxoff);
+#undef PMX_FLAT
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
@@ -1728,17 +1809,19 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     a.offCL = cv->codeL ? (unsigned)(cv->codeL - cv->codes) : 0u; a.offCR = cv->codeR ? (unsigned)(cv->codeR - cv->codes) : 0u;
     a.range = (census_src && cv->has_range) ? cv->range : nullptr;
     a.cb = cv->win / 2;
-    auto pack = [&](const int16_t* src, int Wsrc, const uint32_t* rows, int pitch, int xoff) {
-        hipLaunchKernelGGL(pack_arms_kernel, dim3((Wsrc + 255) / 256, Hc), dim3(256), 0, ctx->stream, src, Hc, Wsrc, (uint32_t*)rows, pitch, xoff);
-    };
+    // pass V through buffers (the choice is made here because it decides which form of the arms is needed)
+    // (worth it when there are more wavefronts than the pointer kernel's 3 per SIMD can hold: 2048^2 x 129 has 4 per SIMD and
+    // runs 1.71 against 1.82 ms with pointers, 10000^2 x 129 has 20 and runs 31 against 35 ms with buffers)
+    const char* ev = getenv("PMX_CBCA_VBUF");  // 0: the phase-split kernel with pointers (test hook)
+    const bool vbuf = rows_ok && (ev ? ev[0] != '0' : (size_t)Wc * cv->D >= (size_t)6144 * 64);
+    const bool want16 = !(march || vbuf);  // the short4 arms: only the kernels that read them through pointers
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_ARMS);
-        rc = build_arms(ctx, 0, o, intensity, distance, tmp, (int16_t*)a.armsL);
+        // the pads are zero arms (the branch-free kernel writes them itself when it writes the packed rows)
+        if (rows_ok && (want16 || !arms_flat(distance))) PMX_HIP(hipMemsetAsync(wbase, 0, wide_bytes, ctx->stream));
+        rc = rows_ok ? build_arms(ctx, 0, o, intensity, distance, tmp, (int16_t*)a.armsL, 0, (uint32_t*)a.armsL8, pitchL, 0, want16)
+                     : build_arms(ctx, 0, o, intensity, distance, tmp, (int16_t*)a.armsL);
         if (rc) return rc;
-        if (rows_ok) {
-            PMX_HIP(hipMemsetAsync(wbase, 0, wide_bytes, ctx->stream));  // the pads are zero arms
-            pack(a.armsL, Wc, a.armsL8, pitchL, 0);
-        }
         if (four) {
             PMX_HIP(hipMemsetAsync(padded, 0, pad_bytes, ctx->stream));
             rc = build_arms(ctx, 1, o, intensity, distance, tmp, padded, 4);
@@ -1747,9 +1830,9 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
             for (int k = 0; k < cv->subpix; ++k) {
                 int16_t* dst = (int16_t*)(base + 2 * img_bytes + arm_bytes * (1 + k));
                 a.armsR[k] = dst;
-                rc = build_arms(ctx, k + 1, o, intensity, distance, tmp, dst);
+                rc = rows_ok ? build_arms(ctx, k + 1, o, intensity, distance, tmp, dst, 0, (uint32_t*)a.armsR8 + (size_t)k * a.phase_words, pitchR, padR, want16)
+                             : build_arms(ctx, k + 1, o, intensity, distance, tmp, dst);
                 if (rc) return rc;
-                if (rows_ok) pack(dst, k == 0 ? Wc : Wc - 1, a.armsR8 + (size_t)k * a.phase_words, pitchR, padR);
             }
         }
     }
@@ -1824,10 +1907,6 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
         int total = Wc * cv->D;
-        const char* ev = getenv("PMX_CBCA_VBUF");  // 0: the phase-split kernel with pointers (test hook)
-        // (worth it when there are more wavefronts than the pointer kernel's 3 per SIMD can hold: 2048^2 x 129 has 4 per SIMD and
-        // runs 1.71 against 1.82 ms with pointers, 10000^2 x 129 has 20 and runs 31 against 35 ms with buffers)
-        const bool vbuf = rows_ok && (ev ? ev[0] != '0' : (size_t)total >= (size_t)6144 * 64);
         // workgroups of 512 threads read 2 KB contiguous per row: a little kinder to the DRAM pages when the workgroups of a launch
         // have drifted rows apart (10000^2 x 129: 32.3 against 35.1 ms; at 2048^2 x 129 the coarser grid costs more than it gains)
         a.dbg = getenv("PMX_CBCA_DBG") ? atoi(getenv("PMX_CBCA_DBG")) : 0;

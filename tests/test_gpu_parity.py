@@ -267,6 +267,39 @@ def test_cbca(eng, oracle, H, W, dmin, dmax, sp, win, method, integer):
     eng.set_masks(None, None)
 
 
+@pytest.mark.parametrize("distance", [1, 2, 3, 5, 6, 7, 10, 11, 17, 18, 19, 26])
+@pytest.mark.parametrize("loop_form", [False, True])
+def test_cross_support_arm_lengths_both_forms(eng, oracle, monkeypatch, distance, loop_form):
+    """aggregation.cpp:224-321: arms by the branch-free kernel (distance <= 18) and by the loop kernel, smooth images so that the
+    arms reach their limit, masked pixels, +-inf and huge values among the neighbours, every border."""
+    if loop_form:
+        monkeypatch.setenv("PMX_CBCA_ARMS_FLAT", "0")
+    rng = np.random.default_rng(distance)
+    H, W = 37, 300
+    yy, xx = np.mgrid[0:H, 0:W]
+    L = (40 * np.sin(xx / 9.0) + 30 * np.cos(yy / 5.0) + rng.normal(0, 4, (H, W))).astype(np.float32)
+    R = np.roll(L, 3, axis=1) + rng.normal(0, 2, (H, W)).astype(np.float32)
+    L[5, 7] = np.inf; L[9, 200] = -np.inf; L[20, 20] = 3e38; L[21, 20] = -3e38; L[0, 0] = np.nan; L[H - 1, W - 1] = np.nan
+    L[12:15, 100:130] = 7.0  # a constant patch: arms limited by the distance only
+    mL = (rng.random((H, W)) < 0.03).astype(np.int16)
+    mR = (rng.random((H, W)) < 0.03).astype(np.int16)
+    for off in (0, 2):
+        eng.set_images(L, R, 2)
+        eng.set_masks(mL, mR, 0, 1)
+        for side, (im, msk, shifted) in enumerate([(L, mL, False), (R, mR, False), (oracle.shift_right(R, 2)[1], mR, True)]):
+            m = im.copy()
+            bad = msk != 0
+            if shifted:
+                bad = bad[:, :-1] | bad[:, 1:]
+            m[bad] = np.nan
+            m = np.nan_to_num(oracle.median3(m), nan=np.inf)
+            if off:
+                m = m[off:-off, off:-off]
+            exp = oracle.cross_support(np.ascontiguousarray(m), distance, 12.5)
+            np.testing.assert_array_equal(eng.cross_support(side, off, 12.5, distance), exp)
+    eng.set_masks(None, None)
+
+
 def test_cbca_reference_known_answer(eng):
     c = ka.CBCA
     cv = gpu_cv(eng, "sad", np.array(c["left"], np.float32), np.array(c["right"], np.float32), -1, 1, 1, 1)
