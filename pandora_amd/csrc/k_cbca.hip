@@ -84,18 +84,28 @@ __global__ __launch_bounds__(kBlock) void median3_inf_kernel(const float* __rest
                 n += num ? 1 : 0;
                 v[(i + 1) * 3 + j + 1] = num ? x : c_inf();
             }
-        // 9-input sorting network (25 compare-exchanges)
-        cb_cswap(v[0], v[1]); cb_cswap(v[3], v[4]); cb_cswap(v[6], v[7]);
-        cb_cswap(v[1], v[2]); cb_cswap(v[4], v[5]); cb_cswap(v[7], v[8]);
-        cb_cswap(v[0], v[1]); cb_cswap(v[3], v[4]); cb_cswap(v[6], v[7]);
-        cb_cswap(v[0], v[3]); cb_cswap(v[3], v[6]); cb_cswap(v[0], v[3]);
-        cb_cswap(v[1], v[4]); cb_cswap(v[4], v[7]); cb_cswap(v[1], v[4]);
-        cb_cswap(v[2], v[5]); cb_cswap(v[5], v[8]); cb_cswap(v[2], v[5]);
-        cb_cswap(v[1], v[3]); cb_cswap(v[5], v[7]);
-        cb_cswap(v[2], v[6]); cb_cswap(v[4], v[6]); cb_cswap(v[2], v[4]);
-        cb_cswap(v[2], v[3]); cb_cswap(v[5], v[6]);
-        const float hi = cb_pick9(v, n / 2);
-        res = (n & 1) ? hi : (cb_pick9(v, n / 2 - 1) + hi) / 2.0f;
+        if (n == 9) {
+            // nine numbers (no NaN among the operands): sort the three columns (min3 / med3 / max3); the median of all nine is the
+            // median of (largest of the minima, median of the medians, smallest of the maxima) - 13 instructions
+            const float lo = fmaxf(fmaxf(fminf(fminf(v[0], v[3]), v[6]), fminf(fminf(v[1], v[4]), v[7])), fminf(fminf(v[2], v[5]), v[8]));
+            const float hi = fminf(fminf(fmaxf(fmaxf(v[0], v[3]), v[6]), fmaxf(fmaxf(v[1], v[4]), v[7])), fmaxf(fmaxf(v[2], v[5]), v[8]));
+            const float mid = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(v[0], v[3], v[6]), __builtin_amdgcn_fmed3f(v[1], v[4], v[7]),
+                                                      __builtin_amdgcn_fmed3f(v[2], v[5], v[8]));
+            res = __builtin_amdgcn_fmed3f(lo, mid, hi);
+        } else {
+            // 9-input sorting network (25 compare-exchanges)
+            cb_cswap(v[0], v[1]); cb_cswap(v[3], v[4]); cb_cswap(v[6], v[7]);
+            cb_cswap(v[1], v[2]); cb_cswap(v[4], v[5]); cb_cswap(v[7], v[8]);
+            cb_cswap(v[0], v[1]); cb_cswap(v[3], v[4]); cb_cswap(v[6], v[7]);
+            cb_cswap(v[0], v[3]); cb_cswap(v[3], v[6]); cb_cswap(v[0], v[3]);
+            cb_cswap(v[1], v[4]); cb_cswap(v[4], v[7]); cb_cswap(v[1], v[4]);
+            cb_cswap(v[2], v[5]); cb_cswap(v[5], v[8]); cb_cswap(v[2], v[5]);
+            cb_cswap(v[1], v[3]); cb_cswap(v[5], v[7]);
+            cb_cswap(v[2], v[6]); cb_cswap(v[4], v[6]); cb_cswap(v[2], v[4]);
+            cb_cswap(v[2], v[3]); cb_cswap(v[5], v[6]);
+            const float hi = cb_pick9(v, n / 2);
+            res = (n & 1) ? hi : (cb_pick9(v, n / 2 - 1) + hi) / 2.0f;
+        }
     }
     // np.nan_to_num(nan=inf): NaN -> +inf, +inf -> FLT_MAX, -inf -> -FLT_MAX
     if (res != res) res = c_inf();
