@@ -130,38 +130,58 @@ static pmx_mc_params make_params(pmx_ctx* ctx, const pmx_cv* cv, int win) {
 // census.cpp:45-95: bit = (window pixel > centre), strict.  Only the Hamming distance of two codes
 // is ever used, so any fixed bit order is equivalent to the reference's MSB-first bytes; codes are
 // packed little-end first into NW = ceil(w*w/32) uint32 words.  Border pixels get code 0.
+// A workgroup takes a 64 x 16 tile (+ the window's border) through LDS, a thread four rows of one column: a window column is read
+// once for the four windows it is part of (WIN x (WIN + 3) LDS reads for four codes instead of 4 x WIN x WIN).
+static constexpr int kCtRows = 4;                              // output rows per thread
+static constexpr int kCtTileY = (kBlock / 64) * kCtRows;       // 16
 template <int WIN>
 __global__ __launch_bounds__(kBlock) void census_transform_kernel(const float* __restrict__ img, int H, int Wd,
                                                                   uint32_t* __restrict__ codes) {
     constexpr int O = WIN / 2;
     constexpr int NW = (WIN * WIN + 31) / 32;
-    constexpr int TX = 64, TY = kBlock / TX;  // 64 x 4 pixel tile per block
-    __shared__ float tile[TY + 2 * O][TX + 2 * O + 1];
-    int c0 = blockIdx.x * TX, r0 = blockIdx.y * TY;
-    for (int i = threadIdx.x; i < (TY + 2 * O) * (TX + 2 * O); i += kBlock) {
-        int ty = i / (TX + 2 * O), tx = i - ty * (TX + 2 * O);
-        int r = r0 + ty - O, c = c0 + tx - O;
+    constexpr int TX = 64, TY = kCtTileY;
+    constexpr int LW = TX + 2 * O, LH = TY + 2 * O;
+    __shared__ float tile[LH][LW + 1];
+    const int c0 = blockIdx.x * TX, r0 = blockIdx.y * TY;
+    for (int i = threadIdx.x; i < LH * LW; i += kBlock) {
+        const int ty = i / LW, tx = i - ty * LW;
+        const int r = r0 + ty - O, c = c0 + tx - O;
         tile[ty][tx] = (r >= 0 && r < H && c >= 0 && c < Wd) ? img[(size_t)r * Wd + c] : 0.f;
     }
     __syncthreads();
-    int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    int r = r0 + ty, c = c0 + tx;
-    if (r >= H || c >= Wd) return;
-    uint32_t w[NW];
+    const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) * kCtRows;
+    const int c = c0 + tx;
+    if (c >= Wd) return;
+    uint32_t w[kCtRows][NW];
+    float ctr[kCtRows];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) w[i] = 0u;
-    if (r >= O && r < H - O && c >= O && c < Wd - O) {
-        float ctr = tile[ty + O][tx + O];
+    for (int y = 0; y < kCtRows; ++y) {
+        ctr[y] = tile[ty + y + O][tx + O];
 #pragma unroll
-        for (int i = 0; i < WIN; ++i)
-#pragma unroll
-            for (int j = 0; j < WIN; ++j) {
-                int b = i * WIN + j;
-                if (tile[ty + i][tx + j] > ctr) w[b >> 5] |= (1u << (b & 31));
-            }
+        for (int i = 0; i < NW; ++i) w[y][i] = 0u;
     }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) codes[((size_t)r * Wd + c) * NW + i] = w[i];
+    for (int j = 0; j < WIN; ++j) {
+        float col[kCtRows + WIN - 1];
+#pragma unroll
+        for (int i = 0; i < kCtRows + WIN - 1; ++i) col[i] = tile[ty + i][tx + j];
+#pragma unroll
+        for (int y = 0; y < kCtRows; ++y)
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const int b = i * WIN + j;
+                if (col[y + i] > ctr[y]) w[y][b >> 5] |= (1u << (b & 31));
+            }
+    }
+    const bool col_in = c >= O && c < Wd - O;
+#pragma unroll
+    for (int y = 0; y < kCtRows; ++y) {
+        const int r = r0 + ty + y;
+        if (r >= H) break;
+        const bool in = col_in && r >= O && r < H - O;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) codes[((size_t)r * Wd + c) * NW + i] = in ? w[y][i] : 0u;
+    }
 }
 
 // ---- census Hamming cost (census.cpp:97-180) ----------------------------------------------------
@@ -293,12 +313,12 @@ static int census_codes(pmx_ctx* ctx, pmx_cv* cv) {
     cv->codeR = left + per_img + kCodePad;
     cv->win = WIN;
     pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_TRANSFORM);
-    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    dim3 grid((W + 63) / 64, (H + kCtTileY - 1) / kCtTileY);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), grid, dim3(kBlock), 0, ctx->stream, ctx->left, H, W, left);
     for (int k = 0; k < cv->subpix; ++k) {
         uint32_t* dst = left + (per_img + kCodePad) * (size_t)(k + 1);
         int wk = pmx_shifted_width(W, k);
-        dim3 g2((wk + 63) / 64, (H + 3) / 4);
+        dim3 g2((wk + 63) / 64, (H + kCtTileY - 1) / kCtTileY);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), g2, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, dst);
     }
     PMX_HIP(hipGetLastError());
