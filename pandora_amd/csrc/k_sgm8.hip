@@ -611,13 +611,10 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair2_kernel(sgm8_arg
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-// Spacing of the eight path volumes: H*W*Dp rounded to 256 bytes.  PMX_DIR_SKEW=<bytes> (multiples of 4) adds a skew between
-// them - an experiment hook: skews of 4 KB ... 1 MB showed no benefit at C3 (tools/skew_probe.sh; the 7 % differences seen
-// between runs follow the box's clock state, not the placement of the buffers).
+// Spacing of the eight path volumes: H*W*Dp rounded to 256 bytes.  (A skew between them - 4 KB ... 1 MB, round 1 - showed no
+// benefit at C3: the 7 % differences seen between runs follow the box's clock state, not the placement of the buffers.)
 size_t pmx_dir_stride(int H, int W, int Dp) {
-    size_t skew = 0;
-    if (const char* e = getenv("PMX_DIR_SKEW")) skew = (size_t)strtoul(e, nullptr, 10) & ~(size_t)3;
-    return (((size_t)H * W * Dp + 255) & ~(size_t)255) + skew;
+    return ((size_t)H * W * Dp + 255) & ~(size_t)255;
 }
 
 bool pmx_sgm8_supported(int gl, int kpl, int nw) { return gl == 16 && (kpl % 4) == 0 && kpl >= 4 && kpl <= 20 && nw <= 6 && nw != 5; }
@@ -662,7 +659,6 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     }
     cv->nvol = nvol;
     cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl; cv->dstride = vol;
-    if (getenv("PMX_DEBUG_PTRS")) fprintf(stderr, "PMX_PTRS cost8=%p ldir=%p codes=%p vol=%zu cvol=%zu\n", (void*)cv->cost8, (void*)cv->ldir, (void*)cv->codes, vol, cvol);
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
         cost8_args c;
