@@ -888,13 +888,11 @@ __global__ __launch_bounds__(64 * kZnccWaves) void zncc_march_kernel(zncc_march_
             if (pix >= o && pix < 64 - o && pc < W && st_k < q.D) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&ostage[par][pix][4 * st_part]);
                 float* dst = q.cv + ((size_t)r * W + pc) * q.D + st_k;
-                if (st_k + 4 <= q.D) {
-                    __builtin_memcpy(dst, &v, 16);
-                } else {
-                    dst[0] = v.x;
-                    if (st_k + 1 < q.D) dst[1] = v.y;
-                    if (st_k + 2 < q.D) dst[2] = v.z;
-                }
+                const int left = q.D - st_k;  // the volume's last piece of a pixel: one store of what is left
+                if (left >= 4) __builtin_memcpy(dst, &v, 16);
+                else if (left == 3) __builtin_memcpy(dst, &v, 12);
+                else if (left == 2) __builtin_memcpy(dst, &v, 8);
+                else dst[0] = v.x;
             }
         }
     }
