@@ -74,7 +74,7 @@ struct fam_args {
     int has_sin;     // S already holds earlier paths (else this pass starts the sum)
     int epilogue;    // last pass: overcounting, sign, NaN restore
     int dmask;       // paths that are added to S: bit 0 vertical, bit 1 predecessor column c-1, bit 2 predecessor column c+1
-    u32x4* halo;     // hand-off blocks [H][NB][NGP] of 16 bytes {value, tag, value, tag}
+    u32x4* halo;     // hand-off blocks [H][NB][NGP] of 16 bytes {value, value, value, epoch ^ the three}
     int NB;          // window borders per row = ceil(W / CW)
     unsigned epoch;
     unsigned* ctl;   // [0] ticket counter (zero at launch), [1] error word
@@ -147,9 +147,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     constexpr int ES = GL * KS + 4;        // LDS floats per (path, column): slices + the minimum
     constexpr int EDIR = (CW + 2) * ES;    // one path: column slots -2 .. CW-1
     constexpr int EBUF = 2 * EDIR;         // one row parity: vertical path, diagonal path
-    constexpr int K2 = (KPL + 1) / 2;      // 16-byte hand-off blocks per lane and vector: two {value, tag} halves each
-    constexpr int NVB = GL * K2;           // blocks per handed-off vector
-    constexpr int NG = 3 * NVB + 2;        // blocks per (row, border): V[CW-1], A[CW-1], A[CW-2], then their three minima
+    constexpr int K3 = (KPL + 2) / 3;      // 16-byte hand-off blocks per lane and vector: {value, value, value, tag} each
+    constexpr int NVB = GL * K3;           // blocks per handed-off vector
+    constexpr int NG = 3 * NVB + 1;        // blocks per (row, border): V[CW-1], A[CW-1], A[CW-2], then one block of their three minima
     constexpr int NQ = (NG + 63) / 64;
     constexpr int NGP = NQ * 64;
     constexpr int KH = NQ > 10 ? 2 : 4;   // hand-off look-ahead in rows (register ring of the hand-off wave)
@@ -183,28 +183,34 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         // (every row's barrier waits for this wavefront: it goes first on its SIMD - A/B on one box at 4096^2 x 257: 14.2-14.4 ms per
         //  family against 15.0-15.2; 10000^2 x 129: no difference)
         __builtin_amdgcn_s_setprio(3);
+        // A block is three values and a tag: tag = epoch ^ the three words, so that a block is taken only whole (a stale block
+        // carries another epoch, a block of which only a part had arrived does not add up), at 12 of 16 bytes payload where two
+        // {value, epoch} halves had 8 (the hand-off was a third of this kernel's traffic at 4096^2 x 257: 482 blocks per row and
+        // border, now 289)
         int ldsoff[NQ];
-        int nreal[NQ];  // how many of the block's two values exist (0: padding block)
+        int nreal[NQ];  // how many of the block's three values exist (0: padding block, 4: the block of the three minima)
+        int pairoff[NQ], oneoff[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int idx = q * 64 + lane;
             int vec, off, n;
             if (idx < 3 * NVB) {
                 vec = idx / NVB;
-                const int rem = idx - vec * NVB;  // block rem = k2 * GL + l: the lanes of one store are contiguous
-                const int k2 = rem / GL;
-                off = (rem - k2 * GL) * KS + 2 * k2;
-                n = (2 * k2 + 1 < KPL) ? 2 : 1;
-            } else if (idx == 3 * NVB) {  // minima of vectors 0 and 1: both live in column slot -1, paths V and A
-                vec = 3; off = GL * KS; n = 2;
-            } else if (idx == 3 * NVB + 1) {
-                vec = 2; off = GL * KS; n = 1;
+                const int rem = idx - vec * NVB;  // block rem = k3 * GL + l: the lanes of one store are contiguous
+                const int k3 = rem / GL;
+                off = (rem - k3 * GL) * KS + 3 * k3;
+                n = KPL - 3 * k3 >= 3 ? 3 : KPL - 3 * k3;
+            } else if (idx == 3 * NVB) {  // the minima: V and A of column slot -1, A of column slot -2
+                vec = 3; off = GL * KS; n = 4;
             } else {
                 vec = 0; off = 0; n = 0;
             }
             // vec 0: vertical path of column CW-1 -> slot -1;  1: diagonal of CW-1 -> slot -1;  2: diagonal of CW-2 -> slot -2
             ldsoff[q] = (vec == 0 || vec == 3 ? 0 : EDIR) + (vec == 2 ? 0 : ES) + off;
-            nreal[q] = vec == 3 ? 3 : n;  // 3: the two values go to different paths (V minimum, A minimum of slot -1)
+            nreal[q] = n;
+            // a full block moves as an 8-byte pair and a single word (whichever of the three sits at an even index starts the pair)
+            pairoff[q] = ldsoff[q] + (off & 1);
+            oneoff[q] = ldsoff[q] + ((off & 1) ? 0 : 2);
         }
         // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
         // Their loads are issued KH barriers ahead into a register ring, so that in the steady state - the neighbour a few rows
@@ -233,7 +239,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) ok &= nreal[q] == 0 || (slot[q].y == a.epoch && slot[q].w == a.epoch);
+                for (int q = 0; q < NQ; ++q) ok &= nreal[q] == 0 || slot[q].w == (a.epoch ^ slot[q].x ^ slot[q].y ^ slot[q].z);
                 if (__all(ok)) break;
                 if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
                 if (spins > kSpinLimit) {
@@ -247,16 +253,19 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             float* Eb = lds + (t & 1) * EBUF;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if (nreal[q] == 2) {
+                if (nreal[q] == 4) {  // (ldsoff: the V minimum of slot -1)
+                    Eb[ldsoff[q]] = __uint_as_float(slot[q].x);
+                    Eb[ldsoff[q] + EDIR] = __uint_as_float(slot[q].y);
+                    Eb[ldsoff[q] + EDIR - ES] = __uint_as_float(slot[q].z);
+                } else if (nreal[q] == 3) {
                     float2 v;
                     v.x = __uint_as_float(slot[q].x);
-                    v.y = __uint_as_float(slot[q].z);
-                    *(float2*)(Eb + ldsoff[q]) = v;
-                } else if (nreal[q] == 1) {
+                    v.y = __uint_as_float(slot[q].y);
+                    *(float2*)(Eb + pairoff[q]) = v;
+                    Eb[oneoff[q]] = __uint_as_float(slot[q].z);
+                } else if (nreal[q] > 0) {
                     Eb[ldsoff[q]] = __uint_as_float(slot[q].x);
-                } else if (nreal[q] == 3) {
-                    Eb[ldsoff[q]] = __uint_as_float(slot[q].x);
-                    Eb[ldsoff[q] + EDIR] = __uint_as_float(slot[q].z);
+                    if (nreal[q] > 1) Eb[ldsoff[q] + 1] = __uint_as_float(slot[q].y);
                 }
             }
             return true;
@@ -274,19 +283,21 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 u32x4 b;
-                b.y = a.epoch;
-                b.w = a.epoch;
                 if (nreal[q] == 3) {
-                    b.x = __float_as_uint(Eb[ldsoff[q]]);
-                    b.z = __float_as_uint(Eb[ldsoff[q] + EDIR]);
-                } else if (nreal[q] == 2) {
-                    const float2 v = *(const float2*)(Eb + ldsoff[q]);
+                    const float2 v = *(const float2*)(Eb + pairoff[q]);
                     b.x = __float_as_uint(v.x);
-                    b.z = __float_as_uint(v.y);
+                    b.y = __float_as_uint(v.y);
+                    b.z = __float_as_uint(Eb[oneoff[q]]);
+                } else if (nreal[q] == 4) {
+                    b.x = __float_as_uint(Eb[ldsoff[q]]);
+                    b.y = __float_as_uint(Eb[ldsoff[q] + EDIR]);
+                    b.z = __float_as_uint(Eb[ldsoff[q] + EDIR - ES]);
                 } else {
                     b.x = __float_as_uint(Eb[ldsoff[q]]);
+                    b.y = nreal[q] > 1 ? __float_as_uint(Eb[ldsoff[q] + 1]) : b.x;
                     b.z = b.x;
                 }
+                b.w = a.epoch ^ b.x ^ b.y ^ b.z;
                 __builtin_amdgcn_raw_buffer_store_b128(b, rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
             }
         };
@@ -655,7 +666,7 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
     PMX_CHECK(pick_shape(cv->D, cv->W, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (family schedule): D = %d not supported", cv->D);
     const int npw = 64 / f.gl, CW = f.nw * npw;
     const int NB = (cv->W + CW - 1) / CW;
-    const int NG = 3 * f.gl * ((f.kpl + 1) / 2) + 2, NGP = (NG + 63) / 64 * 64;  // 16-byte blocks per (row, border)
+    const int NG = 3 * f.gl * ((f.kpl + 2) / 3) + 1, NGP = (NG + 63) / 64 * 64;  // 16-byte blocks per (row, border)
     const size_t halo_bytes = (size_t)cv->H * NB * NGP * 16;
     if (int rcp = pmx_fam_prepare(ctx, halo_bytes)) return rcp;
     const int nwg = (cv->W + cv->H - 2) / CW + 1;
