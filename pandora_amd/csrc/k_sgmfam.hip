@@ -231,7 +231,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         auto issue = [&](int t, u32x4 (&slot)[NQ]) {
             const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
+            for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
         };
         auto consume = [&](int t, u32x4 (&slot)[NQ]) -> bool {
             if (t < tA || t > tB) return true;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                 }
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
+                for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
             }
             float* Eb = lds + (t & 1) * EBUF;
 #pragma unroll
