@@ -17,7 +17,10 @@ meant to span N GPUs cannot print a 1-GPU line.  The line carries RCCL's own ran
 At N>1 a second leg, `d_sharded_exact`, times north_star's exact multi-GPU form on BASELINE configs[3]'s steps that shard over D
 (ZNCC 11x11 + WTA + vfit at 4096x4096x257: disparity slices per rank, ONE ncclAllReduce(min, uint64) of the packed per-pixel keys,
 one ncclAllReduce(sum) of the owner-refined maps) and reports the maps' identity with one GPU doing the whole volume; a third,
-`pair_per_rank`, is the weak-scaling figure beside the strong-scaling `value`: one whole pair per rank and step, no exchange.
+`pair_per_rank`, is the weak-scaling figure beside the strong-scaling `value`: one whole pair per rank and step, no exchange; a
+fourth, `c5_row_tiled`, is BASELINE configs[4] as worded ("10000x10000 ... Census+CBCA+SGM ... row-tiled 8 GPUs"): the strip's fine
+scale over the ranks' row tiles, with the whole strip on one GPU timed beside it.  A self-launched run fails fast: the first rank
+that exits non-zero stops the others, a watchdog bounds the whole run, every rank's last stderr lines are printed.
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the 8-path SGM kernel, HIP-event timed on the engine's stream
 inside the timed region), `cpu_baseline` (the C oracle, kind "port", 1 thread, on a bounded row strip of the same pair),
@@ -325,6 +328,86 @@ def d_sharded_leg(eng, comm, L, R, dmin, dmax, win, steps, check_device):
     return out
 
 
+def c5_row_tiled_leg(eng, comm, H5, W5, steps, check_device):
+    """N > 1: BASELINE configs[4] as BASELINE words it - "10000x10000 ... Census+CBCA+SGM ... row-tiled 8 GPUs" - the fine scale of
+    the strip over all ranks, the reference's ROI convention (marge.py:86-101; optimization/optimization.py:43: 40 rows for SGM, plus
+    the census window's 2): every rank runs census 5x5 + CBCA + SGM 8-path + WTA + vfit (float32 volumes between the steps) on its
+    H5 / N rows + margin, places its owned rows in the full-size maps and ONE group of ncclSend / ncclRecv brings them to rank 0
+    (on the communication stream, under the next step's kernels).  Same barrier / max-over-ranks clock as the headline; after the
+    timed region rank 0 runs the whole strip on its one GPU: `one_gpu_ms_per_step` and the identity of the gathered maps."""
+    from pandora_amd import _lib
+    from pandora_amd.dist import row_tile
+    from pandora_amd.engine import Engine
+
+    rank, world = comm.rank, comm.world
+    dmin, dmax, win = -64, 64, 5
+    D = dmax - dmin + 1
+    margin = SGM_MARGIN + win // 2
+    L5, R5 = synthetic_pair(H5, W5, dmin, dmax)
+    (own_lo, own_hi), (tile_lo, tile_hi) = row_tile(H5, world, rank, margin)
+    eng.set_placement_trials(1)
+    eng.set_images(np.ascontiguousarray(L5[tile_lo:tile_hi]), np.ascontiguousarray(R5[tile_lo:tile_hi]), 1)
+    cv = eng.alloc_cv(D, dmin)
+
+    def pipeline(e, c):
+        e.census(c, win)
+        e.cbca(c, win // 2, 30.0, 5)
+        e.sgm(c, 8.0, 32.0, False, float(win * win + 1), False)
+        e.set_validity(None)
+        e.wta(c, False, -9999.0)
+        e.refine(c, "vfit", False)
+
+    def step():
+        pipeline(eng, cv)
+        eng.tile_place(H5, own_lo, own_hi, tile_lo, True)
+        comm.gather_rows(H5, True, root=0)
+
+    step()
+    eng.sync()
+    comm.barrier()
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    eng.sync()
+    dt = float(comm.host_allreduce(np.array([time.perf_counter() - t0]), "max")[0]) / steps
+    stage = {k: eng.stage_time(k) for k in _lib.STAGES}
+    eng.set_profiling(False)
+    comm.barrier()
+    out = None
+    gathered = eng.get_full_maps(H5, want_itp=True) if rank == 0 else None
+    cv.free()
+    if rank == 0:
+        one = Engine(check_device)
+        one.set_images(L5, R5, 1)
+        cv1 = one.alloc_cv(D, dmin)
+        pipeline(one, cv1)
+        one.sync()
+        t1 = time.perf_counter()
+        pipeline(one, cv1)
+        one.sync()
+        one_ms = (time.perf_counter() - t1) * 1e3
+        od, ov, oi = one.get_disparity(want_itp=True)
+        cv1.free()
+        one.close()
+        gd, gv, gi = gathered
+        cells = H5 * W5 * D
+        out = {"workload": f"BASELINE configs[4], fine scale, row-tiled: {H5}x{W5} synthetic pair, d=[{dmin},{dmax}] (D={D}), Census 5x5 + CBCA + "
+                           f"SGM 8-path + WTA + vfit, float32 volumes between the steps; ONE pair per step over {world} ranks",
+               "parallelism": f"row tiles of {H5 // world} rows + {margin}-row margin (40 SGM + {win // 2} census: the reference's ROI convention), "
+                              f"one ncclSend / ncclRecv gather of the owned rows of 3 maps to GPU 0 per step; strong scaling",
+               "steps": steps, "ms_per_step": round(dt * 1e3, 3), "value": round(cells / dt / 1e6, 1), "unit": "Mdisp/s", "dtype": "f32",
+               "one_gpu_ms_per_step": round(one_ms, 3), "speedup_vs_one_gpu": round(one_ms / (dt * 1e3), 3),
+               "stage_ms_per_step_rank0": {k: round(v[0] / steps, 4) for k, v in stage.items() if v[1]},
+               "gathered_maps_vs_one_gpu": {
+                   "disparity_identical": round(float(np.mean((gd == od) | (np.isnan(gd) & np.isnan(od)))), 6),
+                   "validity_identical": round(float(np.mean(gv == ov)), 6),
+                   "coefficient_identical": round(float(np.mean((gi == oi) | (np.isnan(gi) & np.isnan(oi)))), 6)}}
+    comm.barrier()
+    return out
+
+
 def pair_per_rank_leg(comm, device, H, W, dmin, dmax, win, P1, P2, steps, rank, world):
     """N > 1, weak scaling beside the strong-scaling headline: every rank runs the WHOLE pipeline on a pair of its own (the way the
     reference is deployed on many tiles or many pairs: no exchange at all), same barrier / max-over-ranks protocol; the aggregate is
@@ -352,23 +435,91 @@ def pair_per_rank_leg(comm, device, H, W, dmin, dmax, win, P1, P2, steps, rank, 
             "value": round(world * cells / (elapsed / steps) / 1e6, 1), "unit": "Mdisp/s"}
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: N ranks of this very command, one per device (LOCAL_RANK = device), a free
-    rendezvous port at 127.0.0.1; rank 0's stdout (the JSON line) is passed through, a failing rank fails the run."""
+def _free_port_pair():
+    """a MASTER_PORT whose successor is free too: the library's rendezvous listens one above the launcher's port (comm.py)"""
     import socket
-    import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
+    for _ in range(64):
+        with socket.socket() as a:
+            a.bind(("127.0.0.1", 0))
+            port = a.getsockname()[1]
+            with socket.socket() as b:
+                try:
+                    b.bind(("127.0.0.1", port + 1))
+                except OSError:
+                    continue
+        return port
+    raise OSError("bench.py: no pair of free rendezvous ports at 127.0.0.1")
+
+
+def spawn_ranks(n, watchdog_s):
+    """`python bench.py --gpus N` without a launcher: N ranks of this very command, one per device (LOCAL_RANK = device), a free
+    rendezvous port pair at 127.0.0.1; rank 0's stdout (the JSON line) is passed through.  FAILS FAST: all children are polled, the
+    first non-zero exit (a rank that died in ncclCommInitRank, say) terminates the others - which would otherwise sit in a
+    collective until the driver's timeout - and the launcher exits non-zero within seconds, after printing every rank's last
+    stderr lines; so does an overall watchdog.  RCCL's own warnings are switched on for the children (NCCL_DEBUG=WARN)."""
+    import subprocess
+    import tempfile
+
+    port = _free_port_pair()
+    logs, procs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
+        logs.append(tempfile.TemporaryFile(mode="w+", prefix=f"bench_rank{r}_"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    codes = [p.wait() for p in procs]
-    return next((c for c in codes if c), 0)
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=logs[r]))
+
+    def tails(lines=25):
+        for r, f in enumerate(logs):
+            f.flush()
+            f.seek(0)
+            text = f.read().splitlines()[-lines:]
+            if text:
+                sys.stderr.write(f"---- rank {r}: last {len(text)} stderr lines ----\n" + "\n".join(text) + "\n")
+        sys.stderr.flush()
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0 = time.time()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, c = bad[0]
+            sys.stderr.write(f"bench.py: rank {r} exited with code {c}; stopping the other ranks\n")
+            stop_all()
+            tails()
+            rc = c if c > 0 else 1
+            break
+        if all(c == 0 for c in codes):
+            f = logs[0]  # a clean run: rank 0's stderr (RCCL's banner, warnings) is passed on
+            f.flush()
+            f.seek(0)
+            sys.stderr.write(f.read())
+            break
+        if time.time() - t0 > watchdog_s:
+            sys.stderr.write(f"bench.py: the ranks did not finish within {watchdog_s:.0f} s (watchdog); stopping them\n")
+            stop_all()
+            tails()
+            rc = 124
+            break
+        time.sleep(0.1)
+    for f in logs:
+        f.close()
+    return rc
 
 
 def main():
@@ -387,6 +538,11 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the c4_as_stated / c5_as_stated / default_allocation legs (N=1)")
     ap.add_argument("--no-dshard", action="store_true", help="skip the exact D-sharded leg (N>1)")
     ap.add_argument("--no-weak", action="store_true", help="skip the pair-per-rank (weak scaling) leg (N>1)")
+    ap.add_argument("--no-c5tiled", action="store_true", help="skip the row-tiled BASELINE configs[4] leg (N>1)")
+    ap.add_argument("--c5-height", type=int, default=10000, help="rows of the row-tiled configs[4] leg (N>1)")
+    ap.add_argument("--c5-width", type=int, default=10000, help="columns of the row-tiled configs[4] leg (N>1)")
+    ap.add_argument("--watchdog", type=float, default=1200.0, help="seconds after which a self-launched multi-rank run is stopped")
+    ap.add_argument("--test-die-rank", type=int, default=None, help="TEST HOOK: this rank exits with code 3 after the warm-up")
     ap.add_argument("--test-comm", default=None, metavar="MODULE:CLASS",
                     help="TEST HOOK: a pandora_amd.comm.Comm subclass from tests/ (e.g. tests.transports:TcpComm) that carries the "
                          "exchange steps through the host, so that several ranks can share the one GPU of a test box")
@@ -404,7 +560,7 @@ def main():
     if args.test_device is None and ndev < args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, this box shows {ndev}")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))  # no launcher: bench.py starts its own ranks and relays rank 0's line
+        sys.exit(spawn_ranks(args.gpus, args.watchdog))  # no launcher: bench.py starts its own ranks and relays rank 0's line
     rank, world, local_rank, _, _ = env_world()
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: refusing to print a line for the wrong N")
@@ -442,6 +598,8 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.sync()
+    if args.test_die_rank is not None and args.test_die_rank == rank:
+        os._exit(3)  # TEST HOOK: a rank that dies mid-run; the launcher must notice and stop the others
     eng.set_profiling(True)
     eng.reset_stage_times()
 
@@ -471,6 +629,10 @@ def main():
     weak = None
     if comm is not None and not args.no_weak:
         weak = pair_per_rank_leg(comm, local_rank, H, W, dmin, dmax, win, P1, P2, max(2, args.steps // 2), rank, world)
+    c5tiled = None
+    if comm is not None and not args.no_c5tiled:
+        cv.free()
+        c5tiled = c5_row_tiled_leg(eng, comm, args.c5_height, args.c5_width, max(2, args.steps // 4), local_rank)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -491,7 +653,7 @@ def main():
             "value": round(value, 1),
             "unit": "Mdisp/s",
             "n_gpus": world,
-            "rccl_ranks": comm.nranks if comm is not None else 1,
+            "rccl_ranks": 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -507,6 +669,12 @@ def main():
             "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4),
         }
         if world > 1:
+            # RCCL's own rank count (ncclCommCount) - or, under the --test-comm hook, what carried the exchange instead
+            if getattr(comm, "nranks_note", None):
+                del out["rccl_ranks"]
+                out["transport"] = f"{comm.nranks_note} ({type(comm).__name__}, {comm.world} ranks): NOT RCCL"
+            else:
+                out["rccl_ranks"] = comm.nranks
             out["collective"] = {"kind": "ncclSend / ncclRecv group: owned rows of 3 maps to rank 0 (10 B/pixel, validity as uint16)",
                                  "ms_per_step": round(stage["collective"][0] / args.steps, 4), "bytes_per_step": H * W * 10}
             # what arrived (outside the timed region): the gathered maps of the last step against ONE GPU doing the whole pair.
@@ -528,6 +696,8 @@ def main():
                 out["d_sharded_exact"] = dshard
             if weak is not None:
                 out["pair_per_rank"] = weak
+            if c5tiled is not None:
+                out["c5_row_tiled"] = c5tiled
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
             pcie_s = pcie_inclusive_ms(eng, cv, L, R, win, P1, P2) * 1e-3

@@ -3,6 +3,8 @@
 //
 // The reference's python plugins call three pybind11 modules at these sites:
 //     matching_cost_cpp.compute_matching_costs(img_left, imgs_right, cv, disps, w, h)       matching_cost/census.py:140
+//     matching_cost_cpp.reverse_cost_volume(left_cv, disp_min)                               state_machine.py:438-448 (fast cross-checking)
+//     matching_cost_cpp.reverse_disp_range(left_min, left_max)                               state_machine.py:673
 //     aggregation_cpp.cross_support(image, len_arms, intensity)                              aggregation/cbca.py:237-291
 //     aggregation_cpp.cbca(input, cross_left, cross_right, range_col, range_col_right)       aggregation/cbca.py:158
 //     refinement_cpp.loop_refinement(cv, disp, mask, d_min, d_max, subpixel, measure, method, cst_invalid, cst_stopped)
@@ -37,8 +39,9 @@ using larr = py::array_t<int64_t, py::array::c_style | py::array::forcecast>;
 
 namespace {
 
+pmx_ctx* ctx = nullptr;  // the face's one context; destroyed with the module (the capsule in PYBIND11_MODULE below)
+
 pmx_ctx* context() {
-    static pmx_ctx* ctx = nullptr;
     if (!ctx) {
         const char* dev = std::getenv("PANDORA_AMD_DEVICE");
         ctx = pmx_create(dev ? std::atoi(dev) : 0);
@@ -86,6 +89,51 @@ py::array compute_matching_costs(farr img_left, py::list imgs_right, farr cv, fa
     for (size_t i = 0; i < tmp.size(); ++i)
         if (tmp[i] == tmp[i]) out[i] = tmp[i];
     return std::move(cv);
+}
+
+// matching_cost/cpp/src/matching_cost.cpp:26-56: the right volume by re-indexing, (i, j, d) -> (i, j + d + disp_min, D - 1 - d),
+// NaN where that column is outside the image.  (The reference reads the cells, never the coordinates: the volume's own first
+// disparity does not enter.)
+py::array_t<float> reverse_cost_volume(farr left_cv, int disp_min) {
+    if (left_cv.ndim() != 3) throw std::invalid_argument("reverse_cost_volume: left_cv 3-D (row, col, disp)");
+    const int H = (int)left_cv.shape(0), W = (int)left_cv.shape(1), D = (int)left_cv.shape(2);
+    py::array_t<float> out({(py::ssize_t)H, (py::ssize_t)W, (py::ssize_t)D});
+    if (H == 0 || W == 0 || D == 0) return out;
+    pmx_ctx* ctx = context();
+    std::vector<float> zeros((size_t)H * W, 0.f);  // (the context takes its geometry from the resident pair)
+    ok(pmx_set_images(ctx, zeros.data(), zeros.data(), H, W, 1), "pmx_set_images");
+    cv_guard l{ctx, pmx_cv_alloc(ctx, D, 0)};
+    if (!l.cv) throw std::runtime_error(std::string("pmx_cv_alloc: ") + pmx_last_error());
+    ok(pmx_cv_upload(ctx, l.cv, left_cv.data()), "pmx_cv_upload");
+    cv_guard r{ctx, pmx_reverse_cost_volume(ctx, l.cv, disp_min)};
+    if (!r.cv) throw std::runtime_error(std::string("pmx_reverse_cost_volume: ") + pmx_last_error());
+    ok(pmx_cv_download(ctx, r.cv, out.mutable_data()), "pmx_cv_download");
+    return out;
+}
+
+// matching_cost/cpp/src/matching_cost.cpp:59-132: per-pixel right disparity ranges from the left ones (NaN where no left pixel
+// reaches the column).  The device kernel wants a bracket of every (int)left_min / (int)left_max: one scan of the two maps here.
+std::tuple<py::array_t<float>, py::array_t<float>> reverse_disp_range(farr left_min, farr left_max) {
+    if (left_min.ndim() != 2 || left_max.ndim() != 2 || left_min.shape(0) != left_max.shape(0) || left_min.shape(1) != left_max.shape(1))
+        throw std::invalid_argument("reverse_disp_range: two 2-D maps of one shape");
+    const int H = (int)left_min.shape(0), W = (int)left_min.shape(1);
+    py::array_t<float> rmin({(py::ssize_t)H, (py::ssize_t)W}), rmax({(py::ssize_t)H, (py::ssize_t)W});
+    if (H == 0 || W == 0) return {rmin, rmax};
+    const float *a = left_min.data(), *b = left_max.data();
+    bool any = false;
+    int lo = 0, hi = 0;
+    for (size_t i = 0; i < (size_t)H * W; ++i) {
+        if (a[i] != a[i] || b[i] != b[i]) continue;  // matching_cost.cpp:92-96: NaN ranges are skipped
+        // (a range that cannot reach any column contributes nothing: clamp instead of converting a huge float)
+        const float fa = std::fmax(std::fmin(a[i], (float)W), -(float)W), fb = std::fmax(std::fmin(b[i], (float)W), -(float)W);
+        const int ia = (int)fa, ib = (int)fb;
+        if (!any) { lo = ia; hi = ib; any = true; }
+        lo = ia < lo ? ia : lo;
+        hi = ib > hi ? ib : hi;
+    }
+    if (hi < lo) hi = lo;
+    ok(pmx_reverse_disp_range(context(), a, b, H, W, lo, hi, rmin.mutable_data(), rmax.mutable_data()), "pmx_reverse_disp_range");
+    return {rmin, rmax};
 }
 
 // aggregation/cpp/src/aggregation.cpp:224-321
@@ -191,8 +239,14 @@ std::tuple<py::array_t<float>, py::array_t<float>, py::array_t<int64_t>> loop_re
 
 PYBIND11_MODULE(inner_cpp, m) {
     m.doc() = "The reference's native-function signatures (matching_cost_cpp / aggregation_cpp / refinement_cpp) over libpandora_amd.so";
+    m.add_object("_context_guard", py::capsule(static_cast<void*>(&ctx), [](void*) {
+                     if (ctx) pmx_destroy(ctx);
+                     ctx = nullptr;
+                 }));
     m.def("compute_matching_costs", &compute_matching_costs, py::arg("img_left"), py::arg("imgs_right"), py::arg("cv"), py::arg("disps"),
           py::arg("census_width"), py::arg("census_height"));
+    m.def("reverse_cost_volume", &reverse_cost_volume, py::arg("left_cv"), py::arg("disp_min"));
+    m.def("reverse_disp_range", &reverse_disp_range, py::arg("left_min"), py::arg("left_max"));
     m.def("cross_support", &cross_support, py::arg("image"), py::arg("len_arms"), py::arg("intensity"));
     m.def("cbca", &cbca, py::arg("input"), py::arg("cross_left"), py::arg("cross_right"), py::arg("range_col"), py::arg("range_col_right"));
     m.def("loop_refinement", &loop_refinement, py::arg("cv"), py::arg("disp"), py::arg("mask"), py::arg("d_min"), py::arg("d_max"),

@@ -139,6 +139,20 @@ extern "C" int pmx_cbca_slice(pmx_ctx* ctx, const float* input, const int16_t* c
                   (long long)q);
         colmap[(size_t)c] = (int)q;
     }
+    // The kernels index their prefix sums with the arms (aggregation.cpp:99-117, :181-213 do the same, unchecked): arms that do
+    // not fit the image would read foreign device memory, so they are refused here, on the host, before anything is launched.
+    for (int r = 0; r < H; ++r) {
+        for (int c = 0; c < W; ++c) {
+            const int q = colmap[(size_t)c];
+            if (q < 0) continue;
+            const int16_t* al = cross_left + ((size_t)r * W + c) * 4;
+            const int16_t* ar = cross_right + ((size_t)r * Wr + q) * 4;
+            const int left = al[0] < ar[0] ? al[0] : ar[0], right = al[1] < ar[1] ? al[1] : ar[1];
+            const int top = al[2] < ar[2] ? al[2] : ar[2], bot = al[3] < ar[3] ? al[3] : ar[3];
+            PMX_CHECK(left >= 0 && right >= 0 && c + right <= W && top >= 0 && top <= r && bot >= 0 && r + bot <= H - 1, PMX_ERR_ARG,
+                      "pmx_cbca_slice: the arms (%d, %d, %d, %d) of pixel (%d, %d) do not fit the %d x %d image", left, right, top, bot, r, c, H, W);
+        }
+    }
     PMX_HIP(hipSetDevice(ctx->device));
     const size_t nf = (size_t)H * W * sizeof(float), nl = (size_t)H * W * 4 * sizeof(int16_t), nr = (size_t)H * Wr * 4 * sizeof(int16_t);
     const size_t ns1 = (size_t)H * (W + 1) * sizeof(float), ns3 = (size_t)(H + 1) * W * sizeof(float), ncm = (size_t)W * sizeof(int);

@@ -47,14 +47,16 @@ def test_bench_runs_one_pair_over_the_ranks(world, port, height, width):
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
                                        "--height", str(height), "--width", str(width), "--dmax", "40", "--placement-trials", "1",
-                                       "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
+                                       "--c5-height", "640", "--c5-width", "700", "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), "".join(o[1][-1500:] for o in outs)
     lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
     assert len(lines) == 1 and not any(o[0].strip() for o in outs[1:]), outs
     d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"]
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and "row tiles" in d["config"]["parallelism"]
+    # the line says what carried the exchange: RCCL's own rank count only when RCCL ran it, the stand-in's name otherwise
+    assert "rccl_ranks" not in d and "NOT RCCL" in d["transport"] and f"{world} ranks" in d["transport"], d.get("transport")
     # the exact multi-GPU form rides along: costs sharded over D, one all-reduce(min) of packed keys - identical to one GPU
     assert d["d_sharded_exact"]["maps_identical_to_one_gpu"] == 1.0, d["d_sharded_exact"]
     assert d["collective"]["bytes_per_step"] == height * width * 10
@@ -62,6 +64,12 @@ def test_bench_runs_one_pair_over_the_ranks(world, port, height, width):
     assert d["pair_per_rank"]["scaling"] == "weak" and d["pair_per_rank"]["value"] > 0
     if width >= 2560:
         assert d["stage_ms_per_step"]["sgm_span"] > 0  # the family form ran in the tiles
+    # BASELINE configs[4] as worded (census + CBCA + SGM, row-tiled), here on a 640 x 700 strip: the gathered maps against one GPU
+    t = d["c5_row_tiled"]
+    assert "row-tiled" in t["workload"] and "CBCA" in t["workload"] and t["value"] > 0 and t["one_gpu_ms_per_step"] > 0
+    assert f"row tiles of {640 // world} rows + 42-row margin" in t["parallelism"], t["parallelism"]
+    assert t["gathered_maps_vs_one_gpu"]["disparity_identical"] > (0.97 if world == 2 else 0.85), t
+    assert t["gathered_maps_vs_one_gpu"]["validity_identical"] > 0.97, t
     # what arrived on rank 0 is the pair's result: identical to one GPU doing the whole pair except near the tile seams (SGM paths
     # are cut at the 40-row margin, as in the reference's ROI tiling; with 8 ranks over 300 rows there is a seam every 37 rows)
     g = d["gathered_maps_vs_one_gpu"]
@@ -82,3 +90,33 @@ def test_bench_refuses_to_mislabel_a_run():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr and not out.stdout.strip()
+
+
+def test_launcher_fails_fast_when_a_rank_dies():
+    """`bench.py --gpus 2` launching its own ranks: rank 1 exits after the warm-up (--test-die-rank), rank 0 is left waiting in the
+    exchange of its next step; the launcher must stop it and exit non-zero within seconds, not after the transport's timeout."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "300",
+                          "--width", "256", "--dmax", "40", "--placement-trials", "1", "--no-dshard", "--no-weak", "--no-c5tiled",
+                          "--test-comm", "tests.transports:TcpComm", "--test-device", "0", "--test-die-rank", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    took = time.time() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert not out.stdout.strip(), out.stdout
+    assert "rank 1 exited with code 3" in out.stderr and "stopping the other ranks" in out.stderr, out.stderr[-1500:]
+    assert took < 30.0, took
+
+
+def test_launcher_runs_its_own_ranks_to_the_end():
+    """the same launcher without the fault: one JSON line from rank 0, exit code 0"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "300",
+                          "--width", "256", "--dmax", "40", "--placement-trials", "1", "--no-dshard", "--no-weak", "--no-c5tiled",
+                          "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, out.stdout

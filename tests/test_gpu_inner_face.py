@@ -115,3 +115,94 @@ def test_loop_refinement_like_the_reference_module(face, oracle, method, measure
     np.testing.assert_array_equal(m2, em)
     with pytest.raises(Exception):
         face.loop_refinement(cv, disp, mask, float(dmin), float(dmax), subpix, measure, lambda c, d, m: (0.0, 0.0, 0), 963, 8)
+
+
+NAN = np.nan
+
+
+def test_reverse_cost_volume_like_the_reference_module(face):
+    # the two known answers of tests/test_cpp/test_matching_cost/test_matching_cost.cpp:80-100 (d = [0, 3] -> right min -3) and
+    # :181-201 (d = [-2, 2] -> right min -2), transcribed
+    left = np.array([[[12, 13, 14, 15], [23, 24, 25, 26], [34, 35, 36, NAN], [45, 46, NAN, NAN], [56, NAN, NAN, NAN],
+                      [NAN, NAN, NAN, NAN]]], np.float32)
+    right = np.array([[[NAN, NAN, NAN, NAN], [NAN, NAN, NAN, 12], [NAN, NAN, 13, 23], [NAN, 14, 24, 34], [15, 25, 35, 45],
+                       [26, 36, 46, 56]]], np.float32)
+    got = face.reverse_cost_volume(left, -3)
+    assert got.dtype == np.float32 and got.shape == left.shape
+    np.testing.assert_array_equal(got, right)
+    left = np.array([[[NAN, NAN, 11, 12, 13], [NAN, 21, 22, 23, 24], [31, 32, 33, 34, 35], [42, 43, 44, 45, 46], [53, 54, 55, 56, NAN],
+                      [64, 65, 66, NAN, NAN]]], np.float32)
+    right = np.array([[[NAN, NAN, 11, 21, 31], [NAN, 12, 22, 32, 42], [13, 23, 33, 43, 53], [24, 34, 44, 54, 64], [35, 45, 55, 65, NAN],
+                       [46, 56, 66, NAN, NAN]]], np.float32)
+    np.testing.assert_array_equal(face.reverse_cost_volume(left, -2), right)
+    # random volumes against the reference's compiled module, forcecast included (float64, Fortran order)
+    mc = _ref("matching_cost_cpp")
+    rng = np.random.default_rng(12)
+    for H, W, D, dmin in ((7, 33, 9, -5), (11, 20, 14, 0), (5, 9, 6, -12), (3, 40, 40, -20)):
+        cv = rng.random((H, W, D)).astype(np.float32)
+        cv[rng.random(cv.shape) < 0.15] = np.nan
+        got = face.reverse_cost_volume(cv, dmin)
+        if mc is not None:
+            np.testing.assert_array_equal(got, mc.reverse_cost_volume(cv, dmin))
+            np.testing.assert_array_equal(face.reverse_cost_volume(np.asfortranarray(cv.astype(np.float64)), dmin), got)
+        else:  # matching_cost.cpp:43-52 restated
+            exp = np.full_like(cv, np.nan)
+            for j in range(W):
+                for d in range(D):
+                    col = j + d + dmin
+                    if 0 <= col < W:
+                        exp[:, j, d] = cv[:, col, D - 1 - d]
+            np.testing.assert_array_equal(got, exp)
+
+
+def test_reverse_disp_range_like_the_reference_module(face):
+    mc = _ref("matching_cost_cpp")
+    rng = np.random.default_rng(13)
+    for H, W, lo, hi in ((9, 31, -6, 4), (4, 50, 0, 12), (6, 17, -30, -3), (5, 8, -2, 2)):
+        a = rng.integers(lo, hi + 1, (H, W))
+        b = a + rng.integers(0, 5, (H, W))
+        lmin, lmax = a.astype(np.float32), b.astype(np.float32)
+        lmin[rng.random((H, W)) < 0.1] = np.nan
+        lmax[rng.random((H, W)) < 0.1] = np.nan
+        rmin, rmax = face.reverse_disp_range(lmin, lmax)
+        assert rmin.dtype == np.float32 and rmin.shape == (H, W)
+        if mc is not None:
+            emin, emax = mc.reverse_disp_range(lmin, lmax)
+        else:  # matching_cost.cpp:84-118 restated
+            emin, emax = np.full((H, W), np.inf, np.float32), np.full((H, W), -np.inf, np.float32)
+            for r in range(H):
+                for c in range(W):
+                    if np.isnan(lmin[r, c]) or np.isnan(lmax[r, c]):
+                        continue
+                    for d in range(int(lmin[r, c]), int(lmax[r, c]) + 1):
+                        if 0 <= c + d < W:
+                            emin[r, c + d] = min(emin[r, c + d], -d)
+                            emax[r, c + d] = max(emax[r, c + d], -d)
+            none = np.isinf(emin)
+            emin[none] = np.nan
+            emax[none] = np.nan
+        np.testing.assert_array_equal(rmin, emin)
+        np.testing.assert_array_equal(rmax, emax)
+    # every range NaN: nothing reaches any column
+    n = np.full((3, 5), np.nan, np.float32)
+    rmin, rmax = face.reverse_disp_range(n, n)
+    assert np.isnan(rmin).all() and np.isnan(rmax).all()
+
+
+def test_cbca_refuses_arms_that_do_not_fit_the_image(face):
+    """arms index the kernels' prefix sums (aggregation.cpp:99-117, :181-213, unchecked there): arms that leave the image are an
+    error of the caller, reported before anything is launched"""
+    H, W = 6, 8
+    cv = np.zeros((H, W), np.float32)
+    arms = np.zeros((H, W, 4), np.int16)
+    cols = np.arange(W)
+    face.cbca(cv, arms, arms, cols, cols)
+    for k, (r, c) in enumerate(((2, 1), (2, 6), (1, 3), (4, 3))):  # left, right, up, down arms longer than the image
+        bad = arms.copy()
+        bad[r, c, k] = 3
+        with pytest.raises(RuntimeError, match="do not fit"):
+            face.cbca(cv, bad, bad, cols, cols)
+    neg = arms.copy()
+    neg[3, 3, 1] = -2
+    with pytest.raises(RuntimeError, match="do not fit"):
+        face.cbca(cv, neg, neg, cols, cols)

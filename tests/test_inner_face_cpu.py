@@ -7,7 +7,7 @@ import pytest
 def test_face_exports_the_reference_names_and_has_no_cpu_fallback():
     from pandora_amd import inner_cpp as face
 
-    for name in ("compute_matching_costs", "cross_support", "cbca", "loop_refinement", "vfit_refinement_method",
+    for name in ("compute_matching_costs", "reverse_cost_volume", "reverse_disp_range", "cross_support", "cbca", "loop_refinement", "vfit_refinement_method",
                  "quadratic_refinement_method"):
         assert callable(getattr(face, name)), name
     from pandora_amd import _lib
