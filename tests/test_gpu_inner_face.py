@@ -121,13 +121,13 @@ NAN = np.nan
 
 
 def test_reverse_cost_volume_like_the_reference_module(face):
-    # the two known answers of tests/test_cpp/test_matching_cost/test_matching_cost.cpp:80-100 (d = [0, 3] -> right min -3) and
+    # the two known answers of tests/test_cpp/test_matching_cost/test_matching_cost.cpp:80-100 (d = [1, 4] -> right min -4) and
     # :181-201 (d = [-2, 2] -> right min -2), transcribed
     left = np.array([[[12, 13, 14, 15], [23, 24, 25, 26], [34, 35, 36, NAN], [45, 46, NAN, NAN], [56, NAN, NAN, NAN],
                       [NAN, NAN, NAN, NAN]]], np.float32)
     right = np.array([[[NAN, NAN, NAN, NAN], [NAN, NAN, NAN, 12], [NAN, NAN, 13, 23], [NAN, 14, 24, 34], [15, 25, 35, 45],
                        [26, 36, 46, 56]]], np.float32)
-    got = face.reverse_cost_volume(left, -3)
+    got = face.reverse_cost_volume(left, -4)
     assert got.dtype == np.float32 and got.shape == left.shape
     np.testing.assert_array_equal(got, right)
     left = np.array([[[NAN, NAN, 11, 12, 13], [NAN, 21, 22, 23, 24], [31, 32, 33, 34, 35], [42, 43, 44, 45, 46], [53, 54, 55, 56, NAN],
