@@ -149,7 +149,7 @@ extern "C" int pmx_cbca_slice(pmx_ctx* ctx, const float* input, const int16_t* c
             const int16_t* ar = cross_right + ((size_t)r * Wr + q) * 4;
             const int left = al[0] < ar[0] ? al[0] : ar[0], right = al[1] < ar[1] ? al[1] : ar[1];
             const int top = al[2] < ar[2] ? al[2] : ar[2], bot = al[3] < ar[3] ? al[3] : ar[3];
-            PMX_CHECK(left >= 0 && right >= 0 && c + right <= W && top >= 0 && top <= r && bot >= 0 && r + bot <= H - 1, PMX_ERR_ARG,
+            PMX_CHECK(left >= 0 && left <= c && right >= 0 && c + right <= W && top >= 0 && top <= r && bot >= 0 && r + bot <= H - 1, PMX_ERR_ARG,
                       "pmx_cbca_slice: the arms (%d, %d, %d, %d) of pixel (%d, %d) do not fit the %d x %d image", left, right, top, bot, r, c, H, W);
         }
     }

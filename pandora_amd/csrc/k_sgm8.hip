@@ -214,6 +214,7 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
     };
 #pragma unroll
     for (int i = 0; i < kRing8; ++i) prefetch(ring[i]);
+    PMX_LOOP_ENTRY_DRAIN();
 
     // pad masks (also the restart state of a path): kInf16 in the halves that hold a disparity >= D
     uint32_t padA[Q], padB[Q];
@@ -342,7 +343,9 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args
     const int gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves8 + (threadIdx.x >> 6));
     const int H = a.H, W = a.W, D = a.D;
     if (gwave * kLines8 >= H) return;
-    const int line = min(gwave * kLines8 + grp, H - 1);  // surplus groups of the last wave repeat the last row (same bytes)
+    const int row0 = gwave * kLines8;
+    const int nrows = min(kLines8, H - row0);
+    const int lrow = min(grp, nrows - 1);  // surplus groups of the last wave repeat the last row (same bytes)
     const int d_first = sub * KPL;
     const bool lane_active = d_first < D;
     uint32_t padA[Q], padB[Q];
@@ -353,6 +356,13 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args
         padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
     }
     const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
+    // Every access goes through a descriptor of the wavefront's rows with a per-lane byte offset: lanes without a disparity store
+    // to an out-of-range offset (dropped) instead of sitting out under an exec mask.  A memory instruction inside a conditional
+    // block - even one that is always taken - is not counted by the compiler's wait-count pass on the paths behind it: with the
+    // store under `if (lane_active)` the four-deep read-ahead ring was waited for with vmcnt(3), one step of look-ahead instead
+    // of four; now the counts are the steady state's (PMX_LOOP_ENTRY_DRAIN, pmx_buf.h).
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cost + (size_t)row0 * W * a.Dc), 0, (unsigned)(nrows * W * a.Dc), kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ldir + (size_t)row0 * W * a.Dp), 0, (unsigned)(nrows * W * a.Dp), kRsrcWord3);
     struct slot_t { uint32_t x[NDW]; };
     struct sum_t { uint32_t x[Q]; };
 
@@ -360,23 +370,25 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args
         constexpr bool ACC = decltype(acc_tag)::value;
         const int dc = ACC ? -1 : 1;
         const int c0 = ACC ? W - 1 : 0;
-        const uint8_t* pC = a.cost + ((size_t)line * W + c0) * a.Dc + (lane_active ? sub * NDW * 4 : 0);
-        uint8_t* pO = a.ldir + ((size_t)line * W + c0) * a.Dp + d_first;
-        const uint8_t* pI = pO - (lane_active ? 0 : d_first);  // lanes without a disparity re-read lane 0 (nothing is stored)
+        unsigned offC = (unsigned)((lrow * W + c0) * a.Dc) + (lane_active ? (unsigned)sub * NDW * 4u : 0u);
+        unsigned offI = (unsigned)((lrow * W + c0) * a.Dp) + (lane_active ? (unsigned)d_first : 0u);  // lanes without a disparity re-read lane 0
+        unsigned offO = lane_active ? (unsigned)((lrow * W + c0) * a.Dp) + (unsigned)d_first : kOob;  // ... and store nothing
+        const unsigned stepC = (unsigned)(dc * a.Dc), stepP = (unsigned)(dc * a.Dp);
         int pleft = W - 1;
         slot_t ring[kRing8];
         sum_t prev[kRing8];
         auto prefetch = [&](slot_t& sl, sum_t& pv) {
-            __builtin_memcpy(sl.x, pC, 4 * NDW);
-            if (ACC) __builtin_memcpy(pv.x, pI, 4 * Q);
+            load_dwords<NDW>(rsC, offC, sl.x);
+            if (ACC) load_dwords<Q>(rsO, offI, pv.x);
             if (pleft > 0) {  // wave-uniform; past the end the last pixel is re-read
                 --pleft;
-                pC += (ptrdiff_t)dc * a.Dc;
-                pI += (ptrdiff_t)dc * a.Dp;
+                offC += stepC;
+                offI += stepP;
             }
         };
 #pragma unroll
         for (int i = 0; i < kRing8; ++i) prefetch(ring[i], prev[i]);
+        PMX_LOOP_ENTRY_DRAIN();
         uint32_t A[Q], B[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
@@ -404,11 +416,11 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args
                 nA[q] = add3(tA, ccA, negM);
                 nB[q] = add3(tB, ccB, negM);
             }
-            if (lane_active) {
+            {
                 uint32_t packed[Q];
 #pragma unroll
                 for (int q = 0; q < Q; ++q) packed[q] = (nA[q] | (nB[q] << 8)) + (ACC ? pv.x[q] : 0u);  // bytes d .. d+3 (pads spill upwards only)
-                __builtin_memcpy(pO, packed, 4 * Q);
+                store_dwords<Q>(rsO, offO, packed);
             }
             uint32_t m = hmin(nA[0], nB[0]);
 #pragma unroll
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args
             M = lmin | (lmin << 16);
 #pragma unroll
             for (int q = 0; q < Q; ++q) { A[q] = nA[q]; B[q] = nB[q]; }
-            pO += (ptrdiff_t)dc * a.Dp;
+            offO = lane_active ? offO + stepP : kOob;
         };
         int i = 0;
         for (; i + kRing8 <= W; i += kRing8) {
@@ -439,6 +451,388 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args
     };
     pass(std::false_type{});
     pass(std::true_type{});
+}
+
+// Cells that are not numbers (census.cpp:132-172 leaves them NaN: the window at column c of the left or at column c + d of the
+// right image leaves the image) take invalid_cost.  `vm` = bit k set where the lane's cell k is a number; a pair register holds
+// cells (k, k + 2): each half keeps its Hamming cost or takes invalid_cost, pads of disparities >= D are put back by the caller.
+__device__ __forceinline__ uint32_t cells_that_are_numbers(bool pix_ok, int u0, int wvalid, int kpl) {
+    // cell k is a number iff 0 <= u0 + k < wvalid
+    int klo = -u0, khi = wvalid - u0;
+    klo = klo < 0 ? 0 : klo;
+    khi = khi > kpl ? kpl : khi;
+    const uint32_t m = (khi > klo && pix_ok) ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
+    return m;
+}
+__device__ __forceinline__ uint32_t keep_numbers(uint32_t cc, uint32_t vm, int k, uint32_t invpk) {
+    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)vm, k, 1), m2 = (uint32_t)__builtin_amdgcn_sbfe((int)vm, k + 2, 1);
+    const uint32_t mask = __builtin_amdgcn_perm(m2, m0, 0x07060100u);  // low half from m0, high half from m2
+    return (cc & mask) | (invpk & ~mask);
+}
+
+struct hpc_args {
+    const uint32_t* codeL;  // [H][W], zeroed guards of kCodePad dwords around the image (k_matching.hip census_codes)
+    const uint32_t* codeR;
+    uint8_t* ldir;          // volume 0: the pair's sums, [H][W][Dp] bytes in lane-map order
+    int H, W, D, Dp, d0, o;
+    uint32_t P1, P2, invalid_cost;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_codes_kernel(hpc_args a) {
+    constexpr int Q = KPL / 4;
+    constexpr int NQ = Q + 1;  // 16-byte pieces of right words per group of four pixels
+    static_assert(KPL % 4 == 0, "whole dwords per lane");
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const int gwave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves8 + (threadIdx.x >> 6));
+    const int H = a.H, W = a.W, D = a.D, o = a.o;
+    if (gwave * kLines8 >= H) return;
+    const int line = min(gwave * kLines8 + grp, H - 1);  // surplus groups of the last wave repeat the last row (same bytes)
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < D;
+    const int nact = (D + KPL - 1) / KPL;
+    const int subc = sub < nact ? sub : nact - 1;  // lanes without a disparity read the last lane's words (in bounds, unused)
+    uint32_t padA[Q], padB[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int d = d_first + 4 * q;
+        padA[q] = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
+        padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
+    }
+    const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
+    const uint32_t* const rowR = a.codeR + (ptrdiff_t)line * W + a.d0 + subc * KPL;  // right word of cell (c, k): rowR[c + k]
+    const uint32_t* const rowL = a.codeL + (ptrdiff_t)line * W;
+    const bool rows_ok = gwave * kLines8 >= o && gwave * kLines8 + kLines8 - 1 < H - o;  // (uniform)
+    const bool line_ok = line >= o && line < H - o;
+    const uint32_t wvalid = (uint32_t)(W - 2 * o);
+    const uint32_t invpk = a.invalid_cost | (a.invalid_cost << 16);
+    const int ngroups = (W + 3) / 4;
+    struct words_t { uint32_t r[4 * NQ]; uint32_t l[4]; };
+    struct sum_t { uint32_t x[Q]; };
+
+    auto pass = [&](auto acc_tag) {
+        constexpr bool ACC = decltype(acc_tag)::value;
+        uint8_t* const pix0 = a.ldir + (size_t)line * W * a.Dp + d_first;        // this lane's bytes of pixel (line, 0)
+        const uint8_t* const pin0 = pix0 - (lane_active ? 0 : d_first);          // lanes without a disparity re-read lane 0
+        auto fetch = [&](int jg, words_t& w) {
+            const uint32_t* pr = rowR + 4 * jg;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) __builtin_memcpy(&w.r[4 * i], pr + 4 * i, 16);  // (4-byte aligned: the rows start anywhere)
+            __builtin_memcpy(w.l, rowL + 4 * jg, 16);
+        };
+        sum_t prev[4];
+        if (ACC) {
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {  // the first four columns of the walk (from the right): slot = column & 3
+                int c = (W - 1) - ((W - 1 - uu) & 3);
+                c = c < 0 ? 0 : c;
+                __builtin_memcpy(prev[uu].x, pin0 + (size_t)c * a.Dp, 4 * Q);
+            }
+        }
+        uint32_t A[Q], B[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
+        uint32_t M = 0u;
+
+        auto step = [&](int c, const words_t& w, auto u_tag, bool all_ok) {
+            constexpr int U = decltype(u_tag)::value;
+            // costs of the pixel: (d, d+2) and (d+1, d+3) pairs, padded disparities carry kPad16
+            uint32_t ccA[Q], ccB[Q];
+            const uint32_t lw = w.l[U];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t a0 = __builtin_popcount(lw ^ w.r[U + 4 * q]) + (padA[q] & 0xffffu);
+                const uint32_t a2 = __builtin_popcount(lw ^ w.r[U + 4 * q + 2]) + (padA[q] >> 16);
+                const uint32_t b1 = __builtin_popcount(lw ^ w.r[U + 4 * q + 1]) + (padB[q] & 0xffffu);
+                const uint32_t b3 = __builtin_popcount(lw ^ w.r[U + 4 * q + 3]) + (padB[q] >> 16);
+                ccA[q] = a0 | (a2 << 16);
+                ccB[q] = b1 | (b3 << 16);
+            }
+            if (!all_ok) {  // (uniform; the image's borders)
+                asm volatile("; cells that are not numbers" ::);
+                const uint32_t vm = cells_that_are_numbers(line_ok && c >= o && c < W - o, c + a.d0 + d_first - o, (int)wvalid, KPL);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    ccA[q] = keep_numbers(ccA[q], vm, 4 * q, invpk) | padA[q];
+                    ccB[q] = keep_numbers(ccB[q], vm, 4 * q + 1, invpk) | padB[q];
+                }
+            }
+            const uint32_t belowB = dpp8<0x111>(kPadPk, B[Q - 1]);
+            const uint32_t aboveA = dpp8<0x101>(kPadPk, A[0]);
+            const uint32_t mp2 = M + P2pk, negM = 0u - M;
+            uint32_t nA[Q], nB[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
+                const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
+                const uint32_t tA = hmin3(A[q], hmin(loA, B[q]) + P1pk, mp2);
+                const uint32_t tB = hmin3(B[q], hmin(A[q], hiB) + P1pk, mp2);
+                nA[q] = add3(tA, ccA[q], negM);
+                nB[q] = add3(tB, ccB[q], negM);
+            }
+            if (lane_active) {
+                uint32_t packed[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) packed[q] = (nA[q] | (nB[q] << 8)) + (ACC ? prev[U].x[q] : 0u);  // bytes d .. d+3 (pads spill upwards only)
+                __builtin_memcpy(pix0 + (size_t)c * a.Dp, packed, 4 * Q);
+            }
+            if (ACC && c >= 4) __builtin_memcpy(prev[U].x, pin0 + (size_t)(c - 4) * a.Dp, 4 * Q);  // (uniform) four steps ahead
+            uint32_t m = hmin(nA[0], nB[0]);
+#pragma unroll
+            for (int q = 1; q < Q; ++q) m = hmin3(m, nA[q], nB[q]);
+            uint32_t m1 = m & 0xffffu, m2 = m >> 16;
+            uint32_t lmin = m1 < m2 ? m1 : m2;
+            {
+                uint32_t t;
+                t = dpp8<0x128>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+                t = dpp8<0x124>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+                t = dpp8<0x122>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+                t = dpp8<0x121>(0xffffffffu, lmin); lmin = lmin < t ? lmin : t;
+            }
+            M = lmin | (lmin << 16);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { A[q] = nA[q]; B[q] = nB[q]; }
+        };
+        // one group of four pixels from `cur`, the next group's words on their way into `nxt`
+        auto group = [&](int jg, const words_t& cur, words_t& nxt) {
+            const int jn = ACC ? jg - 1 : jg + 1;
+            if (jn >= 0 && jn < ngroups) fetch(jn, nxt);  // (uniform)
+            const int c4 = 4 * jg;
+            const bool all_ok = rows_ok && c4 >= o && c4 + 3 < W - o && c4 + a.d0 >= o && c4 + 3 + a.d0 + D - 1 < W - o;
+            if (ACC) {
+                if (c4 + 3 < W) step(c4 + 3, cur, std::integral_constant<int, 3>{}, all_ok);
+                if (c4 + 2 < W) step(c4 + 2, cur, std::integral_constant<int, 2>{}, all_ok);
+                if (c4 + 1 < W) step(c4 + 1, cur, std::integral_constant<int, 1>{}, all_ok);
+                step(c4, cur, std::integral_constant<int, 0>{}, all_ok);
+            } else {
+                step(c4, cur, std::integral_constant<int, 0>{}, all_ok);
+                if (c4 + 1 < W) step(c4 + 1, cur, std::integral_constant<int, 1>{}, all_ok);
+                if (c4 + 2 < W) step(c4 + 2, cur, std::integral_constant<int, 2>{}, all_ok);
+                if (c4 + 3 < W) step(c4 + 3, cur, std::integral_constant<int, 3>{}, all_ok);
+            }
+        };
+        words_t wa, wb;
+        int jg = ACC ? ngroups - 1 : 0;
+        fetch(jg, wa);
+        for (int left = ngroups; left > 0; --left) {  // (ONE copy of the four steps in the instruction stream: the words change
+            group(jg, wa, wb);                        //  places at the end of a group, 4 (NQ + 1) moves per four steps)
+            wa = wb;
+            jg += ACC ? -1 : 1;
+        }
+    };
+    pass(std::false_type{});
+    pass(std::true_type{});
+}
+
+// ---- the horizontal pair for SHORT images, from the census words: one image row per wavefront ---------------------------------
+// With four rows per wavefront a 592-row tile (an 8-rank run's) has 148 wavefronts for 1024 SIMDs, each a chain of 2 W steps of
+// ~190 instructions: 2.9 of the tile's 3.7 ms with 85 % of the SIMDs empty.  Here a wavefront owns ONE row: 64 lanes x KPL = 4 or 8
+// disparities (D <= 256 / 512), a third of the instructions per step and four times the wavefronts.  Same recurrence, same
+// bits; the 64-lane minimum is six in-place v_min_u32_dpp and lives in a scalar register.  The costs come from the census words
+// (no cost volume: a lane map of its own would need a cost format of its own): a lane's words of pixel c are the row's right words
+// c + d_first .. c + d_first + KPL - 1, kept in a ring of 16 registers indexed by (column + k) & 15 - the loop is unrolled 16
+// times, so every index is a constant - into which ONE new word per step arrives 16 - KPL steps before its first use; the left
+// words of 64 columns sit in one register, lane = column & 63, and are handed out by v_readlane.  The sums leave in natural
+// disparity order at the family lane map's pixel stride Dp (the last lane stores what fits).
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"  // lane 15 of every row holds the row's minimum
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // into rows 1, 3
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // into rows 2, 3: lane 63 holds the minimum
+        "s_nop 1"
+        : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int KPL>
+__global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
+    // A workgroup = one image row, two wavefronts: wavefront 0 walks it from the left, wavefront 1 from the right; each STORES
+    // its path costs on the first half of its walk (nobody has been there), both meet at one barrier, and each ADDS on the second
+    // half to what the other stored (read 16 columns ahead through the L1-bypassing path: the bytes came from another wavefront).
+    // The walk is ONE loop over blocks of 16 columns whose body issues every load and store unconditionally - columns past the
+    // row's end and the read-back of the first half carry out-of-range offsets (loads return 0, stores are dropped) - because the
+    // compiler's wait-count pass counts only unconditional memory operations (pmx_buf.h): the ring of right words (one per
+    // step, 9 to 12 steps ahead) and the read-back ring (16 steps ahead) are then waited for with the steady state's counts.
+    constexpr int Q = KPL / 4;
+    constexpr unsigned kGuard = 1024u * 4u;  // bytes of zeroed guard in front of a code image (k_matching.hip kCodePad)
+    static_assert(KPL == 4 || KPL == 8, "64 lanes x 4 or 8 disparities");
+    const int lane = threadIdx.x & 63;
+    const bool backward = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;
+    const int row = blockIdx.x;
+    const int H = a.H, W = a.W, D = a.D, o = a.o;
+    const int d_first = lane * KPL;
+    const bool lane_active = d_first < D;
+    const int nact = (D + KPL - 1) / KPL;
+    const int lanec = lane < nact ? lane : nact - 1;  // lanes without a disparity read the last lane's words (in bounds, unused)
+    uint32_t padA[Q], padB[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int d = d_first + 4 * q;
+        padA[q] = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
+        padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
+    }
+    const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
+    const uint32_t invpk = a.invalid_cost | (a.invalid_cost << 16);
+    const bool row_ok = row >= o && row < H - o;
+    const int wvalid = W - 2 * o;
+    // (descriptor of the row, lane-constant offset, scalar offset of the column): no per-step address arithmetic in the vector unit
+    const unsigned row_bytes = (unsigned)W * (unsigned)a.Dp;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ldir + (size_t)row * row_bytes), 0, row_bytes, kRsrcWord3);
+    const unsigned code_span = (unsigned)W * 4u + 2u * kGuard;  // the row's words and a guard's length on both sides
+    const __amdgpu_buffer_rsrc_t rsR =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(a.codeR + (ptrdiff_t)row * W) - kGuard), 0, code_span, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rsL =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(a.codeL + (ptrdiff_t)row * W) - kGuard), 0, code_span, kRsrcWord3);
+    const unsigned offR = kGuard + (unsigned)((a.d0 + lanec * KPL) * 4);  // + 4 (c + k): right word of cell (c, k)
+    const unsigned offL = kGuard + (unsigned)(lane & 15) * 4u;            // + 4 c16: left word of column c16 + (lane & 15)
+    // the volume's pixel stride is the family lane map's: the last lane stores what fits (dword q iff d_first + 4 q < Dp)
+    const bool fits0 = d_first < a.Dp, fits1 = d_first + 4 < a.Dp;
+    const unsigned offS64 = (Q == 2 && fits1) ? (unsigned)d_first : kOob;                   // both dwords
+    const unsigned offS32 = (Q == 2 ? (fits0 && !fits1) : fits0) ? (unsigned)d_first : kOob;  // the first one only
+    unsigned offP = kOob;  // read-back: nothing on the first half (loads return 0), the lane's bytes on the second
+    const int nblk = (W + 15) / 16, hb = nblk / 2;  // blocks [0, hb) are the forward walk's first half
+
+    uint32_t wr[16];        // right words: slot (column + k) & 15
+    uint32_t Lcur, Lnxt;    // left words of this block of 16 columns and of the next: lane & 15 = column & 15
+    uint32_t prev[16][Q];   // what the other wavefront stored: slot column & 15, requested 16 columns ahead
+    uint32_t A[Q], B[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
+    uint32_t M = 0u;  // (wave-uniform: a scalar register)
+
+    auto load_prev = [&](int c, uint32_t (&pv)[Q]) {  // the other wavefront's bytes of column c (sc1: past this CU's L1)
+        const unsigned so = (unsigned)c * (unsigned)a.Dp;
+        if constexpr (Q == 1) {
+            pv[0] = __builtin_amdgcn_raw_buffer_load_b32(rsO, offP, so, 16);
+        } else {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsO, offP, so, 16);
+            pv[0] = t.x; pv[1] = t.y;
+        }
+    };
+    auto step = [&](int c, auto u_tag, auto dir_tag) {
+        constexpr int U = decltype(u_tag)::value;
+        constexpr bool BACK = decltype(dir_tag)::value;
+        const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)Lcur, U);
+        uint32_t ccA[Q], ccB[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t a0 = __builtin_popcount(lw ^ wr[(U + 4 * q) & 15]) + (padA[q] & 0xffffu);
+            const uint32_t a2 = __builtin_popcount(lw ^ wr[(U + 4 * q + 2) & 15]) + (padA[q] >> 16);
+            const uint32_t b1 = __builtin_popcount(lw ^ wr[(U + 4 * q + 1) & 15]) + (padB[q] & 0xffffu);
+            const uint32_t b3 = __builtin_popcount(lw ^ wr[(U + 4 * q + 3) & 15]) + (padB[q] >> 16);
+            ccA[q] = a0 | (a2 << 16);
+            ccB[q] = b1 | (b3 << 16);
+        }
+        const bool all_ok = row_ok && c >= o && c < W - o && c + a.d0 >= o && c + a.d0 + D - 1 < W - o;
+        if (!all_ok) {  // (uniform; the image's borders - no memory operation in here)
+            asm volatile("; cells that are not numbers" ::);
+            const uint32_t vm = cells_that_are_numbers(row_ok && c >= o && c < W - o, c + a.d0 + d_first - o, wvalid, KPL);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                ccA[q] = keep_numbers(ccA[q], vm, 4 * q, invpk) | padA[q];
+                ccB[q] = keep_numbers(ccB[q], vm, 4 * q + 1, invpk) | padB[q];
+            }
+            if (BACK && c >= W) {  // the backward walk's first block may begin past the row's end: the path starts at column W - 1
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
+                M = 0u;
+            }
+        }
+        // one new right word: forward, column c's first word is dead and column c + 16's arrives in its slot; backward, column
+        // c's last word is dead and the first word of column c + KPL - 17 arrives (the descriptor starts a guard's length before
+        // the row: scalar offsets are unsigned)
+        if (BACK) wr[(U + KPL - 1) & 15] = __builtin_amdgcn_raw_buffer_load_b32(rsR, offR - 64u + (unsigned)(KPL - 1) * 4u, (unsigned)c * 4u, 0);
+        else wr[U] = __builtin_amdgcn_raw_buffer_load_b32(rsR, offR + 64u, (unsigned)c * 4u, 0);
+        const uint32_t belowB = dpp8<0x138>(kPadPk, B[Q - 1]);  // wave_shr:1 - the previous lane's (.., L[d_first - 1]); +inf in lane 0
+        const uint32_t aboveA = dpp8<0x130>(kPadPk, A[0]);      // wave_shl:1 - the next lane's (L[d_first + KPL], ..); +inf in lane 63
+        const uint32_t mp2 = M + P2pk, negM = 0u - M;
+        uint32_t nA[Q], nB[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
+            const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
+            const uint32_t tA = hmin3(A[q], hmin(loA, B[q]) + P1pk, mp2);
+            const uint32_t tB = hmin3(B[q], hmin(A[q], hiB) + P1pk, mp2);
+            nA[q] = add3(tA, ccA[q], negM);
+            nB[q] = add3(tB, ccB[q], negM);
+        }
+        {   // bytes d .. d+3 per dword (pads spill upwards only); on the second half the other wavefront's bytes are added
+            const unsigned so = (unsigned)c * (unsigned)a.Dp;  // (past the row's end: out of range, dropped)
+            uint32_t packed[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) packed[q] = (nA[q] | (nB[q] << 8)) + prev[U][q];
+            if constexpr (Q == 2) {
+                u32x2 t; t.x = packed[0]; t.y = packed[1];
+                __builtin_amdgcn_raw_buffer_store_b64(t, rsO, offS64, so, 0);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(packed[0], rsO, offS32, so, 0);
+        }
+        load_prev(BACK ? c - 16 : c + 16, prev[U]);  // the slot just used (first half, and columns outside the row: zeros)
+        uint32_t m = hmin(nA[0], nB[0]);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) m = hmin3(m, nA[q], nB[q]);
+        const uint32_t m1 = m & 0xffffu, m2 = m >> 16;
+        const uint32_t lmin = wave_min_u32(m1 < m2 ? m1 : m2);
+        M = lmin | (lmin << 16);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { A[q] = nA[q]; B[q] = nB[q]; }
+    };
+    auto walk = [&](auto dir_tag) {
+        constexpr bool BACK = decltype(dir_tag)::value;
+        const int b0 = BACK ? nblk - 1 : 0, db = BACK ? -1 : 1;
+        {   // prologue: the first block's words (columns below 0 / past the row read the guards or other rows: never used)
+            const int c16 = 16 * b0;
+            const int top = BACK ? c16 + 15 + KPL - 1 : c16 + 15;  // highest word index (column + k) of the first 16 needed
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl)
+                wr[sl] = __builtin_amdgcn_raw_buffer_load_b32(rsR, offR, (unsigned)(top - ((top - sl) & 15)) * 4u, 0);
+            Lcur = __builtin_amdgcn_raw_buffer_load_b32(rsL, offL, (unsigned)c16 * 4u, 0);
+            Lnxt = __builtin_amdgcn_raw_buffer_load_b32(rsL, BACK ? offL - 64u : offL + 64u, (unsigned)c16 * 4u, 0);
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) load_prev(0, prev[sl]);  // (offP is out of range: zeros)
+        }
+        PMX_LOOP_ENTRY_DRAIN();
+        for (int n = 0; n < nblk; ++n) {
+            const int b = b0 + db * n;
+            const int c16 = 16 * b;
+            if (b == (BACK ? hb - 1 : hb)) {
+                // the meeting point: everybody's first half is in memory before anybody's second half reads it; from here on the
+                // read-back is real (this block's 16 columns now, then 16 columns ahead in every step)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+                offP = lane_active ? (unsigned)d_first : 0u;  // lanes without a disparity re-read lane 0 (nothing is stored)
+#pragma unroll
+                for (int sl = 0; sl < 16; ++sl) load_prev(c16 + sl, prev[sl]);
+                PMX_LOOP_ENTRY_DRAIN();
+            }
+#define PMX_HROW_STEP(UV) step(c16 + UV, std::integral_constant<int, UV>{}, dir_tag)
+            if (BACK) {
+                PMX_HROW_STEP(15); PMX_HROW_STEP(14); PMX_HROW_STEP(13); PMX_HROW_STEP(12); PMX_HROW_STEP(11); PMX_HROW_STEP(10);
+                PMX_HROW_STEP(9); PMX_HROW_STEP(8); PMX_HROW_STEP(7); PMX_HROW_STEP(6); PMX_HROW_STEP(5); PMX_HROW_STEP(4);
+                PMX_HROW_STEP(3); PMX_HROW_STEP(2); PMX_HROW_STEP(1); PMX_HROW_STEP(0);
+            } else {
+                PMX_HROW_STEP(0); PMX_HROW_STEP(1); PMX_HROW_STEP(2); PMX_HROW_STEP(3); PMX_HROW_STEP(4); PMX_HROW_STEP(5);
+                PMX_HROW_STEP(6); PMX_HROW_STEP(7); PMX_HROW_STEP(8); PMX_HROW_STEP(9); PMX_HROW_STEP(10); PMX_HROW_STEP(11);
+                PMX_HROW_STEP(12); PMX_HROW_STEP(13); PMX_HROW_STEP(14); PMX_HROW_STEP(15);
+            }
+#undef PMX_HROW_STEP
+            // the left words: the next block's have had 16 steps to arrive, the one after's are requested
+            Lcur = Lnxt;
+            Lnxt = __builtin_amdgcn_raw_buffer_load_b32(rsL, BACK ? offL - 128u : offL + 128u, (unsigned)c16 * 4u, 0);
+        }
+    };
+    if (backward) walk(std::true_type{});
+    else walk(std::false_type{});
 }
 
 // The horizontal pair for SHORT images (row tiles of a multi-GPU run): with one wavefront per four rows a 592-row tile has 148
@@ -631,13 +1025,6 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     const int ndw = five ? (kpl + 5) / 6 : kpl / 4;
     const int Dc = nact * ndw * 4;
     const size_t cvol = (size_t)H * W * Dc;
-    if (cv->cost8_bytes < cvol) {
-        pmx_pool_free(ctx, cv->cost8);
-        cv->cost8 = nullptr;
-        cv->cost8_bytes = 0;
-        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->cost8, cvol + 64));
-        cv->cost8_bytes = cvol;
-    }
     // Direction families (k_sgmfam8.hip) when a family's sum fits a byte: three volumes (horizontal pair, downward family, upward
     // family) instead of eight.  PMX_SGM8_FAM=0 keeps the eight path volumes, =1 takes the families whatever the size (test hooks).
     // By default for wide images: the marching kernels want one 32-column window per CU and family (2560 columns x 2128 rows:
@@ -649,6 +1036,36 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         if (ef[0] == '0') fam = false;
         if (ef[0] == '1') fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u;
     }
+    // The horizontal pair: one wavefront per four rows (mode 1, tall images), the two-sided walk of the same lane map (mode 2), or -
+    // round 4, short images such as the row tiles of a multi-GPU run - one row per wavefront from the census words (mode 3:
+    // sgm_u8_hrow_codes_kernel).  PMX_SGM8_HPAIR=1 / 2 / 3 forces one: A/B hook.
+    // The family form WITHOUT a cost volume (round 4): with one census word per pixel (windows 3x3, 5x5) and the plain census
+    // geometry (no valid intervals from masks / grids) the SGM kernels can make a cell's Hamming cost where they use it - the cost
+    // kernel, its 0.8 B/cell of stores and the three reads of them go, 2.5 instead of 1 vector instruction per cell and pass
+    // come.  At 4096 x 4096 x 257 the step is no faster that way (14.1 against 13.8 ms: 25 % fewer bytes, 13 % more
+    // instructions), so tall images keep the cost volume; short ones, whose SIMDs are mostly idle, drop it together
+    // with the row-per-wavefront walk.  PMX_SGM8_CODES=1 / 0: both kernels from the words wherever legal / never.
+    const bool codes_ok = nw == 1 && !cv->has_range && cv->D <= 512;
+    const char* ehp = getenv("PMX_SGM8_HPAIR");
+    const char* ec = getenv("PMX_SGM8_CODES");
+    const bool codes_never = ec && ec[0] == '0', codes_always = ec && ec[0] == '1';
+    // (4096 columns x 257, one GPU, ms per step, row walk / two-sided / one-sided: 592 rows 3.0 / 3.5 / 4.9, 1104 rows 4.8 / 5.0 / 6.7,
+    //  2088 rows 9.2 / 8.8 / 9.7, 3072 rows - / 13.0 / 12.3: profiles/r04_tiles.txt, r03_e_shapes.txt)
+    int hp_mode = H < 2560 ? (H < 1536 && W >= 32 && codes_ok && !codes_never ? 3 : 2) : 1;
+    if (ehp && ehp[0] >= '1' && ehp[0] <= '3') hp_mode = ehp[0] - '0';
+    if (hp_mode == 3 && (!codes_ok || W < 32)) hp_mode = 2;
+    const bool two_sided = hp_mode == 2;
+    const bool hp_codes = fam && (hp_mode == 3 || (hp_mode == 1 && codes_ok && codes_always));
+    bool fam_codes = fam && codes_ok && !codes_never && (codes_always || hp_mode == 3);
+    if (const char* efc = getenv("PMX_SGM8_FAMCODES")) fam_codes = fam && codes_ok && efc[0] == '1';  // (A/B hook: the marching kernel alone)
+    const bool from_codes = hp_codes && fam_codes;  // no cost volume at all
+    if (!from_codes && cv->cost8_bytes < cvol) {
+        pmx_pool_free(ctx, cv->cost8);
+        cv->cost8 = nullptr;
+        cv->cost8_bytes = 0;
+        PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->cost8, cvol + 64));
+        cv->cost8_bytes = cvol;
+    }
     const int nvol = fam ? 3 : 8;
     if (cv->ldir_bytes < (size_t)nvol * vol) {
         pmx_pool_free(ctx, cv->ldir);
@@ -659,8 +1076,8 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     }
     cv->nvol = nvol;
     cv->Dp = Dp; cv->gl = 16; cv->kpl = kpl; cv->dstride = vol;
-    {
-        pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
+    auto launch_cost = [&](hipStream_t cst) -> int {
+        pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST, cst);
         cost8_args c;
         c.codeL = cv->codeL; c.codeR = cv->codeR; c.cost = cv->cost8;
         c.range = cv->has_range ? cv->range : nullptr;
@@ -669,8 +1086,8 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         const size_t want = ((size_t)H * W + 15) / 16;  // 4 pixels per wave, 4 waves per block
         const dim3 grid((unsigned)(want < 65536 ? want : 65536));
 #define PMX_COST8(NWV, KPLV)                                                                                                  \
-    if (five && NWV == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, (NWV == 1 ? 5 : 8)>), grid, dim3(256), 0, ctx->stream, c); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, 8>), grid, dim3(256), 0, ctx->stream, c)
+    if (five && NWV == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, (NWV == 1 ? 5 : 8)>), grid, dim3(256), 0, cst, c); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, 8>), grid, dim3(256), 0, cst, c)
 #define PMX_COST8_KPL(NWV)                 \
     switch (kpl) {                         \
         case 4: PMX_COST8(NWV, 4); break;  \
@@ -688,8 +1105,14 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         }
 #undef PMX_COST8_KPL
 #undef PMX_COST8
+        PMX_HIP(hipGetLastError());
+        return PMX_OK;
+    };
+    const bool cost_async = getenv("PMX_SGM8_COST_ASYNC") && getenv("PMX_SGM8_COST_ASYNC")[0] == '1';
+    if (!from_codes && !(fam && cost_async)) {
+        const int rcc = launch_cost(ctx->stream);
+        if (rcc) return rcc;
     }
-    PMX_HIP(hipGetLastError());
     sgm8_args a;
     a.cost = cv->cost8; a.ldir = cv->ldir; a.dstride = cv->dstride;
     a.H = H; a.W = W; a.D = cv->D; a.Dp = Dp; a.Dc = Dc; a.P1 = P1; a.P2 = P2;
@@ -711,11 +1134,12 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
             PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
             hs = ctx->aux_stream;
         }
+        if (!from_codes && cost_async) {
+            const int rcc = launch_cost(hs);
+            if (rcc) return rcc;
+        }
         {   // volume 0: the horizontal pair
             pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED, hs);
-            // one wavefront per four rows, or the two-sided walk for short images (PMX_SGM8_HPAIR=1 / 2 forces one: A/B hook)
-            const char* ehp = getenv("PMX_SGM8_HPAIR");
-            const bool two_sided = ehp ? ehp[0] == '2' : H < 2560;  // (2128 rows: 8.9 against 9.7 ms; 3072 rows: 13.0 against 12.3)
             const int ngroups = (H + kLines8 - 1) / kLines8;
             const dim3 hgrid(two_sided ? (ngroups + 1) / 2 : (ngroups + kWaves8 - 1) / kWaves8), hblock(kWaves8 * 64);
 #define PMX_HP(KPLV)                                                                                                       \
@@ -723,6 +1147,26 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     else if (two_sided) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair2_kernel<KPLV, 8>), hgrid, hblock, 0, hs, a);       \
     else if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 5>), hgrid, hblock, 0, hs, a);             \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_kernel<KPLV, 8>), hgrid, hblock, 0, hs, a)
+            if (hp_codes) {
+                hpc_args h;
+                h.codeL = cv->codeL; h.codeR = cv->codeR; h.ldir = cv->ldir;
+                h.H = H; h.W = W; h.D = cv->D; h.Dp = Dp; h.d0 = cv->d0; h.o = cv->win / 2;
+                h.P1 = P1; h.P2 = P2; h.invalid_cost = invalid_cost;
+#define PMX_HPC(KPLV) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_codes_kernel<KPLV>), hgrid, hblock, 0, hs, h)
+                if (hp_mode == 3) {
+                    const dim3 rgrid(H), rblock(128);  // one row per workgroup: a wavefront from each end
+                    if (cv->D <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hrow_codes_kernel<4>), rgrid, rblock, 0, hs, h);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hrow_codes_kernel<8>), rgrid, rblock, 0, hs, h);
+                } else
+                switch (kpl) {
+                    case 4: PMX_HPC(4); break;
+                    case 8: PMX_HPC(8); break;
+                    case 12: PMX_HPC(12); break;
+                    case 16: PMX_HPC(16); break;
+                    default: PMX_HPC(20); break;
+                }
+#undef PMX_HPC
+            } else
             switch (kpl) {
                 case 4: PMX_HP(4); break;
                 case 8: PMX_HP(8); break;
@@ -735,7 +1179,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         PMX_HIP(hipGetLastError());
         if (overlap) PMX_HIP(hipEventRecord(ctx->aux_join, ctx->aux_stream));
         // volumes 1, 2: the downward and the upward family, one launch
-        const int rcf = pmx_launch_sgm_fam8(ctx, cv, kpl, five, Dc, cv->ldir + vol, vol, P1, P2, 3);
+        const int rcf = pmx_launch_sgm_fam8(ctx, cv, kpl, five, Dc, cv->ldir + vol, vol, P1, P2, 3, fam_codes, invalid_cost);
         if (overlap) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));  // whoever reads the volumes next waits for both
         return rcf;
     }

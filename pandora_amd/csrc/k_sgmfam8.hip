@@ -72,42 +72,13 @@ struct fam8_args {
     unsigned* ctl;        // [0] ticket counter (zero at launch), [1] error word
     int fam0, nfam;       // families of this launch: fam0, fam0 + 1, ... (0 = downward, 1 = upward)
     int prio;             // wave priority of this launch's wavefronts (beside the horizontal-pair kernel on the second stream)
+    // CODES form: no cost volume - the Hamming costs are computed here from the census words (one per pixel)
+    const uint32_t* codes;  // start of the code allocation: [guard | left image | guard | right image | guard], zeroed guards
+    unsigned code_bytes;    // ... its size
+    unsigned codeL_off, codeR_off;  // dword index of pixel (0, 0) of the left / right code image in it
+    int d0, o;              // first disparity, half census window (cells whose windows leave an image carry invalid_cost)
+    uint32_t invalid_cost;
 };
-
-template <int N>
-__device__ __forceinline__ void load_dwords(__amdgpu_buffer_rsrc_t rs, unsigned off, uint32_t (&x)[N]) {
-    static_assert(N >= 1 && N <= 5, "cost dwords per lane");
-    if constexpr (N == 1) {
-        x[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
-    } else if constexpr (N == 2) {
-        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
-        x[0] = t.x; x[1] = t.y;
-    } else if constexpr (N == 3) {
-        const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
-        x[0] = t.x; x[1] = t.y; x[2] = t.z;
-    } else {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
-        if constexpr (N == 5) x[4] = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 16, 0, 0);
-    }
-}
-template <int N>
-__device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, unsigned off, const uint32_t (&x)[N]) {
-    static_assert(N >= 1 && N <= 5, "bytes per lane / 4");
-    if constexpr (N == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(x[0], rs, off, 0, 0);
-    } else if constexpr (N == 2) {
-        u32x2 t; t.x = x[0]; t.y = x[1];
-        __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, 0, 0);
-    } else if constexpr (N == 3) {
-        u32x3 t; t.x = x[0]; t.y = x[1]; t.z = x[2];
-        __builtin_amdgcn_raw_buffer_store_b96(t, rs, off, 0, 0);
-    } else {
-        u32x4 t; t.x = x[0]; t.y = x[1]; t.z = x[2]; t.w = x[3];
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, 0, 0);
-        if constexpr (N == 5) __builtin_amdgcn_raw_buffer_store_b32(x[4], rs, off == kOob ? kOob : off + 16, 0, 0);
-    }
-}
 
 // One path, one pixel per 16-lane row: new path costs (nA, nB) from the predecessor's (A, B, M); returns the packed minimum of the
 // lane's new costs (both halves still to be reduced).
@@ -146,7 +117,14 @@ __device__ __forceinline__ void group_min3(uint32_t& a, uint32_t& b, uint32_t& c
     a |= a << 16; b |= b << 16; c |= c << 16;
 }
 
-template <int KPL, int CBITS, int NW, int PF>
+// CODES: the costs of a row are not read from a volume but made from the census words of the row (census.cpp:132-172: Hamming
+// distance of the two bit strings; cells whose window leaves the left or the right image stay NaN there = invalid_cost here).
+// The compute wavefronts fetch the window's words two rows ahead (one dword per thread: CW left words, CW + 16 KPL + 3 right
+// words - the window's pixels reach disparities d0 .. d0 + 16 KPL - 1), park them in LDS one row ahead - the right words four
+// times, copy g shifted by g words, so that the 16-byte reads of a lane of pixel group g are aligned (an unaligned ds_read_b128
+// is replayed at 64 cycles) - and every lane reads its KPL words and the pixel's left word where the old form read NDW cost
+// dwords from memory: v_xor, v_bcnt (whose addend is the pad of a disparity >= D), v_lshl_or per pair of cells.
+template <int KPL, int CBITS, int NW, int PF, bool CODES>
 __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
     constexpr int Q = KPL / 4;                  // (A, B) register pairs per lane and path
     constexpr int NR = 2 * Q;                   // registers per lane and path
@@ -161,10 +139,17 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
     constexpr int NG = 3 * NVB + 2;             // blocks per (row, border): V[CW-1], A[CW-1], A[CW-2], then their three minima
     constexpr int NQ = (NG + 63) / 64;
     constexpr int NGP = NQ * 64;
+    constexpr int NT = NW * 64;                 // compute threads
+    constexpr int CS = CW + 16 * KPL;           // CODES: right words per copy (a lane of column j reads words j + sub KPL ...)
+    constexpr int NSRC = CS + 3;                // ... distinct right words of a row (copy g starts g words further)
+    constexpr int NLOADS = NSRC + CW;           // ... + the left words
+    constexpr int NLD = (NLOADS + NT - 1) / NT; // ... dwords fetched per thread and row
+    constexpr int CPB = 4 * CS + CW;            // ... LDS dwords per row parity
     static_assert(KPL % 4 == 0 && KPL >= 4 && KPL <= 20, "whole dwords per lane");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds8[];
     typedef __attribute__((address_space(3))) int lds_int;
     volatile lds_int* ctl = (volatile lds_int*)(lds_int*)(lds8 + 2 * EBUF);  // [0] ticket, [1], [2] abort flag by row parity
+    uint32_t* const cbuf = lds8 + 2 * EBUF + 4;  // CODES: [row parity][4 copies of CS right words | CW left words]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -340,20 +325,64 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
 
     // loads of the costs run PF rows ahead in a register ring
     int pr = r_lo;
-    struct slot_t { uint32_t x[NDW]; };
+    struct slot_t { uint32_t x[CODES ? NLD : NDW]; };
     slot_t ring[PF];
+    // CODES: thread tid fetches word m = tid + i NT of the row's list: right words of image columns cb + d0 + m (m < NSRC),
+    // then the left words of columns cb + m - NSRC, cb = column of the window's first pixel.  One descriptor over the whole
+    // code allocation: a column outside the image reads a neighbouring row's words or a zeroed guard (such cells are invalid
+    // and never look at their words), an offset outside the allocation reads 0.
+    const int tid = wave * 64 + lane;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)a.codes, 0, a.code_bytes, kRsrcWord3);
+    int coff[NLD];  // dword index of this thread's words in the row `pr`, relative to the row's first pixel
+    if constexpr (CODES) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = tid + i * NT;
+            coff[i] = m < NSRC ? (int)a.codeR_off + a.d0 + m : (m < NLOADS ? (int)a.codeL_off + m - NSRC : -(1 << 28));
+        }
+    }
+    int code_row = rimg_lo * W + (base - r_lo);  // dword index of the prefetched row's window start, within an image
     auto prefetch = [&](slot_t& sl) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cost_row, 0, cost_row_bytes, kRsrcWord3);
-        load_dwords<NDW>(rs, ((unsigned)pc < (unsigned)W && lane_active) ? pcoff : kOob, sl.x);
-        if (pr < r_hi) {  // (uniform; past the last row the last one is read again)
-            ++pr;
-            cost_row += cost_step;
-            --pc;
-            pcoff -= (unsigned)a.Dc;
+        if constexpr (CODES) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                sl.x[i] = __builtin_amdgcn_raw_buffer_load_b32(crs, (unsigned)(code_row + coff[i]) * 4u, 0, 0);
+            if (pr < r_hi) {
+                ++pr;
+                code_row += (fam ? -W : W) - 1;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cost_row, 0, cost_row_bytes, kRsrcWord3);
+            load_dwords<NDW>(rs, ((unsigned)pc < (unsigned)W && lane_active) ? pcoff : kOob, sl.x);
+            if (pr < r_hi) {  // (uniform; past the last row the last one is read again)
+                ++pr;
+                cost_row += cost_step;
+                --pc;
+                pcoff -= (unsigned)a.Dc;
+            }
+        }
+    };
+    // CODES: the fetched words of a row go to LDS one row before they are used (row parity of the row they belong to)
+    auto park = [&](int row, const slot_t& sl) {
+        uint32_t* Cn = cbuf + (row & 1) * CPB;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = tid + i * NT;
+            if (m < NSRC) {
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    if (m - gg >= 0 && m - gg < CS) Cn[gg * CS + m - gg] = sl.x[i];
+            } else if (m < NLOADS) {
+                Cn[4 * CS + m - NSRC] = sl.x[i];
+            }
         }
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) prefetch(ring[i]);
+    if constexpr (CODES) {  // the first row's words are parked before the first barrier, its slot refilled (row r_lo + PF)
+        park(r_lo, ring[0]);
+        prefetch(ring[0]);
+    }
 
     uint32_t LBa[Q], LBb[Q];  // the path that stays in its lane group (predecessor column c+1)
     uint32_t MB = 0u;
@@ -393,15 +422,63 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
         uint32_t MA = Ep[EDIR + j * ES + 16 * KS];
         // costs of the pixel: (d, d+2) and (d+1, d+3) pairs, padded disparities carry kPad16
         uint32_t ccA[Q], ccB[Q];
+        if constexpr (CODES) {
+            const uint32_t* Cc = cbuf + (r & 1) * CPB;
+            const uint32_t* src = Cc + g * CS + wave * 4 + sub * KPL;  // copy g: word i = right word of local column i + g
+            uint32_t rw[KPL];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            if (CBITS == 8) {
-                ccA[q] = (sl.x[q] & 0x00ff00ffu) | padA[q];
-                ccB[q] = ((sl.x[q] >> 8) & 0x00ff00ffu) | padB[q];
-            } else {  // pair jj of the lane: bits 5 * (jj % 3) of both halves of dword jj / 3 (census_cost_u8_kernel)
-                constexpr uint32_t m5 = 0x001f001fu;
-                ccA[q] = ((sl.x[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
-                ccB[q] = ((sl.x[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
+            for (int q = 0; q < Q; ++q) {
+                const u32x4 t = *(const u32x4*)(src + 4 * q);
+                rw[4 * q] = t.x; rw[4 * q + 1] = t.y; rw[4 * q + 2] = t.z; rw[4 * q + 3] = t.w;
+            }
+            const uint32_t lw = Cc[4 * CS + j];
+            // Which cells are numbers (census.cpp:132-172): the pixel's window inside the left image, the window at column
+            // c + d inside the right one.  Wave-uniform test first: away from the borders every cell of the four pixels is.
+            const int rimg = fam ? H - 1 - r : r;
+            const int c0 = base - r + wave * 4;  // (uniform: column of the wavefront's first pixel)
+            const int o = a.o;
+            const bool all_ok = rimg >= o && rimg < H - o && c0 >= o && c0 + 3 < W - o && c0 + a.d0 >= o && c0 + 3 + a.d0 + D - 1 < W - o;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t a0 = __builtin_popcount(lw ^ rw[4 * q]) + (padA[q] & 0xffffu);
+                const uint32_t a2 = __builtin_popcount(lw ^ rw[4 * q + 2]) + (padA[q] >> 16);
+                const uint32_t b1 = __builtin_popcount(lw ^ rw[4 * q + 1]) + (padB[q] & 0xffffu);
+                const uint32_t b3 = __builtin_popcount(lw ^ rw[4 * q + 3]) + (padB[q] >> 16);
+                ccA[q] = a0 | (a2 << 16);
+                ccB[q] = b1 | (b3 << 16);
+            }
+            if (!all_ok) {  // (uniform: the image's borders)
+                asm volatile("; cells that are not numbers" ::);
+                // cell k of the lane is a number iff 0 <= u0 + k < W - 2 o, u0 = c + d0 + d_first - o (and the pixel's own window fits)
+                const bool pix_ok = rimg >= o && rimg < H - o && c >= o && c < W - o;
+                const int u0 = c + a.d0 + d_first - o;
+                int klo = -u0, khi = W - 2 * o - u0;
+                klo = klo < 0 ? 0 : klo;
+                khi = khi > KPL ? KPL : khi;
+                const uint32_t vm = (khi > klo && pix_ok) ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
+                const uint32_t invpk = a.invalid_cost | (a.invalid_cost << 16);
+                auto keep = [&](uint32_t cc, int k) {
+                    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)vm, k, 1), m2 = (uint32_t)__builtin_amdgcn_sbfe((int)vm, k + 2, 1);
+                    const uint32_t mask = __builtin_amdgcn_perm(m2, m0, 0x07060100u);  // low half from m0, high half from m2
+                    return (cc & mask) | (invpk & ~mask);
+                };
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    ccA[q] = keep(ccA[q], 4 * q) | padA[q];
+                    ccB[q] = keep(ccB[q], 4 * q + 1) | padB[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (CBITS == 8) {
+                    ccA[q] = (sl.x[q] & 0x00ff00ffu) | padA[q];
+                    ccB[q] = ((sl.x[q] >> 8) & 0x00ff00ffu) | padB[q];
+                } else {  // pair jj of the lane: bits 5 * (jj % 3) of both halves of dword jj / 3 (census_cost_u8_kernel)
+                    constexpr uint32_t m5 = 0x001f001fu;
+                    ccA[q] = ((sl.x[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
+                    ccB[q] = ((sl.x[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
+                }
             }
         }
         // paths that start at this pixel (first row, image border): (Lp, M) = (0, 0).  Rare: a wave-uniform branch
@@ -464,17 +541,20 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
         out_row += out_step;
         --c;
         ooff -= (unsigned)a.Dp;
+        if constexpr (CODES) park(r + 1, sl);  // (sl: the ring slot that holds row r + 1's words; refilled with row r + 1 + PF)
         prefetch(sl);
         __syncthreads();
     };
 
+    // ring slot of step u: the step's own costs - or, CODES, the words of the row after it (parked in LDS during the step)
+    constexpr int SH = CODES ? 1 : 0;
     int r = r_lo;
     bool dead = false;
     for (; r + PF <= r_hi + 1 && !dead; r += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (!dead) {
-                step(r + u, ring[u]);
+                step(r + u, ring[(u + SH) % PF]);
                 dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
             }
         }
@@ -483,18 +563,18 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
 #pragma unroll
     for (int u = 0; u < PF - 1; ++u) {
         if (r + u <= r_hi && !dead) {
-            step(r + u, ring[u]);
+            step(r + u, ring[(u + SH) % PF]);
             dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
         }
     }
 }
 
-template <int KPL, int CBITS, int NW>
+template <int KPL, int CBITS, int NW, bool CODES = false>
 int launch_fam8(pmx_ctx* ctx, const fam8_args& a, int nwg) {
     constexpr int PF = 3;
     constexpr int Q = KPL / 4, NR = 2 * Q, KS = (NR + 3) & ~3, ES = 16 * KS + 4, CW = NW * 4;
-    const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4) * sizeof(uint32_t);
-    auto kern = sgm_fam8_kernel<KPL, CBITS, NW, PF>;
+    const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4 + (CODES ? 2 * (4 * (CW + 16 * KPL) + CW) : 0)) * sizeof(uint32_t);
+    auto kern = sgm_fam8_kernel<KPL, CBITS, NW, PF, CODES>;
     PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 1) * 64), lds_bytes, ctx->stream, a);
     PMX_HIP(hipGetLastError());
@@ -517,7 +597,7 @@ bool pmx_fam8_supported(int kpl, int H) { return (kpl % 4) == 0 && kpl >= 4 && k
 
 // Both vertical families (fams: bit 0 downward, bit 1 upward) into out + f * dstride
 int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, uint8_t* out, size_t dstride, uint32_t P1, uint32_t P2,
-                        int fams) {
+                        int fams, bool from_codes, uint32_t invalid_cost) {
     const int nw = pmx_fam8_waves(cv->W), CW = nw * 4;
     const int Q = kpl / 4;
     const int NB = (cv->W + CW - 1) / CW;
@@ -535,13 +615,18 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.ctl = ctx->fam_ctl;
     a.fam0 = fam0; a.nfam = nfam;
     a.prio = getenv("PMX_SGM8_FAM_PRIO") ? atoi(getenv("PMX_SGM8_FAM_PRIO")) : 3;  // (0: 14.6 ms per 4096^2 x 257 step, 3: 13.9)
+    a.codes = cv->codes; a.code_bytes = (unsigned)cv->codes_bytes;
+    a.codeL_off = (unsigned)(cv->codeL - cv->codes); a.codeR_off = (unsigned)(cv->codeR - cv->codes);
+    a.d0 = cv->d0; a.o = cv->win / 2; a.invalid_cost = invalid_cost;
+    if (from_codes) PMX_CHECK(cv->codes && cv->codes_bytes < 0xfffff000ull, PMX_ERR_STATE, "pmx_sgm (family form): census codes missing or too large");
     const int nwin = (cv->W + cv->H - 2) / CW + 1;
     PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));  // the ticket; the error word is sticky
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY);
 #define PMX_FAM8(KPLV, CB)                                                                              \
     (nw == 8 ? launch_fam8<KPLV, CB, 8>(ctx, a, nwin * nfam) : launch_fam8<KPLV, CB, 4>(ctx, a, nwin * nfam))
-#define PMX_FAM8_KPL(KPLV) rc = five ? PMX_FAM8(KPLV, 5) : PMX_FAM8(KPLV, 8)
+#define PMX_FAM8C(KPLV) (nw == 8 ? launch_fam8<KPLV, 8, 8, true>(ctx, a, nwin * nfam) : launch_fam8<KPLV, 8, 4, true>(ctx, a, nwin * nfam))
+#define PMX_FAM8_KPL(KPLV) rc = from_codes ? PMX_FAM8C(KPLV) : (five ? PMX_FAM8(KPLV, 5) : PMX_FAM8(KPLV, 8))
         switch (kpl) {
             case 4: PMX_FAM8_KPL(4); break;
             case 8: PMX_FAM8_KPL(8); break;
@@ -550,6 +635,7 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
             default: PMX_FAM8_KPL(20); break;
         }
 #undef PMX_FAM8_KPL
+#undef PMX_FAM8C
 #undef PMX_FAM8
         if (rc) return rc;
     }

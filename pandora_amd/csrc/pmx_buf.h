@@ -15,6 +15,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kRsrcWord3 = 0x00020000;  // raw buffer: out-of-range loads return 0, out-of-range stores are dropped
 constexpr unsigned kOob = 0x80000000u;       // a byte offset beyond every row: lanes that must not touch memory use it
 
+// The compiler's wait-count pass merges a loop's entry state with its back-edge state, and at the entry a prefetch ring's loads
+// have just been issued: it then counts every load of the steady state as if only the prologue's few operations had followed it.
+// An explicit "everything has arrived" in front of the loop (one memory latency, once per wavefront) makes the entry state empty,
+// and the counts the pass derives are the steady state's.  The same pass counts NONE of the memory operations of a conditional
+// block (uniform or not) on the paths that merge behind it: inside a ring's loop every load and store is issued unconditionally
+// (masked lanes carry kOob), and an abort returns from inside the loop.  (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched)
+#define PMX_LOOP_ENTRY_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)
+
 // A lane's KPL consecutive floats move as 16-byte pieces, then an 8-byte one, then a 4-byte one (4-byte alignment is enough
 // for buffer instructions).  piece i = [piece_start(i), piece_start(i) + piece_width(i)).
 template <int KPL>
@@ -104,3 +112,40 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned ba
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t0), rs, toff, 0, 0);
     }
 }
+
+// ---- a lane's run of N = 1 .. 5 dwords (the integer path's packed bytes) ----------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void load_dwords(__amdgpu_buffer_rsrc_t rs, unsigned off, uint32_t (&x)[N], unsigned soff = 0) {
+    static_assert(N >= 1 && N <= 5, "cost dwords per lane");
+    if constexpr (N == 1) {
+        x[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, soff, 0);
+    } else if constexpr (N == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, soff, 0);
+        x[0] = t.x; x[1] = t.y;
+    } else if constexpr (N == 3) {
+        const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, off, soff, 0);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z;
+    } else {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+        if constexpr (N == 5) x[4] = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 16, soff, 0);
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, unsigned off, const uint32_t (&x)[N], unsigned soff = 0) {
+    static_assert(N >= 1 && N <= 5, "bytes per lane / 4");
+    if constexpr (N == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(x[0], rs, off, soff, 0);
+    } else if constexpr (N == 2) {
+        u32x2 t; t.x = x[0]; t.y = x[1];
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, off, soff, 0);
+    } else if constexpr (N == 3) {
+        u32x3 t; t.x = x[0]; t.y = x[1]; t.z = x[2];
+        __builtin_amdgcn_raw_buffer_store_b96(t, rs, off, soff, 0);
+    } else {
+        u32x4 t; t.x = x[0]; t.y = x[1]; t.z = x[2]; t.w = x[3];
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, off, soff, 0);
+        if constexpr (N == 5) __builtin_amdgcn_raw_buffer_store_b32(x[4], rs, off == kOob ? kOob : off + 16, soff, 0);
+    }
+}
+

@@ -291,7 +291,7 @@ int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes);  // hand-off buffer + tick
 int pmx_fam8_waves(int W);
 bool pmx_fam8_supported(int kpl, int H);
 int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, uint8_t* out, size_t dstride, uint32_t P1, uint32_t P2,
-                        int fams);
+                        int fams, bool from_codes, uint32_t invalid_cost);
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
 int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
 int pmx_near_select(pmx_ctx* ctx, const pmx_cv* cv, bool for_write);  // the winner cache of `cv` becomes ctx->near (see pmx_api.hip)

@@ -63,10 +63,17 @@ def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
     (70, 16, -5, 5, 5, 1, 2),         # exactly one window wide, tall
     (45, 67, -20, 20, 7, 8, 30),      # census 7x7: byte costs (invalid cost 50: 3 * 80 = 240 fits a byte)
 ])
-@pytest.mark.parametrize("nw,hpair", [("4", "2"), ("8", "1"), ("8", "2")])
-def test_family_form_equals_the_oracle(eng, oracle, forced_families, H, W, dmin, dmax, win, P1, P2, nw, hpair):
+@pytest.mark.parametrize("nw,hpair,codes", [("4", "2", "0"), ("8", "1", "0"), ("8", "2", "0"),
+                                            ("8", "1", "1"),   # both kernels from the census words, four rows per wavefront
+                                            ("8", "3", None), ("4", "3", None),  # ... one row per wavefront (short images' default)
+                                            ("8", "3", "0")])  # row walk from the words, marching kernel from the cost volume
+def test_family_form_equals_the_oracle(eng, oracle, forced_families, H, W, dmin, dmax, win, P1, P2, nw, hpair, codes):
     forced_families.setenv("PMX_SGM8_FAM_NW", nw)
-    forced_families.setenv("PMX_SGM8_HPAIR", hpair)  # the horizontal pair's one-sided (tall images) / two-sided (short images) walk
+    # the horizontal pair's one-sided (tall images) / two-sided walk on the cost volume, or the row-per-wavefront walk from the
+    # census words (one-word windows; others fall back to the two-sided walk)
+    forced_families.setenv("PMX_SGM8_HPAIR", hpair)
+    if codes is not None:
+        forced_families.setenv("PMX_SGM8_CODES", codes)
     L, R = pair(H, W, seed=3 * H + W)
     run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2)
 
