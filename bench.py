@@ -117,15 +117,17 @@ def cpu_reference_compiled(L, R, dmin, dmax, win, rows):
                       f"{L.shape[0]}x{L.shape[1]} pair, D={D}, {dt:.1f} s"}
 
 
-def sgm_source_hash():
-    """sha256 (16 hex digits) of the sources of the integer path's SGM kernels: a committed traffic figure (rocprofv3 --pmc cannot
+def kernel_source_hash():
+    """sha256 (16 hex digits) of the native sources (csrc/*.hip, *.h, *.cpp): a committed traffic figure (rocprofv3 --pmc cannot
     run inside bench.py) is only quoted while the kernels it was counted on are the ones that were built."""
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("k_sgm8.hip", "k_sgmfam8.hip", "k_fused.hip"):
-        with open(os.path.join(ROOT, "pandora_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+    d = os.path.join(ROOT, "pandora_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
@@ -156,11 +158,28 @@ def roofline_block(stage, steps, cells):
             "algorithmic_bytes_per_launch": algo}
 
 
-def add_traffic(roof, H, W, D):
-    """`traffic` = counted HBM bytes of the SGM kernels per step, (2 FETCH_SIZE + WRITE_SIZE) * 1024 from the committed rocprofv3 --pmc
-    passes of this very command (profiles/*_pmc_traffic.json, tools/pmc_traffic.py) - only while the kernel sources are the ones
-    the passes ran on; `frac_counted` prices the same launch time with those bytes instead of the algorithmic ones."""
+def own_format(out, w, H, W, D, ms_per_step):
+    """The integer route prices badly against SURVEY 8(d)'s float32 bytes (a `frac` above 1 says that the step moves fewer bytes
+    than 20 B/cell, not that it beats the memory).  What it moves against its OWN format: the bytes its volumes need if every
+    one were written once and read once - the packed costs (Dc bytes per pixel) and the three byte volumes (Dp bytes per pixel
+    each: horizontal pair, downward family, upward family) - and how many times that the counters saw over the whole step."""
+    kpl = next(k for k in (4, 8, 12, 16, 20) if 16 * k >= D)
+    nact = -(-D // kpl)
+    dp, dc = nact * kpl, nact * 4 * -(-kpl // 6)  # (five-bit costs, six per dword: census windows up to 5x5)
+    own = (2 * dc + 6 * dp) / D
+    out["own_format_bytes_per_cell"] = round(own, 3)
+    if w is not None:
+        cells = H * W * D
+        out["counted_bytes_per_cell"] = round(w["step_hbm_bytes"] / cells, 3)
+        out["traffic_amplification"] = round(w["step_hbm_bytes"] / (own * cells), 3)
+        out["pipeline_hbm_frac_counted"] = round(w["step_hbm_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+
+
+def counted_traffic(label, H, W, D):
+    """The committed counter passes of this workload (profiles/*_pmc_traffic.json, tools/pmc_traffic.py: (2 FETCH_SIZE + WRITE_SIZE)
+    * 1024 per kernel and step) - only while the native sources are the ones the passes ran on; None otherwise."""
     prof = os.path.join(ROOT, "profiles")
+    sha = kernel_source_hash()
     for name in sorted(os.listdir(prof), reverse=True):
         if not name.endswith("_pmc_traffic.json"):
             continue
@@ -169,14 +188,25 @@ def add_traffic(roof, H, W, D):
                 pmc = json.load(f)
             for w in pmc if isinstance(pmc, list) else [pmc]:
                 wl = w["workload"]
-                if (wl["H"], wl["W"], wl["D"]) == (H, W, D) and w.get("kernel_source_sha16") == sgm_source_hash():
-                    roof["traffic"] = w["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = f"profiles/{name} (commit {w.get('commit')})"
-                    if roof["avg_launch_ms"] > 0:
-                        roof["frac_counted"] = round(w["hbm_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                    return
+                if (wl.get("label"), wl["H"], wl["W"], wl["D"]) == (label, H, W, D) and w.get("kernel_source_sha16") == sha:
+                    return dict(w, file=f"profiles/{name}")
         except (OSError, KeyError, ValueError, TypeError):
             continue
+    return None
+
+
+def add_traffic(roof, label, H, W, D):
+    """`traffic` = counted HBM bytes of the SGM kernels per step; `frac_counted` prices the same launch time with those bytes instead
+    of the algorithmic ones.  Returns the whole entry (bench.py also quotes the step's total)."""
+    w = counted_traffic(label, H, W, D)
+    if w is None:
+        return None
+    roof["traffic"] = w["sgm_hbm_bytes_per_step"]
+    roof["traffic_source"] = f"{w['file']} (commit {w.get('commit')})"
+    span_ms = roof.get("span_ms_per_step", roof["avg_launch_ms"])
+    if span_ms > 0:
+        roof["frac_counted"] = round(w["sgm_hbm_bytes_per_step"] / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return w
 
 
 def pcie_inclusive_ms(eng, cv, L, R, win, P1, P2, reps=3):
@@ -218,7 +248,7 @@ def measure_shape(eng, H, W, dmin, dmax, steps, warmup, seed, pcie=True):
     return ms, stage, (L, R)
 
 
-def config_leg(eng, L, R, dmin, dmax, cost, cbca, steps, label):
+def config_leg(eng, L, R, dmin, dmax, cost, cbca, steps, label, tag):
     """One BASELINE configuration AS STATED on one GPU through the general float32 kernels (the cost volume is float32 between the
     steps): cost = ("zncc", 11) or ("census", 5), optional CBCA (intensity 30, distance 5), SGM 8-path (P1 = 8, P2 = 32), WTA, vfit.
     Same protocol as the headline: inputs resident, one warm-up, `steps` timed steps between stream syncs; per-stage HIP events of
@@ -258,7 +288,12 @@ def config_leg(eng, L, R, dmin, dmax, cost, cbca, steps, label):
     cells = H * W * D
     roof = roofline_block({k: stage[k] for k in STAGES}, steps, cells)
     per_cell = 36.0 if cbca else 28.0
-    return {"workload": label, "steps": steps, "ms_per_step": round(ms, 3), "value": round(cells / ms / 1e3, 1), "unit": "Mdisp/s",
+    w = add_traffic(roof, tag, H, W, D)
+    extra = {}
+    if w is not None:
+        extra = {"counted_bytes_per_cell": round(w["step_hbm_bytes"] / cells, 3),
+                 "pipeline_hbm_frac_counted": round(w["step_hbm_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return {**extra, "workload": label, "steps": steps, "ms_per_step": round(ms, 3), "value": round(cells / ms / 1e3, 1), "unit": "Mdisp/s",
             "dtype": "f32", "roofline": roof,
             "stage_ms_per_step": {k: round(v[0] / steps, 4) for k, v in stage.items() if v[1]},
             "pipeline_hbm_frac": round(per_cell * cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -639,8 +674,7 @@ def main():
         value = cells / (elapsed / args.steps) / 1e6
         tile_cells = (tile_hi - tile_lo) * W * D  # what this rank's kernels worked on
         roof = roofline_block(stage, args.steps, tile_cells)
-        if stage["sgm_fused"][1] > 0 and world == 1:
-            add_traffic(roof, H, W, D)
+        wtraffic = add_traffic(roof, "headline", H, W, D) if stage["sgm_fused"][1] > 0 and world == 1 else None
         if world == 1:
             parallelism = "1 GPU, no collective"
         else:
@@ -668,6 +702,8 @@ def main():
             "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
             "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * cells / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4),
         }
+        if world == 1 and stage["sgm_span"][1] > 0:
+            own_format(out, wtraffic, H, W, D, ms_per_step)
         if world > 1:
             # RCCL's own rank count (ncclCommCount) - or, under the --test-comm hook, what carried the exchange instead
             if getattr(comm, "nranks_note", None):
@@ -711,7 +747,7 @@ def main():
                 c3 = 2048 * 2048 * 129
                 r3 = roofline_block(st3, args.steps, c3)
                 if st3["sgm_fused"][1] > 0:
-                    add_traffic(r3, 2048, 2048, 129)
+                    add_traffic(r3, "c3", 2048, 2048, 129)
                 out["c3_shape"] = {"workload": "2048x2048 synthetic pair, d=[0,128] (D=129): BASELINE configs[2], the round-1 headline; same "
                                                "pipeline and protocol", "steps": args.steps, "ms_per_step": round(ms3, 3),
                                    "value": round(c3 / ms3 / 1e3, 1), "unit": "Mdisp/s", "roofline": r3,
@@ -730,7 +766,7 @@ def main():
                 eng.set_placement_trials(1)  # (six candidates of a 51.6 GB volume would not fit the device)
                 out["c4_as_stated"] = config_leg(eng, L, R, dmin, dmax, ("zncc", 11), False, 3,
                                                  "BASELINE configs[3] as stated: 4096x4096 synthetic pair, d=[0,256] (D=257), ZNCC 11x11 + SGM 8-path "
-                                                 "+ WTA + vfit, float32 cost volume between the steps; one GPU")
+                                                 "+ WTA + vfit, float32 cost volume between the steps; one GPU", "c4")
                 # BASELINE configs[1] on the reference's own cones pair (tests/golden/cones: data, not code): census + CBCA + SGM + WTA +
                 # vfit, d = [-60, 0] as data_samples/json_conf_files/a_semi_global_matching.json has it for this pair
                 cones_dir = os.path.join(ROOT, "tests", "golden", "cones")
@@ -741,12 +777,12 @@ def main():
                     Rc = np.array(Image.open(os.path.join(cones_dir, "right.png"))).astype(np.float32)
                     out["c2_cones"] = config_leg(eng, Lc, Rc, -60, 0, ("census", 5), True, 20,
                                                  "BASELINE configs[1]: the cones pair (375x450), d=[-60,0] (D=61), Census 5x5 + CBCA + SGM 8-path "
-                                                 "+ WTA + vfit; one GPU (a launch-latency-sized problem: 10.3 M cells)")
+                                                 "+ WTA + vfit; one GPU (a launch-latency-sized problem: 10.3 M cells)", "c2")
                 L5, R5 = synthetic_pair(10000, 10000, -64, 64)
                 out["c5_as_stated"] = config_leg(eng, L5, R5, -64, 64, ("census", 5), True, 2,
                                                  "BASELINE configs[4], fine scale, as stated: 10000x10000 synthetic pair, d=[-64,64] (D=129), "
                                                  "Census 5x5 + CBCA + SGM 8-path + WTA + vfit, float32 cost volume between the steps; the whole "
-                                                 "strip on one GPU")
+                                                 "strip on one GPU", "c5")
                 del L5, R5
             if args.cpu_rows > 0:  # the CPU legs belong to the N=1 line only
                 rows = min(args.cpu_rows, H)

@@ -214,7 +214,6 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
     };
 #pragma unroll
     for (int i = 0; i < kRing8; ++i) prefetch(ring[i]);
-    PMX_LOOP_ENTRY_DRAIN();
 
     // pad masks (also the restart state of a path): kInf16 in the halves that hold a disparity >= D
     uint32_t padA[Q], padB[Q];

@@ -651,7 +651,7 @@ int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes) {
         PMX_HIP(hipHostMalloc((void**)&ctx->fam_err_host, sizeof(unsigned), hipHostMallocDefault));
         *ctx->fam_err_host = 0;
     }
-    if (ctx->fam_epoch >= 0xfffffff0u) {  // epoch space used up: start over on a clean buffer
+    if (ctx->fam_epoch >= 0x7ffffff0u) {  // tags would repeat (pmx_fam_tag): start over on a clean buffer
         PMX_HIP(hipMemsetAsync(ctx->fam_halo, 0, ctx->fam_halo_bytes, ctx->stream));
         ctx->fam_epoch = 0;
     }
@@ -686,7 +686,7 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
         a.dmask = bits;
         a.halo = (u32x4*)ctx->fam_halo;
         a.NB = NB;
-        a.epoch = ++ctx->fam_epoch;
+        a.epoch = pmx_fam_tag(++ctx->fam_epoch);
         a.ctl = ctx->fam_ctl;
         a.dbg = getenv("PMX_SGM_FAM_DBG") ? atoi(getenv("PMX_SGM_FAM_DBG")) : 0;
         const bool use_wta = wta && fam == 1;

@@ -17,9 +17,11 @@
 // always started before it: no co-residency assumption); both families run in ONE launch (ticket & 1 = family), so that a CU
 // holds waves of both and the chip sees 2 x W columns of parallel work.  Inside a workgroup the two shifting paths go through
 // LDS as they are (packed u16 pairs, double-buffered by row parity, one barrier per row); the left neighbour's last two columns
-// arrive through global memory as BYTES (every L_r < 256) in 16-byte blocks {value, tag, value, tag}, tag = launch epoch, each
-// 8-byte half written by one sc1 store and self-validating (cdna_hip_programming.md Guideline 16, form R2), read by a dedicated
-// wave with bounded polling.  Same lane map as the path kernel and the cost kernel: 16 lanes per pixel, KPL = 4 Q consecutive
+// arrive through global memory as BYTES (every L_r < 256) in 16-byte blocks {value, tag, value, tag}, tag = the launch's scrambled
+// count (pmx_fam_tag), each 8-byte half self-validating (cdna_hip_programming.md Guideline 16, form R2), read by a dedicated
+// wave with bounded polling.  (Round 4 tried the float32 kernels' blocks of three values and a checked tag here: 82 instead of 122
+// blocks per row and border, but three (A, B) register pairs per block instead of two is six instead of four LDS instructions per
+// row in the hand-off wavefront, which every row's barrier waits for: the marching kernel alone 7.3 -> 9.0 ms.  Out again.)  Same lane map as the path kernel and the cost kernel: 16 lanes per pixel, KPL = 4 Q consecutive
 // disparities per lane as A[q] = (L[4q], L[4q+2]), B[q] = (L[4q+1], L[4q+3]); 4 pixels per wave.
 //
 // Arithmetic: minima on the f16 pipe (positive halves order like integers; v_pk_minimum3_f16), additions as plain 32-bit adds of
@@ -178,13 +180,25 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
 
     if (wave == NW) {
         // ---- hand-off wave: brings the left neighbour's columns CW-2, CW-1 of row t into column slots -2, -1 -------------------
-        int off0[NQ], off1[NQ];       // LDS dword offsets (within a row parity) of the block's two values
-        uint32_t pA0[NQ], pB0[NQ], pA1[NQ], pB1[NQ];  // pad masks of the two packed dwords (kind 2)
-        int kind[NQ];                 // 0 padding block, 2 two packed dwords, 3 minima (V, A of slot -1), 4 minimum (A of slot -2)
+        // Every row's barrier waits for this wavefront, and it is one chain: LDS -> pack -> store, load -> unpack -> LDS.  So it
+        // runs without a lane-varying branch and without per-row address arithmetic: every lane does the same four LDS accesses per
+        // block (two (A, B) register pairs of a vector and two minima - the kinds a lane's block does not hold go to a spare dword
+        // pair of the column slot), the record of (row t, border) is a running block index.  (Round 4: 270 -> ~150 instructions per
+        // row; three register pairs per block - the float32 kernels' 12-byte payload - cost two LDS instructions more per row and
+        // the marching kernel 7.3 -> 9.0 ms, which is how the length of this chain was found to be what the row time hangs on.)
+        constexpr int SINK = 16 * KS + 2;  // spare dwords of a column slot (its minimum sits at 16 KS): 8-byte aligned
+        int offP0[NQ], offP1[NQ];     // LDS dword offsets (within a row parity) of the block's two register pairs
+        int offM0[NQ], offM1[NQ];     // ... of its two minima
+        uint32_t pA0[NQ], pB0[NQ], pA1[NQ], pB1[NQ];  // pad masks of the two packed dwords
+        bool is_min[NQ], one_min[NQ]; // the block holds minima; ... one of them (twice)
+        unsigned boff[NQ];            // byte offset of the block in a (row, border) record: lanes without a block touch nothing
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int idx = q * 64 + lane;
-            kind[q] = 0; off0[q] = off1[q] = 0; pA0[q] = pB0[q] = pA1[q] = pB1[q] = 0;
+            offP0[q] = offP1[q] = SINK; offM0[q] = offM1[q] = SINK;
+            pA0[q] = pB0[q] = pA1[q] = pB1[q] = 0;
+            is_min[q] = one_min[q] = false;
+            boff[q] = idx < NG ? (unsigned)idx * 16u : kOob;
             if (idx < 3 * NVB) {
                 const int vec = idx / NVB, rem = idx - vec * NVB;
                 // vec 0: vertical path of column CW-1 -> slot -1;  1: diagonal of CW-1 -> slot -1;  2: diagonal of CW-2 -> slot -2
@@ -195,37 +209,37 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
                     pa = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
                     pb = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
                 };
-                place(2 * rem, off0[q], pA0[q], pB0[q]);
-                place(2 * rem + 1, off1[q], pA1[q], pB1[q]);
-                kind[q] = 2;
-            } else if (idx == 3 * NVB) {
-                kind[q] = 3; off0[q] = ES + 16 * KS; off1[q] = EDIR + ES + 16 * KS;
-            } else if (idx == 3 * NVB + 1) {
-                kind[q] = 4; off0[q] = EDIR + 16 * KS; off1[q] = off0[q];
+                place(2 * rem, offP0[q], pA0[q], pB0[q]);
+                place(2 * rem + 1, offP1[q], pA1[q], pB1[q]);
+            } else if (idx == 3 * NVB) {      // minima of slot -1: vertical path, diagonal
+                is_min[q] = true; offM0[q] = ES + 16 * KS; offM1[q] = EDIR + ES + 16 * KS;
+            } else if (idx == 3 * NVB + 1) {  // minimum of slot -2: diagonal
+                is_min[q] = one_min[q] = true; offM0[q] = EDIR + 16 * KS; offM1[q] = offM0[q];
             }
         }
+        constexpr int QM0 = (3 * NVB) / 64, QM1 = (3 * NVB + 1) / 64;  // the blocks that hold minima
         // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
         const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
         const int tB = (r_hi < base ? r_hi : base) - 1;
-        auto in_rsrc = [&](int t) {
-            const bool need = t >= tA && t <= tB;
-            const int cb = base - (t + 1);  // image column of the neighbour's last pixel on row t (0 <= cb < W when needed)
-            return __builtin_amdgcn_make_buffer_rsrc((void*)(halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0,
-                                                     need ? kBlockBytes : 0u, kRsrcWord3);
+        // The record the neighbour wrote for row t sits at block row bi(t) = t NB + (base - t - 1) / CW = t NB + s - 1 - t / CW
+        // (t >= 0), the one this window writes for row t one further (column block (base + CW - 1 - t) / CW): a running index.
+        auto bi_of = [&](int t) { const int tt = t > 0 ? t : 0; return tt * a.NB + s - 1 - tt / CW; };
+        auto rsrc_of = [&](int bi, bool need) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(halo + (size_t)(need ? bi : 0) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
         };
         u32x4 x[NQ];
-        auto issue = [&](int t) {
-            const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
+        auto issue = [&](int t, int bi) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(bi, t >= tA && t <= tB);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
+            for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
         };
-        auto consume = [&](int t) -> bool {
+        auto consume = [&](int t, int bi) -> bool {
             if (t < tA || t > tB) return true;
-            const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(bi, true);
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) ok &= kind[q] == 0 || (x[q].y == a.epoch && x[q].w == a.epoch);
+                for (int q = 0; q < NQ; ++q) ok &= boff[q] == kOob || (x[q].y == a.epoch && x[q].w == a.epoch);
                 if (__all(ok)) break;
                 if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
                 if (spins > kSpinLimit) {
@@ -234,22 +248,19 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
                 }
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + lane) * 16, 0, kSc1);
+                for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
             }
             uint32_t* Eb = lds8 + (t & 1) * EBUF;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if (kind[q] == 2) {
-                    u32x2 v0, v1;  // bytes d, d+1, d+2, d+3 -> A = (d, d+2), B = (d+1, d+3), pads restored
-                    v0.x = (x[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((x[q].x >> 8) & 0x00ff00ffu) | pB0[q];
-                    v1.x = (x[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((x[q].z >> 8) & 0x00ff00ffu) | pB1[q];
-                    *(u32x2*)(Eb + off0[q]) = v0;
-                    *(u32x2*)(Eb + off1[q]) = v1;
-                } else if (kind[q] == 3) {
-                    Eb[off0[q]] = x[q].x;
-                    Eb[off1[q]] = x[q].z;
-                } else if (kind[q] == 4) {
-                    Eb[off0[q]] = x[q].x;
+                u32x2 v0, v1;  // bytes d, d+1, d+2, d+3 -> A = (d, d+2), B = (d+1, d+3), pads restored
+                v0.x = (x[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((x[q].x >> 8) & 0x00ff00ffu) | pB0[q];
+                v1.x = (x[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((x[q].z >> 8) & 0x00ff00ffu) | pB1[q];
+                *(u32x2*)(Eb + offP0[q]) = v0;
+                *(u32x2*)(Eb + offP1[q]) = v1;
+                if (q == QM0 || q == QM1) {  // (compile time)
+                    Eb[offM0[q]] = x[q].x;
+                    Eb[offM1[q]] = one_min[q] ? x[q].x : x[q].z;
                 }
             }
             return true;
@@ -257,40 +268,49 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
         // Publishes row t of this window for window s+1: the compute waves left the path costs of local columns CW-2, CW-1 in LDS
         // (column slots CW, CW+1 of row parity t & 1), complete once barrier t is passed and untouched until barrier t+1.  Window
         // s+1 computes row t+1 at image column cb = base+CW-1-t: it exists and needs the row iff cb < W and t < H-1.
-        auto publish = [&](int t) {
+        auto publish = [&](int t, int bi) {
             const int cb = base + CW - 1 - t;
-            const bool need = t >= r_lo && cb < W && t < H - 1;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(bi + 1, t >= r_lo && cb < W && t < H - 1);
             const uint32_t* Eb = lds8 + (t & 1) * EBUF + CW * ES;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
+                const u32x2 v0 = *(const u32x2*)(Eb + offP0[q]);
+                const u32x2 v1 = *(const u32x2*)(Eb + offP1[q]);
                 u32x4 b;
+                b.x = v0.x | (v0.y << 8);  // (pads spill upwards only: into bytes that are pads themselves)
+                b.z = v1.x | (v1.y << 8);
+                if (q == QM0 || q == QM1) {  // (compile time)
+                    const uint32_t m0 = Eb[offM0[q]], m1 = Eb[offM1[q]];
+                    b.x = is_min[q] ? m0 : b.x;
+                    b.z = is_min[q] ? m1 : b.z;
+                }
                 b.y = a.epoch;
                 b.w = a.epoch;
-                if (kind[q] == 2) {
-                    const u32x2 v0 = *(const u32x2*)(Eb + off0[q]);
-                    const u32x2 v1 = *(const u32x2*)(Eb + off1[q]);
-                    b.x = v0.x | (v0.y << 8);  // (pads spill upwards only: into bytes that are pads themselves)
-                    b.z = v1.x | (v1.y << 8);
-                } else {
-                    b.x = Eb[off0[q]];
-                    b.z = Eb[off1[q]];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(b, rs, kind[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b128(b, rs, boff[q], 0, kSc1);
             }
         };
         // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi.  Row t of the neighbour is asked for as
         // early as it can exist (one look-ahead load per barrier), and polled for when it is due.
-        issue(r_lo - 1);
-        for (int t = r_lo - 1; t <= r_hi; ++t) {
-            publish(t - 1);
-            if (!consume(t)) ctl[1 + (t & 1)] = 1;
-            issue(t + 1);
+        int t = r_lo - 1;
+        int bi_prev = bi_of(t - 1), bi_cur = bi_of(t), bi_next = bi_of(t + 1);
+        int tmod = (t + 1 > 0 ? t + 1 : 0) % CW;  // (t + 1) mod CW: the block index loses one when t + 2 reaches a multiple of CW
+        issue(t, bi_cur);
+        for (; t <= r_hi; ++t) {
+            publish(t - 1, bi_prev);
+            if (!consume(t, bi_cur)) ctl[1 + (t & 1)] = 1;
+            issue(t + 1, bi_next);
             __syncthreads();
             if (__builtin_amdgcn_readfirstlane(ctl[1 + (t & 1)])) return;
+            // bi(t + 2) from bi(t + 1): one row further, one column block back at every multiple of CW
+            bi_prev = bi_cur;
+            bi_cur = bi_next;
+            if (t + 1 >= 0) {
+                ++tmod;
+                bi_next += a.NB;
+                if (tmod == CW) { tmod = 0; --bi_next; }
+            }
         }
-        publish(r_hi);
+        publish(r_hi, bi_prev);
         return;
     }
 
@@ -611,7 +631,7 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.H = cv->H; a.W = cv->W; a.D = cv->D; a.Dp = cv->Dp; a.Dc = Dc;
     a.P1 = P1; a.P2 = P2;
     a.halo = (u32x4*)ctx->fam_halo; a.halo_fam = halo_fam; a.NB = NB;
-    a.epoch = ++ctx->fam_epoch;
+    a.epoch = pmx_fam_tag(++ctx->fam_epoch);
     a.ctl = ctx->fam_ctl;
     a.fam0 = fam0; a.nfam = nfam;
     a.prio = getenv("PMX_SGM8_FAM_PRIO") ? atoi(getenv("PMX_SGM8_FAM_PRIO")) : 3;  // (0: 14.6 ms per 4096^2 x 257 step, 3: 13.9)

@@ -114,7 +114,7 @@ struct pmx_ctx {
     // been written by the current launch; fam_epoch counts launches.  fam_ctl: [0] ticket counter, [1] error word (device).
     unsigned long long* fam_halo = nullptr;
     size_t fam_halo_bytes = 0;
-    unsigned fam_epoch = 0;
+    unsigned fam_epoch = 0;            // launches of the marching kernels (both kinds share the buffer and this counter)
     unsigned* fam_ctl = nullptr;
     unsigned* fam_err_host = nullptr;  // pinned copy of the error word, filled behind every family launch
     int sgm_dir_mask = 0xff;           // pmx_debug_sgm_directions
@@ -290,6 +290,12 @@ int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes);  // hand-off buffer + tick
 // integer path as direction families (k_sgmfam8.hip): the vertical families' byte sums into out + f * dstride
 int pmx_fam8_waves(int W);
 bool pmx_fam8_supported(int kpl, int H);
+// The tag a launch's hand-off blocks carry: the launch count scrambled over all 32 bits, top bit set (a zeroed buffer never
+// matches).  A block is taken when its tag word equals the tag (k_sgmfam8.hip) or the tag XOR its payload (k_sgmfam.hip): with
+// consecutive small epochs a stale or half-arrived block could pass such a test by coincidence of small numbers (a stale packed
+// byte block whose two halves XOR to the epoch, a torn block whose old and new payloads differ by epoch ^ epoch'); with scrambled
+// tags a coincidence needs 31 matching pseudo-random bits.  Distinct launches within 2^31 of each other have distinct tags.
+static inline unsigned pmx_fam_tag(unsigned epoch) { return (epoch * 0x9E3779B9u) | 0x80000000u; }
 int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, uint8_t* out, size_t dstride, uint32_t P1, uint32_t P2,
                         int fams, bool from_codes, uint32_t invalid_cost);
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
