@@ -22,6 +22,7 @@ import bench  # noqa: E402
 SGM_KERNELS = ("sgm_u8_packed_kernel", "sgm_fam8_kernel", "sgm_u8_hpair", "sgm_u8_hrow", "sgm_family_kernel", "sgm_h_checkpoint_kernel",
                "sgm_h_backward_kernel", "sgm_path_kernel", "sgm_sum_paths_kernel", "sgm_census_fused_kernel")
 STEP_MARKERS = ("sum8_refine_kernel", "near_refine_kernel", "refine_kernel")
+NOT_A_STEP = ("placement_probe_kernel", "__amd_rocclr")  # allocation-time probes, the runtime's fills and copies: listed, not summed
 
 
 def short(name):
@@ -55,6 +56,9 @@ def main(args):
             table[k] = {"FETCH_SIZE_KiB_per_dispatch": v["FETCH_SIZE"], "WRITE_SIZE_KiB_per_dispatch": v["WRITE_SIZE"],
                         "hbm_bytes_per_dispatch": int(b), "dispatches_per_step": round(v["dispatches"] / steps, 3),
                         "hbm_bytes_per_step": int(per_step)}
+            if k.startswith(NOT_A_STEP):
+                table[k]["not_part_of_a_step"] = True
+                continue
             total += per_step
             if k.startswith(SGM_KERNELS):
                 sgm += per_step
