@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random pipelines through the direction-family form of the integer path (k_sgmfam8.hip + sgm_u8_hpair_kernel, forced with
+"""Random pipelines through the direction-family form of the integer path (k_sgmfam8.hip + the horizontal-pair kernels, forced with
 PMX_SGM8_FAM=1) against the CPU oracle: random image shapes (down to a few pixels, up to several windows in flight), disparity
 ranges inside / across / outside the image, census windows 3 / 5 / 7, integer penalties, both window widths, optional per-pixel
 disparity grids; the summed volume, the WTA and the refinement must be identical.  Usage: python tools/fuzz_fam8.py [seed0] [n]"""
@@ -39,7 +39,14 @@ def main():
             if P2 <= P1:
                 continue
         os.environ["PMX_SGM8_FAM_NW"] = str(rng.choice([4, 8]))
-        os.environ["PMX_SGM8_HPAIR"] = str(rng.choice([1, 2]))  # the horizontal pair's one-sided / two-sided walk
+        # the horizontal pair's one-sided / two-sided walk on the cost volume / row-per-wavefront walk from the census words; the
+        # Hamming costs from a cost volume or made inside the SGM kernels (round 4), for the marching kernel alone or for both
+        os.environ["PMX_SGM8_HPAIR"] = str(rng.choice([1, 2, 3, 3]))
+        for k, v in (("PMX_SGM8_CODES", rng.choice(["", "0", "1"])), ("PMX_SGM8_FAMCODES", rng.choice(["", "", "0", "1"]))):
+            if v:
+                os.environ[k] = str(v)
+            else:
+                os.environ.pop(k, None)
         base = rng.integers(0, 256, (H, W + 8)).astype(np.float32)
         base = np.floor((base + np.roll(base, 1, 1) + np.roll(base, 1, 0)) / 3.0)
         L = base[:, 4:4 + W].copy()
@@ -77,6 +84,7 @@ def main():
               and np.array_equal(itp, ritp, equal_nan=True))
         if not ok:
             print(f"DIFFERENCE seed {seed}: H={H} W={W} win={win} d=[{dmin},{dmax}] P1={P1} P2={P2} nw={os.environ['PMX_SGM8_FAM_NW']} "
+                  f"hpair={os.environ['PMX_SGM8_HPAIR']} codes={os.environ.get('PMX_SGM8_CODES')} famcodes={os.environ.get('PMX_SGM8_FAMCODES')} "
                   f"grids={grids is not None} family={took_family} volume_equal={np.array_equal(vol, ref, equal_nan=True)}", flush=True)
             sys.exit(1)
         cells += H * W * D
