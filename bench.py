@@ -658,16 +658,32 @@ def main():
     stage = {name: eng.stage_time(name) for name in STAGES}
     eng.set_profiling(False)
     gathered = eng.get_full_maps(H, want_itp=True) if comm is not None and rank == 0 else None  # the last step's maps, before anything else runs
-    dshard = None
-    if comm is not None and not args.no_dshard and D >= 2 * world:
-        dshard = d_sharded_leg(eng, comm, L, R, dmin, dmax, 11, max(2, args.steps // 2), local_rank)
-    weak = None
-    if comm is not None and not args.no_weak:
-        weak = pair_per_rank_leg(comm, local_rank, H, W, dmin, dmax, win, P1, P2, max(2, args.steps // 2), rank, world)
-    c5tiled = None
+    # The extra legs of an N > 1 run: a leg that fails (on any rank) is dropped from the line with its error, it does not take the
+    # headline with it.  (Every rank agrees on the outcome through one small reduction; a rank that hangs inside a collective is
+    # the launcher's watchdog's business.)
+    leg_errors = {}
+
+    def leg(name, fn):
+        err = None
+        res = None
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001 - reported in the line
+            err = f"{type(e).__name__}: {e}"[:300]
+        failed = float(comm.host_allreduce(np.array([1.0 if err else 0.0]), "max")[0]) > 0
+        if failed:
+            leg_errors[name] = err or "failed on another rank"
+            return None
+        return res
+
+    dshard = weak = c5tiled = None
     if comm is not None and not args.no_c5tiled:
         cv.free()
-        c5tiled = c5_row_tiled_leg(eng, comm, args.c5_height, args.c5_width, max(2, args.steps // 4), local_rank)
+        c5tiled = leg("c5_row_tiled", lambda: c5_row_tiled_leg(eng, comm, args.c5_height, args.c5_width, max(2, args.steps // 4), local_rank))
+    if comm is not None and not args.no_dshard and D >= 2 * world:
+        dshard = leg("d_sharded_exact", lambda: d_sharded_leg(eng, comm, L, R, dmin, dmax, 11, max(2, args.steps // 2), local_rank))
+    if comm is not None and not args.no_weak:
+        weak = leg("pair_per_rank", lambda: pair_per_rank_leg(comm, local_rank, H, W, dmin, dmax, win, P1, P2, max(2, args.steps // 2), rank, world))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -734,6 +750,8 @@ def main():
                 out["pair_per_rank"] = weak
             if c5tiled is not None:
                 out["c5_row_tiled"] = c5tiled
+            if leg_errors:
+                out["leg_errors"] = leg_errors
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
             pcie_s = pcie_inclusive_ms(eng, cv, L, R, win, P1, P2) * 1e-3

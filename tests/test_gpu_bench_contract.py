@@ -120,3 +120,18 @@ def test_launcher_runs_its_own_ranks_to_the_end():
     assert out.returncode == 0, out.stderr[-1500:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, out.stdout
+
+
+def test_bench_prices_the_integer_route_against_its_own_format():
+    """A pair wide enough for the direction-family form (three byte volumes): the line says what the route's own volumes need
+    (`own_format_bytes_per_cell`) beside the float32-priced `frac`; counted figures appear only when committed counter passes of
+    this very workload and these very sources exist (they do not for this shape: `traffic` stays null)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--height", "520",
+                          "--width", "2600", "--dmax", "40", "--cpu-rows", "0", "--no-c3", "--no-configs", "--placement-trials", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    assert d["stage_ms_per_step"]["sgm_span"] > 0  # the family form ran
+    # D = 41: KPL 4, 11 lanes: Dp = 44 bytes, Dc = 11 dwords = 44 bytes per pixel -> (2 * 44 + 6 * 44) / 41
+    assert abs(d["own_format_bytes_per_cell"] - (2 * 44 + 6 * 44) / 41) < 1e-3
+    assert d["roofline"]["traffic"] is None and "traffic_amplification" not in d
