@@ -22,6 +22,11 @@
 // spare, so when every cost fits 5 bits (invalid_cost <= 31: census windows up to 5x5) the costs are stored SIX per dword
 // (CBITS = 5): a lane's 12 costs are 8 bytes instead of 12, laid out so that one shift + v_and_or_b32 yields a (lo16, hi16)
 // register of the recurrence (three such pairs per dword).
+//
+// Also in this file: the horizontal pair of the direction-family form (k_sgmfam8.hip runs the six other paths) in its four
+// shapes - sgm_u8_hpair_kernel (one wavefront per four rows, cost volume), sgm_u8_hpair2_kernel (the same rows walked from both
+// ends), sgm_u8_hpair_codes_kernel (costs made from the census words, round 4) and sgm_u8_hrow_codes_kernel (one row per
+// workgroup, a wavefront from each end, costs from the words: short images) - and pmx_launch_sgm8, which picks among them.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -328,9 +333,10 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_packed_kernel(sgm8_arg
 // a wavefront owns 4 rows, walks them left to right storing L_(0,+1), then right to left adding L_(0,-1) to what it reads back
 // through a second read-ahead ring (R cost + W, then R cost + R + W = 4.4 B/cell for two paths; the sums are <= 2 (invalid_cost
 // + P2) and bytes add as plain 32-bit adds).  Same recurrence, registers and cost formats as sgm_u8_packed_kernel<.., true>.
-// The kernel moves 20 GB at 4096 x 4096 x 257 in 4.6 ms = 4.4 TB/s: HBM-bound even with one wavefront per SIMD.  The two-sided
-// walk below (twice the wavefronts, half the steps) ran alone at the same 4.6 ms there and, beside the marching kernel, slowed
-// that one from 10.1 to 12.1 ms; it is the form for SHORT images, where this kernel's few wavefronts are latency-bound.
+// The kernel moves 20 GB at 4096 x 4096 x 257 in 4.3 - 4.5 ms = 4.5 TB/s: HBM-bound even with one wavefront per SIMD.  The two-sided
+// walk below (twice the wavefronts, half the steps) ran alone at the same time there and, beside the marching kernel, slowed
+// that one from 10.1 to 12.1 ms; it is a form for SHORT images, where this kernel's few wavefronts are latency-bound (the other,
+// round 4's default where it is legal: one row per workgroup from the census words, sgm_u8_hrow_codes_kernel).
 template <int KPL, int CBITS>
 __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_kernel(sgm8_args a) {
     constexpr int Q = KPL / 4;
