@@ -74,6 +74,23 @@ __device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t c) {  
     asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// the same with a wave-uniform last operand left in its scalar register (one constant-bus read per instruction is allowed; the
+// compiler copies a value used by several instructions into a vector register first, once per step of a walk)
+__device__ __forceinline__ uint32_t hmin3_s(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t add3_s(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {  // popcount(x) + acc as ONE instruction, whatever acc is
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp8(uint32_t oldv, uint32_t src) {
@@ -640,27 +657,120 @@ __global__ __launch_bounds__(kWaves8 * 64, 4) void sgm_u8_hpair_codes_kernel(hpc
 // times, so every index is a constant - into which ONE new word per step arrives 16 - KPL steps before its first use; the left
 // words of 64 columns sit in one register, lane = column & 63, and are handed out by v_readlane.  The sums leave in natural
 // disparity order at the family lane map's pixel stride Dp (the last lane stores what fits).
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+// The wave's minimum of the 16-bit halves of the new path costs, and - in the two issue slots every cross-lane operand has to
+// wait for its producer anyway (six dependent steps: 12 slots) - the matching costs of the NEXT column:
+// x[k] = popcount(lw ^ w[k]) + p[k], lw = lane UN of the left words.  One asm block because neither the scheduler nor the hazard
+// pass fills those slots (they emit s_nop 1 six times); the block holds its own distances: two instructions between the
+// v_readlane and the first reader of its scalar, two between a vector write and the cross-lane read of it.
+#define PMX_DPP_MIN(ctrl) "v_min_u32_dpp %0, %0, %0 " ctrl "\n\t"
+template <int UN>
+__device__ __forceinline__ uint32_t wave_min_and_costs(const uint32_t (&nA)[1], const uint32_t (&nB)[1], uint32_t lwords,
+                                                       const uint32_t (&w)[4], const uint32_t (&p)[4], uint32_t (&ccA)[1],
+                                                       uint32_t (&ccB)[1]) {
+    uint32_t v, x0, x1, x2, x3, lw;
     asm volatile(
+        "v_readlane_b32 %7, %10, %11\n\t"
+        "v_pk_min_f16 %0, %8, %9\n\t"
+        "v_min_u32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_xor_b32 %1, %7, %12\n\t"
+        "v_xor_b32 %2, %7, %13\n\t"
+        PMX_DPP_MIN("row_shr:1 row_mask:0xf bank_mask:0xf")
+        "v_xor_b32 %3, %7, %14\n\t"
+        "v_xor_b32 %4, %7, %15\n\t"
+        PMX_DPP_MIN("row_shr:2 row_mask:0xf bank_mask:0xf")
+        "v_bcnt_u32_b32 %1, %1, %16\n\t"
+        "v_bcnt_u32_b32 %2, %2, %17\n\t"
+        PMX_DPP_MIN("row_shr:4 row_mask:0xf bank_mask:0xf")
+        "v_bcnt_u32_b32 %3, %3, %18\n\t"
+        "v_bcnt_u32_b32 %4, %4, %19\n\t"
+        PMX_DPP_MIN("row_shr:8 row_mask:0xf bank_mask:0xf")  // lane 15 of every row holds the row's minimum
+        "v_lshl_or_b32 %5, %3, 16, %1\n\t"  // A = (cost 0, cost 2)
+        "v_lshl_or_b32 %6, %4, 16, %2\n\t"  // B = (cost 1, cost 3)
+        PMX_DPP_MIN("row_bcast:15 row_mask:0xa bank_mask:0xf")  // into rows 1, 3
         "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"  // lane 15 of every row holds the row's minimum
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // into rows 1, 3
-        "s_nop 1\n\t"
-        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // into rows 2, 3: lane 63 holds the minimum
-        "s_nop 1"
-        : "+v"(v));
+        PMX_DPP_MIN("row_bcast:31 row_mask:0xc bank_mask:0xf")  // into rows 2, 3: lane 63 holds the minimum
+        : "=&v"(v), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(ccA[0]), "=&v"(ccB[0]), "=&s"(lw)
+        : "v"(nA[0]), "v"(nB[0]), "v"(lwords), "n"(UN), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(p[0]), "v"(p[1]), "v"(p[2]),
+          "v"(p[3]));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// ... the same with one more disparity (nE, its right word wE and addend pE): the 65th lane's worth that D = 4 * 64 + 1 needs
+template <int UN>
+__device__ __forceinline__ uint32_t wave_min_and_costs_x(const uint32_t (&nA)[1], const uint32_t (&nB)[1], uint32_t nE,
+                                                         uint32_t lwords, const uint32_t (&w)[4], uint32_t wE, const uint32_t (&p)[4],
+                                                         uint32_t pE, uint32_t (&ccA)[1], uint32_t (&ccB)[1], uint32_t& ccE) {
+    uint32_t v, x0, x1, x2, x3, lw;
+    asm volatile(
+        "v_readlane_b32 %7, %12, %13\n\t"
+        "v_pk_minimum3_f16 %0, %9, %10, %11\n\t"
+        "v_min_u32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_xor_b32 %1, %7, %14\n\t"
+        "v_xor_b32 %2, %7, %15\n\t"
+        PMX_DPP_MIN("row_shr:1 row_mask:0xf bank_mask:0xf")
+        "v_xor_b32 %3, %7, %16\n\t"
+        "v_xor_b32 %4, %7, %17\n\t"
+        PMX_DPP_MIN("row_shr:2 row_mask:0xf bank_mask:0xf")
+        "v_bcnt_u32_b32 %1, %1, %19\n\t"
+        "v_bcnt_u32_b32 %2, %2, %20\n\t"
+        PMX_DPP_MIN("row_shr:4 row_mask:0xf bank_mask:0xf")
+        "v_bcnt_u32_b32 %3, %3, %21\n\t"
+        "v_bcnt_u32_b32 %4, %4, %22\n\t"
+        PMX_DPP_MIN("row_shr:8 row_mask:0xf bank_mask:0xf")
+        "v_lshl_or_b32 %5, %3, 16, %1\n\t"
+        "v_lshl_or_b32 %6, %4, 16, %2\n\t"
+        PMX_DPP_MIN("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_xor_b32 %8, %7, %18\n\t"
+        "v_bcnt_u32_b32 %8, %8, %23\n\t"
+        PMX_DPP_MIN("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "=&v"(v), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(ccA[0]), "=&v"(ccB[0]), "=&s"(lw), "=&v"(ccE)
+        : "v"(nA[0]), "v"(nB[0]), "v"(nE), "v"(lwords), "n"(UN), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(wE), "v"(p[0]),
+          "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(pE));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int UN>
+__device__ __forceinline__ uint32_t wave_min_and_costs(const uint32_t (&nA)[2], const uint32_t (&nB)[2], uint32_t lwords,
+                                                       const uint32_t (&w)[8], const uint32_t (&p)[8], uint32_t (&ccA)[2],
+                                                       uint32_t (&ccB)[2]) {
+    uint32_t v, x0, x1, x2, x3, x4, x5, x6, x7, lw;
+    asm volatile(
+        "v_readlane_b32 %9, %14, %15\n\t"
+        "v_pk_min_f16 %0, %10, %11\n\t"
+        "v_pk_minimum3_f16 %0, %0, %12, %13\n\t"
+        "v_min_u32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+        "v_xor_b32 %1, %9, %16\n\t"
+        "v_xor_b32 %2, %9, %17\n\t"
+        PMX_DPP_MIN("row_shr:1 row_mask:0xf bank_mask:0xf")
+        "v_xor_b32 %3, %9, %18\n\t"
+        "v_xor_b32 %4, %9, %19\n\t"
+        PMX_DPP_MIN("row_shr:2 row_mask:0xf bank_mask:0xf")
+        "v_xor_b32 %5, %9, %20\n\t"
+        "v_xor_b32 %6, %9, %21\n\t"
+        PMX_DPP_MIN("row_shr:4 row_mask:0xf bank_mask:0xf")
+        "v_xor_b32 %7, %9, %22\n\t"
+        "v_xor_b32 %8, %9, %23\n\t"
+        PMX_DPP_MIN("row_shr:8 row_mask:0xf bank_mask:0xf")
+        "v_bcnt_u32_b32 %1, %1, %24\n\t"
+        "v_bcnt_u32_b32 %2, %2, %25\n\t"
+        PMX_DPP_MIN("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_bcnt_u32_b32 %3, %3, %26\n\t"
+        "v_bcnt_u32_b32 %4, %4, %27\n\t"
+        PMX_DPP_MIN("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "=&v"(v), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "=&s"(lw)
+        : "v"(nA[0]), "v"(nB[0]), "v"(nA[1]), "v"(nB[1]), "v"(lwords), "n"(UN), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]),
+          "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+    ccA[0] = x0 | (x2 << 16);
+    ccB[0] = x1 | (x3 << 16);
+    ccA[1] = bcnt_acc(x4, p[4]) | (bcnt_acc(x6, p[6]) << 16);
+    ccB[1] = bcnt_acc(x5, p[5]) | (bcnt_acc(x7, p[7]) << 16);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+#undef PMX_DPP_MIN
 
-template <int KPL>
+template <int KPL, bool EXTRA>
 __global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
+    // EXTRA: D = 64 KPL + 1 (d = [0, 256] at KPL 4 - the headline's range): the last disparity rides in lane 63 as a fifth value
+    // "E" (every lane computes one, 63 lanes' worth are pads) instead of doubling KPL for a 33rd lane: 10 more instructions per
+    // step against 20.
     // A workgroup = one image row, two wavefronts: wavefront 0 walks it from the left, wavefront 1 from the right; each STORES
     // its path costs on the first half of its walk (nobody has been there), both meet at one barrier, and each ADDS on the second
     // half to what the other stored (read 16 columns ahead through the L1-bypassing path: the bytes came from another wavefront).
@@ -671,6 +781,8 @@ __global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
     constexpr int Q = KPL / 4;
     constexpr unsigned kGuard = 1024u * 4u;  // bytes of zeroed guard in front of a code image (k_matching.hip kCodePad)
     static_assert(KPL == 4 || KPL == 8, "64 lanes x 4 or 8 disparities");
+    static_assert(!EXTRA || KPL == 4, "the extra disparity: one asm block written (Q = 1)");
+    constexpr int NK = KPL + (EXTRA ? 1 : 0);  // right words a lane reads per column
     const int lane = threadIdx.x & 63;
     const bool backward = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;
     const int row = blockIdx.x;
@@ -679,13 +791,16 @@ __global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
     const bool lane_active = d_first < D;
     const int nact = (D + KPL - 1) / KPL;
     const int lanec = lane < nact ? lane : nact - 1;  // lanes without a disparity read the last lane's words (in bounds, unused)
-    uint32_t padA[Q], padB[Q];
+    uint32_t padA[Q], padB[Q], pad1[KPL];  // (pad1: per disparity, the addend of its popcount)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int d = d_first + 4 * q;
         padA[q] = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
         padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
     }
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) pad1[k] = (d_first + k < D) ? 0u : kPad16;
+    const uint32_t padE = (lane == 63 ? 0u : kPad16) | (kPad16 << 16);  // (EXTRA) the pair (L[64 KPL] in lane 63, nothing)
     const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
     const uint32_t invpk = a.invalid_cost | (a.invalid_cost << 16);
     const bool row_ok = row >= o && row < H - o;
@@ -700,20 +815,31 @@ __global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(a.codeL + (ptrdiff_t)row * W) - kGuard), 0, code_span, kRsrcWord3);
     const unsigned offR = kGuard + (unsigned)((a.d0 + lanec * KPL) * 4);  // + 4 (c + k): right word of cell (c, k)
     const unsigned offL = kGuard + (unsigned)(lane & 15) * 4u;            // + 4 c16: left word of column c16 + (lane & 15)
-    // the volume's pixel stride is the family lane map's: the last lane stores what fits (dword q iff d_first + 4 q < Dp)
-    const bool fits0 = d_first < a.Dp, fits1 = d_first + 4 < a.Dp;
-    const unsigned offS64 = (Q == 2 && fits1) ? (unsigned)d_first : kOob;                   // both dwords
-    const unsigned offS32 = (Q == 2 ? (fits0 && !fits1) : fits0) ? (unsigned)d_first : kOob;  // the first one only
-    unsigned offP = kOob;  // read-back: nothing on the first half (loads return 0), the lane's bytes on the second
+    // ONE store per step: the launcher makes the volume's pixel stride a multiple of 8 for this walk (pmx_launch_sgm8), so a
+    // lane's 4 Q bytes never reach into the next pixel.  (A workgroup's vector-memory instructions in flight are what this
+    // kernel's step time hangs on - with four per step a step took 0.93 us, loads and stores out of range or not: DESIGN 7.22.)
+    const unsigned offS = d_first < a.Dp ? (unsigned)d_first : kOob;
+    const unsigned offP = lane_active ? (unsigned)d_first : 0u;  // read-back: lanes without a disparity re-read lane 0 (nothing is stored)
+    const unsigned offSE = lane == 63 ? 64u * KPL : kOob, offPE = lane == 63 ? 64u * KPL : 0u;  // (EXTRA) the last disparity's byte
+    bool blk_ok = false;  // (uniform) every cell of the block's 16 columns is a number
+    bool second = false;  // (uniform) past the meeting point: the other wavefront's bytes are read back and added
     const int nblk = (W + 15) / 16, hb = nblk / 2;  // blocks [0, hb) are the forward walk's first half
 
     uint32_t wr[16];        // right words: slot (column + k) & 15
     uint32_t Lcur, Lnxt;    // left words of this block of 16 columns and of the next: lane & 15 = column & 15
-    uint32_t prev[16][Q];   // what the other wavefront stored: slot column & 15, requested 16 columns ahead
-    uint32_t A[Q], B[Q];
+    uint32_t prev[16][Q];   // what the other wavefront stored: slot column & 15, requested 16 columns ahead (zeros on the first half)
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) prev[sl][q] = 0u;
+    uint32_t prevE[EXTRA ? 16 : 1];
+#pragma unroll
+    for (int sl = 0; sl < (EXTRA ? 16 : 1); ++sl) prevE[sl] = 0u;
+    uint32_t A[Q], B[Q], E = padE;
 #pragma unroll
     for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
     uint32_t M = 0u;  // (wave-uniform: a scalar register)
+    uint32_t belowB = kPadPk, aboveA = kPadPk;  // the neighbouring lanes' edge sums (step)
 
     auto load_prev = [&](int c, uint32_t (&pv)[Q]) {  // the other wavefront's bytes of column c (sc1: past this CU's L1)
         const unsigned so = (unsigned)c * (unsigned)a.Dp;
@@ -724,22 +850,30 @@ __global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
             pv[0] = t.x; pv[1] = t.y;
         }
     };
+    uint32_t nccA[Q], nccB[Q], nccE = padE;  // the costs of the column the next step works on
+    auto costs_of = [&](auto u_tag, uint32_t lwords) {  // column (block) + U: its left word is lane U of lwords
+        constexpr int U = decltype(u_tag)::value;
+        const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)lwords, U);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t a0 = bcnt_acc(lw ^ wr[(U + 4 * q) & 15], pad1[4 * q]);
+            const uint32_t a2 = bcnt_acc(lw ^ wr[(U + 4 * q + 2) & 15], pad1[4 * q + 2]);
+            const uint32_t b1 = bcnt_acc(lw ^ wr[(U + 4 * q + 1) & 15], pad1[4 * q + 1]);
+            const uint32_t b3 = bcnt_acc(lw ^ wr[(U + 4 * q + 3) & 15], pad1[4 * q + 3]);
+            nccA[q] = a0 | (a2 << 16);  // (v_lshl_or_b32)
+            nccB[q] = b1 | (b3 << 16);
+        }
+        if constexpr (EXTRA) nccE = bcnt_acc(lw ^ wr[(U + KPL) & 15], padE);
+    };
     auto step = [&](int c, auto u_tag, auto dir_tag) {
         constexpr int U = decltype(u_tag)::value;
         constexpr bool BACK = decltype(dir_tag)::value;
-        const uint32_t lw = (uint32_t)__builtin_amdgcn_readlane((int)Lcur, U);
-        uint32_t ccA[Q], ccB[Q];
+        uint32_t ccA[Q], ccB[Q];  // this column's costs: made during the previous step (costs_of below)
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const uint32_t a0 = __builtin_popcount(lw ^ wr[(U + 4 * q) & 15]) + (padA[q] & 0xffffu);
-            const uint32_t a2 = __builtin_popcount(lw ^ wr[(U + 4 * q + 2) & 15]) + (padA[q] >> 16);
-            const uint32_t b1 = __builtin_popcount(lw ^ wr[(U + 4 * q + 1) & 15]) + (padB[q] & 0xffffu);
-            const uint32_t b3 = __builtin_popcount(lw ^ wr[(U + 4 * q + 3) & 15]) + (padB[q] >> 16);
-            ccA[q] = a0 | (a2 << 16);
-            ccB[q] = b1 | (b3 << 16);
-        }
-        const bool all_ok = row_ok && c >= o && c < W - o && c + a.d0 >= o && c + a.d0 + D - 1 < W - o;
-        if (!all_ok) {  // (uniform; the image's borders - no memory operation in here)
+        for (int q = 0; q < Q; ++q) { ccA[q] = nccA[q]; ccB[q] = nccB[q]; }
+        uint32_t ccE = nccE;
+        // (uniform; the image's borders - no memory operation in here; blk_ok: nothing to look at in this block of 16 columns)
+        if (!blk_ok && !(row_ok && c >= o && c < W - o && c + a.d0 >= o && c + a.d0 + D - 1 < W - o)) {
             asm volatile("; cells that are not numbers" ::);
             const uint32_t vm = cells_that_are_numbers(row_ok && c >= o && c < W - o, c + a.d0 + d_first - o, wvalid, KPL);
 #pragma unroll
@@ -747,29 +881,42 @@ __global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
                 ccA[q] = keep_numbers(ccA[q], vm, 4 * q, invpk) | padA[q];
                 ccB[q] = keep_numbers(ccB[q], vm, 4 * q + 1, invpk) | padB[q];
             }
+            if constexpr (EXTRA) {  // (uniform: one disparity)
+                const int ue = c + a.d0 + 64 * KPL - o;
+                if (!(row_ok && c >= o && c < W - o && ue >= 0 && ue < wvalid)) ccE = a.invalid_cost | padE;
+            }
             if (BACK && c >= W) {  // the backward walk's first block may begin past the row's end: the path starts at column W - 1
 #pragma unroll
                 for (int q = 0; q < Q; ++q) { A[q] = padA[q]; B[q] = padB[q]; }
+                E = padE;
                 M = 0u;
             }
         }
         // one new right word: forward, column c's first word is dead and column c + 16's arrives in its slot; backward, column
-        // c's last word is dead and the first word of column c + KPL - 17 arrives (the descriptor starts a guard's length before
+        // c's last word is dead and the first word of column c + NK - 17 arrives (the descriptor starts a guard's length before
         // the row: scalar offsets are unsigned)
-        if (BACK) wr[(U + KPL - 1) & 15] = __builtin_amdgcn_raw_buffer_load_b32(rsR, offR - 64u + (unsigned)(KPL - 1) * 4u, (unsigned)c * 4u, 0);
+        if (BACK) wr[(U + NK - 1) & 15] = __builtin_amdgcn_raw_buffer_load_b32(rsR, offR - 64u + (unsigned)(NK - 1) * 4u, (unsigned)c * 4u, 0);
         else wr[U] = __builtin_amdgcn_raw_buffer_load_b32(rsR, offR + 64u, (unsigned)c * 4u, 0);
-        const uint32_t belowB = dpp8<0x138>(kPadPk, B[Q - 1]);  // wave_shr:1 - the previous lane's (.., L[d_first - 1]); +inf in lane 0
-        const uint32_t aboveA = dpp8<0x130>(kPadPk, A[0]);      // wave_shl:1 - the next lane's (L[d_first + KPL], ..); +inf in lane 63
-        const uint32_t mp2 = M + P2pk, negM = 0u - M;
+        // wave_shr:1 - the previous lane's (.., L[d_first - 1]); wave_shl:1 - the next lane's (L[d_first + KPL], ..).  Lane 0 of
+        // the first and lane 63 of the second are never written by the shift: they keep their +inf from before the loop, and
+        // the registers stay where they are (no constant to load per step)
+        belowB = dpp8<0x138>(belowB, B[Q - 1]);
+        aboveA = dpp8<0x130>(EXTRA ? E : aboveA, A[0]);  // (EXTRA: lane 63's upper neighbour is its own fifth value)
+        const uint32_t mp2 = M + P2pk, negM = 0u - M;  // (scalar registers, and read as such: hmin3_s, add3_s)
         uint32_t nA[Q], nB[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const uint32_t loA = __builtin_amdgcn_alignbit(B[q], q > 0 ? B[q > 0 ? q - 1 : 0] : belowB, 16);
             const uint32_t hiB = __builtin_amdgcn_alignbit(q < Q - 1 ? A[q < Q - 1 ? q + 1 : 0] : aboveA, A[q], 16);
-            const uint32_t tA = hmin3(A[q], hmin(loA, B[q]) + P1pk, mp2);
-            const uint32_t tB = hmin3(B[q], hmin(A[q], hiB) + P1pk, mp2);
-            nA[q] = add3(tA, ccA[q], negM);
-            nB[q] = add3(tB, ccB[q], negM);
+            const uint32_t tA = hmin3_s(A[q], hmin(loA, B[q]) + P1pk, mp2);
+            const uint32_t tB = hmin3_s(B[q], hmin(A[q], hiB) + P1pk, mp2);
+            nA[q] = add3_s(tA, ccA[q], negM);
+            nB[q] = add3_s(tB, ccB[q], negM);
+        }
+        uint32_t nE = 0u;
+        if constexpr (EXTRA) {  // low half: L[64 KPL], whose lower neighbour is the lane's last B half; high half: a pad that stays one
+            const uint32_t tE = hmin3_s(E, (B[Q - 1] >> 16) + P1pk, mp2);
+            nE = add3_s(tE, ccE, negM);
         }
         {   // bytes d .. d+3 per dword (pads spill upwards only); on the second half the other wavefront's bytes are added
             const unsigned so = (unsigned)c * (unsigned)a.Dp;  // (past the row's end: out of range, dropped)
@@ -778,46 +925,66 @@ __global__ __launch_bounds__(128) void sgm_u8_hrow_codes_kernel(hpc_args a) {
             for (int q = 0; q < Q; ++q) packed[q] = (nA[q] | (nB[q] << 8)) + prev[U][q];
             if constexpr (Q == 2) {
                 u32x2 t; t.x = packed[0]; t.y = packed[1];
-                __builtin_amdgcn_raw_buffer_store_b64(t, rsO, offS64, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(t, rsO, offS, so, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(packed[0], rsO, offS, so, 0);
             }
-            __builtin_amdgcn_raw_buffer_store_b32(packed[0], rsO, offS32, so, 0);
+            if constexpr (EXTRA) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(nE + prevE[U]), rsO, offSE, so, 0);
         }
-        load_prev(BACK ? c - 16 : c + 16, prev[U]);  // the slot just used (first half, and columns outside the row: zeros)
-        uint32_t m = hmin(nA[0], nB[0]);
+        // the slot just used: the other wavefront's bytes 16 columns ahead (columns outside the row: zeros).  Under a (uniform)
+        // branch: the compiler's wait counts then ignore these loads on the merged path, which only makes the waits for the
+        // right words a few operations earlier than needed - they are requested 9 to 12 steps ahead
+        if (second) {
+            load_prev(BACK ? c - 16 : c + 16, prev[U]);
+            if constexpr (EXTRA)
+                prevE[U] = __builtin_amdgcn_raw_buffer_load_b8(rsO, offPE, (unsigned)(BACK ? c - 16 : c + 16) * (unsigned)a.Dp, 16);
+        }
+        // the wave's minimum; the NEXT column's costs do not hang on it and are made in the reduction's idle issue slots
+        uint32_t lmin;
+        {
+            constexpr int UN = BACK ? (U + 15) & 15 : (U + 1) & 15;
+            uint32_t wn[KPL];
 #pragma unroll
-        for (int q = 1; q < Q; ++q) m = hmin3(m, nA[q], nB[q]);
-        const uint32_t m1 = m & 0xffffu, m2 = m >> 16;
-        const uint32_t lmin = wave_min_u32(m1 < m2 ? m1 : m2);
-        M = lmin | (lmin << 16);
+            for (int kk = 0; kk < KPL; ++kk) wn[kk] = wr[(UN + kk) & 15];
+            const uint32_t lwords = (BACK ? U == 0 : U == 15) ? Lnxt : Lcur;
+            if constexpr (EXTRA) lmin = wave_min_and_costs_x<UN>(nA, nB, nE, lwords, wn, wr[(UN + KPL) & 15], pad1, padE, nccA, nccB, nccE);
+            else lmin = wave_min_and_costs<UN>(nA, nB, lwords, wn, pad1, nccA, nccB);
+        }
+        asm("s_pack_ll_b32_b16 %0, %1, %1" : "=s"(M) : "s"(lmin));  // lmin | lmin << 16
 #pragma unroll
         for (int q = 0; q < Q; ++q) { A[q] = nA[q]; B[q] = nB[q]; }
+        E = nE;
     };
     auto walk = [&](auto dir_tag) {
         constexpr bool BACK = decltype(dir_tag)::value;
         const int b0 = BACK ? nblk - 1 : 0, db = BACK ? -1 : 1;
         {   // prologue: the first block's words (columns below 0 / past the row read the guards or other rows: never used)
             const int c16 = 16 * b0;
-            const int top = BACK ? c16 + 15 + KPL - 1 : c16 + 15;  // highest word index (column + k) of the first 16 needed
+            const int top = BACK ? c16 + 15 + NK - 1 : c16 + 15;  // highest word index (column + k) of the first 16 needed
 #pragma unroll
             for (int sl = 0; sl < 16; ++sl)
                 wr[sl] = __builtin_amdgcn_raw_buffer_load_b32(rsR, offR, (unsigned)(top - ((top - sl) & 15)) * 4u, 0);
             Lcur = __builtin_amdgcn_raw_buffer_load_b32(rsL, offL, (unsigned)c16 * 4u, 0);
             Lnxt = __builtin_amdgcn_raw_buffer_load_b32(rsL, BACK ? offL - 64u : offL + 64u, (unsigned)c16 * 4u, 0);
-#pragma unroll
-            for (int sl = 0; sl < 16; ++sl) load_prev(0, prev[sl]);  // (offP is out of range: zeros)
         }
         PMX_LOOP_ENTRY_DRAIN();
+        if constexpr (BACK) costs_of(std::integral_constant<int, 15>{}, Lcur);
+        else costs_of(std::integral_constant<int, 0>{}, Lcur);
         for (int n = 0; n < nblk; ++n) {
             const int b = b0 + db * n;
             const int c16 = 16 * b;
+            blk_ok = row_ok && c16 >= o && c16 + 15 < W - o && c16 + a.d0 >= o && c16 + 15 + a.d0 + D - 1 < W - o;
             if (b == (BACK ? hb - 1 : hb)) {
                 // the meeting point: everybody's first half is in memory before anybody's second half reads it; from here on the
                 // read-back is real (this block's 16 columns now, then 16 columns ahead in every step)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 __syncthreads();
-                offP = lane_active ? (unsigned)d_first : 0u;  // lanes without a disparity re-read lane 0 (nothing is stored)
+                second = true;
 #pragma unroll
-                for (int sl = 0; sl < 16; ++sl) load_prev(c16 + sl, prev[sl]);
+                for (int sl = 0; sl < 16; ++sl) {
+                    load_prev(c16 + sl, prev[sl]);
+                    if constexpr (EXTRA) prevE[sl] = __builtin_amdgcn_raw_buffer_load_b8(rsO, offPE, (unsigned)(c16 + sl) * (unsigned)a.Dp, 16);
+                }
                 PMX_LOOP_ENTRY_DRAIN();
             }
 #define PMX_HROW_STEP(UV) step(c16 + UV, std::integral_constant<int, UV>{}, dir_tag)
@@ -1021,8 +1188,8 @@ bool pmx_sgm8_supported(int gl, int kpl, int nw) { return gl == 16 && (kpl % 4) 
 int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2, uint32_t invalid_cost) {
     const int H = cv->H, W = cv->W;
     const int nact = (cv->D + kpl - 1) / kpl;
-    const int Dp = nact * kpl;  // multiple of 4
-    const size_t vol = pmx_dir_stride(H, W, Dp);
+    int Dp = nact * kpl;  // multiple of 4
+    size_t vol = pmx_dir_stride(H, W, Dp);
     const int nw = (cv->win * cv->win + 31) / 32;
     // five-bit costs when they fit (PMX_COST5=0 keeps bytes: test hook)
     const char* e5 = getenv("PMX_COST5");
@@ -1054,14 +1221,20 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     const char* ehp = getenv("PMX_SGM8_HPAIR");
     const char* ec = getenv("PMX_SGM8_CODES");
     const bool codes_never = ec && ec[0] == '0', codes_always = ec && ec[0] == '1';
-    // (4096 columns x 257, one GPU, ms per step, row walk / two-sided / one-sided: 592 rows 3.0 / 3.5 / 4.9, 1104 rows 4.8 / 5.0 / 6.7,
-    //  2088 rows 9.2 / 8.8 / 9.7, 3072 rows - / 13.0 / 12.3: profiles/r04_tiles.txt, r03_e_shapes.txt)
-    int hp_mode = H < 2560 ? (H < 1536 && W >= 32 && codes_ok && !codes_never ? 3 : 2) : 1;
+    // (4096 columns x 257, one GPU, ms per step, row walk with the marching kernel from the words / row walk with the marching
+    //  kernel on the cost volume / two-sided / one-sided: 592 rows 2.55 / 2.65 / 3.5 / 4.9, 1104 rows 4.35 / 4.6 / 5.0 / 6.7,
+    //  2088 rows 8.85 / 8.3 / 8.55 / 9.7, 3072 rows - / - / 13.0 / 12.3, 4096 rows 17.2 / 15.9 / - / 14.6: profiles/r04_tiles.txt,
+    //  r03_e_shapes.txt)
+    int hp_mode = H < 2560 ? (W >= 32 && codes_ok && !codes_never ? 3 : 2) : 1;
     if (ehp && ehp[0] >= '1' && ehp[0] <= '3') hp_mode = ehp[0] - '0';
     if (hp_mode == 3 && (!codes_ok || W < 32)) hp_mode = 2;
     const bool two_sided = hp_mode == 2;
+    if (fam && hp_mode == 3) {  // the row walk stores 8 bytes per lane: a pixel stride of a multiple of 8 (at most 4 bytes of pad)
+        Dp = (Dp + 7) & ~7;
+        vol = pmx_dir_stride(H, W, Dp);
+    }
     const bool hp_codes = fam && (hp_mode == 3 || (hp_mode == 1 && codes_ok && codes_always));
-    bool fam_codes = fam && codes_ok && !codes_never && (codes_always || hp_mode == 3);
+    bool fam_codes = fam && codes_ok && !codes_never && (codes_always || (hp_mode == 3 && H < 1536));
     if (const char* efc = getenv("PMX_SGM8_FAMCODES")) fam_codes = fam && codes_ok && efc[0] == '1';  // (A/B hook: the marching kernel alone)
     const bool from_codes = hp_codes && fam_codes;  // no cost volume at all
     if (!from_codes && cv->cost8_bytes < cvol) {
@@ -1160,8 +1333,9 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
 #define PMX_HPC(KPLV) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hpair_codes_kernel<KPLV>), hgrid, hblock, 0, hs, h)
                 if (hp_mode == 3) {
                     const dim3 rgrid(H), rblock(128);  // one row per workgroup: a wavefront from each end
-                    if (cv->D <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hrow_codes_kernel<4>), rgrid, rblock, 0, hs, h);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hrow_codes_kernel<8>), rgrid, rblock, 0, hs, h);
+                    if (cv->D <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hrow_codes_kernel<4, false>), rgrid, rblock, 0, hs, h);
+                    else if (cv->D == 257) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hrow_codes_kernel<4, true>), rgrid, rblock, 0, hs, h);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_hrow_codes_kernel<8, false>), rgrid, rblock, 0, hs, h);
                 } else
                 switch (kpl) {
                     case 4: PMX_HPC(4); break;

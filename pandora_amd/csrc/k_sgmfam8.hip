@@ -86,9 +86,13 @@ struct fam8_args {
 // lane's new costs (both halves still to be reduced).
 template <int Q>
 __device__ __forceinline__ uint32_t path_update(const uint32_t (&A)[Q], const uint32_t (&B)[Q], uint32_t M, const uint32_t (&ccA)[Q],
-                                                const uint32_t (&ccB)[Q], uint32_t P1pk, uint32_t P2pk, uint32_t (&nA)[Q], uint32_t (&nB)[Q]) {
-    const uint32_t belowB = dppo<0x111>(kPadPk, B[Q - 1]);  // row_shr:1 - the previous lane's (.., L[d_first - 1]); +inf in lane 0
-    const uint32_t aboveA = dppo<0x101>(kPadPk, A[0]);      // row_shl:1 - the next lane's (L[d_first + KPL], ..); +inf in lane 15
+                                                const uint32_t (&ccB)[Q], uint32_t P1pk, uint32_t P2pk, uint32_t (&nA)[Q], uint32_t (&nB)[Q],
+                                                uint32_t (&edge)[2]) {
+    // row_shr:1 - the previous lane's (.., L[d_first - 1]); row_shl:1 - the next lane's (L[d_first + KPL], ..).  Lane 0 of a
+    // pixel's 16 is never written by the first shift, lane 15 never by the second: `edge` (kPadPk before the first step, the
+    // caller's for the kernel's life) keeps their +inf, and no constant is loaded per step
+    const uint32_t belowB = edge[0] = dppo<0x111>(edge[0], B[Q - 1]);
+    const uint32_t aboveA = edge[1] = dppo<0x101>(edge[1], A[0]);
     const uint32_t mp2 = M + P2pk;
     const uint32_t negM = 0u - M;
 #pragma unroll
@@ -405,6 +409,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
     }
 
     uint32_t LBa[Q], LBb[Q];  // the path that stays in its lane group (predecessor column c+1)
+    uint32_t edgeV[2] = {kPadPk, kPadPk}, edgeA[2] = {kPadPk, kPadPk}, edgeB[2] = {kPadPk, kPadPk};  // (path_update)
     uint32_t MB = 0u;
 #pragma unroll
     for (int q = 0; q < Q; ++q) { LBa[q] = padA[q]; LBb[q] = padB[q]; }
@@ -515,9 +520,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
             MV = r0 ? 0u : MV; MA = rsA ? 0u : MA; MB = rsB ? 0u : MB;
         }
         uint32_t nVa[Q], nVb[Q], nAa[Q], nAb[Q], nBa[Q], nBb[Q];
-        uint32_t mV = path_update<Q>(LVa, LVb, MV, ccA, ccB, P1pk, P2pk, nVa, nVb);
-        uint32_t mA = path_update<Q>(LAa, LAb, MA, ccA, ccB, P1pk, P2pk, nAa, nAb);
-        uint32_t mB = path_update<Q>(LBa, LBb, MB, ccA, ccB, P1pk, P2pk, nBa, nBb);
+        uint32_t mV = path_update<Q>(LVa, LVb, MV, ccA, ccB, P1pk, P2pk, nVa, nVb, edgeV);
+        uint32_t mA = path_update<Q>(LAa, LAb, MA, ccA, ccB, P1pk, P2pk, nAa, nAb, edgeA);
+        uint32_t mB = path_update<Q>(LBa, LBb, MB, ccA, ccB, P1pk, P2pk, nBa, nBb, edgeB);
         group_min3(mV, mA, mB);
         MB = mB;
         // next row's predecessors

@@ -62,6 +62,11 @@ def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
     (2, 64, 0, 10, 5, 8, 32),         # two rows
     (70, 16, -5, 5, 5, 1, 2),         # exactly one window wide, tall
     (45, 67, -20, 20, 7, 8, 30),      # census 7x7: byte costs (invalid cost 50: 3 * 80 = 240 fits a byte)
+    (20, 600, 0, 256, 5, 8, 32),      # 257 disparities on a row wider than the range: the row walk's 64 x 4 + 1 form, blocks of
+                                      # 16 columns with and without cells that are not numbers
+    (14, 420, -256, 0, 5, 8, 32),     # ... to the other side
+    (12, 340, -255, 0, 5, 8, 32),     # 256 disparities: the row walk's 64 lanes all busy
+    (12, 340, 0, 257, 5, 8, 32),      # 258: eight per lane
 ])
 @pytest.mark.parametrize("nw,hpair,codes", [("4", "2", "0"), ("8", "1", "0"), ("8", "2", "0"),
                                             ("8", "1", "1"),   # both kernels from the census words, four rows per wavefront
