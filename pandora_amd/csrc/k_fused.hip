@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "pmx_internal.h"
+#include "pmx_buf.h"
 
 static constexpr int kWavesPerBlock = 4;
 static constexpr uint32_t kInf = 0x7fffu;
@@ -421,6 +422,141 @@ __global__ __launch_bounds__(256) void sum8_wta_kernel(sum8_args a, size_t npix,
     }
 }
 
+// The WTA of the direction-family form (three byte volumes, 16 lanes x KPL disparities, KPL a multiple of 4, no per-pixel ranges):
+// the kernel above spends about 300 instructions per four pixels and is bound by them (2.8 ms for 13.1 GB at 4096 x 4096 x 257 =
+// 4.7 TB/s).  Same results here with half of them: a wavefront stays in one image row (no 64-bit divisions; the three volumes'
+// rows behind buffer descriptors, a pixel four of them ahead already requested), the bytes are summed in pairs - v_perm spreads
+// the even / odd bytes of a dword into two 16-bit fields, v_add3 adds the three volumes' - the candidate keys (sum << 16 | index)
+// come straight from the pairs (v_lshl_or / v_and_or), the validity tests of the image's borders are one scalar test per four
+// pixels, and the sums go to LDS as pairs (three wide writes instead of 20) for the winner's neighbours.
+template <int KPL>
+__global__ __launch_bounds__(256) void sum3_wta_kernel(sum8_args a, int qpw, double d0, float invalid_disparity, float* __restrict__ disp,
+                                                       int64_t* __restrict__ validity, float4* __restrict__ near) {
+    constexpr int Q = KPL / 4;
+    constexpr int LST = 2 * Q;            // dwords of LDS per lane: the pairs (E0, O0, E1, O1, ..)
+    constexpr int SROW = 16 * LST + 2;    // ... per pixel; S(d) is the 16-bit unit (d & ~3) | (d & 1) << 1 | (d >> 1) & 1 of the row
+    static_assert(KPL % 4 == 0, "whole dwords per lane");
+    __shared__ __attribute__((aligned(8))) uint32_t sbuf[4][4][SROW];
+    const int lane = threadIdx.x & 63, wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane & 15, grp = lane >> 4;
+    const int H = a.H, W = a.W, D = a.D, o = a.o;
+    const int r = blockIdx.y;
+    const int quads_row = (W + 3) / 4;
+    const int q0 = (blockIdx.x * 4 + wv) * qpw;  // (qpw = 16: two quads per turn of the loop, one result per lane of a group)
+    if (q0 >= quads_row) return;
+    const int q1 = min(quads_row, q0 + qpw);
+    const int d_first = sub * KPL;
+    const bool lane_active = d_first < D;
+    const int nown = min(KPL, D - d_first);  // real disparities of this lane (<= 0 for idle lanes)
+    const int wvalid = W - 2 * o;
+    uint32_t idx[KPL];  // pads get all-ones: (sum << 16) | idx is then never a minimum
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) idx[e] = (e < nown) ? (uint32_t)(d_first + e) : 0xffffffffu;
+    const unsigned row_bytes = (unsigned)W * (unsigned)a.Dp;
+    __amdgpu_buffer_rsrc_t rs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        rs[k] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ldir + k * a.dstride + (size_t)r * row_bytes), 0, row_bytes, kRsrcWord3);
+    // (columns past the row's end - the last quad of a width that is no multiple of 4 - and idle lanes read zeros; nothing of them is stored)
+    const unsigned voff = lane_active ? (unsigned)(grp * a.Dp + d_first) : kOob;
+    // quads [qa, qb): every cell of their four pixels is a number (one scalar test per quad instead of the per-cell ones)
+    const bool row_ok = r >= o && r < H - o;
+    const int ca = max(o, o - a.d0), cb = min(W - o, W - o - a.d0 - (D - 1));  // columns [ca, cb)
+    const int qa = row_ok ? (ca + 3) / 4 : 0, qb = row_ok ? cb / 4 : 0;
+    uint32_t* const mine = &sbuf[wv][grp][sub * LST];
+    const uint16_t* const halves = (const uint16_t*)&sbuf[wv][grp][0];
+    auto half_of = [](int d) { return (d & ~3) | ((d & 1) << 1) | ((d >> 1) & 1); };
+
+    auto fetch = [&](int q, uint32_t (&x)[3][Q]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) load_dwords<Q>(rs[k], voff, x[k], (unsigned)(q * 4) * (unsigned)a.Dp);
+    };
+    uint32_t my_key = 0xffffffffu, my_nb = 0u;  // the result of quad q0 + sub (process)
+    auto process = [&](int q, const uint32_t (&x)[3][Q]) {
+        const int c = q * 4 + grp;
+        // ---- sums of the three volumes: E[i] = (S(4i), S(4i+2)), O[i] = (S(4i+1), S(4i+3)) as 16-bit pairs
+        uint32_t E[Q], O[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            auto ev = [](uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x0c020c00u); };
+            auto od = [](uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x0c030c01u); };
+            E[i] = ev(x[0][i]) + ev(x[1][i]) + ev(x[2][i]);
+            O[i] = od(x[0][i]) + od(x[1][i]) + od(x[2][i]);
+            u32x2 t; t.x = E[i]; t.y = O[i];
+            *(u32x2*)(mine + 2 * i) = t;
+        }
+        // ---- candidate keys; slot e of the lane is a number iff elo <= e < ehi
+        uint32_t key = 0xffffffffu;
+        if (q >= qa && q < qb) {  // (uniform)
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                key = umin2(key, (E[i] << 16) | idx[4 * i]);
+                key = umin2(key, (O[i] << 16) | idx[4 * i + 1]);
+                key = umin2(key, (E[i] & 0xffff0000u) | idx[4 * i + 2]);
+                key = umin2(key, (O[i] & 0xffff0000u) | idx[4 * i + 3]);
+            }
+        } else {
+            const bool pix_ok = row_ok & (c >= o) & (c < W - o);
+            const int us = c + a.d0 + d_first - o;  // right column of slot 0, relative to the first valid one
+            const int elo = max(0, -us), ehi = pix_ok ? min(nown, wvalid - us) : 0;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                auto cand = [&](int e, uint32_t k) { return ((e >= elo) & (e < ehi)) ? k : 0xffffffffu; };
+                key = umin2(key, cand(4 * i, (E[i] << 16) | idx[4 * i]));
+                key = umin2(key, cand(4 * i + 1, (O[i] << 16) | idx[4 * i + 1]));
+                key = umin2(key, cand(4 * i + 2, (E[i] & 0xffff0000u) | idx[4 * i + 2]));
+                key = umin2(key, cand(4 * i + 3, (O[i] & 0xffff0000u) | idx[4 * i + 3]));
+            }
+        }
+        key = group_allmin_u<16>(key);  // every lane of the group now holds the pixel's (min sum, first index)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- the winner's neighbours S(k-1), S(k+1) while the pixel's sums are in LDS; lane (q - q0) of the group keeps the
+        // pixel's result: the maps are written once per 16 quads, by all 64 lanes (the result code, about 60 instructions, once
+        // per wavefront instead of once per quad with four lanes active)
+        {
+            const int kb = (int)(key & 0xffffu);  // (a pixel without a number: 0xffff - the reads stay inside the row, unused)
+            const uint32_t c0 = halves[half_of(min(max(kb - 1, 0), 16 * KPL - 1))], c2 = halves[half_of(min(kb + 1, 16 * KPL - 1))];
+            const bool keep = sub == q - q0;
+            my_key = keep ? key : my_key;
+            my_nb = keep ? (c0 | (c2 << 16)) : my_nb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the next quad overwrites the row
+    };
+    // two quads per turn, each requested while the one before it is worked on (a quad past the wavefront's last one reads bytes
+    // nobody uses and stores nothing)
+    uint32_t xa[3][Q], xb[3][Q];
+    fetch(q0, xa);
+    for (int q = q0; q < q1; q += 2) {
+        fetch(q + 1, xb);
+        process(q, xa);
+        fetch(q + 2, xa);
+        process(q + 1, xb);
+    }
+    // ---- the maps: lane `sub` of group `grp` holds pixel (q0 + sub) * 4 + grp
+    const int c = (q0 + sub) * 4 + grp;
+    if (q0 + sub < q1 && c < W) {
+        const size_t pix = (size_t)r * W + c;
+        const uint32_t key = my_key;
+        if (key == 0xffffffffu) {
+            near[pix] = make_float4(g_nan(), g_nan(), g_nan(), __int_as_float(-8));
+            disp[pix] = invalid_disparity;  // disparity.py:452-455
+            int64_t m = validity[pix];
+            if ((m & FMSK_INVALID) == 0) validity[pix] = FMSK_INVALID;  // disparity.py:471-474
+        } else {
+            const int kb = (int)(key & 0xffffu);
+            const int qr = c + a.d0 + kb - o;  // right column of the winner, relative
+            const bool v0 = (kb - 1 >= 0) & (qr - 1 >= 0);
+            const bool v2 = (kb + 1 < D) & (qr + 1 < wvalid);
+            near[pix] = make_float4(v0 ? (float)(my_nb & 0xffffu) : g_nan(), (float)(key >> 16), v2 ? (float)(my_nb >> 16) : g_nan(),
+                                    __int_as_float(kb));
+            disp[pix] = (float)(d0 + (double)kb);
+        }
+    }
+}
+
 __device__ __forceinline__ float sum8_cell(const sum8_args& a, size_t pix, int r, int c, int k) {
     if (cell_is_nan(a, r, c, k)) return g_nan();
     const size_t vol = a.dstride;
@@ -720,6 +856,21 @@ int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity)
     }
         PMX_FUSED_MAPS(PMX_WTA_CASE)
 #undef PMX_WTA_CASE
+        // three volumes, no per-pixel ranges: the leaner kernel (PMX_WTA3=0: the general one, A/B hook)
+        const char* e3 = getenv("PMX_WTA3");
+        if (!launched && cv->nvol == 3 && cv->gl == 16 && !cv->has_range && cv->kpl % 4 == 0 && cv->kpl <= 20 && !(e3 && e3[0] == '0')) {
+            const int qpw = 16;
+            const int quads_row = (cv->W + 3) / 4;
+            const dim3 g3((unsigned)(((quads_row + qpw - 1) / qpw + 3) / 4), (unsigned)cv->H);
+#define PMX_WTA3L(KPLV)                                                                                                       \
+    case KPLV:                                                                                                               \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sum3_wta_kernel<KPLV>), g3, dim3(256), 0, ctx->stream, make_sum8(cv), qpw, (double)cv->d0, \
+                           invalid_disparity, ctx->disp, ctx->validity, (float4*)ctx->near);                                   \
+        break
+            switch (cv->kpl) { PMX_WTA3L(4); PMX_WTA3L(8); PMX_WTA3L(12); PMX_WTA3L(16); PMX_WTA3L(20); }
+#undef PMX_WTA3L
+            launched = true;
+        }
 #define PMX_WTA3_CASE(KPLV)                                                                                             \
     if (!launched && cv->nvol == 3 && cv->gl == 16 && cv->kpl == KPLV) {                                               \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(sum8_wta_kernel<16, KPLV, 3>), dim3(grid), dim3(256), 0, ctx->stream, make_sum8(cv), \
