@@ -533,11 +533,14 @@ def spawn_ranks(n, watchdog_s):
         codes = [p.poll() for p in procs]
         bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
         if bad:
-            r, c = bad[0]
-            sys.stderr.write(f"bench.py: rank {r} exited with code {c}; stopping the other ranks\n")
+            # a rank that dies takes its peers' connections with it: they may fail within the same tenth of a second - every one
+            # that has is named (the exit code is the first named rank's)
+            time.sleep(0.3)
+            bad = [(r, p.poll()) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            sys.stderr.write("bench.py: " + "; ".join(f"rank {r} exited with code {c}" for r, c in bad) + "; stopping the other ranks\n")
             stop_all()
             tails()
-            rc = c if c > 0 else 1
+            rc = bad[0][1] if bad[0][1] > 0 else 1
             break
         if all(c == 0 for c in codes):
             f = logs[0]  # a clean run: rank 0's stderr (RCCL's banner, warnings) is passed on

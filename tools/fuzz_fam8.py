@@ -42,7 +42,9 @@ def main():
         # the horizontal pair's one-sided / two-sided walk on the cost volume / row-per-wavefront walk from the census words; the
         # Hamming costs from a cost volume or made inside the SGM kernels (round 4), for the marching kernel alone or for both
         os.environ["PMX_SGM8_HPAIR"] = str(rng.choice([1, 2, 3, 3]))
-        for k, v in (("PMX_SGM8_CODES", rng.choice(["", "0", "1"])), ("PMX_SGM8_FAMCODES", rng.choice(["", "", "0", "1"]))):
+        # ... and the WTA of the three volumes by the lean kernel (default) or the general one
+        for k, v in (("PMX_SGM8_CODES", rng.choice(["", "0", "1"])), ("PMX_SGM8_FAMCODES", rng.choice(["", "", "0", "1"])),
+                     ("PMX_WTA3", rng.choice(["", "", "", "0"]))):
             if v:
                 os.environ[k] = str(v)
             else:
@@ -85,6 +87,7 @@ def main():
         if not ok:
             print(f"DIFFERENCE seed {seed}: H={H} W={W} win={win} d=[{dmin},{dmax}] P1={P1} P2={P2} nw={os.environ['PMX_SGM8_FAM_NW']} "
                   f"hpair={os.environ['PMX_SGM8_HPAIR']} codes={os.environ.get('PMX_SGM8_CODES')} famcodes={os.environ.get('PMX_SGM8_FAMCODES')} "
+                  f"wta3={os.environ.get('PMX_WTA3')} "
                   f"grids={grids is not None} family={took_family} volume_equal={np.array_equal(vol, ref, equal_nan=True)}", flush=True)
             sys.exit(1)
         cells += H * W * D

@@ -19,4 +19,4 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE TA_TA_BUSY_sum SQ_LDS_BANK_CONFLICT 
 { echo "# rocprofv3 --pmc <SQ counters> (three passes) -- $CMD   (MI355X, $TAG)"
   python tools/rocpd_pmc.py $OUT/mix*.db; python tools/rocpd_pmc.py $OUT/act*.db | tail -n +2; python tools/rocpd_pmc.py $OUT/ta*.db | tail -n +2; } > $OUT/pmc_sq.csv
 find $OUT -name "*.db" -delete
-head -14 $OUT/kernel_stats.csv; grep -E "fam8|hpair|sum8_wta|census_cost" $OUT/pmc_hbm.csv; grep -E "fam8|hpair" $OUT/pmc_sq.csv
+head -14 $OUT/kernel_stats.csv; grep -E "fam8|hpair|hrow|sum8_wta|sum3_wta|census_cost" $OUT/pmc_hbm.csv; grep -E "fam8|hpair" $OUT/pmc_sq.csv
