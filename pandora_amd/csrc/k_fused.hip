@@ -525,15 +525,16 @@ __global__ __launch_bounds__(256) void sum3_wta_kernel(sum8_args a, int qpw, dou
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // the next quad overwrites the row
     };
-    // two quads per turn, each requested while the one before it is worked on (a quad past the wavefront's last one reads bytes
-    // nobody uses and stores nothing)
+    // two quads per turn, each requested while the one before it is worked on (past the wavefront's last quad the last one is
+    // requested again - lines that are in the cache, not a neighbour's bytes from memory - and worked on again: the same result
+    // into the same lane)
     uint32_t xa[3][Q], xb[3][Q];
     fetch(q0, xa);
     for (int q = q0; q < q1; q += 2) {
-        fetch(q + 1, xb);
+        fetch(min(q + 1, q1 - 1), xb);
         process(q, xa);
-        fetch(q + 2, xa);
-        process(q + 1, xb);
+        fetch(min(q + 2, q1 - 1), xa);
+        process(min(q + 1, q1 - 1), xb);
     }
     // ---- the maps: lane `sub` of group `grp` holds pixel (q0 + sub) * 4 + grp
     const int c = (q0 + sub) * 4 + grp;

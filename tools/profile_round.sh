@@ -28,6 +28,10 @@ prof () {  # prof <name> <command...>: kernel trace + HBM counters + SQ mix of o
   find $OUT -name "${name}_*.db" -delete
 }
 prof northstar python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3 --no-configs
+# the shader clock the headline's kernels run at: GRBM_GUI_ACTIVE (cycles the GPU was busy) per dispatch / the dispatch's duration
+timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $OUT -o northstar_clk -- python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3 --no-configs > $OUT/northstar_clk.log 2>&1
+{ echo "# rocprofv3 --pmc GRBM_GUI_ACTIVE -- python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3 --no-configs   (MI355X, $TAG)"; python tools/rocpd_pmc.py $OUT/northstar_clk*.db; } > $OUT/northstar_pmc_clk.csv
+find $OUT -name "northstar_clk*.db" -delete
 prof c3 python bench.py --steps 5 --warmup 2 --cpu-rows 0 --no-c3 --no-configs --height 2048 --width 2048 --dmax 128
 prof float_sgm_c4 python tools/bench_sgm_sched.py C4 --sched fam,seq --reps 2
 prof census_cbca_c3 env PMX_BENCH_ONLY=census_cbca python tools/bench_kernels.py
