@@ -8,7 +8,7 @@ curve that the first run on real links can be compared with.  Two shapes:
 
 A tile = the interior rank's rows: H / N owned rows + the SGM margin (40 rows, optimization/optimization.py:43) on both sides.
 The gather of the result maps runs under the next step's kernels and is not part of these numbers.
-Usage: python tools/bench_tiles.py [--steps K] [--only headline|c5]"""
+Usage: python tools/bench_tiles.py [--steps K] [--only headline|c5] [--ranks 1,2,4,8]"""
 import argparse
 import os
 import sys
@@ -62,6 +62,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--ranks", default="1,2,4,8", help="rank counts whose interior tile is timed")
     args = ap.parse_args()
     eng = Engine(0)
     shapes = []
@@ -74,7 +75,7 @@ def main():
         print(f"# {label}: interior tile of an N-rank run on ONE MI355X, best of 3 x {args.steps} steps")
         print("ranks  tile rows  ms/step   projected speedup   stage ms (one more step)")
         whole = None
-        for n in (1, 2, 4, 8):
+        for n in [int(x) for x in args.ranks.split(",")]:
             rank = 0 if n == 1 else n // 2  # an interior rank: margin on both sides
             (_, _), (tlo, thi) = row_tile(H, n, rank, bench.SGM_MARGIN if n > 1 else 0)
             ms, stages = time_tile(eng, np.ascontiguousarray(L[tlo:thi]), np.ascontiguousarray(R[tlo:thi]), dmin, dmax, cbca,
