@@ -154,3 +154,20 @@ def _family_against_eight_volumes(eng, synthetic_pair, H, W, dmin, dmax):
             os.environ.pop("PMX_SGM8_FAM", None)
     for a, b in zip(maps["0"], maps["auto"]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax", [
+    (7, 33, -3, 1),        # one quad more than eight: the last quad of a row holds one pixel
+    (5, 66, 0, 63),        # 64 disparities, a width that is no multiple of 4
+    (9, 257, -128, 128),   # 257 disparities on a row of 257 columns: every block of a row touches the image's borders
+    (3, 1001, 0, 40),      # 16 wavefronts' worth of quads per row and a ragged end
+    (4, 64, 5, 9),         # a range that starts to the right of every pixel's own column
+])
+@pytest.mark.parametrize("wta3", [None, "0"])
+def test_family_form_wta_kernels_agree_with_the_oracle(eng, oracle, forced_families, H, W, dmin, dmax, wta3):
+    """The WTA of the three byte volumes: the kernel that stays in one image row (sum3_wta_kernel, default) and the general one
+    (PMX_WTA3=0) on widths that are no multiple of a quad, of a wavefront's 16 quads, of a workgroup's 64"""
+    if wta3 is not None:
+        forced_families.setenv("PMX_WTA3", wta3)
+    L, R = pair(H, W, seed=11 * H + W)
+    run_both(eng, oracle, L, R, dmin, dmax, 5, 8, 32)
