@@ -1217,7 +1217,11 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     // come.  At 4096 x 4096 x 257 the step is no faster that way (14.1 against 13.8 ms: 25 % fewer bytes, 13 % more
     // instructions), so tall images keep the cost volume; short ones, whose SIMDs are mostly idle, drop it together
     // with the row-per-wavefront walk.  PMX_SGM8_CODES=1 / 0: both kernels from the words wherever legal / never.
-    const bool codes_ok = nw == 1 && !cv->has_range && cv->D <= 512;
+    // The code-word kernels reach the right image's words through per-lane offsets from a guard of 1024 zeroed dwords in front of
+    // (and behind) each code image (k_matching.hip kCodePad; sgm_u8_hrow_codes_kernel's offR, sgm_u8_hpair_codes_kernel's raw
+    // pointers): a range that starts or ends further than that from the pixel would wrap the unsigned offset (loads answer 0 for
+    // cells that ARE numbers) or leave the allocation.  Such ranges keep the cost volume (census_cost_u8_kernel handles any d0).
+    const bool codes_ok = nw == 1 && !cv->has_range && cv->D <= 512 && abs(cv->d0) + cv->D <= 1024 - 64;
     const char* ehp = getenv("PMX_SGM8_HPAIR");
     const char* ec = getenv("PMX_SGM8_CODES");
     const bool codes_never = ec && ec[0] == '0', codes_always = ec && ec[0] == '1';

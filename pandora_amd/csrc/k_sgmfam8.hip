@@ -28,9 +28,11 @@
 // packed pairs (no half overflows), "- M + C" in one v_add3_u32 - see k_sgm8.hip.  Semantics = oracle.c orc_sgm on integers:
 // L = C + min(Lp[d], min(Lp[d-1], Lp[d+1]) + P1, M + P2) - M, paths start from (Lp, M) = (0, 0) at the image border.
 #include <cstdlib>
+#include <type_traits>
 
 #include "pmx_buf.h"
 #include "pmx_internal.h"
+
 
 namespace {
 
@@ -131,7 +133,7 @@ __device__ __forceinline__ void group_min3(uint32_t& a, uint32_t& b, uint32_t& c
 // is replayed at 64 cycles) - and every lane reads its KPL words and the pixel's left word where the old form read NDW cost
 // dwords from memory: v_xor, v_bcnt (whose addend is the pad of a disparity >= D), v_lshl_or per pair of cells.
 template <int KPL, int CBITS, int NW, int PF, bool CODES>
-__global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
+__global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
     constexpr int Q = KPL / 4;                  // (A, B) register pairs per lane and path
     constexpr int NR = 2 * Q;                   // registers per lane and path
     constexpr int PER = CBITS == 8 ? 4 : 6;     // costs per dword of the cost volume
@@ -182,14 +184,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
     u32x4* const halo = a.halo + (size_t)(fam - a.fam0) * a.halo_fam;
     constexpr unsigned kBlockBytes = (unsigned)NGP * 16u;
 
-    if (wave == NW) {
-        // ---- hand-off wave: brings the left neighbour's columns CW-2, CW-1 of row t into column slots -2, -1 -------------------
-        // Every row's barrier waits for this wavefront, and it is one chain: LDS -> pack -> store, load -> unpack -> LDS.  So it
-        // runs without a lane-varying branch and without per-row address arithmetic: every lane does the same four LDS accesses per
-        // block (two (A, B) register pairs of a vector and two minima - the kinds a lane's block does not hold go to a spare dword
-        // pair of the column slot), the record of (row t, border) is a running block index.  (Round 4: 270 -> ~150 instructions per
-        // row; three register pairs per block - the float32 kernels' 12-byte payload - cost two LDS instructions more per row and
-        // the marching kernel 7.3 -> 9.0 ms, which is how the length of this chain was found to be what the row time hangs on.)
+    if (wave >= NW) {
+        // ---- hand-off wavefronts: wave NW publishes this window's last two columns for window s+1, wave NW+1 brings the left
+        // neighbour's into column slots -2, -1 ---------------------------------------------------------------------------------------
+        // A SIMD issues about one instruction per five cycles, of whatever kind and from whichever of its wavefronts (round 5: the
+        // step's time beside the horizontal pair is the instruction count of the busiest SIMD): one hand-off wavefront
+        // of ~185 instructions per row (110 of them scalar: three descriptors rebuilt per row from 64-bit products) sat on the SIMD
+        // of compute wavefronts 0 and 4 and was a fifth of its load.  Now two wavefronts (they land on different SIMDs), records
+        // addressed by running pointers, and no lane-varying branch: every lane moves two (A, B) register pairs and two minima per
+        // block - the kinds its block does not hold go to a spare dword pair of the column slot.
+        const bool publisher = wave == NW;
         constexpr int SINK = 16 * KS + 2;  // spare dwords of a column slot (its minimum sits at 16 KS): 8-byte aligned
         int offP0[NQ], offP1[NQ];     // LDS dword offsets (within a row parity) of the block's two register pairs
         int offM0[NQ], offM1[NQ];     // ... of its two minima
@@ -222,24 +226,62 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
             }
         }
         constexpr int QM0 = (3 * NVB) / 64, QM1 = (3 * NVB + 1) / 64;  // the blocks that hold minima
+        // The record the neighbour wrote for row t sits at block row bi(t) = t NB + (base - t - 1) / CW = t NB + s - 1 - t / CW
+        // (t >= 0), the one this window writes for row t one further (column block (base + CW - 1 - t) / CW).  From row to row:
+        // bi(t + 1) = bi(t) + NB, one less when t + 1 is a multiple of CW - a running pointer and a counter.
+        auto rec_of = [&](int t) { const int tt = t > 0 ? t : 0; return halo + ((size_t)tt * a.NB + s - 1 - tt / CW) * NGP; };
+        const size_t row_blocks = (size_t)a.NB * NGP;
+        auto rsrc_of = [&](const u32x4* rec, bool need) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, need ? kBlockBytes : 0u, kRsrcWord3);
+        };
+        if (publisher) {
+            // Row p of this window - the path costs of local columns CW-2, CW-1, left by the compute wavefronts in column slots CW,
+            // CW+1 of row parity p & 1 - is complete once barrier p is passed and untouched until barrier p+1.  Window s+1 computes
+            // row p+1 at image column cb = base+CW-1-p: it exists and needs the row iff cb < W and p < H-1.
+            const int pA = r_lo > base + CW - W ? r_lo : base + CW - W;
+            const int pB = r_hi < H - 2 ? r_hi : H - 2;
+            const u32x4* rec = rec_of(r_lo) + NGP;
+            int pmod = r_lo % CW;
+            __syncthreads();  // the barrier before the first step
+            for (int pr = r_lo; pr <= r_hi; ++pr) {
+                __syncthreads();  // barrier pr
+                const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, pr >= pA && pr <= pB);
+                const uint32_t* Eb = lds8 + (pr & 1) * EBUF + CW * ES;
+                const uint32_t gave_up = (uint32_t)ctl[1];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const u32x2 v0 = *(const u32x2*)(Eb + offP0[q]);
+                    const u32x2 v1 = *(const u32x2*)(Eb + offP1[q]);
+                    u32x4 b;
+                    b.x = v0.x | (v0.y << 8);  // (pads spill upwards only: into bytes that are pads themselves)
+                    b.z = v1.x | (v1.y << 8);
+                    if (q == QM0 || q == QM1) {  // (compile time)
+                        const uint32_t m0 = Eb[offM0[q]], m1 = Eb[offM1[q]];
+                        b.x = is_min[q] ? m0 : b.x;
+                        b.z = is_min[q] ? m1 : b.z;
+                    }
+                    b.y = a.epoch;
+                    b.w = a.epoch;
+                    __builtin_amdgcn_raw_buffer_store_b128(b, rs, boff[q], 0, kSc1);
+                }
+                if (__builtin_amdgcn_readfirstlane(gave_up) != 0u) return;  // (the consumer's: this launch has failed)
+                rec += row_blocks;
+                if (++pmod == CW) { pmod = 0; rec -= NGP; }
+            }
+            return;
+        }
         // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
         const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
         const int tB = (r_hi < base ? r_hi : base) - 1;
-        // The record the neighbour wrote for row t sits at block row bi(t) = t NB + (base - t - 1) / CW = t NB + s - 1 - t / CW
-        // (t >= 0), the one this window writes for row t one further (column block (base + CW - 1 - t) / CW): a running index.
-        auto bi_of = [&](int t) { const int tt = t > 0 ? t : 0; return tt * a.NB + s - 1 - tt / CW; };
-        auto rsrc_of = [&](int bi, bool need) {
-            return __builtin_amdgcn_make_buffer_rsrc((void*)(halo + (size_t)(need ? bi : 0) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
-        };
         u32x4 x[NQ];
-        auto issue = [&](int t, int bi) {
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(bi, t >= tA && t <= tB);
+        auto issue = [&](int t, const u32x4* rec) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, t >= tA && t <= tB);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
         };
-        auto consume = [&](int t, int bi) -> bool {
+        auto consume = [&](int t, const u32x4* rec) -> bool {
             if (t < tA || t > tB) return true;
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(bi, true);
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, true);
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
@@ -269,52 +311,27 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
             }
             return true;
         };
-        // Publishes row t of this window for window s+1: the compute waves left the path costs of local columns CW-2, CW-1 in LDS
-        // (column slots CW, CW+1 of row parity t & 1), complete once barrier t is passed and untouched until barrier t+1.  Window
-        // s+1 computes row t+1 at image column cb = base+CW-1-t: it exists and needs the row iff cb < W and t < H-1.
-        auto publish = [&](int t, int bi) {
-            const int cb = base + CW - 1 - t;
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(bi + 1, t >= r_lo && cb < W && t < H - 1);
-            const uint32_t* Eb = lds8 + (t & 1) * EBUF + CW * ES;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const u32x2 v0 = *(const u32x2*)(Eb + offP0[q]);
-                const u32x2 v1 = *(const u32x2*)(Eb + offP1[q]);
-                u32x4 b;
-                b.x = v0.x | (v0.y << 8);  // (pads spill upwards only: into bytes that are pads themselves)
-                b.z = v1.x | (v1.y << 8);
-                if (q == QM0 || q == QM1) {  // (compile time)
-                    const uint32_t m0 = Eb[offM0[q]], m1 = Eb[offM1[q]];
-                    b.x = is_min[q] ? m0 : b.x;
-                    b.z = is_min[q] ? m1 : b.z;
-                }
-                b.y = a.epoch;
-                b.w = a.epoch;
-                __builtin_amdgcn_raw_buffer_store_b128(b, rs, boff[q], 0, kSc1);
-            }
-        };
         // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi.  Row t of the neighbour is asked for as
         // early as it can exist (one look-ahead load per barrier), and polled for when it is due.
         int t = r_lo - 1;
-        int bi_prev = bi_of(t - 1), bi_cur = bi_of(t), bi_next = bi_of(t + 1);
+        const u32x4* rec_cur = rec_of(t);
+        const u32x4* rec_next = rec_of(t + 1);
         int tmod = (t + 1 > 0 ? t + 1 : 0) % CW;  // (t + 1) mod CW: the block index loses one when t + 2 reaches a multiple of CW
-        issue(t, bi_cur);
+        issue(t, rec_cur);
         for (; t <= r_hi; ++t) {
-            publish(t - 1, bi_prev);
-            if (!consume(t, bi_cur)) ctl[1 + (t & 1)] = 1;
-            issue(t + 1, bi_next);
+            const bool got = consume(t, rec_cur);
+            if (!got) ctl[1] = 1;  // (sticky: the other wavefronts read it with their next row's LDS reads)
+            issue(t + 1, rec_next);
             __syncthreads();
-            if (__builtin_amdgcn_readfirstlane(ctl[1 + (t & 1)])) return;
+            if (!got) return;
             // bi(t + 2) from bi(t + 1): one row further, one column block back at every multiple of CW
-            bi_prev = bi_cur;
-            bi_cur = bi_next;
+            rec_cur = rec_next;
             if (t + 1 >= 0) {
                 ++tmod;
-                bi_next += a.NB;
-                if (tmod == CW) { tmod = 0; --bi_next; }
+                rec_next += row_blocks;
+                if (tmod == CW) { tmod = 0; rec_next -= NGP; }
             }
         }
-        publish(r_hi, bi_prev);
         return;
     }
 
@@ -349,8 +366,17 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
 
     // loads of the costs run PF rows ahead in a register ring
     int pr = r_lo;
-    struct slot_t { uint32_t x[CODES ? NLD : NDW]; };
+    // (costs from the volume: the ring is hring<slot> - registers above the compiler's, waited for with the ring's own count, pmx_buf.h;
+    //  CODES: the census words' ring stays in compiler-managed registers, its takers are LDS stores one row later)
+    struct slot_t { uint32_t x[CODES ? NLD : 1]; };
     slot_t ring[PF];
+    constexpr int kRingCnt = (PF - 1) * (hring_loads(NDW) + (Q == 5 ? 2 : 1));  // memory instructions of PF - 1 steps
+    // (slot S: v[96 + 6 S ..]: 114 registers end the allocation at 120 - what a workgroup's wavefronts hold decides who else fits
+    //  on their SIMDs: with the ring at v128.. the marching kernel took 152 registers and the horizontal pair beside it no longer
+    //  found room, 22.5 instead of 8.4 ms.  The compiler's own: 50 .. 90; `make` runs tools/check_hring.py k_sgmfam8.o 96)
+    constexpr int kRing0 = 96;
+    static_assert(PF <= 3 && NDW <= 6, "hring slots");
+    if constexpr (!CODES) PMX_HRING_RESERVE("v113");
     // CODES: thread tid fetches word m = tid + i NT of the row's list: right words of image columns cb + d0 + m (m < NSRC),
     // then the left words of columns cb + m - NSRC, cb = column of the window's first pixel.  One descriptor over the whole
     // code allocation: a column outside the image reads a neighbouring row's words or a zeroed guard (such cells are invalid
@@ -366,7 +392,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
         }
     }
     int code_row = rimg_lo * W + (base - r_lo);  // dword index of the prefetched row's window start, within an image
-    auto prefetch = [&](slot_t& sl) {
+    auto prefetch = [&](auto slot_tag, slot_t& sl) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_tag)::value;
         if constexpr (CODES) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
@@ -376,14 +403,15 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
                 code_row += (fam ? -W : W) - 1;
             }
         } else {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)cost_row, 0, cost_row_bytes, kRsrcWord3);
-            load_dwords<NDW>(rs, ((unsigned)pc < (unsigned)W && lane_active) ? pcoff : kOob, sl.x);
-            if (pr < r_hi) {  // (uniform; past the last row the last one is read again)
-                ++pr;
-                cost_row += cost_step;
-                --pc;
-                pcoff -= (unsigned)a.Dc;
-            }
+            hring_load<kRing0 + 6 * SL, NDW>(rsrc_words(cost_row, cost_row_bytes), ((unsigned)pc < (unsigned)W && lane_active) ? pcoff : kOob);
+            // (uniform selects, no branch: past the last row the last one is read again.  A branch here, or between the steps
+            // of the unrolled loop, splits the body into blocks whose wait counts the compiler derives from merged states -
+            // vmcnt(0) in one step of three, i.e. a wait for the stores just issued: DESIGN 7.27)
+            const bool adv = pr < r_hi;
+            pr += adv ? 1 : 0;
+            cost_row += adv ? cost_step : (ptrdiff_t)0;
+            pc -= adv ? 1 : 0;
+            pcoff -= adv ? (unsigned)a.Dc : 0u;
         }
     };
     // CODES: the fetched words of a row go to LDS one row before they are used (row parity of the row they belong to)
@@ -401,11 +429,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
             }
         }
     };
-#pragma unroll
-    for (int i = 0; i < PF; ++i) prefetch(ring[i]);
+    auto for_slots = [&](auto&& f) __attribute__((always_inline)) {  // f(slot tag) for every ring slot
+        f(std::integral_constant<int, 0>{});
+        if constexpr (PF > 1) f(std::integral_constant<int, 1>{});
+        if constexpr (PF > 2) f(std::integral_constant<int, 2>{});
+        if constexpr (PF > 3) f(std::integral_constant<int, 3>{});
+    };
+    for_slots([&](auto tag) __attribute__((always_inline)) { prefetch(tag, ring[decltype(tag)::value]); });
     if constexpr (CODES) {  // the first row's words are parked before the first barrier, its slot refilled (row r_lo + PF)
         park(r_lo, ring[0]);
-        prefetch(ring[0]);
+        prefetch(std::integral_constant<int, 0>{}, ring[0]);
     }
 
     uint32_t LBa[Q], LBb[Q];  // the path that stays in its lane group (predecessor column c+1)
@@ -415,11 +448,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
     for (int q = 0; q < Q; ++q) { LBa[q] = padA[q]; LBb[q] = padB[q]; }
 
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(ctl[1 + ((r_lo - 1) & 1)])) return;
 
     int c = base - r_lo + j;                                       // column of the step's row
     unsigned ooff = (unsigned)c * (unsigned)a.Dp + out_lane;
-    auto step = [&](int r, slot_t& sl) {
+    uint32_t abort_seen = 0u;
+    auto step = [&](int r, auto slot_tag, slot_t& sl) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_tag)::value;
         const uint32_t* Ep = lds8 + ((r - 1) & 1) * EBUF;
         uint32_t* En = lds8 + (r & 1) * EBUF;
         // predecessors: vertical path (r-1, c) = local column j-1, diagonal (r-1, c-1) = local column j-2 (LDS, previous row
@@ -445,6 +479,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
         }
         uint32_t MV = Ep[(j + 1) * ES + 16 * KS];
         uint32_t MA = Ep[EDIR + j * ES + 16 * KS];
+        // the hand-off wavefront's "gave up" word rides with the predecessors' reads (a read of its own behind the barrier was a
+        // second LDS round trip in every row's chain: ~300 of the row's ~3300 cycles); it is looked at once per PF rows
+        abort_seen |= (uint32_t)ctl[1];
         // costs of the pixel: (d, d+2) and (d+1, d+3) pairs, padded disparities carry kPad16
         uint32_t ccA[Q], ccB[Q];
         if constexpr (CODES) {
@@ -494,15 +531,17 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
                 }
             }
         } else {
+            uint32_t cx[NDW];
+            hring_take<kRing0 + 6 * SL, NDW, kRingCnt>(cx);
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 if (CBITS == 8) {
-                    ccA[q] = (sl.x[q] & 0x00ff00ffu) | padA[q];
-                    ccB[q] = ((sl.x[q] >> 8) & 0x00ff00ffu) | padB[q];
+                    ccA[q] = (cx[q] & 0x00ff00ffu) | padA[q];
+                    ccB[q] = ((cx[q] >> 8) & 0x00ff00ffu) | padB[q];
                 } else {  // pair jj of the lane: bits 5 * (jj % 3) of both halves of dword jj / 3 (census_cost_u8_kernel)
                     constexpr uint32_t m5 = 0x001f001fu;
-                    ccA[q] = ((sl.x[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
-                    ccB[q] = ((sl.x[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
+                    ccA[q] = ((cx[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
+                    ccB[q] = ((cx[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
                 }
             }
         }
@@ -567,31 +606,29 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_fam8_kernel(fam8_args a) {
         --c;
         ooff -= (unsigned)a.Dp;
         if constexpr (CODES) park(r + 1, sl);  // (sl: the ring slot that holds row r + 1's words; refilled with row r + 1 + PF)
-        prefetch(sl);
+        prefetch(slot_tag, sl);
         __syncthreads();
     };
 
     // ring slot of step u: the step's own costs - or, CODES, the words of the row after it (parked in LDS during the step)
     constexpr int SH = CODES ? 1 : 0;
+    // The unrolled body has no branch between its steps and every memory instruction in it is unconditional: the compiler's wait
+    // counts are then the ring's (pmx_buf.h).  After a failed hand-off the rows up to the next look at `abort_seen` are computed from
+    // whatever the column slots hold and stored: the launch has failed by then (pmx_sgm answers PMX_ERR_DEVICE), and a wavefront
+    // that has ended no longer counts at the barrier.
     int r = r_lo;
-    bool dead = false;
-    for (; r + PF <= r_hi + 1 && !dead; r += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (!dead) {
-                step(r + u, ring[(u + SH) % PF]);
-                dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
-            }
-        }
+    PMX_LOOP_ENTRY_DRAIN();
+    for (; r + PF <= r_hi + 1; r += PF) {
+        for_slots([&](auto tag) __attribute__((always_inline)) {
+            constexpr int U = decltype(tag)::value, SL = (U + SH) % PF;
+            step(r + U, std::integral_constant<int, SL>{}, ring[SL]);
+        });
+        if (__builtin_amdgcn_readfirstlane(abort_seen) != 0u) return;
     }
-    if (dead) return;
-#pragma unroll
-    for (int u = 0; u < PF - 1; ++u) {
-        if (r + u <= r_hi && !dead) {
-            step(r + u, ring[(u + SH) % PF]);
-            dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
-        }
-    }
+    for_slots([&](auto tag) __attribute__((always_inline)) {
+        constexpr int U = decltype(tag)::value, SL = (U + SH) % PF;
+        if (U < PF - 1 && r + U <= r_hi) step(r + U, std::integral_constant<int, SL>{}, ring[SL]);
+    });
 }
 
 template <int KPL, int CBITS, int NW, bool CODES = false>
@@ -601,7 +638,7 @@ int launch_fam8(pmx_ctx* ctx, const fam8_args& a, int nwg) {
     const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4 + (CODES ? 2 * (4 * (CW + 16 * KPL) + CW) : 0)) * sizeof(uint32_t);
     auto kern = sgm_fam8_kernel<KPL, CBITS, NW, PF, CODES>;
     PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 1) * 64), lds_bytes, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 2) * 64), lds_bytes, ctx->stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }

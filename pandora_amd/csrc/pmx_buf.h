@@ -149,3 +149,61 @@ __device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, unsigned
     }
 }
 
+// ---- a prefetch ring the compiler cannot see: registers above its own ----------------------------------------------------------------
+// A register ring of loads issued PF steps ahead wants `s_waitcnt vmcnt(N)` with N = the memory instructions issued since the load
+// that is due.  The compiler derives N itself, and where a step also STORES it gets it wrong in ways the source cannot steer: the
+// marching kernels' three-step body was waited for with vmcnt(3), vmcnt(4), vmcnt(0) where 6 is right - one row of look-ahead
+// instead of three, and in every third row a wait for the stores issued a few hundred cycles before (cycle stamps: that row's
+// compute phase 1900-3200 cycles instead of 1085); with the loop reshaped so that its counts came out right it copied
+// the ring's registers at the loop header, i.e. read them - and waited - one row after the load.  Loads hidden in inline asm with
+// ordinary outputs are no way out either: the compiler believes such a value is there when the asm statement ends and may copy it
+// before the hand-written wait (round 4's "rare wrong block").  So the ring lives in registers the compiler does not allocate in
+// these kernels: above their own (the allocator fills from v0).  Accumulation registers would be the natural home, but
+// a kernel that names any gets its register budget split in half between the two files, and then spills into the AGPRs the ring
+// does not name.  hring_load<BASE, N> issues the load of N dwords per lane (offset `off` of the descriptor `rs`) into
+// v[BASE .. BASE + N - 1]; hring_take<BASE, N, CNT> waits until at most CNT younger memory instructions are in flight (vmcnt counts
+// loads and stores alike, in order) and copies them into compiler-visible registers.  The register numbers are immediate operands of
+// the asm statements ("n"), so BASE may come from template arithmetic; what an asm statement cannot take from a template is its
+// clobber list, so the kernel names the ring's LAST register once (PMX_HRING_RESERVE("v111")): that is what makes the kernel's
+// descriptor cover the ring.  Rules for a loop that uses it: every memory instruction between a
+// slot's load and its take is unconditional, and CNT is their number.  `make` checks each object that nothing but these two statements touches
+// the ring's registers (tools/check_hring.py <object> <first register>) - if the compiler ever needs that many, the build fails
+// instead of the results.
+typedef unsigned int pmx_rsrc_words __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pmx_rsrc_words rsrc_words(const void* base, unsigned bytes) {
+    pmx_rsrc_words w;
+    w.x = (unsigned)(uintptr_t)base;
+    w.y = (unsigned)((uintptr_t)base >> 32) & 0xffffu;
+    w.z = bytes;
+    w.w = kRsrcWord3;
+    return w;
+}
+#define PMX_HRING_RESERVE(LAST_REG) asm volatile("; hring: registers up to " LAST_REG ::: LAST_REG)
+// v[BASE .. BASE + N - 1] <- N dwords per lane, as 16-byte pieces and one remainder piece (BASE even: tuples are 2-aligned).
+// (An immediate operand above 64 prints in hexadecimal, which is no register name: a number goes in as "tens" and "ones".)
+#define PMX_RN(R) "n"((R) / 10), "n"((R) % 10)
+template <int BASE, int N>
+__device__ __forceinline__ void hring_load(pmx_rsrc_words rs, unsigned off) {
+    static_assert(BASE % 2 == 0 && BASE >= 32 && BASE + N <= 256 && N >= 1 && N <= 12 && 16 * (N / 4) <= 64, "hidden ring registers");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i)
+        asm volatile("buffer_load_dwordx4 v[%2%3:%4%5], %0, %1, 0 offen offset:%6" ::"v"(off), "s"(rs), PMX_RN(BASE + 4 * i),
+                     PMX_RN(BASE + 4 * i + 3), "n"(16 * i)
+                     : "memory");
+    constexpr int R = N % 4, B = BASE + 4 * (N / 4), O = 16 * (N / 4);
+    if constexpr (R == 3)
+        asm volatile("buffer_load_dwordx3 v[%2%3:%4%5], %0, %1, 0 offen offset:%6" ::"v"(off), "s"(rs), PMX_RN(B), PMX_RN(B + 2), "n"(O) : "memory");
+    else if constexpr (R == 2)
+        asm volatile("buffer_load_dwordx2 v[%2%3:%4%5], %0, %1, 0 offen offset:%6" ::"v"(off), "s"(rs), PMX_RN(B), PMX_RN(B + 1), "n"(O) : "memory");
+    else if constexpr (R == 1)
+        asm volatile("buffer_load_dword v%2%3, %0, %1, 0 offen offset:%4" ::"v"(off), "s"(rs), PMX_RN(B), "n"(O) : "memory");
+}
+// memory instructions hring_load<., N> issues
+constexpr int hring_loads(int n) { return n / 4 + (n % 4 ? 1 : 0); }
+template <int BASE, int N, int CNT, typename T>
+__device__ __forceinline__ void hring_take(T (&x)[N]) {
+    static_assert(sizeof(T) == 4 && CNT >= 0 && CNT < 64, "dwords, vmcnt");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("v_mov_b32 %0, v%1%2" : "=v"(x[k]) : PMX_RN(BASE + k) : "memory");
+}

@@ -67,6 +67,8 @@ def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
     (14, 420, -256, 0, 5, 8, 32),     # ... to the other side
     (12, 340, -255, 0, 5, 8, 32),     # 256 disparities: the row walk's 64 lanes all busy
     (12, 340, 0, 257, 5, 8, 32),      # 258: eight per lane
+    (8, 1400, -1150, -1100, 5, 8, 32),  # a range further from the pixel than the code images' guard (1024 words): the code-word
+    (8, 1400, 1100, 1150, 5, 8, 32),    # kernels must not be chosen (their per-lane offsets would wrap / leave the allocation)
 ])
 @pytest.mark.parametrize("nw,hpair,codes", [("4", "2", "0"), ("8", "1", "0"), ("8", "2", "0"),
                                             ("8", "1", "1"),   # both kernels from the census words, four rows per wavefront
