@@ -29,7 +29,6 @@
 // Lane map: GL lanes per pixel (16 or 32), KPL consecutive disparities per lane, 64/GL pixels per wave, NW compute
 // waves + 1 hand-off wave per workgroup.  Loads of C and S run PF rows ahead in a register ring.  No MFMA: HBM-bound.
 #include <cstdlib>
-#include <type_traits>
 
 #include "pmx_buf.h"
 #include "pmx_internal.h"
@@ -309,12 +308,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             for (int u = 0; u < KH; ++u) {
                 const int tt = t + u;
                 if (tt <= r_hi) {
-                    const bool got = consume(tt, x[u]);
-                    if (!got) ctl[1] = 1;  // (sticky: the compute wavefronts read it with their next row's predecessors)
+                    if (!consume(tt, x[u])) ctl[1 + (tt & 1)] = 1;
                     issue(tt + KH, x[u]);
                     publish(tt - 1);
                     __syncthreads();
-                    if (!got) return;
+                    if (__builtin_amdgcn_readfirstlane(ctl[1 + (tt & 1)])) return;
                 }
             }
         }
@@ -353,38 +351,17 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         return (c >= 0 && c < W) ? (unsigned)c * pix_bytes : kOob;
     };
 
-    // Loads of C and S run PF rows ahead in a register ring.  HID (lane maps up to 9 disparities per lane): the ring is hring - registers
-    // above the compiler's, at the top of the 168 a workgroup of up to 11 wavefronts may have per lane, waited for with the ring's own
-    // count (pmx_buf.h: the compiler's counts for this loop were vmcnt(5) .. vmcnt(0) in one step of three - a full memory round trip
-    // on the row's chain - and 9 .. 20 in the others).  Slot i: C at kRing0 + 2 i KPLE, S behind it.
-    constexpr bool HID = KPL <= 9 && PF == 2;
-    constexpr int KPLE = (KPL + 1) & ~1;
-    constexpr int kRing0 = 168 - 2 * PF * KPLE;
-    constexpr int kStores = WTA ? 2 : P::N;  // + the tail's leftover store when D is not a multiple of KPL (rem, uniform)
-    constexpr int kRingCnt = (PF - 1) * (2 * hring_loads(KPL) + kStores);
-    if constexpr (HID) PMX_HRING_RESERVE("v167");
+    // loads of C and S run PF rows ahead in a register ring
     int pr = r_lo;
-    float cbuf[PF][HID ? 1 : KPL], sbuf[PF][HID ? 1 : KPL];
-    auto prefetch = [&](auto slot_tag) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slot_tag)::value;
+    float cbuf[PF][KPL], sbuf[PF][KPL];
+    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
         const unsigned off = pix_off(pr) + lane_off;
-        const int rimg = a.flip ? H - 1 - pr : pr;
-        if constexpr (HID) {
-            hring_load<kRing0 + 2 * SL * KPLE, KPL>(rsrc_words(a.C + (size_t)rimg * W * D, row_bytes), off);
-            hring_load<kRing0 + (2 * SL + 1) * KPLE, KPL>(rsrc_words(a.S + (size_t)rimg * W * D, row_bytes), a.has_sin ? off : kOob);
-        } else {
-            buf_load<KPL>(row_rsrc(a.C, pr), off, cbuf[SL]);
-            buf_load<KPL>(row_rsrc(a.S, pr), a.has_sin ? off : kOob, sbuf[SL]);  // first pass of a sum: out of range = zeros, no traffic
-        }
-        pr += pr < r_hi ? 1 : 0;  // (a select, not a branch: DESIGN 7.27)
+        buf_load<KPL>(row_rsrc(a.C, pr), off, cslot);
+        buf_load<KPL>(row_rsrc(a.S, pr), a.has_sin ? off : kOob, sslot);  // first pass of a sum: out of range = zeros, no traffic
+        if (pr < r_hi) ++pr;
     };
-    auto for_slots = [&](auto&& f) __attribute__((always_inline)) {  // f(slot tag) for every ring slot
-        f(std::integral_constant<int, 0>{});
-        if constexpr (PF > 1) f(std::integral_constant<int, 1>{});
-        if constexpr (PF > 2) f(std::integral_constant<int, 2>{});
-    };
-    static_assert(PF <= 3, "ring slots");
-    for_slots([&](auto tag) __attribute__((always_inline)) { prefetch(tag); });
+#pragma unroll
+    for (int i = 0; i < PF; ++i) prefetch(cbuf[i], sbuf[i]);
 
     float LB[KPL];  // the path that stays in its lane group (predecessor column c+1)
     float MB = 0.f;
@@ -392,10 +369,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     for (int k = 0; k < KPL; ++k) LB[k] = f_inf();
 
     __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(ctl[1 + ((r_lo - 1) & 1)])) return;
 
-    uint32_t abort_seen = 0u;
-    auto step = [&](int r, auto slot_tag) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slot_tag)::value;
+    auto step = [&](int r, float (&cslot)[KPL], float (&sslot)[KPL]) {
         const int c = base - r + j;
         const float* Ep = lds + ((r - 1) & 1) * EBUF;
         float* En = lds + (r & 1) * EBUF;
@@ -415,21 +391,6 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         }
         const float MV = Ep[(j + 1) * ES + GL * KS];
         const float MA = Ep[EDIR + j * ES + GL * KS];
-        // the hand-off wavefront's "gave up" word rides with the predecessors' reads (a read of its own behind the barrier was a
-        // second LDS round trip in every row's chain); it is looked at once per PF rows
-        abort_seen |= (uint32_t)ctl[1];
-        float cslot[KPL], sslot[KPL];
-        if constexpr (HID) {
-            if (WTA || rem == 0) {  // (uniform: the memory instructions of a step)
-                hring_take<kRing0 + 2 * SL * KPLE, KPL, kRingCnt>(cslot);
-            } else {
-                hring_take<kRing0 + 2 * SL * KPLE, KPL, kRingCnt + (PF - 1)>(cslot);
-            }
-            hring_take<kRing0 + (2 * SL + 1) * KPLE, KPL, 63>(sslot);  // (issued with C's, arrived with them: S's loads precede nothing)
-        } else {
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) { cslot[k] = cbuf[SL][k]; sslot[k] = sbuf[SL][k]; }
-        }
         // costs: NaN -> invalid_cost, sign for "max" measures, +inf on padded disparities
         float cc[KPL];
         // (by bits: this file is compiled with -fno-honor-nans, under which the compiler folds a floating-point class test to
@@ -557,24 +518,30 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rsD, st ? pidx * 4u : kOob, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(nb, rsN, st ? pidx * 16u : kOob, 0, 0);
         }
-        // refill this ring slot with row r + PF (issued after the slot's last use)
-        prefetch(slot_tag);
+        // refill this ring slot with row r + PF (issued after the slot's last use: same registers, no copy)
+        prefetch(cslot, sslot);
         __syncthreads();
     };
 
-    // The unrolled body has no branch between its steps and every memory instruction in it is unconditional (pmx_buf.h).  After a
-    // failed hand-off the rows up to the next look at `abort_seen` are computed from whatever the column slots hold: the launch has
-    // failed by then (pmx_sgm answers PMX_ERR_DEVICE), and a wavefront that has ended no longer counts at the barrier.
     int r = r_lo;
-    PMX_LOOP_ENTRY_DRAIN();
-    for (; r + PF <= r_hi + 1; r += PF) {
-        for_slots([&](auto tag) __attribute__((always_inline)) { step(r + decltype(tag)::value, tag); });
-        if (__builtin_amdgcn_readfirstlane(abort_seen) != 0u) return;
+    bool dead = false;
+    for (; r + PF <= r_hi + 1 && !dead; r += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (!dead) {
+                step(r + u, cbuf[u], sbuf[u]);
+                dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
+            }
+        }
     }
-    for_slots([&](auto tag) __attribute__((always_inline)) {
-        constexpr int U = decltype(tag)::value;
-        if (U < PF - 1 && r + U <= r_hi) step(r + U, tag);
-    });
+    if (dead) return;
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) {
+        if (r + u <= r_hi && !dead) {
+            step(r + u, cbuf[u], sbuf[u]);
+            dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
+        }
+    }
 }
 
 struct fam_shape {
@@ -631,9 +598,7 @@ bool pick_shape(int D, int W, fam_shape* out) {
 
 template <int GL, int KPL, int NW, bool WTA>
 int launch_family(pmx_ctx* ctx, const fam_args& a, int nwg) {
-    // rows of look-ahead: two with the hidden ring (a slot is 2 (KPL + 1) registers nobody else can use: three rows of 9 disparities
-    // would be 60 on top of the ~125 the step needs, and a workgroup of 9 - 11 wavefronts has 168 per lane), two for the widest lane maps
-    constexpr int PF = (KPL > 12 || KPL <= 9) ? 2 : 3;
+    constexpr int PF = KPL > 12 ? 2 : 3;
     constexpr int NPW = 64 / GL, CW = NW * NPW, KS = (KPL + 3) & ~3, ES = GL * KS + 4;
     const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4) * sizeof(float);
     auto kern = sgm_family_kernel<GL, KPL, NW, PF, WTA>;
