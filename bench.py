@@ -19,7 +19,8 @@ At N>1 a second leg, `d_sharded_exact`, times north_star's exact multi-GPU form 
 one ncclAllReduce(sum) of the owner-refined maps) and reports the maps' identity with one GPU doing the whole volume; a third,
 `pair_per_rank`, is the weak-scaling figure beside the strong-scaling `value`: one whole pair per rank and step, no exchange; a
 fourth, `c5_row_tiled`, is BASELINE configs[4] as worded ("10000x10000 ... Census+CBCA+SGM ... row-tiled 8 GPUs"): the strip's fine
-scale over the ranks' row tiles, with the whole strip on one GPU timed beside it.  A self-launched run fails fast: the first rank
+scale over the ranks' row tiles, with the whole strip on one GPU timed beside it; a fifth, `c4_row_tiled`, is configs[3]'s pipeline
+WITH its SGM step (ZNCC 11x11 + SGM + WTA + vfit, 4096x4096x257) over the same row tiles.  A self-launched run fails fast: the first rank
 that exits non-zero stops the others, a watchdog bounds the whole run, every rank's last stderr lines are printed.
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the 8-path SGM kernel, HIP-event timed on the engine's stream
@@ -28,7 +29,9 @@ inside the timed region), `cpu_baseline` (the C oracle, kind "port", 1 thread, o
 census stage only) and, at N=1, `c3_shape` (BASELINE configs[2], 2048x2048x129, the round-1 headline, same protocol),
 `c2_cones` (configs[1]: census + CBCA + SGM on the reference's cones pair), `c4_as_stated` (configs[3] as BASELINE words it: ZNCC 11x11 + SGM + WTA + vfit, 4096x4096x257, float32 kernels) and `c5_as_stated`
 (configs[4]'s fine scale on one GPU: census + CBCA + SGM + WTA + vfit, 10000x10000x129, float32 kernels), each with its own roofline
-block (its dominant kernel family), and `default_allocation` (the headline step with plain hipMalloc placement, --placement-trials 1).
+block (its dominant kernel family), and `placement_tuned` (the headline step on a context that probes six candidates per volume,
+pmx_set_placement_trials: `value` itself is measured on plain hipMalloc buffers).  `roofline.peak_measured` is what plain
+streaming kernels reach on the box in the same run (pmx_measure_hbm), beside `peak` = the data sheet's 8000 GB/s.
 """
 import argparse
 import json
@@ -363,19 +366,26 @@ def d_sharded_leg(eng, comm, L, R, dmin, dmax, win, steps, check_device):
     return out
 
 
-def c5_row_tiled_leg(eng, comm, H5, W5, steps, check_device):
-    """N > 1: BASELINE configs[4] as BASELINE words it - "10000x10000 ... Census+CBCA+SGM ... row-tiled 8 GPUs" - the fine scale of
-    the strip over all ranks, the reference's ROI convention (marge.py:86-101; optimization/optimization.py:43: 40 rows for SGM, plus
-    the census window's 2): every rank runs census 5x5 + CBCA + SGM 8-path + WTA + vfit (float32 volumes between the steps) on its
-    H5 / N rows + margin, places its owned rows in the full-size maps and ONE group of ncclSend / ncclRecv brings them to rank 0
-    (on the communication stream, under the next step's kernels).  Same barrier / max-over-ranks clock as the headline; after the
-    timed region rank 0 runs the whole strip on its one GPU: `one_gpu_ms_per_step` and the identity of the gathered maps."""
+def row_tiled_leg(eng, comm, which, H5, W5, steps, check_device, c4_dmax=256):
+    """N > 1: a BASELINE configuration AS STATED over all ranks by row tiles, the reference's ROI convention (marge.py:86-101;
+    optimization/optimization.py:43: 40 rows for SGM, plus the cost window's radius):
+      which = "c5": configs[4] as BASELINE words it - "10000x10000 ... Census+CBCA+SGM ... row-tiled 8 GPUs" - the fine scale of the
+                    strip, d = [-64, 64], census 5x5 + CBCA + SGM 8-path + WTA + vfit;
+      which = "c4": configs[3]'s pipeline - 4096x4096, d = [0, 256], ZNCC 11x11 + SGM 8-path + WTA + vfit - WITH its SGM step (the
+                    exact D-sharded leg beside it has to leave SGM out: SURVEY 8e).
+    float32 volumes between the steps.  Every rank runs the pipeline on its H / N rows + margin, places its owned rows in the
+    full-size maps and ONE group of ncclSend / ncclRecv brings them to rank 0 (on the communication stream, under the next step's
+    kernels).  Same barrier / max-over-ranks clock as the headline; after the timed region rank 0 runs the whole pair on its one GPU:
+    `one_gpu_ms_per_step` and the identity of the gathered maps."""
     from pandora_amd import _lib
     from pandora_amd.dist import row_tile
     from pandora_amd.engine import Engine
 
     rank, world = comm.rank, comm.world
-    dmin, dmax, win = -64, 64, 5
+    if which == "c5":
+        dmin, dmax, win, cost, cbca, is_max, inv = -64, 64, 5, "census", True, False, 26.0
+    else:
+        dmin, dmax, win, cost, cbca, is_max, inv = 0, c4_dmax, 11, "zncc", False, True, 2.0
     D = dmax - dmin + 1
     margin = SGM_MARGIN + win // 2
     L5, R5 = synthetic_pair(H5, W5, dmin, dmax)
@@ -385,12 +395,16 @@ def c5_row_tiled_leg(eng, comm, H5, W5, steps, check_device):
     cv = eng.alloc_cv(D, dmin)
 
     def pipeline(e, c):
-        e.census(c, win)
-        e.cbca(c, win // 2, 30.0, 5)
-        e.sgm(c, 8.0, 32.0, False, float(win * win + 1), False)
+        if cost == "census":
+            e.census(c, win)
+        else:
+            e.zncc(c, win)
+        if cbca:
+            e.cbca(c, win // 2, 30.0, 5)
+        e.sgm(c, 8.0, 32.0, is_max, inv, False)
         e.set_validity(None)
-        e.wta(c, False, -9999.0)
-        e.refine(c, "vfit", False)
+        e.wta(c, is_max, -9999.0)
+        e.refine(c, "vfit", is_max)
 
     def step():
         pipeline(eng, cv)
@@ -428,9 +442,11 @@ def c5_row_tiled_leg(eng, comm, H5, W5, steps, check_device):
         one.close()
         gd, gv, gi = gathered
         cells = H5 * W5 * D
-        out = {"workload": f"BASELINE configs[4], fine scale, row-tiled: {H5}x{W5} synthetic pair, d=[{dmin},{dmax}] (D={D}), Census 5x5 + CBCA + "
-                           f"SGM 8-path + WTA + vfit, float32 volumes between the steps; ONE pair per step over {world} ranks",
-               "parallelism": f"row tiles of {H5 // world} rows + {margin}-row margin (40 SGM + {win // 2} census: the reference's ROI convention), "
+        what = ("BASELINE configs[4], fine scale, row-tiled" if which == "c5" else "BASELINE configs[3]'s pipeline WITH its SGM step, row-tiled")
+        steps_txt = ("Census 5x5 + CBCA + SGM 8-path + WTA + vfit" if which == "c5" else "ZNCC 11x11 + SGM 8-path + WTA + vfit")
+        out = {"workload": f"{what}: {H5}x{W5} synthetic pair, d=[{dmin},{dmax}] (D={D}), {steps_txt}, float32 volumes between the steps; "
+                           f"ONE pair per step over {world} ranks",
+               "parallelism": f"row tiles of {H5 // world} rows + {margin}-row margin (40 SGM + {win // 2} window: the reference's ROI convention), "
                               f"one ncclSend / ncclRecv gather of the owned rows of 3 maps to GPU 0 per step; strong scaling",
                "steps": steps, "ms_per_step": round(dt * 1e3, 3), "value": round(cells / dt / 1e6, 1), "unit": "Mdisp/s", "dtype": "f32",
                "one_gpu_ms_per_step": round(one_ms, 3), "speedup_vs_one_gpu": round(one_ms / (dt * 1e3), 3),
@@ -439,6 +455,13 @@ def c5_row_tiled_leg(eng, comm, H5, W5, steps, check_device):
                    "disparity_identical": round(float(np.mean((gd == od) | (np.isnan(gd) & np.isnan(od)))), 6),
                    "validity_identical": round(float(np.mean(gv == ov)), 6),
                    "coefficient_identical": round(float(np.mean((gi == oi) | (np.isnan(gi) & np.isnan(oi)))), 6)}}
+        if which == "c4":
+            # ZNCC costs are not integers: the rows a tile does not see change every sum in its last bits, so the REFINED disparity is
+            # rarely the same float; what tiling preserves is the winner and the disparity to a hundredth of a pixel
+            with np.errstate(invalid="ignore"):
+                both_nan = np.isnan(gd) & np.isnan(od)
+                out["gathered_maps_vs_one_gpu"]["winner_identical"] = round(float(np.mean((np.rint(gd) == np.rint(od)) | both_nan)), 6)
+                out["gathered_maps_vs_one_gpu"]["disparity_within_0.01"] = round(float(np.mean((np.abs(gd - od) <= 0.01) | both_nan)), 6)
     comm.barrier()
     return out
 
@@ -570,13 +593,19 @@ def main():
     ap.add_argument("--dmin", type=int, default=0)
     ap.add_argument("--dmax", type=int, default=256)
     ap.add_argument("--cpu-rows", type=int, default=512, help="rows of the CPU-baseline strip (0 = skip)")
-    ap.add_argument("--placement-trials", type=int, default=6,
-                    help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials; 1 = plain hipMalloc)")
+    ap.add_argument("--placement-trials", type=int, default=1,
+                    help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials; 1 = plain hipMalloc, what `value` "
+                         "is measured on by default: the tuned figure is the `placement_tuned` extra)")
+    ap.add_argument("--tuned-trials", type=int, default=6, help="candidates of the `placement_tuned` extra leg (N=1; 1 = skip it)")
     ap.add_argument("--no-c3", action="store_true", help="skip the 2048x2048x129 leg (BASELINE configs[2])")
     ap.add_argument("--no-configs", action="store_true", help="skip the c4_as_stated / c5_as_stated / default_allocation legs (N=1)")
     ap.add_argument("--no-dshard", action="store_true", help="skip the exact D-sharded leg (N>1)")
     ap.add_argument("--no-weak", action="store_true", help="skip the pair-per-rank (weak scaling) leg (N>1)")
     ap.add_argument("--no-c5tiled", action="store_true", help="skip the row-tiled BASELINE configs[4] leg (N>1)")
+    ap.add_argument("--no-c4tiled", action="store_true", help="skip the row-tiled BASELINE configs[3] (ZNCC + SGM) leg (N>1)")
+    ap.add_argument("--c4-height", type=int, default=4096, help="rows of the row-tiled configs[3] leg (N>1)")
+    ap.add_argument("--c4-width", type=int, default=4096, help="columns of the row-tiled configs[3] leg (N>1)")
+    ap.add_argument("--c4-dmax", type=int, default=256, help="last disparity of the row-tiled configs[3] leg (N>1; the tests shrink it)")
     ap.add_argument("--c5-height", type=int, default=10000, help="rows of the row-tiled configs[4] leg (N>1)")
     ap.add_argument("--c5-width", type=int, default=10000, help="columns of the row-tiled configs[4] leg (N>1)")
     ap.add_argument("--watchdog", type=float, default=1200.0, help="seconds after which a self-launched multi-rank run is stopped")
@@ -679,10 +708,14 @@ def main():
             return None
         return res
 
-    dshard = weak = c5tiled = None
+    dshard = weak = c5tiled = c4tiled = None
+    if comm is not None:
+        cv.free()  # (the extra legs bring their own volumes)
     if comm is not None and not args.no_c5tiled:
-        cv.free()
-        c5tiled = leg("c5_row_tiled", lambda: c5_row_tiled_leg(eng, comm, args.c5_height, args.c5_width, max(2, args.steps // 4), local_rank))
+        c5tiled = leg("c5_row_tiled", lambda: row_tiled_leg(eng, comm, "c5", args.c5_height, args.c5_width, max(2, args.steps // 4), local_rank))
+    if comm is not None and not args.no_c4tiled:
+        c4tiled = leg("c4_row_tiled", lambda: row_tiled_leg(eng, comm, "c4", args.c4_height, args.c4_width, max(2, args.steps // 4), local_rank,
+                                                              c4_dmax=args.c4_dmax))
     if comm is not None and not args.no_dshard and D >= 2 * world:
         dshard = leg("d_sharded_exact", lambda: d_sharded_leg(eng, comm, L, R, dmin, dmax, 11, max(2, args.steps // 2), local_rank))
     if comm is not None and not args.no_weak:
@@ -723,6 +756,20 @@ def main():
         }
         if world == 1 and stage["sgm_span"][1] > 0:
             own_format(out, wtraffic, H, W, D, ms_per_step)
+        if world == 1:
+            # "measure achievable with a device memcpy/triad on the box and report both" - plain 16-byte-per-lane
+            # streams over 4 GB in this run, on this box (pmx_measure_hbm), beside the 8000 GB/s of the data sheet
+            hbm = eng.measure_hbm(4 << 30)
+            peak_m = max(hbm.values())
+            roof["peak_measured"] = round(peak_m, 1)
+            roof["peak_measured_streams"] = {k: round(v, 1) for k, v in hbm.items()}
+            roof["peak_measured_note"] = "GB/s of a 4 GB fill / read / copy (copy counts both directions) in this run; peak_measured = the best"
+            if peak_m > 0:
+                roof["frac_of_measured"] = round(roof["achieved"] / peak_m, 4)
+                if "frac_counted" in roof:
+                    roof["frac_counted_of_measured"] = round(roof["frac_counted"] * HBM_PEAK_GBS / peak_m, 4)
+                if "pipeline_hbm_frac_counted" in out:
+                    out["pipeline_hbm_frac_counted_of_measured"] = round(out["pipeline_hbm_frac_counted"] * HBM_PEAK_GBS / peak_m, 4)
         if world > 1:
             # RCCL's own rank count (ncclCommCount) - or, under the --test-comm hook, what carried the exchange instead
             if getattr(comm, "nranks_note", None):
@@ -753,6 +800,8 @@ def main():
                 out["pair_per_rank"] = weak
             if c5tiled is not None:
                 out["c5_row_tiled"] = c5tiled
+            if c4tiled is not None:
+                out["c4_row_tiled"] = c4tiled
             if leg_errors:
                 out["leg_errors"] = leg_errors
         else:
@@ -776,13 +825,23 @@ def main():
                                    "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "pcie_inclusive_ms": round(pcie3, 3)}
             if not args.no_configs and (H, W, D) == (4096, 4096, 257):
-                # the headline step again with plain hipMalloc placement (what a plugin user gets without pmx_set_placement_trials)
+                # `value` is measured on plain hipMalloc buffers - what a plugin user of INTEGRATION.md gets.  The same step on a fresh
+                # context that probes `--tuned-trials` candidates per volume and keeps the fastest (pmx_set_placement_trials):
                 if args.placement_trials > 1:
                     plain = Engine(local_rank)
                     msd, std, _ = measure_shape(plain, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
                     out["default_allocation"] = {"placement_trials": 1, "ms_per_step": round(msd, 3), "value": round(cells / msd / 1e3, 1),
                                                  "unit": "Mdisp/s", "note": "same workload and protocol on a fresh context with plain hipMalloc"}
+                    out["value_default_allocation"] = out["default_allocation"]["value"]
                     plain.close()
+                elif args.tuned_trials > 1:
+                    tuned = Engine(local_rank)
+                    tuned.set_placement_trials(args.tuned_trials)
+                    mst, _, _ = measure_shape(tuned, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
+                    out["placement_tuned"] = {"placement_trials": args.tuned_trials, "ms_per_step": round(mst, 3),
+                                              "value": round(cells / mst / 1e3, 1), "unit": "Mdisp/s",
+                                              "note": "same workload and protocol on a fresh context with pmx_set_placement_trials (opt-in)"}
+                    tuned.close()
                 # BASELINE configs[3] and configs[4] as stated, float32 between the steps, one GPU
                 eng.set_placement_trials(1)  # (six candidates of a 51.6 GB volume would not fit the device)
                 out["c4_as_stated"] = config_leg(eng, L, R, dmin, dmax, ("zncc", 11), False, 3,

@@ -78,6 +78,19 @@ int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, const double* 
  * bandwidth of a hipMalloc'd buffer depends on where the driver placed it.  One-time cost of a few hundred ms per
  * buffer size; cached buffers are reused as they are.  trials = 1 (default) switches it off. */
 int pmx_set_placement_trials(pmx_ctx* ctx, int trials);
+/* What plain streaming kernels reach on this device, in GB/s (no reference counterpart; SURVEY 8d: "measure achievable with a device
+ * memcpy/triad on the box and report both"): a 16-byte-per-lane fill, read and copy of `bytes` (two buffers of that size are allocated
+ * and freed), best of three passes each; copy counts read + written bytes.  bench.py's roofline.peak_measured. */
+int pmx_measure_hbm(pmx_ctx* ctx, size_t bytes, double* read_gbs, double* write_gbs, double* copy_gbs);
+/* Kernel-route and tuning options of a context (no reference counterpart; the list with meanings: DESIGN.md 7b).  By default the
+ * library chooses every kernel from the call's arguments alone.  An option forces a choice - what the parity tests use to drive every
+ * route on small inputs, and the A/B scripts under tools/.  `name` is one of the known names ("SGM8_FAM", "SGM_SCHED", "CBCA_FAST",
+ * ...), `value` a short string ("0", "1", "fam", "16x20"); value = NULL clears the option.  pmx_create seeds the options ONCE
+ * from the environment variables PMX_<name>; after that the environment is never read again.  Unknown names: PMX_ERR_ARG.
+ * pmx_get_option returns the value or NULL (the pointer is valid until the option changes). */
+int pmx_set_option(pmx_ctx* ctx, const char* name, const char* value);
+const char* pmx_get_option(const pmx_ctx* ctx, const char* name);
+const char* pmx_option_name(int index); /* the known names, 0, 1, ...; NULL past the last */
 /* Lazy evaluation (default ON).  A cost volume handle may hold the volume in a cheaper exact form
  * than float32 [H][W][D] - "all NaN", "census codes, costs not yet written", "eight uint8 SGM path
  * volumes" - and only materialises float32 when a step or the caller needs it.  With census costs
@@ -199,6 +212,12 @@ int pmx_validity_frame_map(pmx_ctx* ctx, void* validity_snapshot, int border);
 /* refinement_cpp.loop_refinement + vfit/quadratic (refinement/cpp/src/refinement.cpp:28-99,
  * vfit.cpp:28-56, quadratic.cpp:28-50) on the device-resident WTA result. */
 int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
+/* refinement_cpp.loop_approximate_refinement (refinement/cpp/src/refinement.cpp:103-182; refinement_cpp.pyi:82-122; caller
+ * AbstractRefinement.approximate_subpixel_refinement, refinement.py:124-158): refines the resident map as a RIGHT map found by the
+ * diagonal search of the LEFT volume `cv_left` - pixel (row, col) with disparity d reads the left cells (row, col + d, -d) and its two
+ * diagonal neighbours; borders of the range and of the diagonal stop the interpolation (mask += 8).  The resident map / mask / coefficient
+ * are updated in place like pmx_refine's. */
+int pmx_refine_approximate(pmx_ctx* ctx, const pmx_cv* cv_left, int method, int is_max);
 /* Download disparity float32[H][W], validity int64[H][W], interpolated coeff float32[H][W]
  * (any pointer may be NULL). */
 int pmx_get_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp);

@@ -33,6 +33,9 @@ SIGNATURES = {
     "pmx_set_shifted_right": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float)]),
     "pmx_set_disparity_grids": (C.c_int, [vp, c_double_p, c_double_p]),
     "pmx_set_lazy": (C.c_int, [vp, C.c_int]),
+    "pmx_set_option": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
+    "pmx_get_option": (C.c_char_p, [vp, C.c_char_p]),
+    "pmx_option_name": (C.c_char_p, [C.c_int]),
     "pmx_cv_alloc": (vp, [vp, C.c_int, C.c_int]),
     "pmx_cv_free": (None, [vp, vp]),
     "pmx_cv_fill_nan": (C.c_int, [vp, vp]),
@@ -68,6 +71,7 @@ SIGNATURES = {
     "pmx_map_snapshot_free": (None, [vp, vp]),
     "pmx_wta": (C.c_int, [vp, vp, C.c_int, C.c_float]),
     "pmx_refine": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "pmx_refine_approximate": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "pmx_get_disparity": (C.c_int, [vp, c_float_p, c_i64_p, c_float_p]),
     "pmx_set_disparity": (C.c_int, [vp, c_float_p, c_i64_p]),
     "pmx_wta_minkey": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
@@ -96,6 +100,7 @@ SIGNATURES = {
     "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
     "pmx_debug_small_division": (C.c_int, [vp, C.POINTER(C.c_uint)]),
     "pmx_set_placement_trials": (C.c_int, [vp, C.c_int]),
+    "pmx_measure_hbm": (C.c_int, [vp, C.c_size_t, c_double_p, c_double_p, c_double_p]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmx_reset_stage_times": (C.c_int, [vp]),
     "pmx_stage_time": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),

@@ -9,6 +9,7 @@
 //     aggregation_cpp.cbca(input, cross_left, cross_right, range_col, range_col_right)       aggregation/cbca.py:158
 //     refinement_cpp.loop_refinement(cv, disp, mask, d_min, d_max, subpixel, measure, method, cst_invalid, cst_stopped)
 //                                                                                            refinement/refinement.py:104
+//     refinement_cpp.loop_approximate_refinement(... the same arguments, a right map on the left volume ...)   refinement/refinement.py:146
 //     refinement_cpp.vfit_refinement_method / quadratic_refinement_method(cost, disp, measure, cst_stopped)   vfit.py / quadratic.py
 // This module exports the same names with the same argument meaning and the same array conventions (arguments by value with
 // implicit forcecast - a wrong dtype or a strided slice is silently copied, census WRITES INTO AND RETURNS the cv it was given,
@@ -235,6 +236,36 @@ std::tuple<py::array_t<float>, py::array_t<float>, py::array_t<int64_t>> loop_re
     return {itp, dout, mout};
 }
 
+// refinement/cpp/src/refinement.cpp:103-182 (refinement_cpp.pyi:82-122): the right map of the "fast" cross-checking route, refined on
+// the LEFT volume's diagonals.  disp / mask are the right map's, [d_min, d_max] the LEFT volume's range.
+std::tuple<py::array_t<float>, py::array_t<float>, py::array_t<int64_t>> loop_approximate_refinement(
+    farr cv, farr disp, larr mask, double d_min, double d_max, int subpixel, const std::string& measure, py::object method, int64_t cst_invalid,
+    int64_t cst_stopped) {
+    if (cv.ndim() != 3 || disp.ndim() != 2 || mask.ndim() != 2) throw std::invalid_argument("loop_approximate_refinement: cv 3-D, disp and mask 2-D");
+    const int H = (int)cv.shape(0), W = (int)cv.shape(1), D = (int)cv.shape(2);
+    if (disp.shape(0) != H || disp.shape(1) != W || mask.shape(0) != H || mask.shape(1) != W)
+        throw std::invalid_argument("loop_approximate_refinement: shapes disagree");
+    if (cst_invalid != 0x3C3 || cst_stopped != 0x8)
+        throw std::invalid_argument("loop_approximate_refinement: the device kernels carry pandora.constants' own mask values (963, 8)");
+    if (subpixel < 1 || subpixel > 4 || std::llround((d_max - d_min) * subpixel) + 1 != D)
+        throw std::invalid_argument("loop_approximate_refinement: [d_min, d_max] x subpixel does not match the volume's depth");
+    if (measure != "min" && measure != "max") throw std::invalid_argument("loop_approximate_refinement: measure is 'min' or 'max'");
+    if (d_min != std::floor(d_min)) throw std::invalid_argument("loop_approximate_refinement: d_min is an integer disparity");
+    const int which = identify_method(method);
+    pmx_ctx* ctx = context();
+    std::vector<float> zeros((size_t)H * W, 0.f);  // (the context takes its geometry from the resident pair)
+    ok(pmx_set_images(ctx, zeros.data(), zeros.data(), H, W, subpixel), "pmx_set_images");
+    cv_guard g{ctx, pmx_cv_alloc(ctx, D, (int)d_min)};
+    if (!g.cv) throw std::runtime_error(std::string("pmx_cv_alloc: ") + pmx_last_error());
+    ok(pmx_cv_upload(ctx, g.cv, cv.data()), "pmx_cv_upload");
+    ok(pmx_set_disparity(ctx, disp.data(), mask.data()), "pmx_set_disparity");
+    ok(pmx_refine_approximate(ctx, g.cv, which, measure == "max"), "pmx_refine_approximate");
+    py::array_t<float> itp({(py::ssize_t)H, (py::ssize_t)W}), dout({(py::ssize_t)H, (py::ssize_t)W});
+    py::array_t<int64_t> mout({(py::ssize_t)H, (py::ssize_t)W});
+    ok(pmx_get_disparity(ctx, dout.mutable_data(), mout.mutable_data(), itp.mutable_data()), "pmx_get_disparity");
+    return {itp, dout, mout};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(inner_cpp, m) {
@@ -251,6 +282,9 @@ PYBIND11_MODULE(inner_cpp, m) {
     m.def("cbca", &cbca, py::arg("input"), py::arg("cross_left"), py::arg("cross_right"), py::arg("range_col"), py::arg("range_col_right"));
     m.def("loop_refinement", &loop_refinement, py::arg("cv"), py::arg("disp"), py::arg("mask"), py::arg("d_min"), py::arg("d_max"),
           py::arg("subpixel"), py::arg("measure"), py::arg("method"), py::arg("cst_pandora_msk_pixel_invalid"),
+          py::arg("cst_pandora_msk_pixel_stopped_interpolation"));
+    m.def("loop_approximate_refinement", &loop_approximate_refinement, py::arg("cv"), py::arg("disp"), py::arg("mask"), py::arg("d_min"),
+          py::arg("d_max"), py::arg("subpixel"), py::arg("measure"), py::arg("method"), py::arg("cst_pandora_msk_pixel_invalid"),
           py::arg("cst_pandora_msk_pixel_stopped_interpolation"));
     m.def("vfit_refinement_method", &vfit_refinement_method, py::arg("cost"), py::arg("disp"), py::arg("measure"),
           py::arg("cst_pandora_msk_pixel_stopped_interpolation"));

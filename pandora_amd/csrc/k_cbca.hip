@@ -201,8 +201,8 @@ __global__ __launch_bounds__(kBlock) void cross_support_flat_kernel(const float*
 
 __global__ void pack_arms_kernel(const int16_t* __restrict__ arms, int Hc, int Wsrc, uint32_t* __restrict__ rows, int pitch, int xoff);
 
-static bool arms_flat(int distance) {
-    const char* ef = getenv("PMX_CBCA_ARMS_FLAT");  // =0: the loop form (A/B and test hook)
+static bool arms_flat(const pmx_ctx* ctx, int distance) {
+    const char* ef = pmx_opt(ctx, "CBCA_ARMS_FLAT");  // =0: the loop form (A/B and test hook)
     return !(ef && ef[0] == '0') && distance >= 1 && distance <= 18;
 }
 
@@ -223,7 +223,7 @@ static int build_arms(pmx_ctx* ctx, int side, int offset, float intensity, int d
     int Hc = H - 2 * offset, Wc = Wd - 2 * offset;
     if (Hc <= 0 || Wc <= 0) return PMX_OK;
     dim3 g2((Wc + kBlock - 1) / kBlock, Hc);
-    const bool flat = arms_flat(distance);
+    const bool flat = arms_flat(ctx, distance);
 #define PMX_FLAT(LMV)                                                                                                                  \
     do {                                                                                                                               \
         if (packed && !want16)                                                                                                         \
@@ -257,7 +257,6 @@ int pmx_launch_cross_support(pmx_ctx* ctx, int side, int offset, float intensity
 
 // ---- the two scan passes -------------------------------------------------------------------------
 struct cbca_args {
-    int dbg;          // ablation hook (PMX_CBCA_DBG), pass V through buffers: 1 no right-arm loads, 2 no left-arm loads, 4 no E_h loads, 8 no stores
     float* cv;        // [H][W][D] in/out
     float* eh;        // [H][W][D] horizontal segment sums (scratch)
     const int16_t* armsL;                   // [Hc][Wc][4]
@@ -923,12 +922,12 @@ __global__ __launch_bounds__(BS) void cbca_v_buf_kernel(cbca_args a) {
     // four rows; a lane's own offset stays inside one row, a dead lane's out-of-range offset still drops its access).  (Re-basing every row was 6 scalar instructions per memory instruction -
     // the pass is issue-bound with as many scalar as vector instructions)  PMX_CBCA_DBG empties descriptors.
     const unsigned quad_bytes = 4u * row_bytes;
-    const unsigned e_bytes = (a.dbg & 4) ? 0u : quad_bytes, st_bytes = (a.dbg & 8) ? 0u : quad_bytes;
+    const unsigned e_bytes = quad_bytes, st_bytes = quad_bytes;
     auto rs_at = [&](const void* row_ptr, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)row_ptr, 0, bytes, kRsrcWord3); };
     auto ld = [&](const float* row_ptr) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_at(row_ptr, row_bytes), voff, 0, 0)); };
     const unsigned offL = (unsigned)c * 4u;
     const unsigned offR = ((unsigned)ph * a.phase_words + (unsigned)(a.padR + q)) * 4u;  // (pads: every q of the lane's cells is readable)
-    const unsigned armsL_bytes = (a.dbg & 2) ? 0u : 0x7ffffff0u, armsR_bytes = (a.dbg & 1) ? 0u : 0x7ffffff0u;
+    const unsigned armsL_bytes = 0x7ffffff0u, armsR_bytes = 0x7ffffff0u;
     const unsigned pitchL_bytes = (unsigned)a.pitchL * 4u, pitchR_bytes = (unsigned)a.pitchR * 4u;
     float acc = 0.f;
     uint32_t nacc = 0;
@@ -1677,8 +1676,8 @@ static int cbca_ring_slots(int A) {  // 2A+2 live columns + A+1 still-zero slots
 // rows per workgroup of the whole-row pass H: R*D threads rounded up to whole wavefronts - the fewer idle lanes the better
 // (D = 129: 2 rows are 5 wavefronts, the fifth with 2 lanes; 4 rows are 9 with 4) -, within kRowsT threads and 150 KB of LDS
 // (ring + output stage); 0: the kernel does not fit (very long arms with many disparities)
-static int cbca_rows_per_block(int D, int ring) {
-    const char* er = getenv("PMX_CBCA_ROWS");
+static int cbca_rows_per_block(const pmx_ctx* ctx, int D, int ring) {
+    const char* er = pmx_opt(ctx, "CBCA_ROWS");
     int best = 0;
     double best_waste = 1e9;
     for (int R = 1; R <= 8; ++R) {
@@ -1694,15 +1693,15 @@ static int cbca_rows_per_block(int D, int ring) {
 
 // can pass H compute the census costs itself (no float volume)?  One code word per pixel, whole-row kernel applicable.
 bool pmx_cbca_can_fuse_census(const pmx_ctx* ctx, const pmx_cv* cv, int offset, int distance) {
-    const char* ef = getenv("PMX_CBCA_FAST");
-    const char* eu = getenv("PMX_CBCA_FUSE");
+    const char* ef = pmx_opt(ctx, "CBCA_FAST");
+    const char* eu = pmx_opt(ctx, "CBCA_FUSE");
     if ((ef && atoi(ef) != 1) || (eu && eu[0] == '0')) return false;
     const int A = distance - 1 > 1 ? distance - 1 : 1;
     const int Hc = cv->H - 2 * offset, Wc = cv->W - 2 * offset;
     const int pitchR = (cv->d0 < 0 ? -cv->d0 : 0) + 4 + Wc + (cv->d0 + cv->D - 1 > 0 ? cv->d0 + cv->D - 1 : 0) + 8;
     // (a crop wider than the census border leaves cells with real costs outside the aggregated area: they need the volume)
     return cv->repr == PMX_REPR_CENSUS_DEFERRED && cv->subpix == 1 && cv->win * cv->win <= 32 && offset <= cv->win / 2 && cbca_ring_slots(A) <= 64 &&
-           cbca_rows_per_block(cv->D, cbca_ring_slots(A)) > 0 && Wc >= 2 * A + 8 && Hc >= 2 * A + 8 && cv->codes_bytes < 0x7fffffffu &&
+           cbca_rows_per_block(ctx, cv->D, cbca_ring_slots(A)) > 0 && Wc >= 2 * A + 8 && Hc >= 2 * A + 8 && cv->codes_bytes < 0x7fffffffu &&
            (size_t)Hc * pitchR * 4 < 0x7fffffffu && (size_t)Hc * (Wc + 4) * 4 < 0x7fffffffu && (size_t)8 * cv->W * cv->D * 4 < 0x7fffffffu;
 }
 
@@ -1716,7 +1715,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     // four-disparities-per-thread kernels work IN PLACE (no second volume: 51.6 GB less at 10000^2 x 129) but measured slower
     // (2048^2 x 129: 2.15 + 2.97 ms against 1.50 + 1.96: a quarter of the waves, nothing left to hide latency), so they run when
     // the second volume cannot be had, or on request.  PMX_CBCA_FAST (test hook): 0 generic, 2 phase-split, 4 in-place.
-    const char* ef = getenv("PMX_CBCA_FAST");
+    const char* ef = pmx_opt(ctx, "CBCA_FAST");
     const int want = ef ? atoi(ef) : 1;
     const bool long_scans = Wc >= 2 * a.A + 8 && Hc >= 2 * a.A + 8;
     const bool four_ok = cv->subpix == 1 && 3 * a.A + 3 <= kRing4 && long_scans;
@@ -1739,7 +1738,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     const int pitchL = Wc + 4, pitchR = padR + Wc + (dq_max > 0 ? dq_max : 0) + 8;
     const size_t bL8 = (size_t)Hc * pitchL * 4, bR8 = (size_t)Hc * pitchR * 4;
     const int ring = cbca_ring_slots(a.A);
-    const int rows = ring <= 64 ? cbca_rows_per_block(cv->D, ring) : 0;
+    const int rows = ring <= 64 ? cbca_rows_per_block(ctx, cv->D, ring) : 0;
     const bool rows_ok = !four && want == 1 && long_scans && rows > 0 && (size_t)cv->subpix * bR8 < 0x7fffffffu && bL8 < 0x7fffffffu &&
                          (size_t)8 * W * cv->D * 4 < 0x7fffffffu;
     if (census_src && !rows_ok) {
@@ -1751,7 +1750,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     size_t march_lds = 0;
     bool march = false;
     {
-        const char* em = getenv("PMX_CBCA_MARCH");
+        const char* em = pmx_opt(ctx, "CBCA_MARCH");
         const bool shape_ok = census_src && rows_ok && a.A <= 4 && cv->subpix == 1 && cv->D <= 256 &&
                               (size_t)Hc * 9 * 32 < ((size_t)1 << 24) && bL8 + bR8 < 0xfffffff0u;
         // columns per workgroup: as many (up to 8: a disparity's costs of a row are 16 bytes with the 8 halo columns) as leave
@@ -1822,13 +1821,13 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     // pass V through buffers (the choice is made here because it decides which form of the arms is needed)
     // (worth it when there are more wavefronts than the pointer kernel's 3 per SIMD can hold: 2048^2 x 129 has 4 per SIMD and
     // runs 1.71 against 1.82 ms with pointers, 10000^2 x 129 has 20 and runs 31 against 35 ms with buffers)
-    const char* ev = getenv("PMX_CBCA_VBUF");  // 0: the phase-split kernel with pointers (test hook)
+    const char* ev = pmx_opt(ctx, "CBCA_VBUF");  // 0: the phase-split kernel with pointers (test hook)
     const bool vbuf = rows_ok && (ev ? ev[0] != '0' : (size_t)Wc * cv->D >= (size_t)6144 * 64);
     const bool want16 = !(march || vbuf);  // the short4 arms: only the kernels that read them through pointers
     {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_ARMS);
         // the pads are zero arms (the branch-free kernel writes them itself when it writes the packed rows)
-        if (rows_ok && (want16 || !arms_flat(distance))) PMX_HIP(hipMemsetAsync(wbase, 0, wide_bytes, ctx->stream));
+        if (rows_ok && (want16 || !arms_flat(ctx, distance))) PMX_HIP(hipMemsetAsync(wbase, 0, wide_bytes, ctx->stream));
         rc = rows_ok ? build_arms(ctx, 0, o, intensity, distance, tmp, (int16_t*)a.armsL, 0, (uint32_t*)a.armsL8, pitchL, 0, want16)
                      : build_arms(ctx, 0, o, intensity, distance, tmp, (int16_t*)a.armsL);
         if (rc) return rc;
@@ -1868,7 +1867,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     const bool fast_ok = want != 0 && !small_blocks;
     // costs >= +0: the NaN flags of the input travel in the sign bit of E_h (PMX_CBCA_SIGN=0: test hook; the census source has
     // no input volume to ask)
-    const char* es = getenv("PMX_CBCA_SIGN");
+    const char* es = pmx_opt(ctx, "CBCA_SIGN");
     const bool sign = rows_ok && (census_src || (cv->nonneg && !(es && es[0] == '0')));
     if (march) {
         pmx_stage_scope t(ctx, PMX_STAGE_CBCA_V);
@@ -1895,7 +1894,7 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
                 const unsigned nb = (unsigned)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
                 hipLaunchKernelGGL(cbca_border_nan_kernel, dim3(nb), dim3(256), 0, ctx->stream, cv->data, H, W, cv->D, o);
             }
-            const char* eg = getenv("PMX_CBCA_GEO");  // 0: the general census source even where the geometry one applies (test hook)
+            const char* eg = pmx_opt(ctx, "CBCA_GEO");  // 0: the general census source even where the geometry one applies (test hook)
             if (a.range) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 2>), grid, dim3(T), lds, ctx->stream, a);
             else if (o == a.cb && !(eg && eg[0] == '0')) hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 3>), grid, dim3(T), lds, ctx->stream, a);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(cbca_h_rows_kernel<true, 1>), grid, dim3(T), lds, ctx->stream, a);
@@ -1919,12 +1918,11 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
         int total = Wc * cv->D;
         // workgroups of 512 threads read 2 KB contiguous per row: a little kinder to the DRAM pages when the workgroups of a launch
         // have drifted rows apart (10000^2 x 129: 32.3 against 35.1 ms; at 2048^2 x 129 the coarser grid costs more than it gains)
-        a.dbg = getenv("PMX_CBCA_DBG") ? atoi(getenv("PMX_CBCA_DBG")) : 0;
-        const char* eb = getenv("PMX_CBCA_VBS");
+        const char* eb = pmx_opt(ctx, "CBCA_VBS");
         int vbs = eb ? atoi(eb) : ((size_t)total >= ((size_t)1 << 20) ? 512 : 256);
         while (vbs > 256 && (size_t)2 * ring * vbs * sizeof(float) > (size_t)64 * 1024) vbs >>= 1;  // (long arms: the ring decides)
         // (descriptors per row or per quad of rows: see the kernel - the per-row form wins once a row of the volume is several MB)
-        const char* er = getenv("PMX_CBCA_ROWDESC");
+        const char* er = pmx_opt(ctx, "CBCA_ROWDESC");
         const bool rowdesc = er ? er[0] != '0' : (size_t)cv->W * cv->D * sizeof(float) > ((size_t)5 << 20);
 #define PMX_VBUF(SIGNV, BSV)                                                                                                        \
     do {                                                                                                                            \

@@ -215,6 +215,72 @@ int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max) {
     return PMX_OK;
 }
 
+// ---- refinement of a RIGHT map made by the diagonal search of the left volume (refinement_cpp.loop_approximate_refinement,
+// refinement/cpp/src/refinement.cpp:103-182; caller AbstractRefinement.approximate_subpixel_refinement, refinement.py:124-158) ----
+// Right pixel (row, col) with disparity raw looks at the LEFT volume's cell (row, diag = int(col + raw), dsp = int((-raw - d_min)
+// subpix)) and its diagonal neighbours (diag - 1, dsp + subpix), (diag + 1, dsp - subpix).  The reference indexes them unchecked:
+// dsp -/+ subpix outside [0, D) lands in the neighbouring pixel's run of the contiguous volume, and that is what its compiled
+// module answers - restated here as flat offsets; only an offset outside the whole volume (undefined there) and a winner outside
+// the volume are refused: coefficient NaN, map and mask left alone.
+__global__ __launch_bounds__(kBlock) void approx_refine_kernel(const float* __restrict__ cv, int H, int W, int D, double d_min, double d_max,
+                                                               int subpix, int is_max, int method, float* __restrict__ disp,
+                                                               int64_t* __restrict__ validity, float* __restrict__ itp) {
+    const size_t npix = (size_t)H * W;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    int64_t m = validity[i];
+    if ((m & MSK_INVALID) != 0) { itp[i] = d_nan(); return; }
+    const int col = (int)(i % (size_t)W);
+    const size_t row = i / (size_t)W;
+    const float raw = disp[i];
+    const double fd = ((double)(-raw) - d_min) * (double)subpix;
+    const float fdiag = (float)col + raw;  // (size_t + float in the reference: float arithmetic)
+    if (!(fd > -1.0 && fd < (double)D && fdiag > -1.f && fdiag < (float)W)) { itp[i] = d_nan(); return; }
+    const int dsp = (int)fd, diag = (int)fdiag;
+    const long long total = (long long)npix * D;
+    const long long at = ((long long)row * W + diag) * D + dsp;
+    const float c1 = cv[at];
+    if (c1 != c1) { itp[i] = c1; return; }
+    if ((double)raw == d_min || (double)raw == d_max || diag == 0 || diag == W - 1) { itp[i] = c1; validity[i] = m + MSK_STOPPED; return; }
+    const long long a0 = at - D + subpix, a2 = at + D - subpix;
+    if (a0 < 0 || a2 >= total) { itp[i] = d_nan(); return; }
+    const float c0 = cv[a0], c2 = cv[a2];
+    float ic0, ic2, sd, sc;
+    int64_t flag = 0;
+    if (!validate_costs(c0, c1, c2, is_max != 0, ic0, ic2)) {
+        sd = 0.f; sc = c1; flag = MSK_STOPPED;
+    } else if (method == PMX_REFINE_VFIT) {
+        float a = ic0 > ic2 ? c0 - c1 : c2 - c1;
+        if (fabs((double)a) < 1.0e-15) {
+            sd = 0.f; sc = c1;
+        } else {
+            sd = (c0 - c2) / (2 * a);
+            sc = a * (sd - 1) + c2;
+        }
+    } else {
+        float alpha = (c0 - 2.f * c1 + c2) / 2.f;
+        float beta = (c2 - c0) / 2.f;
+        float x = -beta / (2.f * alpha);
+        float mx = (-1.f < x) ? x : -1.f;
+        sd = (mx < 1.f) ? mx : 1.f;
+        sc = (alpha * sd * sd) + (beta * sd) + c1;
+    }
+    disp[i] = raw + sd / (float)subpix;
+    itp[i] = sc;
+    validity[i] = m + flag;
+}
+
+int pmx_launch_approx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max) {
+    size_t npix = (size_t)cv->H * cv->W;
+    double d_min = (double)cv->d0;
+    double d_max = (double)cv->d0 + (double)(cv->D - 1) / (double)cv->subpix;
+    pmx_stage_scope t(ctx, PMX_STAGE_REFINE);
+    hipLaunchKernelGGL(approx_refine_kernel, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, cv->data, cv->H,
+                       cv->W, cv->D, d_min, d_max, cv->subpix, is_max, method, ctx->disp, ctx->validity, ctx->itp);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+}
+
 // ---- WTA fused into the last float32 SGM pass (k_sgmfam.hip) ----------------------------------------------------------------
 // The pass left disp and, per pixel, near = (S[k-1], S[k], S[k+1], k) of the winner in the output domain, k = -1 where every cost
 // is NaN.  This kernel applies to_disp's validity rule for those pixels (disparity.py:471-474).

@@ -702,15 +702,15 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
     if (cv->subpix != 1 || cv->D >= 16 * 20) return false;
     const int nw = (cv->win * cv->win + 31) / 32;
     if (nw > 2) {  // wider census codes exist for the packed kernels only (k_sgm8.hip)
-        const char* e8 = getenv("PMX_SGM8");
-        if (nw > 6 || nw == 5 || getenv("PMX_FUSED_MAP") || (e8 && e8[0] == '0')) return false;
+        const char* e8 = pmx_opt(ctx, "SGM8");
+        if (nw > 6 || nw == 5 || pmx_opt(ctx, "FUSED_MAP") || (e8 && e8[0] == '0')) return false;
     }
     auto is_int = [](float x) { return x == floorf(x); };
     if (!is_int(P1) || !is_int(P2) || !is_int(invalid_cost)) return false;
     if (invalid_cost < 0 || invalid_cost + P2 > 255.f) return false;
     if (cv->has_range) {  // the snapshot of cv_masked is honoured by the packed kernels only (k_sgm8.hip)
-        const char* e8 = getenv("PMX_SGM8");
-        if (getenv("PMX_FUSED_MAP") || (e8 && e8[0] == '0')) return false;
+        const char* e8 = pmx_opt(ctx, "SGM8");
+        if (pmx_opt(ctx, "FUSED_MAP") || (e8 && e8[0] == '0')) return false;
     }
     return true;
 }
@@ -725,10 +725,10 @@ bool pmx_fused_sgm_eligible(const pmx_ctx* ctx, const pmx_cv* cv, float P1, floa
 //   memory  = #vmem x tau(gl), tau = 55 / 85 / 120 ns   texture path; narrower groups touch more rows per instruction
 //   latency = 250 + 60 kpl (+100 with a trailing byte)  what a step costs a wave that has the SIMD to itself
 //   step    = max(latency, waves_per_SIMD x max(issue, memory));  +8 % for trailing-byte maps (measured, unexplained)
-static void fused_choose_map(int H, int W, int D, int nw, int* gl_out, int* kpl_out) {
+static void fused_choose_map(const pmx_ctx* ctx, int H, int W, int D, int nw, int* gl_out, int* kpl_out) {
     // test hook: PMX_FUSED_MAP=<gl>x<kpl> forces a map (used by the parity tests to reach every instantiation
     // on small volumes); ignored unless it is a legal map for this D
-    if (const char* e = getenv("PMX_FUSED_MAP")) {
+    if (const char* e = pmx_opt(ctx, "FUSED_MAP")) {
         int gl = 0, kpl = 0;
         if (sscanf(e, "%dx%d", &gl, &kpl) == 2 && (gl == 4 || gl == 8 || gl == 16) && gl * kpl > D && (kpl & 3) <= 1 &&
             kpl >= 4 && kpl <= 20) {
@@ -774,12 +774,12 @@ static void fused_choose_map(int H, int W, int D, int nw, int* gl_out, int* kpl_
 int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float invalid_cost) {
     const int H = cv->H, W = cv->W;
     int gl, kpl;
-    fused_choose_map(H, W, cv->D, (cv->win * cv->win + 31) / 32, &gl, &kpl);
+    fused_choose_map(ctx, H, W, cv->D, (cv->win * cv->win + 31) / 32, &gl, &kpl);
     {
         // the packed-arithmetic kernels (k_sgm8.hip) are ~25 % faster than any map of the kernel below and exist for
         // 16 lanes x whole dwords: unless a map is forced, take that one
-        const char* e8 = getenv("PMX_SGM8");
-        if (!getenv("PMX_FUSED_MAP") && !(e8 && e8[0] == '0')) {
+        const char* e8 = pmx_opt(ctx, "SGM8");
+        if (!pmx_opt(ctx, "FUSED_MAP") && !(e8 && e8[0] == '0')) {
             gl = 16;
             kpl = ((cv->D / 16 + 1) + 3) & ~3;
         }
@@ -787,7 +787,7 @@ int pmx_launch_sgm_fused(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, float inv
     // the packed-arithmetic path (k_sgm8.hip: byte costs + two disparities per register) whenever the map allows it;
     // PMX_SGM8=0 keeps the popcount-fused kernel below (test hook: both stay covered by the parity suite)
     {
-        const char* e8 = getenv("PMX_SGM8");
+        const char* e8 = pmx_opt(ctx, "SGM8");
         const int nw8 = (cv->win * cv->win + 31) / 32;
         if (!(e8 && e8[0] == '0') && pmx_sgm8_supported(gl, kpl, nw8)) {
             int rc8 = pmx_launch_sgm8(ctx, cv, kpl, (uint32_t)P1, (uint32_t)P2, (uint32_t)invalid_cost);
@@ -858,7 +858,7 @@ int pmx_launch_sum8_wta(pmx_ctx* ctx, const pmx_cv* cv, float invalid_disparity)
         PMX_FUSED_MAPS(PMX_WTA_CASE)
 #undef PMX_WTA_CASE
         // three volumes, no per-pixel ranges: the leaner kernel (PMX_WTA3=0: the general one, A/B hook)
-        const char* e3 = getenv("PMX_WTA3");
+        const char* e3 = pmx_opt(ctx, "WTA3");
         if (!launched && cv->nvol == 3 && cv->gl == 16 && !cv->has_range && cv->kpl % 4 == 0 && cv->kpl <= 20 && !(e3 && e3[0] == '0')) {
             const int qpw = 16;
             const int quads_row = (cv->W + 3) / 4;

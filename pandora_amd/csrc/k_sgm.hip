@@ -499,7 +499,7 @@ static int sgm_run_horizontal_fused(pmx_ctx* ctx, const sgm_args& base, int mask
 template <int KPL>
 static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask) {
     // both horizontal paths: the checkpoint / recompute pair above (PMX_SGM_HFUSED=0: test hook for the two line passes)
-    const char* e = getenv("PMX_SGM_HFUSED");
+    const char* e = pmx_opt(ctx, "SGM_HFUSED");
     if ((mask & 3) == 3 && KPL <= 6 && !base.p2map && !(e && e[0] == '0')) return sgm_run_horizontal_fused<KPL>(ctx, base, mask);
     for (int k = 0; k < 2; ++k)
         if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
@@ -608,17 +608,17 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     if (cv->cells() <= ((size_t)128 << 20)) sched = PAR;  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
     // the marching passes advance one image row per ~2.5 - 4 us whatever the width: they pay from ~3500 columns on (a window
     // for every CU); measured 4096^2 x 257: 55 ms against 96, 10000^2 x 129: 131 against 265, 2048^2 x 129: 12.4 against 11.3
-    else if (cv->W >= 3584 && cv->H >= 512 && pmx_sgm_family_supported(cv)) sched = FAM;
-    if (const char* e = getenv("PMX_SGM_PAR")) sched = e[0] == '1' ? PAR : SEQ;
-    if (const char* e = getenv("PMX_SGM_SCHED")) {
+    else if (cv->W >= 3584 && cv->H >= 512 && pmx_sgm_family_supported(ctx, cv)) sched = FAM;
+    if (const char* e = pmx_opt(ctx, "SGM_PAR")) sched = e[0] == '1' ? PAR : SEQ;
+    if (const char* e = pmx_opt(ctx, "SGM_SCHED")) {
         if (e[0] == 's') sched = SEQ;
         else if (e[0] == 'p') sched = PAR;
         else if (e[0] == 'f') sched = FAM;
     }
     if (sched == PAR && kpl > 8) sched = SEQ;
-    if (sched == FAM && !pmx_sgm_family_supported(cv)) sched = SEQ;
+    if (sched == FAM && !pmx_sgm_family_supported(ctx, cv)) sched = SEQ;
     if (a.p2map && sched == FAM) sched = SEQ;  // the marching kernels take the constant penalty only
-    const char* ep_ = getenv("PMX_SGM_PENDING");
+    const char* ep_ = pmx_opt(ctx, "SGM_PENDING");
     const bool defer_ = sched == FAM && ctx->lazy && mask == 0xff && !(ep_ && ep_[0] == '0');
     if (!defer_) {
         rc = pmx_need_scratch(ctx, bytes);

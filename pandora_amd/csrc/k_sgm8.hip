@@ -1192,7 +1192,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     size_t vol = pmx_dir_stride(H, W, Dp);
     const int nw = (cv->win * cv->win + 31) / 32;
     // five-bit costs when they fit (PMX_COST5=0 keeps bytes: test hook)
-    const char* e5 = getenv("PMX_COST5");
+    const char* e5 = pmx_opt(ctx, "COST5");
     const bool five = invalid_cost <= 31 && (uint32_t)(cv->win * cv->win) <= 31 && !(e5 && e5[0] == '0');
     const int ndw = five ? (kpl + 5) / 6 : kpl / 4;
     const int Dc = nact * ndw * 4;
@@ -1204,7 +1204,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     // (4096 columns: 336 rows 2.7 ms against 2.8, 592 rows 3.7 against 4.1, 1104 rows 5.5 against 6.6, 2128 rows 8.9 against 12.5, 3072 rows
     // 12.3 against 16.7) - profiles/r03_b_shapes.txt, r03_e_shapes.txt.
     bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && W >= 2560 && H >= 480;
-    if (const char* ef = getenv("PMX_SGM8_FAM")) {
+    if (const char* ef = pmx_opt(ctx, "SGM8_FAM")) {
         if (ef[0] == '0') fam = false;
         if (ef[0] == '1') fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u;
     }
@@ -1222,8 +1222,8 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     // pointers): a range that starts or ends further than that from the pixel would wrap the unsigned offset (loads answer 0 for
     // cells that ARE numbers) or leave the allocation.  Such ranges keep the cost volume (census_cost_u8_kernel handles any d0).
     const bool codes_ok = nw == 1 && !cv->has_range && cv->D <= 512 && abs(cv->d0) + cv->D <= 1024 - 64;
-    const char* ehp = getenv("PMX_SGM8_HPAIR");
-    const char* ec = getenv("PMX_SGM8_CODES");
+    const char* ehp = pmx_opt(ctx, "SGM8_HPAIR");
+    const char* ec = pmx_opt(ctx, "SGM8_CODES");
     const bool codes_never = ec && ec[0] == '0', codes_always = ec && ec[0] == '1';
     // (4096 columns x 257, one GPU, ms per step, row walk with the marching kernel from the words / row walk with the marching
     //  kernel on the cost volume / two-sided / one-sided: 592 rows 2.55 / 2.65 / 3.5 / 4.9, 1104 rows 4.35 / 4.6 / 5.0 / 6.7,
@@ -1239,7 +1239,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     }
     const bool hp_codes = fam && (hp_mode == 3 || (hp_mode == 1 && codes_ok && codes_always));
     bool fam_codes = fam && codes_ok && !codes_never && (codes_always || (hp_mode == 3 && H < 1536));
-    if (const char* efc = getenv("PMX_SGM8_FAMCODES")) fam_codes = fam && codes_ok && efc[0] == '1';  // (A/B hook: the marching kernel alone)
+    if (const char* efc = pmx_opt(ctx, "SGM8_FAMCODES")) fam_codes = fam && codes_ok && efc[0] == '1';  // (A/B hook: the marching kernel alone)
     const bool from_codes = hp_codes && fam_codes;  // no cost volume at all
     if (!from_codes && cv->cost8_bytes < cvol) {
         pmx_pool_free(ctx, cv->cost8);
@@ -1290,8 +1290,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         PMX_HIP(hipGetLastError());
         return PMX_OK;
     };
-    const bool cost_async = getenv("PMX_SGM8_COST_ASYNC") && getenv("PMX_SGM8_COST_ASYNC")[0] == '1';
-    if (!from_codes && !(fam && cost_async)) {
+    if (!from_codes) {
         const int rcc = launch_cost(ctx->stream);
         if (rcc) return rcc;
     }
@@ -1302,7 +1301,7 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         // The horizontal pair has one wavefront per four rows (1024 at 4096 rows: one per SIMD, latency-bound on its own) and is
         // independent of the vertical families: it runs on the context's second stream, beside the marching kernel
         // (PMX_SGM8_OVERLAP=0 keeps everything in line: A/B hook).
-        const char* eo = getenv("PMX_SGM8_OVERLAP");
+        const char* eo = pmx_opt(ctx, "SGM8_OVERLAP");
         const bool overlap = !(eo && eo[0] == '0');
         pmx_stage_scope span(ctx, PMX_STAGE_SGM_SPAN);  // fork ... join on the context's stream: the SGM step as the pipeline sees it
         hipStream_t hs = ctx->stream;
@@ -1315,10 +1314,6 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
             PMX_HIP(hipEventRecord(ctx->aux_fork, ctx->stream));  // behind the cost kernel
             PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
             hs = ctx->aux_stream;
-        }
-        if (!from_codes && cost_async) {
-            const int rcc = launch_cost(hs);
-            if (rcc) return rcc;
         }
         {   // volume 0: the horizontal pair
             pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED, hs);
@@ -1371,7 +1366,8 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FUSED);
         // PMX_SGM8_HF=0: the minima on the integer pipe (v_pk_min_u16 chains), the round-2 form - an A/B hook
-        static const bool hf = !(getenv("PMX_SGM8_HF") && getenv("PMX_SGM8_HF")[0] == '0');
+        const char* ehf = pmx_opt(ctx, "SGM8_HF");
+        const bool hf = !(ehf && ehf[0] == '0');
 #define PMX_SGM8(KPLV)                                                                                                   \
     if (five && hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 5, true>), grid, block, 0, ctx->stream, a); \
     else if (five) hipLaunchKernelGGL(HIP_KERNEL_NAME(sgm_u8_packed_kernel<KPLV, 5, false>), grid, block, 0, ctx->stream, a); \

@@ -551,7 +551,7 @@ struct fam_shape {
 // Lane maps that are instantiated: 16 lanes per pixel up to 144 disparities, 32 up to 512.  The window width CW = nw * 64 / gl sets
 // both the hand-off volume per cell (3 vectors per CW columns) and the number of windows in flight (W / CW): every CU wants a
 // window, so narrow images take the 32-lane map (twice the waves per column) and 4 compute waves per workgroup.
-bool pick_shape(int D, int W, fam_shape* out) {
+bool pick_shape(const pmx_ctx* ctx, int D, int W, fam_shape* out) {
     static const int k16[] = {3, 5, 7, 9}, k32[] = {3, 5, 6, 9, 12, 16};
     fam_shape f{0, 0, 0};
     if (D <= 144 && W >= 16 * 224) {
@@ -582,7 +582,7 @@ bool pick_shape(int D, int W, fam_shape* out) {
         for (int nw : {4, 8, 10})
             if (fits(nw) && (W + nw * npw - 1) / (nw * npw) <= cus) { f.nw = nw; break; }
     }
-    if (const char* e = getenv("PMX_SGM_FAM_SHAPE")) {  // test hook: "gl,kpl,nw" forces an instantiated lane map that fits D
+    if (const char* e = pmx_opt(ctx, "SGM_FAM_SHAPE")) {  // test hook: "gl,kpl,nw" forces an instantiated lane map that fits D
         int gl = 0, kpl = 0, nw = 0;
         if (sscanf(e, "%d,%d,%d", &gl, &kpl, &nw) == 3 && gl * kpl >= D && (nw == 4 || nw == 8 || nw == 10)) {
             bool known = false;
@@ -657,12 +657,12 @@ int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes) {
     return PMX_OK;
 }
 
-bool pmx_sgm_family_supported(const pmx_cv* cv) { return cv->H >= 2 && pick_shape(cv->D, cv->W, nullptr); }
+bool pmx_sgm_family_supported(const pmx_ctx* ctx, const pmx_cv* cv) { return cv->H >= 2 && pick_shape(ctx, cv->D, cv->W, nullptr); }
 
 int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
                             int mask, int fams, const pmx_fam_wta* wta) {
     fam_shape f;
-    PMX_CHECK(pick_shape(cv->D, cv->W, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (family schedule): D = %d not supported", cv->D);
+    PMX_CHECK(pick_shape(ctx, cv->D, cv->W, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (family schedule): D = %d not supported", cv->D);
     const int npw = 64 / f.gl, CW = f.nw * npw;
     const int NB = (cv->W + CW - 1) / CW;
     const int NG = 3 * f.gl * ((f.kpl + 2) / 3) + 1, NGP = (NG + 63) / 64 * 64;  // 16-byte blocks per (row, border)

@@ -647,8 +647,8 @@ int launch_fam8(pmx_ctx* ctx, const fam8_args& a, int nwg) {
 
 // compute wavefronts per window for an image width: the smallest of 4 / 8 that keeps the chain of windows short (every window
 // border costs one hand-off per row and one step of pipeline lag)
-int pmx_fam8_waves(int W) {
-    if (const char* e = getenv("PMX_SGM8_FAM_NW")) {
+int pmx_fam8_waves(const pmx_ctx* ctx, int W) {
+    if (const char* e = pmx_opt(ctx, "SGM8_FAM_NW")) {
         const int v = atoi(e);
         if (v == 4 || v == 8) return v;
     }
@@ -660,7 +660,7 @@ bool pmx_fam8_supported(int kpl, int H) { return (kpl % 4) == 0 && kpl >= 4 && k
 // Both vertical families (fams: bit 0 downward, bit 1 upward) into out + f * dstride
 int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, uint8_t* out, size_t dstride, uint32_t P1, uint32_t P2,
                         int fams, bool from_codes, uint32_t invalid_cost) {
-    const int nw = pmx_fam8_waves(cv->W), CW = nw * 4;
+    const int nw = pmx_fam8_waves(ctx, cv->W), CW = nw * 4;
     const int Q = kpl / 4;
     const int NB = (cv->W + CW - 1) / CW;
     const int NG = 3 * 8 * Q + 2, NGP = (NG + 63) / 64 * 64;
@@ -676,7 +676,8 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.epoch = pmx_fam_tag(++ctx->fam_epoch);
     a.ctl = ctx->fam_ctl;
     a.fam0 = fam0; a.nfam = nfam;
-    a.prio = getenv("PMX_SGM8_FAM_PRIO") ? atoi(getenv("PMX_SGM8_FAM_PRIO")) : 3;  // (0: 14.6 ms per 4096^2 x 257 step, 3: 13.9)
+    const char* eprio = pmx_opt(ctx, "SGM8_FAM_PRIO");
+    a.prio = eprio ? atoi(eprio) : 3;  // (0: 14.6 ms per 4096^2 x 257 step, 3: 13.9)
     a.codes = cv->codes; a.code_bytes = (unsigned)cv->codes_bytes;
     a.codeL_off = (unsigned)(cv->codeL - cv->codes); a.codeR_off = (unsigned)(cv->codeR - cv->codes);
     a.d0 = cv->d0; a.o = cv->win / 2; a.invalid_cost = invalid_cost;

@@ -28,6 +28,38 @@ extern "C" int pmx_device_count(void) {
     return n;
 }
 
+// ---- kernel-route / tuning options ---------------------------------------------------------------------------------------------------
+// Every name the library looks at (DESIGN 7b says what each one forces).  The ONE place the environment is read: pmx_create.
+static const char* const kPmxOptNames[] = {
+    "SGM_SCHED", "SGM_PAR", "SGM_HFUSED", "SGM_PENDING", "SGM_FAM_SHAPE",
+    "SGM8", "FUSED_MAP", "COST5", "WTA3", "SGM8_FAM", "SGM8_HPAIR", "SGM8_CODES", "SGM8_FAMCODES", "SGM8_OVERLAP", "SGM8_HF",
+    "SGM8_FAM_NW", "SGM8_FAM_PRIO",
+    "CBCA_ARMS_FLAT", "CBCA_ROWS", "CBCA_FAST", "CBCA_FUSE", "CBCA_MARCH", "CBCA_VBUF", "CBCA_SIGN", "CBCA_GEO", "CBCA_VBS",
+    "CBCA_ROWDESC", "COMM_OVERLAP",
+};
+static constexpr int kPmxOptCount = (int)(sizeof(kPmxOptNames) / sizeof(kPmxOptNames[0]));
+static_assert(kPmxOptCount <= pmx_ctx::kMaxOpts, "option slots");
+static int opt_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < kPmxOptCount; ++i)
+        if (!strcmp(name, kPmxOptNames[i])) return i;
+    return -1;
+}
+const char* pmx_opt(const pmx_ctx* ctx, const char* name) {
+    const int i = opt_index(name);
+    return (i >= 0 && ctx && ctx->opt_set[i]) ? ctx->opt_val[i].c_str() : nullptr;
+}
+extern "C" int pmx_set_option(pmx_ctx* ctx, const char* name, const char* value) {
+    PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_set_option: null context");
+    const int i = opt_index(name);
+    PMX_CHECK(i >= 0, PMX_ERR_ARG, "pmx_set_option: unknown option '%s'", name ? name : "(null)");
+    ctx->opt_set[i] = value != nullptr;
+    ctx->opt_val[i] = value ? value : "";
+    return PMX_OK;
+}
+extern "C" const char* pmx_get_option(const pmx_ctx* ctx, const char* name) { return pmx_opt(ctx, name); }
+extern "C" const char* pmx_option_name(int index) { return index >= 0 && index < kPmxOptCount ? kPmxOptNames[index] : nullptr; }
+
 extern "C" pmx_ctx* pmx_create(int device) {
     int n = pmx_device_count();
     if (device < 0 || device >= n) {
@@ -44,6 +76,13 @@ extern "C" pmx_ctx* pmx_create(int device) {
         pmx_set_error("pmx_create: hipStreamCreate failed");
         delete ctx;
         return nullptr;
+    }
+    for (int i = 0; i < kPmxOptCount; ++i) {  // the options' start values: PMX_<name> of the environment, read here and nowhere else
+        const std::string var = std::string("PMX_") + kPmxOptNames[i];
+        if (const char* v = getenv(var.c_str())) {
+            ctx->opt_set[i] = true;
+            ctx->opt_val[i] = v;
+        }
     }
     return ctx;
 }
@@ -117,11 +156,6 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     for (hipEvent_t e : ctx->line_ev)
         if (e) hipEventDestroy(e);
     pmx_pool_release(ctx);
-    if (getenv("PMX_DEBUG_PTRS")) {
-        size_t live = 0;
-        for (auto& kv : ctx->pool_live) live += kv.second;
-        fprintf(stderr, "PMX_DESTROY live pool buffers: %zu (%zu MB)\n", ctx->pool_live.size(), live >> 20);
-    }
     for (auto& s : ctx->stages)
         for (auto e : s.ev) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -284,6 +318,60 @@ static float placement_probe_ms(pmx_ctx* ctx, const void* buf, size_t bytes) {
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     return best;
+}
+
+// ---- what plain streaming kernels reach on this device, measured when asked (bench.py: roofline.peak_measured) ------------
+__global__ __launch_bounds__(256) void stream_fill_kernel(uint4* __restrict__ p, size_t n, uint32_t v) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    const uint4 w = make_uint4(v, v + 1u, v + 2u, v + 3u);
+    for (; i < n; i += step) p[i] = w;
+}
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i < n; i += step) dst[i] = src[i];
+}
+
+extern "C" int pmx_measure_hbm(pmx_ctx* ctx, size_t bytes, double* read_gbs, double* write_gbs, double* copy_gbs) {
+    PMX_CHECK(ctx && bytes >= ((size_t)1 << 20), PMX_ERR_ARG, "pmx_measure_hbm: a context and at least 1 MB");
+    PMX_HIP(hipSetDevice(ctx->device));
+    bytes &= ~(size_t)15;
+    void *a = nullptr, *b = nullptr;
+    PMX_HIP(hipMalloc(&a, bytes));
+    if (hipMalloc(&b, bytes) != hipSuccess) {
+        (void)hipFree(a);
+        PMX_CHECK(false, PMX_ERR_HIP, "pmx_measure_hbm: no room for two buffers of %zu bytes", bytes);
+    }
+    if (!ctx->probe_sink && hipMalloc(&ctx->probe_sink, 64) != hipSuccess) ctx->probe_sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const size_t n = bytes / 16;
+    double best[3] = {0, 0, 0};
+    for (int rep = 0; rep < 4; ++rep) {  // (the first pass faults the pages in and is not counted)
+        for (int kind = 0; kind < 3; ++kind) {
+            (void)hipEventRecord(e0, ctx->stream);
+            if (kind == 0) hipLaunchKernelGGL(stream_fill_kernel, dim3(16384), dim3(256), 0, ctx->stream, (uint4*)a, n, (uint32_t)rep);
+            else if (kind == 1) hipLaunchKernelGGL(placement_probe_kernel, dim3(16384), dim3(256), 0, ctx->stream, (const uint4*)a, n, (uint32_t*)ctx->probe_sink);
+            else hipLaunchKernelGGL(stream_copy_kernel, dim3(16384), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n);
+            (void)hipEventRecord(e1, ctx->stream);
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms > 0.f) {
+                const double gbs = (double)bytes * (kind == 2 ? 2.0 : 1.0) / (ms * 1e-3) / 1e9;
+                if (gbs > best[kind]) best[kind] = gbs;
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    PMX_HIP(hipGetLastError());
+    if (write_gbs) *write_gbs = best[0];
+    if (read_gbs) *read_gbs = best[1];
+    if (copy_gbs) *copy_gbs = best[2];
+    return PMX_OK;
 }
 
 static hipError_t placed_alloc(pmx_ctx* ctx, void** out, size_t bytes) {
@@ -1092,6 +1180,19 @@ extern "C" int pmx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max
     rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv));
     if (rc) return rc;
     return pmx_launch_refine(ctx, cv, method, is_max);
+}
+
+extern "C" int pmx_refine_approximate(pmx_ctx* ctx, const pmx_cv* cv_left, int method, int is_max) {
+    int rc = check_cv(ctx, cv_left, "pmx_refine_approximate");
+    if (rc) return rc;
+    PMX_CHECK(method == PMX_REFINE_VFIT || method == PMX_REFINE_QUADRATIC, PMX_ERR_ARG,
+              "pmx_refine_approximate: unknown refinement method %d", method);
+    PMX_CHECK(ctx->disp_ready, PMX_ERR_STATE, "pmx_refine_approximate: no disparity map resident (pmx_set_disparity with the right map first)");
+    rc = pmx_cv_materialize(ctx, const_cast<pmx_cv*>(cv_left));
+    if (rc) return rc;
+    ctx->near_exact = false;
+    ctx->near2_exact = false;
+    return pmx_launch_approx_refine(ctx, cv_left, method, is_max);
 }
 
 extern "C" int pmx_get_disparity(pmx_ctx* ctx, float* disp, int64_t* validity, float* itp) {

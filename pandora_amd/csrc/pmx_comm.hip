@@ -343,7 +343,7 @@ extern "C" int pmx_comm_gather_rows(pmx_ctx* ctx, int root, int with_itp) {
     // the context's stream so far) and whoever touches those maps or the communicator next waits for it (pmx_comm_join) - the
     // kernels of the NEXT pair do neither and run under the transfer.  PMX_COMM_OVERLAP=0: on the context's stream, as a plain
     // sequence.
-    const char* eo = getenv("PMX_COMM_OVERLAP");
+    const char* eo = pmx_opt(ctx, "COMM_OVERLAP");
     const bool overlap = !(eo && eo[0] == '0');
     hipStream_t st = ctx->stream;
     if (overlap) {

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <string>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -126,7 +127,14 @@ struct pmx_ctx {
     int full_H = 0;                    // rows of the whole image in a row-tiled run (pmx_tile_place)
     void* refine_saved[2] = {nullptr, nullptr};  // merged disparity / validity before the owner's refinement
     size_t refine_saved_bytes = 0;
+    // kernel-route / tuning options (pmx_set_option; seeded once from PMX_<name> by pmx_create): slot i belongs to kPmxOptNames[i]
+    static constexpr int kMaxOpts = 48;
+    std::string opt_val[kMaxOpts];
+    bool opt_set[kMaxOpts] = {};
 };
+
+// the value of a route option or nullptr (what getenv("PMX_<name>") used to answer, per context and without the environment)
+const char* pmx_opt(const pmx_ctx* ctx, const char* name);
 
 void pmx_comm_release(pmx_ctx* ctx);  // frees the exchange buffers
 
@@ -280,7 +288,7 @@ int pmx_launch_cv_masked(pmx_ctx* ctx, pmx_cv* cv, int win);
 int pmx_launch_mask_dilate(pmx_ctx* ctx, const int16_t* msk, int H, int W, int win, int valid, int nodata, uint8_t* bad);
 int pmx_launch_fill_nan(pmx_ctx* ctx, float* p, size_t n);
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
-bool pmx_sgm_family_supported(const pmx_cv* cv);
+bool pmx_sgm_family_supported(const pmx_ctx* ctx, const pmx_cv* cv);
 // the six non-horizontal paths of `mask` as two fused marching passes adding into S (which already holds the horizontal ones)
 // fams: bit 0 the downward family, bit 1 the upward one.  wta != nullptr: the upward family (which must be the last pass) does not
 // write S but reduces over D (k_sgmfam.hip WTA mode)
@@ -288,7 +296,7 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
                             int mask, int fams, const pmx_fam_wta* wta);
 int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes);  // hand-off buffer + ticket / error words of the marching kernels
 // integer path as direction families (k_sgmfam8.hip): the vertical families' byte sums into out + f * dstride
-int pmx_fam8_waves(int W);
+int pmx_fam8_waves(const pmx_ctx* ctx, int W);
 bool pmx_fam8_supported(int kpl, int H);
 // The tag a launch's hand-off blocks carry: the launch count scrambled over all 32 bits, top bit set (a zeroed buffer never
 // matches).  A block is taken when its tag word equals the tag (k_sgmfam8.hip) or the tag XOR its payload (k_sgmfam.hip): with
@@ -300,6 +308,7 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
                         int fams, bool from_codes, uint32_t invalid_cost);
 int pmx_launch_wta(pmx_ctx* ctx, const pmx_cv* cv, int is_max, float invalid_disparity);
 int pmx_launch_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
+int pmx_launch_approx_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);
 int pmx_near_select(pmx_ctx* ctx, const pmx_cv* cv, bool for_write);  // the winner cache of `cv` becomes ctx->near (see pmx_api.hip)
 void pmx_near_forget(pmx_ctx* ctx, const pmx_cv* cv);                 // the volume changed: no cache describes it any more
 int pmx_launch_near_refine(pmx_ctx* ctx, const pmx_cv* cv, int method, int is_max);  // from the winner's three values (ctx->near)

@@ -282,10 +282,47 @@ class Engine:
         """Probe up to `trials` candidates for every new volume-sized buffer and keep the fastest (pmx_set_placement_trials)."""
         check(_lib.lib().pmx_set_placement_trials(self.ctx, int(trials)), "pmx_set_placement_trials")
 
+    def measure_hbm(self, nbytes=4 << 30):
+        """GB/s of plain streaming kernels on this device: {"read", "write", "copy"} (pmx_measure_hbm)."""
+        r, w, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        check(_lib.lib().pmx_measure_hbm(self.ctx, int(nbytes), C.byref(r), C.byref(w), C.byref(c)), "pmx_measure_hbm")
+        return {"read": r.value, "write": w.value, "copy": c.value}
+
     def set_lazy(self, on):
         """Lazy exact representations of the volume (default on); off = always float32 (reference-like)."""
         check(_lib.lib().pmx_set_lazy(self.ctx, int(bool(on))), "pmx_set_lazy")
         self.lazy = bool(on)
+
+    def set_option(self, name, value):
+        """Forces a kernel route / tuning choice of this context (include/pandora_amd.h pmx_set_option):
+        name without the PMX_ prefix, value a short string or None to clear.  The library reads its environment once, when the
+        context is created; from then on this is the only way to change a choice."""
+        name = name[4:] if name.startswith("PMX_") else name
+        check(_lib.lib().pmx_set_option(self.ctx, name.encode(), None if value is None else str(value).encode()), "pmx_set_option")
+
+    def get_option(self, name):
+        name = name[4:] if name.startswith("PMX_") else name
+        v = _lib.lib().pmx_get_option(self.ctx, name.encode())
+        return None if v is None else v.decode()
+
+    @staticmethod
+    def option_names():
+        out, i = [], 0
+        while True:
+            n = _lib.lib().pmx_option_name(i)
+            if n is None:
+                return out
+            out.append(n.decode())
+            i += 1
+
+    def options_from_env(self):
+        """Mirrors the PMX_<name> variables of os.environ as they are NOW into this context's options (set or cleared): for scripts
+        that change a route between steps of one process (tools/fuzz_*.py).  The library itself reads the environment only in
+        pmx_create."""
+        import os
+
+        for n in self.option_names():
+            self.set_option(n, os.environ.get("PMX_" + n))
 
     def alloc_cv(self, D, d0):
         h = _lib.lib().pmx_cv_alloc(self.ctx, int(D), int(d0))
@@ -454,6 +491,13 @@ class Engine:
         self.new_maps(superseded)
         m = {"vfit": 0, "quadratic": 1}[method]
         check(_lib.lib().pmx_refine(self.ctx, cv.handle, m, int(bool(is_max))), "pmx_refine")
+
+    def refine_approximate(self, cv_left, method, is_max=False):
+        """pmx_refine_approximate: the resident map as a RIGHT map refined on the left volume's diagonals
+        (refinement_cpp.loop_approximate_refinement)."""
+        self.new_maps()
+        m = {"vfit": 0, "quadratic": 1}[method]
+        check(_lib.lib().pmx_refine_approximate(self.ctx, cv_left.handle, m, int(bool(is_max))), "pmx_refine_approximate")
 
     def get_disparity(self, want_itp=False, out=None):
         """Download disp float32, validity int64 (and interpolated_coeff).  `out` = (disp, validity[, itp]) arrays of

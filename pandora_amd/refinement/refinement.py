@@ -77,6 +77,27 @@ class AbstractRefinement:
         disp["interpolated_coeff"] = DeviceMapArray(eng, "itp", coords=coords)
 
 
+    def approximate_subpixel_refinement(self, cv_left, disp_right):
+        """refinement.py:124-158: the right map of the approximate ("fast") right-side route - a diagonal search of the LEFT cost
+        volume - refined on that volume's diagonals (refinement_cpp.loop_approximate_refinement).  In place on
+        disp_right["disparity_map"] / ["validity_mask"]; adds ["interpolated_coeff"]."""
+        arr = cv_left["cost_volume"]
+        if not hasattr(arr, "device_cv"):
+            raise TypeError("approximate_subpixel_refinement needs a device-resident cost volume (pandora_amd has no CPU path)")
+        dcv = arr.device_cv
+        eng = dcv.engine
+        is_max = cv_left.attrs["type_measure"] == "max"
+        dm, vm = disp_right["disparity_map"], disp_right["validity_mask"]
+        coords = {k: disp_right.coords[k] for k in ("row", "col") if k in disp_right.coords}
+        eng.set_disparity(np.asarray(dm.data, np.float32), np.asarray(vm.data, np.int64))
+        eng.refine_approximate(dcv, self._refinement_method_name, is_max)
+        disp_right["disparity_map"] = DeviceMapArray(eng, "disp", coords=coords)
+        disp_right["validity_mask"] = DeviceMapArray(eng, "validity", coords=coords)
+        disp_right.attrs["refinement"] = self._refinement_method_name
+        disp_right["interpolated_coeff"] = DeviceMapArray(eng, "itp", coords=coords)
+        return disp_right
+
+
 def _simple_conf(name):
     def check_conf(**cfg):
         if cfg.get("refinement_method") != name:

@@ -19,3 +19,31 @@ def oracle():
 
     capi.lib()
     return capi
+
+
+class EngineHooks:
+    """Kernel-route options of ONE engine for the duration of a test (pmx_set_option; the library reads its environment once, at
+    pmx_create, so a test that wants a route on a long-lived engine sets the option on it).  Same call shape as monkeypatch:
+    setenv("PMX_SGM8_FAM", "1") / delenv("PMX_SGM8_FAM"); everything set is cleared again at the end of the test."""
+
+    def __init__(self, eng):
+        self.eng, self.names = eng, set()
+
+    def setenv(self, name, value):
+        self.eng.set_option(name, value)
+        self.names.add(name)
+
+    def delenv(self, name, raising=False):
+        self.eng.set_option(name, None)
+
+    def undo(self):
+        for n in self.names:
+            self.eng.set_option(n, None)
+        self.names.clear()
+
+
+@pytest.fixture
+def hooks(eng):
+    h = EngineHooks(eng)
+    yield h
+    h.undo()

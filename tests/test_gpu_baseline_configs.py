@@ -59,7 +59,7 @@ def maps(eng, cv, is_max):
     return eng.get_disparity(want_itp=True)
 
 
-def check_config(eng, oracle, monkeypatch, H, W, dmin, dmax, kind, shift):
+def check_config(eng, oracle, hooks, H, W, dmin, dmax, kind, shift):
     D = dmax - dmin + 1
     is_max = kind == "zncc11"
     inv = 2.0 if is_max else 26.0
@@ -67,7 +67,7 @@ def check_config(eng, oracle, monkeypatch, H, W, dmin, dmax, kind, shift):
     eng.set_images(L, R, 1)
     cv = eng.alloc_cv(D, dmin)
     # ---- every path family against the oracle on the strip where the oracle can know the answer
-    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    hooks.setenv("PMX_SGM_SCHED", "fam")
     for mask, rows in ((0x03, (H // 2, H // 2 + STRIP)), (0x03, (H - STRIP, H)), (0x1C, (0, STRIP)), (0xE0, (H - STRIP, H))):
         costs(eng, cv, kind)
         strip_costs = cv.rows_to_host(*rows)
@@ -78,12 +78,12 @@ def check_config(eng, oracle, monkeypatch, H, W, dmin, dmax, kind, shift):
     # ---- the whole pipeline as BASELINE states it, both float32 schedules
     out = {}
     for sched in ("fam", "seq"):
-        monkeypatch.setenv("PMX_SGM_SCHED", sched)
+        hooks.setenv("PMX_SGM_SCHED", sched)
         costs(eng, cv, kind)
         eng.sgm(cv, P1, P2, is_max, inv, False)
         out[sched] = maps(eng, cv, is_max)
     # lazy mode: the upward family runs fused with the WTA, the optimised volume is never written
-    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    hooks.setenv("PMX_SGM_SCHED", "fam")
     eng.set_lazy(True)
     costs(eng, cv, kind)
     eng.sgm(cv, P1, P2, is_max, inv, False)
@@ -110,13 +110,13 @@ def check_config(eng, oracle, monkeypatch, H, W, dmin, dmax, kind, shift):
     assert (np.abs(inner - shift) <= 1).mean() > 0.9, (np.abs(inner - shift) <= 1).mean()
 
 
-def test_c4_zncc11_sgm_wta_vfit_at_4096(eng, oracle, monkeypatch):
-    check_config(eng, oracle, monkeypatch, 4096, 4096, 0, 256, "zncc11", 9)
+def test_c4_zncc11_sgm_wta_vfit_at_4096(eng, oracle, hooks):
+    check_config(eng, oracle, hooks, 4096, 4096, 0, 256, "zncc11", 9)
 
 
-def test_c5_census_cbca_sgm_wta_vfit_at_10000(eng, oracle, monkeypatch):
+def test_c5_census_cbca_sgm_wta_vfit_at_10000(eng, oracle, hooks):
     try:
-        check_config(eng, oracle, monkeypatch, 10000, 10000, -64, 64, "census+cbca", 7)
+        check_config(eng, oracle, hooks, 10000, 10000, -64, 64, "census+cbca", 7)
     except RuntimeError as err:
         if "memory" in str(err).lower():
             pytest.skip(f"two 51.6 GB volumes do not fit this device: {err}")
@@ -197,10 +197,13 @@ def test_c5_row_tiles_of_1200_rows_over_two_ranks(tmp_path):
     untiled run (the reference's ROI convention: paths are cut at the margin, so a seam may differ on a few pixels)."""
     script = tmp_path / "bigtiles.py"
     script.write_text(TILED % {"root": ROOT})
+    import bench
+
+    port = str(bench._free_port_pair())  # (a fixed port collides with whatever else runs on the box)
     procs = []
     for rank in range(2):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PANDORA_AMD_DEVICE="0", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29551")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
     outs = [p.communicate(timeout=900) for p in procs]
     assert "BIG_TILED_OK" in outs[0][0], "".join(o[0][-2000:] + o[1][-4000:] for o in outs)

@@ -101,7 +101,7 @@ def test_launcher_fails_fast_when_a_rank_dies():
     t0 = time.time()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "300",
                           "--width", "256", "--dmax", "40", "--placement-trials", "1", "--no-dshard", "--no-weak", "--no-c5tiled",
-                          "--test-comm", "tests.transports:TcpComm", "--test-device", "0", "--test-die-rank", "1"],
+                          "--no-c4tiled", "--test-comm", "tests.transports:TcpComm", "--test-device", "0", "--test-die-rank", "1"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     took = time.time() - t0
     # (rank 0 may itself fail on the closed connection before the launcher looks: the code is the first named rank's)
@@ -116,11 +116,21 @@ def test_launcher_runs_its_own_ranks_to_the_end():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "300",
                           "--width", "256", "--dmax", "40", "--placement-trials", "1", "--no-dshard", "--no-weak", "--no-c5tiled",
-                          "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
+                          "--c4-height", "400", "--c4-width", "320", "--c4-dmax", "40", "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-1500:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, out.stdout
+    # BASELINE configs[3]'s pipeline WITH its SGM step over the ranks' row tiles (ZNCC 11x11 + SGM + WTA + vfit; d = [0, 40] here): the leg is
+    # in the line, and what the two tiles gathered is the one-GPU result except near the seam (SGM paths cut at the 40-row margin)
+    d = json.loads(lines[0])
+    assert "leg_errors" not in d, d.get("leg_errors")
+    c4 = d["c4_row_tiled"]
+    assert "ZNCC 11x11 + SGM" in c4["workload"] and c4["ms_per_step"] > 0 and c4["stage_ms_per_step_rank0"]["zncc"] > 0
+    # (float costs: a tile's sums differ from the whole image's in their last bits, the refined disparity with them; the winner and the
+    # disparity to 0.01 px are what the tiling keeps)
+    g = c4["gathered_maps_vs_one_gpu"]
+    assert g["winner_identical"] > 0.95 and g["disparity_within_0.01"] > 0.7 and g["validity_identical"] > 0.97, g  # (tiles of 200 rows: half the image is within a margin of the seam)
 
 
 def test_bench_prices_the_integer_route_against_its_own_format():
@@ -136,3 +146,7 @@ def test_bench_prices_the_integer_route_against_its_own_format():
     # D = 41: KPL 4, 11 lanes: Dp = 44 bytes, Dc = 11 dwords = 44 bytes per pixel -> (2 * 44 + 6 * 44) / 41
     assert abs(d["own_format_bytes_per_cell"] - (2 * 44 + 6 * 44) / 41) < 1e-3
     assert d["roofline"]["traffic"] is None and "traffic_amplification" not in d
+    # what plain streams reach on this box, measured in the same run, beside the data sheet's peak
+    r = d["roofline"]
+    assert r["peak"] == 8000.0 and 2000.0 < r["peak_measured"] < 8000.0 and set(r["peak_measured_streams"]) == {"read", "write", "copy"}
+    assert abs(r["frac_of_measured"] - r["achieved"] / r["peak_measured"]) < 1e-3

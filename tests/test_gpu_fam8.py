@@ -23,9 +23,9 @@ def eng():
 
 
 @pytest.fixture
-def forced_families(monkeypatch):
-    monkeypatch.setenv("PMX_SGM8_FAM", "1")
-    yield monkeypatch
+def forced_families(hooks):
+    hooks.setenv("PMX_SGM8_FAM", "1")
+    yield hooks
 
 
 def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
@@ -135,10 +135,7 @@ def _family_against_eight_volumes(eng, synthetic_pair, H, W, dmin, dmax):
     L, R = synthetic_pair(H, W, dmin, dmax, seed=5)
     maps = {}
     for mode in ("0", "auto"):
-        if mode == "auto":
-            os.environ.pop("PMX_SGM8_FAM", None)
-        else:
-            os.environ["PMX_SGM8_FAM"] = mode
+        eng.set_option("SGM8_FAM", None if mode == "auto" else mode)
         try:
             eng.set_images(L, R, 1)
             cv = eng.alloc_cv(dmax - dmin + 1, dmin)
@@ -153,7 +150,7 @@ def _family_against_eight_volumes(eng, synthetic_pair, H, W, dmin, dmax):
                     eng.debug_path_costs(cv, raw=True)
             cv.free()
         finally:
-            os.environ.pop("PMX_SGM8_FAM", None)
+            eng.set_option("SGM8_FAM", None)
     for a, b in zip(maps["0"], maps["auto"]):
         np.testing.assert_array_equal(a, b)
 

@@ -117,6 +117,71 @@ def test_loop_refinement_like_the_reference_module(face, oracle, method, measure
         face.loop_refinement(cv, disp, mask, float(dmin), float(dmax), subpix, measure, lambda c, d, m: (0.0, 0.0, 0), 963, 8)
 
 
+def _approx_restated(cv, disp, mask, dmin, dmax, subpix, measure, fn):
+    """refinement/cpp/src/refinement.cpp:103-182 in python loops (the unchecked indices as flat offsets of the contiguous volume)"""
+    H, W, D = cv.shape
+    flat = cv.reshape(-1)
+    itp = np.empty((H, W), np.float32)
+    disp, mask = disp.copy(), mask.copy()
+    for r in range(H):
+        for c in range(W):
+            if mask[r, c] & 963:
+                itp[r, c] = np.nan
+                continue
+            raw = np.float32(disp[r, c])
+            dsp = int((-float(raw) - dmin) * subpix)
+            diag = int(np.float32(c) + raw)
+            at = (r * W + diag) * D + dsp
+            c1 = flat[at]
+            if np.isnan(c1):
+                itp[r, c] = c1
+                continue
+            if raw == dmin or raw == dmax or diag == 0 or diag == W - 1:
+                itp[r, c] = c1
+                mask[r, c] += 8
+                continue
+            x, y, v = fn(np.array([flat[at - D + subpix], c1, flat[at + D - subpix]], np.float32), raw, measure, 8)
+            disp[r, c] = raw + np.float32(x) / np.float32(subpix)
+            itp[r, c] = y
+            mask[r, c] += v
+    return itp, disp, mask
+
+
+@pytest.mark.parametrize("method", ["vfit", "quadratic"])
+@pytest.mark.parametrize("measure,subpix,dmin,dmax", [("min", 1, -4, 3), ("max", 2, -2, 5), ("min", 4, 0, 3), ("min", 1, -6, -1)])
+def test_loop_approximate_refinement_like_the_reference_module(face, method, measure, subpix, dmin, dmax):
+    """refinement_cpp.loop_approximate_refinement (refinement_cpp.pyi:82-122): a right map (disparities in [-dmax, -dmin], every
+    pixel's diagonal inside the image, some pixels invalid) refined on the left volume - against the reference's compiled module where
+    it is built (oracle/_ref) and against the restatement above; asymmetric ranges reach the neighbouring pixel's run of the volume
+    exactly as the reference's unchecked indices do."""
+    H, W = 19, 27
+    D = (dmax - dmin) * subpix + 1
+    rng = np.random.default_rng(D + subpix)
+    cv = rng.integers(0, 9, (H, W, D)).astype(np.float32)
+    cv[rng.random(cv.shape) < 0.1] = np.nan
+    disp = (-(dmin + rng.integers(0, D, (H, W)) / subpix)).astype(np.float32)  # right disparities, on the volume's grid
+    mask = np.zeros((H, W), np.int64)
+    diag = (np.arange(W, dtype=np.float32)[None, :] + disp).astype(np.int64)
+    mask[(diag < 0) | (diag >= W)] = 1 << 1  # (the reference would read outside the volume there)
+    mask[rng.random((H, W)) < 0.05] |= 1
+    mask[rng.random((H, W)) < 0.05] |= 4  # (an information bit: refined all the same)
+    fn = getattr(face, f"{method}_refinement_method")
+    itp, d2, m2 = face.loop_approximate_refinement(cv, disp.copy(), mask.copy(), float(dmin), float(dmax), subpix, measure,
+                                                   lambda cost, d, meas: fn(cost, d, meas, 8), 963, 8)
+    eitp, ed, em = _approx_restated(cv, disp, mask, dmin, dmax, subpix, measure, fn)
+    np.testing.assert_array_equal(itp, eitp)
+    np.testing.assert_array_equal(d2, ed)
+    np.testing.assert_array_equal(m2, em)
+    rf = _ref("refinement_cpp")
+    if rf is not None:
+        rfn = getattr(rf, f"{method}_refinement_method")
+        ritp, rd, rm = rf.loop_approximate_refinement(cv, disp.copy(), mask.copy(), float(dmin), float(dmax), subpix, measure,
+                                                      lambda cost, d, meas: rfn(cost, d, meas, 8), 963, 8)
+        np.testing.assert_array_equal(itp, ritp)
+        np.testing.assert_array_equal(d2, rd)
+        np.testing.assert_array_equal(m2, rm)
+
+
 NAN = np.nan
 
 

@@ -269,11 +269,11 @@ def test_cbca(eng, oracle, H, W, dmin, dmax, sp, win, method, integer):
 
 @pytest.mark.parametrize("distance", [1, 2, 3, 5, 6, 7, 10, 11, 17, 18, 19, 26])
 @pytest.mark.parametrize("loop_form", [False, True])
-def test_cross_support_arm_lengths_both_forms(eng, oracle, monkeypatch, distance, loop_form):
+def test_cross_support_arm_lengths_both_forms(eng, oracle, hooks, distance, loop_form):
     """aggregation.cpp:224-321: arms by the branch-free kernel (distance <= 18) and by the loop kernel, smooth images so that the
     arms reach their limit, masked pixels, +-inf and huge values among the neighbours, every border."""
     if loop_form:
-        monkeypatch.setenv("PMX_CBCA_ARMS_FLAT", "0")
+        hooks.setenv("PMX_CBCA_ARMS_FLAT", "0")
     rng = np.random.default_rng(distance)
     H, W = 37, 300
     yy, xx = np.mgrid[0:H, 0:W]
@@ -459,7 +459,7 @@ def test_variable_disparity_ranges_stay_on_the_integer_path(eng, oracle, with_ma
 
 
 @pytest.mark.parametrize("is_max,P1,P2", [(False, 8.0, 32.0), (True, 0.3, 1.7)])
-def test_float_sgm_schedules_agree(eng, oracle, monkeypatch, is_max, P1, P2):
+def test_float_sgm_schedules_agree(eng, oracle, hooks, is_max, P1, P2):
     """The float32 SGM runs its eight directions one after the other (large volumes) or side by side with an ordered sum
     (small ones): both schedules (PMX_SGM_PAR=0 / 1) give the oracle's bits, overcounting and "max" measures included."""
     rng = np.random.default_rng(30)
@@ -472,7 +472,7 @@ def test_float_sgm_schedules_agree(eng, oracle, monkeypatch, is_max, P1, P2):
     for over in (False, True):
         exp = oracle.sgm(cvh, P1, P2, is_max, 45.0, over)
         for mode in ("0", "1"):
-            monkeypatch.setenv("PMX_SGM_PAR", mode)
+            hooks.setenv("PMX_SGM_PAR", mode)
             cv = eng.alloc_cv(D, -9)
             cv.from_host(cvh)
             eng.sgm(cv, P1, P2, is_max, 45.0, over)
@@ -634,13 +634,13 @@ def test_full_size_properties(eng, oracle):
     (16, 16, -120, 120), (16, 17, 0, 256), (16, 20, -150, 150),
     (8, 8, -30, 30), (8, 9, -40, 26), (8, 12, -60, 30), (8, 13, 0, 100), (8, 16, -63, 63), (8, 17, 0, 128), (8, 17, -64, 64),
     (8, 20, -100, 50), (4, 16, -60, 0), (4, 17, 0, 64), (4, 20, -70, 5)])
-def test_fused_lane_maps(eng, oracle, monkeypatch, gl, kpl, dmin, dmax):
+def test_fused_lane_maps(eng, oracle, hooks, gl, kpl, dmin, dmax):
     """Every (lanes per scanline) x (disparities per lane) instantiation of the fused census->SGM kernel and of
     its WTA consumer, forced through PMX_FUSED_MAP on a small pair (the automatic choice would always take the
     widest group here): path costs, WTA, refinement and materialisation must equal the oracle bit for bit."""
     if not eng.lazy:
         pytest.skip("fused kernels only exist on the lazy path")
-    monkeypatch.setenv("PMX_FUSED_MAP", f"{gl}x{kpl}")
+    hooks.setenv("PMX_FUSED_MAP", f"{gl}x{kpl}")
     H, W, win = 21, 83, 5
     D = dmax - dmin + 1
     assert gl * kpl > D
@@ -669,14 +669,14 @@ def test_fused_lane_maps(eng, oracle, monkeypatch, gl, kpl, dmin, dmax):
 
 @pytest.mark.parametrize("sgm8", ["1", "bytes", "0"])
 @pytest.mark.parametrize("win,dmin,dmax", [(5, -20, 6), (7, -70, 30), (5, 0, 128), (3, -200, 50), (5, -150, 150)])
-def test_packed_and_popcount_fused_kernels_agree_with_the_oracle(eng, oracle, monkeypatch, sgm8, win, dmin, dmax):
+def test_packed_and_popcount_fused_kernels_agree_with_the_oracle(eng, oracle, hooks, sgm8, win, dmin, dmax):
     """The default integer path (k_sgm8.hip: packed 16-bit recurrence on five-bit costs for windows up to 5x5, on byte
     costs otherwise or with PMX_COST5=0; KPL 4..20, one- and two-word census codes) and the popcount-fused kernel behind
     PMX_SGM8=0 (k_fused.hip), all against the oracle pipeline."""
     if not eng.lazy:
         pytest.skip("fused kernels only exist on the lazy path")
-    monkeypatch.setenv("PMX_SGM8", "0" if sgm8 == "0" else "1")
-    monkeypatch.setenv("PMX_COST5", "0" if sgm8 == "bytes" else "1")
+    hooks.setenv("PMX_SGM8", "0" if sgm8 == "0" else "1")
+    hooks.setenv("PMX_COST5", "0" if sgm8 == "bytes" else "1")
     H, W = 19, 70
     D = dmax - dmin + 1
     L, R = pair(H, W, seed=win + D, shift=-2)
@@ -1103,12 +1103,12 @@ def test_interval_bounds_reference_vector(eng):
 
 @pytest.mark.parametrize("fast", ["1", "4", "0"])
 @pytest.mark.parametrize("H,W,dmin,dmax,sp,dist", [(70, 150, -12, 5, 1, 5), (45, 90, -4, 3, 2, 9), (40, 61, 0, 9, 1, 2)])
-def test_cbca_phase_split_and_generic_kernels(eng, oracle, monkeypatch, fast, H, W, dmin, dmax, sp, dist):
+def test_cbca_phase_split_and_generic_kernels(eng, oracle, hooks, fast, H, W, dmin, dmax, sp, dist):
     """CBCA on images large enough for the phase-split kernels (warm-up / steady / drain, four steps in flight), with
     PMX_CBCA_FAST=4 through the in-place four-disparities-per-thread kernels (subpix 1, short arms; else phase-split) and,
     with PMX_CBCA_FAST=0, through the generic ones: all bit-exact against the reference-pinned oracle (sequential fp32
     prefix sums), with masks, sub-pixel volumes, long arms."""
-    monkeypatch.setenv("PMX_CBCA_FAST", fast)
+    hooks.setenv("PMX_CBCA_FAST", fast)
     L, R = pair(H, W, seed=H + dist, integer=True)
     rng = np.random.default_rng(dist)
     mskL = rng.choice([0, 0, 0, 0, 0, 0, 1], (H, W)).astype(np.int16)
@@ -1139,7 +1139,7 @@ def test_cbca_phase_split_and_generic_kernels(eng, oracle, monkeypatch, fast, H,
     (70, 150, -12, 5, 5, False, False), (41, 67, 0, 60, 5, True, False), (45, 91, -30, 3, 3, True, True),
     (40, 203, -64, 64, 5, False, True), (38, 77, -5, 4, 9, False, False), (33, 52, -3, 3, 2, True, False),
     (60, 120, -64, 64, 12, False, False), (70, 110, -5, 4, 24, False, False), (80, 110, -3, 2, 32, True, False)])
-def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, vbuf, H, W, dmin, dmax, dist, with_grids, with_left_mask):
+def test_cbca_whole_rows_and_census_source(eng, oracle, hooks, rows, vbuf, H, W, dmin, dmax, dist, with_grids, with_left_mask):
     """Census + CBCA without a right mask: in lazy mode the census costs are still implicit (codes) when pmx_cbca runs, and pass H
     computes them on the fly - with the per-pixel valid intervals of cv_masked when grids / a left mask are resident - so the
     float volume first exists as the aggregated one (its border cells NaN); in eager mode the same whole-row pass H reads the
@@ -1148,11 +1148,11 @@ def test_cbca_whole_rows_and_census_source(eng, oracle, monkeypatch, rows, vbuf,
     columns at D = 129 need a 64-slot ring (the rows per workgroup follow the LDS); cbca_distance 24 and 32 need 128 slots and run
     through the generic kernels with 64-thread workgroups (they used to fail at launch: 256 KB of LDS)."""
     if rows:
-        monkeypatch.setenv("PMX_CBCA_ROWS", rows)
-    monkeypatch.setenv("PMX_CBCA_MARCH", "0")  # (plain census geometry with short arms would take the one-kernel route: test_cbca_census_march)
-    monkeypatch.setenv("PMX_CBCA_VBUF", vbuf)  # pass V with pointers (what small volumes get) / through buffer instructions (large ones)
+        hooks.setenv("PMX_CBCA_ROWS", rows)
+    hooks.setenv("PMX_CBCA_MARCH", "0")  # (plain census geometry with short arms would take the one-kernel route: test_cbca_census_march)
+    hooks.setenv("PMX_CBCA_VBUF", vbuf)  # pass V with pointers (what small volumes get) / through buffer instructions (large ones)
     if rows == "3":
-        monkeypatch.setenv("PMX_CBCA_VBS", "512")  # ... in the 512-thread workgroups the largest volumes get
+        hooks.setenv("PMX_CBCA_VBS", "512")  # ... in the 512-thread workgroups the largest volumes get
     L, R = pair(H, W, seed=H + W + dist, integer=True)
     rng = np.random.default_rng(H * dist)
     win, off = 5, 2
@@ -1275,14 +1275,14 @@ def test_sgm_with_penalty_maps(eng, oracle, H, W, dmin, dmax, method, win):
     invalid_cost = float(win * win + 1) if method == "census" else float(np.nanmax(np.abs(ocv)) + 1)
     exp = oracle.sgm_p2maps(ocv, 4.5, maps, is_max, invalid_cost, False)
     for sched in ("par", "seq"):
-        os.environ["PMX_SGM_SCHED"] = sched
+        eng.set_option("SGM_SCHED", sched)
         try:
             cv = gpu_cv(eng, method, L, R, dmin, dmax, 1, win)
             eng.sgm_p2maps(cv, 4.5, maps, is_max, invalid_cost, False)
             np.testing.assert_array_equal(cv.to_host(), exp)
             cv.free()
         finally:
-            del os.environ["PMX_SGM_SCHED"]
+            eng.set_option("SGM_SCHED", None)
     cv = gpu_cv(eng, method, L, R, dmin, dmax, 1, win)
     eng.sgm_p2maps(cv, 4.5, np.full((8, H, W), 31.0, np.float32), is_max, invalid_cost, True)
     np.testing.assert_array_equal(cv.to_host(), oracle.sgm(ocv, 4.5, 31.0, is_max, invalid_cost, True))

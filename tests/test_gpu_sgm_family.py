@@ -68,55 +68,55 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("H,W,D,lanes", SHAPES)
-def test_family_schedule_equals_oracle(eng, oracle, monkeypatch, H, W, D, lanes):
+def test_family_schedule_equals_oracle(eng, oracle, hooks, H, W, D, lanes):
     rng = np.random.default_rng(H * 1000 + W)
     cvh = volume(rng, H, W, D)
     exp = oracle.sgm(cvh, 1.5, 7.25, False, 45.0, False)
-    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    hooks.setenv("PMX_SGM_SCHED", "fam")
     if lanes:
-        monkeypatch.setenv("PMX_SGM_FAM_SHAPE", lanes)
+        hooks.setenv("PMX_SGM_FAM_SHAPE", lanes)
     np.testing.assert_array_equal(run(eng, cvh, 1.5, 7.25, False, 45.0, False), exp)
 
 
 @pytest.mark.parametrize("is_max,over", [(False, True), (True, False), (True, True)])
-def test_family_schedule_max_measures_and_overcounting(eng, oracle, monkeypatch, is_max, over):
+def test_family_schedule_max_measures_and_overcounting(eng, oracle, hooks, is_max, over):
     rng = np.random.default_rng(5)
     cvh = volume(rng, 31, 77, 129, is_max)
     exp = oracle.sgm(cvh, 0.3, 1.7, is_max, 45.0, over)
     for sched in ("seq", "par", "fam"):
-        monkeypatch.setenv("PMX_SGM_SCHED", sched)
+        hooks.setenv("PMX_SGM_SCHED", sched)
         np.testing.assert_array_equal(run(eng, cvh, 0.3, 1.7, is_max, 45.0, over), exp)
 
 
 @pytest.mark.parametrize("mask", [0x01, 0x02, 0x03, 0x04, 0x08, 0x10, 0x1C, 0x20, 0x40, 0x80, 0xE0, 0xFC, 0x5A, 0xA5, 0x1F])
-def test_direction_masks_every_schedule(eng, oracle, monkeypatch, mask):
+def test_direction_masks_every_schedule(eng, oracle, hooks, mask):
     """pmx_debug_sgm_directions: any subset of the eight paths, same bits from every schedule (the first path of a subset starts the
     sum, the last one applies the epilogue, whatever kernel it runs in)."""
     rng = np.random.default_rng(mask)
     cvh = volume(rng, 27, 53, 129)
     exp = oracle.sgm(cvh, 2.5, 9.0, False, 45.0, False, dir_mask=mask)
     for sched in ("seq", "par", "fam"):
-        monkeypatch.setenv("PMX_SGM_SCHED", sched)
+        hooks.setenv("PMX_SGM_SCHED", sched)
         np.testing.assert_array_equal(run(eng, cvh, 2.5, 9.0, False, 45.0, False, mask), exp)
 
 
-def test_family_schedule_many_windows(eng, oracle, monkeypatch):
+def test_family_schedule_many_windows(eng, oracle, hooks):
     """Wide enough for 8 compute waves per workgroup (32-column windows) and hundreds of windows in flight: the hand-off chain is
     as long as at full size.  Integer costs keep the oracle fast; the result must still be exact."""
     rng = np.random.default_rng(77)
     H, W, D = 96, 7200, 33
     cvh = rng.integers(0, 30, (H, W, D)).astype(np.float32)
     exp = oracle.sgm(cvh, 8.0, 32.0, False, 45.0, False)
-    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    hooks.setenv("PMX_SGM_SCHED", "fam")
     np.testing.assert_array_equal(run(eng, cvh, 8.0, 32.0, False, 45.0, False), exp)  # the library's choice: 16 x 3, 8 waves
-    monkeypatch.setenv("PMX_SGM_FAM_SHAPE", "32,3,4")                                  # 8-column windows: 900 of them
+    hooks.setenv("PMX_SGM_FAM_SHAPE", "32,3,4")                                  # 8-column windows: 900 of them
     np.testing.assert_array_equal(run(eng, cvh, 8.0, 32.0, False, 45.0, False), exp)
 
 
-def test_family_schedule_repeated_launches(eng, oracle, monkeypatch):
+def test_family_schedule_repeated_launches(eng, oracle, hooks):
     """The hand-off buffer is recycled from launch to launch (tags = launch epochs): a second and third volume through the same
     context must not see the first one's granules."""
-    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    hooks.setenv("PMX_SGM_SCHED", "fam")
     for seed in (1, 2, 3):
         rng = np.random.default_rng(seed)
         cvh = volume(rng, 45, 200, 129)
@@ -125,18 +125,18 @@ def test_family_schedule_repeated_launches(eng, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("H,W,D", [(20, 64, 129), (9, 37, 257), (5, 8, 60), (3, 7, 30), (6, 131, 384)])
-def test_fused_horizontal_pair_equals_the_two_line_passes(eng, oracle, monkeypatch, H, W, D):
+def test_fused_horizontal_pair_equals_the_two_line_passes(eng, oracle, hooks, H, W, D):
     """The family schedule runs (0,+1) and (0,-1) as a checkpoint pass + a backward pass that re-computes the forward path segment by
     segment (k_sgm.hip): same bits as the oracle and as the two separate line passes (PMX_SGM_HFUSED=0); widths that are / are not
     multiples of the 8-column segment, narrower than one segment, max / overcounting epilogue in the backward kernel."""
     rng = np.random.default_rng(W)
-    monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    hooks.setenv("PMX_SGM_SCHED", "fam")
     for is_max, over in ((False, False), (True, True)):
         cvh = volume(rng, H, W, D, is_max)
         for mask in (0x03, 0xFF):
             exp = oracle.sgm(cvh, 1.25, 6.5, is_max, 45.0, over, dir_mask=mask)
             for fused in ("1", "0"):
-                monkeypatch.setenv("PMX_SGM_HFUSED", fused)
+                hooks.setenv("PMX_SGM_HFUSED", fused)
                 np.testing.assert_array_equal(run(eng, cvh, 1.25, 6.5, is_max, 45.0, over, mask), exp)
 
 

@@ -40,7 +40,7 @@ for name in args.names:
     eng.set_images(L, R, 1)
     cv = eng.alloc_cv(D, dmin)
     for sched, mask in [(s_, int(m_, 0)) for s_ in args.sched.split(",") for m_ in args.masks.split(",")]:
-        os.environ["PMX_SGM_SCHED"] = sched
+        eng.set_option("SGM_SCHED", sched)
         eng.census(cv, 5)
         eng.sgm(cv, 8.0, 32.0, False, 26.0, False, dir_mask=mask)  # warm-up: allocations, hand-off buffer
         eng.sync()

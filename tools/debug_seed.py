@@ -49,7 +49,7 @@ if "optimization" in cfg["pipeline"]:
     print("cmax", cmax, "invalid", np.float32(cmax + 1.0), "NaN cells", int(np.isnan(vol).sum()), "of", vol.size)
     dcv = machine.left_cv["cost_volume"].device_cv
     for sched in ("seq", "par"):
-        os.environ["PMX_SGM_SCHED"] = sched
+        eng.set_option("SGM_SCHED", sched)
         for k in range(8):
             dcv.from_host(vol)
             eng.sgm(dcv, P1, P2, False, cmax + 1.0, False, dir_mask=1 << k)
@@ -58,7 +58,7 @@ if "optimization" in cfg["pipeline"]:
             bad = ~((g == e) | (np.isnan(g) & np.isnan(e)))
             print(sched, "dir", k, "mismatches", int(bad.sum()), [(tuple(int(x) for x in i), float(g[tuple(i)]), float(e[tuple(i)])) for i in np.argwhere(bad)[:3]])
     for sched in ("seq", "par"):
-        os.environ["PMX_SGM_SCHED"] = sched
+        eng.set_option("SGM_SCHED", sched)
         for mask in (0xFF, 0x03, 0x1C, 0xE0, 0xFC, 0x1F):
             dcv.from_host(vol)
             eng.sgm(dcv, P1, P2, False, cmax + 1.0, False, dir_mask=mask)

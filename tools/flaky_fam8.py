@@ -45,6 +45,7 @@ for label, env in routes:
     for k in ("PMX_SGM8_HPAIR", "PMX_SGM8_CODES", "PMX_SGM8_FAMCODES"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    eng.options_from_env()  # (the library reads its environment once, at pmx_create)
     bad = []
     for it in range(runs):
         for c in cases:

@@ -49,6 +49,7 @@ def main():
                 os.environ[k] = str(v)
             else:
                 os.environ.pop(k, None)
+        eng.options_from_env()  # (the library reads its environment once, at pmx_create)
         base = rng.integers(0, 256, (H, W + 8)).astype(np.float32)
         base = np.floor((base + np.roll(base, 1, 1) + np.roll(base, 1, 0)) / 3.0)
         L = base[:, 4:4 + W].copy()
