@@ -34,8 +34,8 @@
 #include "pmx_internal.h"
 
 
-#ifndef PMX_FAM8_TS
-#define PMX_FAM8_TS 0
+#ifndef PMX_FAM8_KA
+#define PMX_FAM8_KA 1  // rows of look-ahead of the consumer wavefront's record loads (A/B: tools/build_variant.sh ka1 k_sgmfam8.hip -DPMX_FAM8_KA=1)
 #endif
 
 namespace {
@@ -86,18 +86,7 @@ struct fam8_args {
     unsigned codeL_off, codeR_off;  // dword index of pixel (0, 0) of the left / right code image in it
     int d0, o;              // first disparity, half census window (cells whose windows leave an image carry invalid_cost)
     uint32_t invalid_cost;
-#if PMX_FAM8_TS
-    unsigned* ts;           // timing experiment (tools/build_variant.sh ... -DPMX_FAM8_TS=1): cycle stamps of one window's wavefronts
-#endif
 };
-#if PMX_FAM8_TS
-constexpr int kTsRow0 = 1000, kTsRows = 32, kTsWin = 60;
-#define PMX_TS(ROW, K) do { if (ts_on && (ROW) >= kTsRow0 && (ROW) < kTsRow0 + kTsRows) a.ts[((wave * kTsRows) + ((ROW) - kTsRow0)) * 8 + (K)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#define PMX_TSV(ROW, K, V) do { if (ts_on && (ROW) >= kTsRow0 && (ROW) < kTsRow0 + kTsRows) a.ts[((wave * kTsRows) + ((ROW) - kTsRow0)) * 8 + (K)] = (unsigned)(V); } while (0)
-#else
-#define PMX_TS(ROW, K) do {} while (0)
-#define PMX_TSV(ROW, K, V) do {} while (0)
-#endif
 
 // One path, one pixel per 16-lane row: new path costs (nA, nB) from the predecessor's (A, B, M); returns the packed minimum of the
 // lane's new costs (both halves still to be reduced).
@@ -147,8 +136,11 @@ __device__ __forceinline__ void group_min3(uint32_t& a, uint32_t& b, uint32_t& c
 // times, copy g shifted by g words, so that the 16-byte reads of a lane of pixel group g are aligned (an unaligned ds_read_b128
 // is replayed at 64 cycles) - and every lane reads its KPL words and the pixel's left word where the old form read NDW cost
 // dwords from memory: v_xor, v_bcnt (whose addend is the pad of a disparity >= D), v_lshl_or per pair of cells.
+// hand-off blocks per lane of a (row, border) record: 3 vectors of 8 Q blocks + the minima, 64 to a wavefront
+constexpr int fam8_nq(int kpl) { return (3 * 8 * (kpl / 4) + 2 + 63) / 64; }
+
 template <int KPL, int CBITS, int NW, int PF, bool CODES>
-__global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
+__global__ __launch_bounds__((NW + 2 * fam8_nq(KPL)) * 64) void sgm_fam8_kernel(fam8_args a) {
     constexpr int Q = KPL / 4;                  // (A, B) register pairs per lane and path
     constexpr int NR = 2 * Q;                   // registers per lane and path
     constexpr int PER = CBITS == 8 ? 4 : 6;     // costs per dword of the cost volume
@@ -208,7 +200,11 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
         // of compute wavefronts 0 and 4 and was a fifth of its load.  Now two wavefronts (they land on different SIMDs), records
         // addressed by running pointers, and no lane-varying branch: every lane moves two (A, B) register pairs and two minima per
         // block - the kinds its block does not hold go to a spare dword pair of the column slot.
-        const bool publisher = wave == NW;
+        // (round 5, second step: one wavefront per 64 blocks - at 9 to 20 disparities per lane a record is two wavefronts' worth, so two
+        //  publishers and two consumers, each with HALF the blocks: what a hand-off wavefront adds to its SIMD's row is ~45 instructions
+        //  instead of 62 / 100, on four SIMDs instead of two)
+        const bool publisher = wave < NW + NQ;
+        const int myq = (wave - NW) % NQ;  // the block of every lane this wavefront moves
         constexpr int SINK = 16 * KS + 2;  // spare dwords of a column slot (its minimum sits at 16 KS): 8-byte aligned
         int offP0[NQ], offP1[NQ];     // LDS dword offsets (within a row parity) of the block's two register pairs
         int offM0[NQ], offM1[NQ];     // ... of its two minima
@@ -265,6 +261,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
                 const uint32_t gave_up = (uint32_t)ctl[1];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
+                    if (q != myq) continue;  // (uniform)
                     const u32x2 v0 = *(const u32x2*)(Eb + offP0[q]);
                     const u32x2 v1 = *(const u32x2*)(Eb + offP1[q]);
                     u32x4 b;
@@ -288,64 +285,86 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
         // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
         const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
         const int tB = (r_hi < base ? r_hi : base) - 1;
-        u32x4 x[NQ];
-        auto issue = [&](int t, const u32x4* rec) {
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, t >= tA && t <= tB);
+        // The neighbour's records are asked for KA rows ahead (a register ring); a record's loads bypass L1 and L2 and take a memory
+        // round trip, 1.5 to 2 us under this kernel's own traffic.  KA = 1 is what stays: cycle stamps showed this wavefront waiting
+        // 2500 of a row's 4250 cycles for its one look-ahead load, but that wait is SLACK - a window cannot run ahead of its left
+        // neighbour, the chain of windows moves at the pace of its head, and the head's row is the 3300 cycles two compute wavefronts
+        // per SIMD need to issue their 2 x ~310 instructions.  Three rows of look-ahead, same box, alternated:
+        // 6.90 / 6.98 / 7.16 ms alone against 6.89 / 6.76 / 6.61 with one; beside the horizontal pair 9.78 - 9.98 against 9.37 - 10.13.
+        constexpr int KA = PMX_FAM8_KA;
+        u32x4 x[KA][NQ];
+        int t_ask = r_lo - 1;
+        const u32x4* rec_ask = rec_of(t_ask);
+        int amod = (t_ask > 0 ? t_ask : 0) % CW;
+        auto ask = [&](u32x4 (&slot)[NQ]) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec_ask, t_ask >= tA && t_ask <= tB);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
-        };
-        auto consume = [&](int t, const u32x4* rec) -> bool {
-            if (t < tA || t > tB) return true;
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, true);
-            for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) ok &= boff[q] == kOob || (x[q].y == a.epoch && x[q].w == a.epoch);
-                if (__all(ok)) break;
-                if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-                if (spins > kSpinLimit) {
-                    if (lane == 0) __hip_atomic_store(errw, 0x80000000u + (unsigned)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return false;
-                }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
+            for (int q = 0; q < NQ; ++q)
+                if (q == myq) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
+            if (t_ask >= 0) {  // (row -1 shares row 0's record: nothing to advance)
+                rec_ask += row_blocks;
+                if (++amod == CW) { amod = 0; rec_ask -= NGP; }
             }
-            uint32_t* Eb = lds8 + (t & 1) * EBUF;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                u32x2 v0, v1;  // bytes d, d+1, d+2, d+3 -> A = (d, d+2), B = (d+1, d+3), pads restored
-                v0.x = (x[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((x[q].x >> 8) & 0x00ff00ffu) | pB0[q];
-                v1.x = (x[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((x[q].z >> 8) & 0x00ff00ffu) | pB1[q];
-                *(u32x2*)(Eb + offP0[q]) = v0;
-                *(u32x2*)(Eb + offP1[q]) = v1;
-                if (q == QM0 || q == QM1) {  // (compile time)
-                    Eb[offM0[q]] = x[q].x;
-                    Eb[offM1[q]] = one_min[q] ? x[q].x : x[q].z;
-                }
-            }
-            return true;
+            ++t_ask;
         };
-        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi.  Row t of the neighbour is asked for as
-        // early as it can exist (one look-ahead load per barrier), and polled for when it is due.
         int t = r_lo - 1;
         const u32x4* rec_cur = rec_of(t);
-        const u32x4* rec_next = rec_of(t + 1);
-        int tmod = (t + 1 > 0 ? t + 1 : 0) % CW;  // (t + 1) mod CW: the block index loses one when t + 2 reaches a multiple of CW
-        issue(t, rec_cur);
-        for (; t <= r_hi; ++t) {
-            const bool got = consume(t, rec_cur);
-            if (!got) ctl[1] = 1;  // (sticky: the other wavefronts read it with their next row's LDS reads)
-            issue(t + 1, rec_next);
-            __syncthreads();
-            if (!got) return;
-            // bi(t + 2) from bi(t + 1): one row further, one column block back at every multiple of CW
-            rec_cur = rec_next;
-            if (t + 1 >= 0) {
-                ++tmod;
-                rec_next += row_blocks;
-                if (tmod == CW) { tmod = 0; rec_next -= NGP; }
+        int tmod = (t > 0 ? t : 0) % CW;
+        auto deliver = [&](u32x4 (&slot)[NQ]) __attribute__((always_inline)) -> bool {  // row t of the neighbour into slots -2, -1
+            bool got = true;
+            if (t >= tA && t <= tB) {
+                const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec_cur, true);
+                for (unsigned spins = 0;; ++spins) {
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (q == myq) ok &= boff[q] == kOob || (slot[q].y == a.epoch && slot[q].w == a.epoch);
+                    if (__all(ok)) break;
+                    if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { got = false; break; }
+                    if (spins > kSpinLimit) {
+                        if (lane == 0) __hip_atomic_store(errw, 0x80000000u + (unsigned)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        got = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (q == myq) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
+                }
+                if (got) {
+                    uint32_t* Eb = lds8 + (t & 1) * EBUF;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (q != myq) continue;  // (uniform)
+                        u32x2 v0, v1;  // bytes d, d+1, d+2, d+3 -> A = (d, d+2), B = (d+1, d+3), pads restored
+                        v0.x = (slot[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((slot[q].x >> 8) & 0x00ff00ffu) | pB0[q];
+                        v1.x = (slot[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((slot[q].z >> 8) & 0x00ff00ffu) | pB1[q];
+                        *(u32x2*)(Eb + offP0[q]) = v0;
+                        *(u32x2*)(Eb + offP1[q]) = v1;
+                        if (q == QM0 || q == QM1) {  // (compile time)
+                            Eb[offM0[q]] = slot[q].x;
+                            Eb[offM1[q]] = one_min[q] ? slot[q].x : slot[q].z;
+                        }
+                    }
+                }
             }
+            if (!got) ctl[1] = 1;  // (sticky: the other wavefronts read it with their next row's LDS reads)
+            if (t >= 0) {
+                rec_cur += row_blocks;
+                if (++tmod == CW) { tmod = 0; rec_cur -= NGP; }
+            }
+            ask(slot);  // (row t + KA into the slot that has just been emptied)
+            ++t;
+            __syncthreads();  // barrier t
+            return got;
+        };
+        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi
+#pragma unroll
+        for (int u = 0; u < KA; ++u) ask(x[u]);
+        while (t <= r_hi) {
+#pragma unroll
+            for (int u = 0; u < KA; ++u)
+                if (t <= r_hi && !deliver(x[u])) return;
         }
         return;
     }
@@ -646,456 +665,6 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
     });
 }
 
-// ---- the same march WITHOUT a barrier per row: the wavefronts of a window follow each other through flags ----------------------------
-// Cycle stamps of the kernel above (round 5): a row of a window is read-the-predecessors (350 cycles: 45 KB through an LDS
-// of 128 B per cycle, all eight wavefronts at once), compute (two wavefronts per SIMD, 2 x 1085 cycles of vector issue), write-the-row
-// (another 45 KB, ~600 cycles with the stores), barrier (~300): 3300 cycles of which the vector unit works 2170 - and every
-// wavefront of the window, and through the hand-off every window of the chain, waits for the slowest of each row.  But inside a
-// window every dependency points LEFT (local columns j-1, j-2): wavefront w needs of row r-1 only what wavefront w-1 and itself
-// produced.  So: no barrier.  What crosses a wavefront's border - the vertical path of its last column, the diagonal path of its last
-// two - goes through a ring of R = 4 rows per wavefront in LDS, what stays inside goes through a buffer of its own, and a word per
-// wavefront says "row r is in my ring".  A wavefront reads its left neighbour's word together with the row it hopes to find (LDS
-// serves a wavefront's requests in order: the word first), and looks at its right neighbour's before it overwrites a ring slot.
-// The wavefronts of a SIMD drift apart by themselves - only one can issue at a time - and then one's LDS phases fall into the
-// other's arithmetic; a window that is late delays its neighbour only once that one has used up the rows of slack the ring gives.
-// The two hand-off wavefronts are ring neighbours like any other: the consumer fills ring 0 (up to R - 1 rows ahead of wavefront 0),
-// the publisher empties ring NW.  Semantics, lane map, hand-off records and cost ring: the kernel above.
-template <int KPL, int CBITS, int NW, int PF>
-__global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8s_kernel(fam8_args a) {
-    constexpr int R = 4;                        // rows of slack between neighbouring wavefronts
-    constexpr int Q = KPL / 4, NR = 2 * Q;
-    constexpr int PER = CBITS == 8 ? 4 : 6, NDW = (KPL + PER - 1) / PER;
-    constexpr int CW = NW * 4;
-    constexpr int KS = (NR + 3) & ~3, ES = 16 * KS + 4;
-    constexpr int RSLOT = 3 * ES;               // a ring slot: vertical path of the last column, diagonal of the last two (V3, A2, A3)
-    constexpr int RINGW = R * RSLOT;            // a wavefront's ring
-    constexpr int OWNW = 5 * ES;                // what stays inside a wavefront: V0 V1 V2 A0 A1
-    constexpr int LDS_RINGS = (NW + 1) * RINGW, LDS_OWN = NW * OWNW;
-    constexpr int NVB = 8 * Q, NG = 3 * NVB + 2, NQ = (NG + 63) / 64, NGP = NQ * 64;
-    static_assert(KPL % 4 == 0 && KPL >= 4 && KPL <= 20 && (R & (R - 1)) == 0, "whole dwords per lane; R a power of two");
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds8[];
-    typedef __attribute__((address_space(3))) int lds_int;
-    uint32_t* const rings = lds8;               // [NW + 1][R][3][ES]: ring 0 is filled by the consumer, ring w + 1 by wavefront w
-    // (behind the rings: [NW][5][ES], what stays inside a wavefront)
-    // progress words: [0] consumer (neighbour's row t is in ring 0), [1 + w] wavefront w (row r is in ring w + 1), [NW + 1] publisher
-    // (row p has left ring NW), [NW + 2] ticket, [NW + 3] somebody gave up
-    volatile lds_int* fl = (volatile lds_int*)(lds_int*)(lds8 + LDS_RINGS + LDS_OWN);
-    volatile lds_int* const gave_up = fl + NW + 3;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
-    if (threadIdx.x == 0) {
-        fl[NW + 2] = (int)atomicAdd(a.ctl, 1u);
-        fl[NW + 3] = 0;
-    }
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(fl[NW + 2]);
-    const int fam = a.fam0 + ticket % a.nfam;
-    const int s = ticket / a.nfam;
-    const int H = a.H, W = a.W, D = a.D;
-    const int base = s * CW;
-    const int r_lo = base - W + 1 > 0 ? base - W + 1 : 0;
-    const int r_hi = base + CW - 1 < H - 1 ? base + CW - 1 : H - 1;
-    if (r_lo > r_hi) return;
-#if PMX_FAM8_TS
-    const bool ts_on = fam == 0 && s == kTsWin;
-#endif
-    // rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi)
-    const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
-    const int tB = (r_hi < base ? r_hi : base) - 1;
-    if (lane == 0) fl[wave < NW ? 1 + wave : (wave == NW ? NW + 1 : 0)] = wave == NW + 1 ? tA - 1 : r_lo - 1;  // "done so far"
-    __syncthreads();
-    gu32* errw = (gu32*)(a.ctl + 1);
-    u32x4* const halo = a.halo + (size_t)(fam - a.fam0) * a.halo_fam;
-    constexpr unsigned kBlockBytes = (unsigned)NGP * 16u;
-
-    // waits until the word at fl[i] has reached `need`; false: somebody gave up (or this wait did: a bound on every spin)
-    auto wait_for = [&](int i, int need) __attribute__((always_inline)) -> bool {
-        for (unsigned spins = 0;; ++spins) {
-            if (__builtin_amdgcn_readfirstlane(fl[i]) >= need) return true;
-            if (__builtin_amdgcn_readfirstlane(*gave_up) != 0) return false;
-            if (spins > kSpinLimit) {
-                *gave_up = 1;
-                if (lane == 0) __hip_atomic_store(errw, 0x40000000u + (unsigned)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    };
-
-    if (wave >= NW) {
-        // ---- hand-off wavefronts (records, blocks and tags as in the kernel above; LDS side: ring 0 / ring NW) ---------------------
-        const bool publisher = wave == NW;
-        constexpr int SINK = 16 * KS + 2;  // spare dwords of a vector (its minimum sits at 16 KS)
-        int offP0[NQ], offP1[NQ], offM0[NQ], offM1[NQ];
-        uint32_t pA0[NQ], pB0[NQ], pA1[NQ], pB1[NQ];
-        bool is_min[NQ], one_min[NQ];
-        unsigned boff[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = q * 64 + lane;
-            offP0[q] = offP1[q] = SINK; offM0[q] = offM1[q] = SINK;
-            pA0[q] = pB0[q] = pA1[q] = pB1[q] = 0;
-            is_min[q] = one_min[q] = false;
-            boff[q] = idx < NG ? (unsigned)idx * 16u : kOob;
-            if (idx < 3 * NVB) {
-                const int vec = idx / NVB, rem = idx - vec * NVB;
-                // record vector 0: vertical path of column CW-1 = ring vector V3 (0);  1: diagonal of CW-1 = A3 (2);  2: diagonal of CW-2 = A2 (1)
-                const int slot = (vec == 0 ? 0 : (vec == 1 ? 2 : 1)) * ES;
-                auto place = [&](int m, int& off, uint32_t& pa, uint32_t& pb) {
-                    const int l = m / Q, qq = m - l * Q, d = l * KPL + 4 * qq;
-                    off = slot + l * KS + 2 * qq;
-                    pa = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
-                    pb = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
-                };
-                place(2 * rem, offP0[q], pA0[q], pB0[q]);
-                place(2 * rem + 1, offP1[q], pA1[q], pB1[q]);
-            } else if (idx == 3 * NVB) {      // minima of column CW-1: vertical path (V3), diagonal (A3)
-                is_min[q] = true; offM0[q] = 16 * KS; offM1[q] = 2 * ES + 16 * KS;
-            } else if (idx == 3 * NVB + 1) {  // minimum of column CW-2: diagonal (A2)
-                is_min[q] = one_min[q] = true; offM0[q] = ES + 16 * KS; offM1[q] = offM0[q];
-            }
-        }
-        constexpr int QM0 = (3 * NVB) / 64, QM1 = (3 * NVB + 1) / 64;
-        auto rec_of = [&](int t) { const int tt = t > 0 ? t : 0; return halo + ((size_t)tt * a.NB + s - 1 - tt / CW) * NGP; };
-        const size_t row_blocks = (size_t)a.NB * NGP;
-        auto rsrc_of = [&](const u32x4* rec, bool need) {
-            return __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, need ? kBlockBytes : 0u, kRsrcWord3);
-        };
-        if (publisher) {
-            const int pA = r_lo > base + CW - W ? r_lo : base + CW - W;
-            const int pB = r_hi < H - 2 ? r_hi : H - 2;
-            const u32x4* rec = rec_of(r_lo) + NGP;
-            int pmod = r_lo % CW;
-            for (int pr = r_lo; pr <= r_hi; ++pr) {
-                PMX_TS(pr, 0);
-                if (!wait_for(NW, pr)) return;  // wavefront NW-1 has put row pr into ring NW
-                PMX_TS(pr, 1);
-                const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, pr >= pA && pr <= pB);
-                const uint32_t* Eb = rings + NW * RINGW + (pr & (R - 1)) * RSLOT;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const u32x2 v0 = *(const u32x2*)(Eb + offP0[q]);
-                    const u32x2 v1 = *(const u32x2*)(Eb + offP1[q]);
-                    u32x4 b;
-                    b.x = v0.x | (v0.y << 8);
-                    b.z = v1.x | (v1.y << 8);
-                    if (q == QM0 || q == QM1) {  // (compile time)
-                        const uint32_t m0 = Eb[offM0[q]], m1 = Eb[offM1[q]];
-                        b.x = is_min[q] ? m0 : b.x;
-                        b.z = is_min[q] ? m1 : b.z;
-                    }
-                    b.y = a.epoch;
-                    b.w = a.epoch;
-                    __builtin_amdgcn_raw_buffer_store_b128(b, rs, boff[q], 0, kSc1);
-                }
-                asm volatile("" ::: "memory");
-                fl[NW + 1] = pr;  // (the slot's values are in registers: it may be written again)
-                PMX_TS(pr, 2);
-                rec += row_blocks;
-                if (++pmod == CW) { pmod = 0; rec -= NGP; }
-            }
-            return;
-        }
-        // ---- consumer: the neighbour's rows tA .. tB into ring 0, as early as they exist and the ring has room ---------------------
-        if (tA > tB) {
-            if (lane == 0) fl[0] = 0x7fffffff;
-            return;
-        }
-        // The neighbour's records are asked for KA rows ahead (a register ring): a record's loads bypass L1 and L2 and take a
-        // memory round trip - 1.5 to 2 us under this kernel's own traffic, as long as a row of the march - and a consumer that asks
-        // for row t + 1 when it has delivered row t delivers one row per round trip: that, not the barrier, is what the rows of
-        // the kernel above wait for (cycle stamps: consume 2500 of a row's 4250 cycles).
-        constexpr int KA = 3;
-        u32x4 x[KA][NQ];
-        const u32x4* rec_ask = rec_of(tA);  // record of the next row to ask for
-        int amod = tA % CW, t_ask = tA;
-        auto ask = [&](u32x4 (&slot)[NQ]) __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rn = rsrc_of(rec_ask, t_ask <= tB);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rn, boff[q], 0, kSc1);
-            ++t_ask;
-            rec_ask += row_blocks;
-            if (++amod == CW) { amod = 0; rec_ask -= NGP; }
-        };
-        const u32x4* rec_cur = rec_of(tA);  // record of the row that is due
-        int tmod = tA % CW;
-#pragma unroll
-        for (int u = 0; u < KA; ++u) ask(x[u]);
-        auto deliver = [&](int t, u32x4 (&slot)[NQ]) __attribute__((always_inline)) -> bool {
-            // ring 0's slot of row t held row t - R, which wavefront 0 read in its step t - R + 1
-            PMX_TS(t, 0);
-            if (!wait_for(1, t - R + 1)) return false;
-            PMX_TS(t, 1);
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec_cur, true);
-            unsigned spins = 0;
-            for (;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) ok &= boff[q] == kOob || (slot[q].y == a.epoch && slot[q].w == a.epoch);
-                if (__all(ok)) break;
-                bool stop = (spins & 31) == 31 && (__hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                                                    __builtin_amdgcn_readfirstlane(*gave_up) != 0);
-                if (spins > kSpinLimit) {
-                    if (lane == 0) __hip_atomic_store(errw, 0x80000000u + (unsigned)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    stop = true;
-                }
-                if (stop) {
-                    *gave_up = 1;
-                    return false;
-                }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
-            }
-            PMX_TS(t, 2);
-            PMX_TSV(t, 4, spins);
-            uint32_t* Eb = rings + (t & (R - 1)) * RSLOT;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                u32x2 v0, v1;
-                v0.x = (slot[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((slot[q].x >> 8) & 0x00ff00ffu) | pB0[q];
-                v1.x = (slot[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((slot[q].z >> 8) & 0x00ff00ffu) | pB1[q];
-                *(u32x2*)(Eb + offP0[q]) = v0;
-                *(u32x2*)(Eb + offP1[q]) = v1;
-                if (q == QM0 || q == QM1) {  // (compile time)
-                    Eb[offM0[q]] = slot[q].x;
-                    Eb[offM1[q]] = one_min[q] ? slot[q].x : slot[q].z;
-                }
-            }
-            rec_cur += row_blocks;
-            if (++tmod == CW) { tmod = 0; rec_cur -= NGP; }
-            ask(slot);  // (row t + KA into the slot that has just been emptied)
-            asm volatile("" ::: "memory");
-            fl[0] = t;
-            PMX_TS(t, 3);
-            return true;
-        };
-        for (int t = tA; t <= tB; t += KA) {
-#pragma unroll
-            for (int u = 0; u < KA; ++u)
-                if (t + u <= tB && !deliver(t + u, x[u])) return;
-        }
-        asm volatile("" ::: "memory");
-        fl[0] = 0x7fffffff;  // (rows past tB need nothing from the left)
-        return;
-    }
-
-    // ---- compute wavefronts -----------------------------------------------------------------------------------------------------------
-    const int g = lane >> 4, sub = lane & 15;
-    const int j = wave * 4 + g;
-    const int d_first = sub * KPL;
-    const bool lane_active = d_first < D;
-    const unsigned cost_lane = lane_active ? (unsigned)sub * NDW * 4u : kOob;
-    const unsigned out_lane = (unsigned)sub * KPL;
-    const unsigned cost_row_bytes = (unsigned)W * (unsigned)a.Dc, out_row_bytes = (unsigned)W * (unsigned)a.Dp;
-    uint8_t* const outv = a.out + (size_t)fam * a.dstride;
-    uint32_t padA[Q], padB[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int d = d_first + 4 * q;
-        padA[q] = ((d < D) ? 0u : kPad16) | (((d + 2 < D) ? 0u : kPad16) << 16);
-        padB[q] = ((d + 1 < D) ? 0u : kPad16) | (((d + 3 < D) ? 0u : kPad16) << 16);
-    }
-    const uint32_t P1pk = a.P1 | (a.P1 << 16), P2pk = a.P2 | (a.P2 << 16);
-    const ptrdiff_t cost_step = fam ? -(ptrdiff_t)cost_row_bytes : (ptrdiff_t)cost_row_bytes;
-    const ptrdiff_t out_step = fam ? -(ptrdiff_t)out_row_bytes : (ptrdiff_t)out_row_bytes;
-    const int rimg_lo = fam ? H - 1 - r_lo : r_lo;
-    const uint8_t* cost_row = a.cost + (size_t)rimg_lo * cost_row_bytes;
-    uint8_t* out_row = outv + (size_t)rimg_lo * out_row_bytes;
-    int pc = base - r_lo + j;
-    unsigned pcoff = (unsigned)pc * (unsigned)a.Dc + cost_lane;
-    int pr = r_lo;
-    constexpr int kRingCnt = (PF - 1) * (hring_loads(NDW) + (Q == 5 ? 2 : 1));
-    constexpr int kRing0 = 96;
-    static_assert(PF <= 3 && NDW <= 6, "hring slots");
-    PMX_HRING_RESERVE("v113");
-    auto prefetch = [&](auto slot_tag) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slot_tag)::value;
-        hring_load<kRing0 + 6 * SL, NDW>(rsrc_words(cost_row, cost_row_bytes), ((unsigned)pc < (unsigned)W && lane_active) ? pcoff : kOob);
-        const bool adv = pr < r_hi;
-        pr += adv ? 1 : 0;
-        cost_row += adv ? cost_step : (ptrdiff_t)0;
-        pc -= adv ? 1 : 0;
-        pcoff -= adv ? (unsigned)a.Dc : 0u;
-    };
-    auto for_slots = [&](auto&& f) __attribute__((always_inline)) {
-        f(std::integral_constant<int, 0>{});
-        if constexpr (PF > 1) f(std::integral_constant<int, 1>{});
-        if constexpr (PF > 2) f(std::integral_constant<int, 2>{});
-    };
-    for_slots([&](auto tag) __attribute__((always_inline)) { prefetch(tag); });
-
-    // Where a lane's predecessors come from and its results go (dword offsets in LDS; the ring parts get the row's slot added):
-    //   lane group 0: V <- left ring V3, A <- left ring A2;  1: V <- own V0, A <- left ring A3;  2: V <- own V1, A <- own A0;  3: V <- own V2, A <- own A1
-    //   results       0: V -> own V0, A -> own A0;            1: V -> own V1, A -> own A1;       2: V -> own V2, A -> my ring A2; 3: V -> my ring V3, A -> my ring A3
-    const int ringL = wave * RINGW, ringM = (wave + 1) * RINGW, own = LDS_RINGS + wave * OWNW;
-    const int lane_vec = sub * KS;
-    const int rdV = (g == 0 ? ringL + 0 * ES : own + (g - 1) * ES) + lane_vec;
-    const int rdA = (g == 0 ? ringL + 1 * ES : (g == 1 ? ringL + 2 * ES : own + (3 + g - 2) * ES)) + lane_vec;
-    const int wrV = (g == 3 ? ringM + 0 * ES : own + g * ES) + lane_vec;
-    const int wrA = (g == 2 ? ringM + 1 * ES : (g == 3 ? ringM + 2 * ES : own + (3 + g) * ES)) + lane_vec;
-    const int rdV_ring = g == 0 ? 1 : 0, rdA_ring = g <= 1 ? 1 : 0, wrV_ring = g == 3 ? 1 : 0, wrA_ring = g >= 2 ? 1 : 0;
-    const int needR_adj = wave == NW - 1 ? 0 : 1;  // the publisher's word says "row p has left the ring", a wavefront's "row r is done"
-
-    uint32_t LBa[Q], LBb[Q];
-    uint32_t edgeV[2] = {kPadPk, kPadPk}, edgeA[2] = {kPadPk, kPadPk}, edgeB[2] = {kPadPk, kPadPk};
-    uint32_t MB = 0u;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) { LBa[q] = padA[q]; LBb[q] = padB[q]; }
-    int c = base - r_lo + j;
-    unsigned ooff = (unsigned)c * (unsigned)a.Dp + out_lane;
-    PMX_LOOP_ENTRY_DRAIN();
-
-    auto step = [&](int r, auto slot_tag) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slot_tag)::value;
-        const int so_prev = ((r - 1) & (R - 1)) * RSLOT, so_cur = (r & (R - 1)) * RSLOT;
-        uint32_t LVa[Q], LVb[Q], LAa[Q], LAb[Q], MV, MA;
-        const uint32_t* srcV = lds8 + rdV + rdV_ring * so_prev;
-        const uint32_t* srcA = lds8 + rdA + rdA_ring * so_prev;
-        auto read_predecessors = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < KS / 4; ++i) {
-                if (4 * i + 2 < NR) {
-                    const u32x4 t = *(const u32x4*)(srcV + 4 * i);
-                    const u32x4 u = *(const u32x4*)(srcA + 4 * i);
-                    LVa[2 * i] = t.x; LVb[2 * i] = t.y; LVa[2 * i + 1] = t.z; LVb[2 * i + 1] = t.w;
-                    LAa[2 * i] = u.x; LAb[2 * i] = u.y; LAa[2 * i + 1] = u.z; LAb[2 * i + 1] = u.w;
-                } else if (4 * i < NR) {
-                    const u32x2 t = *(const u32x2*)(srcV + 4 * i);
-                    const u32x2 u = *(const u32x2*)(srcA + 4 * i);
-                    LVa[2 * i] = t.x; LVb[2 * i] = t.y;
-                    LAa[2 * i] = u.x; LAb[2 * i] = u.y;
-                }
-            }
-            MV = (srcV - lane_vec)[16 * KS];
-            MA = (srcA - lane_vec)[16 * KS];
-        };
-        PMX_TS(r, 0);
-        // the neighbours' words first, then - in the same breath - the row they are expected to announce
-        const int seenL = fl[wave];
-        const int seenR = fl[wave + 2];
-        asm volatile("" ::: "memory");
-        read_predecessors();
-        asm volatile("" ::: "memory");
-        if (__builtin_amdgcn_readfirstlane(seenL) < r - 1) {  // (rare once the wavefronts have found their distance)
-            asm volatile("; the left neighbour is not there yet" ::);
-            if (!wait_for(wave, r - 1)) __builtin_amdgcn_endpgm();  // (somebody gave up: the launch has failed, pmx_sgm says so)
-            asm volatile("" ::: "memory");
-            read_predecessors();
-            asm volatile("" ::: "memory");
-        }
-        PMX_TSV(r, 4, (__builtin_amdgcn_readfirstlane(seenL) < r - 1 ? 1 : 0) + (__builtin_amdgcn_readfirstlane(seenR) < r - R + needR_adj ? 2 : 0));
-        PMX_TS(r, 1);
-        uint32_t ccA[Q], ccB[Q];
-        {
-            uint32_t cx[NDW];
-            hring_take<kRing0 + 6 * SL, NDW, kRingCnt>(cx);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                if (CBITS == 8) {
-                    ccA[q] = (cx[q] & 0x00ff00ffu) | padA[q];
-                    ccB[q] = ((cx[q] >> 8) & 0x00ff00ffu) | padB[q];
-                } else {
-                    constexpr uint32_t m5 = 0x001f001fu;
-                    ccA[q] = ((cx[(2 * q) / 3] >> (5 * ((2 * q) % 3))) & m5) | padA[q];
-                    ccB[q] = ((cx[(2 * q + 1) / 3] >> (5 * ((2 * q + 1) % 3))) & m5) | padB[q];
-                }
-            }
-        }
-        const bool r0 = (r == 0);
-        const bool rsA = r0 || c == 0, rsB = r0 || c == W - 1;
-        if (__builtin_amdgcn_ballot_w64(rsA || rsB) != 0ull) {
-            asm volatile("; path starts" ::);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                LVa[q] = r0 ? padA[q] : LVa[q]; LVb[q] = r0 ? padB[q] : LVb[q];
-                LAa[q] = rsA ? padA[q] : LAa[q]; LAb[q] = rsA ? padB[q] : LAb[q];
-                LBa[q] = rsB ? padA[q] : LBa[q]; LBb[q] = rsB ? padB[q] : LBb[q];
-            }
-            MV = r0 ? 0u : MV; MA = rsA ? 0u : MA; MB = rsB ? 0u : MB;
-        }
-        uint32_t nVa[Q], nVb[Q], nAa[Q], nAb[Q], nBa[Q], nBb[Q];
-        uint32_t mV = path_update<Q>(LVa, LVb, MV, ccA, ccB, P1pk, P2pk, nVa, nVb, edgeV);
-        uint32_t mA = path_update<Q>(LAa, LAb, MA, ccA, ccB, P1pk, P2pk, nAa, nAb, edgeA);
-        uint32_t mB = path_update<Q>(LBa, LBb, MB, ccA, ccB, P1pk, P2pk, nBa, nBb, edgeB);
-        group_min3(mV, mA, mB);
-        MB = mB;
-        PMX_TS(r, 2);
-        // my ring's slot of row r held row r - R: the right neighbour must be done with the step that read it
-        if (__builtin_amdgcn_readfirstlane(seenR) < r - R + needR_adj) {
-            asm volatile("; the right neighbour has not made room yet" ::);
-            if (!wait_for(wave + 2, r - R + needR_adj)) __builtin_amdgcn_endpgm();
-        }
-        asm volatile("" ::: "memory");
-        {
-            uint32_t* dstV = lds8 + wrV + wrV_ring * so_cur;
-            uint32_t* dstA = lds8 + wrA + wrA_ring * so_cur;
-#pragma unroll
-            for (int i = 0; i < KS / 4; ++i) {
-                if (4 * i + 2 < NR) {
-                    u32x4 t, u;
-                    t.x = nVa[2 * i]; t.y = nVb[2 * i]; t.z = nVa[2 * i + 1]; t.w = nVb[2 * i + 1];
-                    u.x = nAa[2 * i]; u.y = nAb[2 * i]; u.z = nAa[2 * i + 1]; u.w = nAb[2 * i + 1];
-                    *(u32x4*)(dstV + 4 * i) = t;
-                    *(u32x4*)(dstA + 4 * i) = u;
-                } else if (4 * i < NR) {
-                    u32x2 t, u;
-                    t.x = nVa[2 * i]; t.y = nVb[2 * i];
-                    u.x = nAa[2 * i]; u.y = nAb[2 * i];
-                    *(u32x2*)(dstV + 4 * i) = t;
-                    *(u32x2*)(dstA + 4 * i) = u;
-                }
-            }
-            if (sub == 0) {
-                (dstV - lane_vec)[16 * KS] = mV;
-                (dstA - lane_vec)[16 * KS] = mA;
-            }
-        }
-        asm volatile("" ::: "memory");
-        fl[1 + wave] = r;  // (behind the row in the LDS queue of this wavefront)
-        uint32_t packed[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const uint32_t sa = add3(nVa[q], nAa[q], nBa[q]), sb = add3(nVb[q], nAb[q], nBb[q]);
-            packed[q] = sa | (sb << 8);
-            LBa[q] = nBa[q];
-            LBb[q] = nBb[q];
-        }
-        {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out_row, 0, out_row_bytes, kRsrcWord3);
-            store_dwords<Q>(rs, ((unsigned)c < (unsigned)W && lane_active) ? ooff : kOob, packed);
-        }
-        out_row += out_step;
-        --c;
-        ooff -= (unsigned)a.Dp;
-        prefetch(slot_tag);
-        PMX_TS(r, 3);
-    };
-
-    int r = r_lo;
-    for (; r + PF <= r_hi + 1; r += PF) for_slots([&](auto tag) __attribute__((always_inline)) { step(r + decltype(tag)::value, tag); });
-    for_slots([&](auto tag) __attribute__((always_inline)) {
-        constexpr int U = decltype(tag)::value;
-        if (U < PF - 1 && r + U <= r_hi) step(r + U, tag);
-    });
-}
-
-template <int KPL, int CBITS, int NW>
-int launch_fam8s(pmx_ctx* ctx, const fam8_args& a, int nwg) {
-    constexpr int PF = 3, R = 4;
-    constexpr int Q = KPL / 4, NR = 2 * Q, KS = (NR + 3) & ~3, ES = 16 * KS + 4;
-    const size_t lds_bytes = (size_t)((NW + 1) * R * 3 * ES + NW * 5 * ES + NW + 4) * sizeof(uint32_t);
-    auto kern = sgm_fam8s_kernel<KPL, CBITS, NW, PF>;
-    PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 2) * 64), lds_bytes, ctx->stream, a);
-    PMX_HIP(hipGetLastError());
-    return PMX_OK;
-}
-
 template <int KPL, int CBITS, int NW, bool CODES = false>
 int launch_fam8(pmx_ctx* ctx, const fam8_args& a, int nwg) {
     constexpr int PF = 3;
@@ -1103,7 +672,7 @@ int launch_fam8(pmx_ctx* ctx, const fam8_args& a, int nwg) {
     const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4 + (CODES ? 2 * (4 * (CW + 16 * KPL) + CW) : 0)) * sizeof(uint32_t);
     auto kern = sgm_fam8_kernel<KPL, CBITS, NW, PF, CODES>;
     PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 2) * 64), lds_bytes, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 2 * fam8_nq(KPL)) * 64), lds_bytes, ctx->stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
@@ -1148,26 +717,13 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.d0 = cv->d0; a.o = cv->win / 2; a.invalid_cost = invalid_cost;
     if (from_codes) PMX_CHECK(cv->codes && cv->codes_bytes < 0xfffff000ull, PMX_ERR_STATE, "pmx_sgm (family form): census codes missing or too large");
     const int nwin = (cv->W + cv->H - 2) / CW + 1;
-    // the form without a barrier per row (sgm_fam8s_kernel) for costs from the volume; SGM8_FAM_SKEW=0 keeps the barrier form (A/B hook)
-    const char* esk = pmx_opt(ctx, "SGM8_FAM_SKEW");
-    const bool skew = !from_codes && !(esk && esk[0] == '0');
-#if PMX_FAM8_TS
-    static unsigned* ts_dev = nullptr;
-    static int ts_calls = 0;
-    if (!ts_dev) PMX_HIP(hipMalloc((void**)&ts_dev, 16 * kTsRows * 8 * sizeof(unsigned)));
-    PMX_HIP(hipMemsetAsync(ts_dev, 0, 16 * kTsRows * 8 * sizeof(unsigned), ctx->stream));
-    a.ts = ts_dev;
-#endif
     PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));  // the ticket; the error word is sticky
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY);
 #define PMX_FAM8(KPLV, CB)                                                                              \
     (nw == 8 ? launch_fam8<KPLV, CB, 8>(ctx, a, nwin * nfam) : launch_fam8<KPLV, CB, 4>(ctx, a, nwin * nfam))
 #define PMX_FAM8C(KPLV) (nw == 8 ? launch_fam8<KPLV, 8, 8, true>(ctx, a, nwin * nfam) : launch_fam8<KPLV, 8, 4, true>(ctx, a, nwin * nfam))
-#define PMX_FAM8S(KPLV, CB) (nw == 8 ? launch_fam8s<KPLV, CB, 8>(ctx, a, nwin * nfam) : launch_fam8s<KPLV, CB, 4>(ctx, a, nwin * nfam))
-#define PMX_FAM8_KPL(KPLV)                                                      \
-    rc = from_codes ? PMX_FAM8C(KPLV)                                           \
-                    : (skew ? (five ? PMX_FAM8S(KPLV, 5) : PMX_FAM8S(KPLV, 8)) : (five ? PMX_FAM8(KPLV, 5) : PMX_FAM8(KPLV, 8)))
+#define PMX_FAM8_KPL(KPLV) rc = from_codes ? PMX_FAM8C(KPLV) : (five ? PMX_FAM8(KPLV, 5) : PMX_FAM8(KPLV, 8))
         switch (kpl) {
             case 4: PMX_FAM8_KPL(4); break;
             case 8: PMX_FAM8_KPL(8); break;
@@ -1176,23 +732,10 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
             default: PMX_FAM8_KPL(20); break;
         }
 #undef PMX_FAM8_KPL
-#undef PMX_FAM8S
 #undef PMX_FAM8C
 #undef PMX_FAM8
         if (rc) return rc;
     }
     PMX_HIP(hipMemcpyAsync(ctx->fam_err_host, ctx->fam_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-#if PMX_FAM8_TS
-    if (++ts_calls == 4) {
-        static unsigned host[16 * kTsRows * 8];
-        PMX_HIP(hipStreamSynchronize(ctx->stream));
-        PMX_HIP(hipMemcpy(host, ts_dev, sizeof(host), hipMemcpyDeviceToHost));
-        for (int w = 0; w <= nw + 1; ++w)
-            for (int r = 0; r < kTsRows; ++r) {
-                const unsigned* t = host + (w * kTsRows + r) * 8;
-                fprintf(stderr, "TS wave %d row %d : %u %u %u %u %u\n", w, kTsRow0 + r, t[0], t[1], t[2], t[3], t[4]);
-            }
-    }
-#endif
     return PMX_OK;
 }
