@@ -34,10 +34,6 @@
 #include "pmx_internal.h"
 
 
-#ifndef PMX_FAM8_KA
-#define PMX_FAM8_KA 1  // rows of look-ahead of the consumer wavefront's record loads (A/B: tools/build_variant.sh ka1 k_sgmfam8.hip -DPMX_FAM8_KA=1)
-#endif
-
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned int gu32;
@@ -136,11 +132,8 @@ __device__ __forceinline__ void group_min3(uint32_t& a, uint32_t& b, uint32_t& c
 // times, copy g shifted by g words, so that the 16-byte reads of a lane of pixel group g are aligned (an unaligned ds_read_b128
 // is replayed at 64 cycles) - and every lane reads its KPL words and the pixel's left word where the old form read NDW cost
 // dwords from memory: v_xor, v_bcnt (whose addend is the pad of a disparity >= D), v_lshl_or per pair of cells.
-// hand-off blocks per lane of a (row, border) record: 3 vectors of 8 Q blocks + the minima, 64 to a wavefront
-constexpr int fam8_nq(int kpl) { return (3 * 8 * (kpl / 4) + 2 + 63) / 64; }
-
 template <int KPL, int CBITS, int NW, int PF, bool CODES>
-__global__ __launch_bounds__((NW + 2 * fam8_nq(KPL)) * 64) void sgm_fam8_kernel(fam8_args a) {
+__global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
     constexpr int Q = KPL / 4;                  // (A, B) register pairs per lane and path
     constexpr int NR = 2 * Q;                   // registers per lane and path
     constexpr int PER = CBITS == 8 ? 4 : 6;     // costs per dword of the cost volume
@@ -200,11 +193,7 @@ __global__ __launch_bounds__((NW + 2 * fam8_nq(KPL)) * 64) void sgm_fam8_kernel(
         // of compute wavefronts 0 and 4 and was a fifth of its load.  Now two wavefronts (they land on different SIMDs), records
         // addressed by running pointers, and no lane-varying branch: every lane moves two (A, B) register pairs and two minima per
         // block - the kinds its block does not hold go to a spare dword pair of the column slot.
-        // (round 5, second step: one wavefront per 64 blocks - at 9 to 20 disparities per lane a record is two wavefronts' worth, so two
-        //  publishers and two consumers, each with HALF the blocks: what a hand-off wavefront adds to its SIMD's row is ~45 instructions
-        //  instead of 62 / 100, on four SIMDs instead of two)
-        const bool publisher = wave < NW + NQ;
-        const int myq = (wave - NW) % NQ;  // the block of every lane this wavefront moves
+        const bool publisher = wave == NW;
         constexpr int SINK = 16 * KS + 2;  // spare dwords of a column slot (its minimum sits at 16 KS): 8-byte aligned
         int offP0[NQ], offP1[NQ];     // LDS dword offsets (within a row parity) of the block's two register pairs
         int offM0[NQ], offM1[NQ];     // ... of its two minima
@@ -261,7 +250,6 @@ __global__ __launch_bounds__((NW + 2 * fam8_nq(KPL)) * 64) void sgm_fam8_kernel(
                 const uint32_t gave_up = (uint32_t)ctl[1];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    if (q != myq) continue;  // (uniform)
                     const u32x2 v0 = *(const u32x2*)(Eb + offP0[q]);
                     const u32x2 v1 = *(const u32x2*)(Eb + offP1[q]);
                     u32x4 b;
@@ -285,86 +273,70 @@ __global__ __launch_bounds__((NW + 2 * fam8_nq(KPL)) * 64) void sgm_fam8_kernel(
         // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
         const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
         const int tB = (r_hi < base ? r_hi : base) - 1;
-        // The neighbour's records are asked for KA rows ahead (a register ring); a record's loads bypass L1 and L2 and take a memory
-        // round trip, 1.5 to 2 us under this kernel's own traffic.  KA = 1 is what stays: cycle stamps showed this wavefront waiting
-        // 2500 of a row's 4250 cycles for its one look-ahead load, but that wait is SLACK - a window cannot run ahead of its left
-        // neighbour, the chain of windows moves at the pace of its head, and the head's row is the 3300 cycles two compute wavefronts
-        // per SIMD need to issue their 2 x ~310 instructions.  Three rows of look-ahead, same box, alternated:
-        // 6.90 / 6.98 / 7.16 ms alone against 6.89 / 6.76 / 6.61 with one; beside the horizontal pair 9.78 - 9.98 against 9.37 - 10.13.
-        constexpr int KA = PMX_FAM8_KA;
-        u32x4 x[KA][NQ];
-        int t_ask = r_lo - 1;
-        const u32x4* rec_ask = rec_of(t_ask);
-        int amod = (t_ask > 0 ? t_ask : 0) % CW;
-        auto ask = [&](u32x4 (&slot)[NQ]) __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec_ask, t_ask >= tA && t_ask <= tB);
+        u32x4 x[NQ];
+        auto issue = [&](int t, const u32x4* rec) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, t >= tA && t <= tB);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (q == myq) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
-            if (t_ask >= 0) {  // (row -1 shares row 0's record: nothing to advance)
-                rec_ask += row_blocks;
-                if (++amod == CW) { amod = 0; rec_ask -= NGP; }
-            }
-            ++t_ask;
+            for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
         };
+        auto consume = [&](int t, const u32x4* rec) -> bool {
+            if (t < tA || t > tB) return true;
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, true);
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) ok &= boff[q] == kOob || (x[q].y == a.epoch && x[q].w == a.epoch);
+                if (__all(ok)) break;
+                if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+                if (spins > kSpinLimit) {
+                    if (lane == 0) __hip_atomic_store(errw, 0x80000000u + (unsigned)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
+            }
+            uint32_t* Eb = lds8 + (t & 1) * EBUF;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                u32x2 v0, v1;  // bytes d, d+1, d+2, d+3 -> A = (d, d+2), B = (d+1, d+3), pads restored
+                v0.x = (x[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((x[q].x >> 8) & 0x00ff00ffu) | pB0[q];
+                v1.x = (x[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((x[q].z >> 8) & 0x00ff00ffu) | pB1[q];
+                *(u32x2*)(Eb + offP0[q]) = v0;
+                *(u32x2*)(Eb + offP1[q]) = v1;
+                if (q == QM0 || q == QM1) {  // (compile time)
+                    Eb[offM0[q]] = x[q].x;
+                    Eb[offM1[q]] = one_min[q] ? x[q].x : x[q].z;
+                }
+            }
+            return true;
+        };
+        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi.  Row t of the neighbour is asked for as
+        // early as it can exist (one look-ahead load per barrier), and polled for when it is due.  (Cycle stamps show this wavefront
+        // waiting 2500 of a row's 4250 cycles for that load - but the wait is slack: a window cannot run ahead of its left neighbour,
+        // the chain moves at the pace of its head, and the head's row is what two compute wavefronts per SIMD need to issue.  Three
+        // rows of look-ahead, alternated on one box: 6.90 / 6.98 / 7.16 ms alone against 6.89 / 6.76 / 6.61 with one; two publishers
+        // and two consumers with half the blocks each (commit 1d1420f): 6.79 / 6.79 / 7.10 against 6.44 / 6.87 / 6.76; and the whole
+        // march without a barrier per row - flags between the wavefronts, rings of four rows, commit a538c47: 6.6 - 7.1 against
+        // 6.3 - 6.7.  DESIGN 7.27.)
         int t = r_lo - 1;
         const u32x4* rec_cur = rec_of(t);
-        int tmod = (t > 0 ? t : 0) % CW;
-        auto deliver = [&](u32x4 (&slot)[NQ]) __attribute__((always_inline)) -> bool {  // row t of the neighbour into slots -2, -1
-            bool got = true;
-            if (t >= tA && t <= tB) {
-                const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec_cur, true);
-                for (unsigned spins = 0;; ++spins) {
-                    bool ok = true;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (q == myq) ok &= boff[q] == kOob || (slot[q].y == a.epoch && slot[q].w == a.epoch);
-                    if (__all(ok)) break;
-                    if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { got = false; break; }
-                    if (spins > kSpinLimit) {
-                        if (lane == 0) __hip_atomic_store(errw, 0x80000000u + (unsigned)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        got = false;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (q == myq) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[q], 0, kSc1);
-                }
-                if (got) {
-                    uint32_t* Eb = lds8 + (t & 1) * EBUF;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        if (q != myq) continue;  // (uniform)
-                        u32x2 v0, v1;  // bytes d, d+1, d+2, d+3 -> A = (d, d+2), B = (d+1, d+3), pads restored
-                        v0.x = (slot[q].x & 0x00ff00ffu) | pA0[q]; v0.y = ((slot[q].x >> 8) & 0x00ff00ffu) | pB0[q];
-                        v1.x = (slot[q].z & 0x00ff00ffu) | pA1[q]; v1.y = ((slot[q].z >> 8) & 0x00ff00ffu) | pB1[q];
-                        *(u32x2*)(Eb + offP0[q]) = v0;
-                        *(u32x2*)(Eb + offP1[q]) = v1;
-                        if (q == QM0 || q == QM1) {  // (compile time)
-                            Eb[offM0[q]] = slot[q].x;
-                            Eb[offM1[q]] = one_min[q] ? slot[q].x : slot[q].z;
-                        }
-                    }
-                }
-            }
+        const u32x4* rec_next = rec_of(t + 1);
+        int tmod = (t + 1 > 0 ? t + 1 : 0) % CW;  // (t + 1) mod CW: the block index loses one when t + 2 reaches a multiple of CW
+        issue(t, rec_cur);
+        for (; t <= r_hi; ++t) {
+            const bool got = consume(t, rec_cur);
             if (!got) ctl[1] = 1;  // (sticky: the other wavefronts read it with their next row's LDS reads)
-            if (t >= 0) {
-                rec_cur += row_blocks;
-                if (++tmod == CW) { tmod = 0; rec_cur -= NGP; }
+            issue(t + 1, rec_next);
+            __syncthreads();
+            if (!got) return;
+            // bi(t + 2) from bi(t + 1): one row further, one column block back at every multiple of CW
+            rec_cur = rec_next;
+            if (t + 1 >= 0) {
+                ++tmod;
+                rec_next += row_blocks;
+                if (tmod == CW) { tmod = 0; rec_next -= NGP; }
             }
-            ask(slot);  // (row t + KA into the slot that has just been emptied)
-            ++t;
-            __syncthreads();  // barrier t
-            return got;
-        };
-        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi
-#pragma unroll
-        for (int u = 0; u < KA; ++u) ask(x[u]);
-        while (t <= r_hi) {
-#pragma unroll
-            for (int u = 0; u < KA; ++u)
-                if (t <= r_hi && !deliver(x[u])) return;
         }
         return;
     }
@@ -672,7 +644,7 @@ int launch_fam8(pmx_ctx* ctx, const fam8_args& a, int nwg) {
     const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4 + (CODES ? 2 * (4 * (CW + 16 * KPL) + CW) : 0)) * sizeof(uint32_t);
     auto kern = sgm_fam8_kernel<KPL, CBITS, NW, PF, CODES>;
     PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 2 * fam8_nq(KPL)) * 64), lds_bytes, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 2) * 64), lds_bytes, ctx->stream, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
