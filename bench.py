@@ -769,6 +769,8 @@ def main():
                 roof["frac_of_measured"] = round(roof["achieved"] / peak_m, 4)
                 if "frac_counted" in roof:
                     roof["frac_counted_of_measured"] = round(roof["frac_counted"] * HBM_PEAK_GBS / peak_m, 4)
+                    if hbm["copy"] > 0:  # (the SGM step reads and writes: the copy stream is its like-for-like yardstick)
+                        roof["frac_counted_of_measured_copy"] = round(roof["frac_counted"] * HBM_PEAK_GBS / hbm["copy"], 4)
                 if "pipeline_hbm_frac_counted" in out:
                     out["pipeline_hbm_frac_counted_of_measured"] = round(out["pipeline_hbm_frac_counted"] * HBM_PEAK_GBS / peak_m, 4)
         if world > 1:
