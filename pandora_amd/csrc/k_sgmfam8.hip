@@ -683,7 +683,9 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.ctl = ctx->fam_ctl;
     a.fam0 = fam0; a.nfam = nfam;
     const char* eprio = pmx_opt(ctx, "SGM8_FAM_PRIO");
-    a.prio = eprio ? atoi(eprio) : 3;  // (0: 14.6 ms per 4096^2 x 257 step, 3: 13.9)
+    // (round 4, one hand-off wavefront: 0: 14.6 ms per 4096^2 x 257 step, 3: 13.9.  Round 5, two hand-off wavefronts, alternated on two boxes:
+    //  3: 13.60 - 13.72 / 14.29 - 14.31, 2: 14.26 - 14.36, 1: 13.39 - 13.44 / 13.99 - 14.09, 0: 14.47 - 14.54)
+    a.prio = eprio ? atoi(eprio) : 1;
     a.codes = cv->codes; a.code_bytes = (unsigned)cv->codes_bytes;
     a.codeL_off = (unsigned)(cv->codeL - cv->codes); a.codeR_off = (unsigned)(cv->codeR - cv->codes);
     a.d0 = cv->d0; a.o = cv->win / 2; a.invalid_cost = invalid_cost;
