@@ -33,7 +33,6 @@
 #include "pmx_buf.h"
 #include "pmx_internal.h"
 
-
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned int gu32;
@@ -187,8 +186,8 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
     if (wave >= NW) {
         // ---- hand-off wavefronts: wave NW publishes this window's last two columns for window s+1, wave NW+1 brings the left
         // neighbour's into column slots -2, -1 ---------------------------------------------------------------------------------------
-        // A SIMD issues about one instruction per five cycles, of whatever kind and from whichever of its wavefronts (round 5: the
-        // step's time beside the horizontal pair is the instruction count of the busiest SIMD): one hand-off wavefront
+        // A SIMD issues about one instruction per six cycles here, of whatever kind and from whichever of its wavefronts (round 5:
+        // 6.1 alone, 6.6 with the horizontal pair beside it): one hand-off wavefront
         // of ~185 instructions per row (110 of them scalar: three descriptors rebuilt per row from 64-bit products) sat on the SIMD
         // of compute wavefronts 0 and 4 and was a fifth of its load.  Now two wavefronts (they land on different SIMDs), records
         // addressed by running pointers, and no lane-varying branch: every lane moves two (A, B) register pairs and two minima per
@@ -620,7 +619,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
     constexpr int SH = CODES ? 1 : 0;
     // The unrolled body has no branch between its steps and every memory instruction in it is unconditional: the compiler's wait
     // counts are then the ring's (pmx_buf.h).  After a failed hand-off the rows up to the next look at `abort_seen` are computed from
-    // whatever the column slots hold and stored: the launch has failed by then (pmx_sgm answers PMX_ERR_DEVICE), and a wavefront
+    // whatever the column slots hold and stored: the launch has failed by then (the next call that synchronises reports it: pmx_check_async_error), and a wavefront
     // that has ended no longer counts at the barrier.
     int r = r_lo;
     PMX_LOOP_ENTRY_DRAIN();
