@@ -604,7 +604,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     // definition's order - the same float32 operations, 104 B/cell of traffic, 8 volumes of scratch.  Large volumes are HBM-bound:
     // "fam" reads the costs four times instead of eight and rewrites S three times instead of seven (~46 B/cell against the 92
     // of "seq", one launch per direction).  PMX_SGM_SCHED=seq|par|fam forces one (test hook; PMX_SGM_PAR=0/1 is the round-1 spelling).
-    enum { SEQ, PAR, FAM, SWEEP } sched = SEQ;
+    enum { SEQ, PAR, FAM } sched = SEQ;
     if (cv->cells() <= ((size_t)128 << 20)) sched = PAR;  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
     // the marching passes advance one image row per ~2.5 - 4 us whatever the width: they pay from ~3500 columns on (a window
     // for every CU); measured 4096^2 x 257: 55 ms against 96, 10000^2 x 129: 131 against 265, 2048^2 x 129: 12.4 against 11.3
@@ -614,14 +614,12 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
         if (e[0] == 's') sched = SEQ;
         else if (e[0] == 'p') sched = PAR;
         else if (e[0] == 'f') sched = FAM;
-        else if (e[0] == 'w') sched = SWEEP;
     }
     if (sched == PAR && kpl > 8) sched = SEQ;
     if (sched == FAM && !pmx_sgm_family_supported(ctx, cv)) sched = SEQ;
-    if (sched == SWEEP && !pmx_sgm_sweep_supported(ctx, cv)) sched = SEQ;
-    if (a.p2map && (sched == FAM || sched == SWEEP)) sched = SEQ;  // the marching kernels take the constant penalty only
+    if (a.p2map && sched == FAM) sched = SEQ;  // the marching kernels take the constant penalty only
     const char* ep_ = pmx_opt(ctx, "SGM_PENDING");
-    const bool defer_ = (sched == FAM || sched == SWEEP) && ctx->lazy && mask == 0xff && !(ep_ && ep_[0] == '0');
+    const bool defer_ = sched == FAM && ctx->lazy && mask == 0xff && !(ep_ && ep_[0] == '0');
     if (!defer_) {
         rc = pmx_need_scratch(ctx, bytes);
         if (rc) return rc;
@@ -634,25 +632,6 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
         PMX_KPL_SWITCH(kpl, PMX_CALL)
 #undef PMX_CALL
         pmx_pool_free(ctx, paths);  // stream-ordered reuse: the kernels above are queued on ctx->stream
-    } else if (sched == SWEEP) {
-        // two sweeps (k_sgmfam.hip sgm_sweep_kernel); lazy mode: the second one waits like the upward family below
-        if (defer_) {
-            if (cv->spart_bytes < bytes) {
-                pmx_pool_free(ctx, cv->spart);
-                cv->spart = nullptr;
-                cv->spart_bytes = 0;
-                PMX_HIP(pmx_pool_alloc(ctx, (void**)&cv->spart, bytes));
-                cv->spart_bytes = bytes;
-            }
-            a.S = cv->spart;
-        }
-        rc = pmx_launch_sgm_sweeps(ctx, cv, a.S, P1, P2, is_max, invalid_cost, overcounting, mask, defer_ ? 1 : 3, nullptr);
-        if (rc) return rc;
-        if (defer_) {
-            cv->pending = {P1, P2, invalid_cost, is_max, overcounting, 1};
-            cv->repr = PMX_REPR_SGM_UP_PENDING;
-            return PMX_OK;
-        }
     } else if (sched == FAM) {
         // Lazy mode, all eight paths: the horizontal pair and the downward family run now into the handle's own partial-sum
         // volume; the upward family waits for whoever comes next - pmx_wta runs it in WTA mode (S is never written, the WTA's
@@ -676,7 +655,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
         rc = pmx_launch_sgm_families(ctx, cv, a.S, P1, P2, is_max, invalid_cost, overcounting, mask, defer ? 1 : 3, nullptr);
         if (rc) return rc;
         if (defer) {
-            cv->pending = {P1, P2, invalid_cost, is_max, overcounting, 0};
+            cv->pending = {P1, P2, invalid_cost, is_max, overcounting};
             cv->repr = PMX_REPR_SGM_UP_PENDING;
             return PMX_OK;  // data = the costs, spart = the partial sums
         }
@@ -700,11 +679,8 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
 // disparity map and winner cache are written) or in store mode (the handle becomes a plain float32 volume).
 int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta) {
     PMX_CHECK(cv->repr == PMX_REPR_SGM_UP_PENDING && cv->data && cv->spart, PMX_ERR_STATE, "pmx_sgm_finish_pending: nothing pending");
-    int rc = cv->pending.sweep
-                 ? pmx_launch_sgm_sweeps(ctx, cv, cv->spart, cv->pending.P1, cv->pending.P2, cv->pending.is_max, cv->pending.invalid_cost,
-                                         cv->pending.overcounting, 0xff, 2, wta)
-                 : pmx_launch_sgm_families(ctx, cv, cv->spart, cv->pending.P1, cv->pending.P2, cv->pending.is_max, cv->pending.invalid_cost,
-                                           cv->pending.overcounting, 0xff, 2, wta);
+    int rc = pmx_launch_sgm_families(ctx, cv, cv->spart, cv->pending.P1, cv->pending.P2, cv->pending.is_max, cv->pending.invalid_cost,
+                                     cv->pending.overcounting, 0xff, 2, wta);
     if (rc || wta) return rc;
     // the sums become the volume; the costs' buffer is kept with the handle for the next pair's partial sums
     float* costs = cv->data;

@@ -57,16 +57,6 @@ __device__ __forceinline__ unsigned umin_other_row(unsigned v) {
     return r[0] < r[1] ? r[0] : r[1];
 }
 
-// ... and with the same lane of the wavefront's other half (64 lanes per pixel): v_permlane32_swap
-__device__ __forceinline__ float min_other_half(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __builtin_fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ unsigned umin_other_half(unsigned v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return r[0] < r[1] ? r[0] : r[1];
-}
-
 template <int CTRL>
 __device__ __forceinline__ float dpp(float src) {  // lanes without a source lane read 0
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), CTRL, 0xf, 0xf, true));
@@ -554,472 +544,6 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     }
 }
 
-// ---- two sweeps for eight paths ("sweep" schedule) ------------------------------------------------------------------
-// The family schedule above reads C four times (two families, the horizontal pair's two walks) and moves S four times.  A sweep
-// whose front is the line 2 r + c = t has FOUR paths behind it: at step t a pixel's predecessors (r, c-1), (r-1, c+1), (r-1, c)
-// and (r-1, c-1) were visited at t-1, t-1, t-2 and t-3.  So one sweep gives (+1,0) (+1,+1) (+1,-1) (0,+1), the same sweep over the
-// image turned by 180 degrees gives (0,-1) (-1,0) (-1,+1) (-1,-1) - the definition's order (oracle.c orc_sgm) - and the step is
-// R C + W S, then R C + R S (+ W S): 16 B/cell (12 with the WTA inside the second sweep) where the family schedule moves 32.
-//
-// Decomposition.  A workgroup owns a BAND of BR = NW * 64 / GL image rows; lane group i (row i of the band) walks ITS row from left
-// to right, one pixel per step, two steps behind lane group i-1:  column(u, i) = u - 2 i  at the band's step u.  The horizontal
-// path stays in the lane group's registers; the three paths that come from the row above arrive through LDS rings (one slot per
-// step, 2 / 3 / 4 slots deep for the predecessors visited 1 / 2 / 3 steps ago; one barrier per step).  The row above the band's
-// first row belongs to the band above: its three path vectors per pixel travel as the family kernel's hand-off blocks do (sc1
-// write-through stores of {value, value, value, tag}, one record per pixel of the band's last row, read by a hand-off wavefront of
-// the band below with a look-ahead ring) and are placed in the LDS rings as "row -1".  Bands take their index from an atomic
-// ticket (a band's upper neighbour has always started), every dependency points upward: a one-directional pipeline of bands, each
-// 2 BR steps behind the one above.  Kernel coordinates (r', c') are the image's, or the image's turned by 180 degrees (flip).
-struct sweep_args {
-    const float* C;
-    float* S;
-    int H, W, D;
-    int flip;        // 0: paths (+1,0) (+1,+1) (+1,-1) then (0,+1);  1: the turned image: (0,-1) then (-1,0) (-1,+1) (-1,-1)
-    float P1, P2, invalid_cost;
-    int is_max, overcounting;
-    int has_sin;     // S already holds earlier paths
-    int epilogue;    // last pass: overcounting, sign, NaN restore
-    int dmask;       // paths added to S: bit 0 horizontal, 1 vertical, 2 predecessor c'-1, 3 predecessor c'+1 (kernel coordinates)
-    u32x4* halo;     // hand-off records [band border][W][NGP] of 16 bytes
-    unsigned epoch;
-    unsigned* ctl;   // [0] ticket counter (zero at launch), [1] error word
-    float* disp;     // WTA mode (template flag), as in fam_args
-    float* near;
-    double d0;
-    int subpix;
-    float invalid_disparity;
-};
-
-template <int GL>
-__device__ __forceinline__ void group_min4(float& a, float& b, float& c, float& d) {
-    a = fmin2(a, dpp<0x121>(a)); b = fmin2(b, dpp<0x121>(b)); c = fmin2(c, dpp<0x121>(c)); d = fmin2(d, dpp<0x121>(d));
-    a = fmin2(a, dpp<0x122>(a)); b = fmin2(b, dpp<0x122>(b)); c = fmin2(c, dpp<0x122>(c)); d = fmin2(d, dpp<0x122>(d));
-    a = fmin2(a, dpp<0x124>(a)); b = fmin2(b, dpp<0x124>(b)); c = fmin2(c, dpp<0x124>(c)); d = fmin2(d, dpp<0x124>(d));
-    a = fmin2(a, dpp<0x128>(a)); b = fmin2(b, dpp<0x128>(b)); c = fmin2(c, dpp<0x128>(c)); d = fmin2(d, dpp<0x128>(d));
-    if (GL >= 32) {
-        a = min_other_row(a);
-        b = min_other_row(b);
-        c = min_other_row(c);
-        d = min_other_row(d);
-    }
-    if (GL == 64) {
-        a = min_other_half(a);
-        b = min_other_half(b);
-        c = min_other_half(c);
-        d = min_other_half(d);
-    }
-}
-
-template <int GL, int KPL, int NW, int PF, bool WTA>
-__global__ __launch_bounds__((NW + 2) * 64) void sgm_sweep_kernel(sweep_args a) {
-    constexpr int NPW = 64 / GL;           // rows per wave
-    constexpr int BR = NW * NPW;           // rows per band
-    constexpr int KS = GL == 64 ? (KPL + 1) & ~1 : (KPL + 3) & ~3;  // LDS floats per lane slice (64 lanes per pixel: 8-byte pieces)
-    constexpr int KV = KS % 4 ? 2 : 4;     // floats per LDS access
-    constexpr int ES = GL * KS + 4;        // LDS floats per (path, row): slices + the minimum
-    constexpr int ER = (BR + 1) * ES;      // one ring slot: rows -1 .. BR-1
-    constexpr int OFF_B = 0, OFF_V = 2 * ER, OFF_A = 5 * ER, OFF_CTL = 9 * ER;  // rings: B 2 slots, V 3, A 4
-    constexpr int K3 = (KPL + 2) / 3;
-    constexpr int NVB = GL * K3;
-    constexpr int NG = 3 * NVB + 1;        // blocks per record: V, A, B of one pixel, then one block of their three minima
-    constexpr int NQ = (NG + 63) / 64;
-    constexpr int NGP = NQ * 64;
-    constexpr int KH = NQ > 10 ? 2 : 4;    // hand-off look-ahead in steps
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    typedef __attribute__((address_space(3))) int lds_int;
-    volatile lds_int* ctl = (volatile lds_int*)(lds_int*)(lds + OFF_CTL);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) {
-        ctl[0] = (int)atomicAdd(a.ctl, 1u);
-        ctl[1] = 0;
-        ctl[2] = 0;
-    }
-    __syncthreads();
-    const int s = __builtin_amdgcn_readfirstlane(ctl[0]);
-    const int H = a.H, W = a.W, D = a.D;
-    const int rk0 = s * BR;                // first (kernel) row of the band
-    if (rk0 >= H) return;
-    const int U = W + 2 * (BR - 1);        // steps of the band: u = 0 .. U-1; barrier indices -2 .. U-1
-    gu32* errw = (gu32*)(a.ctl + 1);
-    constexpr unsigned kBlockBytes = (unsigned)NGP * 16u;
-    // ring slots of step u (u >= -3): 12 is a multiple of every ring depth
-    auto slotB = [](int u) { return (u + 12) & 1; };
-    auto slotV = [](int u) { return (u + 12) % 3; };
-    auto slotA = [](int u) { return (u + 12) & 3; };
-
-    if (wave >= NW) {
-        // ---- hand-off waves: NW publishes this band's last row for the band below (stores only: it never waits for memory),
-        // NW + 1 brings the band above's last row into the rings as row -1 (loads only: its waits never see a store's
-        // acknowledgement - one wavefront doing both stood, every step, until the previous step's write-through stores had
-        // been acknowledged by the memory, and every step of the band waited for it at the barrier) ----
-        __builtin_amdgcn_s_setprio(3);
-        int vecq[NQ], offq[NQ], nreal[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int idx = q * 64 + lane;
-            int vec, off, n;
-            if (idx < 3 * NVB) {
-                vec = idx / NVB;
-                const int rem = idx - vec * NVB;
-                const int k3 = rem / GL;
-                off = (rem - k3 * GL) * KS + 3 * k3;
-                n = KPL - 3 * k3 >= 3 ? 3 : KPL - 3 * k3;
-            } else if (idx == 3 * NVB) {
-                vec = 3; off = GL * KS; n = 4;
-            } else {
-                vec = 0; off = 0; n = 0;
-            }
-            vecq[q] = vec; offq[q] = off; nreal[q] = n;
-        }
-        const bool has_up = s > 0, has_down = rk0 + BR < H;
-        // record of pixel column q of a border (the band above's last row / this band's last row)
-        auto rec_rsrc = [&](int border, int q, bool need) {
-            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + ((size_t)(need ? border : 0) * W + (need ? q : 0)) * NGP), 0,
-                                                     need ? kBlockBytes : 0u, kRsrcWord3);
-        };
-        u32x4 x[KH][NQ];
-        auto issue = [&](int q, u32x4 (&slot)[NQ]) {
-            const __amdgpu_buffer_rsrc_t rs = rec_rsrc(s - 1, q, has_up && q >= 0 && q < W);
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) slot[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[k] ? (unsigned)(k * 64 + lane) * 16u : kOob, 0, kSc1);
-        };
-        // record q goes to the ring slots of step q - 2 (row -1 "computes" column u + 2 at step u)
-        auto consume = [&](int q, u32x4 (&slot)[NQ]) -> bool {
-            if (!has_up || q < 0 || q >= W) return true;
-            const __amdgpu_buffer_rsrc_t rs = rec_rsrc(s - 1, q, true);
-            for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) ok &= nreal[k] == 0 || slot[k].w == (a.epoch ^ slot[k].x ^ slot[k].y ^ slot[k].z);
-                if (__all(ok)) break;
-                if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-                if (spins > kSpinLimit) {
-                    if (lane == 0) __hip_atomic_store(errw, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return false;
-                }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int k = 0; k < NQ; ++k) slot[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[k] ? (unsigned)(k * 64 + lane) * 16u : kOob, 0, kSc1);
-            }
-            const int ue = q - 2;
-            float* bV = lds + OFF_V + slotV(ue) * ER;  // row index 0 = row -1
-            float* bA = lds + OFF_A + slotA(ue) * ER;
-            float* bB = lds + OFF_B + slotB(ue) * ER;
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-                float* dst = (vecq[k] == 0 ? bV : vecq[k] == 1 ? bA : bB) + offq[k];
-                if (nreal[k] == 4) {
-                    bV[offq[k]] = __uint_as_float(slot[k].x);
-                    bA[offq[k]] = __uint_as_float(slot[k].y);
-                    bB[offq[k]] = __uint_as_float(slot[k].z);
-                } else if (nreal[k] > 0) {
-                    dst[0] = __uint_as_float(slot[k].x);
-                    if (nreal[k] > 1) dst[1] = __uint_as_float(slot[k].y);
-                    if (nreal[k] > 2) dst[2] = __uint_as_float(slot[k].z);
-                }
-            }
-            return true;
-        };
-        // step up of this band: its last row (ring row index BR) visited column up - 2 (BR - 1)
-        auto publish = [&](int up) {
-            const int q = up - 2 * (BR - 1);
-            const bool need = has_down && up >= 0 && q >= 0 && q < W;
-            const __amdgpu_buffer_rsrc_t rs = rec_rsrc(s, q, need);
-            const float* bV = lds + OFF_V + slotV(up) * ER + BR * ES;
-            const float* bA = lds + OFF_A + slotA(up) * ER + BR * ES;
-            const float* bB = lds + OFF_B + slotB(up) * ER + BR * ES;
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-                const float* src = (vecq[k] == 0 ? bV : vecq[k] == 1 ? bA : bB) + offq[k];
-                u32x4 b;
-                if (nreal[k] == 4) {
-                    b.x = __float_as_uint(bV[offq[k]]);
-                    b.y = __float_as_uint(bA[offq[k]]);
-                    b.z = __float_as_uint(bB[offq[k]]);
-                } else {
-                    b.x = __float_as_uint(src[0]);
-                    b.y = nreal[k] > 1 ? __float_as_uint(src[1]) : b.x;
-                    b.z = nreal[k] > 2 ? __float_as_uint(src[2]) : b.x;
-                }
-                b.w = a.epoch ^ b.x ^ b.y ^ b.z;
-                __builtin_amdgcn_raw_buffer_store_b128(b, rs, nreal[k] ? (unsigned)(k * 64 + lane) * 16u : kOob, 0, kSc1);
-            }
-        };
-        // barrier index t runs from -2 to U-1; at t the record of column t + 2 enters the rings
-        if (wave == NW) {
-            for (int t = -2; t < U; ++t) {
-                publish(t - 1);
-                __syncthreads();
-                if (__builtin_amdgcn_readfirstlane(ctl[1 + (t & 1)])) return;
-            }
-            publish(U - 1);
-            return;
-        }
-#pragma unroll
-        for (int v = 0; v < KH; ++v) issue(v, x[v]);
-        for (int tt = -2; tt < U; tt += KH) {
-#pragma unroll
-            for (int v = 0; v < KH; ++v) {
-                const int t = tt + v;
-                if (t < U) {
-                    if (!consume(t + 2, x[v])) ctl[1 + (t & 1)] = 1;
-                    issue(t + 2 + KH, x[v]);
-                    __syncthreads();
-                    if (__builtin_amdgcn_readfirstlane(ctl[1 + (t & 1)])) return;
-                }
-            }
-        }
-        return;
-    }
-
-    // ---- compute waves -------------------------------------------------------------------------------------------
-    const int g = lane / GL;
-    const int l = lane - g * GL;
-    const int i = wave * NPW + g;          // row of the band
-    const int rk = rk0 + i;                // kernel row
-    const bool row_in = rk < H;
-    const int d0 = l * KPL;
-    const int nv = d0 >= D ? 0 : (D - d0 < KPL ? D - d0 : KPL);
-    const bool is_tail = nv > 0 && nv < KPL;
-    const int tailn = D % KPL;
-    using P = pieces<KPL>;
-    int cov = 0;
-#pragma unroll
-    for (int q = 0; q < P::N; ++q)
-        if (P::start(q) + P::width(q) <= tailn) cov = P::start(q) + P::width(q);
-    const int rem = tailn - cov;
-    const unsigned lane_off = (unsigned)(d0 < D ? d0 : 0) * 4u;
-    const unsigned row_bytes = (unsigned)W * (unsigned)D * 4u;
-    const unsigned pix_bytes = (unsigned)D * 4u;
-    float padv[KPL];
-#pragma unroll
-    for (int k = 0; k < KPL; ++k) padv[k] = k < nv ? -f_inf() : f_inf();
-
-    // one descriptor per wave and volume: the wave's NPW image rows (fixed for the whole sweep), lowest address first
-    const int rkw = rk0 + wave * NPW;                               // the wave's first kernel row
-    const int rimg = a.flip ? H - 1 - rk : rk;                      // this lane group's image row (valid when row_in)
-    int rbase = a.flip ? H - 1 - (rkw + NPW - 1) : rkw;             // lowest image row of the wave
-    rbase = rbase < 0 ? 0 : (rbase > H - 1 ? H - 1 : rbase);
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.C + (size_t)rbase * W * D), 0, (unsigned)NPW * row_bytes, kRsrcWord3);
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(a.S + (size_t)rbase * W * D), 0, (unsigned)NPW * row_bytes, kRsrcWord3);
-    const unsigned row_off = row_in ? (unsigned)(rimg - rbase) * row_bytes : 0u;
-    const unsigned row_px = row_in ? (unsigned)(rimg - rbase) * (unsigned)W : 0u;
-    // byte offset of the pixel this lane group visits at step u (kOob: none)
-    auto pix_col = [&](int u) -> int {  // image column, or -1
-        const int c = u - 2 * i;
-        return (row_in && c >= 0 && c < W) ? (a.flip ? W - 1 - c : c) : -1;
-    };
-    auto pix_off = [&](int u) -> unsigned {
-        const int c = pix_col(u);
-        return c >= 0 ? row_off + (unsigned)c * pix_bytes : kOob;
-    };
-
-    int pu = 0;
-    float cbuf[PF][KPL], sbuf[PF][KPL];
-    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
-        const unsigned po = pix_off(pu);
-        const unsigned off = po == kOob ? kOob : po + lane_off;
-        buf_load<KPL>(rsC, off, cslot);
-        buf_load<KPL>(rsS, a.has_sin ? off : kOob, sslot);
-        ++pu;
-    };
-#pragma unroll
-    for (int q = 0; q < PF; ++q) prefetch(cbuf[q], sbuf[q]);
-
-    float LX[KPL];  // the horizontal path: this lane group's previous pixel
-    float MX = 0.f;
-#pragma unroll
-    for (int k = 0; k < KPL; ++k) LX[k] = f_inf();
-
-    __syncthreads();  // barrier -2
-    if (__builtin_amdgcn_readfirstlane(ctl[1])) return;
-    __syncthreads();  // barrier -1
-    if (__builtin_amdgcn_readfirstlane(ctl[2])) return;
-
-    auto step = [&](int u, float (&cslot)[KPL], float (&sslot)[KPL]) __attribute__((always_inline)) {
-        const int c = u - 2 * i;  // kernel column
-        // predecessors in the row above (ring row index i = row i-1): (r'-1, c'+1) one step ago, (r'-1, c') two, (r'-1, c'-1) three
-        const float* srcB = lds + OFF_B + slotB(u - 1) * ER + i * ES;
-        const float* srcV = lds + OFF_V + slotV(u - 2) * ER + i * ES;
-        const float* srcA = lds + OFF_A + slotA(u - 3) * ER + i * ES;
-        float LV[KPL], LA[KPL], LB[KPL];
-#pragma unroll
-        for (int q = 0; q < KS / KV; ++q) {
-            float t[4], v[4], w[4];
-            if (KV == 4) {
-                *(float4*)t = *(const float4*)(srcV + l * KS + 4 * q);
-                *(float4*)v = *(const float4*)(srcA + l * KS + 4 * q);
-                *(float4*)w = *(const float4*)(srcB + l * KS + 4 * q);
-            } else {
-                *(float2*)t = *(const float2*)(srcV + l * KS + 2 * q);
-                *(float2*)v = *(const float2*)(srcA + l * KS + 2 * q);
-                *(float2*)w = *(const float2*)(srcB + l * KS + 2 * q);
-            }
-#pragma unroll
-            for (int e = 0; e < KV; ++e)
-                if (KV * q + e < KPL) { LV[KV * q + e] = t[e]; LA[KV * q + e] = v[e]; LB[KV * q + e] = w[e]; }
-        }
-        const float MV = srcV[GL * KS], MA = srcA[GL * KS], MB = srcB[GL * KS];
-        float cc[KPL];
-        auto was_nan = [&](int k) { return is_nan_bits(cslot[k]); };
-        if (a.is_max) {
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                const float sg = __uint_as_float(__float_as_uint(cslot[k]) ^ 0x80000000u);
-                cc[k] = __builtin_fmaxf(was_nan(k) ? a.invalid_cost : sg, padv[k]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) cc[k] = __builtin_fmaxf(was_nan(k) ? a.invalid_cost : cslot[k], padv[k]);
-        }
-        const bool r0 = (rk == 0);
-        float nX[KPL], nV[KPL], nA[KPL], nB[KPL];
-        float mX = path_costs<GL, KPL>(LX, MX, c <= 0, l, cc, a.P1, a.P2, nX);
-        float mV = path_costs<GL, KPL>(LV, MV, r0, l, cc, a.P1, a.P2, nV);
-        float mA = path_costs<GL, KPL>(LA, MA, r0 || c <= 0, l, cc, a.P1, a.P2, nA);
-        float mB = path_costs<GL, KPL>(LB, MB, r0 || c >= W - 1, l, cc, a.P1, a.P2, nB);
-        group_min4<GL>(mX, mV, mA, mB);
-        MX = mX;
-#pragma unroll
-        for (int k = 0; k < KPL; ++k) LX[k] = nX[k];
-        // this step's vectors for the row below (ring row index i + 1)
-        float* dstB = lds + OFF_B + slotB(u) * ER + (i + 1) * ES;
-        float* dstV = lds + OFF_V + slotV(u) * ER + (i + 1) * ES;
-        float* dstA = lds + OFF_A + slotA(u) * ER + (i + 1) * ES;
-#pragma unroll
-        for (int q = 0; q < KS / KV; ++q) {
-            float t[4], v[4], w[4];
-#pragma unroll
-            for (int e = 0; e < KV; ++e) {
-                const bool in = KV * q + e < KPL;
-                t[e] = in ? nV[in ? KV * q + e : 0] : 0.f;
-                v[e] = in ? nA[in ? KV * q + e : 0] : 0.f;
-                w[e] = in ? nB[in ? KV * q + e : 0] : 0.f;
-            }
-            if (KV == 4) {
-                *(float4*)(dstV + l * KS + 4 * q) = *(float4*)t;
-                *(float4*)(dstA + l * KS + 4 * q) = *(float4*)v;
-                *(float4*)(dstB + l * KS + 4 * q) = *(float4*)w;
-            } else {
-                *(float2*)(dstV + l * KS + 2 * q) = *(float2*)t;
-                *(float2*)(dstA + l * KS + 2 * q) = *(float2*)v;
-                *(float2*)(dstB + l * KS + 2 * q) = *(float2*)w;
-            }
-        }
-        if (l == 0) {
-            dstV[GL * KS] = mV;
-            dstA[GL * KS] = mA;
-            dstB[GL * KS] = mB;
-        }
-        // S, in the definition's order: the forward sweep adds its three downward paths and then the horizontal one, the sweep
-        // over the turned image its horizontal one first, then vertical, (-1,+1) [kernel predecessor c'+1], (-1,-1)
-        float acc[KPL];
-#pragma unroll
-        for (int k = 0; k < KPL; ++k) acc[k] = sslot[k];
-        auto add = [&](bool on, const float (&v)[KPL]) {
-            if (on) {
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + v[k];
-            }
-        };
-        if (!a.flip) {
-            add(a.dmask & 2, nV); add(a.dmask & 4, nA); add(a.dmask & 8, nB); add(a.dmask & 1, nX);
-        } else {
-            add(a.dmask & 1, nX); add(a.dmask & 2, nV); add(a.dmask & 8, nB); add(a.dmask & 4, nA);
-        }
-        if (a.epilogue) {
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                float sv = acc[k];
-                if (a.overcounting) sv = sv - 7.0f * cc[k];
-                if (a.is_max) sv = __uint_as_float(__float_as_uint(sv) ^ 0x80000000u);
-                acc[k] = was_nan(k) ? __uint_as_float(0x7fc00000u) : sv;
-            }
-        }
-        const unsigned poff = pix_off(u);
-        if (!WTA) {
-            buf_store<KPL>(rsS, poff == kOob ? kOob : poff + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
-        } else {
-            float vv[KPL];
-            float vmin = f_inf();
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                float v = a.is_max ? __uint_as_float(__float_as_uint(acc[k]) ^ 0x80000000u) : acc[k];
-                v = (was_nan(k) || k >= nv) ? f_inf() : v;
-                vv[k] = v;
-                vmin = fmin2(vmin, v);
-            }
-            vmin = fmin2(vmin, dpp<0x121>(vmin));
-            vmin = fmin2(vmin, dpp<0x122>(vmin));
-            vmin = fmin2(vmin, dpp<0x124>(vmin));
-            vmin = fmin2(vmin, dpp<0x128>(vmin));
-            if (GL >= 32) vmin = min_other_row(vmin);
-            if (GL == 64) vmin = min_other_half(vmin);
-            unsigned klo = 0xffffffffu;
-#pragma unroll
-            for (int k = KPL - 1; k >= 0; --k) klo = (vv[k] == vmin) ? (unsigned)(d0 + k) : klo;
-            auto umin_dpp = [&](unsigned o) { klo = o < klo ? o : klo; };
-            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x121, 0xf, 0xf, true));
-            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x122, 0xf, 0xf, true));
-            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x124, 0xf, 0xf, true));
-            umin_dpp((unsigned)__builtin_amdgcn_mov_dpp((int)klo, 0x128, 0xf, 0xf, true));
-            if (GL >= 32) klo = umin_other_row(klo);
-            if (GL == 64) klo = umin_other_half(klo);
-            const unsigned anyb = vmin != f_inf() ? 1u : 0u;
-            const int kw = (int)klo;
-            const int li = kw / KPL, kk = kw - li * KPL;
-            const float qnan = __uint_as_float(0x7fc00000u);
-            float prevv = dpp<0x138>(acc[KPL - 1]);
-            float nextv = dpp<0x130>(acc[0]);
-            float c0 = kk == 0 ? prevv : acc[0], c1 = acc[0], c2 = kk == KPL - 1 ? nextv : acc[0];
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                c1 = kk == k ? acc[k] : c1;
-                if (k > 0) c0 = kk == k ? acc[k - 1] : c0;
-                if (k < KPL - 1) c2 = kk == k ? acc[k + 1] : c2;
-            }
-            if (kw == 0) c0 = qnan;
-            if (kw >= D - 1) c2 = qnan;
-            const bool owner = (l == li);
-            const int cimg = pix_col(u);
-            const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.disp + (size_t)rbase * W), 0, (unsigned)NPW * (unsigned)W * 4u, kRsrcWord3);
-            const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(a.near + (size_t)rbase * W * 4), 0, (unsigned)NPW * (unsigned)W * 16u, kRsrcWord3);
-            const float dv = anyb ? (float)(a.d0 + (double)(unsigned)kw / (double)a.subpix) : a.invalid_disparity;
-            u32x4 nb;
-            nb.x = __float_as_uint(c0); nb.y = __float_as_uint(c1); nb.z = __float_as_uint(c2);
-            nb.w = anyb ? (unsigned)kw : 0xffffffffu;
-            const bool st = owner && cimg >= 0;
-            const unsigned pidx = row_px + (unsigned)(cimg >= 0 ? cimg : 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rsD, st ? pidx * 4u : kOob, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(nb, rsN, st ? pidx * 16u : kOob, 0, 0);
-        }
-        prefetch(cslot, sslot);
-        __syncthreads();
-    };
-
-    int u = 0;
-    bool dead = false;
-    for (; u + PF <= U && !dead; u += PF) {
-#pragma unroll
-        for (int v = 0; v < PF; ++v) {
-            if (!dead) {
-                step(u + v, cbuf[v], sbuf[v]);
-                dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((u + v) & 1)]) != 0;
-            }
-        }
-    }
-    if (dead) return;
-#pragma unroll
-    for (int v = 0; v < PF - 1; ++v) {
-        if (u + v < U && !dead) {
-            step(u + v, cbuf[v], sbuf[v]);
-            dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((u + v) & 1)]) != 0;
-        }
-    }
-}
-
 struct fam_shape {
     int gl, kpl, nw;
 };
@@ -1106,71 +630,6 @@ int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg
     return PMX_ERR_STATE;
 }
 
-// sweep schedule: the lane maps of the family schedule; a band is NW * 64 / GL rows (the rings of a band must fit the LDS)
-struct sweep_shape {
-    int gl, kpl, nw;
-};
-
-constexpr size_t sweep_lds_bytes(int gl, int kpl, int nw) {
-    return (size_t)(9 * (nw * (64 / gl) + 1) * (gl * (gl == 64 ? (kpl + 1) & ~1 : (kpl + 3) & ~3) + 4) + 4) * sizeof(float);
-}
-
-bool pick_sweep_shape(const pmx_ctx* ctx, int D, sweep_shape* out) {
-    static const int k16[] = {3, 5, 7, 9}, k32[] = {3, 5, 6, 9, 12};
-    sweep_shape f{0, 0, 4};
-    if (D <= 144) {
-        f.gl = 16;
-        for (int k : k16)
-            if (16 * k >= D) { f.kpl = k; break; }
-    } else if (D <= 384) {
-        f.gl = 32;
-        for (int k : k32)
-            if (32 * k >= D) { f.kpl = k; break; }
-    }
-    if (const char* e = pmx_opt(ctx, "SGM_SWEEP_SHAPE")) {  // test hook: "gl,kpl,nw"
-        int gl = 0, kpl = 0, nw = 0;
-        if (sscanf(e, "%d,%d,%d", &gl, &kpl, &nw) == 3 && gl * kpl >= D) f = sweep_shape{gl, kpl, nw};
-    }
-    if (!f.kpl || sweep_lds_bytes(f.gl, f.kpl, f.nw) > (size_t)160 * 1024) return false;
-    if (out) *out = f;
-    return true;
-}
-
-template <int GL, int KPL, int NW, bool WTA>
-int launch_sweep(pmx_ctx* ctx, const sweep_args& a, int nwg) {
-#ifdef SWEEP_PF
-    constexpr int PF = SWEEP_PF;
-#else
-    constexpr int PF = KPL > 12 ? 2 : 3;
-#endif
-    const size_t lds_bytes = sweep_lds_bytes(GL, KPL, NW);
-    auto kern = sgm_sweep_kernel<GL, KPL, NW, PF, WTA>;
-    PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 2) * 64), lds_bytes, ctx->stream, a);
-    PMX_HIP(hipGetLastError());
-    return PMX_OK;
-}
-
-int dispatch_sweep(pmx_ctx* ctx, const sweep_shape& f, const sweep_args& a, int nwg, bool wta) {
-#define PMX_SWEEP(GL, KPL)                                                                                      \
-    if (f.gl == GL && f.kpl == KPL && f.nw == 4)                                                                \
-        return wta ? launch_sweep<GL, KPL, 4, true>(ctx, a, nwg) : launch_sweep<GL, KPL, 4, false>(ctx, a, nwg);
-    PMX_SWEEP(16, 3)
-    PMX_SWEEP(16, 5)
-    PMX_SWEEP(16, 7)
-    PMX_SWEEP(16, 9)
-    PMX_SWEEP(32, 3)
-    PMX_SWEEP(32, 5)
-    PMX_SWEEP(32, 6)
-    PMX_SWEEP(32, 9)
-    PMX_SWEEP(32, 12)
-#undef PMX_SWEEP
-    if (f.gl == 64 && f.kpl == 5 && f.nw == 8) return wta ? launch_sweep<64, 5, 8, true>(ctx, a, nwg) : launch_sweep<64, 5, 8, false>(ctx, a, nwg);
-    if (f.gl == 32 && f.kpl == 5 && f.nw == 8) return wta ? launch_sweep<32, 5, 8, true>(ctx, a, nwg) : launch_sweep<32, 5, 8, false>(ctx, a, nwg);
-    pmx_set_error("pmx_sgm (sweep schedule): no kernel for lane map %dx%d", f.gl, f.kpl);
-    return PMX_ERR_STATE;
-}
-
 }  // namespace
 
 // The strip-to-strip hand-off buffer of the marching kernels (this file and k_sgmfam8.hip): at least `halo_bytes`, zeroed when
@@ -1241,54 +700,6 @@ int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float 
             if (rc) return rc;
         }
         // the error word travels to pinned host memory behind the launch; pmx_check_async_error reads it after a sync
-        PMX_HIP(hipMemcpyAsync(ctx->fam_err_host, ctx->fam_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    return PMX_OK;
-}
-
-bool pmx_sgm_sweep_supported(const pmx_ctx* ctx, const pmx_cv* cv) { return cv->H >= 2 && cv->W >= 2 && pick_sweep_shape(ctx, cv->D, nullptr); }
-
-// The two sweeps of the sweep schedule (sgm_sweep_kernel): `which` bit 0 = the forward sweep (paths 2, 3, 4, 0 of the direction
-// table), bit 1 = the sweep over the turned image (paths 1, 5, 6, 7); wta: the second sweep in WTA mode (S is not written).
-int pmx_launch_sgm_sweeps(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
-                          int mask, int which, const pmx_fam_wta* wta) {
-    sweep_shape f;
-    PMX_CHECK(pick_sweep_shape(ctx, cv->D, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (sweep schedule): D = %d not supported", cv->D);
-    const int BR = f.nw * (64 / f.gl);
-    const int NBD = (cv->H + BR - 1) / BR;
-    const int NG = 3 * f.gl * ((f.kpl + 2) / 3) + 1, NGP = (NG + 63) / 64 * 64;
-    const size_t halo_bytes = (size_t)NBD * cv->W * NGP * 16;
-    // kernel bits X, V, A, B of the two sweeps in the definition's direction table ((0,+1) (0,-1) (+1,0) (+1,+1) (+1,-1) (-1,0) (-1,+1) (-1,-1))
-    const int bits[2] = {((mask >> 0) & 1) | ((mask >> 2) & 1) << 1 | ((mask >> 3) & 1) << 2 | ((mask >> 4) & 1) << 3,
-                         ((mask >> 1) & 1) | ((mask >> 5) & 1) << 1 | ((mask >> 7) & 1) << 2 | ((mask >> 6) & 1) << 3};
-    for (int sw = 0; sw < 2; ++sw) {
-        if (!bits[sw] || !(which >> sw & 1)) continue;
-        if (int rcp = pmx_fam_prepare(ctx, halo_bytes)) return rcp;
-        sweep_args a;
-        a.C = cv->data;
-        a.S = S;
-        a.H = cv->H; a.W = cv->W; a.D = cv->D;
-        a.flip = sw;
-        a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
-        a.is_max = is_max; a.overcounting = overcounting;
-        a.has_sin = sw == 1 && bits[0] != 0;
-        a.epilogue = sw == 1 || bits[1] == 0;
-        a.dmask = bits[sw];
-        a.halo = (u32x4*)ctx->fam_halo;
-        a.epoch = pmx_fam_tag(++ctx->fam_epoch);
-        a.ctl = ctx->fam_ctl;
-        const bool use_wta = wta && sw == 1;
-        a.disp = use_wta ? wta->disp : nullptr;
-        a.near = use_wta ? wta->near : nullptr;
-        a.d0 = use_wta ? wta->d0 : 0.0;
-        a.subpix = use_wta ? wta->subpix : 1;
-        a.invalid_disparity = use_wta ? wta->invalid_disparity : 0.f;
-        PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));
-        {
-            pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY);
-            int rc = dispatch_sweep(ctx, f, a, NBD, use_wta);
-            if (rc) return rc;
-        }
         PMX_HIP(hipMemcpyAsync(ctx->fam_err_host, ctx->fam_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     }
     return PMX_OK;

@@ -31,7 +31,7 @@ extern "C" int pmx_device_count(void) {
 // ---- kernel-route / tuning options ---------------------------------------------------------------------------------------------------
 // Every name the library looks at (DESIGN 7b says what each one forces).  The ONE place the environment is read: pmx_create.
 static const char* const kPmxOptNames[] = {
-    "SGM_SCHED", "SGM_PAR", "SGM_HFUSED", "SGM_PENDING", "SGM_FAM_SHAPE", "SGM_SWEEP_SHAPE",
+    "SGM_SCHED", "SGM_PAR", "SGM_HFUSED", "SGM_PENDING", "SGM_FAM_SHAPE",
     "SGM8", "FUSED_MAP", "COST5", "WTA3", "SGM8_FAM", "SGM8_HPAIR", "SGM8_CODES", "SGM8_FAMCODES", "SGM8_OVERLAP", "SGM8_HF",
     "SGM8_FAM_NW", "SGM8_FAM_PRIO",
     "CBCA_ARMS_FLAT", "CBCA_ROWS", "CBCA_FAST", "CBCA_FUSE", "CBCA_MARCH", "CBCA_VBUF", "CBCA_SIGN", "CBCA_GEO", "CBCA_VBS",

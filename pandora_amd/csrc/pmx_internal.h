@@ -187,7 +187,7 @@ struct pmx_cv {
     // PMX_REPR_SGM_UP_PENDING: the partial sum volume (kept with the handle for the next pair) and what pmx_sgm was asked for
     float* spart = nullptr;
     size_t spart_bytes = 0;
-    struct { float P1, P2, invalid_cost; int is_max, overcounting, sweep; } pending = {0.f, 0.f, 0.f, 0, 0, 0};  // sweep: which schedule waits
+    struct { float P1, P2, invalid_cost; int is_max, overcounting; } pending = {0.f, 0.f, 0.f, 0, 0};
     size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
 };
 
@@ -289,9 +289,6 @@ int pmx_launch_mask_dilate(pmx_ctx* ctx, const int16_t* msk, int H, int W, int w
 int pmx_launch_fill_nan(pmx_ctx* ctx, float* p, size_t n);
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
 bool pmx_sgm_family_supported(const pmx_ctx* ctx, const pmx_cv* cv);
-bool pmx_sgm_sweep_supported(const pmx_ctx* ctx, const pmx_cv* cv);
-int pmx_launch_sgm_sweeps(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
-                          int mask, int which, const pmx_fam_wta* wta);
 // the six non-horizontal paths of `mask` as two fused marching passes adding into S (which already holds the horizontal ones)
 // fams: bit 0 the downward family, bit 1 the upward one.  wta != nullptr: the upward family (which must be the last pass) does not
 // write S but reduces over D (k_sgmfam.hip WTA mode)
