@@ -38,6 +38,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -584,6 +585,58 @@ def spawn_ranks(n, watchdog_s):
     return rc
 
 
+class HeadlineGuard:
+    """The line's headline must survive its riders: once the timed region is over, every rank arms this timer; if the extra legs
+    (the BASELINE configurations at N = 1, the row-tiled / D-sharded / pair-per-rank legs at N > 1) have not finished within
+    `budget_s`, rank 0 prints the line as far as it got - with the reason under `leg_errors` - and every rank leaves with status 0
+    (a rank stuck inside a collective cannot be unstuck from Python; the launcher's watchdog would otherwise take the line with it)."""
+
+    def __init__(self, rank, budget_s):
+        self.rank, self.budget_s = rank, budget_s
+        self.out, self.leg_errors = None, None
+        self.lock = threading.Lock()
+        self.done = False
+        self.timer = threading.Timer(budget_s, self._bail)
+        self.timer.daemon = True
+
+    def arm(self, out, leg_errors):
+        self.out, self.leg_errors = out, leg_errors
+        if self.budget_s > 0:
+            self.timer.start()
+
+    def _bail(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0 and self.out is not None:
+                line = dict(self.out)
+                errs = dict(self.leg_errors or {})
+                errs["(extra legs)"] = f"not finished within {self.budget_s:.0f} s of the timed region: dropped, the headline stands"
+                line["leg_errors"] = errs
+                try:
+                    text = json.dumps(line)
+                except (TypeError, ValueError):  # a half-built rider
+                    text = json.dumps({k: v for k, v in line.items() if k in HEADLINE_KEYS or k == "leg_errors"})
+                print(text, flush=True)
+            sys.stderr.write(f"bench.py: rank {self.rank}: extra legs over their budget of {self.budget_s:.0f} s; leaving\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+    def finish(self):
+        """True when the caller may print (the timer has not fired and never will)."""
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+            self.timer.cancel()
+            return True
+
+
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "stage_ms_per_step", "pipeline_hbm_frac")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -609,7 +662,10 @@ def main():
     ap.add_argument("--c4-dmax", type=int, default=256, help="last disparity of the row-tiled configs[3] leg (N>1; the tests shrink it)")
     ap.add_argument("--c5-height", type=int, default=10000, help="rows of the row-tiled configs[4] leg (N>1)")
     ap.add_argument("--c5-width", type=int, default=10000, help="columns of the row-tiled configs[4] leg (N>1)")
+    ap.add_argument("--extras-budget", type=float, default=900.0,
+                    help="seconds the extra legs / configurations may take after the timed region before the line is printed without them (0: no limit)")
     ap.add_argument("--watchdog", type=float, default=1200.0, help="seconds after which a self-launched multi-rank run is stopped")
+    ap.add_argument("--test-fail-rider", default=None, help="TEST HOOK: this rider of the line (c3_shape) raises")
     ap.add_argument("--test-die-rank", type=int, default=None, help="TEST HOOK: this rank exits with code 3 after the warm-up")
     ap.add_argument("--test-comm", default=None, metavar="MODULE:CLASS",
                     help="TEST HOOK: a pandora_amd.comm.Comm subclass from tests/ (e.g. tests.transports:TcpComm) that carries the "
@@ -692,9 +748,10 @@ def main():
     eng.set_profiling(False)
     gathered = eng.get_full_maps(H, want_itp=True) if comm is not None and rank == 0 else None  # the last step's maps, before anything else runs
     # The extra legs of an N > 1 run: a leg that fails (on any rank) is dropped from the line with its error, it does not take the
-    # headline with it.  (Every rank agrees on the outcome through one small reduction; a rank that hangs inside a collective is
-    # the launcher's watchdog's business.)
+    # headline with it.  (Every rank agrees on the outcome through one small reduction; a rank that hangs inside a collective
+    # is left behind by the HeadlineGuard's timer below, which prints the line as far as it got.)
     leg_errors = {}
+    out = None
 
     def leg(name, fn):
         err = None
@@ -709,18 +766,18 @@ def main():
             return None
         return res
 
-    dshard = weak = c5tiled = c4tiled = None
-    if comm is not None:
-        cv.free()  # (the extra legs bring their own volumes)
-    if comm is not None and not args.no_c5tiled:
-        c5tiled = leg("c5_row_tiled", lambda: row_tiled_leg(eng, comm, "c5", args.c5_height, args.c5_width, max(2, args.steps // 4), local_rank))
-    if comm is not None and not args.no_c4tiled:
-        c4tiled = leg("c4_row_tiled", lambda: row_tiled_leg(eng, comm, "c4", args.c4_height, args.c4_width, max(2, args.steps // 4), local_rank,
-                                                              c4_dmax=args.c4_dmax))
-    if comm is not None and not args.no_dshard and D >= 2 * world:
-        dshard = leg("d_sharded_exact", lambda: d_sharded_leg(eng, comm, L, R, dmin, dmax, 11, max(2, args.steps // 2), local_rank))
-    if comm is not None and not args.no_weak:
-        weak = leg("pair_per_rank", lambda: pair_per_rank_leg(comm, local_rank, H, W, dmin, dmax, win, P1, P2, max(2, args.steps // 2), rank, world))
+    class rider:  # a rider of the line that fails is dropped from it with its error; the headline stands
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, et, ev, tb):
+            if et is not None and issubclass(et, Exception):
+                leg_errors[self.name] = f"{et.__name__}: {ev}"[:300]
+                return True
+            return False
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -782,21 +839,40 @@ def main():
                 out["rccl_ranks"] = comm.nranks
             out["collective"] = {"kind": "ncclSend / ncclRecv group: owned rows of 3 maps to rank 0 (10 B/pixel, validity as uint16)",
                                  "ms_per_step": round(stage["collective"][0] / args.steps, 4), "bytes_per_step": H * W * 10}
+    # from here on nothing may take the line: a timer on every rank prints what there is and leaves (HeadlineGuard)
+    guard = HeadlineGuard(rank, args.extras_budget)
+    guard.arm(out, leg_errors)
+    dshard = weak = c5tiled = c4tiled = None
+    if comm is not None:
+        cv.free()  # (the extra legs bring their own volumes)
+    if comm is not None and not args.no_c5tiled:
+        c5tiled = leg("c5_row_tiled", lambda: row_tiled_leg(eng, comm, "c5", args.c5_height, args.c5_width, max(2, args.steps // 4), local_rank))
+    if comm is not None and not args.no_c4tiled:
+        c4tiled = leg("c4_row_tiled", lambda: row_tiled_leg(eng, comm, "c4", args.c4_height, args.c4_width, max(2, args.steps // 4), local_rank,
+                                                              c4_dmax=args.c4_dmax))
+    if comm is not None and not args.no_dshard and D >= 2 * world:
+        dshard = leg("d_sharded_exact", lambda: d_sharded_leg(eng, comm, L, R, dmin, dmax, 11, max(2, args.steps // 2), local_rank))
+    if comm is not None and not args.no_weak:
+        weak = leg("pair_per_rank", lambda: pair_per_rank_leg(comm, local_rank, H, W, dmin, dmax, win, P1, P2, max(2, args.steps // 2), rank, world))
+
+    if rank == 0:
+        if world > 1:
             # what arrived (outside the timed region): the gathered maps of the last step against ONE GPU doing the whole pair.
             # Tiles cut the SGM paths at their 40-row margin, like the reference's ROI tiling: a fraction of a percent of the pixels
             # near the seams may differ, everything else must be identical - anything else means the exchange is broken.
-            gd, gv, gi = gathered
-            one = Engine(local_rank)
-            one.set_images(L, R, 1)
-            cv1 = one.alloc_cv(D, dmin)
-            run_pipeline(one, cv1, win, P1, P2)
-            od, ov, oi = one.get_disparity(want_itp=True)
-            cv1.free()
-            one.close()
-            out["gathered_maps_vs_one_gpu"] = {
-                "disparity_identical": round(float(np.mean((gd == od) | (np.isnan(gd) & np.isnan(od)))), 6),
-                "validity_identical": round(float(np.mean(gv == ov)), 6),
-                "coefficient_identical": round(float(np.mean((gi == oi) | (np.isnan(gi) & np.isnan(oi)))), 6)}
+            with rider("gathered_maps_vs_one_gpu"):
+                gd, gv, gi = gathered
+                one = Engine(local_rank)
+                one.set_images(L, R, 1)
+                cv1 = one.alloc_cv(D, dmin)
+                run_pipeline(one, cv1, win, P1, P2)
+                od, ov, oi = one.get_disparity(want_itp=True)
+                cv1.free()
+                one.close()
+                out["gathered_maps_vs_one_gpu"] = {
+                    "disparity_identical": round(float(np.mean((gd == od) | (np.isnan(gd) & np.isnan(od)))), 6),
+                    "validity_identical": round(float(np.mean(gv == ov)), 6),
+                    "coefficient_identical": round(float(np.mean((gi == oi) | (np.isnan(gi) & np.isnan(oi)))), 6)}
             if dshard is not None:
                 out["d_sharded_exact"] = dshard
             if weak is not None:
@@ -814,94 +890,106 @@ def main():
                                      "note": "pmx_set_images (2 float32 images up) + pipeline + pmx_get_disparity (disp, validity "
                                              "int64, itp down); informational only"}
             cv.free()
-            if not args.no_c3 and (H, W, D) != (2048, 2048, 129):
-                ms3, st3, _ = measure_shape(eng, 2048, 2048, 0, 128, args.steps, args.warmup, 20260928)
-                pcie3 = st3.pop("(pcie inclusive)")[0]
-                c3 = 2048 * 2048 * 129
-                r3 = roofline_block(st3, args.steps, c3)
-                if st3["sgm_fused"][1] > 0:
-                    add_traffic(r3, "c3", 2048, 2048, 129)
-                out["c3_shape"] = {"workload": "2048x2048 synthetic pair, d=[0,128] (D=129): BASELINE configs[2], the round-1 headline; same "
-                                               "pipeline and protocol", "steps": args.steps, "ms_per_step": round(ms3, 3),
-                                   "value": round(c3 / ms3 / 1e3, 1), "unit": "Mdisp/s", "roofline": r3,
-                                   "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in st3.items()},
-                                   "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "pcie_inclusive_ms": round(pcie3, 3)}
+            with rider("c3_shape"):
+                if args.test_fail_rider == "c3_shape":
+                    raise RuntimeError("test hook: --test-fail-rider")
+                if not args.no_c3 and (H, W, D) != (2048, 2048, 129):
+                    ms3, st3, _ = measure_shape(eng, 2048, 2048, 0, 128, args.steps, args.warmup, 20260928)
+                    pcie3 = st3.pop("(pcie inclusive)")[0]
+                    c3 = 2048 * 2048 * 129
+                    r3 = roofline_block(st3, args.steps, c3)
+                    if st3["sgm_fused"][1] > 0:
+                        add_traffic(r3, "c3", 2048, 2048, 129)
+                    out["c3_shape"] = {"workload": "2048x2048 synthetic pair, d=[0,128] (D=129): BASELINE configs[2], the round-1 headline; same "
+                                                   "pipeline and protocol", "steps": args.steps, "ms_per_step": round(ms3, 3),
+                                       "value": round(c3 / ms3 / 1e3, 1), "unit": "Mdisp/s", "roofline": r3,
+                                       "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in st3.items()},
+                                       "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "pcie_inclusive_ms": round(pcie3, 3)}
             if not args.no_configs and (H, W, D) == (4096, 4096, 257):
                 # the headline step on plain hipMalloc buffers (what a plugin user gets who does not call pmx_set_placement_trials), or -
                 # when `value` itself was measured that way - on a context that probes `--tuned-trials` candidates per volume:
-                if args.placement_trials > 1:
-                    plain = Engine(local_rank)
-                    msd, std, _ = measure_shape(plain, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
-                    out["default_allocation"] = {"placement_trials": 1, "ms_per_step": round(msd, 3), "value": round(cells / msd / 1e3, 1),
-                                                 "unit": "Mdisp/s", "note": "same workload and protocol on a fresh context with plain hipMalloc"}
-                    out["value_default_allocation"] = out["default_allocation"]["value"]
-                    plain.close()
-                elif args.tuned_trials > 1:
-                    tuned = Engine(local_rank)
-                    tuned.set_placement_trials(args.tuned_trials)
-                    mst, _, _ = measure_shape(tuned, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
-                    out["placement_tuned"] = {"placement_trials": args.tuned_trials, "ms_per_step": round(mst, 3),
-                                              "value": round(cells / mst / 1e3, 1), "unit": "Mdisp/s",
-                                              "note": "same workload and protocol on a fresh context with pmx_set_placement_trials (opt-in)"}
-                    tuned.close()
+                with rider("default_allocation"):
+                    if args.placement_trials > 1:
+                        plain = Engine(local_rank)
+                        msd, std, _ = measure_shape(plain, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
+                        out["default_allocation"] = {"placement_trials": 1, "ms_per_step": round(msd, 3), "value": round(cells / msd / 1e3, 1),
+                                                     "unit": "Mdisp/s", "note": "same workload and protocol on a fresh context with plain hipMalloc"}
+                        out["value_default_allocation"] = out["default_allocation"]["value"]
+                        plain.close()
+                    elif args.tuned_trials > 1:
+                        tuned = Engine(local_rank)
+                        tuned.set_placement_trials(args.tuned_trials)
+                        mst, _, _ = measure_shape(tuned, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
+                        out["placement_tuned"] = {"placement_trials": args.tuned_trials, "ms_per_step": round(mst, 3),
+                                                  "value": round(cells / mst / 1e3, 1), "unit": "Mdisp/s",
+                                                  "note": "same workload and protocol on a fresh context with pmx_set_placement_trials (opt-in)"}
+                        tuned.close()
                 # BASELINE configs[3] and configs[4] as stated, float32 between the steps, one GPU
                 eng.set_placement_trials(1)  # (six candidates of a 51.6 GB volume would not fit the device)
-                out["c4_as_stated"] = config_leg(eng, L, R, dmin, dmax, ("zncc", 11), False, 3,
-                                                 "BASELINE configs[3] as stated: 4096x4096 synthetic pair, d=[0,256] (D=257), ZNCC 11x11 + SGM 8-path "
-                                                 "+ WTA + vfit, float32 cost volume between the steps; one GPU", "c4")
+                with rider("c4_as_stated"):
+                    out["c4_as_stated"] = config_leg(eng, L, R, dmin, dmax, ("zncc", 11), False, 3,
+                                                     "BASELINE configs[3] as stated: 4096x4096 synthetic pair, d=[0,256] (D=257), ZNCC 11x11 + SGM 8-path "
+                                                     "+ WTA + vfit, float32 cost volume between the steps; one GPU", "c4")
                 # BASELINE configs[1] on the reference's own cones pair (tests/golden/cones: data, not code): census + CBCA + SGM + WTA +
                 # vfit, d = [-60, 0] as data_samples/json_conf_files/a_semi_global_matching.json has it for this pair
-                cones_dir = os.path.join(ROOT, "tests", "golden", "cones")
-                if os.path.exists(os.path.join(cones_dir, "left.png")):
-                    from PIL import Image
+                with rider("c2_cones"):
+                    cones_dir = os.path.join(ROOT, "tests", "golden", "cones")
+                    if os.path.exists(os.path.join(cones_dir, "left.png")):
+                        from PIL import Image
 
-                    Lc = np.array(Image.open(os.path.join(cones_dir, "left.png"))).astype(np.float32)
-                    Rc = np.array(Image.open(os.path.join(cones_dir, "right.png"))).astype(np.float32)
-                    out["c2_cones"] = config_leg(eng, Lc, Rc, -60, 0, ("census", 5), True, 20,
-                                                 "BASELINE configs[1]: the cones pair (375x450), d=[-60,0] (D=61), Census 5x5 + CBCA + SGM 8-path "
-                                                 "+ WTA + vfit; one GPU (a launch-latency-sized problem: 10.3 M cells)", "c2")
-                L5, R5 = synthetic_pair(10000, 10000, -64, 64)
-                out["c5_as_stated"] = config_leg(eng, L5, R5, -64, 64, ("census", 5), True, 2,
-                                                 "BASELINE configs[4], fine scale, as stated: 10000x10000 synthetic pair, d=[-64,64] (D=129), "
-                                                 "Census 5x5 + CBCA + SGM 8-path + WTA + vfit, float32 cost volume between the steps; the whole "
-                                                 "strip on one GPU", "c5")
-                del L5, R5
-            if args.cpu_rows > 0:  # the CPU legs belong to the N=1 line only
-                rows = min(args.cpu_rows, H)
-                base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)
-                out["cpu_baseline"] = base
-                # all host cores: probe on a short strip first, so that a box whose cores are not really available (container
-                # quota, oversubscription) costs seconds, not minutes; the full strip only when the threads pay off
-                probe_rows = min(rows, 64)
-                probe, _ = cpu_baseline(L, R, dmin, dmax, win, P1, P2, probe_rows, threads=0)
-                if probe["value"] > 1.5 * base["value"]:
-                    out["cpu_baseline_all_cores"], (mdisp, mval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows, threads=0)
-                    assert np.array_equal(mdisp, cdisp, equal_nan=True) and np.array_equal(mval, cval)  # thread count changes nothing
-                else:
-                    out["cpu_baseline_all_cores"] = probe
-                refc = cpu_reference_compiled(L, R, dmin, dmax, win, min(rows, 256))
-                if refc is not None:
-                    out["cpu_baseline_reference_compiled"] = refc
-                # parity in the same run: the same strip through the GPU path (vertical paths see only the strip, so the GPU is
-                # re-run on the strip alone)
-                eng2 = Engine(local_rank)
-                eng2.set_images(L[:rows], R[:rows], 1)
-                cv2 = eng2.alloc_cv(D, dmin)
-                eng2.census(cv2, win)
-                eng2.sgm(cv2, P1, P2, False, float(win * win + 1), False)
-                eng2.set_validity(None)
-                eng2.wta(cv2, False, -9999.0)
-                gdisp, gval = eng2.get_disparity()
-                out["disparity_linf_vs_cpu"] = float(np.max(np.abs(gdisp - cdisp)))
-                eng2.close()
+                        Lc = np.array(Image.open(os.path.join(cones_dir, "left.png"))).astype(np.float32)
+                        Rc = np.array(Image.open(os.path.join(cones_dir, "right.png"))).astype(np.float32)
+                        out["c2_cones"] = config_leg(eng, Lc, Rc, -60, 0, ("census", 5), True, 20,
+                                                     "BASELINE configs[1]: the cones pair (375x450), d=[-60,0] (D=61), Census 5x5 + CBCA + SGM 8-path "
+                                                     "+ WTA + vfit; one GPU (a launch-latency-sized problem: 10.3 M cells)", "c2")
+                with rider("c5_as_stated"):
+                    L5, R5 = synthetic_pair(10000, 10000, -64, 64)
+                    out["c5_as_stated"] = config_leg(eng, L5, R5, -64, 64, ("census", 5), True, 2,
+                                                     "BASELINE configs[4], fine scale, as stated: 10000x10000 synthetic pair, d=[-64,64] (D=129), "
+                                                     "Census 5x5 + CBCA + SGM 8-path + WTA + vfit, float32 cost volume between the steps; the whole "
+                                                     "strip on one GPU", "c5")
+                    del L5, R5
+            with rider("cpu_baseline"):
+                if args.cpu_rows > 0:  # the CPU legs belong to the N=1 line only
+                    rows = min(args.cpu_rows, H)
+                    base, (cdisp, cval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows)
+                    out["cpu_baseline"] = base
+                    # all host cores: probe on a short strip first, so that a box whose cores are not really available (container
+                    # quota, oversubscription) costs seconds, not minutes; the full strip only when the threads pay off
+                    probe_rows = min(rows, 64)
+                    probe, _ = cpu_baseline(L, R, dmin, dmax, win, P1, P2, probe_rows, threads=0)
+                    if probe["value"] > 1.5 * base["value"]:
+                        out["cpu_baseline_all_cores"], (mdisp, mval) = cpu_baseline(L, R, dmin, dmax, win, P1, P2, rows, threads=0)
+                        assert np.array_equal(mdisp, cdisp, equal_nan=True) and np.array_equal(mval, cval)  # thread count changes nothing
+                    else:
+                        out["cpu_baseline_all_cores"] = probe
+                    refc = cpu_reference_compiled(L, R, dmin, dmax, win, min(rows, 256))
+                    if refc is not None:
+                        out["cpu_baseline_reference_compiled"] = refc
+                    # parity in the same run: the same strip through the GPU path (vertical paths see only the strip, so the GPU is
+                    # re-run on the strip alone)
+                    eng2 = Engine(local_rank)
+                    eng2.set_images(L[:rows], R[:rows], 1)
+                    cv2 = eng2.alloc_cv(D, dmin)
+                    eng2.census(cv2, win)
+                    eng2.sgm(cv2, P1, P2, False, float(win * win + 1), False)
+                    eng2.set_validity(None)
+                    eng2.wta(cv2, False, -9999.0)
+                    gdisp, gval = eng2.get_disparity()
+                    out["disparity_linf_vs_cpu"] = float(np.max(np.abs(gdisp - cdisp)))
+                    eng2.close()
+        if world == 1 and leg_errors:
+            out["leg_errors"] = leg_errors
         if "value_default_allocation" in out:  # (right behind `value`: the two figures a reader should see together)
             out = {k: v for kk in out if kk != "value_default_allocation" for k, v in
                    ([(kk, out[kk])] + ([("value_default_allocation", out["value_default_allocation"])] if kk == "value" else []))}
-        print(json.dumps(out), flush=True)
+        if guard.finish():
+            print(json.dumps(out), flush=True)
     if comm is not None:
         comm.barrier()
         comm.close()
+    guard.finish()
     eng.close()
 
 

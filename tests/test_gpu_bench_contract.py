@@ -150,3 +150,36 @@ def test_bench_prices_the_integer_route_against_its_own_format():
     r = d["roofline"]
     assert r["peak"] == 8000.0 and 2000.0 < r["peak_measured"] < 8000.0 and set(r["peak_measured_streams"]) == {"read", "write", "copy"}
     assert abs(r["frac_of_measured"] - r["achieved"] / r["peak_measured"]) < 1e-3
+
+
+def test_the_headline_survives_extra_legs_that_do_not_finish():
+    """bench.py --extras-budget: when the riders of the line (the BASELINE configurations at N = 1, the row-tiled legs at N > 1)
+    are not done within the budget after the timed region, rank 0 prints the line as far as it got - the headline whole, the reason
+    under leg_errors - and every rank leaves with status 0.  A budget of a few milliseconds makes that happen on purpose."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--height", "192",
+                          "--width", "256", "--dmax", "40", "--cpu-rows", "64", "--extras-budget", "0.005"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "300",
+                          "--width", "256", "--dmax", "40", "--placement-trials", "1", "--no-dshard", "--no-weak", "--c5-height", "640",
+                          "--c5-width", "700", "--c4-height", "400", "--c4-width", "320", "--c4-dmax", "40", "--extras-budget", "0.005",
+                          "--test-comm", "tests.transports:TcpComm", "--test-device", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    for out, n in ((one, 1), (two, 2)):
+        assert out.returncode == 0, out.stderr[-1500:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, out.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["value"] > 0 and d["ms_per_step"] > 0 and d["roofline"]["achieved"] > 0
+        assert "(extra legs)" in d["leg_errors"], d["leg_errors"]
+        assert "over their budget" in out.stderr
+
+
+def test_a_failing_rider_leaves_the_line():
+    """a configuration leg that raises is dropped from the line with its error; the headline and the other riders stay"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--height", "192",
+                          "--width", "256", "--dmax", "40", "--cpu-rows", "64", "--test-fail-rider", "c3_shape"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-1500:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert "c3_shape" not in d and "test hook" in d["leg_errors"]["c3_shape"] and d["cpu_baseline"]["value"] > 0, d.get("leg_errors")
