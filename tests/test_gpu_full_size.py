@@ -11,7 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SIZES = {"C3": (2048, 2048, 0, 128), "C4": (4096, 4096, 0, 256), "C5": (10000, 10000, -64, 64)}
+SIZES = {"C3": (2048, 2048, 0, 128), "C4": (4096, 4096, 0, 256), "C5": (10000, 10000, -64, 64),
+         "X16K": (16384, 16384, 0, 64)}  # beyond BASELINE: 1.74e10 cells, float32 volumes of 69.8 GB
 P1, P2, WIN = 8.0, 32.0, 5
 
 
@@ -59,7 +60,7 @@ def census_sgm_maps(eng, L, R, dmin, dmax, lazy):
     return out
 
 
-@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+@pytest.mark.parametrize("name", ["C3", "C4", "C5", "X16K"])
 def test_integer_and_float_paths_agree_at_full_size(eng, name):
     H, W, dmin, dmax = SIZES[name]
     L, R = big_pair(name)
