@@ -33,6 +33,9 @@ block (its dominant kernel family), and `default_allocation` / `value_default_al
 buffers, what a caller gets who does not opt into pmx_set_placement_trials; `value` is measured with six candidates per volume, chosen
 before the warm-up - on some boxes the two differ by 10 %).  `roofline.peak_measured` is what plain
 streaming kernels reach on the box in the same run (pmx_measure_hbm), beside `peak` = the data sheet's 8000 GB/s.
+The headline part of the line is complete when the timed region ends; everything after it is a rider: one that raises is dropped
+from the line with its error (`leg_errors`), and if the riders are not done `--extras-budget` seconds later (a rank stuck in a
+collective of an extra leg) the line is printed as far as it got and every rank leaves with status 0 (HeadlineGuard).
 """
 import argparse
 import json
