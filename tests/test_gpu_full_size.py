@@ -129,14 +129,3 @@ def test_bottom_strip_equals_oracle_at_c4_size(eng, oracle, method, win):
         for a, b in zip(got, exp):
             np.testing.assert_array_equal(a, b)
 
-
-def test_beyond_the_baseline_sizes_family_form_against_eight_volumes(eng):
-    """A pair larger than every BASELINE configuration - 16384 x 16384, d = [0, 64]: 1.74e10 cells, byte volumes of 17.4 GB, cell
-    indices far beyond 2^32 - through the integer path's two independent kernel families (three direction-family volumes / eight
-    path volumes: 140 GB): identical maps bit for bit."""
-    from bench import synthetic_pair
-    from tests.test_gpu_fam8 import _family_against_eight_volumes
-
-    eng.set_lazy(True)
-    _PAIRS.clear()
-    _family_against_eight_volumes(eng, synthetic_pair, 16384, 16384, 0, 64)
