@@ -82,6 +82,12 @@ int pmx_set_placement_trials(pmx_ctx* ctx, int trials);
  * memcpy/triad on the box and report both"): a 16-byte-per-lane fill, read and copy of `bytes` (two buffers of that size are allocated
  * and freed), best of three passes each; copy counts read + written bytes.  bench.py's roofline.peak_measured. */
 int pmx_measure_hbm(pmx_ctx* ctx, size_t bytes, double* read_gbs, double* write_gbs, double* copy_gbs);
+/* Gives the device memory a context keeps between calls back to the driver (no reference counterpart: the reference's buffers are
+ * numpy arrays that die with their last reference): the cache of freed volumes, the SGM accumulator volume and the hand-off buffer
+ * of the marching kernels - after a 16384 x 16384 x 65 float32 run that is ~100 GB.  Everything comes back on demand; cost volume
+ * handles, the resident pair and result maps are untouched.  free_bytes / total_bytes (either may be NULL): the device's memory
+ * after the release (hipMemGetInfo). */
+int pmx_release_caches(pmx_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* Kernel-route and tuning options of a context (no reference counterpart; the list with meanings: DESIGN.md 7b).  By default the
  * library chooses every kernel from the call's arguments alone.  An option forces a choice - what the parity tests use to drive every
  * route on small inputs, and the A/B scripts under tools/.  `name` is one of the known names ("SGM8_FAM", "SGM_SCHED", "CBCA_FAST",

@@ -101,6 +101,7 @@ SIGNATURES = {
     "pmx_debug_small_division": (C.c_int, [vp, C.POINTER(C.c_uint)]),
     "pmx_set_placement_trials": (C.c_int, [vp, C.c_int]),
     "pmx_measure_hbm": (C.c_int, [vp, C.c_size_t, c_double_p, c_double_p, c_double_p]),
+    "pmx_release_caches": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "pmx_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmx_reset_stage_times": (C.c_int, [vp]),
     "pmx_stage_time": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),

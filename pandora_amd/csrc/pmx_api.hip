@@ -333,6 +333,28 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restric
     for (; i < n; i += step) dst[i] = src[i];
 }
 
+extern "C" int pmx_release_caches(pmx_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    PMX_CHECK(ctx, PMX_ERR_ARG, "pmx_release_caches: no context");
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) PMX_HIP(hipStreamSynchronize(ctx->aux_stream));
+    pmx_pool_free(ctx, ctx->scratch);  // (the SGM accumulator: pmx_need_scratch brings it back)
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    pmx_pool_release(ctx);
+    if (ctx->fam_halo) {  // pmx_fam_prepare allocates and zeroes a new one, epochs start over
+        PMX_HIP(hipFree(ctx->fam_halo));
+        ctx->fam_halo = nullptr;
+        ctx->fam_halo_bytes = 0;
+        ctx->fam_epoch = 0;
+    }
+    size_t f = 0, t = 0;
+    PMX_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return PMX_OK;
+}
+
 extern "C" int pmx_measure_hbm(pmx_ctx* ctx, size_t bytes, double* read_gbs, double* write_gbs, double* copy_gbs) {
     PMX_CHECK(ctx && bytes >= ((size_t)1 << 20), PMX_ERR_ARG, "pmx_measure_hbm: a context and at least 1 MB");
     PMX_HIP(hipSetDevice(ctx->device));

@@ -288,6 +288,13 @@ class Engine:
         check(_lib.lib().pmx_measure_hbm(self.ctx, int(nbytes), C.byref(r), C.byref(w), C.byref(c)), "pmx_measure_hbm")
         return {"read": r.value, "write": w.value, "copy": c.value}
 
+    def release_caches(self):
+        """Gives the memory the context keeps between calls (freed volumes, the SGM accumulator, the marching kernels' hand-off
+        buffer) back to the driver; returns (free, total) bytes of the device afterwards (pmx_release_caches)."""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        check(_lib.lib().pmx_release_caches(self.ctx, C.byref(f), C.byref(t)), "pmx_release_caches")
+        return f.value, t.value
+
     def set_lazy(self, on):
         """Lazy exact representations of the volume (default on); off = always float32 (reference-like)."""
         check(_lib.lib().pmx_set_lazy(self.ctx, int(bool(on))), "pmx_set_lazy")

@@ -53,3 +53,55 @@ def test_a_forced_route_is_the_one_that_runs(oracle):
             cv.free()
     finally:
         e.close()
+
+
+def test_release_caches_returns_the_memory_and_changes_nothing():
+    """pmx_release_caches: after a float32 SGM run the context holds an accumulator volume, freed volumes and the marching kernels'
+    hand-off buffer; releasing them gives the bytes back to the driver, and the next run (which allocates them again, hand-off
+    epochs starting over) gives the same result bit for bit."""
+    import numpy as np
+
+    from pandora_amd.engine import Engine
+
+    eng = Engine(0)
+    eng.set_lazy(False)
+    try:
+        rng = np.random.default_rng(5)
+        H, W, D = 600, 3600, 40  # wide enough for the family schedule (hand-off buffer)
+        cvh = (rng.random((H, W, D)) * 40).astype(np.float32)
+        z = np.zeros((H, W), np.float32)
+
+        def run():
+            eng.set_images(z, z, 1)
+            cv = eng.alloc_cv(D, 0)
+            cv.from_host(cvh)
+            eng.set_option("SGM_SCHED", "fam")
+            eng.sgm(cv, 1.5, 7.25, False, 45.0, False)
+            eng.set_option("SGM_SCHED", None)
+            out = cv.to_host()
+            cv.free()
+            return out
+
+        first = run()
+        eng.sync()
+        held, total = eng.release_caches()
+        again, _ = eng.release_caches()  # (idempotent)
+        assert again >= held - (64 << 20)
+        second = run()
+        before, _ = eng.release_caches()
+        np.testing.assert_array_equal(first, second)
+        # the volume (346 MB), its accumulator and the hand-off buffer were held between the calls: releasing must have freed at least
+        # the two volumes' worth
+        import ctypes as C
+
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        third = run()
+        np.testing.assert_array_equal(first, third)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemGetInfo(C.byref(f), C.byref(t))
+        busy = f.value
+        freed, _ = eng.release_caches()
+        assert freed - busy >= 2 * cvh.nbytes, (freed, busy, cvh.nbytes)
+        assert total > 0 and abs(freed - before) < (256 << 20)
+    finally:
+        eng.close()
