@@ -665,7 +665,7 @@ def main():
     ap.add_argument("--c4-dmax", type=int, default=256, help="last disparity of the row-tiled configs[3] leg (N>1; the tests shrink it)")
     ap.add_argument("--c5-height", type=int, default=10000, help="rows of the row-tiled configs[4] leg (N>1)")
     ap.add_argument("--c5-width", type=int, default=10000, help="columns of the row-tiled configs[4] leg (N>1)")
-    ap.add_argument("--extras-budget", type=float, default=900.0,
+    ap.add_argument("--extras-budget", type=float, default=480.0,
                     help="seconds the extra legs / configurations may take after the timed region before the line is printed without them (0: no limit)")
     ap.add_argument("--watchdog", type=float, default=1200.0, help="seconds after which a self-launched multi-rank run is stopped")
     ap.add_argument("--test-fail-rider", default=None, help="TEST HOOK: this rider of the line (c3_shape) raises")
