@@ -146,6 +146,26 @@ def test_zncc_marching_kernel_strips_tiles_chunks(eng, oracle, H, W, dmin, dmax,
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("win", [5, 11, 15])
+def test_zncc_constant_patch_below_bright_rows(eng, oracle, win):
+    """window_stats_kernel keeps the sums of the window's rows in a register ring while the window moves down a strip of 8 / 32
+    output rows (direct sums for the uncommon windows): a constant patch - std exactly 0, zncc exactly 0 (zncc.py:273-277) -
+    directly below rows four decimal orders brighter, non-integer values, several strips.  (A window sum that SLID down - minus
+    the row that leaves, plus the row that enters - would carry the bright rows' rounding into the patch and fail here.)"""
+    H, W, dmin, dmax = 90, 130, -4, 5
+    L, R = pair(H, W, seed=win, integer=False)
+    L[:30] *= 1.0e4
+    R[:30] *= 1.0e4
+    L[30:70, 20:90] = 7.0  # (7 and 1234.5 have exact float32 squares: the direct sums give a variance of exactly 0)
+    R[40:80, 10:70] = 1234.5
+    got = gpu_cv(eng, "zncc", L, R, dmin, dmax, 1, win).to_host()
+    exp = cpu_cv(oracle, "zncc", L, R, dmin, dmax, 1, win)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-5)
+    o = win // 2
+    assert np.all(got[30 + o:70 - o, 20 + o:90 - o][~np.isnan(got[30 + o:70 - o, 20 + o:90 - o])] == 0.0)
+
+
 def test_masks_and_variable_disparity_grids(eng, oracle):
     H, W, dmin, dmax, sp, win = 28, 41, -5, 4, 2, 5
     L, R = pair(H, W, seed=99)
