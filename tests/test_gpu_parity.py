@@ -124,7 +124,8 @@ def test_sad_ssd_register_window_kernel_blocks(eng, oracle, method, H, W, dmin, 
 
 
 @pytest.mark.parametrize("integer", [True, False])
-@pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [(30, 44, -6, 3, 1, 5), (18, 33, -2, 2, 2, 3), (26, 40, 0, 5, 1, 11), (14, 30, -3, 0, 4, 5)])
+@pytest.mark.parametrize("H,W,dmin,dmax,sp,win", [(30, 44, -6, 3, 1, 5), (18, 33, -2, 2, 2, 3), (26, 40, 0, 5, 1, 11), (14, 30, -3, 0, 4, 5),
+                                                  (20, 70, 0, 16, 2, 5), (16, 64, -3, 5, 4, 3), (22, 90, -20, 13, 1, 7)])  # (33 / 33 / 34 cost indices)
 def test_zncc(eng, oracle, integer, H, W, dmin, dmax, sp, win):
     L, R = pair(H, W, seed=5 * H + W, integer=integer)
     L[2:8, 3:12] = 7.0  # constant patch: std = 0 -> zncc must be exactly 0 (zncc.py:273-277)
@@ -135,10 +136,12 @@ def test_zncc(eng, oracle, integer, H, W, dmin, dmax, sp, win):
 
 
 @pytest.mark.parametrize("H,W,dmin,dmax,win", [(150, 530, -20, 37, 11), (70, 260, 3, 12, 3), (130, 300, -9, -1, 1),
-                                               (66, 249, -300, -240, 5), (65, 247, 240, 262, 7), (80, 300, -5, 6, 15)])
+                                               (66, 249, -300, -240, 5), (65, 247, 240, 262, 7), (80, 300, -5, 6, 15),
+                                               (70, 200, -3, 61, 11), (67, 150, 0, 128, 5), (40, 120, -70, -5, 9)])
 def test_zncc_marching_kernel_strips_tiles_chunks(eng, oracle, H, W, dmin, dmax, win):
     """subpix == 1 takes the sliding kernel: several row strips (64 rows), column tiles (256 - 2o outputs), disparity
-    chunks of 8 with a ragged last chunk, ranges that leave the image entirely; non-integer images."""
+    chunks of 8 with a ragged last chunk, ranges that leave the image entirely; non-integer images.  The last three have
+    32 n + 1 / 32 n + 2 disparities: a last block of four wavefronts for one or two cost indices per pixel."""
     L, R = pair(H, W, seed=H + W, integer=False)
     got = gpu_cv(eng, "zncc", L, R, dmin, dmax, 1, win).to_host()
     exp = cpu_cv(oracle, "zncc", L, R, dmin, dmax, 1, win)
