@@ -84,6 +84,8 @@ STAGES = "--stages" in sys.argv
 if __name__ == "__main__":
     want = [a for a in sys.argv[1:] if not a.startswith("--")]
     eng = Engine(0)
+    if os.environ.get("PMX_BENCH_TRIALS"):  # candidates per volume-sized buffer (pmx_set_placement_trials)
+        eng.set_placement_trials(int(os.environ["PMX_BENCH_TRIALS"]))
     out = {}
     for name, fn in CONFIGS.items():
         if want and name.split()[0] not in want:
