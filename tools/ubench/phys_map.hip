@@ -4,6 +4,7 @@
 //   phys_map [chunk_mb=1024] [n_chunks=240] [interleave_mb=2]
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -76,7 +77,22 @@ int main(int argc, char** argv) {
         (void)hipDeviceSynchronize();
         (void)hipMemUnmap(va, chunk);
     }
-    for (int i = 0; i < nchunks; ++i) printf("chunk %3d  read %5.0f  fill %5.0f GB/s\n", i, rd[i], wr[i]);
+    // a second pass over the same chunks: is a chunk's rate its own (the two passes agree) or noise?
+    std::vector<float> rd2(nchunks), wr2(nchunks);
+    for (int i = 0; i < nchunks; ++i) {
+        if (hipMemMap(va, chunk, 0, hs[i], 0) != hipSuccess || hipMemSetAccess(va, chunk, &acc, 1) != hipSuccess) { printf("map %d failed\n", i); return 1; }
+        rates(va, chunk, &rd2[i], &wr2[i]);
+        (void)hipDeviceSynchronize();
+        (void)hipMemUnmap(va, chunk);
+    }
+    for (int i = 0; i < nchunks; ++i) printf("chunk %3d  read %5.0f %5.0f  fill %5.0f %5.0f GB/s\n", i, rd[i], rd2[i], wr[i], wr2[i]);
+    {
+        double mx = 0, my = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int i = 0; i < nchunks; ++i) { mx += rd[i]; my += rd2[i]; }
+        mx /= nchunks; my /= nchunks;
+        for (int i = 0; i < nchunks; ++i) { sxx += (rd[i] - mx) * (rd[i] - mx); syy += (rd2[i] - my) * (rd2[i] - my); sxy += (rd[i] - mx) * (rd2[i] - my); }
+        printf("correlation of the two read passes over the chunks: %.3f\n", sxy / sqrt(sxx * syy + 1e-30));
+    }
     // a range of 4 chunks: neighbours in allocation order against chunks taken a quarter of the device apart
     if (nchunks >= 16) {
         void* va4 = nullptr;
