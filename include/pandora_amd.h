@@ -74,7 +74,7 @@ int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_t* msk_righ
 int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, const double* disp_max);
 
 /* Opt-in placement-aware allocation (no reference counterpart: the reference works in host memory).  For every NEW buffer of 256 MB
- * or more the context allocates up to `trials` candidates, times one streaming read of each and keeps the fastest: on MI355X the
+ * or more the context allocates up to `trials` candidates, times one streaming fill and read of each and keeps the fastest: on MI355X the
  * bandwidth of a hipMalloc'd buffer depends on where the driver placed it.  One-time cost of a few hundred ms per
  * buffer size; cached buffers are reused as they are.  trials = 1 (default) switches it off. */
 int pmx_set_placement_trials(pmx_ctx* ctx, int trials);

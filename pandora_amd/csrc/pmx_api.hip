@@ -290,7 +290,7 @@ extern "C" void* pmx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nu
 // On MI355X the bandwidth a kernel gets from a hipMalloc'd buffer is a property of that buffer: of several multi-GB buffers
 // of one process some read 8 % faster than the others, reproducibly (tools/ubench/streams8.hip).  A context that
 // will reuse its volumes for many pairs can afford to choose: allocate up to `placement_trials` candidates (all held until the
-// choice is made, so that they are different memory), time one streaming read of each, keep the fastest.
+// choice is made, so that they are different memory), time one streaming fill and read of each, keep the fastest.
 __global__ __launch_bounds__(256) void placement_probe_kernel(const uint4* __restrict__ p, size_t n, uint32_t* __restrict__ sink) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t step = (size_t)gridDim.x * 256;
@@ -302,22 +302,34 @@ __global__ __launch_bounds__(256) void placement_probe_kernel(const uint4* __res
     if (acc == 0x9e3779b9u) sink[0] = acc;  // (keeps the loads alive)
 }
 
+__global__ __launch_bounds__(256) void stream_fill_kernel(uint4* __restrict__ p, size_t n, uint32_t v);
 static float placement_probe_ms(pmx_ctx* ctx, const void* buf, size_t bytes) {
     if (!ctx->probe_sink && hipMalloc(&ctx->probe_sink, 64) != hipSuccess) return -1.f;
     hipEvent_t a = nullptr, b = nullptr;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.f;
-    float best = -1.f;
-    for (int rep = 0; rep < 3; ++rep) {  // the first pass also faults the pages in
-        (void)hipEventRecord(a, ctx->stream);
-        hipLaunchKernelGGL(placement_probe_kernel, dim3(16384), dim3(256), 0, ctx->stream, (const uint4*)buf, bytes / 16, (uint32_t*)ctx->probe_sink);
-        (void)hipEventRecord(b, ctx->stream);
-        if (hipEventSynchronize(b) != hipSuccess) break;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, a, b) == hipSuccess && rep > 0 && (best < 0.f || ms < best)) best = ms;
+    // a fill and a read, best of two each after a first pass that also faults the pages in; their sum is the candidate's mark.
+    // (The fill separates the faster from the slower stretches of a device's memory more sharply than the read - 6.4 against
+    // 6.0 TB/s with 2 % between passes, tools/ubench/phys_map.hip - the read is what the consumers of a volume do; alternated on
+    // one box with six candidates: read only 12.54 / 12.79 / 12.77 / 13.53 ms per headline step, fill only 12.78 / 12.72 / 12.89 /
+    // 12.81, both 12.59 / 12.56 / 12.89 / 12.89, plain hipMalloc 13.5 - 14.1: profiles/r05_k_probe_kinds.txt.)
+    float best_r = -1.f, best_w = -1.f;
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int kind = 0; kind < 2; ++kind) {
+            (void)hipEventRecord(a, ctx->stream);
+            if (kind == 0) hipLaunchKernelGGL(stream_fill_kernel, dim3(16384), dim3(256), 0, ctx->stream, (uint4*)buf, bytes / 16, (uint32_t)rep);
+            else hipLaunchKernelGGL(placement_probe_kernel, dim3(16384), dim3(256), 0, ctx->stream, (const uint4*)buf, bytes / 16, (uint32_t*)ctx->probe_sink);
+            (void)hipEventRecord(b, ctx->stream);
+            if (hipEventSynchronize(b) != hipSuccess) break;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, a, b) == hipSuccess && rep > 0) {
+                float& best = kind == 0 ? best_w : best_r;
+                if (best < 0.f || ms < best) best = ms;
+            }
+        }
     }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
-    return best;
+    return (best_r > 0.f && best_w > 0.f) ? best_r + best_w : -1.f;
 }
 
 // ---- what plain streaming kernels reach on this device, measured when asked (bench.py: roofline.peak_measured) ------------
