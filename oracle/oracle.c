@@ -460,14 +460,18 @@ void orc_cbca(float* cv, int H, int W, int D, int d0, int subpix, int offset, co
  *   L_r(p,d)  = C'(p,d) + ( min( L_r(p-r,d), min(L_r(p-r,d-1), L_r(p-r,d+1)) + P1, M + P2 ) - M )
  *               with M = min_k L_r(p-r,k); L_r(p,d) = C'(p,d) when p-r is outside the image;
  *               d-1 / d+1 outside [0,D) count as +inf
- *   S(p,d)    = sum over r in order (0,+1) (0,-1) | (+1,0) (+1,+1) (+1,-1) | (-1,0) (-1,+1) (-1,-1)
- *               [(drow,dcol) of the step from p-r to p], accumulated in float32 in that order: the two
- *               horizontal paths, then the three downward ones, then the three upward ones (the order in
- *               which the direction families of the GPU schedule finish; round 2 - before that the
- *               order was (0,+1)(0,-1)(+1,0)(-1,0)(+1,+1)(-1,-1)(+1,-1)(-1,+1); the choice is this
- *               build's own since nothing pins it, and it is invisible for integer-valued costs)
- *   dir_mask  : bit k set = the k-th path of that list contributes (0xff = the definition; subsets
- *               are a test hook that lets a strip of a large image be checked path family by family)
+ *   S(p,d)    = (S_H + S_D) + S_U, the paths summed FAMILY BY FAMILY in float32 [(drow,dcol) = the step from p-r to p]:
+ *                 S_H = L(0,+1) + L(0,-1)                 the horizontal pair
+ *                 S_D = (L(+1,0) + L(+1,+1)) + L(+1,-1)   the three downward paths
+ *                 S_U = (L(-1,0) + L(-1,+1)) + L(-1,-1)   the three upward paths
+ *               (each family on an accumulator of its own that starts at +0.)  Round 6: until then the eight paths were
+ *               added onto ONE running sum in the order H, D, U (round 1: yet another order).  Nothing pins the order -
+ *               libSGM is not vendored, it is invisible for integer-valued costs, and north_star asks 1e-5 of float
+ *               costs - so the choice is this build's own, and a family-wise sum is what lets the three families of
+ *               the GPU schedule run side by side instead of one after the other.
+ *   dir_mask  : bit k set = the k-th path of the list (0,+1) (0,-1) (+1,0) (+1,+1) (+1,-1) (-1,0) (-1,+1) (-1,-1)
+ *               contributes (0xff = the definition; subsets are a test hook that lets a strip of a large image be checked
+ *               path family by family): a family without a path is left out of the sum
  *   overcounting: S -= 7*C'
  *   output    = S (negated back for "max"); NaN wherever the input was NaN.
  * All arithmetic is float32, in exactly the operation order written above.
@@ -549,9 +553,20 @@ static void sgm_all(const float* cv, int H, int W, int D, float P1, float P2, co
         Cp[i] = v;
     }
     static const int dirs[8][2] = {{0, 1}, {0, -1}, {1, 0}, {1, 1}, {1, -1}, {-1, 0}, {-1, 1}, {-1, -1}};
-    for (int k = 0; k < 8; ++k)
-        if (dir_mask >> k & 1)
-            sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, p2maps ? p2maps + (size_t)k * H * W : NULL, S, b0, b1);
+    static const int fam_first[4] = {0, 2, 5, 8};
+    float* F = (float*)malloc(sizeof(float) * n); /* the family being summed */
+    for (int f = 0; f < 3; ++f) {
+        int any = 0;
+        for (int k = fam_first[f]; k < fam_first[f + 1]; ++k) any |= dir_mask >> k & 1;
+        if (!any) continue;
+        memset(F, 0, sizeof(float) * n);
+        for (int k = fam_first[f]; k < fam_first[f + 1]; ++k)
+            if (dir_mask >> k & 1)
+                sgm_path(Cp, H, W, D, dirs[k][0], dirs[k][1], P1, P2, p2maps ? p2maps + (size_t)k * H * W : NULL, F, b0, b1);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; ++i) S[i] = S[i] + F[i];
+    }
+    free(F);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float s = S[i];

@@ -5,12 +5,15 @@
 //   C'(p,d) = C(p,d) (negated for "max" measures), NaN -> invalid_cost
 //   L_r(p,d) = C' + ( min( L_r(p-r,d), min(L_r(p-r,d-1), L_r(p-r,d+1)) + P1, M + P2 ) - M ),
 //              M = min_k L_r(p-r,k);  L_r = C' on the first pixel of a path
-//   S = sum_r L_r in the order (0,+1) (0,-1) | (+1,0) (+1,+1) (+1,-1) | (-1,0) (-1,+1) (-1,-1)
-//       (horizontal, downward, upward paths: the order in which the direction families of k_sgmfam.hip finish)
+//   S = (S_H + S_D) + S_U, family by family (round 6; one running sum over the eight paths until then):
+//       S_H = L(0,+1) + L(0,-1),  S_D = (L(+1,0) + L(+1,+1)) + L(+1,-1),  S_U = (L(-1,0) + L(-1,+1)) + L(-1,-1)
+//       - a family without a path (direction masks) is left out.  Family-wise sums are what lets k_sgmfam.hip run the downward
+//       family beside the horizontal pair instead of behind it.
 //
 // Three schedules compute that definition bit for bit (pmx_launch_sgm picks one by size, PMX_SGM_SCHED=seq|par|fam forces):
-//   seq  one launch per direction, accumulating into S (this file): 92 B/cell of HBM traffic
-//   par  the eight directions side by side into eight path volumes + an ordered sum (this file): small volumes
+//   seq  one launch per direction (this file): the first family accumulates into S, a later one into a second volume T whose
+//        last pass writes S = S + (T + L): 92 B/cell of HBM traffic as before
+//   par  the eight directions side by side into eight path volumes + the family-wise sum (this file): small volumes
 //   fam  two horizontal passes (this file) + two fused three-direction marching passes (k_sgmfam.hip): ~46 B/cell
 //
 // Execution model: ONE WAVEFRONT PER SCANLINE.  The 64 lanes of a wave hold the D path costs of the
@@ -76,12 +79,14 @@ __device__ __forceinline__ float wave_min(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// MODE bits of a pass: it adds to what S already holds / it is the last pass and finishes S (overcounting, sign, NaN)
-enum { SGM_READS_S = 1, SGM_EPILOGUE = 2 };
+// MODE bits of a pass: it adds to what S already holds / it is the last pass and finishes S (overcounting, sign, NaN) / it is the
+// last pass of a family that is not the first one: S = S + (T + L), T the sum of the family's earlier paths
+enum { SGM_READS_S = 1, SGM_EPILOGUE = 2, SGM_READS_T = 4 };
 
 struct sgm_args {
     const float* C;  // raw cost volume (NaN = invalid)
     float* S;        // accumulator / output
+    const float* T;  // SGM_READS_T: the family's earlier paths
     int H, W, D;
     int dr, dc;      // step from p-r to p
     float P1, P2, invalid_cost;
@@ -143,16 +148,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
     int pr = r, pc = c;
     const float* c_pre = a.C + (size_t)r * a.W * D;  // rows of the prefetch cursor ...
     const float* s_pre = a.S + (size_t)r * a.W * D;
+    const float* t_pre = (MODE & SGM_READS_T) ? a.T + (size_t)r * a.W * D : nullptr;
     float* s_row = a.S + (size_t)r * a.W * D;        // ... and of the pixel being computed
 
     float cbuf[kPF][KPL], sbuf[kPF][KPL];
+    float tbuf[(MODE & SGM_READS_T) ? kPF : 1][KPL];
     float p2buf[kPF];  // the pixel's P2 when it varies (rides in the same ring as its costs)
     const bool var_p2 = a.p2map != nullptr;  // (uniform)
     int pleft = nsteps - 1;  // steps the prefetch cursor may still advance (read-ahead past the end re-reads the last pixel)
-    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL], float& p2slot) {
+    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL], float (&tslot)[KPL], float& p2slot) {
         const unsigned off = (unsigned)pc * pix_bytes + lane_load;
         buf_load<KPL>(rsrc_of(c_pre), off, cslot);
         if (MODE & SGM_READS_S) buf_load<KPL>(rsrc_of(s_pre), off, sslot);
+        if (MODE & SGM_READS_T) buf_load<KPL>(rsrc_of(t_pre), off, tslot);
         if (var_p2) p2slot = a.p2map[(size_t)pr * a.W + pc];
         if (pleft > 0) {
             --pleft;
@@ -160,18 +168,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
             pc += a.dc;
             c_pre += row_step;
             s_pre += row_step;
+            if (MODE & SGM_READS_T) t_pre += row_step;
             if (!horizontal) { if (pc >= a.W) pc = 0; else if (pc < 0) pc = a.W - 1; }
         }
     };
 #pragma unroll
-    for (int i = 0; i < kPF; ++i) prefetch(cbuf[i], sbuf[i], p2buf[i]);
+    for (int i = 0; i < kPF; ++i) prefetch(cbuf[i], sbuf[i], tbuf[(MODE & SGM_READS_T) ? i : 0], p2buf[i]);
 
     float Lp[KPL];  // path costs of the previous pixel (+inf on padded disparities)
 #pragma unroll
     for (int k = 0; k < KPL; ++k) Lp[k] = k < nv ? 0.f : f_inf();
     float M = 0.f;  // min_k Lp; (Lp = 0, M = 0) reproduces L = C' on the first pixel of a path
 
-    auto step = [&](float (&cslot)[KPL], float (&sslot)[KPL], float& p2slot) {
+    auto step = [&](float (&cslot)[KPL], float (&sslot)[KPL], float (&tslot)[KPL], float& p2slot) {
         // neighbours across the lane boundary
         const float below = from_lane_below(Lp[KPL - 1], f_inf());
         const float above = from_lane_above(Lp[0], f_inf());
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
             float l = cc + (t - M);
             Ln[k] = k < nv ? l : f_inf();
             lmin = fmin2(lmin, Ln[k]);
-            float s = (MODE & SGM_READS_S) ? (sslot[k] + l) : l;
+            float s = (MODE & SGM_READS_T) ? (sslot[k] + (tslot[k] + l)) : (MODE & SGM_READS_S) ? (sslot[k] + l) : l;
             if (MODE & SGM_EPILOGUE) {
                 if (a.overcounting) s = s - 7.0f * cc;
                 if (a.is_max) s = -s;
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
         buf_store<KPL>(rsrc_of(s_row), (unsigned)c * pix_bytes + lane_store, nv, is_tail, cov, rem, out);
         // refill this ring slot with pixel i + kPF.  Issued AFTER the slot's last use so the new data
         // lands in the same registers (no copy, hence no wait, at the loop back-edge).
-        prefetch(cslot, sslot, p2slot);
+        prefetch(cslot, sslot, tslot, p2slot);
         M = wave_min(lmin);
 #pragma unroll
         for (int k = 0; k < KPL; ++k) Lp[k] = Ln[k];
@@ -221,11 +230,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sgm_path_kernel(sgm_args 
     int i = 0;
     for (; i + kPF <= nsteps; i += kPF) {
 #pragma unroll
-        for (int j = 0; j < kPF; ++j) step(cbuf[j], sbuf[j], p2buf[j]);
+        for (int j = 0; j < kPF; ++j) step(cbuf[j], sbuf[j], tbuf[(MODE & SGM_READS_T) ? j : 0], p2buf[j]);
     }
 #pragma unroll
     for (int j = 0; j < kPF - 1; ++j)
-        if (i + j < nsteps) step(cbuf[j], sbuf[j], p2buf[j]);
+        if (i + j < nsteps) step(cbuf[j], sbuf[j], tbuf[(MODE & SGM_READS_T) ? j : 0], p2buf[j]);
 }
 
 // (drow, dcol) of the step from p-r to p, in the definition's order
@@ -247,26 +256,64 @@ static void sgm_launch_direction(pmx_ctx* ctx, const sgm_args& base, int k, int 
         case 0: PMX_SGM_LAUNCH(0); break;
         case SGM_READS_S: PMX_SGM_LAUNCH(SGM_READS_S); break;
         case SGM_EPILOGUE: PMX_SGM_LAUNCH(SGM_EPILOGUE); break;
-        default: PMX_SGM_LAUNCH(SGM_READS_S | SGM_EPILOGUE); break;
+        case SGM_READS_S | SGM_EPILOGUE: PMX_SGM_LAUNCH(SGM_READS_S | SGM_EPILOGUE); break;
+        case SGM_READS_S | SGM_READS_T: PMX_SGM_LAUNCH(SGM_READS_S | SGM_READS_T); break;
+        default: PMX_SGM_LAUNCH(SGM_READS_S | SGM_READS_T | SGM_EPILOGUE); break;
     }
 #undef PMX_SGM_LAUNCH
 }
 
-// MODE bits of the pass for direction k when the directions of `mask` run one after the other in the definition's order
-static int sgm_pass_mode(int mask, int k) {
-    const int before = mask & ((1 << k) - 1), after = mask >> (k + 1);
-    return (before ? SGM_READS_S : 0) | (after ? 0 : SGM_EPILOGUE);
+// families of the definition's sum: paths [kFamFirst[f], kFamFirst[f + 1])
+static const int kFamFirst[4] = {0, 2, 5, 8};
+static inline int sgm_family_of(int k) { return k < 2 ? 0 : (k < 5 ? 1 : 2); }
+static inline int sgm_family_bits(int mask, int f) { return mask & (((1 << kFamFirst[f + 1]) - 1) & ~((1 << kFamFirst[f]) - 1)); }
+
+// Where the pass of direction k accumulates when the directions of `mask` run one after the other, and its MODE bits.  The first
+// family of the mask sums in S itself; a later family with one path adds it to S; a later family with several sums its earlier
+// paths in T and its last pass writes S = S + (T + L).  *into_t: the pass reads and writes T in S's place.
+static int sgm_pass_mode(int mask, int k, bool* into_t) {
+    const int f = sgm_family_of(k);
+    const int fam = sgm_family_bits(mask, f);
+    const bool first_family = (mask & ((1 << kFamFirst[f]) - 1)) == 0;
+    const int before = fam & ((1 << k) - 1), after_in_family = fam >> (k + 1), after = mask >> (k + 1);
+    *into_t = false;
+    const int epi = after ? 0 : SGM_EPILOGUE;
+    if (first_family) return (before ? SGM_READS_S : 0) | epi;
+    if (after_in_family) {  // an earlier path of a later family: T
+        *into_t = true;
+        return before ? SGM_READS_S : 0;
+    }
+    return SGM_READS_S | (before ? SGM_READS_T : 0) | epi;
+}
+
+// does a sequential run of `mask` need the second accumulator?
+static bool sgm_seq_needs_t(int mask) {
+    for (int f = 1; f < 3; ++f) {
+        const int fam = sgm_family_bits(mask, f);
+        if ((fam & (fam - 1)) != 0 && (mask & ((1 << kFamFirst[f]) - 1)) != 0) return true;
+    }
+    return false;
 }
 
 template <int KPL>
 static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask);
+
+// one pass of a sequential run: the accumulator the definition gives direction k (S, or T for the earlier paths of a later family)
+template <int KPL>
+static void sgm_launch_pass(pmx_ctx* ctx, const sgm_args& base, int mask, int k) {
+    bool into_t = false;
+    const int mode = sgm_pass_mode(mask, k, &into_t);
+    sgm_args a = base;
+    if (into_t) a.S = const_cast<float*>(base.T);
+    sgm_launch_direction<KPL>(ctx, a, k, mode);
+}
 
 template <int KPL>
 static int sgm_run(pmx_ctx* ctx, const sgm_args& base, int mask) {
     int rc = sgm_run_horizontal<KPL>(ctx, base, mask);  // the pair fused when both are wanted
     if (rc) return rc;
     for (int k = 2; k < 8; ++k)
-        if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
+        if (mask >> k & 1) sgm_launch_pass<KPL>(ctx, base, mask, k);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
@@ -502,13 +549,13 @@ static int sgm_run_horizontal(pmx_ctx* ctx, const sgm_args& base, int mask) {
     const char* e = pmx_opt(ctx, "SGM_HFUSED");
     if ((mask & 3) == 3 && KPL <= 6 && !base.p2map && !(e && e[0] == '0')) return sgm_run_horizontal_fused<KPL>(ctx, base, mask);
     for (int k = 0; k < 2; ++k)
-        if (mask >> k & 1) sgm_launch_direction<KPL>(ctx, base, k, sgm_pass_mode(mask, k));
+        if (mask >> k & 1) sgm_launch_pass<KPL>(ctx, base, mask, k);  // (the first family: always into S)
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
-// S = sum of the enabled path volumes, accumulated in float32 in the definition's order (exactly what the sequential passes
-// compute), then the epilogue of the last pass: overcounting, sign, NaN where the input was NaN.
+// S = sum of the enabled path volumes, accumulated in float32 family by family as the definition says (exactly what the sequential
+// passes compute), then the epilogue of the last pass: overcounting, sign, NaN where the input was NaN.
 __global__ __launch_bounds__(256) void sgm_sum_paths_kernel(const float* __restrict__ C, const float* __restrict__ L, size_t n,
                                                             float invalid_cost, int is_max, int overcounting, int mask,
                                                             uint32_t nan_bits, float* __restrict__ out) {
@@ -518,12 +565,22 @@ __global__ __launch_bounds__(256) void sgm_sum_paths_kernel(const float* __restr
         float s = 0.f;
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (mask >> k & 1) {
-                const float v = L[(size_t)k * n + i];
-                s = any ? s + v : v;
+        for (int f = 0; f < 3; ++f) {  // family by family, as the definition adds them
+            const int k0 = f == 0 ? 0 : (f == 1 ? 2 : 5), k1 = f == 0 ? 2 : (f == 1 ? 5 : 8);
+            float fs = 0.f;
+            bool fany = false;
+#pragma unroll
+            for (int k = k0; k < k1; ++k)
+                if (mask >> k & 1) {
+                    const float v = L[(size_t)k * n + i];
+                    fs = fany ? fs + v : v;
+                    fany = true;
+                }
+            if (fany) {
+                s = any ? s + fs : fs;
                 any = true;
             }
+        }
         const float cr = C[i];
         const float cc = is_nan_bits(cr) ? invalid_cost : (is_max ? -cr : cr);
         if (overcounting) s = s - 7.0f * cc;
@@ -591,6 +648,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     sgm_args a;
     a.C = cv->data;
     a.S = nullptr;  // set once the schedule is known
+    a.T = nullptr;
     a.H = cv->H; a.W = cv->W; a.D = cv->D;
     a.dr = 0; a.dc = 0;
     a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
@@ -634,7 +692,7 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
         pmx_pool_free(ctx, paths);  // stream-ordered reuse: the kernels above are queued on ctx->stream
     } else if (sched == FAM) {
         // Lazy mode, all eight paths: the horizontal pair and the downward family run now into the handle's own partial-sum
-        // volume; the upward family waits for whoever comes next - pmx_wta runs it in WTA mode (S is never written, the WTA's
+        // volumes; the upward family waits for whoever comes next - pmx_wta runs it in WTA mode (S is never written, the WTA's
         // read of it never happens: -8 B/cell), anything else runs it in store mode (pmx_sgm_finish_pending).
         const bool defer = defer_;  // (PMX_SGM_PENDING=0: test hook, always finish at once)
         if (defer) {
@@ -647,22 +705,85 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
             }
             a.S = cv->spart;
         }
-        // horizontal pair with the line kernel, then the downward and the upward family (k_sgmfam.hip)
-#define PMX_CALL(K) sgm_run_horizontal<K>(ctx, a, mask)
-        PMX_KPL_SWITCH(kpl, PMX_CALL)
-#undef PMX_CALL
-        if (rc) return rc;
-        rc = pmx_launch_sgm_families(ctx, cv, a.S, P1, P2, is_max, invalid_cost, overcounting, mask, defer ? 1 : 3, nullptr);
-        if (rc) return rc;
-        if (defer) {
-            cv->pending = {P1, P2, invalid_cost, is_max, overcounting};
-            cv->repr = PMX_REPR_SGM_UP_PENDING;
-            return PMX_OK;  // data = the costs, spart = the partial sums
+        const int hb = mask & 3, db = (mask >> 2) & 7, ub = (mask >> 5) & 7;
+        // Round 6: with family-wise sums the downward family reads no earlier sum - it writes S_D into a volume of its own and runs
+        // BESIDE the horizontal pair (second stream); the upward family then adds (S_H + S_D) to its own sum.  The same bytes as
+        // one after the other, one more volume of memory (taken from the pool; without it - or SGM_FAM_PAR=0, the A/B hook -
+        // the downward family runs behind the pair and adds into S).
+        const char* epar = pmx_opt(ctx, "SGM_FAM_PAR");
+        bool par = hb && db && ub && !(epar && epar[0] == '0');
+        float* SD = nullptr;
+        bool sd_temp = false;
+        if (par) {
+            if (defer) {
+                if (cv->spart2_bytes < bytes) {
+                    pmx_pool_free(ctx, cv->spart2);
+                    cv->spart2 = nullptr;
+                    cv->spart2_bytes = 0;
+                    if (pmx_pool_alloc(ctx, (void**)&cv->spart2, bytes) == hipSuccess) cv->spart2_bytes = bytes;
+                    else { cv->spart2 = nullptr; (void)hipGetLastError(); }
+                }
+                SD = cv->spart2;
+            } else if (pmx_pool_alloc(ctx, (void**)&SD, bytes) == hipSuccess) {
+                sd_temp = true;
+            } else {
+                SD = nullptr;
+                (void)hipGetLastError();
+            }
+            par = SD != nullptr;
         }
+        if (db || ub) {
+            rc = pmx_sgm_family_prepare(ctx, cv);
+            if (rc) return rc;
+        }
+        {
+            pmx_stage_scope span(ctx, PMX_STAGE_SGM_SPAN);  // the SGM step as the pipeline sees it (fork ... join)
+            if (par) {
+                if (!ctx->aux_stream) {
+                    PMX_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+                    PMX_HIP(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+                    PMX_HIP(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+                }
+                PMX_HIP(hipEventRecord(ctx->aux_fork, ctx->stream));
+                PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+                // the marching pass first: one workgroup per CU, the pair's wavefronts fill what is left of the SIMDs
+                rc = pmx_launch_sgm_family(ctx, cv, 0, nullptr, nullptr, SD, P1, P2, is_max, invalid_cost, overcounting, db, false, nullptr,
+                                           ctx->aux_stream);
+                if (rc) return rc;
+                PMX_HIP(hipEventRecord(ctx->aux_join, ctx->aux_stream));
+            }
+            // horizontal pair with the line kernel (checkpoint + recompute, this file)
+#define PMX_CALL(K) sgm_run_horizontal<K>(ctx, a, mask)
+            PMX_KPL_SWITCH(kpl, PMX_CALL)
+#undef PMX_CALL
+            if (rc) return rc;
+            if (par) {
+                PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+            } else if (db) {
+                rc = pmx_launch_sgm_family(ctx, cv, 0, hb ? a.S : nullptr, nullptr, a.S, P1, P2, is_max, invalid_cost, overcounting, db,
+                                           ub == 0, nullptr, nullptr);
+                if (rc) return rc;
+            }
+        }
+        if (defer) {
+            cv->pending = {P1, P2, invalid_cost, is_max, overcounting, par ? 1 : 0};
+            cv->repr = PMX_REPR_SGM_UP_PENDING;
+            return PMX_OK;  // data = the costs, spart (+ spart2) = the partial sums
+        }
+        if (ub) {
+            rc = pmx_launch_sgm_family(ctx, cv, 1, (hb || db) ? a.S : nullptr, par ? SD : nullptr, a.S, P1, P2, is_max, invalid_cost,
+                                       overcounting, ub, true, nullptr, nullptr);
+        }
+        if (sd_temp) pmx_pool_free(ctx, SD);  // stream-ordered reuse
+        if (rc) return rc;
     } else {
+        float* T = nullptr;  // the second accumulator of the family-wise sum (a later family with more than one path)
+        if (sgm_seq_needs_t(mask)) PMX_HIP(pmx_pool_alloc(ctx, (void**)&T, bytes));
+        a.T = T;
 #define PMX_CALL(K) sgm_run<K>(ctx, a, mask)
         PMX_KPL_SWITCH(kpl, PMX_CALL)
 #undef PMX_CALL
+        pmx_pool_free(ctx, T);  // stream-ordered reuse
     }
     if (rc) return rc;
     // the accumulator becomes the volume; the old volume becomes the scratch
@@ -678,9 +799,12 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
 // The upward family of a PMX_REPR_SGM_UP_PENDING handle: in WTA mode (wta != nullptr: the volume stays pending, the context's
 // disparity map and winner cache are written) or in store mode (the handle becomes a plain float32 volume).
 int pmx_sgm_finish_pending(pmx_ctx* ctx, pmx_cv* cv, const pmx_fam_wta* wta) {
-    PMX_CHECK(cv->repr == PMX_REPR_SGM_UP_PENDING && cv->data && cv->spart, PMX_ERR_STATE, "pmx_sgm_finish_pending: nothing pending");
-    int rc = pmx_launch_sgm_families(ctx, cv, cv->spart, cv->pending.P1, cv->pending.P2, cv->pending.is_max, cv->pending.invalid_cost,
-                                     cv->pending.overcounting, 0xff, 2, wta);
+    PMX_CHECK(cv->repr == PMX_REPR_SGM_UP_PENDING && cv->data && cv->spart && (!cv->pending.two || cv->spart2), PMX_ERR_STATE,
+              "pmx_sgm_finish_pending: nothing pending");
+    int rc = pmx_sgm_family_prepare(ctx, cv);
+    if (rc) return rc;
+    rc = pmx_launch_sgm_family(ctx, cv, 1, cv->spart, cv->pending.two ? cv->spart2 : nullptr, cv->spart, cv->pending.P1, cv->pending.P2,
+                               cv->pending.is_max, cv->pending.invalid_cost, cv->pending.overcounting, 7, true, wta, nullptr);
     if (rc || wta) return rc;
     // the sums become the volume; the costs' buffer is kept with the handle for the next pair's partial sums
     float* costs = cv->data;

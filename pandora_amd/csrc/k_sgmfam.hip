@@ -4,8 +4,9 @@
 // (8 x 12 B/cell).  The three paths that advance one image row per step - (+1,0), (+1,+1), (+1,-1), or their mirror
 // images - share every read of C and every read-modify-write of S when one kernel marches down the rows computing all
 // three at each pixel:  R C + R S + W S = 12 B/cell for three directions instead of 36.  The definition (oracle.c
-// orc_sgm, k_sgm.hip header) is unchanged: the same float32 operations in the same order, S += L_vertical, then
-// L_(pred col-1), then L_(pred col+1).
+// orc_sgm, k_sgm.hip header) sums family by family: a pass makes its family's sum F = (L_vertical + L_(pred col-1)) +
+// L_(pred col+1) and writes out = F, in1 + F or (in1 + in2) + F - so the downward family, which reads no earlier sum, can run
+// BESIDE the horizontal pair (round 6), and the upward family adds the two: S = (S_H + S_D) + S_U.
 //
 // Decomposition.  Row r needs row r-1 of all three paths, so rows are sequential and columns are the parallel axis.  A
 // workgroup owns a window of CW columns; the diagonal paths cross window borders.  With a fixed window the (+1,+1) path
@@ -66,14 +67,15 @@ constexpr int kSc1 = 16;  // aux bit of the buffer instructions: write-through s
 
 struct fam_args {
     const float* C;  // raw cost volume [H][W][D] (NaN = invalid)
-    float* S;        // accumulator, updated in place
+    const float* in1;  // sums of earlier families (nullptr: none; may be `out`: every cell is read and written by one lane)
+    const float* in2;  // a second earlier family's sums (IN2 instantiations only)
+    float* out;        // in1 + in2 + this family's sum (not written in WTA mode)
     int H, W, D;
     int flip;        // 0: rows top -> bottom, paths (+1,0) (+1,+1) (+1,-1);  1: bottom -> top, paths (-1,0) (-1,+1) (-1,-1)
     float P1, P2, invalid_cost;
     int is_max, overcounting;
-    int has_sin;     // S already holds earlier paths (else this pass starts the sum)
     int epilogue;    // last pass: overcounting, sign, NaN restore
-    int dmask;       // paths that are added to S: bit 0 vertical, bit 1 predecessor column c-1, bit 2 predecessor column c+1
+    int dmask;       // paths that enter the family's sum: bit 0 vertical, bit 1 predecessor column c-1, bit 2 predecessor column c+1
     u32x4* halo;     // hand-off blocks [H][NB][NGP] of 16 bytes {value, value, value, epoch ^ the three}
     int NB;          // window borders per row = ceil(W / CW)
     unsigned epoch;
@@ -138,7 +140,7 @@ __device__ __forceinline__ float path_costs(const float (&Lp)[KPL], float M, boo
     return lmin;
 }
 
-template <int GL, int KPL, int NW, int PF, bool WTA>
+template <int GL, int KPL, int NW, int PF, bool WTA, bool IN2>
 __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     constexpr int NPW = 64 / GL;           // pixels per wave
     constexpr int CW = NW * NPW;           // columns per workgroup window
@@ -224,6 +226,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         auto in_rsrc = [&](int t) {
             const bool need = t >= tA && t <= tB;
             const int cb = base - (t + 1);  // image column of the neighbour's last pixel on row t (0 <= cb < W when needed)
+#if defined(PMX_EXP_HALO) && (PMX_EXP_HALO & 1)  // timing experiment (results wrong): every hand-off read hits one cached slot
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + (size_t)(s & 255) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
+#endif
             return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0,
                                                      need ? kBlockBytes : 0u, kRsrcWord3);
         };
@@ -239,6 +244,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                 bool ok = true;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) ok &= nreal[q] == 0 || slot[q].w == (a.epoch ^ slot[q].x ^ slot[q].y ^ slot[q].z);
+#if defined(PMX_EXP_HALO) && (PMX_EXP_HALO & 1)
+                ok = true;
+#endif
                 if (__all(ok)) break;
                 if ((spins & 31) == 31 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
                 if (spins > kSpinLimit) {
@@ -246,6 +254,15 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                     return false;
                 }
                 __builtin_amdgcn_s_sleep(1);
+                // The row is not there yet: wait on its LAST block alone (the three minima, the producer's last store: one 16-byte
+                // request per poll where re-reading the row was 4.6 KB at D = 257 - round 5's counters show the marching kernels
+                // fetching 2.2 bytes of hand-off for every byte published), then read the row again; every block is still
+                // checked by its own tag above, so a row whose stores landed out of order is simply polled once more.
+                for (unsigned p2 = 0; p2 < 64; ++p2) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(3 * NVB) * 16u, 0, kSc1);
+                    if (t.w == (a.epoch ^ t.x ^ t.y ^ t.z)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
             }
@@ -275,7 +292,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         // it exists and needs the row iff cb < W and t < H-1 (else an empty descriptor drops the stores).
         auto publish = [&](int t) {
             const int cb = base + CW - 1 - t;
+#if defined(PMX_EXP_HALO) && (PMX_EXP_HALO & 2)  // timing experiment (results wrong): nothing is published
+            const bool need = false;
+#else
             const bool need = t >= r_lo && cb < W && t < H - 1;
+#endif
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(a.halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
             const float* Eb = lds + (t & 1) * EBUF + CW * ES;
@@ -354,14 +375,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     // loads of C and S run PF rows ahead in a register ring
     int pr = r_lo;
     float cbuf[PF][KPL], sbuf[PF][KPL];
-    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL]) {
+    float tbuf[IN2 ? PF : 1][KPL];
+    auto prefetch = [&](float (&cslot)[KPL], float (&sslot)[KPL], float (&tslot)[KPL]) {
         const unsigned off = pix_off(pr) + lane_off;
         buf_load<KPL>(row_rsrc(a.C, pr), off, cslot);
-        buf_load<KPL>(row_rsrc(a.S, pr), a.has_sin ? off : kOob, sslot);  // first pass of a sum: out of range = zeros, no traffic
+        buf_load<KPL>(row_rsrc(a.in1, pr), a.in1 ? off : kOob, sslot);  // first family of a sum: out of range = zeros, no traffic
+        if (IN2) buf_load<KPL>(row_rsrc(a.in2, pr), off, tslot);
         if (pr < r_hi) ++pr;
     };
 #pragma unroll
-    for (int i = 0; i < PF; ++i) prefetch(cbuf[i], sbuf[i]);
+    for (int i = 0; i < PF; ++i) prefetch(cbuf[i], sbuf[i], tbuf[IN2 ? i : 0]);
 
     float LB[KPL];  // the path that stays in its lane group (predecessor column c+1)
     float MB = 0.f;
@@ -371,7 +394,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane(ctl[1 + ((r_lo - 1) & 1)])) return;
 
-    auto step = [&](int r, float (&cslot)[KPL], float (&sslot)[KPL]) {
+    auto step = [&](int r, float (&cslot)[KPL], float (&sslot)[KPL], float (&tslot)[KPL]) {
         const int c = base - r + j;
         const float* Ep = lds + ((r - 1) & 1) * EBUF;
         float* En = lds + (r & 1) * EBUF;
@@ -433,10 +456,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         }
 #pragma unroll
         for (int k = 0; k < KPL; ++k) LB[k] = nB[k];
-        // S
+        // the family's sum on an accumulator of its own (from +0, as the definition's), then the earlier families in front of it
         float acc[KPL];
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) acc[k] = sslot[k];
+        for (int k = 0; k < KPL; ++k) acc[k] = 0.f;
         if (a.dmask & 1) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + nV[k];
@@ -449,6 +472,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) acc[k] = acc[k] + nB[k];
         }
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) acc[k] = (IN2 ? sslot[k] + tslot[k] : sslot[k]) + acc[k];  // (no in1: zeros; the family's sum is never -0)
         if (a.epilogue) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
@@ -459,7 +484,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             }
         }
         if (!WTA) {
-            buf_store<KPL>(row_rsrc(a.S, r), pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
+            buf_store<KPL>(row_rsrc(a.out, r), pix_off(r) + (unsigned)d0 * 4u, nv, is_tail, cov, rem, acc);
         } else {
             // winner-takes-all over the pixel's D values, as wta_kernel (k_disparity.hip) would do it on the stored volume: NaN
             // counts as the worst value, the FIRST extremum wins.  Two reductions over the pixel's lanes: the minimum value, then the
@@ -519,7 +544,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             __builtin_amdgcn_raw_buffer_store_b128(nb, rsN, st ? pidx * 16u : kOob, 0, 0);
         }
         // refill this ring slot with row r + PF (issued after the slot's last use: same registers, no copy)
-        prefetch(cslot, sslot);
+        prefetch(cslot, sslot, tslot);
         __syncthreads();
     };
 
@@ -529,7 +554,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (!dead) {
-                step(r + u, cbuf[u], sbuf[u]);
+                step(r + u, cbuf[u], sbuf[u], tbuf[IN2 ? u : 0]);
                 dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
             }
         }
@@ -538,7 +563,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 #pragma unroll
     for (int u = 0; u < PF - 1; ++u) {
         if (r + u <= r_hi && !dead) {
-            step(r + u, cbuf[u], sbuf[u]);
+            step(r + u, cbuf[u], sbuf[u], tbuf[IN2 ? u : 0]);
             dead = __builtin_amdgcn_readfirstlane(ctl[1 + ((r + u) & 1)]) != 0;
         }
     }
@@ -596,24 +621,31 @@ bool pick_shape(const pmx_ctx* ctx, int D, int W, fam_shape* out) {
     return true;
 }
 
-template <int GL, int KPL, int NW, bool WTA>
-int launch_family(pmx_ctx* ctx, const fam_args& a, int nwg) {
-    constexpr int PF = KPL > 12 ? 2 : 3;
+template <int GL, int KPL, int NW, bool WTA, bool IN2>
+int launch_family(pmx_ctx* ctx, const fam_args& a, int nwg, hipStream_t st) {
+    // rows of read-ahead: three; two where three rings of KPL registers would not fit (a second input, 16 disparities per lane)
+    constexpr int PF = (KPL > 12 || IN2) ? 2 : 3;
     constexpr int NPW = 64 / GL, CW = NW * NPW, KS = (KPL + 3) & ~3, ES = GL * KS + 4;
     const size_t lds_bytes = (size_t)(2 * 2 * (CW + 2) * ES + 4) * sizeof(float);
-    auto kern = sgm_family_kernel<GL, KPL, NW, PF, WTA>;
+    auto kern = sgm_family_kernel<GL, KPL, NW, PF, WTA, IN2>;
     PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 1) * 64), lds_bytes, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3((NW + 1) * 64), lds_bytes, st, a);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
 }
 
-int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg, bool wta) {
-#define PMX_FAM(GL, KPL)                                                                                               \
-    if (f.gl == GL && f.kpl == KPL) {                                                                                  \
-        if (f.nw == 10) return wta ? launch_family<GL, KPL, 10, true>(ctx, a, nwg) : launch_family<GL, KPL, 10, false>(ctx, a, nwg); \
-        if (wta) return f.nw == 8 ? launch_family<GL, KPL, 8, true>(ctx, a, nwg) : launch_family<GL, KPL, 4, true>(ctx, a, nwg); \
-        return f.nw == 8 ? launch_family<GL, KPL, 8, false>(ctx, a, nwg) : launch_family<GL, KPL, 4, false>(ctx, a, nwg);        \
+template <int GL, int KPL, int NW>
+int launch_family_mode(pmx_ctx* ctx, const fam_args& a, int nwg, bool wta, hipStream_t st) {
+    const bool in2 = a.in2 != nullptr;
+    if (wta) return in2 ? launch_family<GL, KPL, NW, true, true>(ctx, a, nwg, st) : launch_family<GL, KPL, NW, true, false>(ctx, a, nwg, st);
+    return in2 ? launch_family<GL, KPL, NW, false, true>(ctx, a, nwg, st) : launch_family<GL, KPL, NW, false, false>(ctx, a, nwg, st);
+}
+
+int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg, bool wta, hipStream_t st) {
+#define PMX_FAM(GL, KPL)                                                                          \
+    if (f.gl == GL && f.kpl == KPL) {                                                             \
+        if (f.nw == 10) return launch_family_mode<GL, KPL, 10>(ctx, a, nwg, wta, st);             \
+        return f.nw == 8 ? launch_family_mode<GL, KPL, 8>(ctx, a, nwg, wta, st) : launch_family_mode<GL, KPL, 4>(ctx, a, nwg, wta, st); \
     }
     PMX_FAM(16, 3)
     PMX_FAM(16, 5)
@@ -659,48 +691,56 @@ int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes) {
 
 bool pmx_sgm_family_supported(const pmx_ctx* ctx, const pmx_cv* cv) { return cv->H >= 2 && pick_shape(ctx, cv->D, cv->W, nullptr); }
 
-int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
-                            int mask, int fams, const pmx_fam_wta* wta) {
+// the hand-off buffer for the marching passes of `cv`, made (and zeroed) on the context's own stream: the scheduler calls this
+// before it forks a pass onto the second stream, the launches below then find it ready
+int pmx_sgm_family_prepare(pmx_ctx* ctx, const pmx_cv* cv) {
     fam_shape f;
     PMX_CHECK(pick_shape(ctx, cv->D, cv->W, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (family schedule): D = %d not supported", cv->D);
+    const int CW = f.nw * (64 / f.gl), NB = (cv->W + CW - 1) / CW;
+    const int NG = 3 * f.gl * ((f.kpl + 2) / 3) + 1, NGP = (NG + 63) / 64 * 64;
+    return pmx_fam_prepare(ctx, (size_t)cv->H * NB * NGP * 16);
+}
+
+int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, const float* in2, float* out, float P1, float P2,
+                          int is_max, float invalid_cost, int overcounting, int bits, bool epilogue, const pmx_fam_wta* wta,
+                          hipStream_t st) {
+    fam_shape f;
+    PMX_CHECK(pick_shape(ctx, cv->D, cv->W, &f), PMX_ERR_UNSUPPORTED, "pmx_sgm (family schedule): D = %d not supported", cv->D);
+    PMX_CHECK(bits && (in1 || !in2) && (out || wta), PMX_ERR_STATE, "pmx_sgm (family schedule): bad pass");
+    if (!st) st = ctx->stream;
     const int npw = 64 / f.gl, CW = f.nw * npw;
     const int NB = (cv->W + CW - 1) / CW;
     const int NG = 3 * f.gl * ((f.kpl + 2) / 3) + 1, NGP = (NG + 63) / 64 * 64;  // 16-byte blocks per (row, border)
     const size_t halo_bytes = (size_t)cv->H * NB * NGP * 16;
+    // (the hand-off buffer and its control words are (re)made on the context's own stream: a pass on the second stream was forked
+    //  from it behind them)
     if (int rcp = pmx_fam_prepare(ctx, halo_bytes)) return rcp;
     const int nwg = (cv->W + cv->H - 2) / CW + 1;
-    for (int fam = 0; fam < 2; ++fam) {
-        const int bits = (mask >> (2 + 3 * fam)) & 7;  // definition order: vertical, predecessor c-1, predecessor c+1
-        if (!bits || !(fams >> fam & 1)) continue;
-        if (int rcp = pmx_fam_prepare(ctx, halo_bytes)) return rcp;  // (epoch space used up: starts over on a clean buffer)
-        fam_args a;
-        a.C = cv->data;
-        a.S = S;
-        a.H = cv->H; a.W = cv->W; a.D = cv->D;
-        a.flip = fam;
-        a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
-        a.is_max = is_max; a.overcounting = overcounting;
-        a.has_sin = (mask & ((1 << (2 + 3 * fam)) - 1)) != 0;
-        a.epilogue = (mask >> (5 + 3 * fam)) == 0;
-        a.dmask = bits;
-        a.halo = (u32x4*)ctx->fam_halo;
-        a.NB = NB;
-        a.epoch = pmx_fam_tag(++ctx->fam_epoch);
-        a.ctl = ctx->fam_ctl;
-        const bool use_wta = wta && fam == 1;
-        a.disp = use_wta ? wta->disp : nullptr;
-        a.near = use_wta ? wta->near : nullptr;
-        a.d0 = use_wta ? wta->d0 : 0.0;
-        a.subpix = use_wta ? wta->subpix : 1;
-        a.invalid_disparity = use_wta ? wta->invalid_disparity : 0.f;
-        PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));  // the ticket; the error word is sticky
-        {
-            pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY);
-            int rc = dispatch_family(ctx, f, a, nwg, use_wta);
-            if (rc) return rc;
-        }
-        // the error word travels to pinned host memory behind the launch; pmx_check_async_error reads it after a sync
-        PMX_HIP(hipMemcpyAsync(ctx->fam_err_host, ctx->fam_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    fam_args a;
+    a.C = cv->data;
+    a.in1 = in1; a.in2 = in2; a.out = out;
+    a.H = cv->H; a.W = cv->W; a.D = cv->D;
+    a.flip = fam;
+    a.P1 = P1; a.P2 = P2; a.invalid_cost = invalid_cost;
+    a.is_max = is_max; a.overcounting = overcounting;
+    a.epilogue = epilogue;
+    a.dmask = bits;
+    a.halo = (u32x4*)ctx->fam_halo;
+    a.NB = NB;
+    a.epoch = pmx_fam_tag(++ctx->fam_epoch);
+    a.ctl = ctx->fam_ctl;
+    a.disp = wta ? wta->disp : nullptr;
+    a.near = wta ? wta->near : nullptr;
+    a.d0 = wta ? wta->d0 : 0.0;
+    a.subpix = wta ? wta->subpix : 1;
+    a.invalid_disparity = wta ? wta->invalid_disparity : 0.f;
+    PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), st));  // the ticket; the error word is sticky
+    {
+        pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY, st);
+        int rc = dispatch_family(ctx, f, a, nwg, wta != nullptr, st);
+        if (rc) return rc;
     }
+    // the error word travels to pinned host memory behind the launch; pmx_check_async_error reads it after a sync
+    PMX_HIP(hipMemcpyAsync(ctx->fam_err_host, ctx->fam_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return PMX_OK;
 }

@@ -31,7 +31,7 @@ extern "C" int pmx_device_count(void) {
 // ---- kernel-route / tuning options ---------------------------------------------------------------------------------------------------
 // Every name the library looks at (DESIGN 7b says what each one forces).  The ONE place the environment is read: pmx_create.
 static const char* const kPmxOptNames[] = {
-    "SGM_SCHED", "SGM_PAR", "SGM_HFUSED", "SGM_PENDING", "SGM_FAM_SHAPE",
+    "SGM_SCHED", "SGM_PAR", "SGM_HFUSED", "SGM_PENDING", "SGM_FAM_SHAPE", "SGM_FAM_PAR",
     "SGM8", "FUSED_MAP", "COST5", "WTA3", "SGM8_FAM", "SGM8_HPAIR", "SGM8_CODES", "SGM8_FAMCODES", "SGM8_OVERLAP", "SGM8_HF",
     "SGM8_FAM_NW", "SGM8_FAM_PRIO",
     "CBCA_ARMS_FLAT", "CBCA_ROWS", "CBCA_FAST", "CBCA_FUSE", "CBCA_MARCH", "CBCA_VBUF", "CBCA_SIGN", "CBCA_GEO", "CBCA_VBS",
@@ -47,6 +47,10 @@ static int opt_index(const char* name) {
 }
 const char* pmx_opt(const pmx_ctx* ctx, const char* name) {
     const int i = opt_index(name);
+    if (i < 0) {  // a kernel hook that is not in the table (a typo, a new hook): the route a test forces would silently be the default one
+        fprintf(stderr, "libpandora_amd: pmx_opt(\"%s\") is not in kPmxOptNames (pmx_api.hip)\n", name ? name : "(null)");
+        abort();
+    }
     return (i >= 0 && ctx && ctx->opt_set[i]) ? ctx->opt_val[i].c_str() : nullptr;
 }
 extern "C" int pmx_set_option(pmx_ctx* ctx, const char* name, const char* value) {
@@ -739,6 +743,7 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
         hipSetDevice(ctx->device);
         pmx_pool_free(ctx, cv->data);
         pmx_pool_free(ctx, cv->spart);
+        pmx_pool_free(ctx, cv->spart2);
         pmx_pool_free(ctx, cv->codes);
         pmx_pool_free(ctx, cv->ldir);
         pmx_pool_free(ctx, cv->cost8);
@@ -747,6 +752,7 @@ extern "C" void pmx_cv_free(pmx_ctx* ctx, pmx_cv* cv) {
     } else {
         hipFree(cv->data);
         hipFree(cv->spart);
+        hipFree(cv->spart2);
         hipFree(cv->codes);
         hipFree(cv->ldir);
     }

@@ -146,8 +146,8 @@ void pmx_pool_free(pmx_ctx* ctx, void* p);
 void pmx_pool_release(pmx_ctx* ctx);  // hipFree every cached block
 
 // exact representations a cost-volume handle can be in (see pmx_set_lazy in the public header)
-// PMX_REPR_SGM_UP_PENDING (float32 family schedule, lazy mode): `data` still holds the matching costs, `spart` the sum of the
-// horizontal and downward paths; the upward family has not run.  pmx_wta runs it in WTA mode (S is never written), anything that
+// PMX_REPR_SGM_UP_PENDING (float32 family schedule, lazy mode): `data` still holds the matching costs, `spart` (and `spart2`) the
+// sums of the horizontal and downward paths; the upward family has not run.  pmx_wta runs it in WTA mode (S is never written), anything that
 // needs the optimised volume runs it in store mode first (pmx_cv_materialize).
 enum { PMX_REPR_FLOAT = 0, PMX_REPR_ALL_NAN = 1, PMX_REPR_CENSUS_DEFERRED = 2, PMX_REPR_SGM_U8X8 = 3, PMX_REPR_SGM_UP_PENDING = 4 };
 
@@ -184,10 +184,14 @@ struct pmx_cv {
     uint8_t* missing = nullptr;
     size_t missing_bytes = 0;
     bool has_missing = false;
-    // PMX_REPR_SGM_UP_PENDING: the partial sum volume (kept with the handle for the next pair) and what pmx_sgm was asked for
+    // PMX_REPR_SGM_UP_PENDING: the partial sum volumes (kept with the handle for the next pair) and what pmx_sgm was asked for:
+    // spart = the horizontal pair's sum (or, when the downward family ran behind it, the sum of both), spart2 = the downward
+    // family's own sum when it ran beside the pair (pending.two)
     float* spart = nullptr;
     size_t spart_bytes = 0;
-    struct { float P1, P2, invalid_cost; int is_max, overcounting; } pending = {0.f, 0.f, 0.f, 0, 0};
+    float* spart2 = nullptr;
+    size_t spart2_bytes = 0;
+    struct { float P1, P2, invalid_cost; int is_max, overcounting, two; } pending = {0.f, 0.f, 0.f, 0, 0, 0};
     size_t cells() const { return (size_t)H * (size_t)W * (size_t)D; }
 };
 
@@ -289,11 +293,14 @@ int pmx_launch_mask_dilate(pmx_ctx* ctx, const int16_t* msk, int H, int W, int w
 int pmx_launch_fill_nan(pmx_ctx* ctx, float* p, size_t n);
 int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, float invalid_cost, int overcounting);
 bool pmx_sgm_family_supported(const pmx_ctx* ctx, const pmx_cv* cv);
-// the six non-horizontal paths of `mask` as two fused marching passes adding into S (which already holds the horizontal ones)
-// fams: bit 0 the downward family, bit 1 the upward one.  wta != nullptr: the upward family (which must be the last pass) does not
-// write S but reduces over D (k_sgmfam.hip WTA mode)
-int pmx_launch_sgm_families(pmx_ctx* ctx, pmx_cv* cv, float* S, float P1, float P2, int is_max, float invalid_cost, int overcounting,
-                            int mask, int fams, const pmx_fam_wta* wta);
+// One marching pass (k_sgmfam.hip): family `fam` (0: the three downward paths, 1: the three upward ones), the paths of `bits`
+// (bit 0 vertical, 1 predecessor column c-1, 2 predecessor column c+1) summed on their own and written as out = [in1 +] [in2 +]
+// that sum; epilogue: the pass finishes S.  wta != nullptr: `out` is not written, the pass reduces over D (WTA mode).  st: the stream
+// (nullptr = the context's own).
+int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, const float* in2, float* out, float P1, float P2,
+                          int is_max, float invalid_cost, int overcounting, int bits, bool epilogue, const pmx_fam_wta* wta,
+                          hipStream_t st);
+int pmx_sgm_family_prepare(pmx_ctx* ctx, const pmx_cv* cv);  // the hand-off buffer of the float32 marching passes, on the context's stream
 int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes);  // hand-off buffer + ticket / error words of the marching kernels
 // integer path as direction families (k_sgmfam8.hip): the vertical families' byte sums into out + f * dstride
 int pmx_fam8_waves(const pmx_ctx* ctx, int W);
