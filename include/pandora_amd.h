@@ -73,10 +73,12 @@ int pmx_set_masks(pmx_ctx* ctx, const int16_t* msk_left, const int16_t* msk_righ
  * matching_cost/matching_cost.py:845-860. */
 int pmx_set_disparity_grids(pmx_ctx* ctx, const double* disp_min, const double* disp_max);
 
-/* Opt-in placement-aware allocation (no reference counterpart: the reference works in host memory).  For every NEW buffer of 256 MB
- * or more the context allocates up to `trials` candidates, times one streaming fill and read of each and keeps the fastest: on MI355X the
- * bandwidth of a hipMalloc'd buffer depends on where the driver placed it.  One-time cost of a few hundred ms per
- * buffer size; cached buffers are reused as they are.  trials = 1 (default) switches it off. */
+/* Placement-aware allocation (no reference counterpart: the reference works in host memory).  For every NEW buffer of 256 MB
+ * or more the context allocates up to `trials` candidates (never holding more than half of the free memory), times one streaming fill
+ * and read of each and keeps the fastest: on MI355X the bandwidth of a hipMalloc'd buffer depends on where the driver placed it
+ * (DESIGN.md 4).  One-time cost of a few hundred ms per buffer size; cached buffers are reused as they are.  The default is 6
+ * (round 6: what every caller of the library gets - until round 5 it was an opt-in that only bench.py used); trials = 1 switches
+ * it off (plain hipMalloc). */
 int pmx_set_placement_trials(pmx_ctx* ctx, int trials);
 /* What plain streaming kernels reach on this device, in GB/s (no reference counterpart; SURVEY 8d: "measure achievable with a device
  * memcpy/triad on the box and report both"): a 16-byte-per-lane fill, read and copy of `bytes` (two buffers of that size are allocated
@@ -316,6 +318,10 @@ int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size
  * numerator 0 .. 65535 and denominator 1 .. 1024 on the device; *mismatches receives how many quotients differ in any bit (0 is
  * the contract; aggregation.cpp:108-121 divides in float32). */
 int pmx_debug_small_division(pmx_ctx* ctx, unsigned* mismatches);
+/* Debug: the window table of the last float32 marching pass of SGM (csrc/k_sgmfam.hip): words [0..7] the tickets taken per XCD,
+ * [8 + w] = 1 + the XCD window w ran on.  Returns the number of words copied (<= max_words) or a negative error.  No reference
+ * counterpart (the reference has no GPU code); used by tests/test_gpu_sgm_family.py to check the placement the kernel asked for. */
+int pmx_debug_fam_windows(pmx_ctx* ctx, unsigned* host_out, int max_words);
 /* ---- validation --------------------------------------------------------------------------
  * Replaces validation.CrossCheckingAccurate.disparity_checking (src/pandora/validation/validation.py:226-371; the
  * class is registered for both "cross_checking_accurate" and "cross_checking_fast").  Host maps in/out, computed

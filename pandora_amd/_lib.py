@@ -99,6 +99,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_float)]),
     "pmx_debug_path_costs": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), C.c_size_t, c_int_p, c_int_p, c_int_p]),
     "pmx_debug_small_division": (C.c_int, [vp, C.POINTER(C.c_uint)]),
+    "pmx_debug_fam_windows": (C.c_int, [vp, C.POINTER(C.c_uint), C.c_int]),
     "pmx_set_placement_trials": (C.c_int, [vp, C.c_int]),
     "pmx_measure_hbm": (C.c_int, [vp, C.c_size_t, c_double_p, c_double_p, c_double_p]),
     "pmx_release_caches": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -18,7 +18,9 @@
 // form a one-directional pipeline: nobody waits for anything its right neighbour produces, so the hand-off latency is
 // paid once as pipeline lag and not once per row.  Windows are not wrapped around the image: workgroup s exists for
 // s = 0 .. (W+H-2)/CW and is active on the rows where its window meets the image.  The window index comes from an
-// atomic ticket, so a workgroup's left neighbour has always started before it: no co-residency assumption, no deadlock.
+// atomic ticket of the XCD the workgroup finds itself on (fam_args::xtab): within an XCD's sequence windows are taken in order,
+// so the leftmost unfinished window is either running or the next one of a sequence whose XCD has CUs free - a free CU gets
+// the next workgroup, which takes it: no co-residency assumption, no deadlock (every spin is bounded all the same).
 //
 // Inside a workgroup the two shifting paths change lane group every row: they go through LDS (double-buffered by row
 // parity, one barrier per row).  The left neighbour's last two columns arrive through global memory as 8-byte
@@ -79,7 +81,13 @@ struct fam_args {
     u32x4* halo;     // hand-off blocks [H][NB][NGP] of 16 bytes {value, value, value, epoch ^ the three}
     int NB;          // window borders per row = ceil(W / CW)
     unsigned epoch;
-    unsigned* ctl;   // [0] ticket counter (zero at launch), [1] error word
+    unsigned* ctl;   // [1] error word ([0] is the integer marching kernel's ticket)
+    // Window tickets per XCD (round 6).  A workgroup reads the XCD it runs on and takes the next window of THAT XCD's sequence:
+    // chunks of G consecutive windows go round the eight XCDs, window = ((t / G) * 8 + xcd) * G + t % G for the XCD's t-th ticket,
+    // so G - 1 of G window borders have both sides on one XCD and their hand-off can stay in that XCD's L2 (see publish).
+    // xtab: [0..7] the XCDs' ticket counters, [8 + w] = 1 + the XCD window w runs on, 0 until it has started (zeroed per launch).
+    unsigned* xtab;
+    int G, nwin;
     // WTA mode (last pass only, template flag): S is not written; the pass reduces over D and leaves, per pixel, the winner's
     // disparity and (S[k-1], S[k], S[k+1], k) for the refinement step
     float* disp;
@@ -153,7 +161,6 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     constexpr int NG = 3 * NVB + 1;        // blocks per (row, border): V[CW-1], A[CW-1], A[CW-2], then one block of their three minima
     constexpr int NQ = (NG + 63) / 64;
     constexpr int NGP = NQ * 64;
-    constexpr int KH = NQ > 10 ? 2 : 4;   // hand-off look-ahead in rows (register ring of the hand-off wave)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // [0] window index, [1], [2] abort flag by row parity.  An LDS pointer by TYPE (address space 3): through a generic volatile
     // pointer these reads were flat loads, and a flat load's wait (vmcnt(0) lgkmcnt(0)) also waits for every global load in
@@ -165,12 +172,29 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform values live in scalar registers: buffer
     if (threadIdx.x == 0) {                                              // descriptors built from them need no waterfall loop
-        ctl[0] = (int)atomicAdd(a.ctl, 1u);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        // the next window of this XCD's sequence; when that sequence is used up (more workgroups landed here than it has
+        // windows), of the next XCD's that still has one - placement is for speed only, every window is taken exactly once
+        // whatever the dispatcher does, and within a sequence in order
+        int win = -1;
+        for (int i = 0; i < 8 && win < 0; ++i) {
+            const unsigned x = (xcc + (unsigned)i) & 7u;
+            const unsigned t = atomicAdd(a.xtab + x, 1u);
+            const unsigned cand = ((t / (unsigned)a.G) * 8u + x) * (unsigned)a.G + t % (unsigned)a.G;
+            if (cand < (unsigned)a.nwin) win = (int)cand;
+        }
+        if (win >= 0) __hip_atomic_store(a.xtab + 8 + win, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl[0] = win;
         ctl[1] = 0;
         ctl[2] = 0;
+        ctl[3] = (int)xcc;
     }
     __syncthreads();
     const int s = __builtin_amdgcn_readfirstlane(ctl[0]);
+    if (s < 0) return;  // (more workgroups than windows: the launch is rounded up so that every XCD gets its share)
+    const unsigned my_xcc = (unsigned)__builtin_amdgcn_readfirstlane(ctl[3]);
     const int H = a.H, W = a.W, D = a.D;
     const int base = s * CW;
     const int r_lo = base - W + 1 > 0 ? base - W + 1 : 0;
@@ -214,33 +238,31 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             oneoff[q] = ldsoff[q] + ((off & 1) ? 0 : 2);
         }
         // Rows tA .. tB of the neighbour are needed (row t feeds this window's row t+1: 1 <= t+1 <= base, r_lo <= t+1 <= r_hi).
-        // Their loads are issued KH barriers ahead into a register ring, so that in the steady state - the neighbour a few rows
-        // ahead - the round trip of a row's blocks is hidden behind KH steps of the compute waves; a row that had not been
-        // published yet when its load was issued is re-read (bounded spin) when it is due, which also pushes this window
-        // further behind its neighbour until the look-ahead always hits.
+        // A row is read when it is due and read again (bounded spin) until all of its blocks carry this launch's tag.  Until round
+        // 5 the rows were also requested four barriers ahead into a register ring; with the publishing order of round 6 (below)
+        // a window runs less than a row behind its neighbour, no look-ahead load ever found its row, and the counters showed
+        // 2.2 bytes of hand-off fetched for every byte published: the ring is gone (4096^2 x 257 / 10000^2 x 129, alternated on one
+        // box: 43.9 / 125.2 and 43.7 / 125.4 ms per pipeline step without it against 46.7 / 126.9 and 44.3 / 125.8 with it).
         const int tA = r_lo - 1 > 0 ? r_lo - 1 : 0;
         const int tB = (r_hi < base ? r_hi : base) - 1;
-        u32x4 x[KH][NQ];
-        // descriptor of the neighbour's block for row t; an empty one (every access out of range: loads give 0, no traffic) when
-        // the row is not needed, so that no memory instruction sits under a branch
+        // descriptor of the neighbour's block for row t
         auto in_rsrc = [&](int t) {
-            const bool need = t >= tA && t <= tB;
             const int cb = base - (t + 1);  // image column of the neighbour's last pixel on row t (0 <= cb < W when needed)
 #if defined(PMX_EXP_HALO) && (PMX_EXP_HALO & 1)  // timing experiment (results wrong): every hand-off read hits one cached slot
-            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + (size_t)(s & 255) * NGP), 0, need ? kBlockBytes : 0u, kRsrcWord3);
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + (size_t)(s & 255) * NGP), 0, kBlockBytes, kRsrcWord3);
 #endif
-            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + ((size_t)(need ? t : 0) * a.NB + (need ? cb / CW : 0)) * NGP), 0,
-                                                     need ? kBlockBytes : 0u, kRsrcWord3);
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.halo + ((size_t)t * a.NB + cb / CW) * NGP), 0, kBlockBytes, kRsrcWord3);
         };
-        auto issue = [&](int t, u32x4 (&slot)[NQ]) {
-            const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
-        };
-        auto consume = [&](int t, u32x4 (&slot)[NQ]) -> bool {
+        auto consume = [&](int t) -> bool {
             if (t < tA || t > tB) return true;
             const __amdgpu_buffer_rsrc_t rs = in_rsrc(t);
+            u32x4 slot[NQ];
             for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
+#ifdef PMX_FAM_STATS
+                if (lane == 0) atomicAdd(a.xtab + 8 + a.nwin + (spins == 0 ? 2 : 3), 1u);  // rows consumed / extra reads of a row
+#endif
                 bool ok = true;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) ok &= nreal[q] == 0 || slot[q].w == (a.epoch ^ slot[q].x ^ slot[q].y ^ slot[q].z);
@@ -253,18 +275,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                     if (lane == 0) __hip_atomic_store(errw, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return false;
                 }
+                // (Round 6 tried waiting on the row's LAST block alone - one 16-byte request per poll - before reading the row again:
+                //  fewer bytes, but a second dependent round trip in almost every row, since a window runs right behind its
+                //  neighbour: 4096^2 x 257 48.5 / 47.3 ms with it against 46.7 / 46.3 without, alternated on one box.)
                 __builtin_amdgcn_s_sleep(1);
-                // The row is not there yet: wait on its LAST block alone (the three minima, the producer's last store: one 16-byte
-                // request per poll where re-reading the row was 4.6 KB at D = 257 - round 5's counters show the marching kernels
-                // fetching 2.2 bytes of hand-off for every byte published), then read the row again; every block is still
-                // checked by its own tag above, so a row whose stores landed out of order is simply polled once more.
-                for (unsigned p2 = 0; p2 < 64; ++p2) {
-                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(3 * NVB) * 16u, 0, kSc1);
-                    if (t.w == (a.epoch ^ t.x ^ t.y ^ t.z)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
             }
             float* Eb = lds + (t & 1) * EBUF;
 #pragma unroll
@@ -286,11 +300,30 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
             }
             return true;
         };
-        // Publishes row t of this window for window s+1: the compute waves left the path costs of local columns CW-2, CW-1 in LDS
-        // (column slots CW, CW+1 of row parity t & 1 - the same layout, CW slots further, as the incoming columns), complete
-        // once barrier t is passed and untouched until barrier t+1.  Window s+1 computes row t+1 at image column cb = base+CW-1-t:
-        // it exists and needs the row iff cb < W and t < H-1 (else an empty descriptor drops the stores).
+        // Who reads what this window publishes: window s + 1.  When it runs on THIS XCD (it says so in xtab once it has started;
+        // by construction G - 1 of G neighbours do), the blocks are written with plain stores: they stay in the XCD's L2, where the
+        // neighbour's L1-bypassing loads find them - no trip over the fabric for the reader, and the 2.2 bytes fetched per byte
+        // published (look-ahead loads that came too early, polls) become L2 hits.  Until it is known to be here - not started
+        // yet, another XCD's chunk, a window taken out of turn - write-through (sc1) stores, which every reader sees.  Only ever
+        // a question of speed: a block is taken by its tag whichever way it was written.
+#ifdef PMX_FAM_ALLSC1  // experiment: write-through stores whoever reads them
+        bool peer_known = true, peer_local = false;
+#else
+        bool peer_known = (s + 1) % a.G == 0 || s + 1 >= a.nwin, peer_local = false;
+#endif
+        unsigned peer_probe = 0;  // xtab[8 + s + 1] as read one row ago (in flight behind this row's other loads)
         auto publish = [&](int t) {
+            if (!peer_known) {
+                if (peer_probe != 0u) {
+                    peer_known = true;
+                    peer_local = peer_probe == my_xcc + 1u;
+                } else {
+                    peer_probe = __hip_atomic_load(a.xtab + 8 + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#ifdef PMX_FAM_STATS
+            if (lane == 0) atomicAdd(a.xtab + 8 + a.nwin + (peer_local ? 0 : 1), 1u);  // rows published with plain / write-through stores
+#endif
             const int cb = base + CW - 1 - t;
 #if defined(PMX_EXP_HALO) && (PMX_EXP_HALO & 2)  // timing experiment (results wrong): nothing is published
             const bool need = false;
@@ -318,24 +351,20 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                     b.z = b.x;
                 }
                 b.w = a.epoch ^ b.x ^ b.y ^ b.z;
-                __builtin_amdgcn_raw_buffer_store_b128(b, rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
+                if (peer_local) __builtin_amdgcn_raw_buffer_store_b128(b, rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(b, rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
             }
         };
-        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi; ring slot of row t = (t - (r_lo-1)) % KH
-#pragma unroll
-        for (int u = 0; u < KH; ++u) issue(r_lo - 1 + u, x[u]);
-        for (int t = r_lo - 1; t <= r_hi; t += KH) {
-#pragma unroll
-            for (int u = 0; u < KH; ++u) {
-                const int tt = t + u;
-                if (tt <= r_hi) {
-                    if (!consume(tt, x[u])) ctl[1 + (tt & 1)] = 1;
-                    issue(tt + KH, x[u]);
-                    publish(tt - 1);
-                    __syncthreads();
-                    if (__builtin_amdgcn_readfirstlane(ctl[1 + (tt & 1)])) return;
-                }
-            }
+        // barrier index t runs from r_lo-1 (the barrier before the first step) to r_hi
+        for (int tt = r_lo - 1; tt <= r_hi; ++tt) {
+            // publish first: row tt-1 has been complete since barrier tt-1, and whatever this window still has to wait for from
+            // ITS left neighbour must not hold up the window on its right (round 6: with the stores behind the wait every window
+            // ran one row + one hand-off latency behind its neighbour, now one latency: 4096^2 x 257 46.0 - 46.3 -> 44.3 - 44.6 ms
+            // per pipeline step, 10000^2 x 129 128.9 - 129.7 -> 126.2 - 126.4, alternated on one box)
+            publish(tt - 1);
+            if (!consume(tt)) ctl[1 + (tt & 1)] = 1;
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(ctl[1 + (tt & 1)])) return;
         }
         publish(r_hi);
         return;
@@ -664,6 +693,20 @@ int dispatch_family(pmx_ctx* ctx, const fam_shape& f, const fam_args& a, int nwg
 
 }  // namespace
 
+// CUs of one XCD (the windows of one chunk of an XCD's ticket sequence, this file and k_sgmfam8.hip)
+int pmx_cus_per_xcd() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        const int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                            ? prop.multiProcessorCount : 256;
+        n = cus >= 8 ? cus / 8 : 1;
+        if (n > 64) n = 64;
+    }
+    return n;
+}
+
 // The strip-to-strip hand-off buffer of the marching kernels (this file and k_sgmfam8.hip): at least `halo_bytes`, zeroed when
 // (re)allocated so that a stale tag can never equal a future epoch (epochs count launches from 1), plus the ticket / error words.
 int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes) {
@@ -715,7 +758,24 @@ int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, c
     // (the hand-off buffer and its control words are (re)made on the context's own stream: a pass on the second stream was forked
     //  from it behind them)
     if (int rcp = pmx_fam_prepare(ctx, halo_bytes)) return rcp;
-    const int nwg = (cv->W + cv->H - 2) / CW + 1;
+    const int nwin = (cv->W + cv->H - 2) / CW + 1;
+    // windows per chunk of one XCD's sequence (fam_args::xtab): as many as an XCD has CUs, one workgroup each (SGM_FAM_XCD=<G>: A/B
+    // hook; 1 = every neighbour on another XCD).  Measured at 4096^2 x 257 / 10000^2 x 129, ms per pipeline step on one box:
+    // G = 1: 53.0 / 140, 8: 50.4 / 138, 16: 55.5 / 150, 32: 47.6 / 126 (the global ticket of round 5: 48.4 / 129).
+    int G = pmx_cus_per_xcd();
+    if (const char* eg = pmx_opt(ctx, "SGM_FAM_XCD")) {
+        const int g = atoi(eg);
+        if (g >= 1 && g <= 64) G = g;
+    }
+    const int nwg = (nwin + 8 * G - 1) / (8 * G) * (8 * G);  // every XCD's share of the launch covers its sequence
+    const size_t xtab_words = 8 + (size_t)nwin + 8;  // (+ 8 statistics words of the PMX_FAM_STATS build)
+    if (ctx->fam_xtab_words < xtab_words) {
+        if (ctx->fam_xtab) PMX_HIP(hipFree(ctx->fam_xtab));
+        ctx->fam_xtab = nullptr;
+        ctx->fam_xtab_words = 0;
+        PMX_HIP(hipMalloc((void**)&ctx->fam_xtab, (xtab_words + 1024) * sizeof(unsigned)));
+        ctx->fam_xtab_words = xtab_words + 1024;
+    }
     fam_args a;
     a.C = cv->data;
     a.in1 = in1; a.in2 = in2; a.out = out;
@@ -729,12 +789,15 @@ int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, c
     a.NB = NB;
     a.epoch = pmx_fam_tag(++ctx->fam_epoch);
     a.ctl = ctx->fam_ctl;
+    a.xtab = ctx->fam_xtab;
+    a.G = G;
+    a.nwin = nwin;
     a.disp = wta ? wta->disp : nullptr;
     a.near = wta ? wta->near : nullptr;
     a.d0 = wta ? wta->d0 : 0.0;
     a.subpix = wta ? wta->subpix : 1;
     a.invalid_disparity = wta ? wta->invalid_disparity : 0.f;
-    PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), st));  // the ticket; the error word is sticky
+    PMX_HIP(hipMemsetAsync(ctx->fam_xtab, 0, xtab_words * sizeof(unsigned), st));  // tickets and the windows' XCDs (the error word is sticky)
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY, st);
         int rc = dispatch_family(ctx, f, a, nwg, wta != nullptr, st);
@@ -743,4 +806,14 @@ int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, c
     // the error word travels to pinned host memory behind the launch; pmx_check_async_error reads it after a sync
     PMX_HIP(hipMemcpyAsync(ctx->fam_err_host, ctx->fam_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return PMX_OK;
+}
+
+// debug: the last float32 marching launch's window table (fam_args::xtab): [0..7] tickets per XCD, [8 + w] = 1 + XCD of window w
+extern "C" int pmx_debug_fam_windows(pmx_ctx* ctx, unsigned* host_out, int max_words) {
+    PMX_CHECK(ctx && host_out && max_words > 0, PMX_ERR_ARG, "pmx_debug_fam_windows: null argument");
+    PMX_CHECK(ctx->fam_xtab, PMX_ERR_STATE, "pmx_debug_fam_windows: no marching pass has run");
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t)max_words < ctx->fam_xtab_words ? (size_t)max_words : ctx->fam_xtab_words;
+    PMX_HIP(hipMemcpy(host_out, ctx->fam_xtab, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return (int)n;
 }

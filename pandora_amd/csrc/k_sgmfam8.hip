@@ -72,7 +72,13 @@ struct fam8_args {
     size_t halo_fam;      // blocks per family
     int NB;               // window borders per row = ceil(W / CW)
     unsigned epoch;
-    unsigned* ctl;        // [0] ticket counter (zero at launch), [1] error word
+    unsigned* ctl;        // [1] error word
+    // Window tickets per XCD (round 6, as in k_sgmfam.hip): a workgroup takes the next ticket t of the XCD it runs on: family
+    // t % nfam, window ((t' / G) * 8 + xcd) * G + t' % G with t' = t / nfam - chunks of G consecutive windows of a family share an
+    // XCD, and a publisher whose reader is known to sit on its own XCD writes plain stores instead of write-through ones.
+    // xtab: [0..7] the XCDs' ticket counters, [8 + f * nwin + w] = 1 + the XCD of window w of family fam0 + f (zeroed per launch).
+    unsigned* xtab;
+    int G, nwin;
     int fam0, nfam;       // families of this launch: fam0, fam0 + 1, ... (0 = downward, 1 = upward)
     int prio;             // wave priority of this launch's wavefronts (beside the horizontal-pair kernel on the second stream)
     // CODES form: no cost volume - the Hamming costs are computed here from the census words (one per pixel)
@@ -166,12 +172,31 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) {
-        ctl[0] = (int)atomicAdd(a.ctl, 1u);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        // the next window of this XCD's sequence, or - more workgroups landed here than it has windows - of the next XCD's that
+        // still has one: placement is for speed only, every window is taken exactly once, within a sequence in order
+        int tk = -1;
+        for (int i = 0; i < 8 && tk < 0; ++i) {
+            const unsigned x = (xcc + (unsigned)i) & 7u;
+            const unsigned t = atomicAdd(a.xtab + x, 1u);
+            const unsigned f = t % (unsigned)a.nfam, tp = t / (unsigned)a.nfam;
+            const unsigned cand = ((tp / (unsigned)a.G) * 8u + x) * (unsigned)a.G + tp % (unsigned)a.G;
+            if (cand < (unsigned)a.nwin) {
+                tk = (int)(cand * (unsigned)a.nfam + f);
+                __hip_atomic_store(a.xtab + 8 + f * (unsigned)a.nwin + cand, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        ctl[0] = tk;
         ctl[1] = 0;
         ctl[2] = 0;
+        ctl[3] = (int)xcc;
     }
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(ctl[0]);
+    if (ticket < 0) return;  // (the launch is rounded up so that every XCD's share covers its sequence)
+    const unsigned my_xcc = (unsigned)__builtin_amdgcn_readfirstlane(ctl[3]);
     const int fam = a.fam0 + ticket % a.nfam;  // 0: rows top -> bottom, paths (+1,0) (+1,+1) (+1,-1);  1: bottom -> top, mirrored
     const int s = ticket / a.nfam;
     const int H = a.H, W = a.W, D = a.D;
@@ -241,9 +266,25 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
             const int pB = r_hi < H - 2 ? r_hi : H - 2;
             const u32x4* rec = rec_of(r_lo) + NGP;
             int pmod = r_lo % CW;
+            // Window s + 1 reads what is published here.  Once it has said (xtab) that it runs on THIS XCD - by construction G - 1
+            // of G neighbours do - the blocks go out as plain stores: they stay in the XCD's L2, where the reader's L1-bypassing
+            // loads find them, and cost a fraction of a write-through store (k_sgmfam.hip, round 6: 51.7 -> 43.8 ms per
+            // 4096^2 x 257 float32 step).  Until then, and for a reader elsewhere: sc1, which every reader sees.  A block is taken by
+            // its tags whichever way it was written.
+            bool peer_known = (s + 1) % a.G == 0 || s + 1 >= a.nwin, peer_local = false;
+            unsigned peer_probe = 0;  // the reader's entry as read one row ago
+            const unsigned* peer_entry = a.xtab + 8 + (size_t)(fam - a.fam0) * a.nwin + (s + 1 < a.nwin ? s + 1 : s);
             __syncthreads();  // the barrier before the first step
             for (int pr = r_lo; pr <= r_hi; ++pr) {
                 __syncthreads();  // barrier pr
+                if (!peer_known) {
+                    if (peer_probe != 0u) {
+                        peer_known = true;
+                        peer_local = __builtin_amdgcn_readfirstlane(peer_probe) == my_xcc + 1u;
+                    } else {
+                        peer_probe = __hip_atomic_load(peer_entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 const __amdgpu_buffer_rsrc_t rs = rsrc_of(rec, pr >= pA && pr <= pB);
                 const uint32_t* Eb = lds8 + (pr & 1) * EBUF + CW * ES;
                 const uint32_t gave_up = (uint32_t)ctl[1];
@@ -261,7 +302,8 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
                     }
                     b.y = a.epoch;
                     b.w = a.epoch;
-                    __builtin_amdgcn_raw_buffer_store_b128(b, rs, boff[q], 0, kSc1);
+                    if (peer_local) __builtin_amdgcn_raw_buffer_store_b128(b, rs, boff[q], 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(b, rs, boff[q], 0, kSc1);
                 }
                 if (__builtin_amdgcn_readfirstlane(gave_up) != 0u) return;  // (the consumer's: this launch has failed)
                 rec += row_blocks;
@@ -681,6 +723,24 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.epoch = pmx_fam_tag(++ctx->fam_epoch);
     a.ctl = ctx->fam_ctl;
     a.fam0 = fam0; a.nfam = nfam;
+    const int nwin = (cv->W + cv->H - 2) / CW + 1;
+    // windows of a family per chunk of an XCD's sequence: an XCD's CUs shared by the launch's families (SGM8_FAM_XCD=<G>: A/B hook)
+    int G = pmx_cus_per_xcd() / nfam;
+    if (const char* eg = pmx_opt(ctx, "SGM8_FAM_XCD")) {
+        const int g = atoi(eg);
+        if (g >= 1 && g <= 64) G = g;
+    }
+    if (G < 1) G = 1;
+    const int nwg = (nwin + 8 * G - 1) / (8 * G) * (8 * G) * nfam;
+    const size_t xtab_words = 8 + (size_t)nwin * nfam;
+    if (ctx->fam_xtab_words < xtab_words) {
+        if (ctx->fam_xtab) PMX_HIP(hipFree(ctx->fam_xtab));
+        ctx->fam_xtab = nullptr;
+        ctx->fam_xtab_words = 0;
+        PMX_HIP(hipMalloc((void**)&ctx->fam_xtab, (xtab_words + 1024) * sizeof(unsigned)));
+        ctx->fam_xtab_words = xtab_words + 1024;
+    }
+    a.xtab = ctx->fam_xtab; a.G = G; a.nwin = nwin;
     const char* eprio = pmx_opt(ctx, "SGM8_FAM_PRIO");
     // (round 4, one hand-off wavefront: 0: 14.6 ms per 4096^2 x 257 step, 3: 13.9.  Round 5, two hand-off wavefronts, alternated on two boxes:
     //  3: 13.60 - 13.72 / 14.29 - 14.31, 2: 14.26 - 14.36, 1: 13.39 - 13.44 / 13.99 - 14.09, 0: 14.47 - 14.54)
@@ -689,13 +749,12 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     a.codeL_off = (unsigned)(cv->codeL - cv->codes); a.codeR_off = (unsigned)(cv->codeR - cv->codes);
     a.d0 = cv->d0; a.o = cv->win / 2; a.invalid_cost = invalid_cost;
     if (from_codes) PMX_CHECK(cv->codes && cv->codes_bytes < 0xfffff000ull, PMX_ERR_STATE, "pmx_sgm (family form): census codes missing or too large");
-    const int nwin = (cv->W + cv->H - 2) / CW + 1;
-    PMX_HIP(hipMemsetAsync(ctx->fam_ctl, 0, sizeof(unsigned), ctx->stream));  // the ticket; the error word is sticky
+    PMX_HIP(hipMemsetAsync(ctx->fam_xtab, 0, xtab_words * sizeof(unsigned), ctx->stream));  // tickets and the windows' XCDs (the error word is sticky)
     {
         pmx_stage_scope t(ctx, PMX_STAGE_SGM_FAMILY);
 #define PMX_FAM8(KPLV, CB)                                                                              \
-    (nw == 8 ? launch_fam8<KPLV, CB, 8>(ctx, a, nwin * nfam) : launch_fam8<KPLV, CB, 4>(ctx, a, nwin * nfam))
-#define PMX_FAM8C(KPLV) (nw == 8 ? launch_fam8<KPLV, 8, 8, true>(ctx, a, nwin * nfam) : launch_fam8<KPLV, 8, 4, true>(ctx, a, nwin * nfam))
+    (nw == 8 ? launch_fam8<KPLV, CB, 8>(ctx, a, nwg) : launch_fam8<KPLV, CB, 4>(ctx, a, nwg))
+#define PMX_FAM8C(KPLV) (nw == 8 ? launch_fam8<KPLV, 8, 8, true>(ctx, a, nwg) : launch_fam8<KPLV, 8, 4, true>(ctx, a, nwg))
 #define PMX_FAM8_KPL(KPLV) rc = from_codes ? PMX_FAM8C(KPLV) : (five ? PMX_FAM8(KPLV, 5) : PMX_FAM8(KPLV, 8))
         switch (kpl) {
             case 4: PMX_FAM8_KPL(4); break;

@@ -31,9 +31,9 @@ extern "C" int pmx_device_count(void) {
 // ---- kernel-route / tuning options ---------------------------------------------------------------------------------------------------
 // Every name the library looks at (DESIGN 7b says what each one forces).  The ONE place the environment is read: pmx_create.
 static const char* const kPmxOptNames[] = {
-    "SGM_SCHED", "SGM_PAR", "SGM_HFUSED", "SGM_PENDING", "SGM_FAM_SHAPE", "SGM_FAM_PAR",
+    "SGM_SCHED", "SGM_PAR", "SGM_HFUSED", "SGM_PENDING", "SGM_FAM_SHAPE", "SGM_FAM_PAR", "SGM_FAM_XCD",
     "SGM8", "FUSED_MAP", "COST5", "WTA3", "SGM8_FAM", "SGM8_HPAIR", "SGM8_CODES", "SGM8_FAMCODES", "SGM8_OVERLAP", "SGM8_HF",
-    "SGM8_FAM_NW", "SGM8_FAM_PRIO",
+    "SGM8_FAM_NW", "SGM8_FAM_PRIO", "SGM8_FAM_XCD",
     "CBCA_ARMS_FLAT", "CBCA_ROWS", "CBCA_FAST", "CBCA_FUSE", "CBCA_MARCH", "CBCA_VBUF", "CBCA_SIGN", "CBCA_GEO", "CBCA_VBS",
     "CBCA_ROWDESC", "COMM_OVERLAP",
 };
@@ -153,6 +153,7 @@ extern "C" void pmx_destroy(pmx_ctx* ctx) {
     if (ctx->aux_join) hipEventDestroy(ctx->aux_join);
     hipFree(ctx->fam_halo);
     hipFree(ctx->fam_ctl);
+    hipFree(ctx->fam_xtab);
     if (ctx->fam_err_host) hipHostFree(ctx->fam_err_host);
     if (ctx->line_host) hipHostFree(ctx->line_host);
     if (ctx->stage_host) hipHostFree(ctx->stage_host);
@@ -290,7 +291,7 @@ extern "C" uint64_t pmx_host_fingerprint(const void* data, size_t bytes) { retur
 
 extern "C" void* pmx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-// ---- placement-aware allocation (opt-in, pmx_set_placement_trials) ---------------------------------------------------
+// ---- placement-aware allocation (pmx_set_placement_trials; on by default since round 6) ---------------------------------------------------
 // On MI355X the bandwidth a kernel gets from a hipMalloc'd buffer is a property of that buffer: of several multi-GB buffers
 // of one process some read 8 % faster than the others, reproducibly (tools/ubench/streams8.hip).  A context that
 // will reuse its volumes for many pairs can afford to choose: allocate up to `placement_trials` candidates (all held until the
@@ -343,10 +344,39 @@ __global__ __launch_bounds__(256) void stream_fill_kernel(uint4* __restrict__ p,
     const uint4 w = make_uint4(v, v + 1u, v + 2u, v + 3u);
     for (; i < n; i += step) p[i] = w;
 }
-__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+// The yardstick kernels of pmx_measure_hbm.  Round 6: the one-load-per-iteration grid-stride copy of round 5 got
+// 4.9 - 5.1 TB/s where the guide measures 6.29 for a float4 copy; tools/ubench/hbm_probe.hip tried the shapes (16 B per lane
+// throughout; 4 GiB; one box): copy, a block on a contiguous chunk, four loads in flight per lane, non-temporal: 5.50 - 5.55 TB/s
+// (grid-stride, one load: 4.89; hipMemcpyAsync: 5.10); read, eight loads in flight, 65536 blocks: 6.31 (four, 16384 blocks: 5.99);
+// fill, 16384 blocks: 5.86 - 5.93.  These are the shapes below; the copy does not reach the guide's figure on this pool's boxes,
+// the read does.
+typedef unsigned int pmx_v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(const pmx_v4u* __restrict__ src, pmx_v4u* __restrict__ dst, size_t n) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n ? b0 + per : n;
+    size_t i = b0 + threadIdx.x;
+    for (; i + 3 * 256 < b1; i += 4 * 256) {
+        pmx_v4u v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], dst + i + u * 256);
+    }
+    for (; i < b1; i += 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void stream_read_kernel(const pmx_v4u* __restrict__ p, size_t n, uint32_t* __restrict__ sink) {
     const size_t step = (size_t)gridDim.x * 256;
-    for (; i < n; i += step) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 7 * step < n; i += 8 * step) {
+        pmx_v4u v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + u * step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n; i += step) acc += p[i].x;
+    if (acc == 0x9e3779b9u) sink[0] = acc;  // (keeps the loads alive)
 }
 
 extern "C" int pmx_release_caches(pmx_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
@@ -391,8 +421,8 @@ extern "C" int pmx_measure_hbm(pmx_ctx* ctx, size_t bytes, double* read_gbs, dou
         for (int kind = 0; kind < 3; ++kind) {
             (void)hipEventRecord(e0, ctx->stream);
             if (kind == 0) hipLaunchKernelGGL(stream_fill_kernel, dim3(16384), dim3(256), 0, ctx->stream, (uint4*)a, n, (uint32_t)rep);
-            else if (kind == 1) hipLaunchKernelGGL(placement_probe_kernel, dim3(16384), dim3(256), 0, ctx->stream, (const uint4*)a, n, (uint32_t*)ctx->probe_sink);
-            else hipLaunchKernelGGL(stream_copy_kernel, dim3(16384), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n);
+            else if (kind == 1) hipLaunchKernelGGL(stream_read_kernel, dim3(65536), dim3(256), 0, ctx->stream, (const pmx_v4u*)a, n, (uint32_t*)ctx->probe_sink);
+            else hipLaunchKernelGGL(stream_copy_kernel, dim3(16384), dim3(256), 0, ctx->stream, (const pmx_v4u*)a, (pmx_v4u*)b, n);
             (void)hipEventRecord(e1, ctx->stream);
             float ms = 0.f;
             if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms > 0.f) {

@@ -102,7 +102,7 @@ struct pmx_ctx {
     bool profiling = false;
     bool lazy = true;
     void* probe_sink = nullptr;   // 64 bytes the placement probe may write to
-    int placement_trials = 1;  // pmx_set_placement_trials: candidates probed for every new volume-sized buffer
+    int placement_trials = 6;  // pmx_set_placement_trials: candidates probed for every new volume-sized buffer (round 6: on by default)
     pmx_stage_rec stages[PMX_STAGE_COUNT];
     // caching allocator for the big per-volume buffers (a hipMalloc / hipFree of a few GB costs ~100 ms each on this
     // stack; a stream of pairs allocates and frees the same sizes over and over).  Single stream per context, so a
@@ -117,6 +117,8 @@ struct pmx_ctx {
     size_t fam_halo_bytes = 0;
     unsigned fam_epoch = 0;            // launches of the marching kernels (both kinds share the buffer and this counter)
     unsigned* fam_ctl = nullptr;
+    unsigned* fam_xtab = nullptr;      // float32 marching kernel: per-XCD ticket counters + the windows' XCDs (k_sgmfam.hip fam_args::xtab)
+    size_t fam_xtab_words = 0;
     unsigned* fam_err_host = nullptr;  // pinned copy of the error word, filled behind every family launch
     int sgm_dir_mask = 0xff;           // pmx_debug_sgm_directions
     const float* sgm_p2maps = nullptr; // pmx_sgm_p2maps, for the duration of its call: P2 per pixel and direction (device)
@@ -300,6 +302,7 @@ bool pmx_sgm_family_supported(const pmx_ctx* ctx, const pmx_cv* cv);
 int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, const float* in2, float* out, float P1, float P2,
                           int is_max, float invalid_cost, int overcounting, int bits, bool epilogue, const pmx_fam_wta* wta,
                           hipStream_t st);
+int pmx_cus_per_xcd();  // CUs of one XCD of the current device
 int pmx_sgm_family_prepare(pmx_ctx* ctx, const pmx_cv* cv);  // the hand-off buffer of the float32 marching passes, on the context's stream
 int pmx_fam_prepare(pmx_ctx* ctx, size_t halo_bytes);  // hand-off buffer + ticket / error words of the marching kernels
 // integer path as direction families (k_sgmfam8.hip): the vertical families' byte sums into out + f * dstride
