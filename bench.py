@@ -29,9 +29,11 @@ inside the timed region), `cpu_baseline` (the C oracle, kind "port", 1 thread, o
 census stage only) and, at N=1, `c3_shape` (BASELINE configs[2], 2048x2048x129, the round-1 headline, same protocol),
 `c2_cones` (configs[1]: census + CBCA + SGM on the reference's cones pair), `c4_as_stated` (configs[3] as BASELINE words it: ZNCC 11x11 + SGM + WTA + vfit, 4096x4096x257, float32 kernels) and `c5_as_stated`
 (configs[4]'s fine scale on one GPU: census + CBCA + SGM + WTA + vfit, 10000x10000x129, float32 kernels), each with its own roofline
-block (its dominant kernel family), and `default_allocation` / `value_default_allocation` (the headline step on plain hipMalloc
-buffers, what a caller gets who does not opt into pmx_set_placement_trials; `value` is measured with six candidates per volume, chosen
-before the warm-up - on some boxes the two differ by 10 %).  `roofline.peak_measured` is what plain
+block (its dominant kernel family), and `plain_hipmalloc` (the headline step with the library's buffer placement switched off,
+pmx_set_placement_trials(ctx, 1): what every caller got until round 5.  `value` itself is measured on a context as pmx_create makes
+it - since round 6 the library probes six candidates for every new volume-sized buffer by default, so `value` IS what a plugin user
+gets).  `disparity_linf_vs_cpu` compares the GPU with the CPU oracle on the strip the CPU baseline ran, through the TIMED step's kernel
+instantiation (`disparity_linf_vs_cpu_kernels` names it).  `roofline.peak_measured` is what plain
 streaming kernels reach on the box in the same run (pmx_measure_hbm), beside `peak` = the data sheet's 8000 GB/s.
 The headline part of the line is complete when the timed region ends; everything after it is a rider: one that raises is dropped
 from the line with its error (`leg_errors`), and if the riders are not done `--extras-budget` seconds later (a rank stuck in a
@@ -640,6 +642,10 @@ HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "wa
                  "vs_baseline", "dtype", "data", "config", "roofline", "stage_ms_per_step", "pipeline_hbm_frac")
 
 
+# the routes the 4096-row headline takes by the library's size rules, forced on the short CPU-parity strip (bench parity leg)
+PARITY_ROUTES = (("SGM8_FAM", "1"), ("SGM8_HPAIR", "1"), ("SGM8_CODES", "0"), ("SGM8_FAMCODES", "0"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -650,9 +656,10 @@ def main():
     ap.add_argument("--dmin", type=int, default=0)
     ap.add_argument("--dmax", type=int, default=256)
     ap.add_argument("--cpu-rows", type=int, default=512, help="rows of the CPU-baseline strip (0 = skip)")
-    ap.add_argument("--placement-trials", type=int, default=6,
-                    help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials, an opt-in of the ABI; 1 = plain "
-                         "hipMalloc).  With more than 1, the line also carries `value_default_allocation`: the same step on plain buffers")
+    ap.add_argument("--placement-trials", type=int, default=None,
+                    help="candidates probed for every new volume-sized buffer (pmx_set_placement_trials; 1 = plain hipMalloc).  Not given: "
+                         "the LIBRARY's default (6 since round 6) - `value` is what any caller of pmx_create gets; the line also carries "
+                         "`plain_hipmalloc`: the same step with the placement switched off")
     ap.add_argument("--tuned-trials", type=int, default=6, help="candidates of the `placement_tuned` extra leg when --placement-trials is 1")
     ap.add_argument("--no-c3", action="store_true", help="skip the 2048x2048x129 leg (BASELINE configs[2])")
     ap.add_argument("--no-configs", action="store_true", help="skip the c4_as_stated / c5_as_stated / default_allocation legs (N=1)")
@@ -707,8 +714,9 @@ def main():
             comm = Comm(eng)
         if comm.nranks != world:
             sys.exit(f"bench.py: the communicator reports {comm.nranks} ranks, WORLD_SIZE is {world}")
-    if args.placement_trials > 1:
-        eng.set_placement_trials(args.placement_trials)  # well-placed volumes, chosen once before the warm-up
+    if args.placement_trials is not None:  # (not given: whatever pmx_create set up - the default a plugin user runs with)
+        eng.set_placement_trials(args.placement_trials)
+    placed = args.placement_trials is None or args.placement_trials > 1
 
     # the SAME pair on every rank (strong scaling); a rank keeps its rows + margin resident
     L, R = synthetic_pair(H, W, dmin, dmax)
@@ -910,15 +918,16 @@ def main():
                                        "pipeline_hbm_frac": round(PIPELINE_ALGO_BYTES_PER_CELL * c3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "pcie_inclusive_ms": round(pcie3, 3)}
             if not args.no_configs and (H, W, D) == (4096, 4096, 257):
-                # the headline step on plain hipMalloc buffers (what a plugin user gets who does not call pmx_set_placement_trials), or -
-                # when `value` itself was measured that way - on a context that probes `--tuned-trials` candidates per volume:
-                with rider("default_allocation"):
-                    if args.placement_trials > 1:
+                # the headline step with the library's placement switched off (plain hipMalloc: the round-5 default), or - when `value`
+                # itself was measured that way - on a context that probes `--tuned-trials` candidates per volume:
+                with rider("plain_hipmalloc"):
+                    if placed:
                         plain = Engine(local_rank)
+                        plain.set_placement_trials(1)
                         msd, std, _ = measure_shape(plain, H, W, dmin, dmax, args.steps, args.warmup, 20260928, pcie=False)
-                        out["default_allocation"] = {"placement_trials": 1, "ms_per_step": round(msd, 3), "value": round(cells / msd / 1e3, 1),
-                                                     "unit": "Mdisp/s", "note": "same workload and protocol on a fresh context with plain hipMalloc"}
-                        out["value_default_allocation"] = out["default_allocation"]["value"]
+                        out["plain_hipmalloc"] = {"placement_trials": 1, "ms_per_step": round(msd, 3), "value": round(cells / msd / 1e3, 1),
+                                                  "unit": "Mdisp/s", "note": "same workload and protocol on a fresh context with "
+                                                  "pmx_set_placement_trials(ctx, 1): plain hipMalloc, what every caller got until round 5"}
                         plain.close()
                     elif args.tuned_trials > 1:
                         tuned = Engine(local_rank)
@@ -972,21 +981,32 @@ def main():
                         out["cpu_baseline_reference_compiled"] = refc
                     # parity in the same run: the same strip through the GPU path (vertical paths see only the strip, so the GPU is
                     # re-run on the strip alone)
+                    # ... with the TIMED step's kernels: at this height the library's own size rules would take the row walk and the
+                    # code-word forms (csrc/k_sgm8.hip pmx_launch_sgm8), so the headline's routes are forced on the strip: the cost
+                    # volume, the one-sided horizontal pair, the direction families (roofline.kernel names them)
                     eng2 = Engine(local_rank)
+                    for name, val in PARITY_ROUTES:
+                        eng2.set_option(name, val)
                     eng2.set_images(L[:rows], R[:rows], 1)
                     cv2 = eng2.alloc_cv(D, dmin)
+                    eng2.set_profiling(True)
+                    eng2.reset_stage_times()
                     eng2.census(cv2, win)
                     eng2.sgm(cv2, P1, P2, False, float(win * win + 1), False)
                     eng2.set_validity(None)
                     eng2.wta(cv2, False, -9999.0)
                     gdisp, gval = eng2.get_disparity()
+                    ran = {k: eng2.stage_time(k)[1] for k in ("census_cost", "sgm_fused", "sgm_family", "wta")}
+                    eng2.set_profiling(False)
                     out["disparity_linf_vs_cpu"] = float(np.max(np.abs(gdisp - cdisp)))
+                    out["disparity_linf_vs_cpu_kernels"] = (
+                        "the strip through the timed step's instantiation (" + ", ".join(f"{n}={v}" for n, v in PARITY_ROUTES) + "): "
+                        "census_cost_u8_kernel, sgm_u8_hpair_kernel beside sgm_fam8_kernel, sum3_wta_kernel; launches counted on the strip: "
+                        + json.dumps(ran))
+                    assert ran["census_cost"] and ran["sgm_fused"] and ran["sgm_family"], "the parity strip did not run the headline's kernels"
                     eng2.close()
         if world == 1 and leg_errors:
             out["leg_errors"] = leg_errors
-        if "value_default_allocation" in out:  # (right behind `value`: the two figures a reader should see together)
-            out = {k: v for kk in out if kk != "value_default_allocation" for k, v in
-                   ([(kk, out[kk])] + ([("value_default_allocation", out["value_default_allocation"])] if kk == "value" else []))}
         if guard.finish():
             print(json.dumps(out), flush=True)
     if comm is not None:

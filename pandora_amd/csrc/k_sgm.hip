@@ -706,12 +706,15 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
             a.S = cv->spart;
         }
         const int hb = mask & 3, db = (mask >> 2) & 7, ub = (mask >> 5) & 7;
-        // Round 6: with family-wise sums the downward family reads no earlier sum - it writes S_D into a volume of its own and runs
-        // BESIDE the horizontal pair (second stream); the upward family then adds (S_H + S_D) to its own sum.  The same bytes as
-        // one after the other, one more volume of memory (taken from the pool; without it - or SGM_FAM_PAR=0, the A/B hook -
-        // the downward family runs behind the pair and adds into S).
+        // Round 6: with family-wise sums the downward family reads no earlier sum - it CAN write S_D into a volume of its own and run
+        // BESIDE the horizontal pair (second stream), the upward family then adding (S_H + S_D) to its own sum: SGM_FAM_PAR=1.  Built,
+        // exact, and measured slower than one after the other (alternated twice on one box, ms per pipeline step: 4096^2 x 257
+        // 46.7 / 48.1 beside against 43.8 / 43.8 in line; 10000^2 x 129 133.9 / 128.9 against 125.4 / 125.5): the pair alone moves its
+        // bytes at the rate the box gives a mixed stream, the marching pass nearly so - side by side they share it, and the pair's
+        // wavefronts sit on the marching pass's SIMDs (profiles/r06_fam_par_ab.txt).  So the default stays in line; the hook stays a
+        // tested route.
         const char* epar = pmx_opt(ctx, "SGM_FAM_PAR");
-        bool par = hb && db && ub && !(epar && epar[0] == '0');
+        bool par = hb && db && ub && epar && epar[0] == '1';
         float* SD = nullptr;
         bool sd_temp = false;
         if (par) {

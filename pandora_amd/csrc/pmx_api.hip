@@ -61,7 +61,9 @@ extern "C" int pmx_set_option(pmx_ctx* ctx, const char* name, const char* value)
     ctx->opt_val[i] = value ? value : "";
     return PMX_OK;
 }
-extern "C" const char* pmx_get_option(const pmx_ctx* ctx, const char* name) { return pmx_opt(ctx, name); }
+extern "C" const char* pmx_get_option(const pmx_ctx* ctx, const char* name) {
+    return opt_index(name) >= 0 ? pmx_opt(ctx, name) : nullptr;  // (a caller's unknown name answers "not set"; only the library's own lookups abort)
+}
 extern "C" const char* pmx_option_name(int index) { return index >= 0 && index < kPmxOptCount ? kPmxOptNames[index] : nullptr; }
 
 extern "C" pmx_ctx* pmx_create(int device) {

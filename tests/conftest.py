@@ -27,19 +27,26 @@ class EngineHooks:
     setenv("PMX_SGM8_FAM", "1") / delenv("PMX_SGM8_FAM"); everything set is cleared again at the end of the test."""
 
     def __init__(self, eng):
-        self.eng, self.names = eng, set()
+        self.eng, self.saved = eng, {}
+
+    def _remember(self, name):
+        # what the option held before the test touched it (pmx_create seeds options from PMX_<name>: a run with such a variable
+        # exported must get ITS route back, not "unset")
+        if name not in self.saved:
+            self.saved[name] = self.eng.get_option(name)
 
     def setenv(self, name, value):
+        self._remember(name)
         self.eng.set_option(name, value)
-        self.names.add(name)
 
     def delenv(self, name, raising=False):
+        self._remember(name)
         self.eng.set_option(name, None)
 
     def undo(self):
-        for n in self.names:
-            self.eng.set_option(n, None)
-        self.names.clear()
+        for n, v in self.saved.items():
+            self.eng.set_option(n, v)
+        self.saved.clear()
 
 
 @pytest.fixture

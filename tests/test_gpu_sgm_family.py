@@ -67,12 +67,14 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("beside", ["0", "1"])  # SGM_FAM_PAR: the downward family in line (default) / beside the horizontal pair
 @pytest.mark.parametrize("H,W,D,lanes", SHAPES)
-def test_family_schedule_equals_oracle(eng, oracle, hooks, H, W, D, lanes):
+def test_family_schedule_equals_oracle(eng, oracle, hooks, H, W, D, lanes, beside):
     rng = np.random.default_rng(H * 1000 + W)
     cvh = volume(rng, H, W, D)
     exp = oracle.sgm(cvh, 1.5, 7.25, False, 45.0, False)
     hooks.setenv("PMX_SGM_SCHED", "fam")
+    hooks.setenv("PMX_SGM_FAM_PAR", beside)
     if lanes:
         hooks.setenv("PMX_SGM_FAM_SHAPE", lanes)
     np.testing.assert_array_equal(run(eng, cvh, 1.5, 7.25, False, 45.0, False), exp)
@@ -83,8 +85,9 @@ def test_family_schedule_max_measures_and_overcounting(eng, oracle, hooks, is_ma
     rng = np.random.default_rng(5)
     cvh = volume(rng, 31, 77, 129, is_max)
     exp = oracle.sgm(cvh, 0.3, 1.7, is_max, 45.0, over)
-    for sched in ("seq", "par", "fam"):
+    for sched, beside in (("seq", "0"), ("par", "0"), ("fam", "0"), ("fam", "1")):
         hooks.setenv("PMX_SGM_SCHED", sched)
+        hooks.setenv("PMX_SGM_FAM_PAR", beside)
         np.testing.assert_array_equal(run(eng, cvh, 0.3, 1.7, is_max, 45.0, over), exp)
 
 
@@ -140,14 +143,16 @@ def test_fused_horizontal_pair_equals_the_two_line_passes(eng, oracle, hooks, H,
                 np.testing.assert_array_equal(run(eng, cvh, 1.25, 6.5, is_max, 45.0, over, mask), exp)
 
 
+@pytest.mark.parametrize("beside", ["0", "1"])
 @pytest.mark.parametrize("is_max,over,D", [(False, False, 129), (True, False, 257), (False, True, 61), (True, True, 40)])
-def test_deferred_last_pass_with_fused_wta(oracle, monkeypatch, is_max, over, D):
+def test_deferred_last_pass_with_fused_wta(oracle, monkeypatch, is_max, over, D, beside):
     """Lazy mode + family schedule: pmx_sgm leaves the upward family pending; pmx_wta runs it in WTA mode (the optimised volume is
     never written) and pmx_refine works from the winner's three values; reading the volume instead runs the pass in store mode.
     Every route gives the oracle's bits: disparity, validity (all-NaN pixels included), interpolated coefficient, volume."""
     from pandora_amd.engine import Engine
 
     monkeypatch.setenv("PMX_SGM_SCHED", "fam")
+    monkeypatch.setenv("PMX_SGM_FAM_PAR", beside)  # (two partial-sum volumes pending instead of one)
     rng = np.random.default_rng(D)
     H, W, dmin = 21, 150, -7
     cvh = volume(rng, H, W, D, is_max, nan_frac=0.1)
