@@ -764,13 +764,22 @@ def main():
     leg_errors = {}
     out = None
 
+    leg_seconds = {}
+    trace = os.environ.get("BENCH_TRACE")  # debugging aid: every rank says on stderr when it enters / leaves a leg
+
     def leg(name, fn):
         err = None
         res = None
+        t_leg = time.perf_counter()
+        if trace:
+            print(f"[bench rank {rank}] {time.strftime('%H:%M:%S')} -> {name}", file=sys.stderr, flush=True)
         try:
             res = fn()
         except Exception as e:  # noqa: BLE001 - reported in the line
             err = f"{type(e).__name__}: {e}"[:300]
+        leg_seconds[name] = round(time.perf_counter() - t_leg, 1)
+        if trace:
+            print(f"[bench rank {rank}] {time.strftime('%H:%M:%S')} <- {name} {leg_seconds[name]} s {err or ''}", file=sys.stderr, flush=True)
         failed = float(comm.host_allreduce(np.array([1.0 if err else 0.0]), "max")[0]) > 0
         if failed:
             leg_errors[name] = err or "failed on another rank"
@@ -894,6 +903,7 @@ def main():
                 out["c4_row_tiled"] = c4tiled
             if leg_errors:
                 out["leg_errors"] = leg_errors
+            out["leg_seconds"] = leg_seconds
         else:
             # PCIe-inclusive rate (never `value`): host images in, the three 2-D result maps out, one step, after the barrier
             pcie_s = pcie_inclusive_ms(eng, cv, L, R, win, P1, P2) * 1e-3

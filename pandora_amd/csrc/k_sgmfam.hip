@@ -17,10 +17,11 @@
 // (+1,+1) path from local column j-2: every cross-window dependency now points to the LEFT neighbour only.  Workgroups
 // form a one-directional pipeline: nobody waits for anything its right neighbour produces, so the hand-off latency is
 // paid once as pipeline lag and not once per row.  Windows are not wrapped around the image: workgroup s exists for
-// s = 0 .. (W+H-2)/CW and is active on the rows where its window meets the image.  The window index comes from an
-// atomic ticket of the XCD the workgroup finds itself on (fam_args::xtab): within an XCD's sequence windows are taken in order,
-// so the leftmost unfinished window is either running or the next one of a sequence whose XCD has CUs free - a free CU gets
-// the next workgroup, which takes it: no co-residency assumption, no deadlock (every spin is bounded all the same).
+// s = 0 .. (W+H-2)/CW and is active on the rows where its window meets the image.  The window index comes from the
+// tickets of pmx_buf.h (pmx_take_window): a workgroup prefers windows whose neighbours run on its own XCD and never takes a
+// window whose left neighbour has not been taken - the taken windows are a prefix, every wait is a wait for a resident workgroup,
+// the leftmost unfinished window waits for nobody: no co-residency assumption, no deadlock, also not beside other contexts or
+// processes on the same device (every spin is bounded all the same).
 //
 // Inside a workgroup the two shifting paths change lane group every row: they go through LDS (double-buffered by row
 // parity, one barrier per row).  The left neighbour's last two columns arrive through global memory as 8-byte
@@ -82,12 +83,13 @@ struct fam_args {
     int NB;          // window borders per row = ceil(W / CW)
     unsigned epoch;
     unsigned* ctl;   // [1] error word ([0] is the integer marching kernel's ticket)
-    // Window tickets per XCD (round 6).  A workgroup reads the XCD it runs on and takes the next window of THAT XCD's sequence:
-    // chunks of G consecutive windows go round the eight XCDs, window = ((t / G) * 8 + xcd) * G + t % G for the XCD's t-th ticket,
-    // so G - 1 of G window borders have both sides on one XCD and their hand-off can stay in that XCD's L2 (see publish).
-    // xtab: [0..7] the XCDs' ticket counters, [8 + w] = 1 + the XCD window w runs on, 0 until it has started (zeroed per launch).
+    // Window tickets (pmx_buf.h pmx_take_window): chunks of G consecutive windows belong to XCD (chunk mod 8), a workgroup prefers the
+    // chunks of the XCD it runs on - G - 1 of G window borders then have both sides on one XCD and their hand-off can stay in that
+    // XCD's L2 (see publish) - and never takes a window whose left neighbour is not taken.
+    // xtab: [0 .. nchunk) windows taken per chunk; started[w] = 1 + the XCD window w runs on, 0 until it has started (zeroed per launch).
     unsigned* xtab;
-    int G, nwin;
+    unsigned* started;
+    int G, nwin, nchunk;
     // WTA mode (last pass only, template flag): S is not written; the pass reduces over D and leaves, per pixel, the winner's
     // disparity and (S[k-1], S[k], S[k+1], k) for the refinement step
     float* disp;
@@ -175,17 +177,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;
-        // the next window of this XCD's sequence; when that sequence is used up (more workgroups landed here than it has
-        // windows), of the next XCD's that still has one - placement is for speed only, every window is taken exactly once
-        // whatever the dispatcher does, and within a sequence in order
-        int win = -1;
-        for (int i = 0; i < 8 && win < 0; ++i) {
-            const unsigned x = (xcc + (unsigned)i) & 7u;
-            const unsigned t = atomicAdd(a.xtab + x, 1u);
-            const unsigned cand = ((t / (unsigned)a.G) * 8u + x) * (unsigned)a.G + t % (unsigned)a.G;
-            if (cand < (unsigned)a.nwin) win = (int)cand;
-        }
-        if (win >= 0) __hip_atomic_store(a.xtab + 8 + win, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a window of this XCD's chunks if one may be taken (its left neighbour is), after a while any window that may: placement
+        // is for speed only, every window is taken exactly once whatever the dispatcher does, and never ahead of its left neighbour
+        pmx_win_tickets tk;
+        tk.cnt = a.xtab; tk.G = a.G; tk.nwin = a.nwin; tk.nchunk = a.nchunk; tk.nfam = 1;
+        const int win = pmx_take_window(tk, xcc, 0u);
+        if (win >= 0) __hip_atomic_store(a.started + win, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ctl[0] = win;
         ctl[1] = 0;
         ctl[2] = 0;
@@ -261,7 +258,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) slot[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, nreal[q] ? (unsigned)(q * 64 + lane) * 16u : kOob, 0, kSc1);
 #ifdef PMX_FAM_STATS
-                if (lane == 0) atomicAdd(a.xtab + 8 + a.nwin + (spins == 0 ? 2 : 3), 1u);  // rows consumed / extra reads of a row
+                if (lane == 0) atomicAdd(a.started + a.nwin + (spins == 0 ? 2 : 3), 1u);  // rows consumed / extra reads of a row
 #endif
                 bool ok = true;
 #pragma unroll
@@ -318,11 +315,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void sgm_family_kernel(fam_args a) {
                     peer_known = true;
                     peer_local = peer_probe == my_xcc + 1u;
                 } else {
-                    peer_probe = __hip_atomic_load(a.xtab + 8 + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    peer_probe = __hip_atomic_load(a.started + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 #ifdef PMX_FAM_STATS
-            if (lane == 0) atomicAdd(a.xtab + 8 + a.nwin + (peer_local ? 0 : 1), 1u);  // rows published with plain / write-through stores
+            if (lane == 0) atomicAdd(a.started + a.nwin + (peer_local ? 0 : 1), 1u);  // rows published with plain / write-through stores
 #endif
             const int cb = base + CW - 1 - t;
 #if defined(PMX_EXP_HALO) && (PMX_EXP_HALO & 2)  // timing experiment (results wrong): nothing is published
@@ -767,8 +764,10 @@ int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, c
         const int g = atoi(eg);
         if (g >= 1 && g <= 64) G = g;
     }
-    const int nwg = (nwin + 8 * G - 1) / (8 * G) * (8 * G);  // every XCD's share of the launch covers its sequence
-    const size_t xtab_words = 8 + (size_t)nwin + 8;  // (+ 8 statistics words of the PMX_FAM_STATS build)
+    const int nwg = (nwin + 8 * G - 1) / (8 * G) * (8 * G);  // every XCD's share of the launch covers its chunks
+    const int nchunk = (nwin + G - 1) / G;
+    const size_t ncnt = ((size_t)nchunk + 7) / 8 * 8;
+    const size_t xtab_words = ncnt + (size_t)nwin + 8;  // (+ 8 statistics words of the PMX_FAM_STATS build)
     if (ctx->fam_xtab_words < xtab_words) {
         if (ctx->fam_xtab) PMX_HIP(hipFree(ctx->fam_xtab));
         ctx->fam_xtab = nullptr;
@@ -776,6 +775,7 @@ int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, c
         PMX_HIP(hipMalloc((void**)&ctx->fam_xtab, (xtab_words + 1024) * sizeof(unsigned)));
         ctx->fam_xtab_words = xtab_words + 1024;
     }
+    ctx->fam_xtab_flags = ncnt;
     fam_args a;
     a.C = cv->data;
     a.in1 = in1; a.in2 = in2; a.out = out;
@@ -790,8 +790,10 @@ int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, c
     a.epoch = pmx_fam_tag(++ctx->fam_epoch);
     a.ctl = ctx->fam_ctl;
     a.xtab = ctx->fam_xtab;
+    a.started = ctx->fam_xtab + ncnt;
     a.G = G;
     a.nwin = nwin;
+    a.nchunk = nchunk;
     a.disp = wta ? wta->disp : nullptr;
     a.near = wta ? wta->near : nullptr;
     a.d0 = wta ? wta->d0 : 0.0;
@@ -808,12 +810,15 @@ int pmx_launch_sgm_family(pmx_ctx* ctx, pmx_cv* cv, int fam, const float* in1, c
     return PMX_OK;
 }
 
-// debug: the last float32 marching launch's window table (fam_args::xtab): [0..7] tickets per XCD, [8 + w] = 1 + XCD of window w
+// debug: the last marching launch's window table: [0..7] the first eight chunk counters (windows taken per chunk), [8 + w] = 1 + XCD of
+// window w (of family w / nwin for the integer kernel)
 extern "C" int pmx_debug_fam_windows(pmx_ctx* ctx, unsigned* host_out, int max_words) {
-    PMX_CHECK(ctx && host_out && max_words > 0, PMX_ERR_ARG, "pmx_debug_fam_windows: null argument");
+    PMX_CHECK(ctx && host_out && max_words > 8, PMX_ERR_ARG, "pmx_debug_fam_windows: null argument");
     PMX_CHECK(ctx->fam_xtab, PMX_ERR_STATE, "pmx_debug_fam_windows: no marching pass has run");
     PMX_HIP(hipStreamSynchronize(ctx->stream));
-    const size_t n = (size_t)max_words < ctx->fam_xtab_words ? (size_t)max_words : ctx->fam_xtab_words;
-    PMX_HIP(hipMemcpy(host_out, ctx->fam_xtab, n * sizeof(unsigned), hipMemcpyDeviceToHost));
-    return (int)n;
+    const size_t flags = ctx->fam_xtab_flags, have = ctx->fam_xtab_words - flags;
+    const size_t n = (size_t)(max_words - 8) < have ? (size_t)(max_words - 8) : have;
+    PMX_HIP(hipMemcpy(host_out, ctx->fam_xtab, 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    PMX_HIP(hipMemcpy(host_out + 8, ctx->fam_xtab + flags, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return (int)n + 8;
 }

@@ -13,8 +13,8 @@
 //     column(r, j) = base - r + j,   j = 0 .. CW-1,   base = s * CW,
 // so that the (+1,-1) path stays in its lane group (registers), the vertical path comes from local column j-1 and the (+1,+1)
 // path from j-2: every cross-window dependency points to the LEFT neighbour, workgroups form a one-directional pipeline, and the
-// hand-off latency is paid once as pipeline lag.  Window indices come from an atomic ticket (a window's left neighbour has
-// always started before it: no co-residency assumption); both families run in ONE launch (ticket & 1 = family), so that a CU
+// hand-off latency is paid once as pipeline lag.  Window indices come from the tickets of pmx_buf.h (a window's left neighbour has
+// always been taken before it: no co-residency assumption); both families run in ONE launch, so that a CU
 // holds waves of both and the chip sees 2 x W columns of parallel work.  Inside a workgroup the two shifting paths go through
 // LDS as they are (packed u16 pairs, double-buffered by row parity, one barrier per row); the left neighbour's last two columns
 // arrive through global memory as BYTES (every L_r < 256) in 16-byte blocks {value, tag, value, tag}, tag = the launch's scrambled
@@ -73,12 +73,13 @@ struct fam8_args {
     int NB;               // window borders per row = ceil(W / CW)
     unsigned epoch;
     unsigned* ctl;        // [1] error word
-    // Window tickets per XCD (round 6, as in k_sgmfam.hip): a workgroup takes the next ticket t of the XCD it runs on: family
-    // t % nfam, window ((t' / G) * 8 + xcd) * G + t' % G with t' = t / nfam - chunks of G consecutive windows of a family share an
-    // XCD, and a publisher whose reader is known to sit on its own XCD writes plain stores instead of write-through ones.
-    // xtab: [0..7] the XCDs' ticket counters, [8 + f * nwin + w] = 1 + the XCD of window w of family fam0 + f (zeroed per launch).
+    // Window tickets (pmx_buf.h pmx_take_window, as in k_sgmfam.hip): chunks of G consecutive windows of a family belong to XCD
+    // (chunk mod 8); a workgroup prefers its own XCD's chunks and never takes a window whose left neighbour is not taken; a publisher
+    // whose reader is known to sit on its own XCD writes plain stores instead of write-through ones.
+    // xtab: [f * nchunk + c] windows taken of chunk c of family fam0 + f; started[f * nwin + w] = 1 + the XCD of window w (zeroed per launch).
     unsigned* xtab;
-    int G, nwin;
+    unsigned* started;
+    int G, nwin, nchunk;
     int fam0, nfam;       // families of this launch: fam0, fam0 + 1, ... (0 = downward, 1 = upward)
     int prio;             // wave priority of this launch's wavefronts (beside the horizontal-pair kernel on the second stream)
     // CODES form: no cost volume - the Hamming costs are computed here from the census words (one per pixel)
@@ -175,18 +176,16 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;
-        // the next window of this XCD's sequence, or - more workgroups landed here than it has windows - of the next XCD's that
-        // still has one: placement is for speed only, every window is taken exactly once, within a sequence in order
+        // a window of this XCD's chunks (of either family, the workgroups of an XCD starting with them in turn) if one may be taken,
+        // after a while any window that may: placement is for speed only, every window is taken exactly once and never ahead of its
+        // left neighbour
+        pmx_win_tickets tq;
+        tq.cnt = a.xtab; tq.G = a.G; tq.nwin = a.nwin; tq.nchunk = a.nchunk; tq.nfam = a.nfam;
+        const int got = pmx_take_window(tq, xcc, (blockIdx.x >> 3) & 1u);
         int tk = -1;
-        for (int i = 0; i < 8 && tk < 0; ++i) {
-            const unsigned x = (xcc + (unsigned)i) & 7u;
-            const unsigned t = atomicAdd(a.xtab + x, 1u);
-            const unsigned f = t % (unsigned)a.nfam, tp = t / (unsigned)a.nfam;
-            const unsigned cand = ((tp / (unsigned)a.G) * 8u + x) * (unsigned)a.G + tp % (unsigned)a.G;
-            if (cand < (unsigned)a.nwin) {
-                tk = (int)(cand * (unsigned)a.nfam + f);
-                __hip_atomic_store(a.xtab + 8 + f * (unsigned)a.nwin + cand, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        if (got >= 0) {
+            __hip_atomic_store(a.started + got, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tk = (got % a.nwin) * a.nfam + got / a.nwin;  // (window * nfam + family, as the rest of the kernel reads it)
         }
         ctl[0] = tk;
         ctl[1] = 0;
@@ -273,7 +272,7 @@ __global__ __launch_bounds__((NW + 2) * 64) void sgm_fam8_kernel(fam8_args a) {
             // its tags whichever way it was written.
             bool peer_known = (s + 1) % a.G == 0 || s + 1 >= a.nwin, peer_local = false;
             unsigned peer_probe = 0;  // the reader's entry as read one row ago
-            const unsigned* peer_entry = a.xtab + 8 + (size_t)(fam - a.fam0) * a.nwin + (s + 1 < a.nwin ? s + 1 : s);
+            const unsigned* peer_entry = a.started + (size_t)(fam - a.fam0) * a.nwin + (s + 1 < a.nwin ? s + 1 : s);
             __syncthreads();  // the barrier before the first step
             for (int pr = r_lo; pr <= r_hi; ++pr) {
                 __syncthreads();  // barrier pr
@@ -732,7 +731,9 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
     }
     if (G < 1) G = 1;
     const int nwg = (nwin + 8 * G - 1) / (8 * G) * (8 * G) * nfam;
-    const size_t xtab_words = 8 + (size_t)nwin * nfam;
+    const int nchunk = (nwin + G - 1) / G;
+    const size_t ncnt = ((size_t)nchunk * nfam + 7) / 8 * 8;
+    const size_t xtab_words = ncnt + (size_t)nwin * nfam;
     if (ctx->fam_xtab_words < xtab_words) {
         if (ctx->fam_xtab) PMX_HIP(hipFree(ctx->fam_xtab));
         ctx->fam_xtab = nullptr;
@@ -740,7 +741,8 @@ int pmx_launch_sgm_fam8(pmx_ctx* ctx, pmx_cv* cv, int kpl, bool five, int Dc, ui
         PMX_HIP(hipMalloc((void**)&ctx->fam_xtab, (xtab_words + 1024) * sizeof(unsigned)));
         ctx->fam_xtab_words = xtab_words + 1024;
     }
-    a.xtab = ctx->fam_xtab; a.G = G; a.nwin = nwin;
+    ctx->fam_xtab_flags = ncnt;
+    a.xtab = ctx->fam_xtab; a.started = ctx->fam_xtab + ncnt; a.G = G; a.nwin = nwin; a.nchunk = nchunk;
     const char* eprio = pmx_opt(ctx, "SGM8_FAM_PRIO");
     // (round 4, one hand-off wavefront: 0: 14.6 ms per 4096^2 x 257 step, 3: 13.9.  Round 5, two hand-off wavefronts, alternated on two boxes:
     //  3: 13.60 - 13.72 / 14.29 - 14.31, 2: 14.26 - 14.36, 1: 13.39 - 13.44 / 13.99 - 14.09, 0: 14.47 - 14.54)

@@ -23,6 +23,62 @@ constexpr unsigned kOob = 0x80000000u;       // a byte offset beyond every row: 
 // (masked lanes carry kOob), and an abort returns from inside the loop.  (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched)
 #define PMX_LOOP_ENTRY_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)
 
+// ---- window tickets of the marching kernels (k_sgmfam.hip, k_sgmfam8.hip) --------------------------------------------------------------
+// A marching launch is a one-directional pipeline of column windows: window w reads, row by row, what window w - 1 publishes.
+// WHICH workgroup runs which window is decided when the workgroup starts, and two things are wanted of that decision:
+//   (1) neighbours on one XCD: a hand-off that stays in an XCD's L2 costs a fraction of one over the fabric (round 6: chunks of G
+//       consecutive windows belong to XCD (chunk mod 8); a workgroup prefers the chunks of the XCD it finds itself on);
+//   (2) NO workgroup ever holds a window whose left neighbour has not been taken by a workgroup that is running (or done).  Then
+//       every wait inside the launch is a wait for a resident workgroup, the leftmost unfinished window waits for nobody, and the
+//       launch makes progress on whatever share of the device it gets - beside other kernels, other contexts, other PROCESSES.
+// Round 6's first form (one ticket counter per XCD, taken blindly) had (1) without (2): a workgroup could sit on a CU with the
+// first window of a chunk whose predecessor chunk - another XCD's - nobody had started, and eight processes sharing one GPU held
+// each other's XCDs that way until the spin limits expired ("gave up waiting for a neighbouring window"; found by the 8-rank
+// bench test).  Now: chunk c (of family f) has a counter cnt[f][c] of windows taken; a window of chunk c may only be taken once
+// chunk c - 1 is FULL (cnt >= its size; readiness only ever turns true, so check-then-add needs no compare-and-swap; counters may
+// overshoot, an overshooting ticket is no window).  Inside a chunk windows are taken in order.  So the taken windows of a family
+// are always a prefix: (2).  A workgroup polls its own XCD's chunks for `patience` rounds - at launch the chunks fill one after
+// the other, a ripple of a few microseconds per XCD - and then takes the leftmost window anybody may take, wherever it belongs
+// (always ready, by the prefix property): (1) is a preference, (2) a guarantee.
+// Called by ONE thread.  Returns family * nwin + window, or -1 when every window is taken.
+struct pmx_win_tickets {
+    unsigned* cnt;   // [nfam][nchunk] windows taken per chunk, zeroed per launch
+    int G, nwin, nchunk, nfam;
+};
+__device__ __forceinline__ int pmx_take_window(const pmx_win_tickets& k, unsigned xcc, unsigned first_fam) {
+    auto cap = [&](int c) { const int left = k.nwin - c * k.G; return (unsigned)(left < k.G ? left : k.G); };
+    auto taken = [&](int f, int c) { return __hip_atomic_load(k.cnt + f * k.nchunk + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto try_chunk = [&](int f, int c, bool* not_ready) -> int {
+        if (taken(f, c) >= cap(c)) return -1;                                        // full
+        if (c > 0 && taken(f, c - 1) < cap(c - 1)) { *not_ready = true; return -1; } // its left neighbour chunk still has windows
+        const unsigned t = atomicAdd(k.cnt + f * k.nchunk + c, 1u);
+        return t < cap(c) ? f * k.nwin + c * k.G + (int)t : -1;                      // (filled meanwhile: no window)
+    };
+    constexpr int kPatience = 128;  // rounds of polling the own chunks (several microseconds each) before any window will do
+    for (int round = 0; round < kPatience; ++round) {
+        bool waiting = false;
+        for (int c = (int)xcc; c < k.nchunk; c += 8)
+            for (int ff = 0; ff < k.nfam; ++ff) {
+                const int w = try_chunk((int)((first_fam + (unsigned)ff) % (unsigned)k.nfam), c, &waiting);
+                if (w >= 0) return w;
+            }
+        if (!waiting) break;  // every chunk of this XCD is full
+        __builtin_amdgcn_s_sleep(8);
+    }
+    for (;;) {  // the leftmost window that is free, of either family: its left neighbours are all taken
+        bool any = false;
+        for (int c = 0; c < k.nchunk; ++c)
+            for (int ff = 0; ff < k.nfam; ++ff) {
+                bool nr = false;
+                const int w = try_chunk((int)((first_fam + (unsigned)ff) % (unsigned)k.nfam), c, &nr);
+                if (w >= 0) return w;
+                any |= nr;
+            }
+        if (!any) return -1;  // all full
+        // (a chunk that is not ready behind a chunk that has just been filled by somebody else's add: look again)
+    }
+}
+
 // A lane's KPL consecutive floats move as 16-byte pieces, then an 8-byte one, then a 4-byte one (4-byte alignment is enough
 // for buffer instructions).  piece i = [piece_start(i), piece_start(i) + piece_width(i)).
 template <int KPL>

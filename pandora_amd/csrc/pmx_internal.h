@@ -117,8 +117,9 @@ struct pmx_ctx {
     size_t fam_halo_bytes = 0;
     unsigned fam_epoch = 0;            // launches of the marching kernels (both kinds share the buffer and this counter)
     unsigned* fam_ctl = nullptr;
-    unsigned* fam_xtab = nullptr;      // float32 marching kernel: per-XCD ticket counters + the windows' XCDs (k_sgmfam.hip fam_args::xtab)
+    unsigned* fam_xtab = nullptr;      // marching kernels: chunk counters of the window tickets + the windows' XCDs (pmx_buf.h pmx_take_window)
     size_t fam_xtab_words = 0;
+    size_t fam_xtab_flags = 0;         // ... where the windows' XCD words start in it (behind the chunk counters)
     unsigned* fam_err_host = nullptr;  // pinned copy of the error word, filled behind every family launch
     int sgm_dir_mask = 0xff;           // pmx_debug_sgm_directions
     const float* sgm_p2maps = nullptr; // pmx_sgm_p2maps, for the duration of its call: P2 per pixel and direction (device)
