@@ -147,7 +147,7 @@ def roofline_block(stage, steps, cells):
     launch duration of the marching kernel IS the span of the SGM step (fork -> join on the context's stream, HIP events), and all
     8 paths are priced at SURVEY 8(d)'s 20 B/cell.  Integer path, eight volumes: all 8 paths in one launch.  Otherwise the float32
     schedule's path launches of one step together."""
-    if stage.get("sgm_span", (0, 0))[1] > 0:
+    if stage.get("sgm_span", (0, 0))[1] > 0 and stage["sgm_fused"][1] > 0:  # (the float32 family schedule has a span stage too: the pair + the downward family)
         name = ("sgm_fam8_kernel (two direction families = 6 paths, packed u16 marching kernel, one launch) beside sgm_u8_hpair_kernel "
                 "(horizontal pair) on a second stream: the SGM step, fork -> join")
         ms, n = stage["sgm_span"]

@@ -89,7 +89,11 @@ class AbstractRefinement:
         is_max = cv_left.attrs["type_measure"] == "max"
         dm, vm = disp_right["disparity_map"], disp_right["validity_mask"]
         coords = {k: disp_right.coords[k] for k in ("row", "col") if k in disp_right.coords}
-        eng.set_disparity(np.asarray(dm.data, np.float32), np.asarray(vm.data, np.int64))
+        snaps = [m.device_snapshot() if isinstance(m, DeviceMapArray) and m.engine is eng else None for m in (dm, vm)]
+        if snaps[0] is not None and snaps[1] is not None:
+            eng.maps_restore(snaps[0], snaps[1])  # (device-resident right maps go back device to device, as in subpixel_refinement)
+        else:
+            eng.set_disparity(np.asarray(dm.data, np.float32), np.asarray(vm.data, np.int64))
         eng.refine_approximate(dcv, self._refinement_method_name, is_max)
         disp_right["disparity_map"] = DeviceMapArray(eng, "disp", coords=coords)
         disp_right["validity_mask"] = DeviceMapArray(eng, "validity", coords=coords)

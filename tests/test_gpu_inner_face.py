@@ -271,3 +271,61 @@ def test_cbca_refuses_arms_that_do_not_fit_the_image(face):
     neg[3, 3, 1] = -2
     with pytest.raises(RuntimeError, match="do not fit"):
         face.cbca(cv, neg, neg, cols, cols)
+
+
+@pytest.mark.parametrize("method", ["vfit", "quadratic"])
+@pytest.mark.parametrize("measure,dmin,dmax", [("min", -4, 3), ("max", -2, 5), ("min", -6, -1)])
+def test_plugin_approximate_subpixel_refinement(face, method, measure, dmin, dmax):
+    """AbstractRefinement.approximate_subpixel_refinement (refinement/refinement.py:124-158) on Datasets, as a plugin user calls it:
+    the right map given as host arrays and as device-resident maps (which go back device to device) - both equal the restatement
+    above and, where it is built, the reference's compiled loop_approximate_refinement."""
+    from pandora_amd import refinement
+    from pandora_amd.dataset import Dataset, DeviceVolumeArray
+    from pandora_amd.engine import DeviceMapArray, Engine
+
+    H, W = 19, 27
+    D = dmax - dmin + 1
+    rng = np.random.default_rng(D)
+    cvh = rng.integers(0, 9, (H, W, D)).astype(np.float32)
+    cvh[rng.random(cvh.shape) < 0.1] = np.nan
+    disp = (-(dmin + rng.integers(0, D, (H, W)))).astype(np.float32)
+    mask = np.zeros((H, W), np.int64)
+    diag = (np.arange(W, dtype=np.float32)[None, :] + disp).astype(np.int64)
+    mask[(diag < 0) | (diag >= W)] = 1 << 1
+    mask[rng.random((H, W)) < 0.05] |= 1
+    fn = getattr(face, f"{method}_refinement_method")
+    eitp, ed, em = _approx_restated(cvh, disp, mask, dmin, dmax, 1, measure, fn)
+    rf = _ref("refinement_cpp")
+    if rf is not None:
+        rfn = getattr(rf, f"{method}_refinement_method")
+        ritp, rd, rm = rf.loop_approximate_refinement(cvh, disp.copy(), mask.copy(), float(dmin), float(dmax), 1, measure,
+                                                      lambda cost, d, meas: rfn(cost, d, meas, 8), 963, 8)
+        np.testing.assert_array_equal(eitp, ritp)
+        np.testing.assert_array_equal(ed, rd)
+        np.testing.assert_array_equal(em, rm)
+    eng = Engine(0)
+    try:
+        z = np.zeros((H, W), np.float32)
+        eng.set_images(z, z, 1)
+        dcv = eng.alloc_cv(D, dmin)
+        dcv.from_host(cvh)
+        coords = {"row": np.arange(H), "col": np.arange(W)}
+        cv = Dataset({"cost_volume": DeviceVolumeArray(dcv, coords)}, coords=coords,
+                     attrs={"type_measure": measure, "subpixel": 1})
+        plugin = refinement.AbstractRefinement(refinement_method=method)
+        for resident in (False, True):
+            if resident:  # the maps as a step before would have left them: in the engine's buffers, never read
+                eng.set_disparity(disp, mask)
+                right = Dataset({"disparity_map": DeviceMapArray(eng, "disp", coords=coords),
+                                 "validity_mask": DeviceMapArray(eng, "validity", coords=coords)}, coords=coords)
+            else:
+                right = Dataset({"disparity_map": (("row", "col"), disp.copy()), "validity_mask": (("row", "col"), mask.copy())},
+                                coords=coords)
+            out = plugin.approximate_subpixel_refinement(cv, right)
+            assert out is right and right.attrs["refinement"] == method
+            np.testing.assert_array_equal(np.asarray(right["interpolated_coeff"].data), eitp)
+            np.testing.assert_array_equal(np.asarray(right["disparity_map"].data), ed)
+            np.testing.assert_array_equal(np.asarray(right["validity_mask"].data), em)
+        dcv.free()
+    finally:
+        eng.close()

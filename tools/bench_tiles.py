@@ -64,7 +64,6 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--ranks", default="1,2,4,8", help="rank counts whose interior tile is timed")
     args = ap.parse_args()
-    eng = Engine(0)
     shapes = []
     if args.only in (None, "headline"):
         shapes.append(("headline 4096x4096 d=[0,256] census5+sgm+wta+vfit", 4096, 4096, 0, 256, False))
@@ -78,12 +77,15 @@ def main():
         for n in [int(x) for x in args.ranks.split(",")]:
             rank = 0 if n == 1 else n // 2  # an interior rank: margin on both sides
             (_, _), (tlo, thi) = row_tile(H, n, rank, bench.SGM_MARGIN if n > 1 else 0)
+            # a context of its own per tile size, as a rank of an N-rank run has: its volumes are allocated (and placed) for THIS size -
+            # a tile that re-used the whole pair's cached buffers measured 13 % slower (2.99 against 2.65 ms at 592 rows, round 6)
+            eng = Engine(0)
             ms, stages = time_tile(eng, np.ascontiguousarray(L[tlo:thi]), np.ascontiguousarray(R[tlo:thi]), dmin, dmax, cbca,
                                    args.steps if not cbca else max(1, args.steps // 2))
             whole = ms if whole is None else whole
+            eng.close()
             print(f"{n:5d}  {thi - tlo:9d}  {ms:7.3f}   {whole / ms:6.2f}x             {stages}", flush=True)
         del L, R
-    eng.close()
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@ import bench  # noqa: E402
 SGM_KERNELS = ("sgm_u8_packed_kernel", "sgm_fam8_kernel", "sgm_u8_hpair", "sgm_u8_hrow", "sgm_family_kernel", "sgm_h_checkpoint_kernel",
                "sgm_h_backward_kernel", "sgm_path_kernel", "sgm_sum_paths_kernel", "sgm_census_fused_kernel")
 STEP_MARKERS = ("sum8_refine_kernel", "near_refine_kernel", "refine_kernel")
-NOT_A_STEP = ("placement_probe_kernel", "stream_fill_kernel", "stream_copy_kernel", "__amd_rocclr")  # allocation-time probes, pmx_measure_hbm's streams, the runtime's fills and copies: listed, not summed
+NOT_A_STEP = ("placement_probe_kernel", "stream_fill_kernel", "stream_copy_kernel", "stream_read_kernel", "__amd_rocclr")  # allocation-time probes, pmx_measure_hbm's streams, the runtime's fills and copies: listed, not summed
 
 
 def short(name):
