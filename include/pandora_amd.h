@@ -318,9 +318,11 @@ int pmx_debug_path_costs(pmx_ctx* ctx, const pmx_cv* cv, uint8_t* host_out, size
  * numerator 0 .. 65535 and denominator 1 .. 1024 on the device; *mismatches receives how many quotients differ in any bit (0 is
  * the contract; aggregation.cpp:108-121 divides in float32). */
 int pmx_debug_small_division(pmx_ctx* ctx, unsigned* mismatches);
-/* Debug: the window table of the last float32 marching pass of SGM (csrc/k_sgmfam.hip): words [0..7] the tickets taken per XCD,
- * [8 + w] = 1 + the XCD window w ran on.  Returns the number of words copied (<= max_words) or a negative error.  No reference
- * counterpart (the reference has no GPU code); used by tests/test_gpu_sgm_family.py to check the placement the kernel asked for. */
+/* Debug: the window table of the last marching pass of SGM (csrc/k_sgmfam.hip, k_sgmfam8.hip; tickets: csrc/pmx_buf.h
+ * pmx_take_window): words [0..7] the first eight chunk counters (windows taken per chunk of consecutive windows; a counter may
+ * overshoot its chunk's size), [8 + w] = 1 + the XCD window w ran on (0: never started).  Returns the number of words copied
+ * (<= max_words) or a negative error.  No reference counterpart (the reference has no GPU code); tests/test_gpu_sgm_family.py checks
+ * with it that every window of a launch was taken. */
 int pmx_debug_fam_windows(pmx_ctx* ctx, unsigned* host_out, int max_words);
 /* ---- validation --------------------------------------------------------------------------
  * Replaces validation.CrossCheckingAccurate.disparity_checking (src/pandora/validation/validation.py:226-371; the

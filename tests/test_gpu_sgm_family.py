@@ -203,3 +203,36 @@ def test_deferred_last_pass_with_fused_wta(oracle, monkeypatch, is_max, over, D,
             cv.free()
     finally:
         e.close()
+
+
+def test_every_window_of_a_marching_launch_is_taken(eng, oracle, hooks):
+    """pmx_debug_fam_windows after a family-schedule run with hundreds of windows: every window carries the XCD it ran on (1..8),
+    the chunk counters reached their chunks' sizes - and the result is the oracle's (tickets: csrc/pmx_buf.h pmx_take_window)."""
+    import ctypes
+
+    from pandora_amd import _lib
+
+    rng = np.random.default_rng(11)
+    H, W, D = 64, 5000, 33
+    cvh = rng.integers(0, 30, (H, W, D)).astype(np.float32)
+    exp = oracle.sgm(cvh, 8.0, 32.0, False, 45.0, False)
+    hooks.setenv("PMX_SGM_SCHED", "fam")
+    for g in (None, "4", "1"):  # the library's chunk size (an XCD's CUs), small chunks, every neighbour on another XCD
+        if g:
+            hooks.setenv("PMX_SGM_FAM_XCD", g)
+        np.testing.assert_array_equal(run(eng, cvh, 8.0, 32.0, False, 45.0, False), exp)
+        buf = (ctypes.c_uint * 4096)()
+        n = _lib.lib().pmx_debug_fam_windows(eng.ctx, buf, 4096)
+        assert n > 8
+        words = np.frombuffer(buf, np.uint32)[:n]
+        # 16 lanes x 3 disparities, 8 or 10 compute wavefronts: windows of 32 / 40 columns
+        for cw in (32, 40):
+            nwin = (W + H - 2) // cw + 1
+            flags = words[8:8 + nwin]
+            if (flags >= 1).all() and (flags <= 8).all() and (words[8 + nwin:8 + nwin + 8] == 0).all():
+                break
+        else:
+            raise AssertionError(f"window table: not every window started exactly once: {words[:64]}")
+        G = int(g) if g else None
+        if G:
+            assert (words[:min(8, -(-nwin // G))] >= min(G, nwin)).all() or nwin < G
