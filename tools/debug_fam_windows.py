@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Placement of the float32 marching kernel's windows (csrc/k_sgmfam.hip, fam_args::xtab): which XCD every window ran on, and - in a
+"""Placement of the float32 marching kernel's windows (csrc/k_sgmfam.hip; tickets: csrc/pmx_buf.h pmx_take_window): which XCD every window ran on, and - in a
 library built with -DPMX_FAM_STATS - how many rows were published with plain / write-through stores and consumed at once / re-read.
 Usage: python tools/debug_fam_windows.py [H W D CW]"""
 import ctypes as C
@@ -30,7 +30,7 @@ eng.sync()
 buf = (C.c_uint * 8192)()
 n = _lib.lib().pmx_debug_fam_windows(eng.ctx, buf, 8192)
 t = np.array(buf[:n])
-print("tickets per XCD:", t[:8].tolist())
+print("windows taken of the first eight chunks:", t[:8].tolist())
 tab = t[8:]
 nwin = (W + H - 2) // CW + 1
 x = tab[:nwin].astype(int) - 1
