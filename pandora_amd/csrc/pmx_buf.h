@@ -54,7 +54,10 @@ __device__ __forceinline__ int pmx_take_window(const pmx_win_tickets& k, unsigne
         const unsigned t = atomicAdd(k.cnt + f * k.nchunk + c, 1u);
         return t < cap(c) ? f * k.nwin + c * k.G + (int)t : -1;                      // (filled meanwhile: no window)
     };
-    constexpr int kPatience = 128;  // rounds of polling the own chunks (several microseconds each) before any window will do
+#ifndef PMX_TICKET_PATIENCE
+#define PMX_TICKET_PATIENCE 128
+#endif
+    constexpr int kPatience = PMX_TICKET_PATIENCE;  // rounds of polling the own chunks (several microseconds each) before any window will do
     for (int round = 0; round < kPatience; ++round) {
         bool waiting = false;
         for (int c = (int)xcc; c < k.nchunk; c += 8)
