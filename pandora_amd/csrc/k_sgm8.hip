@@ -1199,11 +1199,20 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     const size_t cvol = (size_t)H * W * Dc;
     // Direction families (k_sgmfam8.hip) when a family's sum fits a byte: three volumes (horizontal pair, downward family, upward
     // family) instead of eight.  PMX_SGM8_FAM=0 keeps the eight path volumes, =1 takes the families whatever the size (test hooks).
-    // By default for wide images: the marching kernels want one 32-column window per CU and family (2560 columns x 2128 rows:
+    // By default for wide images: the marching kernels want one 32-column window per CU and family (round 3: 2560 columns x 2128 rows:
     // 6.8 ms against 7.6; 2048 x 2048 x 129: 3.7 against 2.9), and a few hundred rows to amortise the pipeline of windows
     // (4096 columns: 336 rows 2.7 ms against 2.8, 592 rows 3.7 against 4.1, 1104 rows 5.5 against 6.6, 2128 rows 8.9 against 12.5, 3072 rows
     // 12.3 against 16.7) - profiles/r03_b_shapes.txt, r03_e_shapes.txt.
-    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && W >= 2560 && H >= 480;
+    // Round 6, re-measured after the marching kernel's XCD-local hand-off (profiles/r06_fam_rule.txt): the eight-volume route costs
+    // 4.7 - 6.8 ps per cell (SGM + its WTA), the family form ~(0.48 + 0.058 kpl) us per image ROW whatever the width plus 0.55 ps per
+    // cell for its WTA - so the families win when a row holds enough cells.  Break-even measured at W D = 284 000 for kpl = 12
+    // (2048 rows x 2200 x 129: 3.1 ms either way; 2048 x 129: 2.80 against 2.98) and 390 000 for kpl = 16 (2048 x 191), families
+    // ahead at 195 000 for kpl = 8 (3000 x 3000 x 65: 3.8 against 4.4) and at 526 000 for kpl = 20 (4096 rows x 2048 x 257: 8.5 against
+    // 11.1): a line just below the two break-evens, W D >= 26500 kpl - 50000 (2600 columns x 65 stay with the families, as in rounds
+    // 3 - 5), given 32-column windows (W >= 2048; the 16-column ones
+    // are slower than either route).  Four disparities per lane (D <= 64) keep round 3's bound, which is all that was measured there.
+    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && H >= 480 &&
+               (kpl < 8 ? W >= 2560 : (W >= 2048 && (size_t)W * cv->D + 50000 >= (size_t)26500 * kpl));
     if (const char* ef = pmx_opt(ctx, "SGM8_FAM")) {
         if (ef[0] == '0') fam = false;
         if (ef[0] == '1') fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u;

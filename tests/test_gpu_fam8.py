@@ -1,6 +1,6 @@
 """GPU parity of the integer path's direction-family form (k_sgmfam8.hip + sgm_u8_hpair_kernel): three byte volumes (horizontal
 pair, downward family, upward family) instead of eight path volumes.  Forced onto small pairs with PMX_SGM8_FAM=1 (by default it
-takes images from 2560 columns and 480 rows on) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
+takes images from 480 rows and 2048 columns on whose rows hold enough cells, W D >= 26500 KPL - 50000) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
 refinement.  Shapes exercise every lane map (KPL 4 ... 20), both window widths (16 / 32 columns), images narrower than a window,
 images a window does not divide, and windows that enter and leave the image during the march."""
 import os
@@ -122,7 +122,7 @@ def test_family_form_with_disparity_grids(eng, oracle, forced_families):
 
 
 def test_family_form_mid_size_against_the_eight_volumes(eng):
-    """Pairs large enough for a hundred windows in flight and for the default route (>= 2560 columns, >= 480 rows) - a short one
+    """Pairs large enough for a hundred windows in flight and for the default route (>= 480 rows, >= 2048 columns, W D >= 26500 KPL - 50000) - a short one
     (the two-sided horizontal walk) and a tall one (the one-sided walk): the family form and the eight-volume form give the same
     maps bit for bit."""
     from bench import synthetic_pair
