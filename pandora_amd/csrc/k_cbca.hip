@@ -1453,7 +1453,15 @@ __global__ __launch_bounds__(kBlock4) void cbca_h4_kernel(cbca_args a) {
     const int r0 = (blockIdx.x * kBlock4) / a.G;
     const size_t vol_bytes = (size_t)a.H * a.W * D * 4 + 256;
     const size_t base_el = ((size_t)(r0 + a.o) * a.W + a.o) * D;
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cv + base_el), 0, cb_span(vol_bytes - base_el * 4), kCbRsrc3);
+    // (the descriptor ends behind the block's LAST row: kCbOob, the offset of a lane that must not store, has to lie beyond it.  Until
+    //  round 6 it reached to the volume's end or 4 GB - at 4096^2 x 257 the tail store of every lane with four disparities, meant to
+    //  be dropped, landed 2 GB behind the block's first row; inside the aggregated area its owner wrote the cell again later, in
+    //  the image's border rows nobody did: one cell of the NaN border became a number - found when four processes shared the GPU,
+    //  the second volume could not be had and this route ran at full size for the first time)
+    const int r_last = min(a.Hc - 1, (int)((blockIdx.x * kBlock4 + kBlock4 - 1) / a.G));
+    const size_t blk_bytes = (size_t)(r_last - r0 + 1) * a.W * D * 4 + 256;
+    const size_t left_bytes = vol_bytes - base_el * 4;
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cv + base_el), 0, cb_span(blk_bytes < left_bytes ? blk_bytes : left_bytes), kCbRsrc3);
     const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsL, 0, cb_span((size_t)a.Hc * Wc * 8), kCbRsrc3);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.armsRpad, 0, cb_span((size_t)a.Hc * (Wc + 8) * 8), kCbRsrc3);
     unsigned ov = (unsigned)(((size_t)(r - r0) * a.W * D + k0) * 4);  // cost of column c
@@ -1718,7 +1726,10 @@ int pmx_launch_cbca(pmx_ctx* ctx, pmx_cv* cv, int offset, float intensity, int d
     const char* ef = pmx_opt(ctx, "CBCA_FAST");
     const int want = ef ? atoi(ef) : 1;
     const bool long_scans = Wc >= 2 * a.A + 8 && Hc >= 2 * a.A + 8;
-    const bool four_ok = cv->subpix == 1 && 3 * a.A + 3 <= kRing4 && long_scans;
+    // (in-place kernels: a block's rows of the volume and the arms images lie behind descriptors that must end below the 2^31 marker of
+    //  a lane that does not store)
+    const bool four_ok = cv->subpix == 1 && 3 * a.A + 3 <= kRing4 && long_scans &&
+                         ((size_t)kBlock4 / ((cv->D + 3) / 4) + 2) * W * cv->D * 4 + 256 < 0x80000000ull && (size_t)Hc * (Wc + 8) * 8 < 0xfffffff0ull;
     bool four = want == 4 && four_ok;
     if (!four && four_ok && want == 1 && ctx->scratch_bytes < cv->cells() * sizeof(float) + 256) {
         void* probe = nullptr;  // is there room for the second volume?

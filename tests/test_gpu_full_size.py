@@ -82,7 +82,7 @@ def test_integer_and_float_paths_agree_at_full_size(eng, name):
     np.testing.assert_array_equal(fast[2][lo:lo + 160], fast[2][lo + 160:lo + 320])
 
 
-@pytest.mark.parametrize("method,win", [("census", 5), ("sad", 5), ("ssd", 3), ("zncc", 11), ("census+cbca", 5)])
+@pytest.mark.parametrize("method,win", [("census", 5), ("sad", 5), ("ssd", 3), ("zncc", 11), ("census+cbca", 5), ("census+inplace+cbca", 5)])
 def test_bottom_strip_equals_oracle_at_c4_size(eng, oracle, method, win):
     """Local steps at 4096x4096x257 (float32 volume, 17.3 GB): the bottom rows -- the cells beyond 2^32 elements -- equal the
     oracle run on a strip of the last rows.  Rows closer than `skip` to the strip's artificial top border are left out."""
@@ -106,7 +106,13 @@ def test_bottom_strip_equals_oracle_at_c4_size(eng, oracle, method, win):
         ocv = oracle.zncc(Ls, Rs, D, dmin, 1, win)
     if method.endswith("cbca"):
         off = win // 2
-        eng.cbca(cv, off, 30.0, 5)
+        # "inplace": the passes that run when the second volume cannot be had (CBCA_FAST=4).  Round 6: at this size a lane's dropped
+        # tail store was not dropped - its marker offset lay inside a 4 GB descriptor - and made a number of one NaN border cell.
+        eng.set_option("CBCA_FAST", "4" if "inplace" in method else None)
+        try:
+            eng.cbca(cv, off, 30.0, 5)
+        finally:
+            eng.set_option("CBCA_FAST", None)
 
         def arms(im):  # cbca.py:217-282 without masks: 3x3 nanmedian, crop by the offset, cross supports
             return oracle.cross_support(np.ascontiguousarray(oracle.median3(im)[off:-off, off:-off]), 5, 30.0)
