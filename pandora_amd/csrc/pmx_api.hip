@@ -410,10 +410,14 @@ extern "C" int pmx_measure_hbm(pmx_ctx* ctx, size_t bytes, double* read_gbs, dou
     void *a = nullptr, *b = nullptr;
     PMX_HIP(hipMalloc(&a, bytes));
     if (hipMalloc(&b, bytes) != hipSuccess) {
+        (void)hipGetLastError();
         (void)hipFree(a);
         PMX_CHECK(false, PMX_ERR_HIP, "pmx_measure_hbm: no room for two buffers of %zu bytes", bytes);
     }
-    if (!ctx->probe_sink && hipMalloc(&ctx->probe_sink, 64) != hipSuccess) ctx->probe_sink = nullptr;
+    if (!ctx->probe_sink && hipMalloc(&ctx->probe_sink, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->probe_sink = nullptr;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -577,13 +581,24 @@ extern "C" int pmx_set_images_fingerprinted(pmx_ctx* ctx, const float* left, con
     } else {
         free_images(ctx);
         ctx->H = H; ctx->W = W; ctx->subpix = subpix;
-        PMX_HIP(img_alloc(ctx, &ctx->left, n));
-        PMX_HIP(img_alloc(ctx, &ctx->right[0], n));
-        for (int k = 1; k < subpix; ++k) PMX_HIP(img_alloc(ctx, &ctx->right[k], (size_t)H * (W - 1)));
-        PMX_HIP(hipMalloc((void**)&ctx->disp, n * sizeof(float)));
-        PMX_HIP(hipMalloc((void**)&ctx->itp, n * sizeof(float)));
-        PMX_HIP(hipMalloc((void**)&ctx->validity, n * sizeof(int64_t)));
-        PMX_HIP(hipMalloc(&ctx->near, n * 16));
+        // all of the pair's buffers or none: a context whose allocation failed half way (out of memory) holds no pair - the next call
+        // with the same shape must not take the "same shape, buffers kept" way onto buffers that are not there
+        auto alloc_all = [&]() -> int {
+            PMX_HIP(img_alloc(ctx, &ctx->left, n));
+            PMX_HIP(img_alloc(ctx, &ctx->right[0], n));
+            for (int k = 1; k < subpix; ++k) PMX_HIP(img_alloc(ctx, &ctx->right[k], (size_t)H * (W - 1)));
+            PMX_HIP(hipMalloc((void**)&ctx->disp, n * sizeof(float)));
+            PMX_HIP(hipMalloc((void**)&ctx->itp, n * sizeof(float)));
+            PMX_HIP(hipMalloc((void**)&ctx->validity, n * sizeof(int64_t)));
+            PMX_HIP(hipMalloc(&ctx->near, n * 16));
+            return PMX_OK;
+        };
+        if (int rca = alloc_all()) {
+            free_images(ctx);
+            ctx->H = ctx->W = 0;
+            ctx->disp_ready = false;
+            return rca;
+        }
     }
     ctx->near_owner = nullptr;
     ctx->near2_owner = nullptr;
@@ -763,6 +778,7 @@ int pmx_cv_ensure_data(pmx_ctx* ctx, pmx_cv* cv) {
     if (e != hipSuccess) {
         cv->data = nullptr;
         pmx_set_error("cost volume: hipMalloc(%zu bytes) failed: %s", cv->bytes, hipGetErrorString(e));
+        (void)hipGetLastError();  // (reported: the runtime's sticky "last error" must not fail the next call's launch check)
         return PMX_ERR_HIP;
     }
     return PMX_OK;

@@ -24,6 +24,7 @@ void pmx_set_error(const char* fmt, ...);
         hipError_t e_ = (expr);                                                                   \
         if (e_ != hipSuccess) {                                                                   \
             pmx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* reported once: the runtime's sticky "last error" must not fail the NEXT call's launch check */ \
             return PMX_ERR_HIP;                                                                   \
         }                                                                                         \
     } while (0)

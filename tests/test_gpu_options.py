@@ -105,3 +105,60 @@ def test_release_caches_returns_the_memory_and_changes_nothing():
         assert total > 0 and abs(freed - before) < (256 << 20)
     finally:
         eng.close()
+
+
+def test_out_of_memory_is_an_error_once_and_the_context_stays_usable(oracle):
+    """A pair whose buffers do not fit: pmx_set_images / pmx_census / pmx_sgm answer with an error - and that is all.  The context holds
+    no half-allocated pair (the same shape again, with memory back, works), the runtime's sticky "last error" does not fail the next
+    call's launch check, and the next results are the oracle's.  (Round 6: found when four processes shared one GPU.)"""
+    import ctypes
+
+    from pandora_amd._lib import PmxError
+    from pandora_amd.engine import Engine
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    free_b, total_b = ctypes.c_size_t(), ctypes.c_size_t()
+    eng = Engine(0)
+    hog = ctypes.c_void_p()
+    try:
+        eng.set_lazy(False)
+        assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
+        # leave ~1.2 GB: enough for the 2048 x 2048 images and maps (0.6 GB), not for a 129-disparity float32 volume (2.2 GB)
+        assert hip.hipMalloc(ctypes.byref(hog), ctypes.c_size_t(free_b.value - (1200 << 20))) == 0
+        H, W, dmin, dmax = 2048, 2048, 0, 128
+        L, R = pair(H, W, seed=3)
+        failed = 0
+        for _ in range(2):  # the same shape twice: the second call must not find "same shape, buffers kept" on missing buffers
+            try:
+                eng.set_images(L, R, 1)
+                cv = eng.alloc_cv(dmax - dmin + 1, dmin)
+                eng.census(cv, 5)
+                eng.sgm(cv, 8.0, 32.0, False, 26.0, False)
+                eng.sync()
+                cv.free()
+            except PmxError as err:
+                failed += 1
+                assert "memory" in str(err).lower(), str(err)
+        assert failed == 2
+    finally:
+        if hog.value:
+            hip.hipFree(hog)
+    try:
+        # memory is back: a small pair through the same context, against the oracle
+        Ls, Rs = pair(40, 64, seed=5)
+        eng.set_images(Ls, Rs, 1)
+        cv = eng.alloc_cv(17, -8)
+        eng.census(cv, 5)
+        eng.sgm(cv, 8.0, 32.0, False, 26.0, False)
+        got = cv.to_host()
+        cv.free()
+        exp = oracle.sgm(oracle.census_cost(Ls, Rs, 17, -8, 1, 5), 8.0, 32.0, False, 26.0, False)
+        np.testing.assert_array_equal(got, exp)
+        # ... and the big shape now fits
+        eng.set_images(L, R, 1)
+        cv = eng.alloc_cv(dmax - dmin + 1, dmin)
+        eng.census(cv, 5)
+        eng.sync()
+        cv.free()
+    finally:
+        eng.close()
