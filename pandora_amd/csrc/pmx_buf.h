@@ -209,6 +209,10 @@ __device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, unsigned
 }
 
 // ---- a prefetch ring the compiler cannot see: registers above its own ----------------------------------------------------------------
+// VALIDATED ON: ROCm 7.2.0 (hipcc / HIP 7.2.26015-fc0010cf6a, AMD clang 22.0.0git roc-7.2.0), gfx950.  A toolchain change is a re-validation: `make` runs
+// tools/check_hring.py on the object (nothing but the ring's statements touches its registers; every take's vmcnt equals the memory
+// instructions issued since its slot's load) and FAILS the build otherwise - it does not repair it; then tools/flaky_fam8.py and
+// tests/test_gpu_fam8.py on the GPU.
 // A register ring of loads issued PF steps ahead wants `s_waitcnt vmcnt(N)` with N = the memory instructions issued since the load
 // that is due.  The compiler derives N itself, and where a step also STORES it gets it wrong in ways the source cannot steer: the
 // marching kernels' three-step body was waited for with vmcnt(3), vmcnt(4), vmcnt(0) where 6 is right - one row of look-ahead
