@@ -267,15 +267,25 @@ class Engine:
             raise ValueError(f"shifted right image {a.shape} != {(self.H, self.W - 1)}")
         check(_lib.lib().pmx_set_shifted_right(self.ctx, int(k), _p(a, C.c_float)), "pmx_set_shifted_right")
 
+    def _check_map_shape(self, what, arr):
+        # the C ABI takes a pointer and reads H x W elements behind it: a shorter array is a read past its end (a GPU memory fault
+        # when the runtime pins the caller's pages), so the shape is checked where it is still known
+        if arr is not None and tuple(arr.shape) != (self.H, self.W):
+            raise ValueError(f"{what}: shape {tuple(arr.shape)} is not the resident pair's {(self.H, self.W)}")
+
     def set_masks(self, msk_left=None, msk_right=None, valid=0, nodata=1):
         ml = None if msk_left is None else np.ascontiguousarray(msk_left, np.int16)
         mr = None if msk_right is None else np.ascontiguousarray(msk_right, np.int16)
+        self._check_map_shape("set_masks (left)", ml)
+        self._check_map_shape("set_masks (right)", mr)
         check(_lib.lib().pmx_set_masks(self.ctx, _p(ml, C.c_int16), _p(mr, C.c_int16), int(valid), int(nodata)),
               "pmx_set_masks")
 
     def set_disparity_grids(self, dmin=None, dmax=None):
         a = None if dmin is None else np.ascontiguousarray(dmin, np.float64)
         b = None if dmax is None else np.ascontiguousarray(dmax, np.float64)
+        self._check_map_shape("set_disparity_grids (min)", a)
+        self._check_map_shape("set_disparity_grids (max)", b)
         check(_lib.lib().pmx_set_disparity_grids(self.ctx, _p(a, C.c_double), _p(b, C.c_double)), "pmx_set_disparity_grids")
 
     def set_placement_trials(self, trials):
@@ -528,6 +538,8 @@ class Engine:
         self.new_maps()
         d = None if disp is None else np.ascontiguousarray(disp, np.float32)
         v = None if validity is None else np.ascontiguousarray(validity, np.int64)
+        self._check_map_shape("set_disparity (disparity map)", d)
+        self._check_map_shape("set_disparity (validity mask)", v)
         check(_lib.lib().pmx_set_disparity(self.ctx, _p(d, C.c_float), _p(v, C.c_int64)), "pmx_set_disparity")
 
     def wta_minkey(self, cv, is_max, index_offset, dev_keys_ptr):

@@ -162,3 +162,27 @@ def test_out_of_memory_is_an_error_once_and_the_context_stays_usable(oracle):
         cv.free()
     finally:
         eng.close()
+
+
+def test_maps_of_the_wrong_shape_are_refused_before_the_library_reads_them():
+    """The C ABI takes a pointer and reads H x W elements behind it; Engine checks masks, grids and maps against the resident pair (a
+    mask shorter than the image is a read past its end - a GPU memory fault when the runtime pins the caller's pages)."""
+    from pandora_amd.engine import Engine
+
+    eng = Engine(0)
+    try:
+        L, R = pair(30, 50, seed=1)
+        eng.set_images(L, R, 1)
+        small = np.zeros((20, 50), np.int16)
+        with pytest.raises(ValueError, match="shape"):
+            eng.set_masks(small, None, 0, 1)
+        with pytest.raises(ValueError, match="shape"):
+            eng.set_masks(None, np.zeros((30, 49), np.int16), 0, 1)
+        with pytest.raises(ValueError, match="shape"):
+            eng.set_disparity_grids(np.zeros((29, 50)), np.zeros((30, 50)))
+        with pytest.raises(ValueError, match="shape"):
+            eng.set_disparity(np.zeros((30, 51), np.float32), np.zeros((30, 50), np.int64))
+        eng.set_masks(np.zeros((30, 50), np.int16), None, 0, 1)  # the right shape goes through
+        eng.set_disparity_grids(np.full((30, 50), -3.0), np.full((30, 50), 3.0))
+    finally:
+        eng.close()

@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pandora_amd.engine import Engine  # noqa: E402
-from tests.test_gpu_full_size import big_pair, SIZES  # noqa: E402
+from tests.test_gpu_full_size import big_pair, SIZES, _PAIRS  # noqa: E402
 
 H, W = (int(v) for v in sys.argv[1:3]) if len(sys.argv) > 2 else (4096, 4096)
 
@@ -72,6 +72,7 @@ bad = 0
 for label, kw in cases:
     dmin, dmax = kw["dmin"], kw["dmax"]
     SIZES["DBG"] = (H, W, dmin, dmax)
+    _PAIRS.clear()  # (big_pair caches by name: a pair made for this case's range)
     L, R = big_pair("DBG")
     k = dict(kw)
     if k.pop("grids", False):
