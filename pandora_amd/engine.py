@@ -498,6 +498,7 @@ class Engine:
     def set_validity(self, validity=None):
         self.new_maps()
         v = None if validity is None else np.ascontiguousarray(validity, np.int64)
+        self._check_map_shape("set_validity", v)
         check(_lib.lib().pmx_set_validity(self.ctx, _p(v, C.c_int64)), "pmx_set_validity")
 
     def wta(self, cv, is_max=False, invalid_disparity=-9999.0):
@@ -559,6 +560,8 @@ class Engine:
         if dl.ndim != 2 or dl.shape != dr.shape:
             raise ValueError("cross_checking: left/right disparity maps must be 2-D and of the same shape")
         val = np.array(validity_left, np.int64, order="C", copy=True)
+        if val.shape != dl.shape:
+            raise ValueError(f"cross_checking: validity mask {val.shape} != disparity maps {dl.shape}")
         conf = np.empty(dl.shape, np.float32)
         check(_lib.lib().pmx_cross_checking(self.ctx, _p(dl, C.c_float), _p(val, C.c_int64), _p(dr, C.c_float), dl.shape[0],
                                             dl.shape[1], int(dmin), int(dmax), float(threshold), _p(conf, C.c_float)),
@@ -768,6 +771,10 @@ class Engine:
     def xbuf_upload(self, which, arr):
         idx, dtype = _lib.XBUFS[which]
         a = np.ascontiguousarray(arr, dtype).ravel()
+        n = C.c_size_t(0)
+        check(_lib.lib().pmx_xbuf_info(self.ctx, idx, C.byref(n), None), "pmx_xbuf_info")
+        if a.size != n.value:
+            raise ValueError(f"xbuf_upload: exchange buffer {which!r} holds {n.value} elements, got {a.size}")
         check(_lib.lib().pmx_xbuf_upload(self.ctx, idx, a.ctypes.data_as(C.c_void_p)), "pmx_xbuf_upload")
 
     def shard_minkey(self, cv, is_max, index_offset):
@@ -796,11 +803,18 @@ class Engine:
         d = np.ascontiguousarray(disp, np.float32)
         v = np.ascontiguousarray(validity, np.int64)
         t = None if itp is None else np.ascontiguousarray(itp, np.float32)
-        assert d.shape == (own_hi - own_lo, self.W) == v.shape
+        rows = (int(own_hi) - int(own_lo), self.W)
+        if d.shape != rows or v.shape != rows or (t is not None and t.shape != rows):
+            raise ValueError(f"set_full_rows: rows [{own_lo}, {own_hi}) are {rows} per map, got {d.shape} / {v.shape}"
+                             + ("" if t is None else f" / {t.shape}"))
         check(_lib.lib().pmx_set_full_rows(self.ctx, int(full_H), int(own_lo), int(own_hi), d.ctypes.data_as(C.c_void_p),
                                            v.ctypes.data_as(C.c_void_p), None if t is None else t.ctypes.data_as(C.c_void_p)), "pmx_set_full_rows")
 
     def get_full_maps(self, full_H, want_itp=False):
+        n = C.c_size_t(0)
+        check(_lib.lib().pmx_xbuf_info(self.ctx, _lib.XBUFS["full_disp"][0], C.byref(n), None), "pmx_xbuf_info")
+        if n.value != int(full_H) * self.W:  # the library copies what tile_place / set_full_rows sized, not what the caller expects
+            raise ValueError(f"get_full_maps: the placed maps hold {n.value} pixels, not {full_H} x {self.W}")
         disp = np.empty((full_H, self.W), np.float32)
         val = np.empty((full_H, self.W), np.int64)
         itp = np.empty((full_H, self.W), np.float32) if want_itp else None

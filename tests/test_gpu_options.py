@@ -182,6 +182,18 @@ def test_maps_of_the_wrong_shape_are_refused_before_the_library_reads_them():
             eng.set_disparity_grids(np.zeros((29, 50)), np.zeros((30, 50)))
         with pytest.raises(ValueError, match="shape"):
             eng.set_disparity(np.zeros((30, 51), np.float32), np.zeros((30, 50), np.int64))
+        with pytest.raises(ValueError, match="shape"):
+            eng.set_validity(np.zeros((30, 25), np.int64))
+        with pytest.raises(ValueError, match="validity mask"):
+            eng.cross_checking(np.zeros((30, 50), np.float32), np.zeros((15, 50), np.int64), np.zeros((30, 50), np.float32), -3, 3, 1.0)
+        with pytest.raises(ValueError, match="set_full_rows"):
+            eng.set_full_rows(60, 0, 30, np.zeros((30, 50), np.float32), np.zeros((29, 50), np.int64))
+        eng.set_full_rows(60, 0, 30, np.zeros((30, 50), np.float32), np.zeros((30, 50), np.int64))
+        with pytest.raises(ValueError, match="get_full_maps"):
+            eng.get_full_maps(90)
+        assert eng.get_full_maps(60)[0].shape == (60, 50)
+        with pytest.raises(ValueError, match="xbuf_upload"):
+            eng.xbuf_upload("keys", np.zeros(10, np.uint64))
         eng.set_masks(np.zeros((30, 50), np.int16), None, 0, 1)  # the right shape goes through
         eng.set_disparity_grids(np.full((30, 50), -3.0), np.full((30, 50), 3.0))
     finally:
