@@ -290,7 +290,18 @@ __global__ __launch_bounds__(kBlock) void census_cost4_kernel(pmx_mc_params p, c
     }
 }
 
-static constexpr size_t kCodePad = 1024;  // dwords readable before/after each code image (fast path over-reads)
+static constexpr size_t kCodePad = 1024;  // dwords readable before/after each code image, at least (fast path over-reads)
+
+// The kernels that take a pixel's right words through raw pointers (census_cost4_kernel here; census_cost_u8_kernel and the path
+// kernel of k_fused.hip on the integer path) read NW words per disparity at (pixel + d0 + d) NW for every d of the lane maps' padded
+// range, whether the cell exists or not: the guards have to cover the whole disparity range on both sides, in words of THIS census
+// window.  (Until round 6 the guard was 1024 dwords whatever the range: a 13 x 13 window - six words - with d = [0, 256] read up
+// to 2.5 KB behind the allocation on the image's last rows; the loaded words belong to cells that are not numbers, so nothing was
+// ever wrong, but the addresses were not ours.)
+static size_t code_pad(const pmx_cv* cv, int nw) {
+    const size_t need = ((size_t)abs(cv->d0) + (size_t)cv->D + 64) * (size_t)nw;
+    return need <= kCodePad ? kCodePad : (need + kCodePad - 1) / kCodePad * kCodePad;
+}
 
 // census codes of the resident pair into buffers owned by the volume handle
 template <int WIN>
@@ -298,7 +309,8 @@ static int census_codes(pmx_ctx* ctx, pmx_cv* cv) {
     constexpr int NW = (WIN * WIN + 31) / 32;
     const int H = cv->H, W = cv->W;
     const size_t per_img = (size_t)H * W * NW;
-    const size_t total = (kCodePad + per_img) * (1 + (size_t)cv->subpix) + kCodePad;
+    const size_t pad = code_pad(cv, NW);
+    const size_t total = (pad + per_img) * (1 + (size_t)cv->subpix) + pad;
     if (cv->codes_bytes < total * sizeof(uint32_t)) {
         PMX_HIP(hipStreamSynchronize(ctx->stream));
         pmx_pool_free(ctx, cv->codes);
@@ -308,15 +320,15 @@ static int census_codes(pmx_ctx* ctx, pmx_cv* cv) {
         cv->codes_bytes = total * sizeof(uint32_t);
         PMX_HIP(hipMemsetAsync(cv->codes, 0, total * sizeof(uint32_t), ctx->stream));
     }
-    uint32_t* left = cv->codes + kCodePad;
+    uint32_t* left = cv->codes + pad;
     cv->codeL = left;
-    cv->codeR = left + per_img + kCodePad;
+    cv->codeR = left + per_img + pad;
     cv->win = WIN;
     pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_TRANSFORM);
     dim3 grid((W + 63) / 64, (H + kCtTileY - 1) / kCtTileY);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), grid, dim3(kBlock), 0, ctx->stream, ctx->left, H, W, left);
     for (int k = 0; k < cv->subpix; ++k) {
-        uint32_t* dst = left + (per_img + kCodePad) * (size_t)(k + 1);
+        uint32_t* dst = left + (per_img + pad) * (size_t)(k + 1);
         int wk = pmx_shifted_width(W, k);
         dim3 g2((wk + 63) / 64, (H + kCtTileY - 1) / kCtTileY);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(census_transform_kernel<WIN>), g2, dim3(kBlock), 0, ctx->stream, ctx->right[k], H, wk, dst);
@@ -331,7 +343,8 @@ static int census_costs(pmx_ctx* ctx, pmx_cv* cv) {
     const size_t per_img = (size_t)H * W * NW;
     code_ptrs<NW> cp;
     cp.left = cv->codeL;
-    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) cp.right[k] = k < cv->subpix ? cv->codeL + (per_img + kCodePad) * (size_t)(k + 1) : nullptr;
+    const size_t pad = code_pad(cv, NW);
+    for (int k = 0; k < PMX_MAX_SUBPIX; ++k) cp.right[k] = k < cv->subpix ? cv->codeL + (per_img + pad) * (size_t)(k + 1) : nullptr;
     pmx_mc_params p = make_params(ctx, cv, cv->win);
     pmx_stage_scope t(ctx, PMX_STAGE_CENSUS_COST);
     if (cv->subpix == 1 && cv->D <= 512 && abs(cv->d0) + cv->D <= (int)kCodePad / NW - 64) {

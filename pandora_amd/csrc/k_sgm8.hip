@@ -105,67 +105,88 @@ struct cost8_args {
     const uint32_t* range;  // [H][W] lo | hi << 16 (cv_masked on this path) or nullptr = census geometry
     int H, W, D, Dp, d0, o;
     uint32_t invalid_cost;
+    int nact;  // lanes of a pixel that own disparities in the path kernels = units of a pixel in the volume (Dp = nact units)
 };
 
-// Four pixels per wavefront (one per 16-lane row), lane `sub` owns the same KPL disparities it owns in the path kernel:
-// KPL right codes come in as 16-byte loads, KPL bytes leave as one store.  Invalid census cells (window outside the
-// image on either side; census.cpp:97-180 leaves them NaN) carry invalid_cost, bytes at d >= D are don't-cares.
+// A lane makes ONE unit of the volume per step: the KPL costs that lane `s` of pixel `pixel` owns in the path kernels (NDW dwords:
+// 16 bytes at KPL = 20 and five-bit costs), units numbered t = pixel * nact + s as they lie in memory.  Every lane of a wavefront
+// has a unit, a wavefront's store is 64 consecutive units - whole cache lines - and (pixel, s, row, column) advance with the unit
+// instead of being divided out per step.  KPL right codes come in as 16-byte loads.  Invalid census cells (window outside the image on
+// either side; census.cpp:97-180 leaves them NaN) carry invalid_cost, bytes at d >= D are don't-cares.
+// Round 6 (docs/experiments.md 7.34): the kernel is bound by what its SIMDs issue - with nothing loaded and nothing stored it took 1.0
+// of its 1.27 ms at 4096 x 4096 x 257 - and a cell is three instructions (xor, bit count, shift-or) whatever the map; until round 6
+// four pixels shared a wavefront, one per 16-lane row, which left lanes nact .. 15 of every row idle (3 of 16 at D = 257) and paid a
+// 64-bit division per step: 1.23 - 1.33 ms, this form 1.17 - 1.23 (2048 x 2048 x 129: 0.20 -> 0.15), alternated on one box.
+constexpr int kUnitSteps = 16;  // steps of 256 units per workgroup (4 ... 16: the same time, 32: slower)
 template <int NW, int KPL, int CBITS>
 __global__ __launch_bounds__(256) void census_cost_u8_kernel(cost8_args a) {
     constexpr int PER = CBITS == 8 ? 4 : 6;          // costs per dword
-    constexpr int NDW = (KPL + PER - 1) / PER;       // dwords per lane
-    const int lane = threadIdx.x & 63;
-    const int sub = lane & 15, grp = lane >> 4;
-    const size_t npix = (size_t)a.H * a.W;
-    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * 4;
-    const int d_first = sub * KPL;
-    const bool lane_active = d_first < a.D;
+    constexpr int NDW = (KPL + PER - 1) / PER;       // dwords per unit
+    const int nact = a.nact;
+    const size_t nunits = (size_t)a.H * a.W * (size_t)nact;
     const uint32_t wvalid = (uint32_t)(a.W - 2 * a.o);
-    for (size_t quad = wave; quad * 4 < npix; quad += nwaves) {
-        const size_t pix = min(quad * 4 + grp, npix - 1);  // surplus rows repeat the last pixel (same bytes)
-        const int r = (int)(pix / a.W), c = (int)(pix - (size_t)r * a.W);
-        const bool pix_ok = (r >= a.o) & (r < a.H - a.o) & (c >= a.o) & (c < a.W - a.o);
-        uint32_t lc[NW], rc[KPL * NW];
-        __builtin_memcpy(lc, a.codeL + pix * NW, sizeof(uint32_t) * NW);
-        __builtin_memcpy(rc, a.codeR + ((ptrdiff_t)pix + a.d0 + (lane_active ? d_first : 0)) * NW, sizeof(uint32_t) * KPL * NW);
-        const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
-        const uint32_t rg = a.range ? a.range[pix] : 0u;
-        const int rlo = (int)(rg & 0xffffu) - d_first, rhi = (int)(rg >> 16) - d_first;  // the lane's slots that are numbers
-        uint32_t out[NDW];
+    const bool ranged = a.range != nullptr;  // (uniform)
+    size_t t = (size_t)blockIdx.x * (256 * kUnitSteps) + threadIdx.x;
+    if (t >= nunits) return;  // (a lane whose unit of a later step does not exist skips that step)
+    size_t pixel = t / (size_t)nact;
+    int s = (int)(t - pixel * (size_t)nact);
+    int r = (int)(pixel / (size_t)a.W), c = (int)(pixel - (size_t)r * a.W);
+    const int ds = 256 % nact, dp = 256 / nact;  // (uniform) the unit 256 further: s + ds, pixel + dp, with a carry
+    uint8_t* pC = a.cost + t * (size_t)(NDW * 4);
+#pragma unroll 1
+    for (int it = 0; it < kUnitSteps; ++it) {
+        if (t < nunits) {
+            const int d_first = s * KPL;
+            uint32_t lc[NW], rc[KPL * NW];
+            __builtin_memcpy(lc, a.codeL + pixel * NW, sizeof(uint32_t) * NW);
+            __builtin_memcpy(rc, a.codeR + ((ptrdiff_t)pixel + a.d0 + d_first) * NW, sizeof(uint32_t) * KPL * NW);
+            const bool pix_ok = (r >= a.o) & (r < a.H - a.o) & (c >= a.o) & (c < a.W - a.o);
+            const uint32_t u = (uint32_t)(c + a.d0 + d_first - a.o);
+            const uint32_t rg = ranged ? a.range[pixel] : 0u;
+            const int rlo = (int)(rg & 0xffffu) - d_first, rhi = (int)(rg >> 16) - d_first;  // the unit's slots that are numbers
+            uint32_t out[NDW];
 #pragma unroll
-        for (int j = 0; j < NDW; ++j) out[j] = 0;
-        // In the interior of the image every cell of every lane of the wavefront is a number (at 4096 x 4096, d = [0, 256]: 94 % of
-        // the wavefronts): one wave-uniform test spares them the per-cell validity arithmetic, most of this kernel's instructions
-        const bool lane_full = !lane_active || (a.range ? (rlo <= 0 && rhi >= KPL) : (pix_ok && u < wvalid && u + (uint32_t)(KPL - 1) < wvalid));
-        const bool all_full = __builtin_amdgcn_ballot_w64(!lane_full) == 0ull;
-        auto place = [&](int k, uint32_t v) {
-            if (CBITS == 8) {
-                out[k / 4] |= v << (8 * (k % 4));
+            for (int j = 0; j < NDW; ++j) out[j] = 0;
+            // In the interior of the image every cell of every lane of the wavefront is a number (at 4096 x 4096, d = [0, 256]: 94 % of
+            // the wavefronts): one wave-uniform test spares them the per-cell validity arithmetic, most of this kernel's instructions
+            const bool full = ranged ? (rlo <= 0 && rhi >= KPL) : (pix_ok && u < wvalid && u + (uint32_t)(KPL - 1) < wvalid);
+            const bool all_full = __builtin_amdgcn_ballot_w64(!full) == 0ull;
+            auto place = [&](int k, uint32_t v) {
+                if (CBITS == 8) {
+                    out[k / 4] |= v << (8 * (k % 4));
+                } else {
+                    // five-bit costs sit where the path kernel wants them: pair j = (cost 4q+i, cost 4q+i+2), i = j & 1, is the
+                    // (lo16, hi16) couple of one register, three pairs per dword at bits 0 / 5 / 10 of each half
+                    const int j = 2 * (k / 4) + (k & 1), half = (k >> 1) & 1;
+                    out[j / 3] |= v << (5 * (j % 3) + 16 * half);
+                }
+            };
+            auto hamming = [&](int k) {
+                uint32_t pop = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) pop += __popc(lc[w] ^ rc[k * NW + w]);
+                return pop;
+            };
+            if (all_full) {  // (uniform)
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) place(k, hamming(k));
             } else {
-                // five-bit costs sit where the path kernel wants them: pair j = (cost 4q+i, cost 4q+i+2), i = j & 1, is the
-                // (lo16, hi16) couple of one register, three pairs per dword at bits 0 / 5 / 10 of each half
-                const int j = 2 * (k / 4) + (k & 1), half = (k >> 1) & 1;
-                out[j / 3] |= v << (5 * (j % 3) + 16 * half);
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    const bool ok = ranged ? (k >= rlo && k < rhi) : (pix_ok && (u + (uint32_t)k < wvalid));
+                    place(k, ok ? hamming(k) : a.invalid_cost);
+                }
             }
-        };
-        auto hamming = [&](int k) {
-            uint32_t pop = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) pop += __popc(lc[w] ^ rc[k * NW + w]);
-            return pop;
-        };
-        if (all_full) {  // (uniform)
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) place(k, hamming(k));
-        } else {
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                const bool ok = a.range ? (k >= rlo && k < rhi) : (pix_ok && (u + (uint32_t)k < wvalid));
-                place(k, ok ? hamming(k) : a.invalid_cost);
-            }
+            __builtin_memcpy(pC, out, 4 * NDW);
         }
-        if (lane_active) __builtin_memcpy(a.cost + pix * a.Dp + (size_t)sub * NDW * 4, out, 4 * NDW);
+        t += 256;
+        pC += 256 * NDW * 4;
+        s += ds;
+        int adv = dp;
+        if (s >= nact) { s -= nact; ++adv; }
+        pixel += adv;
+        c += adv;
+        while (c >= a.W) { c -= a.W; ++r; }
     }
 }
 
@@ -1274,8 +1295,10 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         c.range = cv->has_range ? cv->range : nullptr;
         c.H = H; c.W = W; c.D = cv->D; c.Dp = Dc; c.d0 = cv->d0; c.o = cv->win / 2;
         c.invalid_cost = invalid_cost;
-        const size_t want = ((size_t)H * W + 15) / 16;  // 4 pixels per wave, 4 waves per block
-        const dim3 grid((unsigned)(want < 65536 ? want : 65536));
+        c.nact = nact;
+        const size_t want = ((size_t)H * W * nact + 256 * kUnitSteps - 1) / (256 * kUnitSteps);  // a unit per lane and step
+        PMX_CHECK(want < (1u << 31), PMX_ERR_ARG, "census costs: %d x %d x %d units are more than one launch takes", H, W, nact);
+        const dim3 grid((unsigned)want);
 #define PMX_COST8(NWV, KPLV)                                                                                                  \
     if (five && NWV == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, (NWV == 1 ? 5 : 8)>), grid, dim3(256), 0, cst, c); \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(census_cost_u8_kernel<NWV, KPLV, 8>), grid, dim3(256), 0, cst, c)

@@ -28,7 +28,7 @@ def forced_families(hooks):
     yield hooks
 
 
-def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
+def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2, family=True):
     D = dmax - dmin + 1
     eng.set_images(L, R, 1)
     cv = eng.alloc_cv(D, dmin)
@@ -38,8 +38,9 @@ def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2):
     eng.wta(cv, False, -9999.0)
     eng.refine(cv, "vfit", False)
     disp, val, itp = eng.get_disparity(want_itp=True)
-    with pytest.raises(Exception):
-        eng.debug_path_costs(cv, raw=True)  # (there are no eight path volumes: the family form ran)
+    if family:
+        with pytest.raises(Exception):
+            eng.debug_path_costs(cv, raw=True)  # (there are no eight path volumes: the family form ran)
     vol = cv.to_host()
     cv.free()
     ref = oracle.sgm(oracle.census_cost(L, R, D, dmin, 1, win), P1, P2, False, float(win * win + 1), False)
@@ -170,3 +171,20 @@ def test_family_form_wta_kernels_agree_with_the_oracle(eng, oracle, forced_famil
         forced_families.setenv("PMX_WTA3", wta3)
     L, R = pair(H, W, seed=11 * H + W)
     run_both(eng, oracle, L, R, dmin, dmax, 5, 8, 32)
+
+
+@pytest.mark.parametrize("H,W,dmin,dmax,win", [
+    (20, 300, 0, 256, 13),        # six code words per pixel: (256 + 20) x 6 words lie behind a pixel of the last row
+    (16, 1500, 1100, 1160, 11),   # four words, a range a thousand columns away
+    (12, 40, 2000, 2010, 9),      # a range that never meets the image, further away than the image is large
+    (12, 14, -3000, -2990, 5),    # ... to the other side: in front of the code images
+])
+@pytest.mark.parametrize("fam", ["0", "1"])
+def test_code_guards_cover_the_whole_range(eng, oracle, hooks, H, W, dmin, dmax, win, fam):
+    """The integer path's cost kernels read a pixel's right words at (pixel + d) x words-per-pixel through raw pointers for every d
+    of the range, cells that are not numbers included: the guards around the code images are as long as the range is far (round 6;
+    1024 dwords until then, whatever the window and the range).  The results never depended on it - this runs the shapes whose
+    reads used to leave the allocation."""
+    hooks.setenv("PMX_SGM8_FAM", fam)
+    L, R = pair(H, W, seed=H + W)
+    run_both(eng, oracle, L, R, dmin, dmax, win, 8, 32, family=False)
