@@ -1259,7 +1259,13 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     //  kernel on the cost volume / two-sided / one-sided: 592 rows 2.55 / 2.65 / 3.5 / 4.9, 1104 rows 4.35 / 4.6 / 5.0 / 6.7,
     //  2088 rows 8.85 / 8.3 / 8.55 / 9.7, 3072 rows - / - / 13.0 / 12.3, 4096 rows 17.2 / 15.9 / - / 14.6: profiles/r04_tiles.txt,
     //  r03_e_shapes.txt)
-    int hp_mode = H < 2560 ? (W >= 32 && codes_ok && !codes_never ? 3 : 2) : 1;
+    // Round 6, re-measured on the round's kernels (profiles/r06_hpair_rule.txt: 16 shapes x 3 modes x the marching kernel from the words
+    // / from the cost volume, a fresh context each): the row walk wins below ~1000 rows (480 ... 800 rows x 4096 x 257: 2.2 - 3.2 ms
+    // against 2.7 - 3.7 two-sided), the two-sided walk from there to ~2000 rows (1104 rows 4.2 - 4.4 against 4.7 - 5.1, 1536 rows
+    // 4.9 - 5.2 against 6.1 - 6.2, 1500 x 2600 x 65 1.8 against 2.2 - 2.4; 2000 - 2088 rows: one- and two-sided equal), the one-sided
+    // walk from 2048 rows (2088 rows x 4096 x 257: 7.1 - 7.3 against 7.4 - 7.7, 2560 rows 8.1 - 8.5 against 10.3).  Until then: the row
+    // walk below 2560 rows.
+    int hp_mode = H < 1024 ? (W >= 32 && codes_ok && !codes_never ? 3 : 2) : (H < 2048 ? 2 : 1);
     if (ehp && ehp[0] >= '1' && ehp[0] <= '3') hp_mode = ehp[0] - '0';
     if (hp_mode == 3 && (!codes_ok || W < 32)) hp_mode = 2;
     const bool two_sided = hp_mode == 2;
@@ -1268,7 +1274,10 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
         vol = pmx_dir_stride(H, W, Dp);
     }
     const bool hp_codes = fam && (hp_mode == 3 || (hp_mode == 1 && codes_ok && codes_always));
-    bool fam_codes = fam && codes_ok && !codes_never && (codes_always || (hp_mode == 3 && H < 1536));
+    // (the marching kernel from the words: until round 6 the default beside the row walk below 1536 rows; with round 6's cost kernel the
+    //  cost volume is 3 - 6 % ahead on every short shape measured - 480 / 592 / 800 rows x 4096 x 257: 2.18 / 2.56 / 3.15 against 2.30 /
+    //  2.64 / 3.30 ms, 1000 x 6000 x 193: 3.94 against 4.19 - so the words are taken on request only)
+    bool fam_codes = fam && codes_ok && !codes_never && codes_always;
     if (const char* efc = pmx_opt(ctx, "SGM8_FAMCODES")) fam_codes = fam && codes_ok && efc[0] == '1';  // (A/B hook: the marching kernel alone)
     const bool from_codes = hp_codes && fam_codes;  // no cost volume at all
     if (!from_codes && cv->cost8_bytes < cvol) {

@@ -73,8 +73,9 @@ def run_both(eng, oracle, L, R, dmin, dmax, win, P1, P2, family=True):
 ])
 @pytest.mark.parametrize("nw,hpair,codes", [("4", "2", "0"), ("8", "1", "0"), ("8", "2", "0"),
                                             ("8", "1", "1"),   # both kernels from the census words, four rows per wavefront
-                                            ("8", "3", None), ("4", "3", None),  # ... one row per wavefront (short images' default)
-                                            ("8", "3", "0")])  # row walk from the words, marching kernel from the cost volume
+                                            ("8", "3", "1"), ("4", "3", "1"),  # ... one row per wavefront (short images' default until round 6)
+                                            ("8", "3", None), ("4", "3", None),  # row walk from the words, marching kernel from the cost volume (their default since)
+                                            ("8", "3", "0")])  # the same, asked for
 def test_family_form_equals_the_oracle(eng, oracle, forced_families, H, W, dmin, dmax, win, P1, P2, nw, hpair, codes):
     forced_families.setenv("PMX_SGM8_FAM_NW", nw)
     # the horizontal pair's one-sided (tall images) / two-sided walk on the cost volume, or the row-per-wavefront walk from the

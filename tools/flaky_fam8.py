@@ -39,7 +39,7 @@ routes = (("row walk + marching kernel on the cost volume", {"PMX_SGM8_HPAIR": "
           ("two-sided walk + marching kernel on the cost volume", {"PMX_SGM8_HPAIR": "2", "PMX_SGM8_CODES": "0"}),
           ("one-sided walk + marching kernel on the cost volume", {"PMX_SGM8_HPAIR": "1", "PMX_SGM8_CODES": "0"}),
           ("one-sided walk from the words + marching kernel on the cost volume", {"PMX_SGM8_HPAIR": "1", "PMX_SGM8_CODES": "1", "PMX_SGM8_FAMCODES": "0"}),
-          ("row walk + marching kernel from the words (short images' default)", {"PMX_SGM8_HPAIR": "3"}))
+          ("row walk + marching kernel from the words (short images' default until round 6)", {"PMX_SGM8_HPAIR": "3", "PMX_SGM8_CODES": "1"}))
 bad_total = 0
 for label, env in routes:
     for k in ("PMX_SGM8_HPAIR", "PMX_SGM8_CODES", "PMX_SGM8_FAMCODES"):
