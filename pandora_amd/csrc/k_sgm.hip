@@ -666,7 +666,11 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     if (cv->cells() <= ((size_t)128 << 20)) sched = PAR;  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
     // the marching passes advance one image row per ~2.5 - 4 us whatever the width: they pay from ~3500 columns on (a window
     // for every CU); measured 4096^2 x 257: 55 ms against 96, 10000^2 x 129: 131 against 265, 2048^2 x 129: 12.4 against 11.3
-    else if (cv->W >= 3584 && cv->H >= 512 && pmx_sgm_family_supported(ctx, cv)) sched = FAM;
+    // Round 6, re-measured on the round's marching kernel (profiles/r06_float_sched_rule.txt, tools/sweep_float_sched.py): the bound of
+    // round 3 (3584 columns, 512 rows) had become far too careful - 2048 x 2600 x 129: 12.9 against 15.0 ms, 3000^2 x 129: 19.3
+    // against 25.7, 1500 x 3000 x 257: 14.3 against 23.1, 2048 x 3072 x 257: 19.4 against 31.5, 400 rows x 4096 x 257: 7.9 against
+    // 11.0; 2048^2 x 129 stays with "seq" (11.9 against 12.7), 1500 x 2000 x 65 too (4.8 against 6.8).
+    else if (cv->W >= 2400 && cv->H >= 384 && pmx_sgm_family_supported(ctx, cv)) sched = FAM;
     if (const char* e = pmx_opt(ctx, "SGM_PAR")) sched = e[0] == '1' ? PAR : SEQ;
     if (const char* e = pmx_opt(ctx, "SGM_SCHED")) {
         if (e[0] == 's') sched = SEQ;
