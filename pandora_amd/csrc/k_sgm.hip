@@ -663,7 +663,10 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     // "fam" reads the costs four times instead of eight and rewrites S three times instead of seven (~46 B/cell against the 92
     // of "seq", one launch per direction).  PMX_SGM_SCHED=seq|par|fam forces one (test hook; PMX_SGM_PAR=0/1 is the round-1 spelling).
     enum { SEQ, PAR, FAM } sched = SEQ;
-    if (cv->cells() <= ((size_t)128 << 20)) sched = PAR;  // measured break-even ~2e8 cells (tools/bench_sgm_float.py)
+    // (break-even measured ~2e8 cells in round 1, tools/bench_sgm_float.py; on round 6's kernels 7e7 - 1e8: 600 x 800 x 129 1.72 against
+    //  1.98 ms and 900 x 1200 x 65 2.09 against 2.51 for "par", 800 x 1000 x 90 equal, 800 x 1000 x 129 2.94 against 2.66 and
+    //  600 x 800 x 257 3.33 against 2.91 for "seq": profiles/r06_float_sched_rule.txt)
+    if (cv->cells() <= ((size_t)96 << 20)) sched = PAR;
     // the marching passes advance one image row per ~2.5 - 4 us whatever the width: they pay from ~3500 columns on (a window
     // for every CU); measured 4096^2 x 257: 55 ms against 96, 10000^2 x 129: 131 against 265, 2048^2 x 129: 12.4 against 11.3
     // Round 6, re-measured on the round's marching kernel (profiles/r06_float_sched_rule.txt, tools/sweep_float_sched.py): the bound of

@@ -1232,8 +1232,14 @@ int pmx_launch_sgm8(pmx_ctx* ctx, pmx_cv* cv, int kpl, uint32_t P1, uint32_t P2,
     // 11.1): a line just below the two break-evens, W D >= 26500 kpl - 50000 (2600 columns x 65 stay with the families, as in rounds
     // 3 - 5), given 32-column windows (W >= 2048; the 16-column ones
     // are slower than either route).  Four disparities per lane (D <= 64) keep round 3's bound, which is all that was measured there.
-    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && H >= 480 &&
-               (kpl < 8 ? W >= 2560 : (W >= 2048 && (size_t)W * cv->D + 50000 >= (size_t)26500 * kpl));
+    // Short images (round 6, profiles/r06_fam_rows.txt): until then nothing below 480 rows took the families; on the round's kernels they
+    // are ahead from ~200 rows when a row holds 1.8 times the cells of the tall images' bound - 128 / 200 / 300 / 400 rows x 4096 x 257:
+    // 1.41 / 1.54 / 1.81 / 2.00 ms against 1.74 / 2.20 / 2.60 / 3.25, 300 / 400 rows x 4096 x 129: 1.44 / 1.55 against 1.61 / 1.75 (200
+    // rows: equal), 300 x 6000 x 193: 2.40 against 3.02; 300 x 3000 x 129 (1.12 against 1.01) and 2600 x 65 stay with the eight volumes.
+    const size_t row_cells = (size_t)W * cv->D;
+    const bool wide_tall = kpl < 8 ? W >= 2560 : (W >= 2048 && row_cells + 50000 >= (size_t)26500 * kpl);
+    const bool wide_short = kpl >= 8 && W >= 2048 && 5 * (row_cells + 50000) >= (size_t)9 * 26500 * kpl;
+    bool fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u && (H >= 480 ? wide_tall : (H >= 192 && wide_short));
     if (const char* ef = pmx_opt(ctx, "SGM8_FAM")) {
         if (ef[0] == '0') fam = false;
         if (ef[0] == '1') fam = pmx_fam8_supported(kpl, H) && 3u * (invalid_cost + P2) <= 255u;

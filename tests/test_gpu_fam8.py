@@ -1,6 +1,6 @@
 """GPU parity of the integer path's direction-family form (k_sgmfam8.hip + sgm_u8_hpair_kernel): three byte volumes (horizontal
 pair, downward family, upward family) instead of eight path volumes.  Forced onto small pairs with PMX_SGM8_FAM=1 (by default it
-takes images from 480 rows and 2048 columns on whose rows hold enough cells, W D >= 26500 KPL - 50000) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
+takes images from 480 rows and 2048 columns on whose rows hold enough cells, W D >= 26500 KPL - 50000; shorter ones from 192 rows with 1.8 times the cells per row) and compared with the oracle's 8-path SGM bit for bit: the summed volume, the WTA and the
 refinement.  Shapes exercise every lane map (KPL 4 ... 20), both window widths (16 / 32 columns), images narrower than a window,
 images a window does not divide, and windows that enter and leave the image during the march."""
 import os

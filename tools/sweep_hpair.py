@@ -60,4 +60,5 @@ def main():
         print(f"{H} x {W} x {D}: " + "  ".join(f"[{n}] {ms:.2f}" for ms, n in out) + f"   best: {min(out)[1]} ({min(out)[0] / base:.2f} of default)", flush=True)
 
 
-main()
+if __name__ == "__main__":
+    main()
