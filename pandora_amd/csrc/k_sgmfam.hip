@@ -605,7 +605,10 @@ struct fam_shape {
 bool pick_shape(const pmx_ctx* ctx, int D, int W, fam_shape* out) {
     static const int k16[] = {3, 5, 7, 9}, k32[] = {3, 5, 6, 9, 12, 16};
     fam_shape f{0, 0, 0};
-    if (D <= 144 && W >= 16 * 224) {
+    // (round 6, profiles/r06_fam_shape.txt: since the marching schedule is the default from 2400 columns, the 16-lane map is ahead there
+    //  too when a lane holds 7 or 9 disparities - 2048 x 2600 x 129: 11.1 against 13.0 ms, 3000^2 x 129: 16.8 against 19.4, 1024 x 3500
+    //  x 129: 7.8 against 8.7 - and not with 5: 2048 x 2600 x 65 9.7 against 9.0)
+    if (D <= 144 && (W >= 16 * 224 || (W >= 2400 && D > 80))) {
         f.gl = 16;
         for (int k : k16)
             if (16 * k >= D) { f.kpl = k; break; }
