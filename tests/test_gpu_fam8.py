@@ -133,6 +133,22 @@ def test_family_form_mid_size_against_the_eight_volumes(eng):
         _family_against_eight_volumes(eng, synthetic_pair, H, W, dmin, dmax)
 
 
+def test_short_wide_images_take_the_families_by_default(eng):
+    """Round 6's rule for images below 480 rows (profiles/r06_fam_rows.txt): from 192 rows when a row holds 1.8 times the tall images'
+    bound of cells.  300 rows x 4096 x 257 take the families by default (there are no eight path volumes afterwards) and give the
+    eight-volume form's maps bit for bit; 300 x 2600 x 65 stay with the eight volumes."""
+    from bench import synthetic_pair
+
+    _family_against_eight_volumes(eng, synthetic_pair, 300, 4096, 0, 256)
+    L, R = synthetic_pair(300, 2600, 0, 64, seed=5)
+    eng.set_images(L, R, 1)
+    cv = eng.alloc_cv(65, 0)
+    eng.census(cv, 5)
+    eng.sgm(cv, 8, 32, False, 26.0, False)
+    eng.debug_path_costs(cv, raw=True)  # (raises when the family form ran)
+    cv.free()
+
+
 def _family_against_eight_volumes(eng, synthetic_pair, H, W, dmin, dmax):
     L, R = synthetic_pair(H, W, dmin, dmax, seed=5)
     maps = {}

@@ -503,6 +503,34 @@ def test_float_sgm_schedules_agree(eng, oracle, hooks, is_max, P1, P2):
             cv.free()
 
 
+def test_float_sgm_mid_size_takes_the_marching_schedule_by_default(eng, hooks):
+    """Round 6's size rule of the float32 schedules (profiles/r06_float_sched_rule.txt, r06_fam_shape.txt): from 2400 columns x 384 rows
+    the marching schedule, with the 16-lane map when D > 80.  400 x 2600 x 100 (104 M cells: past the side-by-side schedule's bound)
+    runs marching passes by default and gives the bits of one launch per path."""
+    rng = np.random.default_rng(31)
+    H, W, D = 400, 2600, 100
+    cvh = rng.integers(0, 40, (H, W, D)).astype(np.float32)
+    cvh[rng.random((H, W)) < 0.02] = np.nan
+    z = np.zeros((H, W), np.float32)
+    eng.set_images(z, z, 1)
+    out = {}
+    for sched in (None, "seq"):
+        if sched:
+            hooks.setenv("PMX_SGM_SCHED", sched)
+        cv = eng.alloc_cv(D, -9)
+        cv.from_host(cvh)
+        eng.set_profiling(True)
+        eng.reset_stage_times()
+        eng.sgm(cv, 8.0, 32.0, False, 45.0, False)
+        eng.sync()
+        launches = eng.stage_time("sgm_family")[1]
+        eng.set_profiling(False)
+        assert (launches > 0) == (sched is None)
+        out[sched] = cv.to_host()
+        cv.free()
+    np.testing.assert_array_equal(out[None], out["seq"])
+
+
 @pytest.mark.parametrize("H,W,D,md", [(5, 100, 129, -128), (4, 70, 300, -150), (3, 33, 1, 0), (6, 47, 64, 10), (2, 40, 950, -400)])
 def test_reverse_cost_volume_tiles(eng, oracle, H, W, D, md):
     """pmx_reverse_cost_volume through its LDS-tiled kernel (32 or 16 columns per tile, partial last tile, ranges leaving the
