@@ -673,7 +673,13 @@ int pmx_launch_sgm(pmx_ctx* ctx, pmx_cv* cv, float P1, float P2, int is_max, flo
     // round 3 (3584 columns, 512 rows) had become far too careful - 2048 x 2600 x 129: 12.9 against 15.0 ms, 3000^2 x 129: 19.3
     // against 25.7, 1500 x 3000 x 257: 14.3 against 23.1, 2048 x 3072 x 257: 19.4 against 31.5, 400 rows x 4096 x 257: 7.9 against
     // 11.0; 2048^2 x 129 stays with "seq" (11.9 against 12.7), 1500 x 2000 x 65 too (4.8 against 6.8).
-    else if (cv->W >= 2400 && cv->H >= 384 && pmx_sgm_family_supported(ctx, cv)) sched = FAM;
+    // A marching pass costs time per image ROW (more of it the more disparities a lane holds), one launch per path time per CELL: a row
+    // has to hold enough cells - measured break-evens W D = 150 000 at D = 33 (4096 columns: 7.8 ms "seq" against 8.6, 6000: 11.7
+    // against 9.4), 205 000 at D = 49 ... 80 (4096 x 49: 9.4 against 10.5, 3500 x 65: 11.4 against 10.0), ~250 000 at D = 100, ~290 000 at
+    // D = 129: 90 000 + 23 000 per disparity of the 16-lane map's lane.  (2048 x 2600 x 33: 5.5 ms against 8.3 the wrong way.)
+    else if (cv->W >= 2400 && cv->H >= 384 && pmx_sgm_family_supported(ctx, cv) &&
+             (size_t)cv->W * cv->D >= (size_t)90000 + 23000u * (cv->D <= 48 ? 3u : cv->D <= 80 ? 5u : cv->D <= 112 ? 7u : 9u))
+        sched = FAM;
     if (const char* e = pmx_opt(ctx, "SGM_PAR")) sched = e[0] == '1' ? PAR : SEQ;
     if (const char* e = pmx_opt(ctx, "SGM_SCHED")) {
         if (e[0] == 's') sched = SEQ;

@@ -505,10 +505,10 @@ def test_float_sgm_schedules_agree(eng, oracle, hooks, is_max, P1, P2):
 
 def test_float_sgm_mid_size_takes_the_marching_schedule_by_default(eng, hooks):
     """Round 6's size rule of the float32 schedules (profiles/r06_float_sched_rule.txt, r06_fam_shape.txt): from 2400 columns x 384 rows
-    the marching schedule, with the 16-lane map when D > 80.  400 x 2600 x 100 (104 M cells: past the side-by-side schedule's bound)
+    the marching schedule, with the 16-lane map when D > 80.  400 x 2600 x 120 (125 M cells: past the side-by-side schedule's bound; 312 000 cells per row: enough for the marching passes)
     runs marching passes by default and gives the bits of one launch per path."""
     rng = np.random.default_rng(31)
-    H, W, D = 400, 2600, 100
+    H, W, D = 400, 2600, 120
     cvh = rng.integers(0, 40, (H, W, D)).astype(np.float32)
     cvh[rng.random((H, W)) < 0.02] = np.nan
     z = np.zeros((H, W), np.float32)
